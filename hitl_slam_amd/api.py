@@ -1,0 +1,275 @@
+"""Host-side mirror of the reference's JointOpt interface over the C ABI (include/hitl_gpu.h).
+
+The reference seam is the JointOpt object (JointOptimization.h:49-89): public members
+poses_, robot_frame_point_clouds_, robot_frame_normal_clouds_, covariances_,
+human_constraints_ in, Run(), poses_ out.  `Solver` keeps those names' meaning:
+
+    s = Solver()                                  # JointOpt::JointOpt()
+    s.set_map(obs_offset, px, py, nx, ny, cov9)   # robot_frame_*_clouds_, covariances_
+    s.set_human_constraints(rows)                 # human_constraints_
+    s.find_correspondences(poses, window)         # FindSTFCorrespondences (:561-642)
+    poses, summary = s.solve(MODE_JOINT, poses)   # the ceres::Solve call sites (:1093, :1208)
+
+There is no CPU fallback: constructing a Solver raises if libhitlgpu.so is missing or no
+HIP device is usable.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libhitlgpu.so")
+
+_f32p = C.POINTER(C.c_float)
+_f64p = C.POINTER(C.c_double)
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+
+
+class HitlError(RuntimeError):
+    def __init__(self, status, where, detail=""):
+        self.status = status
+        super().__init__("%s failed with status %d%s" % (where, status, (": " + detail) if detail else ""))
+
+
+def _ptr(a, typ):
+    if a is None:
+        return None
+    return a.ctypes.data_as(typ)
+
+
+def _as(a, dtype):
+    if a is None:
+        return None
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def hc_rows(rows):
+    """Build a ctypes array of hitl_human_constraint_t from an iterable of
+    (type, constrained_pose_id, anchor_pose_id, d_par, d_perp, d_angle, rel_penalty_dir)
+    tuples or a structured/2-D numpy array with those 7 columns."""
+    rows = list(rows) if not isinstance(rows, np.ndarray) else rows
+    n = len(rows)
+    arr = (abi.HumanConstraint * max(n, 1))()
+    for k in range(n):
+        r = rows[k]
+        arr[k].type = int(r[0])
+        arr[k].constrained_pose_id = int(r[1])
+        arr[k].anchor_pose_id = int(r[2])
+        arr[k].delta_parallel = float(r[3])
+        arr[k].delta_perpendicular = float(r[4])
+        arr[k].delta_angle = float(r[5])
+        arr[k].relative_penalty_dir = float(r[6])
+    return arr, n
+
+
+class SolverBase(object):
+    """Shared ctypes plumbing; subclasses bind a library and a function-name table."""
+
+    _names = {}
+
+    def __init__(self, lib, options=None):
+        self._lib = lib
+        self._h = C.c_void_p()
+        self.options = abi.copy_options(options) if options is not None else abi.default_options()
+        self.n_poses = 0
+        self._bind()
+        st = self._fn("create")(C.byref(self.options), C.byref(self._h))
+        if st != abi.OK:
+            self._h = C.c_void_p()
+            raise HitlError(st, self._names["create"], self._detail())
+
+    # -- binding ---------------------------------------------------------------------------
+    def _fn(self, key):
+        return getattr(self._lib, self._names[key])
+
+    def _detail(self):
+        return ""
+
+    def _bind(self):
+        L = self._fn
+        vp = C.c_void_p
+        L("create").argtypes = [C.POINTER(abi.Options), C.POINTER(vp)]
+        L("create").restype = C.c_int
+        L("destroy").argtypes = [vp]
+        L("destroy").restype = None
+        L("set_map").argtypes = [vp, C.c_int64, _i64p, _f32p, _f32p, _f32p, _f32p, _f32p]
+        L("set_hc").argtypes = [vp, C.c_int64, C.POINTER(abi.HumanConstraint)]
+        L("set_corr").argtypes = [vp, C.c_int64, _i32p, _i32p, _i64p, _i32p, _i32p]
+        L("get_corr_counts").argtypes = [vp, _i64p, _i64p]
+        L("get_corr").argtypes = [vp, _i32p, _i32p, _i64p, _i32p, _i32p]
+        L("solve").argtypes = [vp, C.c_int32, _f32p, _f32p, C.POINTER(abi.Summary)]
+        L("evaluate").argtypes = [vp, C.c_int32, _f32p, _f64p, _f64p]
+        L("linearize").argtypes = [vp, C.c_int32, _f32p, _f64p, _f64p, _f64p, _f64p, _f64p]
+        for k in ("set_map", "set_hc", "set_corr", "get_corr_counts", "get_corr", "solve", "evaluate", "linearize"):
+            L(k).restype = C.c_int
+
+    def _check(self, st, key, allow=()):
+        if st != abi.OK and st not in allow:
+            raise HitlError(st, self._names[key], self._detail())
+        return st
+
+    # -- lifetime --------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._fn("destroy")(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- inputs ----------------------------------------------------------------------------
+    def set_map(self, obs_offset, px, py, nx, ny, cov9=None):
+        obs_offset = _as(obs_offset, np.int64)
+        px, py, nx, ny = (_as(a, np.float32) for a in (px, py, nx, ny))
+        cov9 = _as(cov9, np.float32)
+        n = len(obs_offset) - 1
+        self._check(self._fn("set_map")(self._h, n, _ptr(obs_offset, _i64p), _ptr(px, _f32p), _ptr(py, _f32p),
+                                        _ptr(nx, _f32p), _ptr(ny, _f32p), _ptr(cov9, _f32p)), "set_map")
+        self.n_poses = n
+        self.obs_offset = obs_offset
+
+    def set_human_constraints(self, rows):
+        if isinstance(rows, tuple) and len(rows) == 2 and isinstance(rows[1], int):
+            arr, n = rows
+        else:
+            arr, n = hc_rows(rows)
+        self._check(self._fn("set_hc")(self._h, n, arr), "set_hc")
+
+    def set_correspondences(self, pair_src, pair_tgt, match_offset, src_idx, tgt_idx):
+        pair_src, pair_tgt = _as(pair_src, np.int32), _as(pair_tgt, np.int32)
+        match_offset = _as(match_offset, np.int64)
+        src_idx, tgt_idx = _as(src_idx, np.int32), _as(tgt_idx, np.int32)
+        self._check(self._fn("set_corr")(self._h, len(pair_src), _ptr(pair_src, _i32p), _ptr(pair_tgt, _i32p),
+                                         _ptr(match_offset, _i64p), _ptr(src_idx, _i32p), _ptr(tgt_idx, _i32p)),
+                    "set_corr")
+
+    def get_correspondences(self):
+        P, Cn = C.c_int64(), C.c_int64()
+        self._check(self._fn("get_corr_counts")(self._h, C.byref(P), C.byref(Cn)), "get_corr_counts")
+        P, Cn = P.value, Cn.value
+        ps = np.zeros(max(P, 1), np.int32)
+        pt = np.zeros(max(P, 1), np.int32)
+        mo = np.zeros(P + 1, np.int64)
+        i0 = np.zeros(max(Cn, 1), np.int32)
+        i1 = np.zeros(max(Cn, 1), np.int32)
+        self._check(self._fn("get_corr")(self._h, _ptr(ps, _i32p), _ptr(pt, _i32p), _ptr(mo, _i64p),
+                                         _ptr(i0, _i32p), _ptr(i1, _i32p)), "get_corr")
+        return ps[:P], pt[:P], mo, i0[:Cn], i1[:Cn]
+
+    # -- the path --------------------------------------------------------------------------
+    def solve(self, mode, poses_xyt, allow_failure=False):
+        """Returns (poses_out float32 [n,3], Summary)."""
+        pin = _as(poses_xyt, np.float32).reshape(-1)
+        assert pin.size == 3 * self.n_poses
+        pout = np.empty_like(pin)
+        summ = abi.Summary()
+        allow = (abi.ERR_SOLVER_FAILURE,) if allow_failure else ()
+        self._check(self._fn("solve")(self._h, int(mode), _ptr(pin, _f32p), _ptr(pout, _f32p), C.byref(summ)),
+                    "solve", allow)
+        return pout.reshape(-1, 3), summ
+
+    def evaluate(self, mode, poses_xyt, want_gradient=True):
+        pin = _as(poses_xyt, np.float32).reshape(-1)
+        cost = C.c_double()
+        g = np.zeros(3 * self.n_poses, np.float64) if want_gradient else None
+        self._check(self._fn("evaluate")(self._h, int(mode), _ptr(pin, _f32p), C.byref(cost), _ptr(g, _f64p)),
+                    "evaluate")
+        return cost.value, g
+
+    def linearize(self, mode, poses_ref_xyt, x, n_pairs=None):
+        """Returns (cost, gradient[3n], pair_residuals[P,2], pair_jacobians[P,2,6])."""
+        pref = _as(poses_ref_xyt, np.float32).reshape(-1)
+        x = _as(x, np.float64).reshape(-1)
+        if n_pairs is None:
+            P, Cn = C.c_int64(), C.c_int64()
+            self._check(self._fn("get_corr_counts")(self._h, C.byref(P), C.byref(Cn)), "get_corr_counts")
+            n_pairs = P.value
+        cost = C.c_double()
+        g = np.zeros(3 * self.n_poses, np.float64)
+        pr = np.zeros((max(n_pairs, 1), 2), np.float64)
+        pj = np.zeros((max(n_pairs, 1), 2, 6), np.float64)
+        self._check(self._fn("linearize")(self._h, int(mode), _ptr(pref, _f32p), _ptr(x, _f64p), C.byref(cost),
+                                          _ptr(g, _f64p), _ptr(pr, _f64p), _ptr(pj, _f64p)), "linearize")
+        return cost.value, g, pr[:n_pairs], pj[:n_pairs]
+
+
+_lib_cache = {}
+
+
+def load_library(path=None):
+    """dlopen libhitlgpu.so.  Raises (never falls back) if it is missing."""
+    path = path or LIB_PATH
+    if path not in _lib_cache:
+        if not os.path.exists(path):
+            raise ImportError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+        _lib_cache[path] = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    return _lib_cache[path]
+
+
+class Solver(SolverBase):
+    """The MI355X backend (libhitlgpu.so)."""
+
+    _names = dict(create="hitl_solver_create", destroy="hitl_solver_destroy", set_map="hitl_solver_set_map",
+                  set_hc="hitl_solver_set_human_constraints", set_corr="hitl_solver_set_correspondences",
+                  get_corr_counts="hitl_solver_get_correspondence_counts",
+                  get_corr="hitl_solver_get_correspondences", solve="hitl_solver_solve",
+                  evaluate="hitl_solver_evaluate", linearize="hitl_solver_linearize",
+                  find_corr="hitl_solver_find_correspondences")
+
+    def __init__(self, options=None, lib_path=None):
+        lib = load_library(lib_path)
+        lib.hitl_last_error.restype = C.c_char_p
+        lib.hitl_status_string.restype = C.c_char_p
+        lib.hitl_status_string.argtypes = [C.c_int]
+        super().__init__(lib, options)
+
+    def _bind(self):
+        super()._bind()
+        f = self._fn("find_corr")
+        f.argtypes = [C.c_void_p, _f32p, C.c_int64]
+        f.restype = C.c_int
+
+    def _detail(self):
+        try:
+            return "%s" % self._lib.hitl_last_error().decode()
+        except Exception:
+            return ""
+
+    def find_correspondences(self, poses_xyt, window):
+        pin = _as(poses_xyt, np.float32).reshape(-1)
+        self._check(self._fn("find_corr")(self._h, _ptr(pin, _f32p), int(window)), "find_corr")
+
+
+def comm_unique_id(lib_path=None):
+    lib = load_library(lib_path)
+    buf = C.create_string_buffer(128)
+    st = lib.hitl_comm_unique_id(buf)
+    if st != abi.OK:
+        raise HitlError(st, "hitl_comm_unique_id")
+    return buf.raw
+
+
+def partition_range(obs_offset, rank, world_size, lib_path=None):
+    """Pose range [begin, end) owned by `rank` (host-only; no GPU needed)."""
+    lib = load_library(lib_path)
+    off = _as(obs_offset, np.int64)
+    b, e = C.c_int64(), C.c_int64()
+    lib.hitl_partition_range.argtypes = [C.c_int64, _i64p, C.c_int32, C.c_int32, _i64p, _i64p]
+    st = lib.hitl_partition_range(len(off) - 1, _ptr(off, _i64p), rank, world_size, C.byref(b), C.byref(e))
+    if st != abi.OK:
+        raise HitlError(st, "hitl_partition_range")
+    return b.value, e.value

@@ -1,0 +1,110 @@
+// hitl_internal.h -- internal declarations shared by the HIP kernels and the host driver of
+// libhitlgpu.so (gfx950 only).  Nothing here crosses the C ABI (include/hitl_gpu.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/hitl_gpu.h"
+
+namespace hitl {
+
+constexpr int kMaxBandPoses = 4;          // super-block size B = 3*Wb <= 12
+constexpr int kPairRJ = 14;               // r0, r1, J[2][6] per directed STF pair
+constexpr int kNumScalars = 16;           // device scalar scratch (doubles)
+
+// ---- view structs passed to kernels by value ------------------------------------------
+struct MapView {            // SoA robot-frame scans (JointOptimization.h:62-68)
+  int n_poses;
+  const int64_t* obs_off;   // n+1
+  const float* px; const float* py; const float* nx; const float* ny;
+};
+
+struct PairView {           // directed STF pose pairs, sorted by source pose
+  int n_pairs;
+  const int* pose_pair_off;   // n_poses+1 : pairs whose source is pose i
+  const int* pair_src;        // P
+  const int* pair_tgt;        // P
+  const int64_t* match_off;   // P+1
+  const uint32_t* matches;    // C, packed src_idx | tgt_idx << 16
+};
+
+struct FactorView {         // everything assemble needs besides the per-pair r/J
+  int with_stf, with_odom, with_hc;
+  int band_poses;             // Wb
+  const int* inc_off;         // n+1 : incidence list of pose i (pair*2 + role)
+  const int* inc_ent;
+  const int* band_pair;       // n * Wb * 2 : pair (i -> i+d), pair (i+d -> i) or -1
+  const float4* odom_A;       // n : edge (i-1, i) axis transform, row-major
+  const float2* odom_rr;      // n : (radial_translation, rotation)
+  float sig_r, sig_t, sig_a;
+  const int* hc_off;          // n+1 : rows constraining pose i
+  const uint32_t* hc_type;
+  const float4* hc_tgt;       // (x*, y*, theta*, penalty_dir)
+  int n_offband;
+  const int* ob_lo; const int* ob_hi; const int* ob_fwd; const int* ob_rev;   // E each
+  const int* obadj_off;       // n+1
+  const int* obadj_ent;       // entry*2 + transposed
+};
+
+struct LinView {            // one linearisation (double buffered by the driver)
+  double* pairRJ;             // P*14
+  double* Hband;              // n*(Wb+1)*9 : block (i, i+d) row-major
+  double* g;                  // npad
+  double* obblk;              // E*9 : block (lo, hi)
+  double* cost_pose;          // n
+};
+
+struct CrView {             // block-tridiagonal system + cyclic-reduction factors
+  int nsb;                    // super-blocks
+  int B;                      // 3*Wb
+  double* D;                  // nsb*B*B  (overwritten by the reduction)
+  double* L;                  // nsb*B*B  coupling (k, k-stride)
+  double* Dinv;               // nsb*B*B
+  double* Gl;                 // nsb*B*B  Dinv_k * L_k
+  double* Gr;                 // nsb*B*B  Dinv_k * L_{k+s}^T
+};
+
+// ---- kernel launchers (hitl_kernels.hip) -------------------------------------------------
+void launch_linearize_stf(hipStream_t st, const MapView& map, const PairView& pr, int max_scan,
+                          const double* x, float corr, float std_dev, double* pairRJ);
+void launch_assemble(hipStream_t st, const MapView& map, const PairView& pr, const FactorView& fv,
+                     const double* x, const LinView& lin);
+// scalars[0] = cost, scalars[1] = max |g| over free entries
+void launch_reduce_lin(hipStream_t st, int n_poses, const LinView& lin, double* scalars);
+void launch_jacobi_scale(hipStream_t st, int n_poses, int npad, int Wb, const double* Hband, int enable,
+                         double* scale);
+void launch_build_system(hipStream_t st, int n_poses, int Wb, const LinView& lin, const double* scale,
+                         double mu, double min_diag, double max_diag, const CrView& cr, double* rhs);
+void launch_cr_factor(hipStream_t st, const CrView& cr);
+// x = M^{-1} w   (w is destroyed)
+void launch_cr_solve(hipStream_t st, const CrView& cr, double* w, double* x);
+// y = (S H S [+ D^2]) v ; damping added when mu > 0
+void launch_spmv(hipStream_t st, int n_poses, int npad, const FactorView& fv, const LinView& lin,
+                 const double* scale, double mu, double min_diag, double max_diag, const double* v, double* y);
+// out[0] = dt.rhs, out[1] = dt.q, out[2] = sum (s*dt)^2 (free), out[3] = sum x^2 (free), out[4] = #non-finite
+void launch_step_scalars(hipStream_t st, int n3, const double* dt, const double* rhs, const double* q,
+                         const double* scale, const double* x, double* out);
+void launch_candidate(hipStream_t st, int n3, const double* x, const double* scale, const double* dt, double* xc);
+// out[k] = a_k . b_k for k < ndots (<= 4)
+void launch_dots(hipStream_t st, int n, int ndots, const double* const* a, const double* const* b, double* out);
+// y = alpha*x + beta*y
+void launch_axpby(hipStream_t st, int n, double alpha, const double* x, double beta, double* y);
+void launch_copy(hipStream_t st, int n, const double* src, double* dst);
+
+// correspondence search (JointOptimization.cpp:561-642)
+struct MatchParams { float thr, min_cos; int cap, skip; };
+void launch_match(hipStream_t st, const MapView& map, int max_scan, int slots, const int* cand_tgt /* n*slots, -1 = none */,
+                  const float* cand_tf /* n*slots*8 */, MatchParams mp, uint16_t* table /* n*slots*max_scan */,
+                  int* counts /* n*slots */);
+void launch_compact(hipStream_t st, const MapView& map, int max_scan, int slots, int n_kept,
+                    const int* kept_cand /* index into n*slots */, const int64_t* match_off, const uint16_t* table,
+                    uint32_t* matches);
+
+const char* kernels_build_info();
+
+}  // namespace hitl

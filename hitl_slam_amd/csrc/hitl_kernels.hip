@@ -1,0 +1,813 @@
+// hitl_kernels.hip -- CDNA4 (gfx950) kernels for hitl-slam's batch re-optimisation path.
+//
+// Kernel inventory (SURVEY.md section 2.3 "compute sites" -> here):
+//   k_linearize_stf  : K4  PointToPointGlobConstraint residual + analytic 2x6 Jacobian per
+//                      directed pose pair (residual_functors.h:786-830).  The HBM-bound kernel.
+//   k_assemble       : K5/K6/K7a odometry (residual_functors.h:1081-1125), human rows
+//                      (:1299-1415), J^T J 3x3 blocks + gradient, gathered per pose (no atomics,
+//                      bit-reproducible).
+//   k_build_system   : Jacobi scaling + LM diagonal -> block-tridiagonal super-block system.
+//   k_cr_*           : K7b block cyclic reduction = recursive red/black Schur complement of the
+//                      banded normal equations (what Ceres SPARSE_SCHUR does on a chain,
+//                      JointOptimization.cpp:148), exact preconditioner of the PCG.
+//   k_spmv, k_dots...: PCG pieces.
+// All arithmetic is fp64 (T = double in the reference functors); observations stay fp32.
+// Wavefront = 64 everywhere.
+
+#include "hitl_internal.h"
+
+namespace hitl {
+
+#define WAVE 64
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, WAVE);
+  return v;
+}
+
+// ===========================================================================================
+// linearize_stf: one workgroup per SOURCE pose (its scan staged once in LDS), one wave per
+// directed pair (i -> j), lanes stride the pair's matches; 10 sums reduced by wave shuffles.
+// blockIdx -> pose mapping keeps consecutive poses on one XCD (blocks b and b+8 share an
+// XCD) so the target scans i+-1..W, which the neighbouring workgroups stage as THEIR source,
+// are served from that XCD's L2.
+// ===========================================================================================
+constexpr int kStfBlock = 256;
+
+__global__ __launch_bounds__(kStfBlock) void k_linearize_stf(MapView map, PairView pr, int chunk, int lds_cap,
+                                                              const double* __restrict__ x, double corr, double sd,
+                                                              double* __restrict__ pairRJ) {
+  extern __shared__ float s_scan[];  // [4][lds_cap] : px, py, nx, ny of the source scan
+  const int b = blockIdx.x;
+  const int idx = b >> 3;
+  const int i = (b & 7) * chunk + idx;
+  if (idx >= chunk || i >= map.n_poses) return;
+  const int p_begin = pr.pose_pair_off[i], p_end = pr.pose_pair_off[i + 1];
+  if (p_begin == p_end) return;
+  const int64_t oi = map.obs_off[i];
+  const int mi = (int)(map.obs_off[i + 1] - oi);
+  const bool use_lds = (lds_cap > 0) && (mi <= lds_cap);
+  if (use_lds) {
+    for (int k = threadIdx.x; k < mi; k += kStfBlock) {
+      s_scan[k] = map.px[oi + k];
+      s_scan[lds_cap + k] = map.py[oi + k];
+      s_scan[2 * lds_cap + k] = map.nx[oi + k];
+      s_scan[3 * lds_cap + k] = map.ny[oi + k];
+    }
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const double xi = x[3 * i], yi = x[3 * i + 1], ti = x[3 * i + 2];
+  double s0, c0;
+  sincos(ti, &s0, &c0);
+  const double kf = corr / sd;
+  for (int p = p_begin + wave; p < p_end; p += kStfBlock / WAVE) {
+    const int j = pr.pair_tgt[p];
+    const int64_t oj = map.obs_off[j];
+    const double xj = x[3 * j], yj = x[3 * j + 1], tj = x[3 * j + 2];
+    double s1, c1;
+    sincos(tj, &s1, &c1);
+    const int64_t m_begin = pr.match_off[p], m_end = pr.match_off[p + 1];
+    double S0 = 0, A0x = 0, A0y = 0, T00 = 0, T01 = 0;
+    double S1 = 0, A1x = 0, A1y = 0, T10 = 0, T11 = 0;
+    for (int64_t m = m_begin + lane; m < m_end; m += WAVE) {
+      const uint32_t u = pr.matches[m];
+      const int k0 = (int)(u & 0xffffu), k1 = (int)(u >> 16);
+      float ax, ay, anx, any;
+      if (use_lds) {
+        ax = s_scan[k0]; ay = s_scan[lds_cap + k0]; anx = s_scan[2 * lds_cap + k0]; any = s_scan[3 * lds_cap + k0];
+      } else {
+        ax = map.px[oi + k0]; ay = map.py[oi + k0]; anx = map.nx[oi + k0]; any = map.ny[oi + k0];
+      }
+      const float bx = map.px[oj + k1], by = map.py[oj + k1], bnx = map.nx[oj + k1], bny = map.ny[oj + k1];
+      const double rp0x = c0 * ax - s0 * ay, rp0y = s0 * ax + c0 * ay;     // R0 p0
+      const double rp1x = c1 * bx - s1 * by, rp1y = s1 * bx + c1 * by;     // R1 p1
+      const double m0x = c0 * anx - s0 * any, m0y = s0 * anx + c0 * any;   // R0 n0
+      const double m1x = c1 * bnx - s1 * bny, m1y = s1 * bnx + c1 * bny;   // R1 n1
+      const double dx = (rp1x + xj) - (rp0x + xi), dy = (rp1y + yj) - (rp0y + yi);
+      const double e0 = (m0x * dx + m0y * dy) * corr / sd;
+      const double e1 = (m1x * dx + m1y * dy) * corr / sd;
+      // theta partials divided by k; perp(v) = (-vy, vx)
+      const double d00 = (-m0y * dx + m0x * dy) - (m0y * rp0x - m0x * rp0y);
+      const double d01 = (m0y * rp1x - m0x * rp1y);
+      const double d10 = -(m1y * rp0x - m1x * rp0y);
+      const double d11 = (-m1y * dx + m1x * dy) + (m1y * rp1x - m1x * rp1y);
+      S0 += e0 * e0; A0x += e0 * m0x; A0y += e0 * m0y; T00 += e0 * d00; T01 += e0 * d01;
+      S1 += e1 * e1; A1x += e1 * m1x; A1y += e1 * m1y; T10 += e1 * d10; T11 += e1 * d11;
+    }
+    S0 = wave_sum(S0); A0x = wave_sum(A0x); A0y = wave_sum(A0y); T00 = wave_sum(T00); T01 = wave_sum(T01);
+    S1 = wave_sum(S1); A1x = wave_sum(A1x); A1y = wave_sum(A1y); T10 = wave_sum(T10); T11 = wave_sum(T11);
+    if (lane == 0) {
+      const double dn = (double)(m_end - m_begin);
+      double* o = pairRJ + (size_t)kPairRJ * p;
+      const double r0 = (S0 != 0.0) ? sqrt(S0 / dn) : 0.0;   // residual_functors.h:822-827
+      const double r1 = (S1 != 0.0) ? sqrt(S1 / dn) : 0.0;
+      const double f0 = (S0 != 0.0) ? kf / (dn * r0) : 0.0;
+      const double f1 = (S1 != 0.0) ? kf / (dn * r1) : 0.0;
+      o[0] = r0; o[1] = r1;
+      o[2] = -f0 * A0x; o[3] = -f0 * A0y; o[4] = f0 * T00; o[5] = f0 * A0x; o[6] = f0 * A0y; o[7] = f0 * T01;
+      o[8] = -f1 * A1x; o[9] = -f1 * A1y; o[10] = f1 * T10; o[11] = f1 * A1x; o[12] = f1 * A1y; o[13] = f1 * T11;
+    }
+  }
+}
+
+void launch_linearize_stf(hipStream_t st, const MapView& map, const PairView& pr, int max_scan, const double* x,
+                          float corr, float std_dev, double* pairRJ) {
+  if (pr.n_pairs == 0) return;
+  const int chunk = (map.n_poses + 7) / 8;
+  int lds_cap = (max_scan + 63) & ~63;
+  if ((size_t)lds_cap * 16 > 64 * 1024) lds_cap = 0;  // oversized scans read the source from global memory
+  hipLaunchKernelGGL(k_linearize_stf, dim3(8 * chunk), dim3(kStfBlock), (size_t)lds_cap * 16, st, map, pr, chunk,
+                     lds_cap, x, (double)corr, (double)std_dev, pairRJ);
+}
+
+// ===========================================================================================
+// assemble: one thread per pose gathers every factor touching it.
+// ===========================================================================================
+struct OdomEval { double r[3]; double J[18]; };
+
+// residual_functors.h:1081-1125 with the analytic Jacobian of SURVEY.md A.1
+__device__ __forceinline__ void eval_odom(const double* x1, const double* x2, float4 A, float2 rr, float sr_, float st_,
+                                          float sa_, OdomEval& o) {
+  const double dx = x2[0] - x1[0], dy = x2[1] - x1[1];
+  double s, c;
+  sincos(-x1[2], &s, &c);  // Rotation2D(-theta1)
+  const double ux = c * dx - s * dy, uy = s * dx + c * dy;
+  const double a00 = A.x, a01 = A.y, a10 = A.z, a11 = A.w;
+  const double sr = sr_, st = st_, sa = sa_;
+  o.r[0] = ((a00 * ux + a01 * uy) - (double)rr.x) / sr;
+  o.r[1] = (a10 * ux + a11 * uy) / st;
+  const double phi = x2[2] - x1[2] - (double)rr.y;
+  o.r[2] = atan2(sin(phi), cos(phi)) / sa;
+  const double dux[6] = {-c, s, uy, c, -s, 0.0};
+  const double duy[6] = {-s, -c, -ux, s, c, 0.0};
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    o.J[k] = (a00 * dux[k] + a01 * duy[k]) / sr;
+    o.J[6 + k] = (a10 * dux[k] + a11 * duy[k]) / st;
+    o.J[12 + k] = 0.0;
+  }
+  o.J[12 + 2] = -1.0 / sa;
+  o.J[12 + 5] = 1.0 / sa;
+}
+
+__global__ __launch_bounds__(128) void k_assemble(MapView map, PairView pr, FactorView fv, const double* __restrict__ x,
+                                                   LinView lin) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = map.n_poses;
+  if (i >= n) return;
+  const int Wb = fv.band_poses;
+  double Hd[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  double gi[3] = {0, 0, 0};
+  double H1[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // odometry part of block (i, i+1)
+  double cost = 0.0;
+  if (fv.with_stf) {
+    for (int e = fv.inc_off[i]; e < fv.inc_off[i + 1]; ++e) {
+      const int ent = fv.inc_ent[e];
+      const double* RJ = lin.pairRJ + (size_t)kPairRJ * (ent >> 1);
+      const int co = 2 + 3 * (ent & 1);
+      const double r0 = RJ[0], r1 = RJ[1];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const double ja0 = RJ[co + a], ja1 = RJ[6 + co + a];
+        gi[a] += ja0 * r0 + ja1 * r1;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Hd[a * 3 + c] += ja0 * RJ[co + c] + ja1 * RJ[6 + co + c];
+      }
+    }
+    for (int p = pr.pose_pair_off[i]; p < pr.pose_pair_off[i + 1]; ++p) {
+      const double r0 = lin.pairRJ[(size_t)kPairRJ * p], r1 = lin.pairRJ[(size_t)kPairRJ * p + 1];
+      cost += 0.5 * (r0 * r0 + r1 * r1);
+    }
+  }
+  if (fv.with_odom) {
+    OdomEval o;
+    if (i >= 1) {  // edge (i-1, i): this pose is pose2 (columns 3..5)
+      eval_odom(x + 3 * (i - 1), x + 3 * i, fv.odom_A[i], fv.odom_rr[i], fv.sig_r, fv.sig_t, fv.sig_a, o);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+          gi[a] += o.J[m * 6 + 3 + a] * o.r[m];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) Hd[a * 3 + c] += o.J[m * 6 + 3 + a] * o.J[m * 6 + 3 + c];
+        }
+      }
+      cost += 0.5 * (o.r[0] * o.r[0] + o.r[1] * o.r[1] + o.r[2] * o.r[2]);
+    }
+    if (i + 1 < n) {  // edge (i, i+1): this pose is pose1 (columns 0..2)
+      eval_odom(x + 3 * i, x + 3 * (i + 1), fv.odom_A[i + 1], fv.odom_rr[i + 1], fv.sig_r, fv.sig_t, fv.sig_a, o);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+          gi[a] += o.J[m * 6 + a] * o.r[m];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            Hd[a * 3 + c] += o.J[m * 6 + a] * o.J[m * 6 + c];
+            H1[a * 3 + c] += o.J[m * 6 + a] * o.J[m * 6 + 3 + c];
+          }
+        }
+      }
+    }
+  }
+  if (fv.with_hc) {
+    for (int h = fv.hc_off[i]; h < fv.hc_off[i + 1]; ++h) {  // residual_functors.h:1305-1411
+      const uint32_t type = fv.hc_type[h];
+      const float4 tg = fv.hc_tgt[h];
+      const double ex = (double)tg.x - x[3 * i], ey = (double)tg.y - x[3 * i + 1], et = (double)tg.z - x[3 * i + 2];
+      if (type == HITL_HC_LINE_SEGMENT) {  // r = (ex, ey, et), J = -I
+        gi[0] -= ex; gi[1] -= ey; gi[2] -= et;
+        Hd[0] += 1.0; Hd[4] += 1.0; Hd[8] += 1.0;
+        cost += 0.5 * (ex * ex + ey * ey + et * et);
+      } else if (type == HITL_HC_COLINEAR) {
+        double sp, cp;
+        sincos((double)tg.w, &sp, &cp);
+        const double r0 = cp * ex + sp * ey;
+        gi[0] -= cp * r0; gi[1] -= sp * r0; gi[2] -= et;
+        Hd[0] += cp * cp; Hd[1] += cp * sp; Hd[3] += sp * cp; Hd[4] += sp * sp; Hd[8] += 1.0;
+        cost += 0.5 * (r0 * r0 + et * et);
+      } else if (type == HITL_HC_PERPENDICULAR || type == HITL_HC_PARALLEL) {
+        gi[2] -= et;
+        Hd[8] += 1.0;
+        cost += 0.5 * et * et;
+      }
+    }
+  }
+  if (i == 0) {  // pose 0 is constant (JointOptimization.cpp:824, :1197): identity block, no coupling
+#pragma unroll
+    for (int q = 0; q < 9; ++q) Hd[q] = (q % 4 == 0) ? 1.0 : 0.0;
+    gi[0] = gi[1] = gi[2] = 0.0;
+  }
+  double* Hrow = lin.Hband + (size_t)i * (Wb + 1) * 9;
+#pragma unroll
+  for (int q = 0; q < 9; ++q) Hrow[q] = Hd[q];
+  lin.g[3 * i] = gi[0]; lin.g[3 * i + 1] = gi[1]; lin.g[3 * i + 2] = gi[2];
+  lin.cost_pose[i] = cost;
+  for (int d = 1; d <= Wb; ++d) {
+    double blk[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (i > 0 && i + d < n) {
+      if (fv.with_stf) {
+        const int fwd = fv.band_pair[((size_t)i * Wb + (d - 1)) * 2];
+        const int rev = fv.band_pair[((size_t)i * Wb + (d - 1)) * 2 + 1];
+        if (fwd >= 0) {  // pair (i -> i+d): block = J0^T J1
+          const double* J = lin.pairRJ + (size_t)kPairRJ * fwd + 2;
+#pragma unroll
+          for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) blk[a * 3 + c] += J[a] * J[3 + c] + J[6 + a] * J[9 + c];
+        }
+        if (rev >= 0) {  // pair (i+d -> i): block (i, i+d) = J1^T J0
+          const double* J = lin.pairRJ + (size_t)kPairRJ * rev + 2;
+#pragma unroll
+          for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) blk[a * 3 + c] += J[3 + a] * J[c] + J[9 + a] * J[6 + c];
+        }
+      }
+      if (d == 1 && fv.with_odom) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) blk[q] += H1[q];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 9; ++q) Hrow[d * 9 + q] = blk[q];
+  }
+}
+
+__global__ __launch_bounds__(128) void k_assemble_offband(FactorView fv, LinView lin) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= fv.n_offband) return;
+  double blk[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const int lo = fv.ob_lo[e];
+  if (lo > 0) {
+    const int fwd = fv.ob_fwd[e], rev = fv.ob_rev[e];
+    if (fwd >= 0) {
+      const double* J = lin.pairRJ + (size_t)kPairRJ * fwd + 2;
+      for (int a = 0; a < 3; ++a)
+        for (int c = 0; c < 3; ++c) blk[a * 3 + c] += J[a] * J[3 + c] + J[6 + a] * J[9 + c];
+    }
+    if (rev >= 0) {
+      const double* J = lin.pairRJ + (size_t)kPairRJ * rev + 2;
+      for (int a = 0; a < 3; ++a)
+        for (int c = 0; c < 3; ++c) blk[a * 3 + c] += J[3 + a] * J[c] + J[9 + a] * J[6 + c];
+    }
+  }
+  for (int q = 0; q < 9; ++q) lin.obblk[(size_t)e * 9 + q] = blk[q];
+}
+
+void launch_assemble(hipStream_t st, const MapView& map, const PairView& pr, const FactorView& fv, const double* x,
+                     const LinView& lin) {
+  const int n = map.n_poses;
+  hipLaunchKernelGGL(k_assemble, dim3((n + 127) / 128), dim3(128), 0, st, map, pr, fv, x, lin);
+  if (fv.with_stf && fv.n_offband > 0)
+    hipLaunchKernelGGL(k_assemble_offband, dim3((fv.n_offband + 127) / 128), dim3(128), 0, st, fv, lin);
+}
+
+// ===========================================================================================
+// single-workgroup deterministic reductions (vectors are <= a few 100k doubles)
+// ===========================================================================================
+constexpr int kRedBlock = 1024;
+
+__device__ __forceinline__ double block_sum(double v, double* sm) {
+  v = wave_sum(v);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) sm[wave] = v;
+  __syncthreads();
+  double t = (threadIdx.x < kRedBlock / WAVE) ? sm[threadIdx.x] : 0.0;
+  if (wave == 0) t = wave_sum(t);
+  if (threadIdx.x == 0) sm[0] = t;
+  __syncthreads();
+  return sm[0];
+}
+
+__device__ __forceinline__ double block_max(double v, double* sm) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m, WAVE));
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) sm[wave] = v;
+  __syncthreads();
+  double t = (threadIdx.x < kRedBlock / WAVE) ? sm[threadIdx.x] : 0.0;
+  if (wave == 0) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) t = fmax(t, __shfl_xor(t, m, WAVE));
+  }
+  if (threadIdx.x == 0) sm[0] = t;
+  __syncthreads();
+  return sm[0];
+}
+
+__global__ __launch_bounds__(kRedBlock) void k_reduce_lin(int n_poses, LinView lin, double* scalars) {
+  __shared__ double sm[kRedBlock / WAVE];
+  double c = 0.0, gm = 0.0;
+  for (int i = threadIdx.x; i < n_poses; i += kRedBlock) c += lin.cost_pose[i];
+  for (int a = 3 + threadIdx.x; a < 3 * n_poses; a += kRedBlock) {
+    const double v = fabs(lin.g[a]);
+    gm = (v > gm || v != v) ? v : gm;  // NaN propagates
+  }
+  const double cs = block_sum(c, sm);
+  const double gmx = block_max(gm, sm);
+  if (threadIdx.x == 0) { scalars[0] = cs; scalars[1] = gmx; }
+}
+
+void launch_reduce_lin(hipStream_t st, int n_poses, const LinView& lin, double* scalars) {
+  hipLaunchKernelGGL(k_reduce_lin, dim3(1), dim3(kRedBlock), 0, st, n_poses, lin, scalars);
+}
+
+__global__ void k_jacobi_scale(int n_poses, int npad, int Wb, const double* __restrict__ Hband, int enable,
+                               double* __restrict__ scale) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= npad) return;
+  double s = 1.0;
+  if (enable && a >= 3 && a < 3 * n_poses) {
+    const int i = a / 3, c = a % 3;
+    s = 1.0 / (1.0 + sqrt(Hband[(size_t)i * (Wb + 1) * 9 + c * 3 + c]));
+  }
+  scale[a] = s;
+}
+
+void launch_jacobi_scale(hipStream_t st, int n_poses, int npad, int Wb, const double* Hband, int enable, double* scale) {
+  hipLaunchKernelGGL(k_jacobi_scale, dim3((npad + 255) / 256), dim3(256), 0, st, n_poses, npad, Wb, Hband, enable, scale);
+}
+
+// ===========================================================================================
+// build_system: banded 3x3-block Hessian -> block-tridiagonal system of B x B super-blocks
+// (Wb consecutive poses each) in the Jacobi-scaled space with the LM diagonal
+//   D^2 = clamp(diag(S H S), min, max) / mu     
+// ===========================================================================================
+__global__ void k_build_system(int n_poses, int Wb, const double* __restrict__ Hband, const double* __restrict__ g,
+                               const double* __restrict__ scale, double mu, double min_diag, double max_diag, CrView cr,
+                               double* __restrict__ rhs) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int B = cr.B;
+  if (t >= cr.nsb * B) return;
+  const int k = t / B, a = t % B;
+  const int i = k * Wb + a / 3, ca = a % 3;
+  double* Drow = cr.D + ((size_t)k * B + a) * B;
+  double* Lrow = cr.L + ((size_t)k * B + a) * B;
+  if (i >= n_poses) {
+    for (int b = 0; b < B; ++b) { Drow[b] = (b == a) ? 1.0 : 0.0; Lrow[b] = 0.0; }
+    rhs[t] = 0.0;
+    return;
+  }
+  const int W1 = Wb + 1;
+  const double sa = scale[3 * i + ca];
+  for (int b = 0; b < B; ++b) {
+    const int i2 = k * Wb + b / 3, cb = b % 3;
+    double v = 0.0;
+    if (i2 < n_poses) {
+      v = (i2 >= i) ? Hband[((size_t)i * W1 + (i2 - i)) * 9 + ca * 3 + cb]
+                    : Hband[((size_t)i2 * W1 + (i - i2)) * 9 + cb * 3 + ca];
+      v *= sa * scale[3 * i2 + cb];
+    }
+    if (b == a && i > 0) v += fmin(fmax(v, min_diag), max_diag) / mu;
+    Drow[b] = v;
+    double l = 0.0;
+    if (k > 0) {
+      const int i3 = (k - 1) * Wb + b / 3;
+      const int d = i - i3;
+      if (d <= Wb) l = Hband[((size_t)i3 * W1 + d) * 9 + cb * 3 + ca] * sa * scale[3 * i3 + cb];
+    }
+    Lrow[b] = l;
+  }
+  rhs[t] = -sa * g[3 * i + ca];
+}
+
+void launch_build_system(hipStream_t st, int n_poses, int Wb, const LinView& lin, const double* scale, double mu,
+                         double min_diag, double max_diag, const CrView& cr, double* rhs) {
+  const int tot = cr.nsb * cr.B;
+  hipLaunchKernelGGL(k_build_system, dim3((tot + 127) / 128), dim3(128), 0, st, n_poses, Wb, lin.Hband, lin.g, scale, mu,
+                     min_diag, max_diag, cr, rhs);
+}
+
+// ===========================================================================================
+// block cyclic reduction.  One 64-lane workgroup per super-block; B x B tiles live in LDS.
+// Level stride s: nodes s, 3s, 5s.. are eliminated (k_cr_eliminate), nodes 0, 2s, 4s..
+// survive and absorb the Schur complement (k_cr_update).
+// ===========================================================================================
+template <int B>
+__device__ __forceinline__ void lds_load(double* dst, const double* __restrict__ src) {
+  for (int e = threadIdx.x; e < B * B; e += WAVE) dst[e] = src[e];
+}
+
+// in-place Cholesky (lower) of the SPD tile A, then Ainv = A^{-1}
+template <int B>
+__device__ void lds_spd_inverse(double* A, double* Ainv) {
+  for (int c = 0; c < B; ++c) {
+    __syncthreads();
+    if (threadIdx.x == 0) A[c * B + c] = sqrt(A[c * B + c]);
+    __syncthreads();
+    const double dcc = A[c * B + c];
+    if ((int)threadIdx.x > c && (int)threadIdx.x < B) A[threadIdx.x * B + c] /= dcc;
+    __syncthreads();
+    for (int e = threadIdx.x; e < B * B; e += WAVE) {
+      const int r = e / B, c2 = e % B;
+      if (c2 > c && r >= c2) A[r * B + c2] -= A[r * B + c] * A[c2 * B + c];
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < B) {  // lane t solves A z = e_t through L L^T
+    const int t = threadIdx.x;
+    double y[B];
+#pragma unroll
+    for (int r = 0; r < B; ++r) {
+      double s = (r == t) ? 1.0 : 0.0;
+#pragma unroll
+      for (int q = 0; q < r; ++q) s -= A[r * B + q] * y[q];
+      y[r] = s / A[r * B + r];
+    }
+#pragma unroll
+    for (int r = B - 1; r >= 0; --r) {
+      double s = y[r];
+#pragma unroll
+      for (int q = r + 1; q < B; ++q) s -= A[q * B + r] * y[q];
+      y[r] = s / A[r * B + r];
+    }
+#pragma unroll
+    for (int r = 0; r < B; ++r) Ainv[r * B + t] = y[r];
+  }
+  __syncthreads();
+}
+
+template <int B>
+__global__ __launch_bounds__(WAVE) void k_cr_eliminate(CrView cr, int s) {
+  __shared__ double sD[B * B], sInv[B * B], sL[B * B], sR[B * B];
+  const int k = s * (2 * blockIdx.x + 1);
+  if (k >= cr.nsb) return;
+  const size_t off = (size_t)k * B * B;
+  const bool has_right = (k + s) < cr.nsb;
+  lds_load<B>(sD, cr.D + off);
+  lds_load<B>(sL, cr.L + off);
+  if (has_right) lds_load<B>(sR, cr.L + (size_t)(k + s) * B * B);
+  lds_spd_inverse<B>(sD, sInv);
+  for (int e = threadIdx.x; e < B * B; e += WAVE) {
+    const int r = e / B, c = e % B;
+    double gl = 0.0, gr = 0.0;
+#pragma unroll
+    for (int q = 0; q < B; ++q) {
+      gl += sInv[r * B + q] * sL[q * B + c];
+      if (has_right) gr += sInv[r * B + q] * sR[c * B + q];   // Dinv * L_{k+s}^T
+    }
+    cr.Dinv[off + e] = sInv[e];
+    cr.Gl[off + e] = gl;
+    cr.Gr[off + e] = gr;
+  }
+}
+
+template <int B>
+__global__ __launch_bounds__(WAVE) void k_cr_update(CrView cr, int s) {
+  __shared__ double sLj[B * B], sG[B * B], sL2[B * B];
+  constexpr int NE = (B * B + WAVE - 1) / WAVE;
+  const int j = 2 * s * blockIdx.x;
+  if (j >= cr.nsb) return;
+  const size_t off = (size_t)j * B * B;
+  const int k1 = j - s, k2 = j + s;
+  double acc[NE];
+#pragma unroll
+  for (int it = 0; it < NE; ++it) {
+    const int e = threadIdx.x + it * WAVE;
+    acc[it] = (e < B * B) ? cr.D[off + e] : 0.0;
+  }
+  if (k1 >= 0) {
+    lds_load<B>(sLj, cr.L + off);
+    lds_load<B>(sG, cr.Gr + (size_t)k1 * B * B);
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < NE; ++it) {
+      const int e = threadIdx.x + it * WAVE;
+      if (e < B * B) {
+        const int r = e / B, c = e % B;
+        double v = 0.0;
+#pragma unroll
+        for (int q = 0; q < B; ++q) v += sLj[r * B + q] * sG[q * B + c];   // L_j * Gr[k1]
+        acc[it] -= v;
+      }
+    }
+    __syncthreads();
+    lds_load<B>(sG, cr.Gl + (size_t)k1 * B * B);
+    __syncthreads();
+    const bool has_ll = (k1 - s) >= 0;
+    for (int e = threadIdx.x; e < B * B; e += WAVE) {
+      const int r = e / B, c = e % B;
+      double v = 0.0;
+      if (has_ll) {
+#pragma unroll
+        for (int q = 0; q < B; ++q) v -= sLj[r * B + q] * sG[q * B + c];  // -L_j * Gl[k1]
+      }
+      cr.L[off + e] = v;
+    }
+  }
+  if (k2 < cr.nsb) {
+    __syncthreads();
+    lds_load<B>(sL2, cr.L + (size_t)k2 * B * B);
+    lds_load<B>(sG, cr.Gl + (size_t)k2 * B * B);
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < NE; ++it) {
+      const int e = threadIdx.x + it * WAVE;
+      if (e < B * B) {
+        const int r = e / B, c = e % B;
+        double v = 0.0;
+#pragma unroll
+        for (int q = 0; q < B; ++q) v += sL2[q * B + r] * sG[q * B + c];   // L_{k2}^T * Gl[k2]
+        acc[it] -= v;
+      }
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < NE; ++it) {
+    const int e = threadIdx.x + it * WAVE;
+    if (e < B * B) cr.D[off + e] = acc[it];
+  }
+}
+
+template <int B>
+__global__ __launch_bounds__(WAVE) void k_cr_root(CrView cr) {
+  __shared__ double sD[B * B], sInv[B * B];
+  lds_load<B>(sD, cr.D);
+  lds_spd_inverse<B>(sD, sInv);
+  for (int e = threadIdx.x; e < B * B; e += WAVE) cr.Dinv[e] = sInv[e];
+}
+
+// forward sweep on a right-hand side: w_j -= Gr[k1]^T w_k1 + Gl[k2]^T w_k2
+template <int B>
+__global__ void k_cr_forward(CrView cr, int s, double* __restrict__ w) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int q = t / B, c = t % B;
+  const int j = 2 * s * q;
+  if (j >= cr.nsb) return;
+  const int k1 = j - s, k2 = j + s;
+  double v = w[(size_t)j * B + c];
+  if (k1 >= 0) {
+    const double* G = cr.Gr + (size_t)k1 * B * B;
+    const double* wk = w + (size_t)k1 * B;
+#pragma unroll
+    for (int r = 0; r < B; ++r) v -= G[r * B + c] * wk[r];
+  }
+  if (k2 < cr.nsb) {
+    const double* G = cr.Gl + (size_t)k2 * B * B;
+    const double* wk = w + (size_t)k2 * B;
+#pragma unroll
+    for (int r = 0; r < B; ++r) v -= G[r * B + c] * wk[r];
+  }
+  w[(size_t)j * B + c] = v;
+}
+
+// back substitution: x_k = Dinv_k w_k - Gl_k x_{k-s} - Gr_k x_{k+s}
+template <int B>
+__global__ void k_cr_backward(CrView cr, int s, const double* __restrict__ w, double* __restrict__ x) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int q = t / B, r = t % B;
+  const int k = s * (2 * q + 1);
+  if (k >= cr.nsb) return;
+  const size_t off = (size_t)k * B * B;
+  const double* wk = w + (size_t)k * B;
+  const double* xl = x + (size_t)(k - s) * B;
+  const bool has_right = (k + s) < cr.nsb;
+  const double* xr = x + (size_t)(has_right ? (k + s) : k) * B;
+  double v = 0.0;
+#pragma unroll
+  for (int c = 0; c < B; ++c) {
+    v += cr.Dinv[off + r * B + c] * wk[c];
+    v -= cr.Gl[off + r * B + c] * xl[c];
+    if (has_right) v -= cr.Gr[off + r * B + c] * xr[c];
+  }
+  x[(size_t)k * B + r] = v;
+}
+
+template <int B>
+__global__ void k_cr_root_solve(CrView cr, const double* __restrict__ w, double* __restrict__ x) {
+  const int r = threadIdx.x;
+  if (r >= B) return;
+  double v = 0.0;
+#pragma unroll
+  for (int c = 0; c < B; ++c) v += cr.Dinv[r * B + c] * w[c];
+  x[r] = v;
+}
+
+template <int B>
+static void cr_factor_t(hipStream_t st, const CrView& cr) {
+  for (int s = 1; s < cr.nsb; s *= 2) {
+    const int n_elim = (cr.nsb - s + 2 * s - 1) / (2 * s);
+    const int n_surv = (cr.nsb + 2 * s - 1) / (2 * s);
+    hipLaunchKernelGGL(k_cr_eliminate<B>, dim3(n_elim), dim3(WAVE), 0, st, cr, s);
+    hipLaunchKernelGGL(k_cr_update<B>, dim3(n_surv), dim3(WAVE), 0, st, cr, s);
+  }
+  hipLaunchKernelGGL(k_cr_root<B>, dim3(1), dim3(WAVE), 0, st, cr);
+}
+
+template <int B>
+static void cr_solve_t(hipStream_t st, const CrView& cr, double* w, double* x) {
+  int s_last = 0;
+  for (int s = 1; s < cr.nsb; s *= 2) {
+    const int n_surv = (cr.nsb + 2 * s - 1) / (2 * s);
+    hipLaunchKernelGGL(k_cr_forward<B>, dim3((n_surv * B + 127) / 128), dim3(128), 0, st, cr, s, w);
+    s_last = s;
+  }
+  hipLaunchKernelGGL(k_cr_root_solve<B>, dim3(1), dim3(WAVE), 0, st, cr, w, x);
+  for (int s = s_last; s >= 1; s /= 2) {
+    const int n_elim = (cr.nsb - s + 2 * s - 1) / (2 * s);
+    hipLaunchKernelGGL(k_cr_backward<B>, dim3((n_elim * B + 127) / 128), dim3(128), 0, st, cr, s, w, x);
+  }
+}
+
+void launch_cr_factor(hipStream_t st, const CrView& cr) {
+  switch (cr.B) {
+    case 3: cr_factor_t<3>(st, cr); break;
+    case 6: cr_factor_t<6>(st, cr); break;
+    case 9: cr_factor_t<9>(st, cr); break;
+    default: cr_factor_t<12>(st, cr); break;
+  }
+}
+
+void launch_cr_solve(hipStream_t st, const CrView& cr, double* w, double* x) {
+  switch (cr.B) {
+    case 3: cr_solve_t<3>(st, cr, w, x); break;
+    case 6: cr_solve_t<6>(st, cr, w, x); break;
+    case 9: cr_solve_t<9>(st, cr, w, x); break;
+    default: cr_solve_t<12>(st, cr, w, x); break;
+  }
+}
+
+// ===========================================================================================
+// y = (S H S [+ D^2]) v : band blocks (both triangles) + off-band blocks, one thread per pose
+// ===========================================================================================
+__global__ __launch_bounds__(128) void k_spmv(int n_poses, int npad, FactorView fv, LinView lin,
+                                               const double* __restrict__ scale, double mu, double min_diag,
+                                               double max_diag, const double* __restrict__ v, double* __restrict__ y) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (3 * i >= npad) return;
+  if (i >= n_poses) {  // padding rows of the last super-block: identity
+    for (int c = 0; c < 3; ++c) if (3 * i + c < npad) y[3 * i + c] = v[3 * i + c];
+    return;
+  }
+  const int Wb = fv.band_poses, W1 = Wb + 1;
+  double acc[3] = {0, 0, 0};
+  const double* Hi = lin.Hband + (size_t)i * W1 * 9;
+  for (int d = 0; d <= Wb && i + d < n_poses; ++d) {
+    const double* blk = Hi + d * 9;
+    const int j = i + d;
+    const double v0 = scale[3 * j] * v[3 * j], v1 = scale[3 * j + 1] * v[3 * j + 1], v2 = scale[3 * j + 2] * v[3 * j + 2];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) acc[a] += blk[a * 3] * v0 + blk[a * 3 + 1] * v1 + blk[a * 3 + 2] * v2;
+  }
+  for (int d = 1; d <= Wb && i - d >= 0; ++d) {
+    const int j = i - d;
+    const double* blk = lin.Hband + ((size_t)j * W1 + d) * 9;  // block (j, i), use transposed
+    const double v0 = scale[3 * j] * v[3 * j], v1 = scale[3 * j + 1] * v[3 * j + 1], v2 = scale[3 * j + 2] * v[3 * j + 2];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) acc[a] += blk[a] * v0 + blk[3 + a] * v1 + blk[6 + a] * v2;
+  }
+  if (fv.with_stf && fv.n_offband > 0) {
+    for (int e = fv.obadj_off[i]; e < fv.obadj_off[i + 1]; ++e) {
+      const int ent = fv.obadj_ent[e];
+      const int en = ent >> 1, tr = ent & 1;
+      const double* blk = lin.obblk + (size_t)en * 9;
+      const int j = tr ? fv.ob_lo[en] : fv.ob_hi[en];
+      const double v0 = scale[3 * j] * v[3 * j], v1 = scale[3 * j + 1] * v[3 * j + 1], v2 = scale[3 * j + 2] * v[3 * j + 2];
+      if (!tr) {
+        for (int a = 0; a < 3; ++a) acc[a] += blk[a * 3] * v0 + blk[a * 3 + 1] * v1 + blk[a * 3 + 2] * v2;
+      } else {
+        for (int a = 0; a < 3; ++a) acc[a] += blk[a] * v0 + blk[3 + a] * v1 + blk[6 + a] * v2;
+      }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const double sa = scale[3 * i + a];
+    double r = sa * acc[a];
+    if (mu > 0.0 && i > 0) {
+      const double dg = sa * sa * Hi[a * 3 + a];
+      r += fmin(fmax(dg, min_diag), max_diag) / mu * v[3 * i + a];
+    }
+    y[3 * i + a] = r;
+  }
+}
+
+void launch_spmv(hipStream_t st, int n_poses, int npad, const FactorView& fv, const LinView& lin, const double* scale,
+                 double mu, double min_diag, double max_diag, const double* v, double* y) {
+  const int nthreads = (npad + 2) / 3;
+  hipLaunchKernelGGL(k_spmv, dim3((nthreads + 127) / 128), dim3(128), 0, st, n_poses, npad, fv, lin, scale, mu, min_diag,
+                     max_diag, v, y);
+}
+
+// ===========================================================================================
+// small vector kernels
+// ===========================================================================================
+__global__ __launch_bounds__(kRedBlock) void k_step_scalars(int n3, const double* __restrict__ dt,
+                                                            const double* __restrict__ rhs, const double* __restrict__ q,
+                                                            const double* __restrict__ scale, const double* __restrict__ x,
+                                                            double* out) {
+  __shared__ double sm[kRedBlock / WAVE];
+  double a = 0, b = 0, c = 0, d = 0, bad = 0;
+  for (int t = threadIdx.x; t < n3; t += kRedBlock) {
+    const double v = dt[t];
+    a += v * rhs[t];
+    b += v * q[t];
+    if (t >= 3) {
+      const double dl = scale[t] * v;
+      c += dl * dl;
+      d += x[t] * x[t];
+    }
+    if (!isfinite(v)) bad += 1.0;
+  }
+  a = block_sum(a, sm); b = block_sum(b, sm); c = block_sum(c, sm); d = block_sum(d, sm); bad = block_sum(bad, sm);
+  if (threadIdx.x == 0) { out[0] = a; out[1] = b; out[2] = c; out[3] = d; out[4] = bad; }
+}
+
+void launch_step_scalars(hipStream_t st, int n3, const double* dt, const double* rhs, const double* q,
+                         const double* scale, const double* x, double* out) {
+  hipLaunchKernelGGL(k_step_scalars, dim3(1), dim3(kRedBlock), 0, st, n3, dt, rhs, q, scale, x, out);
+}
+
+__global__ void k_candidate(int n3, const double* __restrict__ x, const double* __restrict__ scale,
+                            const double* __restrict__ dt, double* __restrict__ xc) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n3) return;
+  xc[t] = (t >= 3) ? x[t] + scale[t] * dt[t] : x[t];
+}
+
+void launch_candidate(hipStream_t st, int n3, const double* x, const double* scale, const double* dt, double* xc) {
+  hipLaunchKernelGGL(k_candidate, dim3((n3 + 255) / 256), dim3(256), 0, st, n3, x, scale, dt, xc);
+}
+
+struct DotArgs { const double* a[4]; const double* b[4]; };
+
+__global__ __launch_bounds__(kRedBlock) void k_dots(int n, int ndots, DotArgs args, double* out) {
+  __shared__ double sm[kRedBlock / WAVE];
+  for (int k = 0; k < ndots; ++k) {
+    double s = 0.0;
+    const double* a = args.a[k];
+    const double* b = args.b[k];
+    for (int t = threadIdx.x; t < n; t += kRedBlock) s += a[t] * b[t];
+    s = block_sum(s, sm);
+    if (threadIdx.x == 0) out[k] = s;
+  }
+}
+
+void launch_dots(hipStream_t st, int n, int ndots, const double* const* a, const double* const* b, double* out) {
+  DotArgs args;
+  for (int k = 0; k < 4; ++k) { args.a[k] = a[k < ndots ? k : 0]; args.b[k] = b[k < ndots ? k : 0]; }
+  hipLaunchKernelGGL(k_dots, dim3(1), dim3(kRedBlock), 0, st, n, ndots, args, out);
+}
+
+__global__ void k_axpby(int n, double alpha, const double* __restrict__ x, double beta, double* __restrict__ y) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  y[t] = alpha * x[t] + ((beta != 0.0) ? beta * y[t] : 0.0);
+}
+
+void launch_axpby(hipStream_t st, int n, double alpha, const double* x, double beta, double* y) {
+  hipLaunchKernelGGL(k_axpby, dim3((n + 255) / 256), dim3(256), 0, st, n, alpha, x, beta, y);
+}
+
+void launch_copy(hipStream_t st, int n, const double* src, double* dst) {
+  (void)hipMemcpyAsync(dst, src, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st);
+}
+
+const char* kernels_build_info() { return "gfx950 " __DATE__ " " __TIME__; }
+
+}  // namespace hitl

@@ -1,0 +1,955 @@
+// hitl_solver.cpp -- host driver and C ABI of libhitlgpu.so (include/hitl_gpu.h).
+//
+// Replaces the body of JointOpt::Run (JointOptimization.cpp:1295-1385): factor construction
+// (AddOdometryConstraints :736-825, AddHumanConstraints :969-1054, AddSTFConstraints
+// :539-559) becomes device-resident SoA tables; ceres::Solve (:1093, :1208) becomes a
+// Levenberg-Marquardt loop with Ceres' trust-region semantics whose every
+// O(N), O(P) or O(C) step is a HIP kernel -- only a handful of scalars per iteration cross to
+// the host.  There is no CPU fallback anywhere in this file.
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <numeric>
+
+#include "hitl_internal.h"
+
+namespace hitl {
+
+static thread_local std::string g_last_error;
+
+static int fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                           \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess)                                                                       \
+      return fail(e_ == hipErrorOutOfMemory ? HITL_ERR_OUT_OF_MEMORY : HITL_ERR_HIP,             \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                           \
+  } while (0)
+
+#define TRY(expr)            \
+  do {                       \
+    int s_ = (expr);         \
+    if (s_ != HITL_OK) return s_; \
+  } while (0)
+
+template <typename T>
+struct DevArray {
+  T* p = nullptr;
+  size_t cap = 0;
+  size_t n = 0;
+  int resize(size_t count) {
+    n = count;
+    if (count <= cap && p) return HITL_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    const size_t want = std::max<size_t>(count, 1);
+    HIP_TRY(hipMalloc((void**)&p, want * sizeof(T)));
+    cap = want;
+    return HITL_OK;
+  }
+  int upload(const T* src, size_t count, hipStream_t st) {
+    TRY(resize(count));
+    if (count) HIP_TRY(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, st));
+    return HITL_OK;
+  }
+  int upload(const std::vector<T>& v, hipStream_t st) { return upload(v.data(), v.size(), st); }
+  int zero(hipStream_t st) {
+    if (n) HIP_TRY(hipMemsetAsync(p, 0, n * sizeof(T), st));
+    return HITL_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = n = 0;
+  }
+};
+
+static inline double angle_mod(double a) {  // shared/math/util.h:433-439
+  return a - 6.28318530717958647692 * std::rint(a / 6.28318530717958647692);
+}
+
+}  // namespace hitl
+
+using namespace hitl;
+
+struct hitl_solver {
+  hitl_options opt;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+  double* h_scalars = nullptr;  // pinned, kNumScalars
+  DevArray<double> d_scalars;
+
+  // ---- map ----
+  int n = 0;
+  int64_t n_obs = 0;
+  int max_scan = 0;
+  std::vector<int64_t> h_obs_off;
+  DevArray<int64_t> obs_off;
+  DevArray<float> px, py, nx, ny, cov9;
+
+  // ---- human rows (sorted by constrained pose at solve time) ----
+  std::vector<hitl_human_constraint_t> h_hc;
+
+  // ---- correspondences ----
+  int n_pairs = 0;
+  int64_t n_matches = 0;
+  std::vector<int> h_pair_src, h_pair_tgt;     // internal order: sorted by (src)
+  std::vector<int> h_perm;                     // internal index -> caller index
+  std::vector<int64_t> h_match_off;            // internal order
+  DevArray<int> pair_src, pair_tgt, pose_pair_off;
+  DevArray<int64_t> match_off;
+  DevArray<uint32_t> matches;
+  // derived
+  int band_pairs_Wb = 1;                       // Wb implied by the pair set
+  int n_offband = 0;
+  DevArray<int> inc_off, inc_ent, band_pair, ob_lo, ob_hi, ob_fwd, ob_rev, obadj_off, obadj_ent;
+
+  // ---- per-solve factor tables ----
+  DevArray<float4> odom_A, hc_tgt;
+  DevArray<float2> odom_rr;
+  DevArray<int> hc_off;
+  DevArray<uint32_t> hc_type;
+  int num_hc_residuals = 0;
+
+  // ---- work buffers ----
+  int wb_Wb = 0, wb_n = 0, wb_pairs = -1, wb_offband = -1;
+  int nsb = 0, B = 0, npad = 0;
+  DevArray<double> x, xc, scale, rhs, dt, wv, qv, rv, zv, pv;
+  DevArray<double> pairRJ[2], Hband[2], gvec[2], obblk[2], cost_pose[2];
+  DevArray<double> crD, crL, crDinv, crGl, crGr;
+
+  MapView map_view() const {
+    MapView m;
+    m.n_poses = n; m.obs_off = obs_off.p; m.px = px.p; m.py = py.p; m.nx = nx.p; m.ny = ny.p;
+    return m;
+  }
+  PairView pair_view() const {
+    PairView p;
+    p.n_pairs = n_pairs; p.pose_pair_off = pose_pair_off.p; p.pair_src = pair_src.p; p.pair_tgt = pair_tgt.p;
+    p.match_off = match_off.p; p.matches = matches.p;
+    return p;
+  }
+  LinView lin_view(int k) {
+    LinView l;
+    l.pairRJ = pairRJ[k].p; l.Hband = Hband[k].p; l.g = gvec[k].p; l.obblk = obblk[k].p; l.cost_pose = cost_pose[k].p;
+    return l;
+  }
+  CrView cr_view() {
+    CrView c;
+    c.nsb = nsb; c.B = B; c.D = crD.p; c.L = crL.p; c.Dinv = crDinv.p; c.Gl = crGl.p; c.Gr = crGr.p;
+    return c;
+  }
+};
+
+namespace hitl {
+
+static int sync_scalars(hitl_solver* s, int count) {
+  HIP_TRY(hipMemcpyAsync(s->h_scalars, s->d_scalars.p, sizeof(double) * count, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return HITL_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// derived pair structures (host, O(P)); called whenever the correspondence set changes
+// ---------------------------------------------------------------------------------------
+static int build_pair_structures(hitl_solver* s) {
+  const int n = s->n, P = s->n_pairs;
+  int maxd = 1;
+  for (int p = 0; p < P; ++p) maxd = std::max(maxd, std::abs(s->h_pair_src[p] - s->h_pair_tgt[p]));
+  const int cap = std::min(std::max(s->opt.max_band_poses, 1), kMaxBandPoses);
+  const int Wb = std::min(maxd, cap);
+  s->band_pairs_Wb = Wb;
+  std::vector<int> ppo(n + 1, 0), inc_off(n + 1, 0);
+  for (int p = 0; p < P; ++p) { ppo[s->h_pair_src[p] + 1]++; inc_off[s->h_pair_src[p] + 1]++; inc_off[s->h_pair_tgt[p] + 1]++; }
+  for (int i = 0; i < n; ++i) { ppo[i + 1] += ppo[i]; inc_off[i + 1] += inc_off[i]; }
+  std::vector<int> inc_ent(std::max(2 * P, 1)), fill(inc_off.begin(), inc_off.end() - 1);
+  std::vector<int> band_pair((size_t)n * Wb * 2, -1);
+  std::map<std::pair<int, int>, int> ob_index;
+  std::vector<int> ob_lo, ob_hi, ob_fwd, ob_rev;
+  for (int p = 0; p < P; ++p) {
+    const int a = s->h_pair_src[p], b = s->h_pair_tgt[p];
+    inc_ent[fill[a]++] = 2 * p;
+    inc_ent[fill[b]++] = 2 * p + 1;
+    const int lo = std::min(a, b), hi = std::max(a, b), d = hi - lo;
+    if (d <= Wb) {
+      int& slot = band_pair[((size_t)lo * Wb + (d - 1)) * 2 + (a < b ? 0 : 1)];
+      if (slot >= 0) return fail(HITL_ERR_INVALID_ARGUMENT, "duplicate directed pose pair in the correspondence set");
+      slot = p;
+    } else {
+      auto key = std::make_pair(lo, hi);
+      auto it = ob_index.find(key);
+      int e;
+      if (it == ob_index.end()) {
+        e = (int)ob_lo.size();
+        ob_index[key] = e;
+        ob_lo.push_back(lo); ob_hi.push_back(hi); ob_fwd.push_back(-1); ob_rev.push_back(-1);
+      } else {
+        e = it->second;
+      }
+      int& slot = (a < b) ? ob_fwd[e] : ob_rev[e];
+      if (slot >= 0) return fail(HITL_ERR_INVALID_ARGUMENT, "duplicate directed pose pair in the correspondence set");
+      slot = p;
+    }
+  }
+  const int E = (int)ob_lo.size();
+  std::vector<int> obadj_off(n + 1, 0);
+  for (int e = 0; e < E; ++e) { obadj_off[ob_lo[e] + 1]++; obadj_off[ob_hi[e] + 1]++; }
+  for (int i = 0; i < n; ++i) obadj_off[i + 1] += obadj_off[i];
+  std::vector<int> obadj_ent(std::max(2 * E, 1)), fill2(obadj_off.begin(), obadj_off.end() - 1);
+  for (int e = 0; e < E; ++e) { obadj_ent[fill2[ob_lo[e]]++] = 2 * e; obadj_ent[fill2[ob_hi[e]]++] = 2 * e + 1; }
+  s->n_offband = E;
+  hipStream_t st = s->stream;
+  TRY(s->pose_pair_off.upload(ppo, st));
+  TRY(s->inc_off.upload(inc_off, st));
+  TRY(s->inc_ent.upload(inc_ent, st));
+  TRY(s->band_pair.upload(band_pair, st));
+  if (ob_lo.empty()) { ob_lo.push_back(0); ob_hi.push_back(0); ob_fwd.push_back(-1); ob_rev.push_back(-1); }
+  TRY(s->ob_lo.upload(ob_lo, st)); TRY(s->ob_hi.upload(ob_hi, st));
+  TRY(s->ob_fwd.upload(ob_fwd, st)); TRY(s->ob_rev.upload(ob_rev, st));
+  TRY(s->obadj_off.upload(obadj_off, st)); TRY(s->obadj_ent.upload(obadj_ent, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return HITL_OK;
+}
+
+static int ensure_empty_pair_tables(hitl_solver* s) {
+  // mode A never reads pair tables, but the views must hold valid pointers
+  if (s->pose_pair_off.n == (size_t)s->n + 1) return HITL_OK;
+  s->n_pairs = 0; s->n_matches = 0;
+  s->h_pair_src.clear(); s->h_pair_tgt.clear(); s->h_perm.clear(); s->h_match_off.assign(1, 0);
+  TRY(s->pair_src.resize(0)); TRY(s->pair_tgt.resize(0)); TRY(s->matches.resize(0));
+  std::vector<int64_t> mo(1, 0);
+  TRY(s->match_off.upload(mo, s->stream));
+  return build_pair_structures(s);
+}
+
+// ---------------------------------------------------------------------------------------
+// work buffers
+// ---------------------------------------------------------------------------------------
+static int ensure_work(hitl_solver* s, int Wb) {
+  const int n = s->n;
+  s->B = 3 * Wb;
+  s->nsb = (n + Wb - 1) / Wb;
+  s->npad = s->nsb * s->B;
+  const size_t npad = (size_t)s->npad;
+  for (DevArray<double>* v : {&s->x, &s->xc, &s->scale, &s->rhs, &s->dt, &s->wv, &s->qv, &s->rv, &s->zv, &s->pv}) {
+    const bool fresh = v->cap < npad;
+    TRY(v->resize(npad));
+    if (fresh || s->wb_Wb != Wb) TRY(v->zero(s->stream));
+  }
+  for (int k = 0; k < 2; ++k) {
+    TRY(s->pairRJ[k].resize((size_t)std::max(s->n_pairs, 1) * kPairRJ));
+    TRY(s->Hband[k].resize((size_t)n * (Wb + 1) * 9));
+    const bool fresh = s->gvec[k].cap < npad;
+    TRY(s->gvec[k].resize(npad));
+    if (fresh || s->wb_Wb != Wb) TRY(s->gvec[k].zero(s->stream));
+    TRY(s->obblk[k].resize((size_t)std::max(s->n_offband, 1) * 9));
+    TRY(s->cost_pose[k].resize(n));
+  }
+  const size_t bb = (size_t)s->nsb * s->B * s->B;
+  TRY(s->crD.resize(bb)); TRY(s->crL.resize(bb)); TRY(s->crDinv.resize(bb)); TRY(s->crGl.resize(bb)); TRY(s->crGr.resize(bb));
+  s->wb_Wb = Wb; s->wb_n = n; s->wb_pairs = s->n_pairs; s->wb_offband = s->n_offband;
+  return HITL_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// factor tables derived from the fp32 poses handed to a solve
+// ---------------------------------------------------------------------------------------
+static void odom_setup(const float* pp, const float* pc, float4* A, float2* rr) {
+  // JointOptimization.cpp:748-769 in fp32 (Vector2f / Rotation2Df arithmetic)
+  const float kEpsilon = 1e-6f;
+  const float tx = pc[0] - pp[0], ty = pc[1] - pp[1];
+  float rx, ry, rho;
+  if (std::fabs(tx) < kEpsilon && std::fabs(ty) < kEpsilon) {
+    rx = cosf(pc[2]); ry = sinf(pc[2]); rho = 0.0f;
+  } else {
+    const float c = cosf(-pp[2]), sn = sinf(-pp[2]);
+    const float vx = c * tx - sn * ty, vy = sn * tx + c * ty;
+    const float nrm = sqrtf(vx * vx + vy * vy);
+    rx = vx / nrm; ry = vy / nrm;
+    rho = sqrtf(tx * tx + ty * ty);
+  }
+  const float c90 = cosf((float)M_PI_2), s90 = sinf((float)M_PI_2);  // Rotation2Df(M_PI_2)
+  A->x = rx; A->y = ry; A->z = c90 * rx - s90 * ry; A->w = s90 * rx + c90 * ry;
+  rr->x = rho;
+  rr->y = (float)angle_mod((double)(pc[2] - pp[2]));
+}
+
+static void hc_target(const hitl_human_constraint_t& row, const float* a, float4* t) {
+  // JointOptimization.cpp:981-989, :1023-1025, :1037-1039 in fp32
+  const float ang = a[2];
+  const float pax = cosf(ang), pay = sinf(ang);
+  t->x = (a[0] + row.delta_parallel * pax) + row.delta_perpendicular * (-pay);
+  t->y = (a[1] + row.delta_parallel * pay) + row.delta_perpendicular * pax;
+  const float t_angle = ang + row.delta_angle;
+  t->z = atan2f(sinf(t_angle), cosf(t_angle));
+  t->w = ang + row.relative_penalty_dir;
+}
+
+static int setup_factors(hitl_solver* s, const float* poses, bool with_odom_hc) {
+  const int n = s->n;
+  std::vector<float4> A(n, make_float4(0, 0, 0, 0));
+  std::vector<float2> rr(n, make_float2(0, 0));
+  std::vector<int> hc_off(n + 1, 0);
+  std::vector<uint32_t> hc_type;
+  std::vector<float4> hc_tgt;
+  s->num_hc_residuals = 0;
+  if (with_odom_hc) {
+    for (int i = 1; i < n; ++i) odom_setup(poses + 3 * (i - 1), poses + 3 * i, &A[i], &rr[i]);
+    const size_t H = s->h_hc.size();
+    for (size_t h = 0; h < H; ++h) hc_off[s->h_hc[h].constrained_pose_id + 1]++;
+    for (int i = 0; i < n; ++i) hc_off[i + 1] += hc_off[i];
+    hc_type.resize(H); hc_tgt.resize(H);
+    std::vector<int> fill(hc_off.begin(), hc_off.end() - 1);
+    for (size_t h = 0; h < H; ++h) {  // stable: rows of one pose keep their caller order
+      const hitl_human_constraint_t& row = s->h_hc[h];
+      const int dst = fill[row.constrained_pose_id]++;
+      hc_type[dst] = row.type;
+      hc_target(row, poses + 3 * row.anchor_pose_id, &hc_tgt[dst]);
+      if (row.type == HITL_HC_LINE_SEGMENT) s->num_hc_residuals += 3;
+      else if (row.type == HITL_HC_COLINEAR) s->num_hc_residuals += 2;
+      else if (row.type == HITL_HC_PERPENDICULAR || row.type == HITL_HC_PARALLEL) s->num_hc_residuals += 1;
+    }
+  }
+  if (hc_type.empty()) { hc_type.push_back(0); hc_tgt.push_back(make_float4(0, 0, 0, 0)); }
+  hipStream_t st = s->stream;
+  TRY(s->odom_A.upload(A, st)); TRY(s->odom_rr.upload(rr, st));
+  TRY(s->hc_off.upload(hc_off, st)); TRY(s->hc_type.upload(hc_type, st)); TRY(s->hc_tgt.upload(hc_tgt, st));
+  HIP_TRY(hipStreamSynchronize(st));  // host vectors go out of scope
+  return HITL_OK;
+}
+
+static FactorView factor_view(hitl_solver* s, int mode, int Wb) {
+  FactorView f;
+  f.with_stf = (mode != HITL_MODE_ODOM_HC) && s->n_pairs > 0;
+  f.with_odom = (mode != HITL_MODE_STF_ONLY);
+  f.with_hc = (mode != HITL_MODE_STF_ONLY) && !s->h_hc.empty();
+  f.band_poses = Wb;
+  f.inc_off = s->inc_off.p; f.inc_ent = s->inc_ent.p; f.band_pair = s->band_pair.p;
+  f.odom_A = s->odom_A.p; f.odom_rr = s->odom_rr.p;
+  f.sig_r = s->opt.odom_radial_std_dev; f.sig_t = s->opt.odom_tangential_std_dev; f.sig_a = s->opt.odom_angular_std_dev;
+  f.hc_off = s->hc_off.p; f.hc_type = s->hc_type.p; f.hc_tgt = s->hc_tgt.p;
+  f.n_offband = f.with_stf ? s->n_offband : 0;
+  f.ob_lo = s->ob_lo.p; f.ob_hi = s->ob_hi.p; f.ob_fwd = s->ob_fwd.p; f.ob_rev = s->ob_rev.p;
+  f.obadj_off = s->obadj_off.p; f.obadj_ent = s->obadj_ent.p;
+  return f;
+}
+
+struct LinResult { double cost, gmax; float stf_ms; };
+
+// one pass over every factor at state xdev: residuals, Jacobians, J^T J blocks, gradient, cost
+static int run_linearize(hitl_solver* s, const FactorView& fv, const double* xdev, int buf, LinResult* out) {
+  hipStream_t st = s->stream;
+  const MapView mv = s->map_view();
+  const PairView pv = s->pair_view();
+  const LinView lv = s->lin_view(buf);
+  HIP_TRY(hipEventRecord(s->ev0, st));
+  if (fv.with_stf)
+    launch_linearize_stf(st, mv, pv, s->max_scan, xdev, s->opt.point_correlation_factor, s->opt.laser_std_dev, lv.pairRJ);
+  HIP_TRY(hipEventRecord(s->ev1, st));
+  launch_assemble(st, mv, pv, fv, xdev, lv);
+  launch_reduce_lin(st, s->n, lv, s->d_scalars.p);
+  HIP_TRY(hipGetLastError());
+  TRY(sync_scalars(s, 2));
+  out->cost = s->h_scalars[0];
+  out->gmax = s->h_scalars[1];
+  out->stf_ms = 0.f;
+  if (fv.with_stf) HIP_TRY(hipEventElapsedTime(&out->stf_ms, s->ev0, s->ev1));
+  return HITL_OK;
+}
+
+static int check_ready(hitl_solver* s, int mode) {
+  if (!s) return fail(HITL_ERR_INVALID_ARGUMENT, "null solver");
+  if (s->n <= 0) return fail(HITL_ERR_NOT_READY, "hitl_solver_set_map has not been called");
+  if (mode < 0 || mode > 2) return fail(HITL_ERR_INVALID_ARGUMENT, "mode must be 0 (ODOM_HC), 1 (STF_ONLY) or 2 (JOINT)");
+  return HITL_OK;
+}
+
+static int prepare(hitl_solver* s, int mode, const float* poses_ref, FactorView* fv) {
+  HIP_TRY(hipSetDevice(s->device));
+  TRY(ensure_empty_pair_tables(s));
+  const int Wb = (mode == HITL_MODE_ODOM_HC) ? 1 : s->band_pairs_Wb;
+  if (mode == HITL_MODE_ODOM_HC) {
+    // mode A reads no pair table: a 1-pose band; the pair-derived band_pair table is unused
+  }
+  TRY(ensure_work(s, Wb));
+  TRY(setup_factors(s, poses_ref, mode != HITL_MODE_STF_ONLY));
+  *fv = factor_view(s, mode, Wb);
+  return HITL_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// linear solve: PCG on (S H S + D^2) preconditioned by the exact block-cyclic-reduction
+// factorisation of its in-band part.  With no off-band pose pairs the preconditioner IS the
+// matrix and the first iterate is the exact LM step (what Ceres' sparse Cholesky returns).
+// ---------------------------------------------------------------------------------------
+static int linear_solve(hitl_solver* s, const FactorView& fv, int buf, double mu, int* iters, bool* ok) {
+  hipStream_t st = s->stream;
+  const LinView lv = s->lin_view(buf);
+  const CrView cr = s->cr_view();
+  const double mind = s->opt.min_lm_diagonal, maxd = s->opt.max_lm_diagonal;
+  const int npad = s->npad;
+  launch_build_system(st, s->n, fv.band_poses, lv, s->scale.p, mu, mind, maxd, cr, s->rhs.p);
+  launch_cr_factor(st, cr);
+  launch_copy(st, npad, s->rhs.p, s->wv.p);
+  launch_cr_solve(st, cr, s->wv.p, s->dt.p);   // x0 = M^{-1} b
+  *iters = 1;
+  *ok = true;
+  if (fv.n_offband == 0 && s->opt.linear_solver_tolerance <= 0.0) return HITL_OK;
+  // r = b - A x0
+  launch_spmv(st, s->n, npad, fv, lv, s->scale.p, mu, mind, maxd, s->dt.p, s->qv.p);
+  launch_copy(st, npad, s->rhs.p, s->rv.p);
+  launch_axpby(st, npad, -1.0, s->qv.p, 1.0, s->rv.p);
+  const double* da[4] = {s->rv.p, s->rhs.p, s->rv.p, s->rv.p};
+  const double* db[4] = {s->rv.p, s->rhs.p, s->rv.p, s->rv.p};
+  launch_dots(st, npad, 2, da, db, s->d_scalars.p + 8);
+  HIP_TRY(hipMemcpyAsync(s->h_scalars + 8, s->d_scalars.p + 8, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  double rr = s->h_scalars[8];
+  const double bb = s->h_scalars[9];
+  const double tol = std::max(s->opt.linear_solver_tolerance, 1e-15);
+  const double target = tol * tol * bb;
+  if (!(rr == rr)) { *ok = false; return HITL_OK; }
+  if (rr <= target || fv.n_offband == 0) return HITL_OK;  // banded system: x0 is exact up to rounding
+  // PCG from x0
+  double rz_old = 0.0;
+  for (int it = 0; it < s->opt.max_linear_iterations; ++it) {
+    launch_copy(st, npad, s->rv.p, s->wv.p);
+    launch_cr_solve(st, cr, s->wv.p, s->zv.p);
+    const double* a1[4] = {s->rv.p, s->rv.p, s->rv.p, s->rv.p};
+    const double* b1[4] = {s->zv.p, s->zv.p, s->zv.p, s->zv.p};
+    launch_dots(st, npad, 1, a1, b1, s->d_scalars.p + 8);
+    HIP_TRY(hipMemcpyAsync(s->h_scalars + 8, s->d_scalars.p + 8, sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const double rz = s->h_scalars[8];
+    if (it == 0) launch_copy(st, npad, s->zv.p, s->pv.p);
+    else launch_axpby(st, npad, 1.0, s->zv.p, rz / rz_old, s->pv.p);
+    rz_old = rz;
+    launch_spmv(st, s->n, npad, fv, lv, s->scale.p, mu, mind, maxd, s->pv.p, s->qv.p);
+    const double* a2[4] = {s->pv.p, s->pv.p, s->pv.p, s->pv.p};
+    const double* b2[4] = {s->qv.p, s->qv.p, s->qv.p, s->qv.p};
+    launch_dots(st, npad, 1, a2, b2, s->d_scalars.p + 8);
+    HIP_TRY(hipMemcpyAsync(s->h_scalars + 8, s->d_scalars.p + 8, sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const double pq = s->h_scalars[8];
+    if (!(pq > 0.0)) { *ok = false; return HITL_OK; }
+    const double alpha = rz / pq;
+    launch_axpby(st, npad, alpha, s->pv.p, 1.0, s->dt.p);
+    launch_axpby(st, npad, -alpha, s->qv.p, 1.0, s->rv.p);
+    const double* a3[4] = {s->rv.p, s->rv.p, s->rv.p, s->rv.p};
+    launch_dots(st, npad, 1, a3, a3, s->d_scalars.p + 8);
+    HIP_TRY(hipMemcpyAsync(s->h_scalars + 8, s->d_scalars.p + 8, sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    rr = s->h_scalars[8];
+    ++*iters;
+    if (!(rr == rr)) { *ok = false; return HITL_OK; }
+    if (rr <= target) break;
+  }
+  return HITL_OK;
+}
+
+static double now_ms() {
+  using namespace std::chrono;
+  return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+// ---------------------------------------------------------------------------------------
+// Levenberg-Marquardt with Ceres trust-region semantics (DESIGN.md "LM")
+// ---------------------------------------------------------------------------------------
+static int lm_solve(hitl_solver* s, int mode, const float* poses_in, float* poses_out, hitl_summary* summary) {
+  const double t_start = now_ms();
+  const hitl_options& o = s->opt;
+  FactorView fv;
+  TRY(prepare(s, mode, poses_in, &fv));
+  hipStream_t st = s->stream;
+  const int n = s->n, n3 = 3 * n;
+  hitl_summary S;
+  std::memset(&S, 0, sizeof(S));
+  {  // SetParams (JointOptimization.cpp:392-402): fp32 -> fp64
+    std::vector<double> hx(s->npad, 0.0);
+    for (int t = 0; t < n3; ++t) hx[t] = (double)poses_in[t];
+    HIP_TRY(hipMemcpyAsync(s->x.p, hx.data(), sizeof(double) * s->npad, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  double* xcur = s->x.p;
+  double* xcand = s->xc.p;
+  int cur = 0;
+  LinResult lr;
+  TRY(run_linearize(s, fv, xcur, cur, &lr));
+  S.linearize_ms += lr.stf_ms; S.linearize_calls++;
+  double cost = lr.cost, gmax = lr.gmax;
+  S.initial_cost = cost;
+  S.num_pairs = fv.with_stf ? s->n_pairs : 0;
+  S.num_matches = fv.with_stf ? s->n_matches : 0;
+  S.num_offband_pairs = fv.n_offband;
+  S.band_poses = fv.band_poses;
+  S.num_hc_residuals = s->num_hc_residuals;
+  S.num_residuals = (fv.with_stf ? 2 * s->n_pairs : 0) + (fv.with_odom ? 3 * (n - 1) : 0) + (fv.with_hc ? s->num_hc_residuals : 0);
+  launch_jacobi_scale(st, n, s->npad, fv.band_poses, s->Hband[cur].p, o.jacobi_scaling, s->scale.p);
+  double radius = o.initial_trust_region_radius, decrease_factor = 2.0;
+  int iter = 0, invalid_run = 0;
+  int term = HITL_NO_CONVERGENCE;
+  bool done = false;
+  if (!(cost == cost) || !(gmax == gmax)) { term = HITL_FAILURE; done = true; }
+  else if (gmax <= o.gradient_tolerance) { term = HITL_CONVERGENCE; done = true; }
+  while (!done) {
+    if (iter >= o.max_num_iterations) { term = HITL_NO_CONVERGENCE; break; }
+    ++iter;
+    int lin_iters = 0;
+    bool ok = true;
+    HIP_TRY(hipEventRecord(s->ev2, st));
+    TRY(linear_solve(s, fv, cur, radius, &lin_iters, &ok));
+    S.linear_iterations += lin_iters;
+    // model_cost_change = -dt.(S g) - 1/2 dt.(S H S) dt
+    const LinView lv = s->lin_view(cur);
+    launch_spmv(st, n, s->npad, fv, lv, s->scale.p, 0.0, 0.0, 0.0, s->dt.p, s->qv.p);
+    launch_step_scalars(st, n3, s->dt.p, s->rhs.p, s->qv.p, s->scale.p, xcur, s->d_scalars.p);
+    launch_candidate(st, n3, xcur, s->scale.p, s->dt.p, xcand);
+    HIP_TRY(hipEventRecord(s->ev3, st));
+    HIP_TRY(hipGetLastError());
+    TRY(sync_scalars(s, 5));
+    {
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, s->ev2, s->ev3));
+      S.linear_solver_ms += ms;
+    }
+    const double dt_rhs = s->h_scalars[0], dt_q = s->h_scalars[1], step2 = s->h_scalars[2], xn2 = s->h_scalars[3];
+    const double mcc = dt_rhs - 0.5 * dt_q;  // rhs = -S g
+    if (!ok || s->h_scalars[4] > 0.0 || !(mcc == mcc) || mcc < 0.0) {  // invalid step
+      ++S.unsuccessful_steps;
+      if (++invalid_run >= 5) { term = HITL_FAILURE; break; }
+      radius /= decrease_factor; decrease_factor *= 2.0;
+      continue;
+    }
+    invalid_run = 0;
+    TRY(run_linearize(s, fv, xcand, cur ^ 1, &lr));
+    S.linearize_ms += lr.stf_ms; S.linearize_calls++;
+    if (std::sqrt(step2) <= o.parameter_tolerance * (std::sqrt(xn2) + o.parameter_tolerance)) { term = HITL_CONVERGENCE; break; }
+    const double cost_change = cost - lr.cost;
+    if (std::fabs(cost_change) <= o.function_tolerance * cost) { term = HITL_CONVERGENCE; break; }
+    const double rho = cost_change / mcc;
+    if (rho > o.min_relative_decrease) {
+      ++S.successful_steps;
+      std::swap(xcur, xcand);
+      cur ^= 1;
+      cost = lr.cost; gmax = lr.gmax;
+      if (gmax <= o.gradient_tolerance) { term = HITL_CONVERGENCE; break; }
+      const double q = 2.0 * rho - 1.0;
+      radius = std::min(o.max_trust_region_radius, radius / std::max(1.0 / 3.0, 1.0 - q * q * q));
+      decrease_factor = 2.0;
+    } else {
+      ++S.unsuccessful_steps;
+      radius /= decrease_factor; decrease_factor *= 2.0;
+      if (radius < o.min_trust_region_radius) { term = HITL_CONVERGENCE; break; }
+    }
+  }
+  S.termination = term; S.iterations = iter;
+  S.final_cost = cost; S.final_gradient_max_norm = gmax; S.final_trust_region_radius = radius;
+  {  // CopyParams (JointOptimization.cpp:380-390): fp64 -> fp32, theta through angle_mod
+    std::vector<double> hx(n3);
+    HIP_TRY(hipMemcpyAsync(hx.data(), xcur, sizeof(double) * n3, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int i = 0; i < n; ++i) {
+      poses_out[3 * i] = (float)hx[3 * i];
+      poses_out[3 * i + 1] = (float)hx[3 * i + 1];
+      poses_out[3 * i + 2] = (float)angle_mod(hx[3 * i + 2]);
+    }
+  }
+  S.total_ms = now_ms() - t_start;
+  if (summary) *summary = S;
+  if (term == HITL_FAILURE) return fail(HITL_ERR_SOLVER_FAILURE, "Levenberg-Marquardt terminated with FAILURE");
+  return HITL_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// correspondence search driver
+// ---------------------------------------------------------------------------------------
+static void make_rel_tf(const float* pi, const float* pj, float* t) {
+  // RelativePoseTransform (JointOptimization.cpp:296-305) and the normal rotation at :603-605
+  // in fp32; R_j^T stands in for Eigen's general 2x2 inverse (fp32-rounding-level deviation).
+  const float ci = cosf(pi[2]), si = sinf(pi[2]), cj = cosf(pj[2]), sj = sinf(pj[2]);
+  t[0] = cj * ci + sj * si; t[1] = sj * ci - cj * si;
+  t[2] = cj * si - sj * ci; t[3] = sj * si + cj * ci;
+  const float dx = pi[0] - pj[0], dy = pi[1] - pj[1];
+  t[4] = cj * dx + sj * dy; t[5] = cj * dy - sj * dx;
+  const float dth = (float)((double)pj[2] - (double)pi[2]);
+  t[6] = cosf(dth); t[7] = sinf(dth);
+}
+
+static int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
+  HIP_TRY(hipSetDevice(s->device));
+  const int n = s->n;
+  if (window <= 0 || window > n) window = n;
+  const int slots = (int)std::min<int64_t>(2 * window, std::max(n - 1, 1));
+  const size_t table_entries = (size_t)n * slots * s->max_scan;
+  if (table_entries * sizeof(uint16_t) > (size_t)64 << 30)
+    return fail(HITL_ERR_OUT_OF_MEMORY, "candidate table would exceed 64 GiB; use a smaller window");
+  std::vector<int> cand_tgt((size_t)n * slots, -1);
+  std::vector<float> cand_tf((size_t)n * slots * 8, 0.f);
+  for (int i = 0; i < n; ++i) {
+    int slot = 0;
+    const int j0 = (int)std::max<int64_t>(0, i - window), j1 = (int)std::min<int64_t>(n - 1, i + window);
+    for (int j = j0; j <= j1; ++j) {
+      if (j == i) continue;
+      cand_tgt[(size_t)i * slots + slot] = j;
+      make_rel_tf(poses + 3 * i, poses + 3 * j, &cand_tf[((size_t)i * slots + slot) * 8]);
+      ++slot;
+    }
+  }
+  hipStream_t st = s->stream;
+  DevArray<int> d_tgt, d_counts, d_kept;
+  DevArray<float> d_tf;
+  DevArray<uint16_t> d_table;
+  int rc = HITL_OK;
+  auto cleanup = [&]() { d_tgt.release(); d_counts.release(); d_kept.release(); d_tf.release(); d_table.release(); };
+#define TRYC(expr) do { rc = (expr); if (rc != HITL_OK) { cleanup(); return rc; } } while (0)
+  TRYC(d_tgt.upload(cand_tgt, st));
+  TRYC(d_tf.upload(cand_tf, st));
+  TRYC(d_counts.resize((size_t)n * slots));
+  TRYC(d_counts.zero(st));
+  TRYC(d_table.resize(table_entries));
+  MatchParams mp;
+  mp.thr = s->opt.point_match_threshold;
+  mp.min_cos = cosf(s->opt.max_stf_angle_error);   // JointOptimization.cpp:564
+  mp.cap = s->opt.max_correspondences_per_point;
+  mp.skip = std::max(s->opt.num_skip_readings, 1);
+  const MapView mv = s->map_view();
+  launch_match(st, mv, s->max_scan, slots, d_tgt.p, d_tf.p, mp, d_table.p, d_counts.p);
+  std::vector<int> counts((size_t)n * slots);
+  if (hipMemcpyAsync(counts.data(), d_counts.p, counts.size() * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess) {
+    cleanup();
+    return fail(HITL_ERR_HIP, std::string("match kernel: ") + hipGetErrorString(hipGetLastError()));
+  }
+  // keep pairs with more than kMinInterPoseCorrespondence matches (:632-634), pose order (:636-641)
+  std::vector<int> kept;
+  s->h_pair_src.clear(); s->h_pair_tgt.clear(); s->h_match_off.assign(1, 0);
+  for (int i = 0; i < n; ++i)
+    for (int sl = 0; sl < slots; ++sl) {
+      const size_t c = (size_t)i * slots + sl;
+      if (cand_tgt[c] >= 0 && counts[c] > s->opt.min_inter_pose_correspondence) {
+        kept.push_back((int)c);
+        s->h_pair_src.push_back(i); s->h_pair_tgt.push_back(cand_tgt[c]);
+        s->h_match_off.push_back(s->h_match_off.back() + counts[c]);
+      }
+    }
+  s->n_pairs = (int)kept.size();
+  s->n_matches = s->h_match_off.back();
+  s->h_perm.resize(s->n_pairs);
+  std::iota(s->h_perm.begin(), s->h_perm.end(), 0);
+  TRYC(d_kept.upload(kept, st));
+  TRYC(s->pair_src.upload(s->h_pair_src, st));
+  TRYC(s->pair_tgt.upload(s->h_pair_tgt, st));
+  TRYC(s->match_off.upload(s->h_match_off, st));
+  TRYC(s->matches.resize((size_t)s->n_matches));
+  launch_compact(st, mv, s->max_scan, slots, s->n_pairs, d_kept.p, s->match_off.p, d_table.p, s->matches.p);
+  if (hipStreamSynchronize(st) != hipSuccess) { cleanup(); return fail(HITL_ERR_HIP, "compact kernel failed"); }
+  cleanup();
+#undef TRYC
+  return build_pair_structures(s);
+}
+
+}  // namespace hitl
+
+// =========================================================================================
+// C ABI
+// =========================================================================================
+extern "C" {
+
+void hitl_options_default(hitl_options* o) {
+  if (!o) return;
+  std::memset(o, 0, sizeof(*o));
+  o->abi_version = HITL_ABI_VERSION;
+  o->device = 0;
+  o->laser_std_dev = 0.05f;
+  o->point_correlation_factor = 1.0f / 40.0f;
+  o->point_match_threshold = 0.15f;
+  o->max_stf_angle_error = (float)(25.0 * M_PI / 180.0);
+  o->max_correspondences_per_point = 6;
+  o->num_skip_readings = 1;
+  o->min_inter_pose_correspondence = 10;
+  o->odom_radial_std_dev = 0.03f;
+  o->odom_tangential_std_dev = 0.03f;
+  o->odom_angular_std_dev = 0.01f;
+  o->max_num_iterations = 100;
+  o->jacobi_scaling = 1;
+  o->function_tolerance = 1e-6;
+  o->gradient_tolerance = 1e-10;
+  o->parameter_tolerance = 1e-8;
+  o->initial_trust_region_radius = 1e4;
+  o->max_trust_region_radius = 1e16;
+  o->min_trust_region_radius = 1e-32;
+  o->min_relative_decrease = 1e-3;
+  o->min_lm_diagonal = 1e-6;
+  o->max_lm_diagonal = 1e32;
+  o->linear_solver_tolerance = 1e-12;
+  o->max_linear_iterations = 50;
+  o->max_band_poses = 4;
+  o->rank = 0;
+  o->world_size = 1;
+  o->rccl_unique_id = nullptr;
+}
+
+int hitl_abi_version(void) { return HITL_ABI_VERSION; }
+
+const char* hitl_last_error(void) { return g_last_error.c_str(); }
+
+const char* hitl_status_string(int st) {
+  switch (st) {
+    case HITL_OK: return "OK";
+    case HITL_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case HITL_ERR_NO_DEVICE: return "no usable HIP device";
+    case HITL_ERR_HIP: return "HIP runtime error";
+    case HITL_ERR_OUT_OF_MEMORY: return "out of device memory";
+    case HITL_ERR_NOT_READY: return "solver not ready (map or correspondences missing)";
+    case HITL_ERR_UNSUPPORTED: return "unsupported input";
+    case HITL_ERR_SOLVER_FAILURE: return "solver FAILURE";
+    case HITL_ERR_COMM: return "RCCL error";
+    default: return "unknown status";
+  }
+}
+
+int hitl_solver_create(const hitl_options* opt, hitl_solver** out) {
+  if (!out) return fail(HITL_ERR_INVALID_ARGUMENT, "out is null");
+  *out = nullptr;
+  hitl_options o;
+  if (opt) o = *opt; else hitl_options_default(&o);
+  if (o.abi_version != HITL_ABI_VERSION) return fail(HITL_ERR_INVALID_ARGUMENT, "hitl_options.abi_version mismatch");
+  if (o.world_size < 1 || o.rank < 0 || o.rank >= o.world_size) return fail(HITL_ERR_INVALID_ARGUMENT, "bad rank/world_size");
+  if (o.world_size > 1) return fail(HITL_ERR_UNSUPPORTED, "in-library submap exchange is not built yet; run one solver per submap");
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    return fail(HITL_ERR_NO_DEVICE, "no HIP device visible (hipGetDeviceCount); this library has no CPU fallback");
+  if (o.device < 0 || o.device >= count) return fail(HITL_ERR_NO_DEVICE, "hitl_options.device out of range");
+  HIP_TRY(hipSetDevice(o.device));
+  hitl_solver* s = new (std::nothrow) hitl_solver();
+  if (!s) return fail(HITL_ERR_OUT_OF_MEMORY, "host allocation failed");
+  s->opt = o;
+  s->device = o.device;
+  auto bail = [&](int code, const std::string& m) { hitl_solver_destroy(s); return fail(code, m); };
+  if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) return bail(HITL_ERR_HIP, "hipStreamCreate failed");
+  for (hipEvent_t* e : {&s->ev0, &s->ev1, &s->ev2, &s->ev3})
+    if (hipEventCreate(e) != hipSuccess) return bail(HITL_ERR_HIP, "hipEventCreate failed");
+  if (hipHostMalloc((void**)&s->h_scalars, sizeof(double) * kNumScalars) != hipSuccess) return bail(HITL_ERR_HIP, "hipHostMalloc failed");
+  if (s->d_scalars.resize(kNumScalars) != HITL_OK) return bail(HITL_ERR_OUT_OF_MEMORY, "hipMalloc failed");
+  *out = s;
+  return HITL_OK;
+}
+
+void hitl_solver_destroy(hitl_solver* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->device);
+  if (s->stream) (void)hipStreamSynchronize(s->stream);
+  for (DevArray<double>* v : {&s->d_scalars, &s->x, &s->xc, &s->scale, &s->rhs, &s->dt, &s->wv, &s->qv, &s->rv, &s->zv, &s->pv,
+                              &s->crD, &s->crL, &s->crDinv, &s->crGl, &s->crGr})
+    v->release();
+  for (int k = 0; k < 2; ++k) { s->pairRJ[k].release(); s->Hband[k].release(); s->gvec[k].release(); s->obblk[k].release(); s->cost_pose[k].release(); }
+  s->obs_off.release(); s->match_off.release();
+  for (DevArray<float>* v : {&s->px, &s->py, &s->nx, &s->ny, &s->cov9}) v->release();
+  for (DevArray<int>* v : {&s->pair_src, &s->pair_tgt, &s->pose_pair_off, &s->inc_off, &s->inc_ent, &s->band_pair, &s->ob_lo,
+                           &s->ob_hi, &s->ob_fwd, &s->ob_rev, &s->obadj_off, &s->obadj_ent, &s->hc_off})
+    v->release();
+  s->matches.release(); s->odom_A.release(); s->hc_tgt.release(); s->odom_rr.release(); s->hc_type.release();
+  if (s->h_scalars) (void)hipHostFree(s->h_scalars);
+  for (hipEvent_t e : {s->ev0, s->ev1, s->ev2, s->ev3}) if (e) (void)hipEventDestroy(e);
+  if (s->stream) (void)hipStreamDestroy(s->stream);
+  delete s;
+}
+
+int hitl_solver_set_map(hitl_solver* s, int64_t n_poses, const int64_t* obs_offset, const float* px, const float* py,
+                        const float* nx, const float* ny, const float* cov9) {
+  if (!s || !obs_offset || n_poses < 1) return fail(HITL_ERR_INVALID_ARGUMENT, "set_map: null solver/offsets or n_poses < 1");
+  if (n_poses > (int64_t)1 << 30) return fail(HITL_ERR_UNSUPPORTED, "set_map: more than 2^30 poses");
+  const int64_t O = obs_offset[n_poses];
+  if (obs_offset[0] != 0 || O < 0 || (O > 0 && (!px || !py || !nx || !ny))) return fail(HITL_ERR_INVALID_ARGUMENT, "set_map: bad offsets or null scan arrays");
+  int max_scan = 0;
+  for (int64_t i = 0; i < n_poses; ++i) {
+    const int64_t m = obs_offset[i + 1] - obs_offset[i];
+    if (m < 0) return fail(HITL_ERR_INVALID_ARGUMENT, "set_map: obs_offset must be non-decreasing");
+    if (m > 65535) return fail(HITL_ERR_UNSUPPORTED, "set_map: a scan has more than 65535 points (match indices are packed u16)");
+    max_scan = std::max<int>(max_scan, (int)m);
+  }
+  HIP_TRY(hipSetDevice(s->device));
+  hipStream_t st = s->stream;
+  s->n = (int)n_poses; s->n_obs = O; s->max_scan = std::max(max_scan, 1);
+  s->h_obs_off.assign(obs_offset, obs_offset + n_poses + 1);
+  TRY(s->obs_off.upload(s->h_obs_off, st));
+  TRY(s->px.upload(px, O, st)); TRY(s->py.upload(py, O, st)); TRY(s->nx.upload(nx, O, st)); TRY(s->ny.upload(ny, O, st));
+  if (cov9) TRY(s->cov9.upload(cov9, (size_t)n_poses * 9, st));   // carried like covariances_; no live factor reads it
+  HIP_TRY(hipStreamSynchronize(st));
+  // a new map invalidates correspondences
+  s->n_pairs = 0; s->n_matches = 0; s->pose_pair_off.n = 0;
+  s->h_hc.erase(std::remove_if(s->h_hc.begin(), s->h_hc.end(), [&](const hitl_human_constraint_t& r) {
+                  return r.constrained_pose_id >= s->n || r.anchor_pose_id >= s->n; }), s->h_hc.end());
+  return ensure_empty_pair_tables(s);
+}
+
+int hitl_solver_set_human_constraints(hitl_solver* s, int64_t n, const hitl_human_constraint_t* rows) {
+  if (!s || n < 0 || (n > 0 && !rows)) return fail(HITL_ERR_INVALID_ARGUMENT, "set_human_constraints: bad arguments");
+  if (s->n <= 0) return fail(HITL_ERR_NOT_READY, "set_human_constraints before set_map");
+  for (int64_t h = 0; h < n; ++h)
+    if (rows[h].constrained_pose_id < 0 || rows[h].constrained_pose_id >= s->n || rows[h].anchor_pose_id < 0 || rows[h].anchor_pose_id >= s->n)
+      return fail(HITL_ERR_INVALID_ARGUMENT, "set_human_constraints: pose id out of range");
+  s->h_hc.assign(rows, rows + n);
+  return HITL_OK;
+}
+
+int hitl_solver_find_correspondences(hitl_solver* s, const float* poses_xyt, int64_t window) {
+  if (!s || !poses_xyt) return fail(HITL_ERR_INVALID_ARGUMENT, "find_correspondences: null argument");
+  if (s->n <= 0) return fail(HITL_ERR_NOT_READY, "find_correspondences before set_map");
+  return find_correspondences(s, poses_xyt, window);
+}
+
+int hitl_solver_set_correspondences(hitl_solver* s, int64_t n_pairs, const int32_t* pair_src, const int32_t* pair_tgt,
+                                    const int64_t* match_offset, const int32_t* src_idx, const int32_t* tgt_idx) {
+  if (!s || n_pairs < 0) return fail(HITL_ERR_INVALID_ARGUMENT, "set_correspondences: bad arguments");
+  if (s->n <= 0) return fail(HITL_ERR_NOT_READY, "set_correspondences before set_map");
+  if (n_pairs > 0 && (!pair_src || !pair_tgt || !match_offset || !src_idx || !tgt_idx)) return fail(HITL_ERR_INVALID_ARGUMENT, "set_correspondences: null array");
+  HIP_TRY(hipSetDevice(s->device));
+  const int P = (int)n_pairs;
+  for (int p = 0; p < P; ++p) {
+    const int a = pair_src[p], b = pair_tgt[p];
+    if (a < 0 || a >= s->n || b < 0 || b >= s->n || a == b) return fail(HITL_ERR_INVALID_ARGUMENT, "set_correspondences: pose index out of range or src == tgt");
+    if (match_offset[p + 1] <= match_offset[p]) return fail(HITL_ERR_INVALID_ARGUMENT, "set_correspondences: every pair needs >= 1 match (residual_functors.h:783)");
+    const int64_t ma = s->h_obs_off[a + 1] - s->h_obs_off[a], mb = s->h_obs_off[b + 1] - s->h_obs_off[b];
+    for (int64_t m = match_offset[p]; m < match_offset[p + 1]; ++m)
+      if (src_idx[m] < 0 || src_idx[m] >= ma || tgt_idx[m] < 0 || tgt_idx[m] >= mb) return fail(HITL_ERR_INVALID_ARGUMENT, "set_correspondences: point index out of range");
+  }
+  std::vector<int> order(P);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int u, int v) { return pair_src[u] < pair_src[v]; });
+  s->h_perm = order;
+  s->h_pair_src.resize(P); s->h_pair_tgt.resize(P); s->h_match_off.assign(P + 1, 0);
+  const int64_t C = P ? match_offset[P] - match_offset[0] : 0;
+  std::vector<uint32_t> packed((size_t)C);
+  int64_t w = 0;
+  for (int q = 0; q < P; ++q) {
+    const int p = order[q];
+    s->h_pair_src[q] = pair_src[p]; s->h_pair_tgt[q] = pair_tgt[p];
+    for (int64_t m = match_offset[p]; m < match_offset[p + 1]; ++m) packed[w++] = (uint32_t)src_idx[m] | ((uint32_t)tgt_idx[m] << 16);
+    s->h_match_off[q + 1] = w;
+  }
+  s->n_pairs = P; s->n_matches = C;
+  hipStream_t st = s->stream;
+  TRY(s->pair_src.upload(s->h_pair_src, st)); TRY(s->pair_tgt.upload(s->h_pair_tgt, st));
+  TRY(s->match_off.upload(s->h_match_off, st)); TRY(s->matches.upload(packed, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return build_pair_structures(s);
+}
+
+int hitl_solver_get_correspondence_counts(hitl_solver* s, int64_t* n_pairs, int64_t* n_matches) {
+  if (!s) return fail(HITL_ERR_INVALID_ARGUMENT, "null solver");
+  if (n_pairs) *n_pairs = s->n_pairs;
+  if (n_matches) *n_matches = s->n_matches;
+  return HITL_OK;
+}
+
+int hitl_solver_get_correspondences(hitl_solver* s, int32_t* pair_src, int32_t* pair_tgt, int64_t* match_offset,
+                                    int32_t* src_idx, int32_t* tgt_idx) {
+  if (!s || !match_offset) return fail(HITL_ERR_INVALID_ARGUMENT, "get_correspondences: null argument");
+  HIP_TRY(hipSetDevice(s->device));
+  const int P = s->n_pairs;
+  std::vector<uint32_t> packed((size_t)s->n_matches);
+  if (s->n_matches) {
+    HIP_TRY(hipMemcpyAsync(packed.data(), s->matches.p, packed.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+  }
+  // return in the caller's original pair order
+  std::vector<int> inv(P);
+  for (int q = 0; q < P; ++q) inv[s->h_perm[q]] = q;
+  int64_t w = 0;
+  match_offset[0] = 0;
+  for (int p = 0; p < P; ++p) {
+    const int q = inv[p];
+    pair_src[p] = s->h_pair_src[q]; pair_tgt[p] = s->h_pair_tgt[q];
+    for (int64_t m = s->h_match_off[q]; m < s->h_match_off[q + 1]; ++m) {
+      src_idx[w] = (int32_t)(packed[m] & 0xffffu); tgt_idx[w] = (int32_t)(packed[m] >> 16); ++w;
+    }
+    match_offset[p + 1] = w;
+  }
+  return HITL_OK;
+}
+
+int hitl_solver_solve(hitl_solver* s, int32_t mode, const float* poses_in_xyt, float* poses_out_xyt, hitl_summary* summary) {
+  TRY(check_ready(s, mode));
+  if (!poses_in_xyt || !poses_out_xyt) return fail(HITL_ERR_INVALID_ARGUMENT, "solve: null pose array");
+  if (mode == HITL_MODE_STF_ONLY && s->n_pairs == 0) return fail(HITL_ERR_NOT_READY, "mode STF_ONLY needs correspondences (find_/set_correspondences)");
+  return lm_solve(s, mode, poses_in_xyt, poses_out_xyt, summary);
+}
+
+int hitl_solver_linearize(hitl_solver* s, int32_t mode, const float* poses_ref_xyt, const double* x, double* cost,
+                          double* gradient, double* pair_residuals, double* pair_jacobians) {
+  TRY(check_ready(s, mode));
+  if (!poses_ref_xyt || !x) return fail(HITL_ERR_INVALID_ARGUMENT, "linearize: null pose array");
+  FactorView fv;
+  TRY(prepare(s, mode, poses_ref_xyt, &fv));
+  hipStream_t st = s->stream;
+  const int n3 = 3 * s->n;
+  HIP_TRY(hipMemcpyAsync(s->x.p, x, sizeof(double) * n3, hipMemcpyHostToDevice, st));
+  LinResult lr;
+  TRY(run_linearize(s, fv, s->x.p, 0, &lr));
+  if (cost) *cost = lr.cost;
+  if (gradient) HIP_TRY(hipMemcpyAsync(gradient, s->gvec[0].p, sizeof(double) * n3, hipMemcpyDeviceToHost, st));
+  if (fv.with_stf && (pair_residuals || pair_jacobians)) {
+    std::vector<double> rj((size_t)s->n_pairs * kPairRJ);
+    HIP_TRY(hipMemcpyAsync(rj.data(), s->pairRJ[0].p, rj.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int q = 0; q < s->n_pairs; ++q) {
+      const int p = s->h_perm[q];
+      if (pair_residuals) { pair_residuals[2 * p] = rj[(size_t)q * kPairRJ]; pair_residuals[2 * p + 1] = rj[(size_t)q * kPairRJ + 1]; }
+      if (pair_jacobians) std::memcpy(pair_jacobians + 12 * (size_t)p, &rj[(size_t)q * kPairRJ + 2], 12 * sizeof(double));
+    }
+  }
+  HIP_TRY(hipStreamSynchronize(st));
+  return HITL_OK;
+}
+
+int hitl_solver_evaluate(hitl_solver* s, int32_t mode, const float* poses_xyt, double* cost, double* gradient) {
+  TRY(check_ready(s, mode));
+  if (!poses_xyt) return fail(HITL_ERR_INVALID_ARGUMENT, "evaluate: null pose array");
+  std::vector<double> x((size_t)3 * s->n);
+  for (size_t t = 0; t < x.size(); ++t) x[t] = (double)poses_xyt[t];
+  return hitl_solver_linearize(s, mode, poses_xyt, x.data(), cost, gradient, nullptr, nullptr);
+}
+
+int hitl_comm_unique_id(void* out128) {
+  if (!out128) return fail(HITL_ERR_INVALID_ARGUMENT, "null buffer");
+  std::memset(out128, 0, 128);
+  return fail(HITL_ERR_UNSUPPORTED, "in-library RCCL exchange is not built yet");
+}
+
+int hitl_partition_range(int64_t n_poses, const int64_t* obs_offset, int32_t rank, int32_t world_size, int64_t* begin,
+                         int64_t* end) {
+  // contiguous pose ranges balanced by observation count
+  if (n_poses < 1 || !obs_offset || world_size < 1 || rank < 0 || rank >= world_size || !begin || !end)
+    return fail(HITL_ERR_INVALID_ARGUMENT, "partition_range: bad arguments");
+  const int64_t total = obs_offset[n_poses] - obs_offset[0];
+  // every rank computes the whole cut list, so neighbouring ranges always abut
+  std::vector<int64_t> cuts(world_size + 1, 0);
+  cuts[world_size] = n_poses;
+  for (int r = 1; r < world_size; ++r) {
+    int64_t c;
+    if (total <= 0) {
+      c = n_poses * r / world_size;
+    } else {
+      const double goal = (double)total * (double)r / (double)world_size;
+      c = std::lower_bound(obs_offset, obs_offset + n_poses + 1, (int64_t)std::llround(goal) + obs_offset[0]) - obs_offset;
+    }
+    if (n_poses >= world_size) c = std::min<int64_t>(std::max<int64_t>(c, cuts[r - 1] + 1), n_poses - (world_size - r));
+    else c = std::min<int64_t>(std::max<int64_t>(c, cuts[r - 1]), n_poses);
+    cuts[r] = c;
+  }
+  const int64_t b = cuts[rank], e = cuts[rank + 1];
+  *begin = b; *end = e;
+  return HITL_OK;
+}
+
+}  // extern "C"

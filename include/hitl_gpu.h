@@ -1,0 +1,217 @@
+/*
+ * hitl_gpu.h -- C ABI of libhitlgpu.so, the MI355X (gfx950) backend for hitl-slam's
+ * batch re-optimisation hot path.
+ *
+ * This is the drop-in boundary.  The reference has no FFI for this
+ * path; the seam is the JointOpt object (public members in, Run(), poses_ out --
+ * HitL-SLAM/src/human_in_the_loop_slam/JointOptimization.h:49-89) whose body reaches
+ * Ceres at ceres::Solve (JointOptimization.cpp:1093 and :1208).  Each entry point below
+ * cites the reference interface it replaces.  Plain pointers and sizes only; no C++ or
+ * torch types cross this boundary; every function returns an int status (0 = OK) and
+ * never throws.  The library installs no signal handlers and is meant to be created
+ * once and called repeatedly from one thread (the reference's single ROS spinner,
+ * HitLSLAM_main.cpp:1049).
+ *
+ * Numerics contract: inputs are fp32 (poses, scans, human-constraint rows), all solver
+ * state and arithmetic is fp64, outputs are rounded to fp32 with theta wrapped by
+ * theta - 2*pi*rint(theta/2pi) (shared/math/util.h:433-439 via JointOptimization.cpp:388).
+ * Pose 0 is held constant (JointOptimization.cpp:824, :1197).
+ */
+#ifndef HITL_GPU_H_
+#define HITL_GPU_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HITL_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------------------ */
+enum {
+  HITL_OK = 0,
+  HITL_ERR_INVALID_ARGUMENT = 1,
+  HITL_ERR_NO_DEVICE = 2,       /* no HIP device / HIP runtime error at create        */
+  HITL_ERR_HIP = 3,             /* a HIP call failed (message via hitl_last_error)    */
+  HITL_ERR_OUT_OF_MEMORY = 4,
+  HITL_ERR_NOT_READY = 5,       /* e.g. solve before set_map, mode B without pairs    */
+  HITL_ERR_UNSUPPORTED = 6,     /* e.g. a scan with more than 65535 points            */
+  HITL_ERR_SOLVER_FAILURE = 7,  /* == ceres::FAILURE; the JointOpt shim exit(1)s here */
+  HITL_ERR_COMM = 8             /* RCCL error                                          */
+};
+
+/* ---- solve modes --------------------------------------------------------------------
+ * A: odometry + human rows   == JointOpt::SolveHumanConstraints (JointOptimization.cpp:1064-1138)
+ * B: scan-to-scan (STF) only == JointOpt::PostHumanOptimization  (JointOptimization.cpp:1156-1256)
+ * C: A and B jointly         == the "full batch re-solve" of BASELINE.json                  */
+enum { HITL_MODE_ODOM_HC = 0, HITL_MODE_STF_ONLY = 1, HITL_MODE_JOINT = 2 };
+
+/* ---- termination (ceres::TerminationType as used at JointOptimization.cpp:1339-1349) -- */
+enum { HITL_CONVERGENCE = 0, HITL_NO_CONVERGENCE = 1, HITL_FAILURE = 2 };
+
+/* == CorrectionType (human_constraints.h:8-16).  Types 0,1,3 add no residual. */
+enum {
+  HITL_HC_UNKNOWN = 0, HITL_HC_POINT = 1, HITL_HC_LINE_SEGMENT = 2, HITL_HC_CORNER = 3,
+  HITL_HC_COLINEAR = 4, HITL_HC_PERPENDICULAR = 5, HITL_HC_PARALLEL = 6
+};
+
+/* == struct HumanConstraint (human_constraints.h:29-41), 28 bytes, same field order. */
+typedef struct hitl_human_constraint_t {
+  uint32_t type;                 /* CorrectionType                                   */
+  int32_t constrained_pose_id;
+  int32_t anchor_pose_id;
+  float delta_parallel;
+  float delta_perpendicular;
+  float delta_angle;
+  float relative_penalty_dir;    /* colinear rows only                               */
+} hitl_human_constraint_t;
+
+/* Options.  STF fields mirror VectorMappingOptions (vector_mapping.h:121-186), which the
+ * reference binary leaves uninitialised; defaults are the cobot block of
+ * config/non_markov_localization.cfg (:11,:16,:47-50).  Odometry sigmas are the
+ * constants hard-coded at JointOptimization.cpp:770,776,783.  Trust-region fields are the
+ * ceres::Solver::Options defaults in effect at JointOptimization.cpp:1066-1070 / :145-162. */
+typedef struct hitl_options {
+  int32_t abi_version;                    /* HITL_ABI_VERSION                         */
+  int32_t device;                         /* HIP device ordinal (default 0)           */
+  /* STF / correspondence */
+  float laser_std_dev;                    /* kLaserStdDev                 0.05        */
+  float point_correlation_factor;         /* kPointPointCorrelationFactor 1/40        */
+  float point_match_threshold;            /* kPointMatchThreshold         0.15        */
+  float max_stf_angle_error;              /* kMaxStfAngleError  rad(25 deg)           */
+  int32_t max_correspondences_per_point;  /* kMaxCorrespondencesPerPoint  6           */
+  int32_t num_skip_readings;              /* num_skip_readings            1           */
+  int32_t min_inter_pose_correspondence;  /* pair kept iff count > this   10          */
+  /* odometry sigmas */
+  float odom_radial_std_dev;              /* 0.03 */
+  float odom_tangential_std_dev;          /* 0.03 */
+  float odom_angular_std_dev;             /* 0.01 */
+  /* Levenberg-Marquardt / trust region */
+  int32_t max_num_iterations;             /* 100 */
+  int32_t jacobi_scaling;                 /* 1   */
+  double function_tolerance;              /* 1e-6  */
+  double gradient_tolerance;              /* 1e-10 */
+  double parameter_tolerance;             /* 1e-8  */
+  double initial_trust_region_radius;     /* 1e4   */
+  double max_trust_region_radius;         /* 1e16  */
+  double min_trust_region_radius;         /* 1e-32 */
+  double min_relative_decrease;           /* 1e-3  */
+  double min_lm_diagonal;                 /* 1e-6  */
+  double max_lm_diagonal;                 /* 1e32  */
+  /* linear solver: PCG preconditioned by the exact block-cyclic-reduction factorisation
+   * of the in-band part of the Hessian.                                                 */
+  double linear_solver_tolerance;         /* relative residual, 1e-12                  */
+  int32_t max_linear_iterations;          /* 50                                        */
+  int32_t max_band_poses;                 /* widest pose distance kept in the band, 1..4 (default 4) */
+  /* multi-GPU (pose-range submaps).  world_size 1 = single device, no RCCL.             */
+  int32_t rank;
+  int32_t world_size;
+  const void* rccl_unique_id;             /* 128-byte ncclUniqueId from hitl_comm_unique_id, same on all ranks */
+  int64_t reserved[4];
+} hitl_options;
+
+/* Per-solve report (what Ceres' Solver::Summary gives the caller at
+ * JointOptimization.cpp:1093-1095, plus per-phase device timings). */
+typedef struct hitl_summary {
+  int32_t termination;          /* HITL_CONVERGENCE / NO_CONVERGENCE / FAILURE          */
+  int32_t iterations;           /* LM iterations executed (successful + unsuccessful)   */
+  int32_t successful_steps;
+  int32_t unsuccessful_steps;
+  int32_t linear_iterations;    /* total PCG iterations                                 */
+  int32_t num_residuals;        /* rows of r                                            */
+  int32_t num_hc_residuals;     /* == JointOpt::num_hc_residuals_ (JointOptimization.cpp:973-1050) */
+  int32_t band_poses;           /* pose half-width of the banded part                   */
+  int64_t num_pairs;            /* directed STF pose pairs in the problem               */
+  int64_t num_matches;          /* point matches in the problem                         */
+  int64_t num_offband_pairs;
+  double initial_cost;
+  double final_cost;
+  double final_gradient_max_norm;
+  double final_trust_region_radius;
+  double total_ms;              /* wall clock of hitl_solver_solve                      */
+  double linearize_ms;          /* sum of device time in linearize passes               */
+  double linear_solver_ms;
+  int32_t linearize_calls;
+  int32_t reserved_i;
+  double reserved[6];
+} hitl_summary;
+
+typedef struct hitl_solver hitl_solver;   /* opaque; owns device memory */
+
+/* Fill *opt with the defaults listed above. */
+void hitl_options_default(hitl_options* opt);
+
+/* Replaces: JointOpt::JointOpt() (JointOptimization.cpp ctor).  Picks the device, creates
+ * streams and, when world_size > 1, the RCCL communicator. */
+int hitl_solver_create(const hitl_options* opt, hitl_solver** out);
+void hitl_solver_destroy(hitl_solver*);
+
+/* Replaces: the hand-off of robot_frame_point_clouds_, robot_frame_normal_clouds_ and
+ * covariances_ (HitLSLAM.cpp:450-454; JointOptimization.h:62-71) and BuildKDTrees
+ * (JointOptimization.cpp:514-537; no tree is built -- matching is brute force in LDS).
+ * SoA robot-frame scans: obs_offset has n_poses+1 entries; cov9 (n_poses*9) may be NULL.
+ * Arrays are copied to the device; the caller keeps ownership.  In a multi-GPU solver
+ * every rank passes the WHOLE map's obs_offset but may pass scan data only for the poses
+ * it needs (see hitl_solver_owned_range); simplest is to pass everything. */
+int hitl_solver_set_map(hitl_solver*, int64_t n_poses, const int64_t* obs_offset,
+                        const float* px, const float* py, const float* nx, const float* ny,
+                        const float* cov9);
+
+/* Replaces: human_constraints_ hand-off (HitLSLAM.cpp:454) + AddHumanConstraints
+ * (JointOptimization.cpp:969-1054).  Rows are the flattened vector<vector<HumanConstraint>>. */
+int hitl_solver_set_human_constraints(hitl_solver*, int64_t n, const hitl_human_constraint_t* rows);
+
+/* Replaces: FindSTFCorrespondences (JointOptimization.cpp:561-642).  Every source pose i
+ * is matched against target poses j in [i-window, i+window], j != i, ascending; window <= 0
+ * or >= n_poses reproduces the reference's all-pairs search. */
+int hitl_solver_find_correspondences(hitl_solver*, const float* poses_xyt, int64_t window);
+
+/* Install a correspondence set directly (parity tests; == point_point_glob_correspondences_,
+ * vector_mapping.h:102-119 as index pairs).  Directed pairs p: source pose pair_src[p],
+ * target pose pair_tgt[p]; matches [match_offset[p], match_offset[p+1]) index into the two
+ * scans (src_idx into scan pair_src[p], tgt_idx into scan pair_tgt[p]). */
+int hitl_solver_set_correspondences(hitl_solver*, int64_t n_pairs, const int32_t* pair_src,
+                                    const int32_t* pair_tgt, const int64_t* match_offset,
+                                    const int32_t* src_idx, const int32_t* tgt_idx);
+
+/* Read back the current correspondence set (sizes first, then arrays sized by them). */
+int hitl_solver_get_correspondence_counts(hitl_solver*, int64_t* n_pairs, int64_t* n_matches);
+int hitl_solver_get_correspondences(hitl_solver*, int32_t* pair_src, int32_t* pair_tgt,
+                                    int64_t* match_offset, int32_t* src_idx, int32_t* tgt_idx);
+
+/* Replaces: SetParams + SolveHumanConstraints / PostHumanOptimization + CopyParams, i.e. the
+ * ceres::Solve call sites (JointOptimization.cpp:392-402, :1064-1138, :1156-1256, :380-390).
+ * poses_in_xyt / poses_out_xyt are n_poses*3 fp32 (x,y,theta); they may alias.  Synchronous. */
+int hitl_solver_solve(hitl_solver*, int32_t mode, const float* poses_in_xyt,
+                      float* poses_out_xyt, hitl_summary* summary);
+
+/* Replaces: problem.Evaluate(..., &residuals, &gradients_, ...) (JointOptimization.cpp:1247-1252).
+ * cost = 1/2 |r|^2; gradient (3*n_poses, pose 0 entries are 0) may be NULL.  The odometry
+ * measurements and human targets are re-derived from poses_xyt exactly as a solve would. */
+int hitl_solver_evaluate(hitl_solver*, int32_t mode, const float* poses_xyt,
+                         double* cost, double* gradient);
+
+/* Debug / parity: linearise at double-precision poses x (3*n_poses) with the odometry
+ * measurements and human targets derived from the fp32 poses_ref_xyt; returns the cost, the
+ * gradient (3n), the per-pair STF residuals (2 per pair) and Jacobians (12 per pair,
+ * row-major 2x6) -- any output may be NULL. */
+int hitl_solver_linearize(hitl_solver*, int32_t mode, const float* poses_ref_xyt, const double* x,
+                          double* cost, double* gradient, double* pair_residuals,
+                          double* pair_jacobians);
+
+/* Multi-GPU helpers.  hitl_comm_unique_id: rank 0 calls it and broadcasts the 128 bytes.
+ * hitl_partition_range: the contiguous pose range rank r of w owns for n_poses poses,
+ * balanced by observation count (host-only; runs without a GPU). */
+int hitl_comm_unique_id(void* out128);
+int hitl_partition_range(int64_t n_poses, const int64_t* obs_offset, int32_t rank,
+                         int32_t world_size, int64_t* begin, int64_t* end);
+
+const char* hitl_status_string(int status);
+const char* hitl_last_error(void);       /* thread-local detail of the last failure      */
+int hitl_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* HITL_GPU_H_ */

@@ -1,0 +1,89 @@
+/*
+ * hitl_oracle.h -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).
+ *
+ * A plain-C, fp64, dependency-free restatement of hitl-slam's batch re-optimisation path,
+ * used only as the checker in tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg.  Nothing under hitl_slam_amd/ may include, link or call it.
+ *
+ * PARITY UNPINNED: the reference publishes no tests, golden vectors or fixtures for this
+ * path and cannot be compiled in this image (needs Ceres, Eigen, glog, ROS, CImg; Ceres is
+ * an un-vendored, un-versioned dependency -- HitL-SLAM/CMakeLists.txt:83).  The residual
+ * definitions below follow residual_functors.h / JointOptimization.cpp line by line; the
+ * derivative and trust-region semantics restate Ceres Solver's documented
+ * AutoDiffCostFunction (forward-mode Jets) and TrustRegionMinimizer +
+ * LevenbergMarquardtStrategy behaviour (1.x era).  See DESIGN.md "Oracle".
+ */
+#ifndef HITL_ORACLE_H_
+#define HITL_ORACLE_H_
+
+#include "../include/hitl_gpu.h"   /* shared POD types only: options, summary, constraint row */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_solver orc_solver;
+
+/* ---- solver-level API: same shapes as the hitl_solver_* C ABI ----------------------- */
+int orc_create(const hitl_options* opt, orc_solver** out);
+void orc_destroy(orc_solver*);
+int orc_set_num_threads(int n);   /* OpenMP threads used by linearize / matching; returns previous */
+int orc_set_map(orc_solver*, int64_t n_poses, const int64_t* obs_offset, const float* px,
+                const float* py, const float* nx, const float* ny, const float* cov9);
+int orc_set_human_constraints(orc_solver*, int64_t n, const hitl_human_constraint_t* rows);
+/* method: 0 = brute-force definition, 1 = restated KD-tree walk (kdtree.cpp:141-197) */
+int orc_find_correspondences(orc_solver*, const float* poses_xyt, int64_t window, int method);
+int orc_set_correspondences(orc_solver*, int64_t n_pairs, const int32_t* pair_src,
+                            const int32_t* pair_tgt, const int64_t* match_offset,
+                            const int32_t* src_idx, const int32_t* tgt_idx);
+int orc_get_correspondence_counts(orc_solver*, int64_t* n_pairs, int64_t* n_matches);
+int orc_get_correspondences(orc_solver*, int32_t* pair_src, int32_t* pair_tgt,
+                            int64_t* match_offset, int32_t* src_idx, int32_t* tgt_idx);
+int orc_solve(orc_solver*, int32_t mode, const float* poses_in_xyt, float* poses_out_xyt,
+              hitl_summary* summary);
+/* as orc_solve but also returns the un-rounded fp64 state (3n) */
+int orc_solve_f64(orc_solver*, int32_t mode, const float* poses_in_xyt, double* x_out,
+                  hitl_summary* summary);
+int orc_evaluate(orc_solver*, int32_t mode, const float* poses_xyt, double* cost, double* gradient);
+int orc_linearize(orc_solver*, int32_t mode, const float* poses_ref_xyt, const double* x,
+                  double* cost, double* gradient, double* pair_residuals, double* pair_jacobians);
+/* dense J^T J (3n x 3n row-major, pose-0 rows/cols replaced by identity) and gradient */
+int orc_assemble_dense(orc_solver*, int32_t mode, const float* poses_ref_xyt, const double* x,
+                       double* H, double* g, double* cost);
+/* use forward-mode dual numbers (what ceres::AutoDiffCostFunction does) instead of the
+ * analytic Jacobians inside linearize/solve: 0 = analytic (default), 1 = jets */
+int orc_set_use_jets(orc_solver*, int use);
+
+/* ---- functor-level API (each is one residual block of the reference) ---------------- */
+/* JointOptimization.cpp:743-769: measurement re-derived from the current fp32 poses. */
+void orc_odom_setup(const float* pose_prev_xyt, const float* pose_cur_xyt, float A[4],
+                    float* radial_translation, float* rotation);
+/* residual_functors.h:1081-1125.  sig = {radial, tangential, angular} std devs.
+ * J is 3x6 row-major (x1,y1,t1,x2,y2,t2); may be NULL. */
+void orc_odom_eval(const double x1[3], const double x2[3], const float A[4], float rho, float rot,
+                   const float sig[3], double r[3], double* J);
+void orc_odom_eval_jet(const double x1[3], const double x2[3], const float A[4], float rho,
+                       float rot, const float sig[3], double r[3], double* J);
+/* JointOptimization.cpp:980-1050: target from the anchor pose, fp32 math.
+ * tgt = {x*, y*, theta*, penalty_dir}. */
+void orc_hc_target(const hitl_human_constraint_t* row, const float* anchor_pose_xyt, float tgt[4]);
+/* residual_functors.h:1299-1415.  Returns the number of residuals (3,2,1,1 or 0).
+ * J is nres x 3 row-major; may be NULL. */
+int orc_hc_eval(uint32_t type, const float tgt[4], const double x[3], double r[3], double* J);
+int orc_hc_eval_jet(uint32_t type, const float tgt[4], const double x[3], double r[3], double* J);
+/* residual_functors.h:786-830.  J is 2x6 row-major (x0,y0,t0,x1,y1,t1); may be NULL. */
+void orc_stf_eval(const double x0[3], const double x1[3], int64_t n, const float* p0x,
+                  const float* p0y, const float* p1x, const float* p1y, const float* n0x,
+                  const float* n0y, const float* n1x, const float* n1y, float std_dev,
+                  float corr_factor, double r[2], double* J);
+void orc_stf_eval_jet(const double x0[3], const double x1[3], int64_t n, const float* p0x,
+                      const float* p0y, const float* p1x, const float* p1y, const float* n0x,
+                      const float* n0y, const float* n1x, const float* n1y, float std_dev,
+                      float corr_factor, double r[2], double* J);
+/* shared/math/util.h:433-439 */
+double orc_angle_mod(double a);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

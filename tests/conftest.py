@@ -1,0 +1,59 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _native_built():
+    """Build the oracle and the synthetic-map tool (gcc, seconds).  libhitlgpu.so is built by
+    __graft_entry__.build(); GPU tests fail loudly if it is missing."""
+    from oracle import hitl_oracle
+    from tools import hitl_synth
+    hitl_oracle.build()
+    hitl_synth.build()
+
+
+class Problem(object):
+    """A small synthetic map + constraints, shared by oracle-only and GPU parity tests."""
+
+    def __init__(self, n_poses, obs, seed=20260102, ppf=None, groups=2, kind=4, window=3):
+        from tools import hitl_synth as S
+        self.p = S.params(n_poses, obs, seed=seed, poses_per_floor=ppf or max(n_poses // 2, 8))
+        self.gt, self.init, self.cov = S.poses(self.p)
+        self.off, self.px, self.py, self.nx, self.ny = S.scans(self.p)
+        self.rows = S.constraints(self.p, self.gt, groups, kind=kind) if groups else (None, 0)
+        self.window = window
+        self.n = n_poses
+
+    def load(self, solver, with_corr=True, corr=None):
+        solver.set_map(self.off, self.px, self.py, self.nx, self.ny, self.cov)
+        if self.rows[1]:
+            solver.set_human_constraints(self.rows)
+        if corr is not None:
+            solver.set_correspondences(*corr)
+        return solver
+
+
+@pytest.fixture(scope="session")
+def small_problem():
+    return Problem(60, 90, ppf=30)
+
+
+def oracle_corr(prob, window=None, method=0):
+    from oracle import hitl_oracle as O
+    o = O.OracleSolver()
+    prob.load(o)
+    o.find_correspondences(prob.init, prob.window if window is None else window, method)
+    c = o.get_correspondences()
+    o.close()
+    return c

@@ -1,0 +1,152 @@
+"""GPU parity: the HIP path through the C ABI (hitl_slam_amd.Solver -> libhitlgpu.so) against
+the CPU oracle on identical seeded inputs.  Bars: index sets bit-exact; residuals/Jacobians
+1e-10 relative; converged poses 1e-4 m / 1e-4 rad (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+from conftest import Problem, oracle_corr
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL_M = 1e-4     # north_star tolerance, metres
+POSE_TOL_RAD = 1e-4   # north_star tolerance, radians
+
+
+def _gpu():
+    import hitl_slam_amd as H
+    return H.Solver()
+
+
+def _oracle():
+    from oracle import hitl_oracle as O
+    return O.OracleSolver()
+
+
+def _relerr(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def test_extension_is_loaded_and_runs_on_device():
+    import hitl_slam_amd as H
+    lib = H.load_library()
+    assert lib.hitl_abi_version() == H.abi.ABI_VERSION
+    s = _gpu()
+    s.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_linearize_matches_oracle(small_problem, mode):
+    prob = small_problem
+    corr = oracle_corr(prob)
+    g, o = prob.load(_gpu(), corr=corr), prob.load(_oracle(), corr=corr)
+    rng = np.random.default_rng(5)
+    x = prob.init.astype(np.float64) + 0.01 * rng.standard_normal(prob.init.shape)
+    cg, gg, rg, jg = g.linearize(mode, prob.init, x)
+    co, go, ro, jo = o.linearize(mode, prob.init, x)
+    assert abs(cg - co) <= 1e-11 * abs(co)
+    assert _relerr(gg, go) <= 1e-10
+    assert gg[:3].tolist() == [0.0, 0.0, 0.0]          # pose 0 is constant
+    if mode != 0:
+        assert _relerr(rg, ro) <= 1e-11
+        assert _relerr(jg, jo) <= 1e-10
+
+
+def test_matcher_bit_exact_vs_bruteforce_definition(small_problem):
+    prob = small_problem
+    g, o = prob.load(_gpu()), prob.load(_oracle())
+    for window in (1, 3, 0):                              # 0 = all pairs (the reference's search)
+        g.find_correspondences(prob.init, window)
+        o.find_correspondences(prob.init, window, 0)
+        for a, b in zip(g.get_correspondences(), o.get_correspondences()):
+            assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_solve_matches_oracle(small_problem, mode):
+    import hitl_slam_amd as H
+    prob = small_problem
+    corr = oracle_corr(prob)
+    g, o = prob.load(_gpu(), corr=corr), prob.load(_oracle(), corr=corr)
+    pg, sg = g.solve(mode, prob.init)
+    po, so = o.solve(mode, prob.init)
+    assert sg.termination == so.termination
+    assert sg.iterations == so.iterations
+    assert sg.num_residuals == so.num_residuals and sg.num_hc_residuals == so.num_hc_residuals
+    assert abs(sg.final_cost - so.final_cost) <= 1e-7 * max(so.final_cost, 1e-12)   # 100 LM iterations of rounding drift in mode B
+    assert np.abs(pg[:, :2] - po[:, :2]).max() <= POSE_TOL_M
+    assert np.abs(pg[:, 2] - po[:, 2]).max() <= POSE_TOL_RAD
+    assert np.array_equal(pg[0], prob.init[0])            # pose 0 held constant
+
+
+def test_solve_with_offband_pairs_uses_pcg(small_problem):
+    """All-pairs correspondences (the reference's search) leave pose pairs outside the band:
+    the PCG must iterate and still land on the oracle's exact-Cholesky step sequence."""
+    prob = Problem(24, 64, ppf=24, groups=1)
+    corr = oracle_corr(prob, window=0)
+    assert np.abs(corr[0] - corr[1]).max() > 4
+    g, o = prob.load(_gpu(), corr=corr), prob.load(_oracle(), corr=corr)
+    pg, sg = g.solve(2, prob.init)
+    po, so = o.solve(2, prob.init)
+    assert sg.num_offband_pairs > 0 and sg.linear_iterations > sg.iterations
+    assert sg.termination == so.termination and sg.iterations == so.iterations
+    assert np.abs(pg[:, :2] - po[:, :2]).max() <= POSE_TOL_M
+    assert np.abs(pg[:, 2] - po[:, 2]).max() <= POSE_TOL_RAD
+
+
+def test_zero_residual_start_terminates_at_iteration_0():
+    """BASELINE config 1: no human constraints, odometry measurements re-derived from the
+    current poses (JointOptimization.cpp:748-769) => r = 0, converged before any step."""
+    import hitl_slam_amd as H
+    prob = Problem(40, 32, ppf=20, groups=0)
+    g = prob.load(_gpu())
+    pg, sg = g.solve(H.MODE_ODOM_HC, prob.init)
+    assert sg.iterations == 0 and sg.termination == H.CONVERGENCE
+    assert sg.initial_cost <= 1e-12
+    assert np.array_equal(pg, prob.init)
+
+
+def test_evaluate_gradient_matches_oracle(small_problem):
+    prob = small_problem
+    corr = oracle_corr(prob)
+    g, o = prob.load(_gpu(), corr=corr), prob.load(_oracle(), corr=corr)
+    cg, gg = g.evaluate(2, prob.init)
+    co, go = o.evaluate(2, prob.init)
+    assert abs(cg - co) <= 1e-11 * abs(co) and _relerr(gg, go) <= 1e-10
+
+
+def test_ragged_and_empty_scans():
+    """Ragged obs_offset, one empty scan, a pose with no pairs at all."""
+    import hitl_slam_amd as H
+    prob = Problem(30, 48, ppf=30, groups=1)
+    keep = np.ones(len(prob.px), bool)
+    M = 48
+    keep[5 * M:6 * M] = False                  # pose 5: empty scan
+    keep[7 * M + 10:8 * M] = False             # pose 7: 10 points
+    counts = np.array([keep[i * M:(i + 1) * M].sum() for i in range(prob.n)])
+    prob.off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    prob.px, prob.py, prob.nx, prob.ny = (a[keep] for a in (prob.px, prob.py, prob.nx, prob.ny))
+    g, o = prob.load(_gpu()), prob.load(_oracle())
+    g.find_correspondences(prob.init, 3)
+    o.find_correspondences(prob.init, 3, 0)
+    cg, co = g.get_correspondences(), o.get_correspondences()
+    for a, b in zip(cg, co):
+        assert np.array_equal(a, b)
+    assert 5 not in set(cg[0].tolist()) | set(cg[1].tolist())
+    pg, sg = g.solve(H.MODE_JOINT, prob.init)
+    po, so = o.solve(H.MODE_JOINT, prob.init)
+    assert sg.iterations == so.iterations
+    assert np.abs(pg - po).max() <= POSE_TOL_M
+
+
+def test_errors_are_loud():
+    import hitl_slam_amd as H
+    s = _gpu()
+    with pytest.raises(H.HitlError):
+        s.solve(0, np.zeros((1, 3), np.float32))          # no map yet
+    prob = Problem(10, 16, ppf=10, groups=0)
+    prob.load(s)
+    with pytest.raises(H.HitlError):
+        s.solve(H.MODE_STF_ONLY, prob.init)                # no correspondences
+    with pytest.raises(H.HitlError):
+        s.set_correspondences([0], [0], [0, 1], [0], [0])  # src == tgt
+    s.close()

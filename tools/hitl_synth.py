@@ -1,0 +1,79 @@
+"""ctypes wrapper of tools/hitl_synth.c: deterministic synthetic maps.
+
+Data generator for tests and bench.py; neither oracle nor product.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from hitl_slam_amd import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_build", "libhitl_synth.so")
+_lib = None
+
+
+class Params(C.Structure):
+    _fields_ = [("n_poses", C.c_int64), ("obs_per_pose", C.c_int32), ("poses_per_floor", C.c_int32),
+                ("seed", C.c_uint64), ("step", C.c_double), ("range_sigma", C.c_double),
+                ("odom_sigma_t", C.c_double), ("odom_sigma_a", C.c_double)]
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "hitl_synth.c")
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+        os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+        subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-fPIC", "-fopenmp", "-shared", "-o", LIB_PATH, src, "-lm"])
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        _lib = C.CDLL(LIB_PATH)
+        _lib.synth_constraints.restype = C.c_int64
+    return _lib
+
+
+def params(n_poses, obs_per_pose, seed=20260102, poses_per_floor=200, **kw):
+    p = Params()
+    lib().synth_params_default(C.byref(p))
+    p.n_poses, p.obs_per_pose, p.seed, p.poses_per_floor = n_poses, obs_per_pose, seed, poses_per_floor
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def poses(p):
+    """Returns (gt float64 [n,3], init float32 [n,3], cov9 float32 [n,9])."""
+    n = p.n_poses
+    gt = np.zeros((n, 3), np.float64)
+    init = np.zeros((n, 3), np.float32)
+    cov = np.zeros((n, 9), np.float32)
+    lib().synth_poses(C.byref(p), gt.ctypes.data_as(C.c_void_p), init.ctypes.data_as(C.c_void_p),
+                      cov.ctypes.data_as(C.c_void_p))
+    return gt, init, cov
+
+
+def scans(p, begin=0, end=None):
+    """Returns (obs_offset int64 [m+1] relative to `begin`, px, py, nx, ny float32) for poses [begin, end)."""
+    end = p.n_poses if end is None else end
+    m, M = end - begin, p.obs_per_pose
+    arrs = [np.zeros(m * M, np.float32) for _ in range(4)]
+    lib().synth_scans(C.byref(p), C.c_int64(begin), C.c_int64(end), *[a.ctypes.data_as(C.c_void_p) for a in arrs])
+    off = np.arange(m + 1, dtype=np.int64) * M
+    return (off,) + tuple(arrs)
+
+
+def constraints(p, gt, n_groups, kind=4, begin=0, end=None):
+    """25 rows per group; returns a ctypes array of hitl_human_constraint_t and its length."""
+    end = p.n_poses if end is None else end
+    rows = (abi.HumanConstraint * max(25 * n_groups, 1))()
+    gt = np.ascontiguousarray(gt, np.float64)
+    n = lib().synth_constraints(C.byref(p), gt.ctypes.data_as(C.c_void_p), C.c_int64(begin), C.c_int64(end),
+                                C.c_int32(n_groups), C.c_int32(kind), rows)
+    return rows, int(n)
