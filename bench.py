@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""bench.py -- full batch re-solve throughput of the MI355X pose-graph backend.
+
+A "step" is one complete batch re-solve (hitl_solver_solve, mode C = odometry + human rows +
+scan-to-scan factors: every Levenberg-Marquardt iteration re-evaluates all matched
+observation rows) of one synthetic map whose scans and correspondences are already resident
+in HBM; poses and human-constraint rows are handed over inside the timed region, as at the
+reference call site (HitLSLAM.cpp:450-458 -> JointOpt::Run).
+
+Default workload (N=1): BASELINE.json's target configuration "50k poses x 400 obs/pose, 50
+human constraints" on one GPU (configs[3]'s map at 1 GPU, the size the north-star target
+">= 10x lower wall-clock per full batch re-solve ... at 1 GPU" is quoted on).
+--workload c2 selects configs[1] (1k x 360, 2 colinear constraints).
+
+With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) the trajectory is
+N times longer and split into N pose-range submaps, one per rank (weak scaling).  Ranks cut
+the map where it shards naturally (between floors: no scan overlap, one odometry edge).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (poses per GPU, obs per pose, constraint groups per submap, constraint kind, window)
+    "c4": dict(poses=50000, obs=400, groups=50, kind=0, window=3,
+               desc="synthetic multi-floor: 50k poses x 400 obs/pose, 50 human constraints (mixed), mode C"),
+    "c2": dict(poses=1000, obs=360, groups=2, kind=4, window=3,
+               desc="synthetic corridor: 1k poses x 360 obs/pose, 2 colinearity constraints, mode C"),
+    "c5": dict(poses=25000, obs=512, groups=25, kind=0, window=3,
+               desc="synthetic campus-scale: 200k poses x 512 obs/pose over 8 submaps, 200 mixed constraints, mode C"),
+}
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes_stf(n_obs, n_matches, n_poses, n_pairs):
+    """Algorithmic bytes of ONE k_linearize_stf launch, SURVEY.md section 8(d) `linearize` row
+    restricted to what this kernel touches: 16 B per observation (point + normal, read once as
+    a source), 24 B per match (u32 src idx + u32 tgt idx + 16 B gathered target point/normal),
+    24 B per pose (fp64 state), and 112 B per directed pair (r[2] + J[2x6] written; the 3x3
+    blocks of the survey's 72(N+P) term are produced from these by k_assemble)."""
+    return 16 * n_obs + 24 * n_matches + 24 * n_poses + 112 * n_pairs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
+    ap.add_argument("--poses", type=int, default=0, help="override poses per GPU")
+    ap.add_argument("--obs", type=int, default=0, help="override observations per pose")
+    ap.add_argument("--cpu-sample-poses", type=int, default=6000, help="poses in the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    use_dist = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
+    torch.cuda.set_device(local_rank)
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import hitl_slam_amd as H
+    from tools import hitl_synth as S
+
+    wl = dict(WORKLOADS[args.workload])
+    if args.poses:
+        wl["poses"] = args.poses
+    if args.obs:
+        wl["obs"] = args.obs
+    n_local, M = wl["poses"], wl["obs"]
+    ppf = 200 if n_local >= 400 else max(n_local // 2, 8)
+    n_global = n_local * world
+    seed = 20260102 + 1000 * {"c2": 2, "c4": 4, "c5": 5}[args.workload]
+
+    # ---- synthetic map: this rank's pose-range submap of the global trajectory ------------------
+    t0 = time.time()
+    p = S.params(n_global, M, seed=seed, poses_per_floor=ppf)
+    gt, init, cov = S.poses(p)
+    begin, end = rank * n_local, (rank + 1) * n_local        # floors hold ppf poses: cuts fall between floors
+    off, px, py, nx, ny = S.scans(p, begin, end)
+    rows = S.constraints(p, gt, wl["groups"], kind=wl["kind"], begin=begin, end=end)
+    # local pose indices
+    for k in range(rows[1]):
+        rows[0][k].constrained_pose_id -= begin
+        rows[0][k].anchor_pose_id -= begin
+    init_l = np.ascontiguousarray(init[begin:end])
+    gen_s = time.time() - t0
+
+    opt = H.default_options()
+    opt.device = local_rank
+    solver = H.Solver(opt)
+    solver.set_map(off, px, py, nx, ny, cov[begin:end])
+    solver.set_human_constraints(rows)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    solver.find_correspondences(init_l, wl["window"])
+    match_ms = (time.time() - t0) * 1e3
+    n_obs = int(off[-1])
+
+    # ---- warm-up, then exactly K timed re-solves -----------------------------------------------------
+    for _ in range(args.warmup):
+        out, summ = solver.solve(H.MODE_JOINT, init_l)
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    iters = 0
+    stf_ms = 0.0
+    stf_calls = 0
+    lin_solver_ms = 0.0
+    for _ in range(args.steps):
+        out, summ = solver.solve(H.MODE_JOINT, init_l)
+        iters += summ.iterations
+        stf_ms += summ.linearize_ms
+        stf_calls += summ.linearize_calls
+        lin_solver_ms += summ.linear_solver_ms
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t_start
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tot = torch.tensor([float(iters), float(n_obs) * iters], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        iters_all, obs_iters_all = float(tot[0].item()), float(tot[1].item())
+    else:
+        iters_all, obs_iters_all = float(iters), float(n_obs) * iters
+
+    if rank != 0:
+        if use_dist:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed * 1e3 / args.steps
+    avg_stf_ms = stf_ms / max(stf_calls, 1)
+    alg_bytes = algorithmic_bytes_stf(n_obs, summ.num_matches, n_local, summ.num_pairs)
+    achieved = alg_bytes / (avg_stf_ms * 1e-3) / 1e9 if avg_stf_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("n_obs") == n_obs:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    err_gt = float(np.abs(out[:, :2].astype(np.float64) - gt[begin:end, :2]).max())
+
+    result = {
+        "metric": "full batch re-solve throughput (observation rows x Gauss-Newton/LM iterations per second); "
+                  "resolve_ms = full batch re-solve wall-clock, gn_iters_per_sec alongside",
+        "value": obs_iters_all / elapsed,
+        "unit": "obs-iters/s",
+        "n_gpus": args.gpus,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": wl["desc"], "poses_per_gpu": n_local, "obs_per_pose": M, "n_poses_total": n_global,
+                   "n_obs_per_gpu": n_obs, "matches_per_gpu": int(summ.num_matches), "pairs_per_gpu": int(summ.num_pairs),
+                   "matches_per_obs": summ.num_matches / max(n_obs, 1), "window": wl["window"],
+                   "human_constraint_rows": rows[1], "mode": "C (joint)", "band_poses": int(summ.band_poses),
+                   "parallelism": "1 pose-range submap per GPU" if world > 1 else "single GPU"},
+        "resolve_ms": ms_per_step,
+        "gn_iters_per_sec": iters_all / elapsed,
+        "lm_iterations_per_resolve": summ.iterations,
+        "termination": int(summ.termination),
+        "final_cost": summ.final_cost,
+        "correspondence_search_ms": match_ms,
+        "linear_solver_ms_per_resolve": lin_solver_ms / args.steps,
+        "max_xy_error_vs_ground_truth_m": err_gt,
+        "roofline": {"bound": "hbm", "kernel": "k_linearize_stf", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_stf_ms, "launches": stf_calls,
+                     "compulsory_bytes_this_layout": 16 * n_obs + 4 * int(summ.num_matches) + 24 * n_local + 112 * int(summ.num_pairs)},
+        "synth_gen_s": gen_s,
+    }
+
+    # ---- CPU baseline: the oracle (a port, not the reference binary) on a bounded sample ----------
+    if not args.no_cpu_baseline and args.cpu_sample_poses > 0 and world == 1:
+        try:
+            from oracle import hitl_oracle as O
+            ns = min(args.cpu_sample_poses, n_local)
+            ns = max((ns // ppf) * ppf, min(ppf, n_local))
+            ps, pt, mo, i0, i1 = solver.get_correspondences()
+            sel = (ps < ns) & (pt < ns)
+            keep_idx = np.nonzero(sel)[0]
+            lens = (mo[1:] - mo[:-1])[keep_idx]
+            mo_s = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+            take = np.concatenate([np.arange(mo[k], mo[k + 1]) for k in keep_idx]) if len(keep_idx) else np.zeros(0, np.int64)
+            groups_s = max(1, int(round(wl["groups"] * ns / n_local)))
+            # the sample IS the first ns poses of the GPU workload (same scans, poses, matches)
+            rows_s = S.constraints(p, gt, groups_s, kind=wl["kind"], begin=0, end=ns)
+            init_s, cov_s = np.ascontiguousarray(init_l[:ns]), cov[:ns]
+            orc = O.OracleSolver()
+            orc.set_map(off[:ns + 1], px[:off[ns]], py[:off[ns]], nx[:off[ns]], ny[:off[ns]], cov_s)
+            orc.set_human_constraints(rows_s)
+            orc.set_correspondences(ps[keep_idx], pt[keep_idx], mo_s, i0[take], i1[take])
+            cores = os.cpu_count() or 1
+            O.set_num_threads(cores)
+            orc.solve(H.MODE_JOINT, init_s)                       # warm-up
+            best = None
+            for _ in range(3):
+                t0 = time.perf_counter()
+                _, so = orc.solve(H.MODE_JOINT, init_s)
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            n_obs_s = int(off[ns])
+            result["cpu_baseline"] = {
+                "value": n_obs_s * so.iterations / best, "unit": "obs-iters/s", "cores": cores, "kind": "port",
+                "sample": "oracle (C/OpenMP restatement, analytic Jacobians, exact banded Cholesky) on the first %d poses "
+                          "x %d obs (%d matches, %d constraint rows), same mode C, best of 3: %.1f ms per re-solve, %d LM iterations"
+                          % (ns, M, int(mo_s[-1]), rows_s[1], best * 1e3, so.iterations),
+                "resolve_ms_sample": best * 1e3, "sample_obs": n_obs_s,
+                "resolve_ms_extrapolated_to_workload": best * 1e3 * n_obs / n_obs_s,
+            }
+            result["speedup_vs_cpu_port"] = result["value"] / result["cpu_baseline"]["value"]
+        except Exception as e:  # the baseline is a reported extra; never fail the bench line on it
+            result["cpu_baseline"] = {"value": None, "unit": "obs-iters/s", "cores": os.cpu_count(), "kind": "port",
+                                      "sample": "failed: %r" % (e,)}
+    print(json.dumps(result))
+    sys.stdout.flush()
+    solver.close()
+    if use_dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

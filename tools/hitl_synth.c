@@ -35,13 +35,13 @@ typedef struct synth_params {
   uint64_t seed;
   double step;                /* 0.3 m */
   double range_sigma;         /* 0.01 m */
-  double odom_sigma_t;        /* 0.005 m per step */
-  double odom_sigma_a;        /* 0.002 rad per step */
+  double odom_sigma_t;        /* 0.003 m per step (scan-matched front end) */
+  double odom_sigma_a;        /* 0.0005 rad per step */
 } synth_params;
 
 void synth_params_default(synth_params* p) {
   p->n_poses = 1000; p->obs_per_pose = 360; p->poses_per_floor = 200; p->seed = 20260102ull;
-  p->step = 0.3; p->range_sigma = 0.01; p->odom_sigma_t = 0.005; p->odom_sigma_a = 0.002;
+  p->step = 0.3; p->range_sigma = 0.01; p->odom_sigma_t = 0.003; p->odom_sigma_a = 0.0005;
 }
 
 /* ---- RNG ------------------------------------------------------------------------------ */
