@@ -28,8 +28,7 @@ def build(force=False):
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            build()
+        build()          # no-op when the .so is newer than its source
         _lib = C.CDLL(LIB_PATH)
         _bind_functors(_lib)
     return _lib

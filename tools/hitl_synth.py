@@ -32,8 +32,7 @@ def build(force=False):
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            build()
+        build()          # no-op when the .so is newer than its source
         _lib = C.CDLL(LIB_PATH)
         _lib.synth_constraints.restype = C.c_int64
     return _lib
