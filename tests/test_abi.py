@@ -1,0 +1,105 @@
+"""The C-ABI shared library loads without a GPU, exports every symbol include/hitl_gpu.h
+declares, agrees with the ctypes mirror on struct layout, runs its host-only entry points,
+and fails loudly (never falls back) when asked to compute without a device."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "hitl_gpu.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import hitl_slam_amd as H
+    if not os.path.exists(H.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return H.load_library()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    src = open(HEADER).read()
+    names = sorted(set(re.findall(r"\b(hitl_[a-z_0-9]+)\s*\(", src)))
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), "libhitlgpu.so does not export %s" % n
+
+
+def test_struct_layout_matches_ctypes_mirror(lib):
+    from hitl_slam_amd import abi
+    prog = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "hitl_gpu.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(hitl_human_constraint_t), sizeof(hitl_options), sizeof(hitl_summary),
+         offsetof(hitl_options, function_tolerance), offsetof(hitl_options, rccl_unique_id),
+         offsetof(hitl_summary, initial_cost), offsetof(hitl_summary, linearize_calls));
+  return 0;
+}'''
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(prog)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", os.path.join(d, "t"), os.path.join(d, "t.c")])
+        out = subprocess.check_output([os.path.join(d, "t")]).decode().split()
+    got = [int(v) for v in out]
+    assert got[0] == C.sizeof(abi.HumanConstraint) == 28       # == struct HumanConstraint (human_constraints.h:29-41)
+    assert got[1] == C.sizeof(abi.Options)
+    assert got[2] == C.sizeof(abi.Summary)
+    assert got[3] == abi.Options.function_tolerance.offset
+    assert got[4] == abi.Options.rccl_unique_id.offset
+    assert got[5] == abi.Summary.initial_cost.offset
+    assert got[6] == abi.Summary.linearize_calls.offset
+
+
+def test_defaults_agree_between_c_and_python(lib):
+    from hitl_slam_amd import abi
+    o = abi.Options()
+    lib.hitl_options_default(C.byref(o))
+    p = abi.default_options()
+    for name, _ in abi.Options._fields_:
+        if name in ("reserved", "rccl_unique_id"):
+            continue
+        assert getattr(o, name) == getattr(p, name), name
+    assert lib.hitl_abi_version() == abi.ABI_VERSION
+
+
+def test_partition_range_covers_and_balances(lib):
+    from hitl_slam_amd.api import partition_range
+    rng = np.random.default_rng(0)
+    counts = rng.integers(0, 500, 1000)
+    off = np.concatenate([[0], np.cumsum(counts)])
+    for w in (1, 2, 3, 4, 8):
+        rs = [partition_range(off, r, w) for r in range(w)]
+        assert rs[0][0] == 0 and rs[-1][1] == 1000
+        for a, b in zip(rs[:-1], rs[1:]):
+            assert a[1] == b[0]
+        loads = [off[e] - off[b] for b, e in rs]
+        assert all(e > b for b, e in rs)
+        assert max(loads) - min(loads) <= 2 * counts.max()
+    # more ranks than poses is the caller's problem, but must not crash
+    assert partition_range(np.array([0, 5, 9]), 0, 2) == (0, 1)
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
+def test_no_silent_cpu_fallback(lib):
+    import hitl_slam_amd as H
+    with pytest.raises(H.HitlError) as e:
+        H.Solver()
+    assert e.value.status == H.abi.ERR_NO_DEVICE
+    assert b"no CPU fallback" in lib.hitl_last_error() or b"HIP" in lib.hitl_last_error()
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "hitl_slam_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "hitl_oracle" not in txt and "orc_" not in txt, "%s references the oracle" % f

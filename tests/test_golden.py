@@ -1,0 +1,69 @@
+"""Committed golden fixtures (tests/golden/*.npz, made by tests/golden/make_golden.py from
+the oracle; the reference itself has none -- parity unpinned).  CPU: the oracle still
+reproduces them bit-for-bit in its index work and to 1e-12 in fp64.  GPU: the HIP path
+through the C ABI lands on them within the north-star tolerance."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from hitl_slam_amd import abi
+from hitl_slam_amd.api import hc_rows
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "*.npz")))
+POSE_TOL_M = 1e-4
+POSE_TOL_RAD = 1e-4
+
+
+def _load(solver, z, with_corr=True):
+    solver.set_map(z["obs_offset"], z["px"], z["py"], z["nx"], z["ny"], z["cov9"])
+    solver.set_human_constraints(hc_rows(z["hc"]))
+    if with_corr:
+        solver.set_correspondences(z["pair_src"], z["pair_tgt"], z["match_offset"], z["src_idx"].astype(np.int32),
+                                   z["tgt_idx"].astype(np.int32))
+    return solver
+
+
+def _check(solver, z, lin_rtol, matcher):
+    if matcher is not None:
+        matcher(solver, z)
+        got = solver.get_correspondences()
+        for a, key in zip(got, ("pair_src", "pair_tgt", "match_offset", "src_idx", "tgt_idx")):
+            assert np.array_equal(a, z[key].astype(a.dtype)), key
+    for mode in (0, 1, 2):
+        cost, g, pr, pj = solver.linearize(mode, z["init"], z["xlin"])
+        assert abs(cost - z["lin_cost_%d" % mode]) <= lin_rtol * abs(z["lin_cost_%d" % mode])
+        assert np.abs(g - z["lin_grad_%d" % mode]).max() <= lin_rtol * np.abs(z["lin_grad_%d" % mode]).max()
+        if mode:
+            assert np.abs(pr - z["lin_pair_r_%d" % mode]).max() <= lin_rtol * np.abs(z["lin_pair_r_%d" % mode]).max()
+            assert np.abs(pj - z["lin_pair_J_%d" % mode]).max() <= lin_rtol * np.abs(z["lin_pair_J_%d" % mode]).max()
+        poses, summ = solver.solve(mode, z["init"])
+        exp = z["solve_summary_%d" % mode]
+        assert [summ.termination, summ.iterations, summ.successful_steps, summ.num_residuals, summ.num_hc_residuals] == exp.tolist()
+        ec = z["solve_cost_%d" % mode]
+        assert abs(summ.initial_cost - ec[0]) <= 1e-9 * ec[0] and abs(summ.final_cost - ec[1]) <= 1e-7 * ec[1]
+        assert np.abs(poses[:, :2] - z["solve_poses_%d" % mode][:, :2]).max() <= POSE_TOL_M
+        assert np.abs(poses[:, 2] - z["solve_poses_%d" % mode][:, 2]).max() <= POSE_TOL_RAD
+
+
+def test_fixtures_exist():
+    assert len(GOLDEN) >= 3
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_oracle_reproduces_golden(path):
+    from oracle import hitl_oracle as O
+    z = np.load(path)
+    s = _load(O.OracleSolver(), z, with_corr=False)
+    _check(s, z, 1e-12, lambda sv, zz: sv.find_correspondences(zz["init"], int(zz["window"]), 0))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_hip_path_reproduces_golden(path):
+    import hitl_slam_amd as H
+    z = np.load(path)
+    s = _load(H.Solver(), z, with_corr=False)
+    _check(s, z, 1e-10, lambda sv, zz: sv.find_correspondences(zz["init"], int(zz["window"])))
+    s.close()
