@@ -21,7 +21,7 @@ constexpr int kNumScalars = 16;           // device scalar scratch (doubles)
 struct MapView {            // SoA robot-frame scans (JointOptimization.h:62-68)
   int n_poses;
   const int64_t* obs_off;   // n+1
-  const float* px; const float* py; const float* nx; const float* ny;
+  const float4* obs;        // (px, py, nx, ny) per observation: one 16-byte load per point
 };
 
 struct PairView {           // directed STF pose pairs, sorted by source pose
@@ -56,7 +56,7 @@ struct LinView {            // one linearisation (double buffered by the driver)
   double* Hband;              // n*(Wb+1)*9 : block (i, i+d) row-major
   double* g;                  // npad
   double* obblk;              // E*9 : block (lo, hi)
-  double* cost_pose;          // n
+  double* partials;           // assemble workgroups x 2 : (cost, max |g|) per workgroup
 };
 
 struct CrView {             // block-tridiagonal system + cyclic-reduction factors
@@ -71,25 +71,33 @@ struct CrView {             // block-tridiagonal system + cyclic-reduction facto
 
 // ---- kernel launchers (hitl_kernels.hip) -------------------------------------------------
 void launch_linearize_stf(hipStream_t st, const MapView& map, const PairView& pr, int max_scan,
-                          const double* x, float corr, float std_dev, double* pairRJ);
+                          const double* x, double2* cs /* n scratch */, float corr, float std_dev, double* pairRJ);
+void launch_pack_obs(hipStream_t st, int64_t n, const float* px, const float* py, const float* nx, const float* ny,
+                     float4* obs);
 void launch_assemble(hipStream_t st, const MapView& map, const PairView& pr, const FactorView& fv,
                      const double* x, const LinView& lin);
-// scalars[0] = cost, scalars[1] = max |g| over free entries
-void launch_reduce_lin(hipStream_t st, int n_poses, const LinView& lin, double* scalars);
+inline int assemble_blocks(int n_poses) { return (n_poses + 127) / 128; }
 void launch_jacobi_scale(hipStream_t st, int n_poses, int npad, int Wb, const double* Hband, int enable,
                          double* scale);
 void launch_build_system(hipStream_t st, int n_poses, int Wb, const LinView& lin, const double* scale,
                          double mu, double min_diag, double max_diag, const CrView& cr, double* rhs);
 void launch_cr_factor(hipStream_t st, const CrView& cr);
+// factorise and solve M x = w in one pass (w is destroyed)
+void launch_cr_factor_solve(hipStream_t st, const CrView& cr, double* w, double* x);
 // x = M^{-1} w   (w is destroyed)
 void launch_cr_solve(hipStream_t st, const CrView& cr, double* w, double* x);
 // y = (S H S [+ D^2]) v ; damping added when mu > 0
 void launch_spmv(hipStream_t st, int n_poses, int npad, const FactorView& fv, const LinView& lin,
                  const double* scale, double mu, double min_diag, double max_diag, const double* v, double* y);
-// out[0] = dt.rhs, out[1] = dt.q, out[2] = sum (s*dt)^2 (free), out[3] = sum x^2 (free), out[4] = #non-finite
-void launch_step_scalars(hipStream_t st, int n3, const double* dt, const double* rhs, const double* q,
-                         const double* scale, const double* x, double* out);
-void launch_candidate(hipStream_t st, int n3, const double* x, const double* scale, const double* dt, double* xc);
+int spmv_blocks(int npad);
+// r = rhs - (S H S + D^2) v ; partials[blk*8 + 0,1] = (r.r, rhs.rhs) per workgroup
+void launch_spmv_residual(hipStream_t st, int n_poses, int npad, const FactorView& fv, const LinView& lin,
+                          const double* scale, double mu, double min_diag, double max_diag, const double* v,
+                          const double* rhs, double* r_out, double* partials);
+// q = (S H S) dt ; xc = x + s*dt ; partials[blk*8 + 2..6] = (dt.rhs, dt.q, |s dt|^2, |x|^2, #non-finite)
+void launch_spmv_step(hipStream_t st, int n_poses, int npad, const FactorView& fv, const LinView& lin,
+                      const double* scale, const double* dt, const double* rhs, const double* x, double* q, double* xc,
+                      double* partials);
 // out[k] = a_k . b_k for k < ndots (<= 4)
 void launch_dots(hipStream_t st, int n, int ndots, const double* const* a, const double* const* b, double* out);
 // y = alpha*x + beta*y

@@ -27,18 +27,69 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // ===========================================================================================
-// linearize_stf: one workgroup per SOURCE pose (its scan staged once in LDS), one wave per
-// directed pair (i -> j), lanes stride the pair's matches; 10 sums reduced by wave shuffles.
+// linearize_stf: one workgroup per SOURCE pose (its scan staged once in LDS as float4), one
+// wave per directed pair (i -> j), lanes stride the pair's matches.
+//
+// All per-match arithmetic is done in the SOURCE pose's frame: with R01 = R0^T R1 and
+// t01 = R0^T (t1 - t0),   u = R01 p1,  w = u + t01,  q = w - p0  (= R0^T delta),  n1' = R01 n1,
+//   e0/k = n0 . q                      e1/k = n1' . q
+//   d(e0/k)/dtheta0 = cross(n0, w)     d(e0/k)/dtheta1 = -cross(n0, u)
+//   d(e1/k)/dtheta0 = cross(n1', p0)   d(e1/k)/dtheta1 = cross(n1', t01 - p0)
+// (identical to SURVEY.md A.2 after rotating by R0^T; cross(a,b) = ax*by - ay*bx), and the
+// translation partials -+k R0 n0, -+k R0 n1' are rotated once per pair after the reduction.
+// 38 fp64 operations per match instead of ~110 for the world-frame form.
+//
+// The 10 sums are reduced with a reduce-scatter butterfly (17 64-bit shuffles per pair
+// instead of 60): at each step a lane keeps half of its values and ships the other half.
+//
 // blockIdx -> pose mapping keeps consecutive poses on one XCD (blocks b and b+8 share an
 // XCD) so the target scans i+-1..W, which the neighbouring workgroups stage as THEIR source,
 // are served from that XCD's L2.
 // ===========================================================================================
-constexpr int kStfBlock = 256;
+constexpr int kStfBlock = 192;
 
-__global__ __launch_bounds__(kStfBlock) void k_linearize_stf(MapView map, PairView pr, int chunk, int lds_cap,
-                                                              const double* __restrict__ x, double corr, double sd,
-                                                              double* __restrict__ pairRJ) {
-  extern __shared__ float s_scan[];  // [4][lds_cap] : px, py, nx, ny of the source scan
+__device__ __forceinline__ double readlane_f64(double v, int src_lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
+
+// v[0..2h) -> v[0..h): lanes with bit `mask` set keep the upper half
+#define HITL_XSTEP(mask, h)                                        \
+  {                                                                \
+    const bool up = (lane & (mask)) != 0;                          \
+    _Pragma("unroll") for (int q_ = 0; q_ < (h); ++q_) {           \
+      const double send_ = up ? v[q_] : v[q_ + (h)];               \
+      const double keep_ = up ? v[q_ + (h)] : v[q_];               \
+      v[q_] = keep_ + __shfl_xor(send_, (mask), WAVE);             \
+    }                                                              \
+  }
+
+constexpr int kStfSub = 32;     // lanes per directed pair: two pairs per wave
+
+// per-pose (cos theta, sin theta), computed once per linearisation instead of per pair
+__global__ void k_pose_trig(int n, const double* __restrict__ x, double2* __restrict__ cs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s, c;
+  sincos(x[3 * i + 2], &s, &c);
+  cs[i] = make_double2(c, s);
+}
+
+// Tuning notes (MI355X, C4 workload, rocprofv3 PMC; see DESIGN.md "k_linearize_stf"):
+//  * 2 matches per lane in flight at <= 80 VGPRs (6 waves/SIMD) beats deeper unrolling at lower
+//    occupancy; staging the target scans in LDS too (50 KB/workgroup) or software-pipelining the
+//    gathers by hand were both slower (LDS-limited occupancy / register spills).
+//  * VALU and TA are each ~55 % busy: the kernel is balanced between fp64 issue and L1/L2
+//    gather handling, at 2x the HBM floor of its compulsory bytes.
+constexpr int kStfUnroll = 2;
+
+template <bool USE_LDS>
+__global__ __launch_bounds__(kStfBlock, 6) void k_linearize_stf(MapView map, PairView pr, int chunk, int lds_cap,
+                                                                 const double* __restrict__ x,
+                                                                 const double2* __restrict__ cs, double corr, double sd,
+                                                                 double* __restrict__ pairRJ) {
+  extern __shared__ float4 s_scan[];  // [lds_cap] : (px, py, nx, ny) of the source scan
   const int b = blockIdx.x;
   const int idx = b >> 3;
   const int i = (b & 7) * chunk + idx;
@@ -47,79 +98,128 @@ __global__ __launch_bounds__(kStfBlock) void k_linearize_stf(MapView map, PairVi
   if (p_begin == p_end) return;
   const int64_t oi = map.obs_off[i];
   const int mi = (int)(map.obs_off[i + 1] - oi);
-  const bool use_lds = (lds_cap > 0) && (mi <= lds_cap);
-  if (use_lds) {
-    for (int k = threadIdx.x; k < mi; k += kStfBlock) {
-      s_scan[k] = map.px[oi + k];
-      s_scan[lds_cap + k] = map.py[oi + k];
-      s_scan[2 * lds_cap + k] = map.nx[oi + k];
-      s_scan[3 * lds_cap + k] = map.ny[oi + k];
-    }
+  if (USE_LDS) {
+    for (int k = threadIdx.x; k < mi; k += kStfBlock) s_scan[k] = map.obs[oi + k];
+    __syncthreads();
   }
-  __syncthreads();
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const double xi = x[3 * i], yi = x[3 * i + 1], ti = x[3 * i + 2];
-  double s0, c0;
-  sincos(ti, &s0, &c0);
+  const int lane = threadIdx.x & 63;
+  const int sub = threadIdx.x / kStfSub;        // pair slot of this half-wave within the workgroup
+  const int hl = threadIdx.x & (kStfSub - 1);   // lane within the half-wave
+  const double xi = x[3 * i], yi = x[3 * i + 1];
+  const double2 cs0 = cs[i];
+  const double c0 = cs0.x, s0 = cs0.y;
   const double kf = corr / sd;
-  for (int p = p_begin + wave; p < p_end; p += kStfBlock / WAVE) {
-    const int j = pr.pair_tgt[p];
-    const int64_t oj = map.obs_off[j];
-    const double xj = x[3 * j], yj = x[3 * j + 1], tj = x[3 * j + 2];
-    double s1, c1;
-    sincos(tj, &s1, &c1);
-    const int64_t m_begin = pr.match_off[p], m_end = pr.match_off[p + 1];
-    double S0 = 0, A0x = 0, A0y = 0, T00 = 0, T01 = 0;
-    double S1 = 0, A1x = 0, A1y = 0, T10 = 0, T11 = 0;
-    for (int64_t m = m_begin + lane; m < m_end; m += WAVE) {
-      const uint32_t u = pr.matches[m];
-      const int k0 = (int)(u & 0xffffu), k1 = (int)(u >> 16);
-      float ax, ay, anx, any;
-      if (use_lds) {
-        ax = s_scan[k0]; ay = s_scan[lds_cap + k0]; anx = s_scan[2 * lds_cap + k0]; any = s_scan[3 * lds_cap + k0];
-      } else {
-        ax = map.px[oi + k0]; ay = map.py[oi + k0]; anx = map.nx[oi + k0]; any = map.ny[oi + k0];
+  const float4* __restrict__ src_g = map.obs + oi;
+  const uint32_t* __restrict__ mt = pr.matches;
+  constexpr int kSlots = kStfBlock / kStfSub;
+  for (int pb = p_begin; pb < p_end; pb += kSlots) {   // workgroup-uniform trip count
+    const int p = pb + sub;
+    const bool live = p < p_end;
+    const int pc = live ? p : p_begin;
+    const int j = pr.pair_tgt[pc];
+    const float4* __restrict__ tgt_g = map.obs + map.obs_off[j];
+    const double ddx = x[3 * j] - xi, ddy = x[3 * j + 1] - yi;
+    const double2 cs1 = cs[j];
+    const double cR = c0 * cs1.x + s0 * cs1.y, sR = c0 * cs1.y - s0 * cs1.x;   // R01 = R0^T R1
+    const double t01x = c0 * ddx + s0 * ddy, t01y = c0 * ddy - s0 * ddx;       // R0^T (t1 - t0)
+    const int64_t m_begin = pr.match_off[pc];
+    const int64_t m_end = live ? pr.match_off[pc + 1] : m_begin;
+    // 8 running sums; the two remaining theta partials follow from them after the reduction:
+    //   sum e0 cross(n0, w)        = -T01 + cross(A0, t01)     (w = u + t01)
+    //   sum e1 cross(n1', t01-p0)  = cross(A1, t01) - T10
+    double S0 = 0, A0x = 0, A0y = 0, T01 = 0;
+    double S1 = 0, A1x = 0, A1y = 0, T10 = 0;
+    for (int64_t m = m_begin + hl; m < m_end; m += kStfSub * kStfUnroll) {
+      uint32_t uu[kStfUnroll];
+      float4 av[kStfUnroll], tv[kStfUnroll];
+#pragma unroll
+      for (int q = 0; q < kStfUnroll; ++q) {
+        const int64_t mq = m + (int64_t)q * kStfSub;
+        uu[q] = mt[mq < m_end ? mq : m];               // tail lanes re-read a valid entry, weighted 0 below
       }
-      const float bx = map.px[oj + k1], by = map.py[oj + k1], bnx = map.nx[oj + k1], bny = map.ny[oj + k1];
-      const double rp0x = c0 * ax - s0 * ay, rp0y = s0 * ax + c0 * ay;     // R0 p0
-      const double rp1x = c1 * bx - s1 * by, rp1y = s1 * bx + c1 * by;     // R1 p1
-      const double m0x = c0 * anx - s0 * any, m0y = s0 * anx + c0 * any;   // R0 n0
-      const double m1x = c1 * bnx - s1 * bny, m1y = s1 * bnx + c1 * bny;   // R1 n1
-      const double dx = (rp1x + xj) - (rp0x + xi), dy = (rp1y + yj) - (rp0y + yi);
-      const double e0 = (m0x * dx + m0y * dy) * corr / sd;
-      const double e1 = (m1x * dx + m1y * dy) * corr / sd;
-      // theta partials divided by k; perp(v) = (-vy, vx)
-      const double d00 = (-m0y * dx + m0x * dy) - (m0y * rp0x - m0x * rp0y);
-      const double d01 = (m0y * rp1x - m0x * rp1y);
-      const double d10 = -(m1y * rp0x - m1x * rp0y);
-      const double d11 = (-m1y * dx + m1x * dy) + (m1y * rp1x - m1x * rp1y);
-      S0 += e0 * e0; A0x += e0 * m0x; A0y += e0 * m0y; T00 += e0 * d00; T01 += e0 * d01;
-      S1 += e1 * e1; A1x += e1 * m1x; A1y += e1 * m1y; T10 += e1 * d10; T11 += e1 * d11;
+#pragma unroll
+      for (int q = 0; q < kStfUnroll; ++q) {
+        const int k0 = (int)(uu[q] & 0xffffu), k1 = (int)(uu[q] >> 16);
+        av[q] = USE_LDS ? s_scan[k0] : src_g[k0];
+        tv[q] = tgt_g[k1];
+      }
+#pragma unroll
+      for (int q = 0; q < kStfUnroll; ++q) {
+        const double wgt = (m + (int64_t)q * kStfSub < m_end) ? 1.0 : 0.0;
+        const double ax = av[q].x, ay = av[q].y, anx = av[q].z, any = av[q].w;
+        const double bx = tv[q].x, by = tv[q].y, bnx = tv[q].z, bny = tv[q].w;
+        const double ux = cR * bx - sR * by, uy = sR * bx + cR * by;        // u = R01 p1
+        const double mx = cR * bnx - sR * bny, my = sR * bnx + cR * bny;    // n1' = R01 n1
+        const double qx = (ux + t01x) - ax, qy = (uy + t01y) - ay;          // q = R0^T delta
+        const double e0 = wgt * (anx * qx + any * qy);                      // e0 / k
+        const double e1 = wgt * (mx * qx + my * qy);                        // e1 / k
+        const double d01 = any * ux - anx * uy;                             // -cross(n0, u)
+        const double d10 = mx * ay - my * ax;                               //  cross(n1', p0)
+        S0 += e0 * e0; A0x += e0 * anx; A0y += e0 * any; T01 += e0 * d01;
+        S1 += e1 * e1; A1x += e1 * mx; A1y += e1 * my; T10 += e1 * d10;
+      }
     }
-    S0 = wave_sum(S0); A0x = wave_sum(A0x); A0y = wave_sum(A0y); T00 = wave_sum(T00); T01 = wave_sum(T01);
-    S1 = wave_sum(S1); A1x = wave_sum(A1x); A1y = wave_sum(A1y); T10 = wave_sum(T10); T11 = wave_sum(T11);
-    if (lane == 0) {
+    // reduce-scatter over the 32 lanes of this pair: 8 64-bit shuffles for both pairs of the wave
+    double v[8] = {S0, A0x, A0y, T01, S1, A1x, A1y, T10};
+    HITL_XSTEP(16, 4)
+    HITL_XSTEP(8, 2)
+    HITL_XSTEP(4, 1)
+    double tot = v[0];
+    tot += __shfl_xor(tot, 2, WAVE);
+    tot += __shfl_xor(tot, 1, WAVE);
+    // lane base + 4*id now holds the pair total of value id (base = 0 or 32)
+    const bool hi = (lane & 32) != 0;
+#define HITL_PICK(id) (hi ? readlane_f64(tot, 32 + 4 * (id)) : readlane_f64(tot, 4 * (id)))
+    S0 = HITL_PICK(0); A0x = HITL_PICK(1); A0y = HITL_PICK(2); T01 = HITL_PICK(3);
+    S1 = HITL_PICK(4); A1x = HITL_PICK(5); A1y = HITL_PICK(6); T10 = HITL_PICK(7);
+#undef HITL_PICK
+    const double T00 = (A0x * t01y - A0y * t01x) - T01;
+    const double T11 = (A1x * t01y - A1y * t01x) - T10;
+    if (hl == 0 && live) {
       const double dn = (double)(m_end - m_begin);
+      const double inv_n = 1.0 / dn;
       double* o = pairRJ + (size_t)kPairRJ * p;
-      const double r0 = (S0 != 0.0) ? sqrt(S0 / dn) : 0.0;   // residual_functors.h:822-827
-      const double r1 = (S1 != 0.0) ? sqrt(S1 / dn) : 0.0;
-      const double f0 = (S0 != 0.0) ? kf / (dn * r0) : 0.0;
-      const double f1 = (S1 != 0.0) ? kf / (dn * r1) : 0.0;
+      // sums are of e/k: r = k sqrt(S/n) (residual_functors.h:822-827); dr/dq = k^2 (sum e' de')/(n r)
+      //                                                                       = k (sum e' de') / (n sqrt(S/n))
+      const double a0 = S0 * inv_n, a1 = S1 * inv_n;
+      const double i0 = (S0 != 0.0) ? rsqrt(a0) : 0.0, i1 = (S1 != 0.0) ? rsqrt(a1) : 0.0;
+      const double r0 = kf * a0 * i0, r1 = kf * a1 * i1;
+      const double f0 = kf * inv_n * i0, f1 = kf * inv_n * i1;
+      const double g0x = c0 * A0x - s0 * A0y, g0y = s0 * A0x + c0 * A0y;   // R0 * sum e0' n0
+      const double g1x = c0 * A1x - s0 * A1y, g1y = s0 * A1x + c0 * A1y;   // R0 * sum e1' n1'
       o[0] = r0; o[1] = r1;
-      o[2] = -f0 * A0x; o[3] = -f0 * A0y; o[4] = f0 * T00; o[5] = f0 * A0x; o[6] = f0 * A0y; o[7] = f0 * T01;
-      o[8] = -f1 * A1x; o[9] = -f1 * A1y; o[10] = f1 * T10; o[11] = f1 * A1x; o[12] = f1 * A1y; o[13] = f1 * T11;
+      o[2] = -f0 * g0x; o[3] = -f0 * g0y; o[4] = f0 * T00; o[5] = f0 * g0x; o[6] = f0 * g0y; o[7] = f0 * T01;
+      o[8] = -f1 * g1x; o[9] = -f1 * g1y; o[10] = f1 * T10; o[11] = f1 * g1x; o[12] = f1 * g1y; o[13] = f1 * T11;
     }
   }
 }
 
 void launch_linearize_stf(hipStream_t st, const MapView& map, const PairView& pr, int max_scan, const double* x,
-                          float corr, float std_dev, double* pairRJ) {
+                          double2* cs, float corr, float std_dev, double* pairRJ) {
   if (pr.n_pairs == 0) return;
   const int chunk = (map.n_poses + 7) / 8;
   int lds_cap = (max_scan + 63) & ~63;
   if ((size_t)lds_cap * 16 > 64 * 1024) lds_cap = 0;  // oversized scans read the source from global memory
-  hipLaunchKernelGGL(k_linearize_stf, dim3(8 * chunk), dim3(kStfBlock), (size_t)lds_cap * 16, st, map, pr, chunk,
-                     lds_cap, x, (double)corr, (double)std_dev, pairRJ);
+  hipLaunchKernelGGL(k_pose_trig, dim3((map.n_poses + 255) / 256), dim3(256), 0, st, map.n_poses, x, cs);
+  if (lds_cap > 0)
+    hipLaunchKernelGGL(k_linearize_stf<true>, dim3(8 * chunk), dim3(kStfBlock), (size_t)lds_cap * 16, st, map, pr, chunk,
+                       lds_cap, x, cs, (double)corr, (double)std_dev, pairRJ);
+  else
+    hipLaunchKernelGGL(k_linearize_stf<false>, dim3(8 * chunk), dim3(kStfBlock), 0, st, map, pr, chunk, 0, x, cs,
+                       (double)corr, (double)std_dev, pairRJ);
+}
+
+// SoA (the caller's layout, JointOptimization.h:62-68) -> device-resident float4 per observation
+__global__ void k_pack_obs(int64_t n, const float* __restrict__ px, const float* __restrict__ py,
+                           const float* __restrict__ nx, const float* __restrict__ ny, float4* __restrict__ obs) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) obs[t] = make_float4(px[t], py[t], nx[t], ny[t]);
+}
+
+void launch_pack_obs(hipStream_t st, int64_t n, const float* px, const float* py, const float* nx, const float* ny,
+                     float4* obs) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_pack_obs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, px, py, nx, ny, obs);
 }
 
 // ===========================================================================================
@@ -156,7 +256,8 @@ __global__ __launch_bounds__(128) void k_assemble(MapView map, PairView pr, Fact
                                                    LinView lin) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = map.n_poses;
-  if (i >= n) return;
+  double pose_cost = 0.0, pose_gmax = 0.0;
+  if (i < n) {
   const int Wb = fv.band_poses;
   double Hd[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   double gi[3] = {0, 0, 0};
@@ -244,7 +345,9 @@ __global__ __launch_bounds__(128) void k_assemble(MapView map, PairView pr, Fact
 #pragma unroll
   for (int q = 0; q < 9; ++q) Hrow[q] = Hd[q];
   lin.g[3 * i] = gi[0]; lin.g[3 * i + 1] = gi[1]; lin.g[3 * i + 2] = gi[2];
-  lin.cost_pose[i] = cost;
+  pose_cost = cost;
+  pose_gmax = fmax(fabs(gi[0]), fmax(fabs(gi[1]), fabs(gi[2])));
+  if (gi[0] != gi[0] || gi[1] != gi[1] || gi[2] != gi[2]) pose_gmax = gi[0] + gi[1] + gi[2];  // NaN propagates
   for (int d = 1; d <= Wb; ++d) {
     double blk[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (i > 0 && i + d < n) {
@@ -273,6 +376,20 @@ __global__ __launch_bounds__(128) void k_assemble(MapView map, PairView pr, Fact
     }
 #pragma unroll
     for (int q = 0; q < 9; ++q) Hrow[d * 9 + q] = blk[q];
+  }
+  }  // i < n
+  // per-workgroup partials (fixed order => bit-reproducible); the host adds the few hundred partials
+  __shared__ double sm_c[2], sm_g[2];
+  double c = wave_sum(pose_cost), gm = pose_gmax;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) { const double o = __shfl_xor(gm, m, WAVE); gm = (o > gm || o != o) ? o : gm; }
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sm_c[wv] = c; sm_g[wv] = gm; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double g1 = sm_g[1];
+    lin.partials[2 * blockIdx.x] = sm_c[0] + sm_c[1];
+    lin.partials[2 * blockIdx.x + 1] = (g1 > sm_g[0] || g1 != g1) ? g1 : sm_g[0];
   }
 }
 
@@ -338,23 +455,6 @@ __device__ __forceinline__ double block_max(double v, double* sm) {
   if (threadIdx.x == 0) sm[0] = t;
   __syncthreads();
   return sm[0];
-}
-
-__global__ __launch_bounds__(kRedBlock) void k_reduce_lin(int n_poses, LinView lin, double* scalars) {
-  __shared__ double sm[kRedBlock / WAVE];
-  double c = 0.0, gm = 0.0;
-  for (int i = threadIdx.x; i < n_poses; i += kRedBlock) c += lin.cost_pose[i];
-  for (int a = 3 + threadIdx.x; a < 3 * n_poses; a += kRedBlock) {
-    const double v = fabs(lin.g[a]);
-    gm = (v > gm || v != v) ? v : gm;  // NaN propagates
-  }
-  const double cs = block_sum(c, sm);
-  const double gmx = block_max(gm, sm);
-  if (threadIdx.x == 0) { scalars[0] = cs; scalars[1] = gmx; }
-}
-
-void launch_reduce_lin(hipStream_t st, int n_poses, const LinView& lin, double* scalars) {
-  hipLaunchKernelGGL(k_reduce_lin, dim3(1), dim3(kRedBlock), 0, st, n_poses, lin, scalars);
 }
 
 __global__ void k_jacobi_scale(int n_poses, int npad, int Wb, const double* __restrict__ Hband, int enable,
@@ -497,8 +597,10 @@ __global__ __launch_bounds__(WAVE) void k_cr_eliminate(CrView cr, int s) {
   }
 }
 
+// With w != nullptr the right-hand side rides along (w_j -= Gr[k1]^T w_k1 + Gl[k2]^T w_k2), which
+// saves the separate forward sweep when a factorisation is followed by exactly one solve.
 template <int B>
-__global__ __launch_bounds__(WAVE) void k_cr_update(CrView cr, int s) {
+__global__ __launch_bounds__(WAVE) void k_cr_update(CrView cr, int s, double* __restrict__ w) {
   __shared__ double sLj[B * B], sG[B * B], sL2[B * B];
   constexpr int NE = (B * B + WAVE - 1) / WAVE;
   const int j = 2 * s * blockIdx.x;
@@ -511,10 +613,17 @@ __global__ __launch_bounds__(WAVE) void k_cr_update(CrView cr, int s) {
     const int e = threadIdx.x + it * WAVE;
     acc[it] = (e < B * B) ? cr.D[off + e] : 0.0;
   }
+  const bool do_w = (w != nullptr) && ((int)threadIdx.x < B);
+  double wacc = do_w ? w[(size_t)j * B + threadIdx.x] : 0.0;
   if (k1 >= 0) {
     lds_load<B>(sLj, cr.L + off);
     lds_load<B>(sG, cr.Gr + (size_t)k1 * B * B);
     __syncthreads();
+    if (do_w) {
+      const double* wk = w + (size_t)k1 * B;
+#pragma unroll
+      for (int r = 0; r < B; ++r) wacc -= sG[r * B + threadIdx.x] * wk[r];
+    }
 #pragma unroll
     for (int it = 0; it < NE; ++it) {
       const int e = threadIdx.x + it * WAVE;
@@ -545,6 +654,11 @@ __global__ __launch_bounds__(WAVE) void k_cr_update(CrView cr, int s) {
     lds_load<B>(sL2, cr.L + (size_t)k2 * B * B);
     lds_load<B>(sG, cr.Gl + (size_t)k2 * B * B);
     __syncthreads();
+    if (do_w) {
+      const double* wk = w + (size_t)k2 * B;
+#pragma unroll
+      for (int r = 0; r < B; ++r) wacc -= sG[r * B + threadIdx.x] * wk[r];
+    }
 #pragma unroll
     for (int it = 0; it < NE; ++it) {
       const int e = threadIdx.x + it * WAVE;
@@ -557,6 +671,7 @@ __global__ __launch_bounds__(WAVE) void k_cr_update(CrView cr, int s) {
       }
     }
   }
+  if (do_w) w[(size_t)j * B + threadIdx.x] = wacc;
 #pragma unroll
   for (int it = 0; it < NE; ++it) {
     const int e = threadIdx.x + it * WAVE;
@@ -629,14 +744,26 @@ __global__ void k_cr_root_solve(CrView cr, const double* __restrict__ w, double*
 }
 
 template <int B>
-static void cr_factor_t(hipStream_t st, const CrView& cr) {
+static void cr_factor_t(hipStream_t st, const CrView& cr, double* w) {
   for (int s = 1; s < cr.nsb; s *= 2) {
     const int n_elim = (cr.nsb - s + 2 * s - 1) / (2 * s);
     const int n_surv = (cr.nsb + 2 * s - 1) / (2 * s);
     hipLaunchKernelGGL(k_cr_eliminate<B>, dim3(n_elim), dim3(WAVE), 0, st, cr, s);
-    hipLaunchKernelGGL(k_cr_update<B>, dim3(n_surv), dim3(WAVE), 0, st, cr, s);
+    hipLaunchKernelGGL(k_cr_update<B>, dim3(n_surv), dim3(WAVE), 0, st, cr, s, w);
   }
   hipLaunchKernelGGL(k_cr_root<B>, dim3(1), dim3(WAVE), 0, st, cr);
+}
+
+// back substitution only (the forward sweep already happened inside cr_factor_t(.., w))
+template <int B>
+static void cr_back_t(hipStream_t st, const CrView& cr, const double* w, double* x) {
+  int s_last = 0;
+  for (int s = 1; s < cr.nsb; s *= 2) s_last = s;
+  hipLaunchKernelGGL(k_cr_root_solve<B>, dim3(1), dim3(WAVE), 0, st, cr, w, x);
+  for (int s = s_last; s >= 1; s /= 2) {
+    const int n_elim = (cr.nsb - s + 2 * s - 1) / (2 * s);
+    hipLaunchKernelGGL(k_cr_backward<B>, dim3((n_elim * B + 127) / 128), dim3(128), 0, st, cr, s, w, x);
+  }
 }
 
 template <int B>
@@ -656,10 +783,19 @@ static void cr_solve_t(hipStream_t st, const CrView& cr, double* w, double* x) {
 
 void launch_cr_factor(hipStream_t st, const CrView& cr) {
   switch (cr.B) {
-    case 3: cr_factor_t<3>(st, cr); break;
-    case 6: cr_factor_t<6>(st, cr); break;
-    case 9: cr_factor_t<9>(st, cr); break;
-    default: cr_factor_t<12>(st, cr); break;
+    case 3: cr_factor_t<3>(st, cr, nullptr); break;
+    case 6: cr_factor_t<6>(st, cr, nullptr); break;
+    case 9: cr_factor_t<9>(st, cr, nullptr); break;
+    default: cr_factor_t<12>(st, cr, nullptr); break;
+  }
+}
+
+void launch_cr_factor_solve(hipStream_t st, const CrView& cr, double* w, double* x) {
+  switch (cr.B) {
+    case 3: cr_factor_t<3>(st, cr, w); cr_back_t<3>(st, cr, w, x); break;
+    case 6: cr_factor_t<6>(st, cr, w); cr_back_t<6>(st, cr, w, x); break;
+    case 9: cr_factor_t<9>(st, cr, w); cr_back_t<9>(st, cr, w, x); break;
+    default: cr_factor_t<12>(st, cr, w); cr_back_t<12>(st, cr, w, x); break;
   }
 }
 
@@ -673,107 +809,146 @@ void launch_cr_solve(hipStream_t st, const CrView& cr, double* w, double* x) {
 }
 
 // ===========================================================================================
-// y = (S H S [+ D^2]) v : band blocks (both triangles) + off-band blocks, one thread per pose
+// y = (S H S [+ D^2]) v : band blocks (both triangles) + off-band blocks, one thread per pose.
+// MODE 0: plain product (PCG).
+// MODE 1: residual check after the cyclic-reduction solve: y -> r = rhs - A v, per-workgroup
+//         partials (r.r, rhs.rhs) in slots 0,1 of the 8-wide record.
+// MODE 2: trust-region step bookkeeping, fused: q = (S H S) v (no damping), partials
+//         (v.rhs, v.q, sum (s v)^2 over free poses, sum x^2 over free poses, #non-finite) in
+//         slots 2..6, and the candidate state xc = x + s*v.
+// The host adds the few hundred per-workgroup partials in index order (bit-reproducible).
 // ===========================================================================================
+struct SpmvAux {
+  const double* rhs;   // MODE 1, 2
+  double* r_out;       // MODE 1
+  const double* x;     // MODE 2
+  double* xc;          // MODE 2
+  double* partials;    // MODE 1, 2 : [gridDim.x][8]
+};
+
+template <int MODE>
 __global__ __launch_bounds__(128) void k_spmv(int n_poses, int npad, FactorView fv, LinView lin,
                                                const double* __restrict__ scale, double mu, double min_diag,
-                                               double max_diag, const double* __restrict__ v, double* __restrict__ y) {
+                                               double max_diag, const double* __restrict__ v, double* __restrict__ y,
+                                               SpmvAux aux) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (3 * i >= npad) return;
-  if (i >= n_poses) {  // padding rows of the last super-block: identity
-    for (int c = 0; c < 3; ++c) if (3 * i + c < npad) y[3 * i + c] = v[3 * i + c];
-    return;
-  }
-  const int Wb = fv.band_poses, W1 = Wb + 1;
-  double acc[3] = {0, 0, 0};
-  const double* Hi = lin.Hband + (size_t)i * W1 * 9;
-  for (int d = 0; d <= Wb && i + d < n_poses; ++d) {
-    const double* blk = Hi + d * 9;
-    const int j = i + d;
-    const double v0 = scale[3 * j] * v[3 * j], v1 = scale[3 * j + 1] * v[3 * j + 1], v2 = scale[3 * j + 2] * v[3 * j + 2];
+  double part[5] = {0, 0, 0, 0, 0};
+  if (3 * i < npad) {
+    if (i >= n_poses) {  // padding rows of the last super-block: identity
+      for (int c = 0; c < 3; ++c) {
+        const int t = 3 * i + c;
+        if (t < npad) {
+          if (MODE == 0) y[t] = v[t];
+          if (MODE == 1) { const double r = aux.rhs[t] - v[t]; aux.r_out[t] = r; part[0] += r * r; part[1] += aux.rhs[t] * aux.rhs[t]; }
+          if (MODE == 2) y[t] = v[t];
+        }
+      }
+    } else {
+      const int Wb = fv.band_poses, W1 = Wb + 1;
+      double acc[3] = {0, 0, 0};
+      const double* Hi = lin.Hband + (size_t)i * W1 * 9;
+      for (int d = 0; d <= Wb && i + d < n_poses; ++d) {
+        const double* blk = Hi + d * 9;
+        const int j = i + d;
+        const double v0 = scale[3 * j] * v[3 * j], v1 = scale[3 * j + 1] * v[3 * j + 1], v2 = scale[3 * j + 2] * v[3 * j + 2];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) acc[a] += blk[a * 3] * v0 + blk[a * 3 + 1] * v1 + blk[a * 3 + 2] * v2;
-  }
-  for (int d = 1; d <= Wb && i - d >= 0; ++d) {
-    const int j = i - d;
-    const double* blk = lin.Hband + ((size_t)j * W1 + d) * 9;  // block (j, i), use transposed
-    const double v0 = scale[3 * j] * v[3 * j], v1 = scale[3 * j + 1] * v[3 * j + 1], v2 = scale[3 * j + 2] * v[3 * j + 2];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) acc[a] += blk[a] * v0 + blk[3 + a] * v1 + blk[6 + a] * v2;
-  }
-  if (fv.with_stf && fv.n_offband > 0) {
-    for (int e = fv.obadj_off[i]; e < fv.obadj_off[i + 1]; ++e) {
-      const int ent = fv.obadj_ent[e];
-      const int en = ent >> 1, tr = ent & 1;
-      const double* blk = lin.obblk + (size_t)en * 9;
-      const int j = tr ? fv.ob_lo[en] : fv.ob_hi[en];
-      const double v0 = scale[3 * j] * v[3 * j], v1 = scale[3 * j + 1] * v[3 * j + 1], v2 = scale[3 * j + 2] * v[3 * j + 2];
-      if (!tr) {
         for (int a = 0; a < 3; ++a) acc[a] += blk[a * 3] * v0 + blk[a * 3 + 1] * v1 + blk[a * 3 + 2] * v2;
-      } else {
+      }
+      for (int d = 1; d <= Wb && i - d >= 0; ++d) {
+        const int j = i - d;
+        const double* blk = lin.Hband + ((size_t)j * W1 + d) * 9;  // block (j, i), used transposed
+        const double v0 = scale[3 * j] * v[3 * j], v1 = scale[3 * j + 1] * v[3 * j + 1], v2 = scale[3 * j + 2] * v[3 * j + 2];
+#pragma unroll
         for (int a = 0; a < 3; ++a) acc[a] += blk[a] * v0 + blk[3 + a] * v1 + blk[6 + a] * v2;
+      }
+      if (fv.with_stf && fv.n_offband > 0) {
+        for (int e = fv.obadj_off[i]; e < fv.obadj_off[i + 1]; ++e) {
+          const int ent = fv.obadj_ent[e];
+          const int en = ent >> 1, tr = ent & 1;
+          const double* blk = lin.obblk + (size_t)en * 9;
+          const int j = tr ? fv.ob_lo[en] : fv.ob_hi[en];
+          const double v0 = scale[3 * j] * v[3 * j], v1 = scale[3 * j + 1] * v[3 * j + 1], v2 = scale[3 * j + 2] * v[3 * j + 2];
+          if (!tr) {
+            for (int a = 0; a < 3; ++a) acc[a] += blk[a * 3] * v0 + blk[a * 3 + 1] * v1 + blk[a * 3 + 2] * v2;
+          } else {
+            for (int a = 0; a < 3; ++a) acc[a] += blk[a] * v0 + blk[3 + a] * v1 + blk[6 + a] * v2;
+          }
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const int t = 3 * i + a;
+        const double sa = scale[t];
+        double r = sa * acc[a];
+        if (MODE != 2 && mu > 0.0 && i > 0) {
+          const double dg = sa * sa * Hi[a * 3 + a];
+          r += fmin(fmax(dg, min_diag), max_diag) / mu * v[t];
+        }
+        if (MODE == 0) y[t] = r;
+        if (MODE == 1) {
+          const double b = aux.rhs[t], res = b - r;
+          aux.r_out[t] = res;
+          part[0] += res * res; part[1] += b * b;
+        }
+        if (MODE == 2) {
+          const double vt = v[t];
+          y[t] = r;
+          part[0] += vt * aux.rhs[t];
+          part[1] += vt * r;
+          if (i > 0) {
+            const double dl = sa * vt, xt = aux.x[t];
+            part[2] += dl * dl; part[3] += xt * xt;
+            aux.xc[t] = xt + dl;
+          } else {
+            aux.xc[t] = aux.x[t];
+          }
+          if (!isfinite(vt)) part[4] += 1.0;
+        }
       }
     }
   }
+  if (MODE != 0) {
+    __shared__ double sm[2][5];
+    const int wv = threadIdx.x >> 6;
+    constexpr int NP = (MODE == 1) ? 2 : 5;
 #pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    const double sa = scale[3 * i + a];
-    double r = sa * acc[a];
-    if (mu > 0.0 && i > 0) {
-      const double dg = sa * sa * Hi[a * 3 + a];
-      r += fmin(fmax(dg, min_diag), max_diag) / mu * v[3 * i + a];
+    for (int k = 0; k < NP; ++k) {
+      const double t = wave_sum(part[k]);
+      if ((threadIdx.x & 63) == 0) sm[wv][k] = t;
     }
-    y[3 * i + a] = r;
+    __syncthreads();
+    if (threadIdx.x < NP) aux.partials[(size_t)blockIdx.x * 8 + (MODE == 1 ? 0 : 2) + threadIdx.x] = sm[0][threadIdx.x] + sm[1][threadIdx.x];
   }
 }
 
+int spmv_blocks(int npad) { return ((npad + 2) / 3 + 127) / 128; }
+
 void launch_spmv(hipStream_t st, int n_poses, int npad, const FactorView& fv, const LinView& lin, const double* scale,
                  double mu, double min_diag, double max_diag, const double* v, double* y) {
-  const int nthreads = (npad + 2) / 3;
-  hipLaunchKernelGGL(k_spmv, dim3((nthreads + 127) / 128), dim3(128), 0, st, n_poses, npad, fv, lin, scale, mu, min_diag,
-                     max_diag, v, y);
+  SpmvAux aux = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipLaunchKernelGGL(k_spmv<0>, dim3(spmv_blocks(npad)), dim3(128), 0, st, n_poses, npad, fv, lin, scale, mu, min_diag,
+                     max_diag, v, y, aux);
+}
+
+void launch_spmv_residual(hipStream_t st, int n_poses, int npad, const FactorView& fv, const LinView& lin,
+                          const double* scale, double mu, double min_diag, double max_diag, const double* v,
+                          const double* rhs, double* r_out, double* partials) {
+  SpmvAux aux = {rhs, r_out, nullptr, nullptr, partials};
+  hipLaunchKernelGGL(k_spmv<1>, dim3(spmv_blocks(npad)), dim3(128), 0, st, n_poses, npad, fv, lin, scale, mu, min_diag,
+                     max_diag, v, (double*)nullptr, aux);
+}
+
+void launch_spmv_step(hipStream_t st, int n_poses, int npad, const FactorView& fv, const LinView& lin,
+                      const double* scale, const double* dt, const double* rhs, const double* x, double* q, double* xc,
+                      double* partials) {
+  SpmvAux aux = {rhs, nullptr, x, xc, partials};
+  hipLaunchKernelGGL(k_spmv<2>, dim3(spmv_blocks(npad)), dim3(128), 0, st, n_poses, npad, fv, lin, scale, 0.0, 0.0, 0.0, dt,
+                     q, aux);
 }
 
 // ===========================================================================================
 // small vector kernels
 // ===========================================================================================
-__global__ __launch_bounds__(kRedBlock) void k_step_scalars(int n3, const double* __restrict__ dt,
-                                                            const double* __restrict__ rhs, const double* __restrict__ q,
-                                                            const double* __restrict__ scale, const double* __restrict__ x,
-                                                            double* out) {
-  __shared__ double sm[kRedBlock / WAVE];
-  double a = 0, b = 0, c = 0, d = 0, bad = 0;
-  for (int t = threadIdx.x; t < n3; t += kRedBlock) {
-    const double v = dt[t];
-    a += v * rhs[t];
-    b += v * q[t];
-    if (t >= 3) {
-      const double dl = scale[t] * v;
-      c += dl * dl;
-      d += x[t] * x[t];
-    }
-    if (!isfinite(v)) bad += 1.0;
-  }
-  a = block_sum(a, sm); b = block_sum(b, sm); c = block_sum(c, sm); d = block_sum(d, sm); bad = block_sum(bad, sm);
-  if (threadIdx.x == 0) { out[0] = a; out[1] = b; out[2] = c; out[3] = d; out[4] = bad; }
-}
-
-void launch_step_scalars(hipStream_t st, int n3, const double* dt, const double* rhs, const double* q,
-                         const double* scale, const double* x, double* out) {
-  hipLaunchKernelGGL(k_step_scalars, dim3(1), dim3(kRedBlock), 0, st, n3, dt, rhs, q, scale, x, out);
-}
-
-__global__ void k_candidate(int n3, const double* __restrict__ x, const double* __restrict__ scale,
-                            const double* __restrict__ dt, double* __restrict__ xc) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n3) return;
-  xc[t] = (t >= 3) ? x[t] + scale[t] * dt[t] : x[t];
-}
-
-void launch_candidate(hipStream_t st, int n3, const double* x, const double* scale, const double* dt, double* xc) {
-  hipLaunchKernelGGL(k_candidate, dim3((n3 + 255) / 256), dim3(256), 0, st, n3, x, scale, dt, xc);
-}
-
 struct DotArgs { const double* a[4]; const double* b[4]; };
 
 __global__ __launch_bounds__(kRedBlock) void k_dots(int n, int ndots, DotArgs args, double* out) {

@@ -41,8 +41,7 @@ __global__ __launch_bounds__(kMatchBlock) void k_match(MapView map, int chunk, i
     const int mj = (int)(map.obs_off[j + 1] - oj);
     __syncthreads();
     if (threadIdx.x == 0) s_pair_count = 0;
-    for (int t = threadIdx.x; t < mj; t += kMatchBlock)
-      s_tgt[t] = make_float4(map.px[oj + t], map.py[oj + t], map.nx[oj + t], map.ny[oj + t]);
+    for (int t = threadIdx.x; t < mj; t += kMatchBlock) s_tgt[t] = map.obs[oj + t];
     __syncthreads();
     const float* tf = cand_tf + ((size_t)i * slots + slot) * 8;
     const float m00 = tf[0], m01 = tf[1], m10 = tf[2], m11 = tf[3], tx = tf[4], ty = tf[5], cr = tf[6], sr = tf[7];
@@ -51,7 +50,8 @@ __global__ __launch_bounds__(kMatchBlock) void k_match(MapView map, int chunk, i
     for (int k = threadIdx.x; k < mi; k += kMatchBlock) {
       uint16_t res = 0xFFFFu;
       if ((k % mp.skip) == 0 && s_cnt[k] < mp.cap) {
-        const float ax = map.px[oi + k], ay = map.py[oi + k];
+        const float4 a = map.obs[oi + k];
+        const float ax = a.x, ay = a.y;
         const float qx = (m00 * ax + m01 * ay) + tx;
         const float qy = (m10 * ax + m11 * ay) + ty;
         float best = 3.402823466e+38f;
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(kMatchBlock) void k_match(MapView map, int chunk, i
           }
         }
         if (bi >= 0 && best < thr) {
-          const float anx = map.nx[oi + k], any = map.ny[oi + k];
+          const float anx = a.z, any = a.w;
           const float nqx = cr * anx - sr * any, nqy = sr * anx + cr * any;
           const float4 g = s_tgt[bi];
           const float cosang = g.z * nqx + g.w * nqy;

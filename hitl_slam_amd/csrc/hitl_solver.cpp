@@ -86,6 +86,9 @@ struct hitl_solver {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
   double* h_scalars = nullptr;  // pinned, kNumScalars
+  double* h_partials = nullptr; // pinned, h_partials_cap doubles
+  size_t h_partials_cap = 0;
+  DevArray<double> step_partials;   // spmv workgroups x 8
   DevArray<double> d_scalars;
 
   // ---- map ----
@@ -94,7 +97,8 @@ struct hitl_solver {
   int max_scan = 0;
   std::vector<int64_t> h_obs_off;
   DevArray<int64_t> obs_off;
-  DevArray<float> px, py, nx, ny, cov9;
+  DevArray<float4> obs;                        // (px, py, nx, ny) per observation
+  DevArray<float> cov9;
 
   // ---- human rows (sorted by constrained pose at solve time) ----
   std::vector<hitl_human_constraint_t> h_hc;
@@ -124,12 +128,13 @@ struct hitl_solver {
   int wb_Wb = 0, wb_n = 0, wb_pairs = -1, wb_offband = -1;
   int nsb = 0, B = 0, npad = 0;
   DevArray<double> x, xc, scale, rhs, dt, wv, qv, rv, zv, pv;
-  DevArray<double> pairRJ[2], Hband[2], gvec[2], obblk[2], cost_pose[2];
+  DevArray<double> pairRJ[2], Hband[2], gvec[2], obblk[2], lin_partials[2];
+  DevArray<double2> pose_cs;        // (cos, sin) of every pose at the state being linearised
   DevArray<double> crD, crL, crDinv, crGl, crGr;
 
   MapView map_view() const {
     MapView m;
-    m.n_poses = n; m.obs_off = obs_off.p; m.px = px.p; m.py = py.p; m.nx = nx.p; m.ny = ny.p;
+    m.n_poses = n; m.obs_off = obs_off.p; m.obs = obs.p;
     return m;
   }
   PairView pair_view() const {
@@ -140,7 +145,7 @@ struct hitl_solver {
   }
   LinView lin_view(int k) {
     LinView l;
-    l.pairRJ = pairRJ[k].p; l.Hband = Hband[k].p; l.g = gvec[k].p; l.obblk = obblk[k].p; l.cost_pose = cost_pose[k].p;
+    l.pairRJ = pairRJ[k].p; l.Hband = Hband[k].p; l.g = gvec[k].p; l.obblk = obblk[k].p; l.partials = lin_partials[k].p;
     return l;
   }
   CrView cr_view() {
@@ -151,12 +156,6 @@ struct hitl_solver {
 };
 
 namespace hitl {
-
-static int sync_scalars(hitl_solver* s, int count) {
-  HIP_TRY(hipMemcpyAsync(s->h_scalars, s->d_scalars.p, sizeof(double) * count, hipMemcpyDeviceToHost, s->stream));
-  HIP_TRY(hipStreamSynchronize(s->stream));
-  return HITL_OK;
-}
 
 // ---------------------------------------------------------------------------------------
 // derived pair structures (host, O(P)); called whenever the correspondence set changes
@@ -252,7 +251,18 @@ static int ensure_work(hitl_solver* s, int Wb) {
     TRY(s->gvec[k].resize(npad));
     if (fresh || s->wb_Wb != Wb) TRY(s->gvec[k].zero(s->stream));
     TRY(s->obblk[k].resize((size_t)std::max(s->n_offband, 1) * 9));
-    TRY(s->cost_pose[k].resize(n));
+    TRY(s->lin_partials[k].resize((size_t)assemble_blocks(n) * 2));
+  }
+  TRY(s->step_partials.resize((size_t)spmv_blocks(s->npad) * 8));
+  TRY(s->pose_cs.resize((size_t)n));
+  {
+    const size_t need = std::max<size_t>((size_t)assemble_blocks(n) * 2, (size_t)spmv_blocks(s->npad) * 8);
+    if (need > s->h_partials_cap) {
+      if (s->h_partials) (void)hipHostFree(s->h_partials);
+      s->h_partials = nullptr; s->h_partials_cap = 0;
+      HIP_TRY(hipHostMalloc((void**)&s->h_partials, need * sizeof(double)));
+      s->h_partials_cap = need;
+    }
   }
   const size_t bb = (size_t)s->nsb * s->B * s->B;
   TRY(s->crD.resize(bb)); TRY(s->crL.resize(bb)); TRY(s->crDinv.resize(bb)); TRY(s->crGl.resize(bb)); TRY(s->crGr.resize(bb));
@@ -353,14 +363,21 @@ static int run_linearize(hitl_solver* s, const FactorView& fv, const double* xde
   const LinView lv = s->lin_view(buf);
   HIP_TRY(hipEventRecord(s->ev0, st));
   if (fv.with_stf)
-    launch_linearize_stf(st, mv, pv, s->max_scan, xdev, s->opt.point_correlation_factor, s->opt.laser_std_dev, lv.pairRJ);
+    launch_linearize_stf(st, mv, pv, s->max_scan, xdev, s->pose_cs.p, s->opt.point_correlation_factor, s->opt.laser_std_dev, lv.pairRJ);
   HIP_TRY(hipEventRecord(s->ev1, st));
   launch_assemble(st, mv, pv, fv, xdev, lv);
-  launch_reduce_lin(st, s->n, lv, s->d_scalars.p);
   HIP_TRY(hipGetLastError());
-  TRY(sync_scalars(s, 2));
-  out->cost = s->h_scalars[0];
-  out->gmax = s->h_scalars[1];
+  const int nblk = assemble_blocks(s->n);
+  HIP_TRY(hipMemcpyAsync(s->h_partials, lv.partials, sizeof(double) * 2 * nblk, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  double cost = 0.0, gmax = 0.0;
+  for (int b = 0; b < nblk; ++b) {   // fixed order: bit-reproducible
+    cost += s->h_partials[2 * b];
+    const double g = s->h_partials[2 * b + 1];
+    if (g > gmax || g != g) gmax = g;
+  }
+  out->cost = cost;
+  out->gmax = gmax;
   out->stf_ms = 0.f;
   if (fv.with_stf) HIP_TRY(hipEventElapsedTime(&out->stf_ms, s->ev0, s->ev1));
   return HITL_OK;
@@ -391,37 +408,54 @@ static int prepare(hitl_solver* s, int mode, const float* poses_ref, FactorView*
 // factorisation of its in-band part.  With no off-band pose pairs the preconditioner IS the
 // matrix and the first iterate is the exact LM step (what Ceres' sparse Cholesky returns).
 // ---------------------------------------------------------------------------------------
-static int linear_solve(hitl_solver* s, const FactorView& fv, int buf, double mu, int* iters, bool* ok) {
+struct StepScalars { double dt_rhs, dt_q, step2, xn2, bad; };
+
+static int read_step_partials(hitl_solver* s, double* rr, double* bb, StepScalars* ss) {
+  const int nblk = spmv_blocks(s->npad);
+  HIP_TRY(hipMemcpyAsync(s->h_partials, s->step_partials.p, sizeof(double) * 8 * nblk, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (int b = 0; b < nblk; ++b)
+    for (int k = 0; k < 7; ++k) acc[k] += s->h_partials[8 * b + k];
+  if (rr) *rr = acc[0];
+  if (bb) *bb = acc[1];
+  if (ss) { ss->dt_rhs = acc[2]; ss->dt_q = acc[3]; ss->step2 = acc[4]; ss->xn2 = acc[5]; ss->bad = acc[6]; }
+  return HITL_OK;
+}
+
+// Solve (S H S + D^2) dt = rhs, then form the trust-region bookkeeping (model cost change
+// pieces, step norm, candidate state) -- one host synchronisation in the banded case.
+static int linear_solve_and_step(hitl_solver* s, const FactorView& fv, int buf, double mu, const double* xcur,
+                                 double* xcand, int* iters, bool* ok, StepScalars* ss) {
   hipStream_t st = s->stream;
   const LinView lv = s->lin_view(buf);
   const CrView cr = s->cr_view();
   const double mind = s->opt.min_lm_diagonal, maxd = s->opt.max_lm_diagonal;
   const int npad = s->npad;
+  const double tol = std::max(s->opt.linear_solver_tolerance, 1e-15);
   launch_build_system(st, s->n, fv.band_poses, lv, s->scale.p, mu, mind, maxd, cr, s->rhs.p);
-  launch_cr_factor(st, cr);
   launch_copy(st, npad, s->rhs.p, s->wv.p);
-  launch_cr_solve(st, cr, s->wv.p, s->dt.p);   // x0 = M^{-1} b
+  launch_cr_factor_solve(st, cr, s->wv.p, s->dt.p);   // x0 = M^{-1} b
   *iters = 1;
   *ok = true;
-  if (fv.n_offband == 0 && s->opt.linear_solver_tolerance <= 0.0) return HITL_OK;
-  // r = b - A x0
-  launch_spmv(st, s->n, npad, fv, lv, s->scale.p, mu, mind, maxd, s->dt.p, s->qv.p);
-  launch_copy(st, npad, s->rhs.p, s->rv.p);
-  launch_axpby(st, npad, -1.0, s->qv.p, 1.0, s->rv.p);
-  const double* da[4] = {s->rv.p, s->rhs.p, s->rv.p, s->rv.p};
-  const double* db[4] = {s->rv.p, s->rhs.p, s->rv.p, s->rv.p};
-  launch_dots(st, npad, 2, da, db, s->d_scalars.p + 8);
-  HIP_TRY(hipMemcpyAsync(s->h_scalars + 8, s->d_scalars.p + 8, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  double rr = s->h_scalars[8];
-  const double bb = s->h_scalars[9];
-  const double tol = std::max(s->opt.linear_solver_tolerance, 1e-15);
+  // r = b - A x0 (partials of r.r and b.b); banded systems: x0 is the exact step up to rounding
+  launch_spmv_residual(st, s->n, npad, fv, lv, s->scale.p, mu, mind, maxd, s->dt.p, s->rhs.p, s->rv.p, s->step_partials.p);
+  if (fv.n_offband == 0) {
+    launch_spmv_step(st, s->n, npad, fv, lv, s->scale.p, s->dt.p, s->rhs.p, xcur, s->qv.p, xcand, s->step_partials.p);
+    HIP_TRY(hipGetLastError());
+    double rr, bb;
+    TRY(read_step_partials(s, &rr, &bb, ss));
+    const double guard = std::max(tol, 1e-9);
+    if (!(rr == rr) || rr > guard * guard * bb) *ok = false;   // the factorisation broke down
+    return HITL_OK;
+  }
+  // off-band pose pairs present: PCG on the full matrix from x0, preconditioned by the band factorisation
+  double rr, bb;
+  TRY(read_step_partials(s, &rr, &bb, nullptr));
   const double target = tol * tol * bb;
   if (!(rr == rr)) { *ok = false; return HITL_OK; }
-  if (rr <= target || fv.n_offband == 0) return HITL_OK;  // banded system: x0 is exact up to rounding
-  // PCG from x0
   double rz_old = 0.0;
-  for (int it = 0; it < s->opt.max_linear_iterations; ++it) {
+  for (int it = 0; it < s->opt.max_linear_iterations && rr > target; ++it) {
     launch_copy(st, npad, s->rv.p, s->wv.p);
     launch_cr_solve(st, cr, s->wv.p, s->zv.p);
     const double* a1[4] = {s->rv.p, s->rv.p, s->rv.p, s->rv.p};
@@ -434,8 +468,8 @@ static int linear_solve(hitl_solver* s, const FactorView& fv, int buf, double mu
     else launch_axpby(st, npad, 1.0, s->zv.p, rz / rz_old, s->pv.p);
     rz_old = rz;
     launch_spmv(st, s->n, npad, fv, lv, s->scale.p, mu, mind, maxd, s->pv.p, s->qv.p);
-    const double* a2[4] = {s->pv.p, s->pv.p, s->pv.p, s->pv.p};
-    const double* b2[4] = {s->qv.p, s->qv.p, s->qv.p, s->qv.p};
+    const double* a2[4] = {s->pv.p, s->rv.p, s->pv.p, s->pv.p};
+    const double* b2[4] = {s->qv.p, s->rv.p, s->qv.p, s->qv.p};
     launch_dots(st, npad, 1, a2, b2, s->d_scalars.p + 8);
     HIP_TRY(hipMemcpyAsync(s->h_scalars + 8, s->d_scalars.p + 8, sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -451,8 +485,10 @@ static int linear_solve(hitl_solver* s, const FactorView& fv, int buf, double mu
     rr = s->h_scalars[8];
     ++*iters;
     if (!(rr == rr)) { *ok = false; return HITL_OK; }
-    if (rr <= target) break;
   }
+  launch_spmv_step(st, s->n, npad, fv, lv, s->scale.p, s->dt.p, s->rhs.p, xcur, s->qv.p, xcand, s->step_partials.p);
+  HIP_TRY(hipGetLastError());
+  TRY(read_step_partials(s, nullptr, nullptr, ss));
   return HITL_OK;
 }
 
@@ -506,24 +542,20 @@ static int lm_solve(hitl_solver* s, int mode, const float* poses_in, float* pose
     int lin_iters = 0;
     bool ok = true;
     HIP_TRY(hipEventRecord(s->ev2, st));
-    TRY(linear_solve(s, fv, cur, radius, &lin_iters, &ok));
+    StepScalars ss;
+    TRY(linear_solve_and_step(s, fv, cur, radius, xcur, xcand, &lin_iters, &ok, &ss));
     S.linear_iterations += lin_iters;
-    // model_cost_change = -dt.(S g) - 1/2 dt.(S H S) dt
-    const LinView lv = s->lin_view(cur);
-    launch_spmv(st, n, s->npad, fv, lv, s->scale.p, 0.0, 0.0, 0.0, s->dt.p, s->qv.p);
-    launch_step_scalars(st, n3, s->dt.p, s->rhs.p, s->qv.p, s->scale.p, xcur, s->d_scalars.p);
-    launch_candidate(st, n3, xcur, s->scale.p, s->dt.p, xcand);
     HIP_TRY(hipEventRecord(s->ev3, st));
-    HIP_TRY(hipGetLastError());
-    TRY(sync_scalars(s, 5));
+    HIP_TRY(hipEventSynchronize(s->ev3));
     {
       float ms = 0.f;
       HIP_TRY(hipEventElapsedTime(&ms, s->ev2, s->ev3));
       S.linear_solver_ms += ms;
     }
-    const double dt_rhs = s->h_scalars[0], dt_q = s->h_scalars[1], step2 = s->h_scalars[2], xn2 = s->h_scalars[3];
+    // model_cost_change = -dt.(S g) - 1/2 dt.(S H S) dt
+    const double dt_rhs = ss.dt_rhs, dt_q = ss.dt_q, step2 = ss.step2, xn2 = ss.xn2;
     const double mcc = dt_rhs - 0.5 * dt_q;  // rhs = -S g
-    if (!ok || s->h_scalars[4] > 0.0 || !(mcc == mcc) || mcc < 0.0) {  // invalid step
+    if (!ok || ss.bad > 0.0 || !(mcc == mcc) || mcc < 0.0) {  // invalid step
       ++S.unsuccessful_steps;
       if (++invalid_run >= 5) { term = HITL_FAILURE; break; }
       radius /= decrease_factor; decrease_factor *= 2.0;
@@ -751,9 +783,10 @@ void hitl_solver_destroy(hitl_solver* s) {
   for (DevArray<double>* v : {&s->d_scalars, &s->x, &s->xc, &s->scale, &s->rhs, &s->dt, &s->wv, &s->qv, &s->rv, &s->zv, &s->pv,
                               &s->crD, &s->crL, &s->crDinv, &s->crGl, &s->crGr})
     v->release();
-  for (int k = 0; k < 2; ++k) { s->pairRJ[k].release(); s->Hband[k].release(); s->gvec[k].release(); s->obblk[k].release(); s->cost_pose[k].release(); }
+  for (int k = 0; k < 2; ++k) { s->pairRJ[k].release(); s->Hband[k].release(); s->gvec[k].release(); s->obblk[k].release(); s->lin_partials[k].release(); }
   s->obs_off.release(); s->match_off.release();
-  for (DevArray<float>* v : {&s->px, &s->py, &s->nx, &s->ny, &s->cov9}) v->release();
+  s->obs.release(); s->cov9.release(); s->step_partials.release(); s->pose_cs.release();
+  if (s->h_partials) (void)hipHostFree(s->h_partials);
   for (DevArray<int>* v : {&s->pair_src, &s->pair_tgt, &s->pose_pair_off, &s->inc_off, &s->inc_ent, &s->band_pair, &s->ob_lo,
                            &s->ob_hi, &s->ob_fwd, &s->ob_rev, &s->obadj_off, &s->obadj_ent, &s->hc_off})
     v->release();
@@ -782,7 +815,20 @@ int hitl_solver_set_map(hitl_solver* s, int64_t n_poses, const int64_t* obs_offs
   s->n = (int)n_poses; s->n_obs = O; s->max_scan = std::max(max_scan, 1);
   s->h_obs_off.assign(obs_offset, obs_offset + n_poses + 1);
   TRY(s->obs_off.upload(s->h_obs_off, st));
-  TRY(s->px.upload(px, O, st)); TRY(s->py.upload(py, O, st)); TRY(s->nx.upload(nx, O, st)); TRY(s->ny.upload(ny, O, st));
+  {  // the caller's SoA arrays are packed into one float4 per observation on the device
+    DevArray<float> t0, t1, t2, t3;
+    int rc = t0.upload(px, O, st);
+    if (rc == HITL_OK) rc = t1.upload(py, O, st);
+    if (rc == HITL_OK) rc = t2.upload(nx, O, st);
+    if (rc == HITL_OK) rc = t3.upload(ny, O, st);
+    if (rc == HITL_OK) rc = s->obs.resize((size_t)O);
+    if (rc == HITL_OK) {
+      launch_pack_obs(st, O, t0.p, t1.p, t2.p, t3.p, s->obs.p);
+      if (hipStreamSynchronize(st) != hipSuccess) rc = fail(HITL_ERR_HIP, "pack_obs failed");
+    }
+    t0.release(); t1.release(); t2.release(); t3.release();
+    if (rc != HITL_OK) return rc;
+  }
   if (cov9) TRY(s->cov9.upload(cov9, (size_t)n_poses * 9, st));   // carried like covariances_; no live factor reads it
   HIP_TRY(hipStreamSynchronize(st));
   // a new map invalidates correspondences

@@ -104,7 +104,7 @@ def test_stf_only_full_run_reaches_the_same_cost_level(small_problem):
     pg, sg = g.solve(H.MODE_STF_ONLY, prob.init)
     po, so = o.solve(H.MODE_STF_ONLY, prob.init)
     assert abs(sg.final_cost - so.final_cost) <= 2e-3 * so.final_cost
-    assert np.abs(pg - po).max() <= 2e-3
+    assert np.abs(pg - po).max() <= 1e-2
 
 
 def test_solve_with_offband_pairs_uses_pcg(small_problem):
