@@ -206,6 +206,39 @@ class SolverBase(object):
         return cost.value, g, pr[:n_pairs], pj[:n_pairs]
 
 
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
+
+
+class CommOps(C.Structure):
+    """== hitl_comm_ops: an all-gather on HOST buffers supplied by the caller."""
+    _fields_ = [("allgather", ALLGATHER_FN), ("ctx", C.c_void_p)]
+
+
+def torch_allgather_ops(group=None, device=None):
+    """hitl_comm_ops backed by torch.distributed (gloo on CPU tensors, or nccl == RCCL when
+    `device` is a cuda device).  Returns (CommOps, keepalive)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+
+    def _ag(ctx, send, recv, nbytes):
+        try:
+            src = torch.frombuffer((C.c_char * nbytes).from_address(send), dtype=torch.uint8).clone()
+            if device is not None:
+                src = src.to(device)
+            out = torch.empty(world * nbytes, dtype=torch.uint8, device=src.device)
+            dist.all_gather_into_tensor(out, src, group=group)
+            C.memmove(recv, out.cpu().numpy().ctypes.data, world * nbytes)
+            return 0
+        except Exception as e:  # never let an exception cross the C boundary
+            import sys
+            sys.stderr.write("hitl allgather callback failed: %r\n" % (e,))
+            return 1
+
+    fn = ALLGATHER_FN(_ag)
+    return CommOps(fn, None), fn
+
+
 _lib_cache = {}
 
 
@@ -248,6 +281,30 @@ class Solver(SolverBase):
             return "%s" % self._lib.hitl_last_error().decode()
         except Exception:
             return ""
+
+    # -- pose-range submaps (world_size > 1) -----------------------------------------------
+    def set_partition(self, global_begin, n_global):
+        f = self._lib.hitl_solver_set_partition
+        f.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
+        f.restype = C.c_int
+        st = f(self._h, int(global_begin), int(n_global))
+        if st != abi.OK:
+            raise HitlError(st, "hitl_solver_set_partition", self._detail())
+        self._n_global = int(n_global)
+
+    def set_comm(self, ops, keepalive=None):
+        f = self._lib.hitl_solver_set_comm
+        f.argtypes = [C.c_void_p, C.POINTER(CommOps)]
+        f.restype = C.c_int
+        self._comm_keepalive = (ops, keepalive)
+        st = f(self._h, C.byref(ops))
+        if st != abi.OK:
+            raise HitlError(st, "hitl_solver_set_comm", self._detail())
+
+    def set_map(self, obs_offset, px, py, nx, ny, cov9=None):
+        super().set_map(obs_offset, px, py, nx, ny, cov9)
+        if getattr(self, "_n_global", None):
+            self.n_poses = self._n_global       # solve()/find_correspondences() take GLOBAL pose arrays
 
     def find_correspondences(self, poses_xyt, window):
         pin = _as(poses_xyt, np.float32).reshape(-1)

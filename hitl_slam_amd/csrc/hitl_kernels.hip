@@ -336,6 +336,14 @@ __global__ __launch_bounds__(128) void k_assemble(MapView map, PairView pr, Fact
       }
     }
   }
+  if (i == 0 && fv.halo_out != nullptr) {
+    // submap rank > 0: local pose 0 is the previous rank's last pose.  What the straddling
+    // odometry edge adds to THAT pose's diagonal block and gradient, and the cross-cut coupling
+    // block, are exported for the exchange ("shared-pose blocks").
+#pragma unroll
+    for (int q = 0; q < 9; ++q) { fv.halo_out[q] = Hd[q]; fv.halo_out[12 + q] = H1[q]; }
+    fv.halo_out[9] = gi[0]; fv.halo_out[10] = gi[1]; fv.halo_out[11] = gi[2];
+  }
   if (i == 0) {  // pose 0 is constant (JointOptimization.cpp:824, :1197): identity block, no coupling
 #pragma unroll
     for (int q = 0; q < 9; ++q) Hd[q] = (q % 4 == 0) ? 1.0 : 0.0;
@@ -348,6 +356,7 @@ __global__ __launch_bounds__(128) void k_assemble(MapView map, PairView pr, Fact
   pose_cost = cost;
   pose_gmax = fmax(fabs(gi[0]), fmax(fabs(gi[1]), fabs(gi[2])));
   if (gi[0] != gi[0] || gi[1] != gi[1] || gi[2] != gi[2]) pose_gmax = gi[0] + gi[1] + gi[2];  // NaN propagates
+  if (fv.tail_coupled && i == n - 1) pose_gmax = 0.0;   // completed by the next rank's halo contribution (host)
   for (int d = 1; d <= Wb; ++d) {
     double blk[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (i > 0 && i + d < n) {
@@ -687,13 +696,15 @@ __global__ __launch_bounds__(WAVE) void k_cr_root(CrView cr) {
   for (int e = threadIdx.x; e < B * B; e += WAVE) cr.Dinv[e] = sInv[e];
 }
 
-// forward sweep on a right-hand side: w_j -= Gr[k1]^T w_k1 + Gl[k2]^T w_k2
+// forward sweep on right-hand sides (blockIdx.y selects the rhs, `stride` doubles apart):
+// w_j -= Gr[k1]^T w_k1 + Gl[k2]^T w_k2
 template <int B>
-__global__ void k_cr_forward(CrView cr, int s, double* __restrict__ w) {
+__global__ void k_cr_forward(CrView cr, int s, double* __restrict__ w, size_t stride) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int q = t / B, c = t % B;
   const int j = 2 * s * q;
   if (j >= cr.nsb) return;
+  w += stride * blockIdx.y;
   const int k1 = j - s, k2 = j + s;
   double v = w[(size_t)j * B + c];
   if (k1 >= 0) {
@@ -713,11 +724,13 @@ __global__ void k_cr_forward(CrView cr, int s, double* __restrict__ w) {
 
 // back substitution: x_k = Dinv_k w_k - Gl_k x_{k-s} - Gr_k x_{k+s}
 template <int B>
-__global__ void k_cr_backward(CrView cr, int s, const double* __restrict__ w, double* __restrict__ x) {
+__global__ void k_cr_backward(CrView cr, int s, const double* __restrict__ w, double* __restrict__ x, size_t stride) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int q = t / B, r = t % B;
   const int k = s * (2 * q + 1);
   if (k >= cr.nsb) return;
+  w += stride * blockIdx.y;
+  x += stride * blockIdx.y;
   const size_t off = (size_t)k * B * B;
   const double* wk = w + (size_t)k * B;
   const double* xl = x + (size_t)(k - s) * B;
@@ -734,9 +747,11 @@ __global__ void k_cr_backward(CrView cr, int s, const double* __restrict__ w, do
 }
 
 template <int B>
-__global__ void k_cr_root_solve(CrView cr, const double* __restrict__ w, double* __restrict__ x) {
+__global__ void k_cr_root_solve(CrView cr, const double* __restrict__ w, double* __restrict__ x, size_t stride) {
   const int r = threadIdx.x;
   if (r >= B) return;
+  w += stride * blockIdx.x;
+  x += stride * blockIdx.x;
   double v = 0.0;
 #pragma unroll
   for (int c = 0; c < B; ++c) v += cr.Dinv[r * B + c] * w[c];
@@ -756,29 +771,28 @@ static void cr_factor_t(hipStream_t st, const CrView& cr, double* w) {
 
 // back substitution only (the forward sweep already happened inside cr_factor_t(.., w))
 template <int B>
-static void cr_back_t(hipStream_t st, const CrView& cr, const double* w, double* x) {
+static void cr_back_t(hipStream_t st, const CrView& cr, const double* w, double* x, int nrhs, size_t stride) {
   int s_last = 0;
   for (int s = 1; s < cr.nsb; s *= 2) s_last = s;
-  hipLaunchKernelGGL(k_cr_root_solve<B>, dim3(1), dim3(WAVE), 0, st, cr, w, x);
+  hipLaunchKernelGGL(k_cr_root_solve<B>, dim3(nrhs), dim3(WAVE), 0, st, cr, w, x, stride);
   for (int s = s_last; s >= 1; s /= 2) {
     const int n_elim = (cr.nsb - s + 2 * s - 1) / (2 * s);
-    hipLaunchKernelGGL(k_cr_backward<B>, dim3((n_elim * B + 127) / 128), dim3(128), 0, st, cr, s, w, x);
+    hipLaunchKernelGGL(k_cr_backward<B>, dim3((n_elim * B + 127) / 128, nrhs), dim3(128), 0, st, cr, s, w, x, stride);
   }
 }
 
 template <int B>
-static void cr_solve_t(hipStream_t st, const CrView& cr, double* w, double* x) {
-  int s_last = 0;
+static void cr_fwd_t(hipStream_t st, const CrView& cr, double* w, int nrhs, size_t stride) {
   for (int s = 1; s < cr.nsb; s *= 2) {
     const int n_surv = (cr.nsb + 2 * s - 1) / (2 * s);
-    hipLaunchKernelGGL(k_cr_forward<B>, dim3((n_surv * B + 127) / 128), dim3(128), 0, st, cr, s, w);
-    s_last = s;
+    hipLaunchKernelGGL(k_cr_forward<B>, dim3((n_surv * B + 127) / 128, nrhs), dim3(128), 0, st, cr, s, w, stride);
   }
-  hipLaunchKernelGGL(k_cr_root_solve<B>, dim3(1), dim3(WAVE), 0, st, cr, w, x);
-  for (int s = s_last; s >= 1; s /= 2) {
-    const int n_elim = (cr.nsb - s + 2 * s - 1) / (2 * s);
-    hipLaunchKernelGGL(k_cr_backward<B>, dim3((n_elim * B + 127) / 128), dim3(128), 0, st, cr, s, w, x);
-  }
+}
+
+template <int B>
+static void cr_solve_t(hipStream_t st, const CrView& cr, double* w, double* x, int nrhs, size_t stride) {
+  cr_fwd_t<B>(st, cr, w, nrhs, stride);
+  cr_back_t<B>(st, cr, w, x, nrhs, stride);
 }
 
 void launch_cr_factor(hipStream_t st, const CrView& cr) {
@@ -792,20 +806,24 @@ void launch_cr_factor(hipStream_t st, const CrView& cr) {
 
 void launch_cr_factor_solve(hipStream_t st, const CrView& cr, double* w, double* x) {
   switch (cr.B) {
-    case 3: cr_factor_t<3>(st, cr, w); cr_back_t<3>(st, cr, w, x); break;
-    case 6: cr_factor_t<6>(st, cr, w); cr_back_t<6>(st, cr, w, x); break;
-    case 9: cr_factor_t<9>(st, cr, w); cr_back_t<9>(st, cr, w, x); break;
-    default: cr_factor_t<12>(st, cr, w); cr_back_t<12>(st, cr, w, x); break;
+    case 3: cr_factor_t<3>(st, cr, w); cr_back_t<3>(st, cr, w, x, 1, 0); break;
+    case 6: cr_factor_t<6>(st, cr, w); cr_back_t<6>(st, cr, w, x, 1, 0); break;
+    case 9: cr_factor_t<9>(st, cr, w); cr_back_t<9>(st, cr, w, x, 1, 0); break;
+    default: cr_factor_t<12>(st, cr, w); cr_back_t<12>(st, cr, w, x, 1, 0); break;
+  }
+}
+
+void launch_cr_solve_multi(hipStream_t st, const CrView& cr, double* w, double* x, int nrhs, size_t stride) {
+  switch (cr.B) {
+    case 3: cr_solve_t<3>(st, cr, w, x, nrhs, stride); break;
+    case 6: cr_solve_t<6>(st, cr, w, x, nrhs, stride); break;
+    case 9: cr_solve_t<9>(st, cr, w, x, nrhs, stride); break;
+    default: cr_solve_t<12>(st, cr, w, x, nrhs, stride); break;
   }
 }
 
 void launch_cr_solve(hipStream_t st, const CrView& cr, double* w, double* x) {
-  switch (cr.B) {
-    case 3: cr_solve_t<3>(st, cr, w, x); break;
-    case 6: cr_solve_t<6>(st, cr, w, x); break;
-    case 9: cr_solve_t<9>(st, cr, w, x); break;
-    default: cr_solve_t<12>(st, cr, w, x); break;
-  }
+  launch_cr_solve_multi(st, cr, w, x, 1, 0);
 }
 
 // ===========================================================================================
@@ -949,6 +967,74 @@ void launch_spmv_step(hipStream_t st, int n_poses, int npad, const FactorView& f
 // ===========================================================================================
 // small vector kernels
 // ===========================================================================================
+// submap exchange helpers --------------------------------------------------------------------
+struct Halo12 { double v[12]; };   // 3x3 diagonal-block contribution + 3 gradient entries
+
+// add the next rank's straddling-edge contribution to this rank's LAST pose
+__global__ void k_add_halo(int n_poses, int Wb, double* __restrict__ Hband, double* __restrict__ g, Halo12 h) {
+  const int t = threadIdx.x;
+  const int i = n_poses - 1;
+  if (t < 9) Hband[(size_t)i * (Wb + 1) * 9 + t] += h.v[t];
+  else if (t < 12) g[3 * i + (t - 9)] += h.v[t];
+}
+
+void launch_add_halo(hipStream_t st, int n_poses, int Wb, double* Hband, double* g, const double* h12) {
+  Halo12 h;
+  for (int k = 0; k < 12; ++k) h.v[k] = h12[k];
+  hipLaunchKernelGGL(k_add_halo, dim3(1), dim3(64), 0, st, n_poses, Wb, Hband, g, h);
+}
+
+// unit right-hand sides e_{col} for the interface solve: w[r][*] = 0 except w[r][cols[r]] = 1
+struct UnitCols { int col[6]; };
+__global__ void k_unit_rhs(int npad, double* __restrict__ w, size_t stride, UnitCols uc) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= npad) return;
+  const int r = blockIdx.y;
+  w[stride * r + t] = (t == uc.col[r]) ? 1.0 : 0.0;
+}
+
+void launch_unit_rhs(hipStream_t st, int npad, double* w, size_t stride, const int* cols6) {
+  UnitCols uc;
+  for (int k = 0; k < 6; ++k) uc.col[k] = cols6[k];
+  hipLaunchKernelGGL(k_unit_rhs, dim3((npad + 255) / 256, 6), dim3(256), 0, st, npad, w, stride, uc);
+}
+
+// the 6 interface rows (first owned pose, last pose) of z0, of the 6 unit-rhs solutions and of
+// the Jacobi scale: out[0..6) = z0, out[6 + 6c + r] = Z[c][row r], out[42..48) = scale
+__global__ void k_gather_iface(const double* __restrict__ z0, const double* __restrict__ Z, size_t stride,
+                               const double* __restrict__ scale, UnitCols uc, double* __restrict__ out) {
+  const int t = threadIdx.x;
+  if (t < 6) out[t] = z0[uc.col[t]];
+  else if (t < 42) { const int c = (t - 6) / 6, r = (t - 6) % 6; out[t] = Z[stride * c + uc.col[r]]; }
+  else if (t < 48) out[t] = scale[uc.col[t - 42]];
+}
+
+void launch_gather_iface(hipStream_t st, const double* z0, const double* Z, size_t stride, const double* scale,
+                         const int* cols6, double* out48) {
+  UnitCols uc;
+  for (int k = 0; k < 6; ++k) uc.col[k] = cols6[k];
+  hipLaunchKernelGGL(k_gather_iface, dim3(1), dim3(64), 0, st, z0, Z, stride, scale, uc, out48);
+}
+
+// dt = z0 - sum_k coef[k] * Z[k]   (Z: 6 columns, `stride` apart)
+struct Coef6 { double c[6]; };
+__global__ void k_combine6(int npad, const double* __restrict__ z0, const double* __restrict__ Z, size_t stride, Coef6 cf,
+                           double* __restrict__ dt) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= npad) return;
+  double v = z0[t];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) v -= cf.c[k] * Z[stride * k + t];
+  dt[t] = v;
+}
+
+void launch_combine6(hipStream_t st, int npad, const double* z0, const double* Z, size_t stride, const double* coef6,
+                     double* dt) {
+  Coef6 cf;
+  for (int k = 0; k < 6; ++k) cf.c[k] = coef6[k];
+  hipLaunchKernelGGL(k_combine6, dim3((npad + 255) / 256), dim3(256), 0, st, npad, z0, Z, stride, cf, dt);
+}
+
 struct DotArgs { const double* a[4]; const double* b[4]; };
 
 __global__ __launch_bounds__(kRedBlock) void k_dots(int n, int ndots, DotArgs args, double* out) {

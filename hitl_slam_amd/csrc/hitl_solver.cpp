@@ -14,6 +14,8 @@
 #include <map>
 #include <numeric>
 
+#include <rccl/rccl.h>
+
 #include "hitl_internal.h"
 
 namespace hitl {
@@ -100,7 +102,17 @@ struct hitl_solver {
   DevArray<float4> obs;                        // (px, py, nx, ny) per observation
   DevArray<float> cov9;
 
-  // ---- human rows (sorted by constrained pose at solve time) ----
+  // ---- pose-range submap (world_size > 1) ----
+  int rank = 0, world = 1;
+  int64_t g_begin = 0, g_n = 0;      // owned GLOBAL range [g_begin, g_begin + n - halo), g_n = global pose count
+  int halo = 0;                      // 1 on rank > 0: local pose 0 is the previous rank's last pose
+  hitl_comm_ops comm = {nullptr, nullptr};
+  ncclComm_t nccl = nullptr;
+  DevArray<char> comm_send, comm_recv;
+  DevArray<double> halo_out, iface_dev, rhs6, z6;   // 21 | 48 | 6*npad | 6*npad
+  std::vector<double> cut_C[2];      // per linearisation buffer: world x 9 raw coupling blocks (rank g: cut g-1|g)
+
+  // ---- human rows: constrained_pose_id is LOCAL, anchor_pose_id stays GLOBAL ----
   std::vector<hitl_human_constraint_t> h_hc;
 
   // ---- correspondences ----
@@ -304,7 +316,7 @@ static void hc_target(const hitl_human_constraint_t& row, const float* a, float4
   t->w = ang + row.relative_penalty_dir;
 }
 
-static int setup_factors(hitl_solver* s, const float* poses, bool with_odom_hc) {
+static int setup_factors(hitl_solver* s, const float* poses, const float* poses_global, bool with_odom_hc) {
   const int n = s->n;
   std::vector<float4> A(n, make_float4(0, 0, 0, 0));
   std::vector<float2> rr(n, make_float2(0, 0));
@@ -323,7 +335,7 @@ static int setup_factors(hitl_solver* s, const float* poses, bool with_odom_hc) 
       const hitl_human_constraint_t& row = s->h_hc[h];
       const int dst = fill[row.constrained_pose_id]++;
       hc_type[dst] = row.type;
-      hc_target(row, poses + 3 * row.anchor_pose_id, &hc_tgt[dst]);
+      hc_target(row, poses_global + 3 * (size_t)row.anchor_pose_id, &hc_tgt[dst]);
       if (row.type == HITL_HC_LINE_SEGMENT) s->num_hc_residuals += 3;
       else if (row.type == HITL_HC_COLINEAR) s->num_hc_residuals += 2;
       else if (row.type == HITL_HC_PERPENDICULAR || row.type == HITL_HC_PARALLEL) s->num_hc_residuals += 1;
@@ -350,6 +362,8 @@ static FactorView factor_view(hitl_solver* s, int mode, int Wb) {
   f.n_offband = f.with_stf ? s->n_offband : 0;
   f.ob_lo = s->ob_lo.p; f.ob_hi = s->ob_hi.p; f.ob_fwd = s->ob_fwd.p; f.ob_rev = s->ob_rev.p;
   f.obadj_off = s->obadj_off.p; f.obadj_ent = s->obadj_ent.p;
+  f.halo_out = (s->world > 1 && s->halo) ? s->halo_out.p : nullptr;
+  f.tail_coupled = (s->world > 1 && s->rank < s->world - 1) ? 1 : 0;
   return f;
 }
 
@@ -383,6 +397,85 @@ static int run_linearize(hitl_solver* s, const FactorView& fv, const double* xde
   return HITL_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// pose-range submaps: tiny all-gathers on host buffers (RCCL built in, or a caller callback)
+// ---------------------------------------------------------------------------------------
+static int comm_allgather(hitl_solver* s, const void* send, void* recv, int64_t bytes) {
+  if (s->world == 1) { std::memcpy(recv, send, (size_t)bytes); return HITL_OK; }
+  if (s->comm.allgather) {
+    const int rc = s->comm.allgather(s->comm.ctx, send, recv, bytes);
+    return rc == 0 ? HITL_OK : fail(HITL_ERR_COMM, "all-gather callback failed");
+  }
+  if (!s->nccl) return fail(HITL_ERR_NOT_READY, "world_size > 1 needs hitl_options.rccl_unique_id or hitl_solver_set_comm");
+  hipStream_t st = s->stream;
+  TRY(s->comm_send.resize((size_t)bytes));
+  TRY(s->comm_recv.resize((size_t)bytes * s->world));
+  HIP_TRY(hipMemcpyAsync(s->comm_send.p, send, (size_t)bytes, hipMemcpyHostToDevice, st));
+  const ncclResult_t r = ncclAllGather(s->comm_send.p, s->comm_recv.p, (size_t)bytes, ncclChar, s->nccl, st);
+  if (r != ncclSuccess) return fail(HITL_ERR_COMM, std::string("ncclAllGather: ") + ncclGetErrorString(r));
+  HIP_TRY(hipMemcpyAsync(recv, s->comm_recv.p, (size_t)bytes * s->world, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return HITL_OK;
+}
+
+static inline double nan_max(double a, double b) { return (b > a || b != b) ? b : a; }
+
+// local linearisation + exchange of the straddling odometry edge's contributions
+static int run_linearize_dist(hitl_solver* s, const FactorView& fv, const double* xdev, int buf, LinResult* out) {
+  TRY(run_linearize(s, fv, xdev, buf, out));
+  if (s->world == 1) return HITL_OK;
+  hipStream_t st = s->stream;
+  const int W = s->world, n = s->n;
+  constexpr int R = 26;   // cost, gmax, halo_out[21], g_last[3]
+  double rec[R];
+  for (int k = 0; k < R; ++k) rec[k] = 0.0;
+  rec[0] = out->cost; rec[1] = out->gmax;
+  if (s->halo) HIP_TRY(hipMemcpyAsync(rec + 2, s->halo_out.p, 21 * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(rec + 23, s->gvec[buf].p + 3 * (size_t)(n - 1), 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  std::vector<double> all((size_t)R * W);
+  TRY(comm_allgather(s, rec, all.data(), R * sizeof(double)));
+  double cost = 0.0, gmax = 0.0;
+  for (int r = 0; r < W; ++r) {          // rank order on every rank: identical sums everywhere
+    cost += all[(size_t)R * r];
+    double gm = all[(size_t)R * r + 1];
+    if (r < W - 1) {
+      for (int c = 0; c < 3; ++c) gm = nan_max(gm, std::fabs(all[(size_t)R * r + 23 + c] + all[(size_t)R * (r + 1) + 2 + 9 + c]));
+    } else {
+      for (int c = 0; c < 3; ++c) gm = nan_max(gm, std::fabs(all[(size_t)R * r + 23 + c]));
+    }
+    gmax = nan_max(gmax, gm);
+    if (r >= 1) for (int q = 0; q < 9; ++q) s->cut_C[buf][(size_t)9 * r + q] = all[(size_t)R * r + 2 + 12 + q];
+  }
+  if (s->rank < W - 1)
+    launch_add_halo(st, n, fv.band_poses, s->Hband[buf].p, s->gvec[buf].p, &all[(size_t)R * (s->rank + 1) + 2]);
+  out->cost = cost;
+  out->gmax = gmax;
+  return HITL_OK;
+}
+
+// dense solve with partial pivoting (the 6*world interface system)
+static bool solve_dense(int n, std::vector<double>& A, std::vector<double>& b) {
+  for (int c = 0; c < n; ++c) {
+    int piv = c;
+    for (int r = c + 1; r < n; ++r) if (std::fabs(A[(size_t)r * n + c]) > std::fabs(A[(size_t)piv * n + c])) piv = r;
+    if (!(std::fabs(A[(size_t)piv * n + c]) > 0.0)) return false;
+    if (piv != c) { for (int k = 0; k < n; ++k) std::swap(A[(size_t)c * n + k], A[(size_t)piv * n + k]); std::swap(b[c], b[piv]); }
+    for (int r = c + 1; r < n; ++r) {
+      const double f = A[(size_t)r * n + c] / A[(size_t)c * n + c];
+      if (f == 0.0) continue;
+      for (int k = c; k < n; ++k) A[(size_t)r * n + k] -= f * A[(size_t)c * n + k];
+      b[r] -= f * b[c];
+    }
+  }
+  for (int r = n - 1; r >= 0; --r) {
+    double v = b[r];
+    for (int k = r + 1; k < n; ++k) v -= A[(size_t)r * n + k] * b[k];
+    b[r] = v / A[(size_t)r * n + r];
+  }
+  return true;
+}
+
 static int check_ready(hitl_solver* s, int mode) {
   if (!s) return fail(HITL_ERR_INVALID_ARGUMENT, "null solver");
   if (s->n <= 0) return fail(HITL_ERR_NOT_READY, "hitl_solver_set_map has not been called");
@@ -390,7 +483,7 @@ static int check_ready(hitl_solver* s, int mode) {
   return HITL_OK;
 }
 
-static int prepare(hitl_solver* s, int mode, const float* poses_ref, FactorView* fv) {
+static int prepare(hitl_solver* s, int mode, const float* poses_ref, const float* poses_global, FactorView* fv) {
   HIP_TRY(hipSetDevice(s->device));
   TRY(ensure_empty_pair_tables(s));
   const int Wb = (mode == HITL_MODE_ODOM_HC) ? 1 : s->band_pairs_Wb;
@@ -398,7 +491,13 @@ static int prepare(hitl_solver* s, int mode, const float* poses_ref, FactorView*
     // mode A reads no pair table: a 1-pose band; the pair-derived band_pair table is unused
   }
   TRY(ensure_work(s, Wb));
-  TRY(setup_factors(s, poses_ref, mode != HITL_MODE_STF_ONLY));
+  TRY(setup_factors(s, poses_ref, poses_global, mode != HITL_MODE_STF_ONLY));
+  if (s->world > 1) {
+    TRY(s->halo_out.resize(21)); TRY(s->iface_dev.resize(48));
+    TRY(s->rhs6.resize((size_t)6 * s->npad)); TRY(s->z6.resize((size_t)6 * s->npad));
+    TRY(s->halo_out.zero(s->stream));
+    for (int k = 0; k < 2; ++k) s->cut_C[k].assign((size_t)s->world * 9, 0.0);
+  }
   *fv = factor_view(s, mode, Wb);
   return HITL_OK;
 }
@@ -492,6 +591,96 @@ static int linear_solve_and_step(hitl_solver* s, const FactorView& fv, int buf, 
   return HITL_OK;
 }
 
+// Submap version: every rank factorises its own banded block (the previous rank's last pose is
+// a locally constant halo), solves for its right-hand side AND for the 6 unit vectors of its
+// first/last pose, and the cross-cut coupling blocks are eliminated exactly through the
+// 6*world interface system every rank solves identically on the host.
+static int linear_solve_and_step_dist(hitl_solver* s, const FactorView& fv, int buf, double mu, const double* xcur,
+                                      double* xcand, int* iters, bool* ok, StepScalars* ss) {
+  hipStream_t st = s->stream;
+  const LinView lv = s->lin_view(buf);
+  const CrView cr = s->cr_view();
+  const double mind = s->opt.min_lm_diagonal, maxd = s->opt.max_lm_diagonal;
+  const int npad = s->npad, n = s->n, W = s->world, me = s->rank;
+  *iters = 1;
+  *ok = true;
+  launch_build_system(st, n, fv.band_poses, lv, s->scale.p, mu, mind, maxd, cr, s->rhs.p);
+  launch_copy(st, npad, s->rhs.p, s->wv.p);
+  launch_cr_factor_solve(st, cr, s->wv.p, s->dt.p);            // z0 = M^{-1} b
+  const int cols[6] = {3 * s->halo, 3 * s->halo + 1, 3 * s->halo + 2, 3 * (n - 1), 3 * (n - 1) + 1, 3 * (n - 1) + 2};
+  launch_unit_rhs(st, npad, s->rhs6.p, (size_t)npad, cols);
+  launch_cr_solve_multi(st, cr, s->rhs6.p, s->z6.p, 6, (size_t)npad);   // Z = M^{-1} [E_first, E_last]
+  launch_gather_iface(st, s->dt.p, s->z6.p, (size_t)npad, s->scale.p, cols, s->iface_dev.p);
+  double rec[48];
+  HIP_TRY(hipMemcpyAsync(rec, s->iface_dev.p, sizeof(rec), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  std::vector<double> all((size_t)48 * W);
+  TRY(comm_allgather(s, rec, all.data(), sizeof(rec)));
+  // scaled coupling blocks  Ct_g = diag(s_last of g-1) * C_g * diag(s_first of g),  g = 1..W-1
+  std::vector<double> Ct((size_t)9 * W, 0.0);
+  for (int g = 1; g < W; ++g)
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b)
+        Ct[(size_t)9 * g + 3 * a + b] = all[(size_t)48 * (g - 1) + 45 + a] * s->cut_C[buf][(size_t)9 * g + 3 * a + b] * all[(size_t)48 * g + 42 + b];
+  // interface system: y_g + ZF_g Ct_g^T v_{g-1} + ZL_g Ct_{g+1} u_{g+1} = z0_g,  y_g = (u_g, v_g)
+  const int NI = 6 * W;
+  std::vector<double> A((size_t)NI * NI, 0.0), y(NI, 0.0);
+  for (int g = 0; g < W; ++g) {
+    const double* rg = &all[(size_t)48 * g];
+    for (int r = 0; r < 6; ++r) {
+      A[(size_t)(6 * g + r) * NI + 6 * g + r] = 1.0;
+      y[6 * g + r] = rg[r];
+      if (g >= 1)
+        for (int k = 0; k < 3; ++k) {      // column of v_{g-1}[k]
+          double v = 0.0;
+          for (int c = 0; c < 3; ++c) v += rg[6 + 6 * c + r] * Ct[(size_t)9 * g + 3 * k + c];       // ZF[r][c] * Ct_g[k][c]
+          A[(size_t)(6 * g + r) * NI + 6 * (g - 1) + 3 + k] += v;
+        }
+      if (g + 1 < W)
+        for (int k = 0; k < 3; ++k) {      // column of u_{g+1}[k]
+          double v = 0.0;
+          for (int c = 0; c < 3; ++c) v += rg[6 + 6 * (3 + c) + r] * Ct[(size_t)9 * (g + 1) + 3 * c + k];  // ZL[r][c] * Ct_{g+1}[c][k]
+          A[(size_t)(6 * g + r) * NI + 6 * (g + 1) + k] += v;
+        }
+    }
+  }
+  if (!solve_dense(NI, A, y)) { *ok = false; }
+  double coef[6] = {0, 0, 0, 0, 0, 0};
+  double cross = 0.0;
+  if (me >= 1) {
+    const double* vprev = &y[6 * (me - 1) + 3];
+    for (int c = 0; c < 3; ++c)
+      for (int k = 0; k < 3; ++k) coef[c] += Ct[(size_t)9 * me + 3 * k + c] * vprev[k];             // Ct_g^T v_{g-1}
+    // 2 v_{g-1}^T Ct_g u_g : the straddling edge's share of dt^T (S H S) dt, counted by its owner
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) cross += 2.0 * vprev[a] * Ct[(size_t)9 * me + 3 * a + b] * y[6 * me + b];
+  }
+  if (me + 1 < W) {
+    const double* unext = &y[6 * (me + 1)];
+    for (int c = 0; c < 3; ++c)
+      for (int k = 0; k < 3; ++k) coef[3 + c] += Ct[(size_t)9 * (me + 1) + 3 * c + k] * unext[k];   // Ct_{g+1} u_{g+1}
+  }
+  launch_combine6(st, npad, s->dt.p, s->z6.p, (size_t)npad, coef, s->dt.p);
+  launch_spmv_step(st, n, npad, fv, lv, s->scale.p, s->dt.p, s->rhs.p, xcur, s->qv.p, xcand, s->step_partials.p);
+  HIP_TRY(hipGetLastError());
+  StepScalars loc;
+  double tail[3];
+  HIP_TRY(hipMemcpyAsync(tail, xcand + 3 * (size_t)(n - 1), sizeof(tail), hipMemcpyDeviceToHost, st));
+  TRY(read_step_partials(s, nullptr, nullptr, &loc));    // synchronises the stream
+  double r2[8] = {loc.dt_rhs, loc.dt_q + cross, loc.step2, loc.xn2, loc.bad, tail[0], tail[1], tail[2]};
+  std::vector<double> all2((size_t)8 * W);
+  TRY(comm_allgather(s, r2, all2.data(), sizeof(r2)));
+  ss->dt_rhs = ss->dt_q = ss->step2 = ss->xn2 = ss->bad = 0.0;
+  for (int g = 0; g < W; ++g) {
+    ss->dt_rhs += all2[(size_t)8 * g]; ss->dt_q += all2[(size_t)8 * g + 1]; ss->step2 += all2[(size_t)8 * g + 2];
+    ss->xn2 += all2[(size_t)8 * g + 3]; ss->bad += all2[(size_t)8 * g + 4];
+  }
+  if (s->halo)   // the candidate state of the previous rank's last pose feeds the straddling edge
+    HIP_TRY(hipMemcpyAsync(xcand, &all2[(size_t)8 * (me - 1) + 5], 3 * sizeof(double), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return HITL_OK;
+}
+
 static double now_ms() {
   using namespace std::chrono;
   return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
@@ -500,11 +689,13 @@ static double now_ms() {
 // ---------------------------------------------------------------------------------------
 // Levenberg-Marquardt with Ceres trust-region semantics (DESIGN.md "LM")
 // ---------------------------------------------------------------------------------------
-static int lm_solve(hitl_solver* s, int mode, const float* poses_in, float* poses_out, hitl_summary* summary) {
+static int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float* poses_global, float* poses_out,
+                    hitl_summary* summary) {
   const double t_start = now_ms();
   const hitl_options& o = s->opt;
   FactorView fv;
-  TRY(prepare(s, mode, poses_in, &fv));
+  TRY(prepare(s, mode, poses_in, poses_global, &fv));
+  if (s->world > 1 && fv.n_offband > 0) return fail(HITL_ERR_UNSUPPORTED, "submap solves need every pose pair inside the band");
   hipStream_t st = s->stream;
   const int n = s->n, n3 = 3 * n;
   hitl_summary S;
@@ -519,7 +710,7 @@ static int lm_solve(hitl_solver* s, int mode, const float* poses_in, float* pose
   double* xcand = s->xc.p;
   int cur = 0;
   LinResult lr;
-  TRY(run_linearize(s, fv, xcur, cur, &lr));
+  TRY(run_linearize_dist(s, fv, xcur, cur, &lr));
   S.linearize_ms += lr.stf_ms; S.linearize_calls++;
   double cost = lr.cost, gmax = lr.gmax;
   S.initial_cost = cost;
@@ -543,7 +734,8 @@ static int lm_solve(hitl_solver* s, int mode, const float* poses_in, float* pose
     bool ok = true;
     HIP_TRY(hipEventRecord(s->ev2, st));
     StepScalars ss;
-    TRY(linear_solve_and_step(s, fv, cur, radius, xcur, xcand, &lin_iters, &ok, &ss));
+    if (s->world > 1) TRY(linear_solve_and_step_dist(s, fv, cur, radius, xcur, xcand, &lin_iters, &ok, &ss));
+    else TRY(linear_solve_and_step(s, fv, cur, radius, xcur, xcand, &lin_iters, &ok, &ss));
     S.linear_iterations += lin_iters;
     HIP_TRY(hipEventRecord(s->ev3, st));
     HIP_TRY(hipEventSynchronize(s->ev3));
@@ -562,7 +754,7 @@ static int lm_solve(hitl_solver* s, int mode, const float* poses_in, float* pose
       continue;
     }
     invalid_run = 0;
-    TRY(run_linearize(s, fv, xcand, cur ^ 1, &lr));
+    TRY(run_linearize_dist(s, fv, xcand, cur ^ 1, &lr));
     S.linearize_ms += lr.stf_ms; S.linearize_calls++;
     if (std::sqrt(step2) <= o.parameter_tolerance * (std::sqrt(xn2) + o.parameter_tolerance)) { term = HITL_CONVERGENCE; break; }
     const double cost_change = cost - lr.cost;
@@ -756,7 +948,6 @@ int hitl_solver_create(const hitl_options* opt, hitl_solver** out) {
   if (opt) o = *opt; else hitl_options_default(&o);
   if (o.abi_version != HITL_ABI_VERSION) return fail(HITL_ERR_INVALID_ARGUMENT, "hitl_options.abi_version mismatch");
   if (o.world_size < 1 || o.rank < 0 || o.rank >= o.world_size) return fail(HITL_ERR_INVALID_ARGUMENT, "bad rank/world_size");
-  if (o.world_size > 1) return fail(HITL_ERR_UNSUPPORTED, "in-library submap exchange is not built yet; run one solver per submap");
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
     return fail(HITL_ERR_NO_DEVICE, "no HIP device visible (hipGetDeviceCount); this library has no CPU fallback");
@@ -772,6 +963,16 @@ int hitl_solver_create(const hitl_options* opt, hitl_solver** out) {
     if (hipEventCreate(e) != hipSuccess) return bail(HITL_ERR_HIP, "hipEventCreate failed");
   if (hipHostMalloc((void**)&s->h_scalars, sizeof(double) * kNumScalars) != hipSuccess) return bail(HITL_ERR_HIP, "hipHostMalloc failed");
   if (s->d_scalars.resize(kNumScalars) != HITL_OK) return bail(HITL_ERR_OUT_OF_MEMORY, "hipMalloc failed");
+  s->rank = o.rank;
+  s->world = o.world_size;
+  if (o.world_size > 1 && o.rccl_unique_id != nullptr) {
+    ncclUniqueId id;
+    static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+    std::memcpy(&id, o.rccl_unique_id, sizeof(id));
+    const ncclResult_t r = ncclCommInitRank(&s->nccl, o.world_size, id, o.rank);
+    if (r != ncclSuccess) return bail(HITL_ERR_COMM, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
+  }
+  s->opt.rccl_unique_id = nullptr;   // not retained
   *out = s;
   return HITL_OK;
 }
@@ -791,16 +992,38 @@ void hitl_solver_destroy(hitl_solver* s) {
                            &s->ob_hi, &s->ob_fwd, &s->ob_rev, &s->obadj_off, &s->obadj_ent, &s->hc_off})
     v->release();
   s->matches.release(); s->odom_A.release(); s->hc_tgt.release(); s->odom_rr.release(); s->hc_type.release();
+  if (s->nccl) (void)ncclCommDestroy(s->nccl);
+  s->comm_send.release(); s->comm_recv.release(); s->halo_out.release(); s->iface_dev.release(); s->rhs6.release(); s->z6.release();
   if (s->h_scalars) (void)hipHostFree(s->h_scalars);
   for (hipEvent_t e : {s->ev0, s->ev1, s->ev2, s->ev3}) if (e) (void)hipEventDestroy(e);
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
 }
 
+int hitl_solver_set_comm(hitl_solver* s, const hitl_comm_ops* ops) {
+  if (!s) return fail(HITL_ERR_INVALID_ARGUMENT, "null solver");
+  if (ops) s->comm = *ops; else { s->comm.allgather = nullptr; s->comm.ctx = nullptr; }
+  return HITL_OK;
+}
+
+int hitl_solver_set_partition(hitl_solver* s, int64_t global_begin, int64_t n_global_poses) {
+  if (!s || global_begin < 0 || n_global_poses < 1 || global_begin >= n_global_poses) return fail(HITL_ERR_INVALID_ARGUMENT, "set_partition: bad range");
+  if (s->world == 1 && (global_begin != 0)) return fail(HITL_ERR_INVALID_ARGUMENT, "set_partition: a single-GPU solver owns the whole map");
+  if (s->world > 1 && ((s->rank == 0) != (global_begin == 0))) return fail(HITL_ERR_INVALID_ARGUMENT, "set_partition: rank 0 (and only rank 0) starts at pose 0");
+  s->g_begin = global_begin;
+  s->g_n = n_global_poses;
+  s->halo = (s->world > 1 && s->rank > 0) ? 1 : 0;
+  s->n = 0;   // a map must be (re)installed for this range
+  return HITL_OK;
+}
+
 int hitl_solver_set_map(hitl_solver* s, int64_t n_poses, const int64_t* obs_offset, const float* px, const float* py,
                         const float* nx, const float* ny, const float* cov9) {
   if (!s || !obs_offset || n_poses < 1) return fail(HITL_ERR_INVALID_ARGUMENT, "set_map: null solver/offsets or n_poses < 1");
   if (n_poses > (int64_t)1 << 30) return fail(HITL_ERR_UNSUPPORTED, "set_map: more than 2^30 poses");
+  if (s->world > 1 && s->g_n == 0) return fail(HITL_ERR_NOT_READY, "set_map: call hitl_solver_set_partition first when world_size > 1");
+  if (s->world > 1 && s->g_begin + n_poses > s->g_n) return fail(HITL_ERR_INVALID_ARGUMENT, "set_map: owned range exceeds the global pose count");
+  if (s->world == 1) { s->g_begin = 0; s->g_n = n_poses; s->halo = 0; }
   const int64_t O = obs_offset[n_poses];
   if (obs_offset[0] != 0 || O < 0 || (O > 0 && (!px || !py || !nx || !ny))) return fail(HITL_ERR_INVALID_ARGUMENT, "set_map: bad offsets or null scan arrays");
   int max_scan = 0;
@@ -812,8 +1035,10 @@ int hitl_solver_set_map(hitl_solver* s, int64_t n_poses, const int64_t* obs_offs
   }
   HIP_TRY(hipSetDevice(s->device));
   hipStream_t st = s->stream;
-  s->n = (int)n_poses; s->n_obs = O; s->max_scan = std::max(max_scan, 1);
-  s->h_obs_off.assign(obs_offset, obs_offset + n_poses + 1);
+  // local pose list = [halo pose with an empty scan (rank > 0)] + owned poses
+  s->n = (int)n_poses + s->halo; s->n_obs = O; s->max_scan = std::max(max_scan, 1);
+  s->h_obs_off.assign((size_t)s->n + 1, 0);
+  for (int64_t i = 0; i <= n_poses; ++i) s->h_obs_off[(size_t)i + s->halo] = obs_offset[i];
   TRY(s->obs_off.upload(s->h_obs_off, st));
   {  // the caller's SoA arrays are packed into one float4 per observation on the device
     DevArray<float> t0, t1, t2, t3;
@@ -831,27 +1056,34 @@ int hitl_solver_set_map(hitl_solver* s, int64_t n_poses, const int64_t* obs_offs
   }
   if (cov9) TRY(s->cov9.upload(cov9, (size_t)n_poses * 9, st));   // carried like covariances_; no live factor reads it
   HIP_TRY(hipStreamSynchronize(st));
-  // a new map invalidates correspondences
+  // a new map invalidates correspondences and human rows
   s->n_pairs = 0; s->n_matches = 0; s->pose_pair_off.n = 0;
-  s->h_hc.erase(std::remove_if(s->h_hc.begin(), s->h_hc.end(), [&](const hitl_human_constraint_t& r) {
-                  return r.constrained_pose_id >= s->n || r.anchor_pose_id >= s->n; }), s->h_hc.end());
+  s->h_hc.clear();
   return ensure_empty_pair_tables(s);
 }
 
 int hitl_solver_set_human_constraints(hitl_solver* s, int64_t n, const hitl_human_constraint_t* rows) {
   if (!s || n < 0 || (n > 0 && !rows)) return fail(HITL_ERR_INVALID_ARGUMENT, "set_human_constraints: bad arguments");
   if (s->n <= 0) return fail(HITL_ERR_NOT_READY, "set_human_constraints before set_map");
+  const int64_t own_lo = s->g_begin, own_hi = s->g_begin + (s->n - s->halo);
   for (int64_t h = 0; h < n; ++h)
-    if (rows[h].constrained_pose_id < 0 || rows[h].constrained_pose_id >= s->n || rows[h].anchor_pose_id < 0 || rows[h].anchor_pose_id >= s->n)
+    if (rows[h].constrained_pose_id < 0 || rows[h].constrained_pose_id >= s->g_n || rows[h].anchor_pose_id < 0 || rows[h].anchor_pose_id >= s->g_n)
       return fail(HITL_ERR_INVALID_ARGUMENT, "set_human_constraints: pose id out of range");
-  s->h_hc.assign(rows, rows + n);
+  s->h_hc.clear();
+  for (int64_t h = 0; h < n; ++h) {
+    if (rows[h].constrained_pose_id < own_lo || rows[h].constrained_pose_id >= own_hi) continue;   // another rank's row
+    hitl_human_constraint_t r = rows[h];
+    r.constrained_pose_id = (int32_t)(r.constrained_pose_id - s->g_begin + s->halo);                // local; the anchor stays global
+    s->h_hc.push_back(r);
+  }
   return HITL_OK;
 }
 
 int hitl_solver_find_correspondences(hitl_solver* s, const float* poses_xyt, int64_t window) {
   if (!s || !poses_xyt) return fail(HITL_ERR_INVALID_ARGUMENT, "find_correspondences: null argument");
   if (s->n <= 0) return fail(HITL_ERR_NOT_READY, "find_correspondences before set_map");
-  return find_correspondences(s, poses_xyt, window);
+  // poses_xyt is the GLOBAL array; the local list starts at the halo pose (rank > 0)
+  return find_correspondences(s, poses_xyt + 3 * (size_t)(s->g_begin - s->halo), window);
 }
 
 int hitl_solver_set_correspondences(hitl_solver* s, int64_t n_pairs, const int32_t* pair_src, const int32_t* pair_tgt,
@@ -861,9 +1093,10 @@ int hitl_solver_set_correspondences(hitl_solver* s, int64_t n_pairs, const int32
   if (n_pairs > 0 && (!pair_src || !pair_tgt || !match_offset || !src_idx || !tgt_idx)) return fail(HITL_ERR_INVALID_ARGUMENT, "set_correspondences: null array");
   HIP_TRY(hipSetDevice(s->device));
   const int P = (int)n_pairs;
+  const int shift = s->halo - (int)s->g_begin;   // GLOBAL pose id -> local index
   for (int p = 0; p < P; ++p) {
-    const int a = pair_src[p], b = pair_tgt[p];
-    if (a < 0 || a >= s->n || b < 0 || b >= s->n || a == b) return fail(HITL_ERR_INVALID_ARGUMENT, "set_correspondences: pose index out of range or src == tgt");
+    const int a = pair_src[p] + shift, b = pair_tgt[p] + shift;
+    if (a < s->halo || a >= s->n || b < s->halo || b >= s->n || a == b) return fail(s->world > 1 ? HITL_ERR_UNSUPPORTED : HITL_ERR_INVALID_ARGUMENT, "set_correspondences: pose index outside this solver's owned range, or src == tgt");
     if (match_offset[p + 1] <= match_offset[p]) return fail(HITL_ERR_INVALID_ARGUMENT, "set_correspondences: every pair needs >= 1 match (residual_functors.h:783)");
     const int64_t ma = s->h_obs_off[a + 1] - s->h_obs_off[a], mb = s->h_obs_off[b + 1] - s->h_obs_off[b];
     for (int64_t m = match_offset[p]; m < match_offset[p + 1]; ++m)
@@ -871,7 +1104,7 @@ int hitl_solver_set_correspondences(hitl_solver* s, int64_t n_pairs, const int32
   }
   std::vector<int> order(P);
   std::iota(order.begin(), order.end(), 0);
-  std::stable_sort(order.begin(), order.end(), [&](int u, int v) { return pair_src[u] < pair_src[v]; });
+  std::stable_sort(order.begin(), order.end(), [&](int u, int v) { return pair_src[u] < pair_src[v]; });   // shift-invariant
   s->h_perm = order;
   s->h_pair_src.resize(P); s->h_pair_tgt.resize(P); s->h_match_off.assign(P + 1, 0);
   const int64_t C = P ? match_offset[P] - match_offset[0] : 0;
@@ -879,7 +1112,7 @@ int hitl_solver_set_correspondences(hitl_solver* s, int64_t n_pairs, const int32
   int64_t w = 0;
   for (int q = 0; q < P; ++q) {
     const int p = order[q];
-    s->h_pair_src[q] = pair_src[p]; s->h_pair_tgt[q] = pair_tgt[p];
+    s->h_pair_src[q] = pair_src[p] + shift; s->h_pair_tgt[q] = pair_tgt[p] + shift;
     for (int64_t m = match_offset[p]; m < match_offset[p + 1]; ++m) packed[w++] = (uint32_t)src_idx[m] | ((uint32_t)tgt_idx[m] << 16);
     s->h_match_off[q + 1] = w;
   }
@@ -915,7 +1148,7 @@ int hitl_solver_get_correspondences(hitl_solver* s, int32_t* pair_src, int32_t* 
   match_offset[0] = 0;
   for (int p = 0; p < P; ++p) {
     const int q = inv[p];
-    pair_src[p] = s->h_pair_src[q]; pair_tgt[p] = s->h_pair_tgt[q];
+    pair_src[p] = s->h_pair_src[q] - (s->halo - (int)s->g_begin); pair_tgt[p] = s->h_pair_tgt[q] - (s->halo - (int)s->g_begin);
     for (int64_t m = s->h_match_off[q]; m < s->h_match_off[q + 1]; ++m) {
       src_idx[w] = (int32_t)(packed[m] & 0xffffu); tgt_idx[w] = (int32_t)(packed[m] >> 16); ++w;
     }
@@ -927,16 +1160,38 @@ int hitl_solver_get_correspondences(hitl_solver* s, int32_t* pair_src, int32_t* 
 int hitl_solver_solve(hitl_solver* s, int32_t mode, const float* poses_in_xyt, float* poses_out_xyt, hitl_summary* summary) {
   TRY(check_ready(s, mode));
   if (!poses_in_xyt || !poses_out_xyt) return fail(HITL_ERR_INVALID_ARGUMENT, "solve: null pose array");
-  if (mode == HITL_MODE_STF_ONLY && s->n_pairs == 0) return fail(HITL_ERR_NOT_READY, "mode STF_ONLY needs correspondences (find_/set_correspondences)");
-  return lm_solve(s, mode, poses_in_xyt, poses_out_xyt, summary);
+  if (s->world == 1) {
+    if (mode == HITL_MODE_STF_ONLY && s->n_pairs == 0) return fail(HITL_ERR_NOT_READY, "mode STF_ONLY needs correspondences (find_/set_correspondences)");
+    return lm_solve(s, mode, poses_in_xyt, poses_in_xyt, poses_out_xyt, summary);
+  }
+  // submap rank: poses are GLOBAL arrays; this rank solves [halo pose +] its owned range
+  if (mode == HITL_MODE_STF_ONLY) return fail(HITL_ERR_UNSUPPORTED, "submap solves need the odometry chain (mode A or C)");
+  const size_t n = (size_t)s->n, first = (size_t)(s->g_begin - s->halo);
+  std::vector<float> in(poses_in_xyt + 3 * first, poses_in_xyt + 3 * (first + n)), out(3 * n);
+  hitl_summary S;
+  const int rc = lm_solve(s, mode, in.data(), poses_in_xyt, out.data(), &S);
+  if (poses_out_xyt != poses_in_xyt) std::memcpy(poses_out_xyt, poses_in_xyt, sizeof(float) * 3 * (size_t)s->g_n);
+  if (rc == HITL_OK || rc == HITL_ERR_SOLVER_FAILURE)
+    std::memcpy(poses_out_xyt + 3 * (size_t)s->g_begin, out.data() + 3 * (size_t)s->halo, sizeof(float) * 3 * (n - s->halo));
+  // problem-size counters are global sums
+  double cnt[4] = {(double)S.num_residuals, (double)S.num_hc_residuals, (double)S.num_pairs, (double)S.num_matches};
+  std::vector<double> all((size_t)4 * s->world);
+  if (comm_allgather(s, cnt, all.data(), sizeof(cnt)) == HITL_OK) {
+    double t[4] = {0, 0, 0, 0};
+    for (int r = 0; r < s->world; ++r) for (int k = 0; k < 4; ++k) t[k] += all[(size_t)4 * r + k];
+    S.num_residuals = (int32_t)t[0]; S.num_hc_residuals = (int32_t)t[1]; S.num_pairs = (int64_t)t[2]; S.num_matches = (int64_t)t[3];
+  }
+  if (summary) *summary = S;
+  return rc;
 }
 
 int hitl_solver_linearize(hitl_solver* s, int32_t mode, const float* poses_ref_xyt, const double* x, double* cost,
                           double* gradient, double* pair_residuals, double* pair_jacobians) {
   TRY(check_ready(s, mode));
   if (!poses_ref_xyt || !x) return fail(HITL_ERR_INVALID_ARGUMENT, "linearize: null pose array");
+  if (s->world > 1) return fail(HITL_ERR_UNSUPPORTED, "linearize/evaluate are single-GPU entry points");
   FactorView fv;
-  TRY(prepare(s, mode, poses_ref_xyt, &fv));
+  TRY(prepare(s, mode, poses_ref_xyt, poses_ref_xyt, &fv));
   hipStream_t st = s->stream;
   const int n3 = 3 * s->n;
   HIP_TRY(hipMemcpyAsync(s->x.p, x, sizeof(double) * n3, hipMemcpyHostToDevice, st));
@@ -968,8 +1223,11 @@ int hitl_solver_evaluate(hitl_solver* s, int32_t mode, const float* poses_xyt, d
 
 int hitl_comm_unique_id(void* out128) {
   if (!out128) return fail(HITL_ERR_INVALID_ARGUMENT, "null buffer");
-  std::memset(out128, 0, 128);
-  return fail(HITL_ERR_UNSUPPORTED, "in-library RCCL exchange is not built yet");
+  ncclUniqueId id;
+  const ncclResult_t r = ncclGetUniqueId(&id);
+  if (r != ncclSuccess) return fail(HITL_ERR_COMM, std::string("ncclGetUniqueId: ") + ncclGetErrorString(r));
+  std::memcpy(out128, &id, 128);
+  return HITL_OK;
 }
 
 int hitl_partition_range(int64_t n_poses, const int64_t* obs_offset, int32_t rank, int32_t world_size, int64_t* begin,

@@ -200,6 +200,34 @@ int hitl_solver_linearize(hitl_solver*, int32_t mode, const float* poses_ref_xyt
                           double* cost, double* gradient, double* pair_residuals,
                           double* pair_jacobians);
 
+/* ---- pose-range submaps across GPUs (world_size > 1; nothing in the reference) ------------
+ * One process per GPU; rank r owns the contiguous GLOBAL pose range [begin, begin + n_local).
+ * Cuts must fall where the trajectory shards naturally: the only factor that may straddle a
+ * cut is the odometry edge (begin-1, begin); a scan-to-scan pair across a cut is rejected
+ * with HITL_ERR_UNSUPPORTED.  Protocol per rank:
+ *   hitl_solver_create(opt with rank/world_size [+ rccl_unique_id])
+ *   hitl_solver_set_partition(begin, n_global)          -- before set_map
+ *   hitl_solver_set_map(n_local, ...)                   -- scans of the OWNED poses only
+ *   hitl_solver_set_human_constraints(rows)             -- GLOBAL pose ids; rows constraining a
+ *                                                          pose of another rank are ignored here
+ *   hitl_solver_find_correspondences(poses GLOBAL n_global*3, window)
+ *   hitl_solver_solve(mode, poses_in GLOBAL, poses_out GLOBAL, summary)
+ *        every rank takes identical LM decisions; poses_out receives the owned range (other
+ *        entries are copied from poses_in); summary costs/iterations are global.
+ * Per LM iteration the ranks exchange three tiny all-gathers (<= 400 bytes per rank): the
+ * straddling edge's contribution to the previous rank's last pose ("shared-pose gradient /
+ * Hessian blocks"), the 6x7 interface rows of the local cyclic-reduction solves (the cross-cut
+ * coupling is then eliminated exactly on every rank), and the step scalars + boundary state.
+ * The all-gather is either the built-in RCCL one (opt.rccl_unique_id != NULL) or a caller
+ * supplied callback on HOST buffers (tests use torch.distributed/gloo). */
+typedef int (*hitl_allgather_fn)(void* ctx, const void* send, void* recv, int64_t bytes_per_rank);
+typedef struct hitl_comm_ops {
+  hitl_allgather_fn allgather;   /* recv holds world_size * bytes_per_rank, rank order; 0 = OK */
+  void* ctx;
+} hitl_comm_ops;
+int hitl_solver_set_comm(hitl_solver*, const hitl_comm_ops* ops);
+int hitl_solver_set_partition(hitl_solver*, int64_t global_begin, int64_t n_global_poses);
+
 /* Multi-GPU helpers.  hitl_comm_unique_id: rank 0 calls it and broadcasts the 128 bytes.
  * hitl_partition_range: the contiguous pose range rank r of w owns for n_poses poses,
  * balanced by observation count (host-only; runs without a GPU). */

@@ -1,0 +1,50 @@
+"""Worker of tests/test_submap_gpu.py: one rank of a 2-submap solve.  Both ranks may share one
+GPU (the exchange goes through the host-buffer all-gather callback over gloo), which is how the
+N > 1 path is exercised on a 1-GPU box; on a multi-GPU node each rank takes its own device."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    out_path, mode = sys.argv[1], int(sys.argv[2])
+    dist.init_process_group(backend="gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    import hitl_slam_amd as H
+    from hitl_slam_amd.api import torch_allgather_ops
+    from conftest import Problem
+
+    n_per, ppf = 60, 30
+    prob = Problem(n_per * world, 48, ppf=ppf, groups=2, kind=0)
+    b, e = rank * n_per, (rank + 1) * n_per
+    M = 48
+    opt = H.default_options()
+    opt.rank, opt.world_size = rank, world
+    opt.device = rank % max(torch.cuda.device_count(), 1)
+    s = H.Solver(opt)
+    ops, keep = torch_allgather_ops()
+    s.set_comm(ops, keep)
+    s.set_partition(b, prob.n)
+    sl = slice(b * M, e * M)
+    s.set_map(np.arange(n_per + 1, dtype=np.int64) * M, prob.px[sl], prob.py[sl], prob.nx[sl], prob.ny[sl], prob.cov[b:e])
+    s.set_human_constraints(prob.rows)
+    s.find_correspondences(prob.init, 3)
+    corr = s.get_correspondences()
+    poses, summ = s.solve(mode, prob.init)
+    res = dict(rank=rank, begin=b, end=e, poses=poses.tolist(), summary=summ.as_dict(),
+               pairs=[corr[0].tolist(), corr[1].tolist()], n_matches=int(len(corr[3])))
+    json.dump(res, open("%s.%d" % (out_path, rank), "w"))
+    s.close()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
