@@ -19,6 +19,7 @@ the map where it shards naturally (between floors: no scan overlap, one odometry
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -61,6 +62,9 @@ def main():
     ap.add_argument("--obs", type=int, default=0, help="override observations per pose")
     ap.add_argument("--cpu-sample-poses", type=int, default=6000, help="poses in the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--comm", default="rccl", choices=["rccl", "torch"], help="N>1 exchange: in-library RCCL or torch.distributed")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend; gloo lets several ranks share one GPU (debugging on a 1-GPU box)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -74,10 +78,16 @@ def main():
     use_dist = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
-    torch.cuda.set_device(local_rank)
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    tdev = "cuda" if args.backend == "nccl" else "cpu"
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend="gloo")
+            args.comm = "torch"
 
     import hitl_slam_amd as H
     from tools import hitl_synth as S
@@ -99,27 +109,60 @@ def main():
     begin, end = rank * n_local, (rank + 1) * n_local        # floors hold ppf poses: cuts fall between floors
     off, px, py, nx, ny = S.scans(p, begin, end)
     rows = S.constraints(p, gt, wl["groups"], kind=wl["kind"], begin=begin, end=end)
-    # local pose indices
-    for k in range(rows[1]):
-        rows[0][k].constrained_pose_id -= begin
-        rows[0][k].anchor_pose_id -= begin
     init_l = np.ascontiguousarray(init[begin:end])
     gen_s = time.time() - t0
 
     opt = H.default_options()
-    opt.device = local_rank
-    solver = H.Solver(opt)
-    solver.set_map(off, px, py, nx, ny, cov[begin:end])
-    solver.set_human_constraints(rows)
+    opt.device = dev_index
+    comm_kind = "none"
+    keep = []
+    if use_dist:
+        # pose-range submaps: rank r owns global poses [begin, end); the cut falls between two floors,
+        # so only the odometry edge straddles it.  Exchange = 3 tiny all-gathers per LM iteration.
+        opt.rank, opt.world_size = rank, world
+        solver = None
+        if args.comm == "rccl":
+            try:
+                from hitl_slam_amd.api import comm_unique_id
+                uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+                if rank == 0:
+                    uid.copy_(torch.frombuffer(bytearray(comm_unique_id()), dtype=torch.uint8))
+                dist.broadcast(uid, 0)
+                buf = (C.c_char * 128).from_buffer_copy(bytes(uid.cpu().numpy().tobytes()))
+                keep.append(buf)
+                opt.rccl_unique_id = C.cast(buf, C.c_void_p)
+                solver = H.Solver(opt)
+                solver.comm_selftest()
+                comm_kind = "rccl (in-library ncclAllGather)"
+            except Exception as e:   # fall back to torch.distributed (also RCCL) rather than lose the run
+                sys.stderr.write("rank %d: in-library RCCL unavailable (%r); using torch.distributed\n" % (rank, e))
+                solver = None
+        if solver is None:
+            from hitl_slam_amd.api import torch_allgather_ops
+            opt.rccl_unique_id = None
+            solver = H.Solver(opt)
+            ops, fn = torch_allgather_ops(device=torch.device("cuda", dev_index) if args.backend == "nccl" else None)
+            solver.set_comm(ops, fn)
+            comm_kind = "torch.distributed all_gather (%s backend)" % ("nccl = RCCL" if args.backend == "nccl" else "gloo")
+        solver.set_partition(begin, n_global)
+        solver.set_map(off, px, py, nx, ny, cov[begin:end])
+        solver.set_human_constraints(rows)          # global pose ids
+        pose_arg = init                             # global pose array
+    else:
+        solver = H.Solver(opt)
+        solver.set_map(off, px, py, nx, ny, cov[begin:end])
+        solver.set_human_constraints(rows)
+        pose_arg = init_l
     torch.cuda.synchronize()
     t0 = time.time()
-    solver.find_correspondences(init_l, wl["window"])
+    solver.find_correspondences(pose_arg, wl["window"])
     match_ms = (time.time() - t0) * 1e3
     n_obs = int(off[-1])
+    n_pairs_l, n_matches_l = solver.correspondence_counts()     # this rank's submap
 
     # ---- warm-up, then exactly K timed re-solves -----------------------------------------------------
     for _ in range(args.warmup):
-        out, summ = solver.solve(H.MODE_JOINT, init_l)
+        out, summ = solver.solve(H.MODE_JOINT, pose_arg)
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -129,7 +172,7 @@ def main():
     stf_calls = 0
     lin_solver_ms = 0.0
     for _ in range(args.steps):
-        out, summ = solver.solve(H.MODE_JOINT, init_l)
+        out, summ = solver.solve(H.MODE_JOINT, pose_arg)
         iters += summ.iterations
         stf_ms += summ.linearize_ms
         stf_calls += summ.linearize_calls
@@ -139,12 +182,13 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t_start
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        tot = torch.tensor([float(iters), float(n_obs) * iters], dtype=torch.float64, device="cuda")
+        tot = torch.tensor([float(n_obs)], dtype=torch.float64, device=tdev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        iters_all, obs_iters_all = float(tot[0].item()), float(tot[1].item())
+        # one global Levenberg-Marquardt loop: every rank reports the same iteration count
+        iters_all, obs_iters_all = float(iters), float(tot[0].item()) * iters
     else:
         iters_all, obs_iters_all = float(iters), float(n_obs) * iters
 
@@ -155,7 +199,7 @@ def main():
 
     ms_per_step = elapsed * 1e3 / args.steps
     avg_stf_ms = stf_ms / max(stf_calls, 1)
-    alg_bytes = algorithmic_bytes_stf(n_obs, summ.num_matches, n_local, summ.num_pairs)
+    alg_bytes = algorithmic_bytes_stf(n_obs, n_matches_l, n_local, n_pairs_l)
     achieved = alg_bytes / (avg_stf_ms * 1e-3) / 1e9 if avg_stf_ms > 0 else 0.0
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
@@ -166,7 +210,8 @@ def main():
                 traffic = tj.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    err_gt = float(np.abs(out[:, :2].astype(np.float64) - gt[begin:end, :2]).max())
+    out_l = out[begin:end] if use_dist else out
+    err_gt = float(np.abs(out_l[:, :2].astype(np.float64) - gt[begin:end, :2]).max())
 
     result = {
         "metric": "full batch re-solve throughput (observation rows x Gauss-Newton/LM iterations per second); "
@@ -183,10 +228,10 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": wl["desc"], "poses_per_gpu": n_local, "obs_per_pose": M, "n_poses_total": n_global,
-                   "n_obs_per_gpu": n_obs, "matches_per_gpu": int(summ.num_matches), "pairs_per_gpu": int(summ.num_pairs),
-                   "matches_per_obs": summ.num_matches / max(n_obs, 1), "window": wl["window"],
+                   "n_obs_per_gpu": n_obs, "matches_per_gpu": int(n_matches_l), "pairs_per_gpu": int(n_pairs_l),
+                   "matches_per_obs": n_matches_l / max(n_obs, 1), "window": wl["window"],
                    "human_constraint_rows": rows[1], "mode": "C (joint)", "band_poses": int(summ.band_poses),
-                   "parallelism": "1 pose-range submap per GPU" if world > 1 else "single GPU"},
+                   "parallelism": ("%d pose-range submaps, 1 per GPU, one global LM; exchange: %s" % (world, comm_kind)) if world > 1 else "single GPU"},
         "resolve_ms": ms_per_step,
         "gn_iters_per_sec": iters_all / elapsed,
         "lm_iterations_per_resolve": summ.iterations,
@@ -198,7 +243,7 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "k_linearize_stf", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_stf_ms, "launches": stf_calls,
-                     "compulsory_bytes_this_layout": 16 * n_obs + 4 * int(summ.num_matches) + 24 * n_local + 112 * int(summ.num_pairs)},
+                     "compulsory_bytes_this_layout": 16 * n_obs + 4 * int(n_matches_l) + 24 * n_local + 112 * int(n_pairs_l)},
         "synth_gen_s": gen_s,
     }
 

@@ -156,6 +156,12 @@ class SolverBase(object):
                                          _ptr(match_offset, _i64p), _ptr(src_idx, _i32p), _ptr(tgt_idx, _i32p)),
                     "set_corr")
 
+    def correspondence_counts(self):
+        """(directed pose pairs, point matches) held by THIS solver (local counts for a submap rank)."""
+        P, Cn = C.c_int64(), C.c_int64()
+        self._check(self._fn("get_corr_counts")(self._h, C.byref(P), C.byref(Cn)), "get_corr_counts")
+        return P.value, Cn.value
+
     def get_correspondences(self):
         P, Cn = C.c_int64(), C.c_int64()
         self._check(self._fn("get_corr_counts")(self._h, C.byref(P), C.byref(Cn)), "get_corr_counts")
@@ -291,6 +297,11 @@ class Solver(SolverBase):
         if st != abi.OK:
             raise HitlError(st, "hitl_solver_set_partition", self._detail())
         self._n_global = int(n_global)
+
+    def comm_selftest(self):
+        st = self._lib.hitl_solver_comm_selftest(self._h)
+        if st != abi.OK:
+            raise HitlError(st, "hitl_solver_comm_selftest", self._detail())
 
     def set_comm(self, ops, keepalive=None):
         f = self._lib.hitl_solver_set_comm

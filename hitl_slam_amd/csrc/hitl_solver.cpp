@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <numeric>
@@ -401,7 +402,7 @@ static int run_linearize(hitl_solver* s, const FactorView& fv, const double* xde
 // pose-range submaps: tiny all-gathers on host buffers (RCCL built in, or a caller callback)
 // ---------------------------------------------------------------------------------------
 static int comm_allgather(hitl_solver* s, const void* send, void* recv, int64_t bytes) {
-  if (s->world == 1) { std::memcpy(recv, send, (size_t)bytes); return HITL_OK; }
+  if (s->world == 1 && !s->nccl && !s->comm.allgather) { std::memcpy(recv, send, (size_t)bytes); return HITL_OK; }
   if (s->comm.allgather) {
     const int rc = s->comm.allgather(s->comm.ctx, send, recv, bytes);
     return rc == 0 ? HITL_OK : fail(HITL_ERR_COMM, "all-gather callback failed");
@@ -965,7 +966,7 @@ int hitl_solver_create(const hitl_options* opt, hitl_solver** out) {
   if (s->d_scalars.resize(kNumScalars) != HITL_OK) return bail(HITL_ERR_OUT_OF_MEMORY, "hipMalloc failed");
   s->rank = o.rank;
   s->world = o.world_size;
-  if (o.world_size > 1 && o.rccl_unique_id != nullptr) {
+  if ((o.world_size > 1 || std::getenv("HITL_FORCE_RCCL")) && o.rccl_unique_id != nullptr) {
     ncclUniqueId id;
     static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
     std::memcpy(&id, o.rccl_unique_id, sizeof(id));
@@ -1003,6 +1004,19 @@ void hitl_solver_destroy(hitl_solver* s) {
 int hitl_solver_set_comm(hitl_solver* s, const hitl_comm_ops* ops) {
   if (!s) return fail(HITL_ERR_INVALID_ARGUMENT, "null solver");
   if (ops) s->comm = *ops; else { s->comm.allgather = nullptr; s->comm.ctx = nullptr; }
+  return HITL_OK;
+}
+
+int hitl_solver_comm_selftest(hitl_solver* s) {
+  if (!s) return fail(HITL_ERR_INVALID_ARGUMENT, "null solver");
+  HIP_TRY(hipSetDevice(s->device));
+  uint64_t send[8];
+  for (int k = 0; k < 8; ++k) send[k] = 0x4849544c00000000ull + (uint64_t)s->rank * 8 + k;
+  std::vector<uint64_t> recv((size_t)8 * s->world, 0);
+  TRY(comm_allgather(s, send, recv.data(), sizeof(send)));
+  for (int r = 0; r < s->world; ++r)
+    for (int k = 0; k < 8; ++k)
+      if (recv[(size_t)8 * r + k] != 0x4849544c00000000ull + (uint64_t)r * 8 + k) return fail(HITL_ERR_COMM, "all-gather self-test: wrong payload");
   return HITL_OK;
 }
 

@@ -227,6 +227,8 @@ typedef struct hitl_comm_ops {
 } hitl_comm_ops;
 int hitl_solver_set_comm(hitl_solver*, const hitl_comm_ops* ops);
 int hitl_solver_set_partition(hitl_solver*, int64_t global_begin, int64_t n_global_poses);
+/* one small all-gather through the active communicator, payload verified (bring-up check) */
+int hitl_solver_comm_selftest(hitl_solver*);
 
 /* Multi-GPU helpers.  hitl_comm_unique_id: rank 0 calls it and broadcasts the 128 bytes.
  * hitl_partition_range: the contiguous pose range rank r of w owns for n_poses poses,

@@ -184,3 +184,20 @@ def test_errors_are_loud():
     with pytest.raises(H.HitlError):
         s.set_correspondences([0], [0], [0, 1], [0], [0])  # src == tgt
     s.close()
+
+
+def test_in_library_rccl_allgather_world1(monkeypatch):
+    """Bring-up check of the built-in RCCL exchange (ncclGetUniqueId, ncclCommInitRank,
+    ncclAllGather on the solver's stream) on the single GPU of the test box."""
+    import ctypes as C
+    import hitl_slam_amd as H
+    from hitl_slam_amd.api import comm_unique_id
+    monkeypatch.setenv("HITL_FORCE_RCCL", "1")
+    uid = comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    buf = (C.c_char * 128).from_buffer_copy(uid)
+    opt = H.default_options()
+    opt.rccl_unique_id = C.cast(buf, C.c_void_p)
+    s = H.Solver(opt)
+    s.comm_selftest()
+    s.close()
