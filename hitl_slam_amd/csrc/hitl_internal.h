@@ -73,8 +73,9 @@ struct CrView {             // block-tridiagonal system + cyclic-reduction facto
 };
 
 // ---- kernel launchers (hitl_kernels.hip) -------------------------------------------------
+void launch_pose_trig(hipStream_t st, int n_poses, const double* x, double2* cs);   // cs[i] = (cos, sin) of pose i
 void launch_linearize_stf(hipStream_t st, const MapView& map, const PairView& pr, int max_scan,
-                          const double* x, double2* cs /* n scratch */, float corr, float std_dev, double* pairRJ);
+                          const double* x, const double2* cs, float corr, float std_dev, double* pairRJ);
 void launch_pack_obs(hipStream_t st, int64_t n, const float* px, const float* py, const float* nx, const float* ny,
                      float4* obs);
 void launch_assemble(hipStream_t st, const MapView& map, const PairView& pr, const FactorView& fv,

@@ -194,13 +194,16 @@ __global__ __launch_bounds__(kStfBlock, 6) void k_linearize_stf(MapView map, Pai
   }
 }
 
+void launch_pose_trig(hipStream_t st, int n_poses, const double* x, double2* cs) {
+  hipLaunchKernelGGL(k_pose_trig, dim3((n_poses + 255) / 256), dim3(256), 0, st, n_poses, x, cs);
+}
+
 void launch_linearize_stf(hipStream_t st, const MapView& map, const PairView& pr, int max_scan, const double* x,
-                          double2* cs, float corr, float std_dev, double* pairRJ) {
+                          const double2* cs, float corr, float std_dev, double* pairRJ) {
   if (pr.n_pairs == 0) return;
   const int chunk = (map.n_poses + 7) / 8;
   int lds_cap = (max_scan + 63) & ~63;
   if ((size_t)lds_cap * 16 > 64 * 1024) lds_cap = 0;  // oversized scans read the source from global memory
-  hipLaunchKernelGGL(k_pose_trig, dim3((map.n_poses + 255) / 256), dim3(256), 0, st, map.n_poses, x, cs);
   if (lds_cap > 0)
     hipLaunchKernelGGL(k_linearize_stf<true>, dim3(8 * chunk), dim3(kStfBlock), (size_t)lds_cap * 16, st, map, pr, chunk,
                        lds_cap, x, cs, (double)corr, (double)std_dev, pairRJ);

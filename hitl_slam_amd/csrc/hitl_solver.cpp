@@ -376,7 +376,8 @@ static int run_linearize(hitl_solver* s, const FactorView& fv, const double* xde
   const MapView mv = s->map_view();
   const PairView pv = s->pair_view();
   const LinView lv = s->lin_view(buf);
-  HIP_TRY(hipEventRecord(s->ev0, st));
+  if (fv.with_stf) launch_pose_trig(st, s->n, xdev, s->pose_cs.p);
+  HIP_TRY(hipEventRecord(s->ev0, st));   // ev0..ev1 brackets exactly the k_linearize_stf launch
   if (fv.with_stf)
     launch_linearize_stf(st, mv, pv, s->max_scan, xdev, s->pose_cs.p, s->opt.point_correlation_factor, s->opt.laser_std_dev, lv.pairRJ);
   HIP_TRY(hipEventRecord(s->ev1, st));
