@@ -26,6 +26,12 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+__device__ __forceinline__ double readlane_f64(double v, int src_lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
+
 // ===========================================================================================
 // linearize_stf: one workgroup per SOURCE pose (its scan staged once in LDS as float4), one
 // wave per directed pair (i -> j), lanes stride the pair's matches.
@@ -47,12 +53,6 @@ __device__ __forceinline__ double wave_sum(double v) {
 // are served from that XCD's L2.
 // ===========================================================================================
 constexpr int kStfBlock = 192;
-
-__device__ __forceinline__ double readlane_f64(double v, int src_lane) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
-  return __hiloint2double(hi, lo);
-}
 
 // v[0..2h) -> v[0..h): lanes with bit `mask` set keep the upper half
 #define HITL_XSTEP(mask, h)                                        \
@@ -540,75 +540,125 @@ void launch_build_system(hipStream_t st, int n_poses, int Wb, const LinView& lin
 // Level stride s: nodes s, 3s, 5s.. are eliminated (k_cr_eliminate), nodes 0, 2s, 4s..
 // survive and absorb the Schur complement (k_cr_update).
 // ===========================================================================================
+// Register-resident Gauss-Jordan sweep of one SPD super-block: lane (grp, c) owns column c of
+// the augmented matrix [D | I | L_k | L_{k+s}^T]; for pivot p the pivot column is broadcast from
+// lane p with v_readlane (no LDS, no barriers, no pivoting needed for SPD tiles).  Result:
+// [I | Dinv | Gl = Dinv L_k | Gr = Dinv L_{k+s}^T].
+template <int B>
+__device__ __forceinline__ void gauss_jordan_cols(double (&col)[B]) {
+#pragma unroll
+  for (int p = 0; p < B; ++p) {
+    double m[B];
+#pragma unroll
+    for (int r = 0; r < B; ++r) m[r] = readlane_f64(col[r], p);   // current column p (lane p, group 0)
+    const double inv = 1.0 / m[p];
+    const double vk = col[p] * inv;
+#pragma unroll
+    for (int r = 0; r < B; ++r) col[r] = (r == p) ? vk : col[r] - m[r] * vk;
+  }
+}
+
+template <int B>
+__device__ __forceinline__ void cr_eliminate_node(const CrView& cr, int s, int k, int lane) {
+  static_assert(4 * B <= WAVE, "four column groups must fit one wave");
+  const size_t off = (size_t)k * B * B;
+  const bool has_right = (k + s) < cr.nsb;
+  const int grp = lane / B, c = lane % B;
+  const double* Dk = cr.D + off;
+  const double* Lk = cr.L + off;
+  const double* Lr = cr.L + (size_t)(has_right ? (k + s) : k) * B * B;
+  double col[B];
+#pragma unroll
+  for (int r = 0; r < B; ++r) {
+    double v = 0.0;
+    if (grp == 0) v = Dk[r * B + c];
+    else if (grp == 1) v = (r == c) ? 1.0 : 0.0;
+    else if (grp == 2) v = Lk[r * B + c];
+    else if (grp == 3 && has_right) v = Lr[c * B + r];      // column c of L_{k+s}^T
+    col[r] = v;
+  }
+  gauss_jordan_cols<B>(col);
+  double* dst = (grp == 1) ? cr.Dinv + off : (grp == 2) ? cr.Gl + off : cr.Gr + off;
+  if (grp >= 1 && grp <= 3) {
+#pragma unroll
+    for (int r = 0; r < B; ++r) dst[r * B + c] = col[r];
+  }
+}
+
+template <int B>
+__global__ __launch_bounds__(WAVE) void k_cr_eliminate(CrView cr, int s) {
+  const int k = s * (2 * blockIdx.x + 1);
+  if (k >= cr.nsb) return;
+  cr_eliminate_node<B>(cr, s, k, threadIdx.x);
+}
+
+// Schur-complement update of survivor j at level stride s (LDS-free):
+//   D_j  -= L_j Gr[k1] + L_{k2}^T Gl[k2]        L'_j = -L_j Gl[k1]
+// Lane (grp, c) owns column c of the right operands (grp 0: Gr[k1], Gl[k2] -> D_j; grp 1: Gl[k1]
+// -> L'_j); the left matrices L_j and L_{k2}^T are the same for every lane (uniform loads).
+// With w != nullptr the right-hand side rides along (w_j -= Gr[k1]^T w_k1 + Gl[k2]^T w_k2), which
+// saves the separate forward sweep when a factorisation is followed by exactly one solve.
+template <int B>
+__device__ __forceinline__ void cr_update_node(const CrView& cr, int s, int j, int lane, double* w) {
+  const size_t off = (size_t)j * B * B;
+  const int k1 = j - s, k2 = j + s;
+  const bool has1 = k1 >= 0, has2 = k2 < cr.nsb, has_ll = (k1 - s) >= 0;
+  const int grp = lane / B, c = lane % B;
+  if (grp > 1) return;
+  const double* Lj = cr.L + off;                                   // overwritten below: no __restrict__
+  const double* L2 = cr.L + (size_t)(has2 ? k2 : j) * B * B;
+  double b1[B], b2[B], acc[B];
+  const double* B1 = (grp == 0 ? cr.Gr : cr.Gl) + (size_t)(has1 ? k1 : j) * B * B;
+  const double* B2 = cr.Gl + (size_t)(has2 ? k2 : j) * B * B;
+#pragma unroll
+  for (int r = 0; r < B; ++r) {
+    b1[r] = has1 ? B1[r * B + c] : 0.0;
+    b2[r] = (has2 && grp == 0) ? B2[r * B + c] : 0.0;
+    acc[r] = 0.0;
+  }
+  if (has1) {
+#pragma unroll
+    for (int r = 0; r < B; ++r)
+#pragma unroll
+      for (int q = 0; q < B; ++q) acc[r] += Lj[r * B + q] * b1[q];          // (L_j * B1)[r][c]
+  }
+  if (has2) {
+#pragma unroll
+    for (int r = 0; r < B; ++r)
+#pragma unroll
+      for (int q = 0; q < B; ++q) acc[r] += L2[q * B + r] * b2[q];          // (L_{k2}^T * Gl[k2])[r][c]
+  }
+  if (grp == 0) {
+    if (w != nullptr) {   // rhs forward sweep: w_j[c] -= Gr[k1][:,c] . w_k1 + Gl[k2][:,c] . w_k2
+      double wacc = w[(size_t)j * B + c];
+      if (has1) {
+        const double* wk = w + (size_t)k1 * B;
+#pragma unroll
+        for (int r = 0; r < B; ++r) wacc -= b1[r] * wk[r];
+      }
+      if (has2) {
+        const double* wk = w + (size_t)k2 * B;
+#pragma unroll
+        for (int r = 0; r < B; ++r) wacc -= b2[r] * wk[r];
+      }
+      w[(size_t)j * B + c] = wacc;
+    }
+#pragma unroll
+    for (int r = 0; r < B; ++r) cr.D[off + r * B + c] -= acc[r];
+  } else if (has1) {
+    // every read of the old L_j happened above (same wave, in order); now it is replaced
+#pragma unroll
+    for (int r = 0; r < B; ++r) cr.L[off + r * B + c] = has_ll ? -acc[r] : 0.0;
+  }
+}
+
 template <int B>
 __device__ __forceinline__ void lds_load(double* dst, const double* __restrict__ src) {
   for (int e = threadIdx.x; e < B * B; e += WAVE) dst[e] = src[e];
 }
 
-// in-place Cholesky (lower) of the SPD tile A, then Ainv = A^{-1}
-template <int B>
-__device__ void lds_spd_inverse(double* A, double* Ainv) {
-  for (int c = 0; c < B; ++c) {
-    __syncthreads();
-    if (threadIdx.x == 0) A[c * B + c] = sqrt(A[c * B + c]);
-    __syncthreads();
-    const double dcc = A[c * B + c];
-    if ((int)threadIdx.x > c && (int)threadIdx.x < B) A[threadIdx.x * B + c] /= dcc;
-    __syncthreads();
-    for (int e = threadIdx.x; e < B * B; e += WAVE) {
-      const int r = e / B, c2 = e % B;
-      if (c2 > c && r >= c2) A[r * B + c2] -= A[r * B + c] * A[c2 * B + c];
-    }
-  }
-  __syncthreads();
-  if ((int)threadIdx.x < B) {  // lane t solves A z = e_t through L L^T
-    const int t = threadIdx.x;
-    double y[B];
-#pragma unroll
-    for (int r = 0; r < B; ++r) {
-      double s = (r == t) ? 1.0 : 0.0;
-#pragma unroll
-      for (int q = 0; q < r; ++q) s -= A[r * B + q] * y[q];
-      y[r] = s / A[r * B + r];
-    }
-#pragma unroll
-    for (int r = B - 1; r >= 0; --r) {
-      double s = y[r];
-#pragma unroll
-      for (int q = r + 1; q < B; ++q) s -= A[q * B + r] * y[q];
-      y[r] = s / A[r * B + r];
-    }
-#pragma unroll
-    for (int r = 0; r < B; ++r) Ainv[r * B + t] = y[r];
-  }
-  __syncthreads();
-}
-
-template <int B>
-__global__ __launch_bounds__(WAVE) void k_cr_eliminate(CrView cr, int s) {
-  __shared__ double sD[B * B], sInv[B * B], sL[B * B], sR[B * B];
-  const int k = s * (2 * blockIdx.x + 1);
-  if (k >= cr.nsb) return;
-  const size_t off = (size_t)k * B * B;
-  const bool has_right = (k + s) < cr.nsb;
-  lds_load<B>(sD, cr.D + off);
-  lds_load<B>(sL, cr.L + off);
-  if (has_right) lds_load<B>(sR, cr.L + (size_t)(k + s) * B * B);
-  lds_spd_inverse<B>(sD, sInv);
-  for (int e = threadIdx.x; e < B * B; e += WAVE) {
-    const int r = e / B, c = e % B;
-    double gl = 0.0, gr = 0.0;
-#pragma unroll
-    for (int q = 0; q < B; ++q) {
-      gl += sInv[r * B + q] * sL[q * B + c];
-      if (has_right) gr += sInv[r * B + q] * sR[c * B + q];   // Dinv * L_{k+s}^T
-    }
-    cr.Dinv[off + e] = sInv[e];
-    cr.Gl[off + e] = gl;
-    cr.Gr[off + e] = gr;
-  }
-}
-
+// Standalone (one workgroup per survivor) version for the big levels: the left matrices are
+// staged through LDS once per workgroup, which beats 2*B*B uniform global loads per lane.
 // With w != nullptr the right-hand side rides along (w_j -= Gr[k1]^T w_k1 + Gl[k2]^T w_k2), which
 // saves the separate forward sweep when a factorisation is followed by exactly one solve.
 template <int B>
@@ -692,11 +742,83 @@ __global__ __launch_bounds__(WAVE) void k_cr_update(CrView cr, int s, double* __
 }
 
 template <int B>
-__global__ __launch_bounds__(WAVE) void k_cr_root(CrView cr) {
-  __shared__ double sD[B * B], sInv[B * B];
-  lds_load<B>(sD, cr.D);
-  lds_spd_inverse<B>(sD, sInv);
-  for (int e = threadIdx.x; e < B * B; e += WAVE) cr.Dinv[e] = sInv[e];
+__device__ __forceinline__ void cr_root_node(const CrView& cr, int lane) {
+  const int grp = lane / B, c = lane % B;
+  double col[B];
+#pragma unroll
+  for (int r = 0; r < B; ++r) col[r] = (grp == 0) ? cr.D[r * B + c] : ((grp == 1 && r == c) ? 1.0 : 0.0);
+  gauss_jordan_cols<B>(col);
+  if (grp == 1) {
+#pragma unroll
+    for (int r = 0; r < B; ++r) cr.Dinv[r * B + c] = col[r];
+  }
+}
+
+template <int B>
+__global__ __launch_bounds__(WAVE) void k_cr_root(CrView cr) { cr_root_node<B>(cr, threadIdx.x); }
+
+// back substitution of one row: x_k[r] = (Dinv_k w_k - Gl_k x_{k-s} - Gr_k x_{k+s})[r]
+template <int B>
+__device__ __forceinline__ void cr_backward_row(const CrView& cr, int s, int k, int r, const double* w, double* x) {
+  const size_t off = (size_t)k * B * B;
+  const double* wk = w + (size_t)k * B;
+  const double* xl = x + (size_t)(k - s) * B;
+  const bool has_right = (k + s) < cr.nsb;
+  const double* xr = x + (size_t)(has_right ? (k + s) : k) * B;
+  double v = 0.0;
+#pragma unroll
+  for (int c = 0; c < B; ++c) {
+    v += cr.Dinv[off + r * B + c] * wk[c];
+    v -= cr.Gl[off + r * B + c] * xl[c];
+    if (has_right) v -= cr.Gr[off + r * B + c] * xr[c];
+  }
+  x[(size_t)k * B + r] = v;
+}
+
+// All levels from stride s_start up to the root, the root itself and (x != nullptr) the
+// matching back-substitution levels in ONE single-workgroup launch: these levels hold at most a
+// few hundred super-blocks, so they are pure launch latency when issued as 3 kernels per level.
+// 16 waves, one super-block per wave per step, __syncthreads between phases (all traffic is
+// workgroup-local global memory).
+constexpr int kCrTopThreads = 1024;
+template <int B>
+__global__ __launch_bounds__(kCrTopThreads) void k_cr_top(CrView cr, int s_start, double* w, double* x) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  constexpr int NW = kCrTopThreads / WAVE;
+  int s_last = 0;
+  for (int s = s_start; s < cr.nsb; s *= 2) {
+    for (int q = wave;; q += NW) {
+      const int k = s * (2 * q + 1);
+      if (k >= cr.nsb) break;
+      cr_eliminate_node<B>(cr, s, k, lane);
+    }
+    __syncthreads();
+    for (int q = wave;; q += NW) {
+      const int j = 2 * s * q;
+      if (j >= cr.nsb) break;
+      cr_update_node<B>(cr, s, j, lane, w);
+    }
+    __syncthreads();
+    s_last = s;
+  }
+  if (wave == 0) cr_root_node<B>(cr, lane);
+  __syncthreads();
+  if (x == nullptr) return;
+  if ((int)threadIdx.x < B) {
+    double v = 0.0;
+#pragma unroll
+    for (int c = 0; c < B; ++c) v += cr.Dinv[threadIdx.x * B + c] * w[c];
+    x[threadIdx.x] = v;
+  }
+  __syncthreads();
+  for (int s = s_last; s >= s_start && s >= 1; s /= 2) {
+    for (int t = threadIdx.x;; t += kCrTopThreads) {
+      const int k = s * (2 * (t / B) + 1);
+      if (k >= cr.nsb) break;
+      cr_backward_row<B>(cr, s, k, t % B, w, x);
+    }
+    __syncthreads();
+  }
 }
 
 // forward sweep on right-hand sides (blockIdx.y selects the rhs, `stride` doubles apart):
@@ -732,21 +854,7 @@ __global__ void k_cr_backward(CrView cr, int s, const double* __restrict__ w, do
   const int q = t / B, r = t % B;
   const int k = s * (2 * q + 1);
   if (k >= cr.nsb) return;
-  w += stride * blockIdx.y;
-  x += stride * blockIdx.y;
-  const size_t off = (size_t)k * B * B;
-  const double* wk = w + (size_t)k * B;
-  const double* xl = x + (size_t)(k - s) * B;
-  const bool has_right = (k + s) < cr.nsb;
-  const double* xr = x + (size_t)(has_right ? (k + s) : k) * B;
-  double v = 0.0;
-#pragma unroll
-  for (int c = 0; c < B; ++c) {
-    v += cr.Dinv[off + r * B + c] * wk[c];
-    v -= cr.Gl[off + r * B + c] * xl[c];
-    if (has_right) v -= cr.Gr[off + r * B + c] * xr[c];
-  }
-  x[(size_t)k * B + r] = v;
+  cr_backward_row<B>(cr, s, k, r, w + stride * blockIdx.y, x + stride * blockIdx.y);
 }
 
 template <int B>
@@ -761,18 +869,34 @@ __global__ void k_cr_root_solve(CrView cr, const double* __restrict__ w, double*
   x[r] = v;
 }
 
+// first stride handled by the fused single-workgroup kernel: at most kCrTopNodes eliminations
+constexpr int kCrTopNodes = 32;
+static int cr_top_start(int nsb) {
+  int s = 1;
+  while (s < nsb && (nsb - s + 2 * s - 1) / (2 * s) > kCrTopNodes) s *= 2;
+  return s;
+}
+
+// x == nullptr: factorise only (w, if given, still receives the forward sweep)
 template <int B>
-static void cr_factor_t(hipStream_t st, const CrView& cr, double* w) {
-  for (int s = 1; s < cr.nsb; s *= 2) {
+static void cr_factor_t(hipStream_t st, const CrView& cr, double* w, double* x) {
+  const int s_top = cr_top_start(cr.nsb);
+  for (int s = 1; s < s_top; s *= 2) {
     const int n_elim = (cr.nsb - s + 2 * s - 1) / (2 * s);
     const int n_surv = (cr.nsb + 2 * s - 1) / (2 * s);
     hipLaunchKernelGGL(k_cr_eliminate<B>, dim3(n_elim), dim3(WAVE), 0, st, cr, s);
     hipLaunchKernelGGL(k_cr_update<B>, dim3(n_surv), dim3(WAVE), 0, st, cr, s, w);
   }
-  hipLaunchKernelGGL(k_cr_root<B>, dim3(1), dim3(WAVE), 0, st, cr);
+  hipLaunchKernelGGL(k_cr_top<B>, dim3(1), dim3(kCrTopThreads), 0, st, cr, s_top, w, x);
+  if (x != nullptr) {
+    for (int s = s_top / 2; s >= 1; s /= 2) {
+      const int n_elim = (cr.nsb - s + 2 * s - 1) / (2 * s);
+      hipLaunchKernelGGL(k_cr_backward<B>, dim3((n_elim * B + 127) / 128, 1), dim3(128), 0, st, cr, s, w, x, (size_t)0);
+    }
+  }
 }
 
-// back substitution only (the forward sweep already happened inside cr_factor_t(.., w))
+// back substitution only, any number of right-hand sides (after cr_fwd_t)
 template <int B>
 static void cr_back_t(hipStream_t st, const CrView& cr, const double* w, double* x, int nrhs, size_t stride) {
   int s_last = 0;
@@ -800,19 +924,19 @@ static void cr_solve_t(hipStream_t st, const CrView& cr, double* w, double* x, i
 
 void launch_cr_factor(hipStream_t st, const CrView& cr) {
   switch (cr.B) {
-    case 3: cr_factor_t<3>(st, cr, nullptr); break;
-    case 6: cr_factor_t<6>(st, cr, nullptr); break;
-    case 9: cr_factor_t<9>(st, cr, nullptr); break;
-    default: cr_factor_t<12>(st, cr, nullptr); break;
+    case 3: cr_factor_t<3>(st, cr, nullptr, nullptr); break;
+    case 6: cr_factor_t<6>(st, cr, nullptr, nullptr); break;
+    case 9: cr_factor_t<9>(st, cr, nullptr, nullptr); break;
+    default: cr_factor_t<12>(st, cr, nullptr, nullptr); break;
   }
 }
 
 void launch_cr_factor_solve(hipStream_t st, const CrView& cr, double* w, double* x) {
   switch (cr.B) {
-    case 3: cr_factor_t<3>(st, cr, w); cr_back_t<3>(st, cr, w, x, 1, 0); break;
-    case 6: cr_factor_t<6>(st, cr, w); cr_back_t<6>(st, cr, w, x, 1, 0); break;
-    case 9: cr_factor_t<9>(st, cr, w); cr_back_t<9>(st, cr, w, x, 1, 0); break;
-    default: cr_factor_t<12>(st, cr, w); cr_back_t<12>(st, cr, w, x, 1, 0); break;
+    case 3: cr_factor_t<3>(st, cr, w, x); break;
+    case 6: cr_factor_t<6>(st, cr, w, x); break;
+    case 9: cr_factor_t<9>(st, cr, w, x); break;
+    default: cr_factor_t<12>(st, cr, w, x); break;
   }
 }
 
