@@ -490,48 +490,46 @@ void launch_jacobi_scale(hipStream_t st, int n_poses, int npad, int Wb, const do
 // (Wb consecutive poses each) in the Jacobi-scaled space with the LM diagonal
 //   D^2 = clamp(diag(S H S), min, max) / mu     
 // ===========================================================================================
+// one thread per (super-block k, row a, column b): coalesced stores of D and L
 __global__ void k_build_system(int n_poses, int Wb, const double* __restrict__ Hband, const double* __restrict__ g,
                                const double* __restrict__ scale, double mu, double min_diag, double max_diag, CrView cr,
                                double* __restrict__ rhs) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int B = cr.B;
-  if (t >= cr.nsb * B) return;
-  const int k = t / B, a = t % B;
+  const int B = cr.B, BB = B * B;
+  if (t >= cr.nsb * BB) return;
+  const int k = t / BB, e = t % BB, a = e / B, b = e % B;
   const int i = k * Wb + a / 3, ca = a % 3;
-  double* Drow = cr.D + ((size_t)k * B + a) * B;
-  double* Lrow = cr.L + ((size_t)k * B + a) * B;
-  if (i >= n_poses) {
-    for (int b = 0; b < B; ++b) { Drow[b] = (b == a) ? 1.0 : 0.0; Lrow[b] = 0.0; }
-    rhs[t] = 0.0;
+  if (i >= n_poses) {     // padding rows of the last super-block: identity
+    cr.D[t] = (b == a) ? 1.0 : 0.0;
+    cr.L[t] = 0.0;
+    if (b == 0) rhs[k * B + a] = 0.0;
     return;
   }
   const int W1 = Wb + 1;
   const double sa = scale[3 * i + ca];
-  for (int b = 0; b < B; ++b) {
-    const int i2 = k * Wb + b / 3, cb = b % 3;
-    double v = 0.0;
-    if (i2 < n_poses) {
-      v = (i2 >= i) ? Hband[((size_t)i * W1 + (i2 - i)) * 9 + ca * 3 + cb]
-                    : Hband[((size_t)i2 * W1 + (i - i2)) * 9 + cb * 3 + ca];
-      v *= sa * scale[3 * i2 + cb];
-    }
-    if (b == a && i > 0) v += fmin(fmax(v, min_diag), max_diag) / mu;
-    Drow[b] = v;
-    double l = 0.0;
-    if (k > 0) {
-      const int i3 = (k - 1) * Wb + b / 3;
-      const int d = i - i3;
-      if (d <= Wb) l = Hband[((size_t)i3 * W1 + d) * 9 + cb * 3 + ca] * sa * scale[3 * i3 + cb];
-    }
-    Lrow[b] = l;
+  const int i2 = k * Wb + b / 3, cb = b % 3;
+  double v = 0.0;
+  if (i2 < n_poses) {
+    v = (i2 >= i) ? Hband[((size_t)i * W1 + (i2 - i)) * 9 + ca * 3 + cb]
+                  : Hband[((size_t)i2 * W1 + (i - i2)) * 9 + cb * 3 + ca];
+    v *= sa * scale[3 * i2 + cb];
   }
-  rhs[t] = -sa * g[3 * i + ca];
+  if (b == a && i > 0) v += fmin(fmax(v, min_diag), max_diag) / mu;
+  cr.D[t] = v;
+  double l = 0.0;
+  if (k > 0) {
+    const int i3 = (k - 1) * Wb + b / 3;
+    const int d = i - i3;
+    if (d <= Wb) l = Hband[((size_t)i3 * W1 + d) * 9 + cb * 3 + ca] * sa * scale[3 * i3 + cb];
+  }
+  cr.L[t] = l;
+  if (b == 0) rhs[k * B + a] = -sa * g[3 * i + ca];
 }
 
 void launch_build_system(hipStream_t st, int n_poses, int Wb, const LinView& lin, const double* scale, double mu,
                          double min_diag, double max_diag, const CrView& cr, double* rhs) {
-  const int tot = cr.nsb * cr.B;
-  hipLaunchKernelGGL(k_build_system, dim3((tot + 127) / 128), dim3(128), 0, st, n_poses, Wb, lin.Hband, lin.g, scale, mu,
+  const int tot = cr.nsb * cr.B * cr.B;
+  hipLaunchKernelGGL(k_build_system, dim3((tot + 255) / 256), dim3(256), 0, st, n_poses, Wb, lin.Hband, lin.g, scale, mu,
                      min_diag, max_diag, cr, rhs);
 }
 
