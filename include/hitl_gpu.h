@@ -237,6 +237,33 @@ int hitl_comm_unique_id(void* out128);
 int hitl_partition_range(int64_t n_poses, const int64_t* obs_offset, int32_t rank,
                          int32_t world_size, int64_t* begin, int64_t* end);
 
+/* ---- file formats either side of the path (host-only, no GPU needed) ----
+ * hitl_io_load_stfs_covars   == loadPoseGraph      (HitLSLAM_main.cpp:192-300): rows of 16 numbers
+ *     "pose_x,pose_y,pose_theta,obs_x,obs_y, n_x,n_y, c00..c22" with obs/normal in the WORLD frame;
+ *     rows are grouped into poses on any bit difference of (x,y,theta); scans come back in the
+ *     robot frame, SoA, ready for hitl_solver_set_map.  fix_normals = 0 reproduces the reference's
+ *     normal transform R(-theta)(n - t) (:269, :293); != 0 rotates normals only.
+ * hitl_io_save_stfs_covars   == SaveStfsandCovars  (vector_mapping_main.cpp:1855-1901), "%.4f" x7, "%f" x9.
+ * hitl_io_save_results       == saveHitLResults    (HitLSLAM_main.cpp:572-581), "%f %f %f\n" per pose. */
+typedef struct hitl_posegraph hitl_posegraph;
+int hitl_io_load_stfs_covars(const char* path, int fix_normals, hitl_posegraph** out);
+void hitl_posegraph_free(hitl_posegraph*);
+int64_t hitl_posegraph_num_poses(const hitl_posegraph*);
+int64_t hitl_posegraph_num_obs(const hitl_posegraph*);
+double hitl_posegraph_timestamp(const hitl_posegraph*);
+const char* hitl_posegraph_map_name(const hitl_posegraph*);
+const float* hitl_posegraph_poses(const hitl_posegraph*);        /* n*3 (x, y, theta)      */
+const float* hitl_posegraph_cov9(const hitl_posegraph*);         /* n*9 row-major          */
+const int64_t* hitl_posegraph_obs_offset(const hitl_posegraph*); /* n+1                    */
+const float* hitl_posegraph_px(const hitl_posegraph*);
+const float* hitl_posegraph_py(const hitl_posegraph*);
+const float* hitl_posegraph_nx(const hitl_posegraph*);
+const float* hitl_posegraph_ny(const hitl_posegraph*);
+int hitl_io_save_stfs_covars(const char* path, const char* map_name, double timestamp, int64_t n_poses,
+                             const float* poses_xyt, const int64_t* obs_offset, const float* px, const float* py,
+                             const float* nx, const float* ny, const float* cov9 /* may be NULL */);
+int hitl_io_save_results(const char* path, int64_t n_poses, const float* poses_xyt);
+
 const char* hitl_status_string(int status);
 const char* hitl_last_error(void);       /* thread-local detail of the last failure      */
 int hitl_abi_version(void);
