@@ -1,0 +1,53 @@
+// Test driver of hitl_slam_amd/shim/JointOptGpu.h: fills a JointOpt object the way
+// HitLSLAM::Run does (HitLSLAM.cpp:450-454) from a .stfs.covars file + a constraint list,
+// calls Run-equivalent, writes the poses with hitl_io_save_results.
+// The tiny structs below stand in for the reference's Eigen/perception_2d types ONLY as
+// template arguments of the shim (same accessors), so the test builds without Eigen.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "JointOptGpu.h"
+
+struct V2 { float v[2]; float& x() { return v[0]; } float& y() { return v[1]; } float x() const { return v[0]; } float y() const { return v[1]; } };
+struct P2 { V2 translation; float angle; };
+struct M3 { float m[9]; float& operator()(int r, int c) { return m[3 * r + c]; } float operator()(int r, int c) const { return m[3 * r + c]; } };
+struct HC { unsigned type; int constrained_pose_id, anchor_pose_id; float delta_parallel, delta_perpendicular, delta_angle, relative_penalty_dir; };
+typedef hitl::JointOptGpuT<P2, V2, M3, HC> JointOpt;
+
+int main(int argc, char** argv) {
+  if (argc < 5) { std::fprintf(stderr, "usage: shim_driver map.stfs.covars constraints.txt mode out.txt\n"); return 64; }
+  hitl_posegraph* g = NULL;
+  if (hitl_io_load_stfs_covars(argv[1], 1, &g) != HITL_OK) return 65;
+  JointOpt jo;
+  const int64_t n = hitl_posegraph_num_poses(g);
+  const int64_t* off = hitl_posegraph_obs_offset(g);
+  jo.poses_.resize(n); jo.robot_frame_point_clouds_.resize(n); jo.robot_frame_normal_clouds_.resize(n); jo.covariances_.resize(n);
+  for (int64_t i = 0; i < n; ++i) {
+    jo.poses_[i].translation.x() = hitl_posegraph_poses(g)[3 * i]; jo.poses_[i].translation.y() = hitl_posegraph_poses(g)[3 * i + 1];
+    jo.poses_[i].angle = hitl_posegraph_poses(g)[3 * i + 2];
+    for (int q = 0; q < 9; ++q) jo.covariances_[i].m[q] = hitl_posegraph_cov9(g)[9 * i + q];
+    for (int64_t k = off[i]; k < off[i + 1]; ++k) {
+      V2 p = {{hitl_posegraph_px(g)[k], hitl_posegraph_py(g)[k]}}, nn = {{hitl_posegraph_nx(g)[k], hitl_posegraph_ny(g)[k]}};
+      jo.robot_frame_point_clouds_[i].push_back(p); jo.robot_frame_normal_clouds_[i].push_back(nn);
+    }
+  }
+  FILE* f = std::fopen(argv[2], "r");
+  if (!f) return 66;
+  std::vector<HC> group;
+  HC h;
+  while (std::fscanf(f, "%u %d %d %f %f %f %f", &h.type, &h.constrained_pose_id, &h.anchor_pose_id, &h.delta_parallel,
+                     &h.delta_perpendicular, &h.delta_angle, &h.relative_penalty_dir) == 7) group.push_back(h);
+  std::fclose(f);
+  if (!group.empty()) jo.human_constraints_.push_back(group);
+  jo.SetMode(std::atoi(argv[3]), 3);
+  jo.want_gradients = true;
+  const int st = jo.RunStatus();
+  if (st != HITL_OK) { std::fprintf(stderr, "shim: %s (%s)\n", hitl_status_string(st), hitl_last_error()); return st == HITL_ERR_NO_DEVICE ? 3 : 70; }
+  std::vector<float> xyt(3 * n);
+  for (int64_t i = 0; i < n; ++i) { xyt[3 * i] = jo.poses_[i].translation.x(); xyt[3 * i + 1] = jo.poses_[i].translation.y(); xyt[3 * i + 2] = jo.poses_[i].angle; }
+  if (hitl_io_save_results(argv[4], n, xyt.data()) != HITL_OK) return 67;
+  std::printf("iterations %d num_hc_residuals %d final_cost %.17g gradients %zu\n", jo.Summary().iterations, jo.num_hc_residuals_, jo.Summary().final_cost, jo.gradients_.size());
+  hitl_posegraph_free(g);
+  return 0;
+}

@@ -1,0 +1,67 @@
+"""The JointOpt drop-in class (hitl_slam_amd/shim/JointOptGpu.h): it
+compiles with plain g++ against include/hitl_gpu.h + libhitlgpu.so, fails loudly without a
+GPU, and on a GPU reproduces the oracle when driven like HitLSLAM::Run drives JointOpt."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import figure8
+from hitl_slam_amd import abi
+from hitl_slam_amd import io as hio
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "hitl_slam_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def driver(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("shim") / "shim_driver")
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), "-I",
+                           os.path.join(ROOT, "hitl_slam_amd", "shim"), os.path.join(ROOT, "tests", "shim_driver.cpp"), "-o", exe,
+                           "-L", CSRC, "-lhitlgpu", "-Wl,-rpath," + CSRC, "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+@pytest.fixture(scope="module")
+def case(tmp_path_factory):
+    d = figure8.make(100, 64)
+    tmp = tmp_path_factory.mktemp("shimcase")
+    path = str(tmp / "fig8.stfs.covars")
+    hio.save_stfs_covars(path, "AMRL", 1.0, d["init"], d["off"], d["px"], d["py"], d["nx"], d["ny"], d["cov"])
+    rows = figure8.constraints(d["gt"], 2, 1)
+    cpath = str(tmp / "constraints.txt")
+    with open(cpath, "w") as f:
+        for r in rows:
+            f.write("%d %d %d %.9g %.9g %.9g %.9g\n" % r)
+    return path, cpath, rows, str(tmp / "out.txt")
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
+def test_shim_compiles_and_fails_loudly_without_a_gpu(driver, case):
+    path, cpath, _, out = case
+    r = subprocess.run([driver, path, cpath, "0", out], capture_output=True, text=True)
+    assert r.returncode == 3 and "no CPU fallback" in r.stderr      # HITL_ERR_NO_DEVICE, not a silent fallback
+    assert not os.path.exists(out)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 2])
+def test_shim_reproduces_the_oracle(driver, case, mode):
+    from hitl_slam_amd.api import hc_rows
+    from oracle import hitl_oracle as O
+    path, cpath, rows, out = case
+    r = subprocess.run([driver, path, cpath, str(mode), out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = np.loadtxt(out, dtype=np.float32).reshape(-1, 3)
+    g = hio.load_stfs_covars(path, fix_normals=True)
+    o = O.OracleSolver()
+    o.set_map(g["obs_offset"], g["px"], g["py"], g["nx"], g["ny"], g["cov9"])
+    o.set_human_constraints(hc_rows(rows))
+    if mode:
+        o.find_correspondences(g["poses"], 3, 0)
+    po, so = o.solve(mode, g["poses"])
+    fields = r.stdout.split()
+    assert int(fields[1]) == so.iterations and int(fields[3]) == so.num_hc_residuals and int(fields[7]) == 3 * len(po)
+    assert np.abs(got - po).max() <= 1e-4 + 1e-6      # results file prints "%f"
