@@ -122,6 +122,7 @@ def main():
         opt.rank, opt.world_size = rank, world
         solver = None
         if args.comm == "rccl":
+            ok = 1
             try:
                 from hitl_slam_amd.api import comm_unique_id
                 uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
@@ -132,10 +133,25 @@ def main():
                 keep.append(buf)
                 opt.rccl_unique_id = C.cast(buf, C.c_void_p)
                 solver = H.Solver(opt)
-                solver.comm_selftest()
+            except Exception as e:
+                sys.stderr.write("rank %d: in-library RCCL unavailable (%r)\n" % (rank, e))
+                ok, solver = 0, None
+            # the choice of transport must be the same on every rank
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                try:
+                    solver.comm_selftest()
+                except Exception as e:
+                    sys.stderr.write("rank %d: RCCL self-test failed (%r)\n" % (rank, e))
+                    ok = 0
+                flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
                 comm_kind = "rccl (in-library ncclAllGather)"
-            except Exception as e:   # fall back to torch.distributed (also RCCL) rather than lose the run
-                sys.stderr.write("rank %d: in-library RCCL unavailable (%r); using torch.distributed\n" % (rank, e))
+            else:
+                if solver is not None:
+                    solver.close()
                 solver = None
         if solver is None:
             from hitl_slam_amd.api import torch_allgather_ops
