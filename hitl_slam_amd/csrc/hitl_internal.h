@@ -94,7 +94,7 @@ void launch_gather_iface(hipStream_t st, const double* z0, const double* Z, size
 void launch_combine6(hipStream_t st, int npad, const double* z0, const double* Z, size_t stride, const double* coef6,
                      double* dt);
 // factorise and solve M x = w in one pass (w is destroyed)
-void launch_cr_factor_solve(hipStream_t st, const CrView& cr, double* w, double* x);
+void launch_cr_factor_solve(hipStream_t st, const CrView& cr, double* w, double* x, int nrhs = 1, size_t stride = 0);
 // x = M^{-1} w   (w is destroyed)
 void launch_cr_solve(hipStream_t st, const CrView& cr, double* w, double* x);
 // y = (S H S [+ D^2]) v ; damping added when mu > 0

@@ -597,7 +597,7 @@ __global__ __launch_bounds__(WAVE) void k_cr_eliminate(CrView cr, int s) {
 // With w != nullptr the right-hand side rides along (w_j -= Gr[k1]^T w_k1 + Gl[k2]^T w_k2), which
 // saves the separate forward sweep when a factorisation is followed by exactly one solve.
 template <int B>
-__device__ __forceinline__ void cr_update_node(const CrView& cr, int s, int j, int lane, double* w) {
+__device__ __forceinline__ void cr_update_node(const CrView& cr, int s, int j, int lane, double* w, int nrhs, size_t stride) {
   const size_t off = (size_t)j * B * B;
   const int k1 = j - s, k2 = j + s;
   const bool has1 = k1 >= 0, has2 = k2 < cr.nsb, has_ll = (k1 - s) >= 0;
@@ -628,18 +628,21 @@ __device__ __forceinline__ void cr_update_node(const CrView& cr, int s, int j, i
   }
   if (grp == 0) {
     if (w != nullptr) {   // rhs forward sweep: w_j[c] -= Gr[k1][:,c] . w_k1 + Gl[k2][:,c] . w_k2
-      double wacc = w[(size_t)j * B + c];
-      if (has1) {
-        const double* wk = w + (size_t)k1 * B;
+      for (int v = 0; v < nrhs; ++v) {
+        double* wv = w + stride * v;
+        double wacc = wv[(size_t)j * B + c];
+        if (has1) {
+          const double* wk = wv + (size_t)k1 * B;
 #pragma unroll
-        for (int r = 0; r < B; ++r) wacc -= b1[r] * wk[r];
-      }
-      if (has2) {
-        const double* wk = w + (size_t)k2 * B;
+          for (int r = 0; r < B; ++r) wacc -= b1[r] * wk[r];
+        }
+        if (has2) {
+          const double* wk = wv + (size_t)k2 * B;
 #pragma unroll
-        for (int r = 0; r < B; ++r) wacc -= b2[r] * wk[r];
+          for (int r = 0; r < B; ++r) wacc -= b2[r] * wk[r];
+        }
+        wv[(size_t)j * B + c] = wacc;
       }
-      w[(size_t)j * B + c] = wacc;
     }
 #pragma unroll
     for (int r = 0; r < B; ++r) cr.D[off + r * B + c] -= acc[r];
@@ -660,7 +663,7 @@ __device__ __forceinline__ void lds_load(double* dst, const double* __restrict__
 // With w != nullptr the right-hand side rides along (w_j -= Gr[k1]^T w_k1 + Gl[k2]^T w_k2), which
 // saves the separate forward sweep when a factorisation is followed by exactly one solve.
 template <int B>
-__global__ __launch_bounds__(WAVE) void k_cr_update(CrView cr, int s, double* __restrict__ w) {
+__global__ __launch_bounds__(WAVE) void k_cr_update(CrView cr, int s, double* __restrict__ w, int nrhs, size_t stride) {
   __shared__ double sLj[B * B], sG[B * B], sL2[B * B];
   constexpr int NE = (B * B + WAVE - 1) / WAVE;
   const int j = 2 * s * blockIdx.x;
@@ -674,15 +677,22 @@ __global__ __launch_bounds__(WAVE) void k_cr_update(CrView cr, int s, double* __
     acc[it] = (e < B * B) ? cr.D[off + e] : 0.0;
   }
   const bool do_w = (w != nullptr) && ((int)threadIdx.x < B);
-  double wacc = do_w ? w[(size_t)j * B + threadIdx.x] : 0.0;
+  constexpr int kMaxRhs = 8;
+  double wacc[kMaxRhs];
+#pragma unroll
+  for (int v = 0; v < kMaxRhs; ++v) wacc[v] = (do_w && v < nrhs) ? w[stride * v + (size_t)j * B + threadIdx.x] : 0.0;
   if (k1 >= 0) {
     lds_load<B>(sLj, cr.L + off);
     lds_load<B>(sG, cr.Gr + (size_t)k1 * B * B);
     __syncthreads();
     if (do_w) {
-      const double* wk = w + (size_t)k1 * B;
 #pragma unroll
-      for (int r = 0; r < B; ++r) wacc -= sG[r * B + threadIdx.x] * wk[r];
+      for (int v = 0; v < kMaxRhs; ++v)
+        if (v < nrhs) {
+          const double* wk = w + stride * v + (size_t)k1 * B;
+#pragma unroll
+          for (int r = 0; r < B; ++r) wacc[v] -= sG[r * B + threadIdx.x] * wk[r];
+        }
     }
 #pragma unroll
     for (int it = 0; it < NE; ++it) {
@@ -715,9 +725,13 @@ __global__ __launch_bounds__(WAVE) void k_cr_update(CrView cr, int s, double* __
     lds_load<B>(sG, cr.Gl + (size_t)k2 * B * B);
     __syncthreads();
     if (do_w) {
-      const double* wk = w + (size_t)k2 * B;
 #pragma unroll
-      for (int r = 0; r < B; ++r) wacc -= sG[r * B + threadIdx.x] * wk[r];
+      for (int v = 0; v < kMaxRhs; ++v)
+        if (v < nrhs) {
+          const double* wk = w + stride * v + (size_t)k2 * B;
+#pragma unroll
+          for (int r = 0; r < B; ++r) wacc[v] -= sG[r * B + threadIdx.x] * wk[r];
+        }
     }
 #pragma unroll
     for (int it = 0; it < NE; ++it) {
@@ -731,7 +745,11 @@ __global__ __launch_bounds__(WAVE) void k_cr_update(CrView cr, int s, double* __
       }
     }
   }
-  if (do_w) w[(size_t)j * B + threadIdx.x] = wacc;
+  if (do_w) {
+#pragma unroll
+    for (int v = 0; v < kMaxRhs; ++v)
+      if (v < nrhs) w[stride * v + (size_t)j * B + threadIdx.x] = wacc[v];
+  }
 #pragma unroll
   for (int it = 0; it < NE; ++it) {
     const int e = threadIdx.x + it * WAVE;
@@ -780,7 +798,7 @@ __device__ __forceinline__ void cr_backward_row(const CrView& cr, int s, int k, 
 // workgroup-local global memory).
 constexpr int kCrTopThreads = 1024;
 template <int B>
-__global__ __launch_bounds__(kCrTopThreads) void k_cr_top(CrView cr, int s_start, double* w, double* x) {
+__global__ __launch_bounds__(kCrTopThreads) void k_cr_top(CrView cr, int s_start, double* w, double* x, int nrhs, size_t stride) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   constexpr int NW = kCrTopThreads / WAVE;
   int s_last = 0;
@@ -794,7 +812,7 @@ __global__ __launch_bounds__(kCrTopThreads) void k_cr_top(CrView cr, int s_start
     for (int q = wave;; q += NW) {
       const int j = 2 * s * q;
       if (j >= cr.nsb) break;
-      cr_update_node<B>(cr, s, j, lane, w);
+      cr_update_node<B>(cr, s, j, lane, w, nrhs, stride);
     }
     __syncthreads();
     s_last = s;
@@ -802,19 +820,21 @@ __global__ __launch_bounds__(kCrTopThreads) void k_cr_top(CrView cr, int s_start
   if (wave == 0) cr_root_node<B>(cr, lane);
   __syncthreads();
   if (x == nullptr) return;
-  if ((int)threadIdx.x < B) {
+  if ((int)threadIdx.x < B * nrhs) {
+    const int vv = threadIdx.x / B, r = threadIdx.x % B;
     double v = 0.0;
 #pragma unroll
-    for (int c = 0; c < B; ++c) v += cr.Dinv[threadIdx.x * B + c] * w[c];
-    x[threadIdx.x] = v;
+    for (int c = 0; c < B; ++c) v += cr.Dinv[r * B + c] * w[stride * vv + c];
+    x[stride * vv + r] = v;
   }
   __syncthreads();
   for (int s = s_last; s >= s_start && s >= 1; s /= 2) {
-    for (int t = threadIdx.x;; t += kCrTopThreads) {
-      const int k = s * (2 * (t / B) + 1);
-      if (k >= cr.nsb) break;
-      cr_backward_row<B>(cr, s, k, t % B, w, x);
-    }
+    for (int vv = 0; vv < nrhs; ++vv)
+      for (int t = threadIdx.x;; t += kCrTopThreads) {
+        const int k = s * (2 * (t / B) + 1);
+        if (k >= cr.nsb) break;
+        cr_backward_row<B>(cr, s, k, t % B, w + stride * vv, x + stride * vv);
+      }
     __syncthreads();
   }
 }
@@ -877,19 +897,19 @@ static int cr_top_start(int nsb) {
 
 // x == nullptr: factorise only (w, if given, still receives the forward sweep)
 template <int B>
-static void cr_factor_t(hipStream_t st, const CrView& cr, double* w, double* x) {
+static void cr_factor_t(hipStream_t st, const CrView& cr, double* w, double* x, int nrhs, size_t stride) {
   const int s_top = cr_top_start(cr.nsb);
   for (int s = 1; s < s_top; s *= 2) {
     const int n_elim = (cr.nsb - s + 2 * s - 1) / (2 * s);
     const int n_surv = (cr.nsb + 2 * s - 1) / (2 * s);
     hipLaunchKernelGGL(k_cr_eliminate<B>, dim3(n_elim), dim3(WAVE), 0, st, cr, s);
-    hipLaunchKernelGGL(k_cr_update<B>, dim3(n_surv), dim3(WAVE), 0, st, cr, s, w);
+    hipLaunchKernelGGL(k_cr_update<B>, dim3(n_surv), dim3(WAVE), 0, st, cr, s, w, nrhs, stride);
   }
-  hipLaunchKernelGGL(k_cr_top<B>, dim3(1), dim3(kCrTopThreads), 0, st, cr, s_top, w, x);
+  hipLaunchKernelGGL(k_cr_top<B>, dim3(1), dim3(kCrTopThreads), 0, st, cr, s_top, w, x, nrhs, stride);
   if (x != nullptr) {
     for (int s = s_top / 2; s >= 1; s /= 2) {
       const int n_elim = (cr.nsb - s + 2 * s - 1) / (2 * s);
-      hipLaunchKernelGGL(k_cr_backward<B>, dim3((n_elim * B + 127) / 128, 1), dim3(128), 0, st, cr, s, w, x, (size_t)0);
+      hipLaunchKernelGGL(k_cr_backward<B>, dim3((n_elim * B + 127) / 128, nrhs), dim3(128), 0, st, cr, s, w, x, stride);
     }
   }
 }
@@ -922,19 +942,20 @@ static void cr_solve_t(hipStream_t st, const CrView& cr, double* w, double* x, i
 
 void launch_cr_factor(hipStream_t st, const CrView& cr) {
   switch (cr.B) {
-    case 3: cr_factor_t<3>(st, cr, nullptr, nullptr); break;
-    case 6: cr_factor_t<6>(st, cr, nullptr, nullptr); break;
-    case 9: cr_factor_t<9>(st, cr, nullptr, nullptr); break;
-    default: cr_factor_t<12>(st, cr, nullptr, nullptr); break;
+    case 3: cr_factor_t<3>(st, cr, nullptr, nullptr, 0, 0); break;
+    case 6: cr_factor_t<6>(st, cr, nullptr, nullptr, 0, 0); break;
+    case 9: cr_factor_t<9>(st, cr, nullptr, nullptr, 0, 0); break;
+    default: cr_factor_t<12>(st, cr, nullptr, nullptr, 0, 0); break;
   }
 }
 
-void launch_cr_factor_solve(hipStream_t st, const CrView& cr, double* w, double* x) {
+void launch_cr_factor_solve(hipStream_t st, const CrView& cr, double* w, double* x, int nrhs, size_t stride) {
+  // nrhs <= 8 right-hand sides `stride` doubles apart ride through the factorisation
   switch (cr.B) {
-    case 3: cr_factor_t<3>(st, cr, w, x); break;
-    case 6: cr_factor_t<6>(st, cr, w, x); break;
-    case 9: cr_factor_t<9>(st, cr, w, x); break;
-    default: cr_factor_t<12>(st, cr, w, x); break;
+    case 3: cr_factor_t<3>(st, cr, w, x, nrhs, stride); break;
+    case 6: cr_factor_t<6>(st, cr, w, x, nrhs, stride); break;
+    case 9: cr_factor_t<9>(st, cr, w, x, nrhs, stride); break;
+    default: cr_factor_t<12>(st, cr, w, x, nrhs, stride); break;
   }
 }
 

@@ -496,7 +496,7 @@ static int prepare(hitl_solver* s, int mode, const float* poses_ref, const float
   TRY(setup_factors(s, poses_ref, poses_global, mode != HITL_MODE_STF_ONLY));
   if (s->world > 1) {
     TRY(s->halo_out.resize(21)); TRY(s->iface_dev.resize(48));
-    TRY(s->rhs6.resize((size_t)6 * s->npad)); TRY(s->z6.resize((size_t)6 * s->npad));
+    TRY(s->rhs6.resize((size_t)7 * s->npad)); TRY(s->z6.resize((size_t)7 * s->npad));
     TRY(s->halo_out.zero(s->stream));
     for (int k = 0; k < 2; ++k) s->cut_C[k].assign((size_t)s->world * 9, 0.0);
   }
@@ -607,12 +607,14 @@ static int linear_solve_and_step_dist(hitl_solver* s, const FactorView& fv, int 
   *iters = 1;
   *ok = true;
   launch_build_system(st, n, fv.band_poses, lv, s->scale.p, mu, mind, maxd, cr, s->rhs.p);
-  launch_copy(st, npad, s->rhs.p, s->wv.p);
-  launch_cr_factor_solve(st, cr, s->wv.p, s->dt.p);            // z0 = M^{-1} b
+  // 7 right-hand sides ride through ONE factorisation: b and the unit vectors of the first/last pose
   const int cols[6] = {3 * s->halo, 3 * s->halo + 1, 3 * s->halo + 2, 3 * (n - 1), 3 * (n - 1) + 1, 3 * (n - 1) + 2};
-  launch_unit_rhs(st, npad, s->rhs6.p, (size_t)npad, cols);
-  launch_cr_solve_multi(st, cr, s->rhs6.p, s->z6.p, 6, (size_t)npad);   // Z = M^{-1} [E_first, E_last]
-  launch_gather_iface(st, s->dt.p, s->z6.p, (size_t)npad, s->scale.p, cols, s->iface_dev.p);
+  launch_copy(st, npad, s->rhs.p, s->rhs6.p);
+  launch_unit_rhs(st, npad, s->rhs6.p + npad, (size_t)npad, cols);
+  launch_cr_factor_solve(st, cr, s->rhs6.p, s->z6.p, 7, (size_t)npad);     // z0 = M^{-1} b, Z = M^{-1} [E_first, E_last]
+  launch_copy(st, npad, s->z6.p, s->dt.p);
+  const double* Z = s->z6.p + npad;
+  launch_gather_iface(st, s->dt.p, Z, (size_t)npad, s->scale.p, cols, s->iface_dev.p);
   double rec[48];
   HIP_TRY(hipMemcpyAsync(rec, s->iface_dev.p, sizeof(rec), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
@@ -662,7 +664,7 @@ static int linear_solve_and_step_dist(hitl_solver* s, const FactorView& fv, int 
     for (int c = 0; c < 3; ++c)
       for (int k = 0; k < 3; ++k) coef[3 + c] += Ct[(size_t)9 * (me + 1) + 3 * c + k] * unext[k];   // Ct_{g+1} u_{g+1}
   }
-  launch_combine6(st, npad, s->dt.p, s->z6.p, (size_t)npad, coef, s->dt.p);
+  launch_combine6(st, npad, s->dt.p, Z, (size_t)npad, coef, s->dt.p);
   launch_spmv_step(st, n, npad, fv, lv, s->scale.p, s->dt.p, s->rhs.p, xcur, s->qv.p, xcand, s->step_partials.p);
   HIP_TRY(hipGetLastError());
   StepScalars loc;
