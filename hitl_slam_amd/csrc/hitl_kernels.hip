@@ -888,7 +888,7 @@ __global__ void k_cr_root_solve(CrView cr, const double* __restrict__ w, double*
 }
 
 // first stride handled by the fused single-workgroup kernel: at most kCrTopNodes eliminations
-constexpr int kCrTopNodes = 32;
+constexpr int kCrTopNodes = 6;
 static int cr_top_start(int nsb) {
   int s = 1;
   while (s < nsb && (nsb - s + 2 * s - 1) / (2 * s) > kCrTopNodes) s *= 2;
