@@ -106,8 +106,10 @@ def main():
     t0 = time.time()
     p = S.params(n_global, M, seed=seed, poses_per_floor=ppf)
     gt, init, cov = S.poses(p)
-    begin, end = rank * n_local, (rank + 1) * n_local        # floors hold ppf poses: cuts fall between floors
-    off, px, py, nx, ny = S.scans(p, begin, end)
+    begin, end = rank * n_local, (rank + 1) * n_local        # this rank's owned pose range
+    halo = 2 * wl["window"] if use_dist else 0               # scans + state of the neighbours' nearest poses
+    lo, hi = begin - (halo if rank > 0 else 0), end + (halo if rank < world - 1 else 0)
+    off, px, py, nx, ny = S.scans(p, lo, hi)
     rows = S.constraints(p, gt, wl["groups"], kind=wl["kind"], begin=begin, end=end)
     init_l = np.ascontiguousarray(init[begin:end])
     gen_s = time.time() - t0
@@ -160,8 +162,8 @@ def main():
             ops, fn = torch_allgather_ops(device=torch.device("cuda", dev_index) if args.backend == "nccl" else None)
             solver.set_comm(ops, fn)
             comm_kind = "torch.distributed all_gather (%s backend)" % ("nccl = RCCL" if args.backend == "nccl" else "gloo")
-        solver.set_partition(begin, n_global)
-        solver.set_map(off, px, py, nx, ny, cov[begin:end])
+        solver.set_partition(begin, n_global, halo)
+        solver.set_map(off, px, py, nx, ny, cov[lo:hi])
         solver.set_human_constraints(rows)          # global pose ids
         pose_arg = init                             # global pose array
     else:
@@ -173,8 +175,8 @@ def main():
     t0 = time.time()
     solver.find_correspondences(pose_arg, wl["window"])
     match_ms = (time.time() - t0) * 1e3
-    n_obs = int(off[-1])
-    n_pairs_l, n_matches_l = solver.correspondence_counts()     # this rank's submap
+    n_obs = int(off[end - lo] - off[begin - lo])               # observations of the OWNED poses
+    n_pairs_l, n_matches_l = solver.correspondence_counts()     # this rank's submap (incl. the few halo-sourced pairs)
 
     # ---- warm-up, then exactly K timed re-solves -----------------------------------------------------
     for _ in range(args.warmup):

@@ -289,11 +289,13 @@ class Solver(SolverBase):
             return ""
 
     # -- pose-range submaps (world_size > 1) -----------------------------------------------
-    def set_partition(self, global_begin, n_global):
+    def set_partition(self, global_begin, n_global, halo_poses):
+        """Submap rank: owns GLOBAL poses from global_begin; set_map then takes the scans of
+        [global_begin - halo, end + halo) (no lower halo on rank 0, no upper halo on the last rank)."""
         f = self._lib.hitl_solver_set_partition
-        f.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
+        f.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int32]
         f.restype = C.c_int
-        st = f(self._h, int(global_begin), int(n_global))
+        st = f(self._h, int(global_begin), int(n_global), int(halo_poses))
         if st != abi.OK:
             raise HitlError(st, "hitl_solver_set_partition", self._detail())
         self._n_global = int(n_global)

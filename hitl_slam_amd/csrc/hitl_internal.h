@@ -49,9 +49,9 @@ struct FactorView {         // everything assemble needs besides the per-pair r/
   const int* ob_lo; const int* ob_hi; const int* ob_fwd; const int* ob_rev;   // E each
   const int* obadj_off;       // n+1
   const int* obadj_ent;       // entry*2 + transposed
-  // pose-range submaps (world_size > 1)
-  double* halo_out;           // rank > 0: 21 doubles exported by local pose 0 (see k_assemble), else nullptr
-  int tail_coupled;           // rank < world-1: the last pose also receives the next rank's contribution
+  // constant poses (global pose 0, submap halos) and the owned range of a submap
+  const unsigned char* fixed; // n : 1 = constant
+  int own_lo, own_hi;         // cost / |g|max / step scalars are taken over local poses [own_lo, own_hi)
 };
 
 struct LinView {            // one linearisation (double buffered by the driver)
@@ -82,17 +82,21 @@ void launch_assemble(hipStream_t st, const MapView& map, const PairView& pr, con
                      const double* x, const LinView& lin);
 inline int assemble_blocks(int n_poses) { return (n_poses + 127) / 128; }
 void launch_jacobi_scale(hipStream_t st, int n_poses, int npad, int Wb, const double* Hband, int enable,
-                         double* scale);
+                         const unsigned char* fixed, double* scale);
 void launch_build_system(hipStream_t st, int n_poses, int Wb, const LinView& lin, const double* scale,
-                         double mu, double min_diag, double max_diag, const CrView& cr, double* rhs);
+                         const unsigned char* fixed, double mu, double min_diag, double max_diag, const CrView& cr,
+                         double* rhs);
 void launch_cr_factor(hipStream_t st, const CrView& cr);
 void launch_cr_solve_multi(hipStream_t st, const CrView& cr, double* w, double* x, int nrhs, size_t stride);
-void launch_add_halo(hipStream_t st, int n_poses, int Wb, double* Hband, double* g, const double* h12);
-void launch_unit_rhs(hipStream_t st, int npad, double* w, size_t stride, const int* cols6);
+void launch_unit_rhs(hipStream_t st, int npad, double* w, size_t stride, const int* cols_dev, int ncols);
 void launch_gather_iface(hipStream_t st, const double* z0, const double* Z, size_t stride, const double* scale,
-                         const int* cols6, double* out48);
-void launch_combine6(hipStream_t st, int npad, const double* z0, const double* Z, size_t stride, const double* coef6,
-                     double* dt);
+                         const int* cols_dev, int ncols, double* out /* ncols * (ncols + 2) */);
+void launch_combine(hipStream_t st, int npad, const double* z0, const double* Z, size_t stride, const double* coef_dev,
+                    int ncols, double* dt);
+void launch_scatter_halo(hipStream_t st, int cnt, const int* idx, const double* val, const double* sc, double* dt,
+                         double* scale);
+void launch_halo_candidate(hipStream_t st, int cnt, const int* idx, const double* x, const double* scale, const double* dt,
+                           double* xc);
 // factorise and solve M x = w in one pass (w is destroyed)
 void launch_cr_factor_solve(hipStream_t st, const CrView& cr, double* w, double* x, int nrhs = 1, size_t stride = 0);
 // x = M^{-1} w   (w is destroyed)

@@ -339,19 +339,13 @@ __global__ __launch_bounds__(128) void k_assemble(MapView map, PairView pr, Fact
       }
     }
   }
-  if (i == 0 && fv.halo_out != nullptr) {
-    // submap rank > 0: local pose 0 is the previous rank's last pose.  What the straddling
-    // odometry edge adds to THAT pose's diagonal block and gradient, and the cross-cut coupling
-    // block, are exported for the exchange ("shared-pose blocks").
-#pragma unroll
-    for (int q = 0; q < 9; ++q) { fv.halo_out[q] = Hd[q]; fv.halo_out[12 + q] = H1[q]; }
-    fv.halo_out[9] = gi[0]; fv.halo_out[10] = gi[1]; fv.halo_out[11] = gi[2];
-  }
-  if (i == 0) {  // pose 0 is constant (JointOptimization.cpp:824, :1197): identity block, no coupling
-#pragma unroll
-    for (int q = 0; q < 9; ++q) Hd[q] = (q % 4 == 0) ? 1.0 : 0.0;
-    gi[0] = gi[1] = gi[2] = 0.0;
-  }
+  // Constant poses (global pose 0: JointOptimization.cpp:824, :1197; submap halos) keep their
+  // assembled blocks here; k_build_system / k_spmv / k_jacobi_scale treat them as fixed.  Their
+  // rows are only meaningful as COLUMNS of free neighbours (cross-cut coupling blocks).
+  const bool is_fixed = fv.fixed[i] != 0;
+  const bool is_owned = (i >= fv.own_lo) && (i < fv.own_hi);
+  if (is_fixed) { gi[0] = gi[1] = gi[2] = 0.0; }
+  if (!is_owned) cost = 0.0;        // every factor's cost is counted once: by the rank owning it
   double* Hrow = lin.Hband + (size_t)i * (Wb + 1) * 9;
 #pragma unroll
   for (int q = 0; q < 9; ++q) Hrow[q] = Hd[q];
@@ -359,10 +353,10 @@ __global__ __launch_bounds__(128) void k_assemble(MapView map, PairView pr, Fact
   pose_cost = cost;
   pose_gmax = fmax(fabs(gi[0]), fmax(fabs(gi[1]), fabs(gi[2])));
   if (gi[0] != gi[0] || gi[1] != gi[1] || gi[2] != gi[2]) pose_gmax = gi[0] + gi[1] + gi[2];  // NaN propagates
-  if (fv.tail_coupled && i == n - 1) pose_gmax = 0.0;   // completed by the next rank's halo contribution (host)
+  if (!is_owned) pose_gmax = 0.0;
   for (int d = 1; d <= Wb; ++d) {
     double blk[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (i > 0 && i + d < n) {
+    if (i + d < n) {
       if (fv.with_stf) {
         const int fwd = fv.band_pair[((size_t)i * Wb + (d - 1)) * 2];
         const int rev = fv.band_pair[((size_t)i * Wb + (d - 1)) * 2 + 1];
@@ -409,8 +403,7 @@ __global__ __launch_bounds__(128) void k_assemble_offband(FactorView fv, LinView
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= fv.n_offband) return;
   double blk[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  const int lo = fv.ob_lo[e];
-  if (lo > 0) {
+  {
     const int fwd = fv.ob_fwd[e], rev = fv.ob_rev[e];
     if (fwd >= 0) {
       const double* J = lin.pairRJ + (size_t)kPairRJ * fwd + 2;
@@ -470,19 +463,20 @@ __device__ __forceinline__ double block_max(double v, double* sm) {
 }
 
 __global__ void k_jacobi_scale(int n_poses, int npad, int Wb, const double* __restrict__ Hband, int enable,
-                               double* __restrict__ scale) {
+                               const unsigned char* __restrict__ fixed, double* __restrict__ scale) {
   const int a = blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= npad) return;
   double s = 1.0;
-  if (enable && a >= 3 && a < 3 * n_poses) {
+  if (enable && a < 3 * n_poses && !fixed[a / 3]) {
     const int i = a / 3, c = a % 3;
     s = 1.0 / (1.0 + sqrt(Hband[(size_t)i * (Wb + 1) * 9 + c * 3 + c]));
   }
   scale[a] = s;
 }
 
-void launch_jacobi_scale(hipStream_t st, int n_poses, int npad, int Wb, const double* Hband, int enable, double* scale) {
-  hipLaunchKernelGGL(k_jacobi_scale, dim3((npad + 255) / 256), dim3(256), 0, st, n_poses, npad, Wb, Hband, enable, scale);
+void launch_jacobi_scale(hipStream_t st, int n_poses, int npad, int Wb, const double* Hband, int enable,
+                         const unsigned char* fixed, double* scale) {
+  hipLaunchKernelGGL(k_jacobi_scale, dim3((npad + 255) / 256), dim3(256), 0, st, n_poses, npad, Wb, Hband, enable, fixed, scale);
 }
 
 // ===========================================================================================
@@ -492,14 +486,14 @@ void launch_jacobi_scale(hipStream_t st, int n_poses, int npad, int Wb, const do
 // ===========================================================================================
 // one thread per (super-block k, row a, column b): coalesced stores of D and L
 __global__ void k_build_system(int n_poses, int Wb, const double* __restrict__ Hband, const double* __restrict__ g,
-                               const double* __restrict__ scale, double mu, double min_diag, double max_diag, CrView cr,
-                               double* __restrict__ rhs) {
+                               const double* __restrict__ scale, const unsigned char* __restrict__ fixed, double mu,
+                               double min_diag, double max_diag, CrView cr, double* __restrict__ rhs) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int B = cr.B, BB = B * B;
   if (t >= cr.nsb * BB) return;
   const int k = t / BB, e = t % BB, a = e / B, b = e % B;
   const int i = k * Wb + a / 3, ca = a % 3;
-  if (i >= n_poses) {     // padding rows of the last super-block: identity
+  if (i >= n_poses || fixed[i]) {     // padding rows and constant poses: identity
     cr.D[t] = (b == a) ? 1.0 : 0.0;
     cr.L[t] = 0.0;
     if (b == 0) rhs[k * B + a] = 0.0;
@@ -509,28 +503,29 @@ __global__ void k_build_system(int n_poses, int Wb, const double* __restrict__ H
   const double sa = scale[3 * i + ca];
   const int i2 = k * Wb + b / 3, cb = b % 3;
   double v = 0.0;
-  if (i2 < n_poses) {
+  if (i2 < n_poses && !fixed[i2]) {
     v = (i2 >= i) ? Hband[((size_t)i * W1 + (i2 - i)) * 9 + ca * 3 + cb]
                   : Hband[((size_t)i2 * W1 + (i - i2)) * 9 + cb * 3 + ca];
     v *= sa * scale[3 * i2 + cb];
   }
-  if (b == a && i > 0) v += fmin(fmax(v, min_diag), max_diag) / mu;
+  if (b == a) v += fmin(fmax(v, min_diag), max_diag) / mu;
   cr.D[t] = v;
   double l = 0.0;
   if (k > 0) {
     const int i3 = (k - 1) * Wb + b / 3;
     const int d = i - i3;
-    if (d <= Wb) l = Hband[((size_t)i3 * W1 + d) * 9 + cb * 3 + ca] * sa * scale[3 * i3 + cb];
+    if (d <= Wb && !fixed[i3]) l = Hband[((size_t)i3 * W1 + d) * 9 + cb * 3 + ca] * sa * scale[3 * i3 + cb];
   }
   cr.L[t] = l;
   if (b == 0) rhs[k * B + a] = -sa * g[3 * i + ca];
 }
 
-void launch_build_system(hipStream_t st, int n_poses, int Wb, const LinView& lin, const double* scale, double mu,
-                         double min_diag, double max_diag, const CrView& cr, double* rhs) {
+void launch_build_system(hipStream_t st, int n_poses, int Wb, const LinView& lin, const double* scale,
+                         const unsigned char* fixed, double mu, double min_diag, double max_diag, const CrView& cr,
+                         double* rhs) {
   const int tot = cr.nsb * cr.B * cr.B;
-  hipLaunchKernelGGL(k_build_system, dim3((tot + 255) / 256), dim3(256), 0, st, n_poses, Wb, lin.Hband, lin.g, scale, mu,
-                     min_diag, max_diag, cr, rhs);
+  hipLaunchKernelGGL(k_build_system, dim3((tot + 255) / 256), dim3(256), 0, st, n_poses, Wb, lin.Hband, lin.g, scale, fixed,
+                     mu, min_diag, max_diag, cr, rhs);
 }
 
 // ===========================================================================================
@@ -677,22 +672,19 @@ __global__ __launch_bounds__(WAVE) void k_cr_update(CrView cr, int s, double* __
     acc[it] = (e < B * B) ? cr.D[off + e] : 0.0;
   }
   const bool do_w = (w != nullptr) && ((int)threadIdx.x < B);
-  constexpr int kMaxRhs = 8;
-  double wacc[kMaxRhs];
-#pragma unroll
-  for (int v = 0; v < kMaxRhs; ++v) wacc[v] = (do_w && v < nrhs) ? w[stride * v + (size_t)j * B + threadIdx.x] : 0.0;
   if (k1 >= 0) {
     lds_load<B>(sLj, cr.L + off);
     lds_load<B>(sG, cr.Gr + (size_t)k1 * B * B);
     __syncthreads();
     if (do_w) {
+      for (int v = 0; v < nrhs; ++v) {     // each lane read-modify-writes its own entry of w_j
+        double* wv = w + stride * v;
+        const double* wk = wv + (size_t)k1 * B;
+        double acc_w = wv[(size_t)j * B + threadIdx.x];
 #pragma unroll
-      for (int v = 0; v < kMaxRhs; ++v)
-        if (v < nrhs) {
-          const double* wk = w + stride * v + (size_t)k1 * B;
-#pragma unroll
-          for (int r = 0; r < B; ++r) wacc[v] -= sG[r * B + threadIdx.x] * wk[r];
-        }
+        for (int r = 0; r < B; ++r) acc_w -= sG[r * B + threadIdx.x] * wk[r];
+        wv[(size_t)j * B + threadIdx.x] = acc_w;
+      }
     }
 #pragma unroll
     for (int it = 0; it < NE; ++it) {
@@ -725,13 +717,14 @@ __global__ __launch_bounds__(WAVE) void k_cr_update(CrView cr, int s, double* __
     lds_load<B>(sG, cr.Gl + (size_t)k2 * B * B);
     __syncthreads();
     if (do_w) {
+      for (int v = 0; v < nrhs; ++v) {
+        double* wv = w + stride * v;
+        const double* wk = wv + (size_t)k2 * B;
+        double acc_w = wv[(size_t)j * B + threadIdx.x];
 #pragma unroll
-      for (int v = 0; v < kMaxRhs; ++v)
-        if (v < nrhs) {
-          const double* wk = w + stride * v + (size_t)k2 * B;
-#pragma unroll
-          for (int r = 0; r < B; ++r) wacc[v] -= sG[r * B + threadIdx.x] * wk[r];
-        }
+        for (int r = 0; r < B; ++r) acc_w -= sG[r * B + threadIdx.x] * wk[r];
+        wv[(size_t)j * B + threadIdx.x] = acc_w;
+      }
     }
 #pragma unroll
     for (int it = 0; it < NE; ++it) {
@@ -744,11 +737,6 @@ __global__ __launch_bounds__(WAVE) void k_cr_update(CrView cr, int s, double* __
         acc[it] -= v;
       }
     }
-  }
-  if (do_w) {
-#pragma unroll
-    for (int v = 0; v < kMaxRhs; ++v)
-      if (v < nrhs) w[stride * v + (size_t)j * B + threadIdx.x] = wacc[v];
   }
 #pragma unroll
   for (int it = 0; it < NE; ++it) {
@@ -950,7 +938,7 @@ void launch_cr_factor(hipStream_t st, const CrView& cr) {
 }
 
 void launch_cr_factor_solve(hipStream_t st, const CrView& cr, double* w, double* x, int nrhs, size_t stride) {
-  // nrhs <= 8 right-hand sides `stride` doubles apart ride through the factorisation
+  // nrhs right-hand sides `stride` doubles apart ride through the factorisation
   switch (cr.B) {
     case 3: cr_factor_t<3>(st, cr, w, x, nrhs, stride); break;
     case 6: cr_factor_t<6>(st, cr, w, x, nrhs, stride); break;
@@ -998,28 +986,33 @@ __global__ __launch_bounds__(128) void k_spmv(int n_poses, int npad, FactorView 
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   double part[5] = {0, 0, 0, 0, 0};
   if (3 * i < npad) {
-    if (i >= n_poses) {  // padding rows of the last super-block: identity
+    if (i >= n_poses || fv.fixed[i]) {  // padding rows and constant poses: identity rows
       for (int c = 0; c < 3; ++c) {
         const int t = 3 * i + c;
         if (t < npad) {
           if (MODE == 0) y[t] = v[t];
           if (MODE == 1) { const double r = aux.rhs[t] - v[t]; aux.r_out[t] = r; part[0] += r * r; part[1] += aux.rhs[t] * aux.rhs[t]; }
-          if (MODE == 2) y[t] = v[t];
+          if (MODE == 2) { y[t] = v[t]; if (i < n_poses) aux.xc[t] = aux.x[t]; }
         }
       }
     } else {
+      // Columns of constant poses are not part of the linear system (MODE 0/1).  In MODE 2 they
+      // ARE included: v then carries the neighbouring submap's step on the halo poses (0 for pose 0),
+      // so owned rows see the cross-cut coupling in the model cost change.
       const int Wb = fv.band_poses, W1 = Wb + 1;
       double acc[3] = {0, 0, 0};
       const double* Hi = lin.Hband + (size_t)i * W1 * 9;
       for (int d = 0; d <= Wb && i + d < n_poses; ++d) {
-        const double* blk = Hi + d * 9;
         const int j = i + d;
+        if (MODE != 2 && fv.fixed[j]) continue;
+        const double* blk = Hi + d * 9;
         const double v0 = scale[3 * j] * v[3 * j], v1 = scale[3 * j + 1] * v[3 * j + 1], v2 = scale[3 * j + 2] * v[3 * j + 2];
 #pragma unroll
         for (int a = 0; a < 3; ++a) acc[a] += blk[a * 3] * v0 + blk[a * 3 + 1] * v1 + blk[a * 3 + 2] * v2;
       }
       for (int d = 1; d <= Wb && i - d >= 0; ++d) {
         const int j = i - d;
+        if (MODE != 2 && fv.fixed[j]) continue;
         const double* blk = lin.Hband + ((size_t)j * W1 + d) * 9;  // block (j, i), used transposed
         const double v0 = scale[3 * j] * v[3 * j], v1 = scale[3 * j + 1] * v[3 * j + 1], v2 = scale[3 * j + 2] * v[3 * j + 2];
 #pragma unroll
@@ -1031,6 +1024,7 @@ __global__ __launch_bounds__(128) void k_spmv(int n_poses, int npad, FactorView 
           const int en = ent >> 1, tr = ent & 1;
           const double* blk = lin.obblk + (size_t)en * 9;
           const int j = tr ? fv.ob_lo[en] : fv.ob_hi[en];
+          if (MODE != 2 && fv.fixed[j]) continue;
           const double v0 = scale[3 * j] * v[3 * j], v1 = scale[3 * j + 1] * v[3 * j + 1], v2 = scale[3 * j + 2] * v[3 * j + 2];
           if (!tr) {
             for (int a = 0; a < 3; ++a) acc[a] += blk[a * 3] * v0 + blk[a * 3 + 1] * v1 + blk[a * 3 + 2] * v2;
@@ -1044,7 +1038,7 @@ __global__ __launch_bounds__(128) void k_spmv(int n_poses, int npad, FactorView 
         const int t = 3 * i + a;
         const double sa = scale[t];
         double r = sa * acc[a];
-        if (MODE != 2 && mu > 0.0 && i > 0) {
+        if (MODE != 2 && mu > 0.0) {
           const double dg = sa * sa * Hi[a * 3 + a];
           r += fmin(fmax(dg, min_diag), max_diag) / mu * v[t];
         }
@@ -1056,16 +1050,12 @@ __global__ __launch_bounds__(128) void k_spmv(int n_poses, int npad, FactorView 
         }
         if (MODE == 2) {
           const double vt = v[t];
+          const double dl = sa * vt, xt = aux.x[t];
           y[t] = r;
           part[0] += vt * aux.rhs[t];
           part[1] += vt * r;
-          if (i > 0) {
-            const double dl = sa * vt, xt = aux.x[t];
-            part[2] += dl * dl; part[3] += xt * xt;
-            aux.xc[t] = xt + dl;
-          } else {
-            aux.xc[t] = aux.x[t];
-          }
+          part[2] += dl * dl; part[3] += xt * xt;
+          aux.xc[t] = xt + dl;
           if (!isfinite(vt)) part[4] += 1.0;
         }
       }
@@ -1114,71 +1104,79 @@ void launch_spmv_step(hipStream_t st, int n_poses, int npad, const FactorView& f
 // small vector kernels
 // ===========================================================================================
 // submap exchange helpers --------------------------------------------------------------------
-struct Halo12 { double v[12]; };   // 3x3 diagonal-block contribution + 3 gradient entries
-
-// add the next rank's straddling-edge contribution to this rank's LAST pose
-__global__ void k_add_halo(int n_poses, int Wb, double* __restrict__ Hband, double* __restrict__ g, Halo12 h) {
-  const int t = threadIdx.x;
-  const int i = n_poses - 1;
-  if (t < 9) Hband[(size_t)i * (Wb + 1) * 9 + t] += h.v[t];
-  else if (t < 12) g[3 * i + (t - 9)] += h.v[t];
-}
-
-void launch_add_halo(hipStream_t st, int n_poses, int Wb, double* Hband, double* g, const double* h12) {
-  Halo12 h;
-  for (int k = 0; k < 12; ++k) h.v[k] = h12[k];
-  hipLaunchKernelGGL(k_add_halo, dim3(1), dim3(64), 0, st, n_poses, Wb, Hband, g, h);
-}
-
-// unit right-hand sides e_{col} for the interface solve: w[r][*] = 0 except w[r][cols[r]] = 1
-struct UnitCols { int col[6]; };
-__global__ void k_unit_rhs(int npad, double* __restrict__ w, size_t stride, UnitCols uc) {
+// unit right-hand sides for the interface solve: w[r][*] = 0 except w[r][cols[r]] = 1  (r < ncols)
+__global__ void k_unit_rhs(int npad, double* __restrict__ w, size_t stride, const int* __restrict__ cols) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= npad) return;
   const int r = blockIdx.y;
-  w[stride * r + t] = (t == uc.col[r]) ? 1.0 : 0.0;
+  w[stride * r + t] = (t == cols[r]) ? 1.0 : 0.0;
 }
 
-void launch_unit_rhs(hipStream_t st, int npad, double* w, size_t stride, const int* cols6) {
-  UnitCols uc;
-  for (int k = 0; k < 6; ++k) uc.col[k] = cols6[k];
-  hipLaunchKernelGGL(k_unit_rhs, dim3((npad + 255) / 256, 6), dim3(256), 0, st, npad, w, stride, uc);
+void launch_unit_rhs(hipStream_t st, int npad, double* w, size_t stride, const int* cols_dev, int ncols) {
+  hipLaunchKernelGGL(k_unit_rhs, dim3((npad + 255) / 256, ncols), dim3(256), 0, st, npad, w, stride, cols_dev);
 }
 
-// the 6 interface rows (first owned pose, last pose) of z0, of the 6 unit-rhs solutions and of
-// the Jacobi scale: out[0..6) = z0, out[6 + 6c + r] = Z[c][row r], out[42..48) = scale
+// interface rows of z0, of the ncols unit-rhs solutions and of the Jacobi scale:
+// out[0..nc) = z0[cols], out[nc + nc*c + r] = Z[c][cols[r]], out[nc + nc*nc + r] = scale[cols[r]]
 __global__ void k_gather_iface(const double* __restrict__ z0, const double* __restrict__ Z, size_t stride,
-                               const double* __restrict__ scale, UnitCols uc, double* __restrict__ out) {
-  const int t = threadIdx.x;
-  if (t < 6) out[t] = z0[uc.col[t]];
-  else if (t < 42) { const int c = (t - 6) / 6, r = (t - 6) % 6; out[t] = Z[stride * c + uc.col[r]]; }
-  else if (t < 48) out[t] = scale[uc.col[t - 42]];
+                               const double* __restrict__ scale, const int* __restrict__ cols, int nc,
+                               double* __restrict__ out) {
+  for (int t = threadIdx.x; t < nc * (nc + 2); t += blockDim.x) {
+    if (t < nc) out[t] = z0[cols[t]];
+    else if (t < nc + nc * nc) { const int c = (t - nc) / nc, r = (t - nc) % nc; out[t] = Z[stride * c + cols[r]]; }
+    else out[t] = scale[cols[t - nc - nc * nc]];
+  }
 }
 
 void launch_gather_iface(hipStream_t st, const double* z0, const double* Z, size_t stride, const double* scale,
-                         const int* cols6, double* out48) {
-  UnitCols uc;
-  for (int k = 0; k < 6; ++k) uc.col[k] = cols6[k];
-  hipLaunchKernelGGL(k_gather_iface, dim3(1), dim3(64), 0, st, z0, Z, stride, scale, uc, out48);
+                         const int* cols_dev, int ncols, double* out) {
+  hipLaunchKernelGGL(k_gather_iface, dim3(1), dim3(256), 0, st, z0, Z, stride, scale, cols_dev, ncols, out);
 }
 
-// dt = z0 - sum_k coef[k] * Z[k]   (Z: 6 columns, `stride` apart)
-struct Coef6 { double c[6]; };
-__global__ void k_combine6(int npad, const double* __restrict__ z0, const double* __restrict__ Z, size_t stride, Coef6 cf,
-                           double* __restrict__ dt) {
+// dt = z0 - sum_k coef[k] * Z[k]   (Z: ncols columns, `stride` apart; coef in device memory)
+__global__ void k_combine(int npad, const double* __restrict__ z0, const double* __restrict__ Z, size_t stride,
+                          const double* __restrict__ coef, int ncols, double* __restrict__ dt) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= npad) return;
   double v = z0[t];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) v -= cf.c[k] * Z[stride * k + t];
+  for (int k = 0; k < ncols; ++k) v -= coef[k] * Z[stride * k + t];
   dt[t] = v;
 }
 
-void launch_combine6(hipStream_t st, int npad, const double* z0, const double* Z, size_t stride, const double* coef6,
-                     double* dt) {
-  Coef6 cf;
-  for (int k = 0; k < 6; ++k) cf.c[k] = coef6[k];
-  hipLaunchKernelGGL(k_combine6, dim3((npad + 255) / 256), dim3(256), 0, st, npad, z0, Z, stride, cf, dt);
+void launch_combine(hipStream_t st, int npad, const double* z0, const double* Z, size_t stride, const double* coef_dev,
+                    int ncols, double* dt) {
+  hipLaunchKernelGGL(k_combine, dim3((npad + 255) / 256), dim3(256), 0, st, npad, z0, Z, stride, coef_dev, ncols, dt);
+}
+
+// halo poses (constant in the local system) take the neighbouring submap's step:
+// dt[idx[k]] = val[k], scale[idx[k]] = sc[k]  (k < cnt)
+__global__ void k_scatter_halo(int cnt, const int* __restrict__ idx, const double* __restrict__ val,
+                               const double* __restrict__ sc, double* __restrict__ dt, double* __restrict__ scale) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= cnt) return;
+  dt[idx[k]] = val[k];
+  scale[idx[k]] = sc[k];
+}
+
+void launch_scatter_halo(hipStream_t st, int cnt, const int* idx, const double* val, const double* sc, double* dt,
+                         double* scale) {
+  if (cnt <= 0) return;
+  hipLaunchKernelGGL(k_scatter_halo, dim3((cnt + 63) / 64), dim3(64), 0, st, cnt, idx, val, sc, dt, scale);
+}
+
+// candidate state of the halo poses: xc = x + scale * dt  (k_spmv<2> leaves xc = x on constant poses)
+__global__ void k_halo_candidate(int cnt, const int* __restrict__ idx, const double* __restrict__ x,
+                                 const double* __restrict__ scale, const double* __restrict__ dt, double* __restrict__ xc) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= cnt) return;
+  const int t = idx[k];
+  xc[t] = x[t] + scale[t] * dt[t];
+}
+
+void launch_halo_candidate(hipStream_t st, int cnt, const int* idx, const double* x, const double* scale, const double* dt,
+                           double* xc) {
+  if (cnt <= 0) return;
+  hipLaunchKernelGGL(k_halo_candidate, dim3((cnt + 63) / 64), dim3(64), 0, st, cnt, idx, x, scale, dt, xc);
 }
 
 struct DotArgs { const double* a[4]; const double* b[4]; };

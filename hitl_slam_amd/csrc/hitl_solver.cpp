@@ -104,14 +104,22 @@ struct hitl_solver {
   DevArray<float> cov9;
 
   // ---- pose-range submap (world_size > 1) ----
+  // local pose list = [hl halo poses | owned poses | hh halo poses]; halos carry scans and state
+  // of the neighbouring ranks' nearest poses and are constant in the local linear system.
   int rank = 0, world = 1;
-  int64_t g_begin = 0, g_n = 0;      // owned GLOBAL range [g_begin, g_begin + n - halo), g_n = global pose count
-  int halo = 0;                      // 1 on rank > 0: local pose 0 is the previous rank's last pose
+  int64_t g_begin = 0, g_n = 0;      // first owned GLOBAL pose, global pose count
+  int halo_req = 0;                  // halo width asked for at set_partition
+  int hl = 0, hh = 0;                // halo poses actually present below / above the owned range
+  int own_lo = 0, own_hi = 0;        // owned local range [own_lo, own_hi)
   hitl_comm_ops comm = {nullptr, nullptr};
   ncclComm_t nccl = nullptr;
   DevArray<char> comm_send, comm_recv;
-  DevArray<double> halo_out, iface_dev, rhs6, z6;   // 21 | 48 | 6*npad | 6*npad
-  std::vector<double> cut_C[2];      // per linearisation buffer: world x 9 raw coupling blocks (rank g: cut g-1|g)
+  DevArray<unsigned char> fixed;     // n : constant poses (global pose 0, halos)
+  DevArray<int> if_cols, halo_idx;   // interface column indices (2m) ; scalar indices of the nearest halo poses
+  DevArray<double> iface_dev, rhsN, zN, coef_dev, halo_val, halo_sc;
+  int Wi = 1;                        // interface width in poses: deepest reach of a factor across any cut (global max)
+  int n_pairs_owned = 0;             // pairs whose SOURCE pose is owned (each pair is counted by one rank)
+  int64_t n_matches_owned = 0;
 
   // ---- human rows: constrained_pose_id is LOCAL, anchor_pose_id stays GLOBAL ----
   std::vector<hitl_human_constraint_t> h_hc;
@@ -212,6 +220,9 @@ static int build_pair_structures(hitl_solver* s) {
       slot = p;
     }
   }
+  s->n_pairs_owned = 0; s->n_matches_owned = 0;
+  for (int p = 0; p < P; ++p)
+    if (s->h_pair_src[p] >= s->own_lo && s->h_pair_src[p] < s->own_hi) { s->n_pairs_owned++; s->n_matches_owned += s->h_match_off[p + 1] - s->h_match_off[p]; }
   const int E = (int)ob_lo.size();
   std::vector<int> obadj_off(n + 1, 0);
   for (int e = 0; e < E; ++e) { obadj_off[ob_lo[e] + 1]++; obadj_off[ob_hi[e] + 1]++; }
@@ -363,8 +374,7 @@ static FactorView factor_view(hitl_solver* s, int mode, int Wb) {
   f.n_offband = f.with_stf ? s->n_offband : 0;
   f.ob_lo = s->ob_lo.p; f.ob_hi = s->ob_hi.p; f.ob_fwd = s->ob_fwd.p; f.ob_rev = s->ob_rev.p;
   f.obadj_off = s->obadj_off.p; f.obadj_ent = s->obadj_ent.p;
-  f.halo_out = (s->world > 1 && s->halo) ? s->halo_out.p : nullptr;
-  f.tail_coupled = (s->world > 1 && s->rank < s->world - 1) ? 1 : 0;
+  f.fixed = s->fixed.p; f.own_lo = s->own_lo; f.own_hi = s->own_hi;
   return f;
 }
 
@@ -422,41 +432,26 @@ static int comm_allgather(hitl_solver* s, const void* send, void* recv, int64_t 
 
 static inline double nan_max(double a, double b) { return (b > a || b != b) ? b : a; }
 
-// local linearisation + exchange of the straddling odometry edge's contributions
+// local linearisation (every rank evaluates all factors touching its owned poses, so its rows are
+// complete) + the global cost and gradient max-norm
 static int run_linearize_dist(hitl_solver* s, const FactorView& fv, const double* xdev, int buf, LinResult* out) {
   TRY(run_linearize(s, fv, xdev, buf, out));
   if (s->world == 1) return HITL_OK;
-  hipStream_t st = s->stream;
-  const int W = s->world, n = s->n;
-  constexpr int R = 26;   // cost, gmax, halo_out[21], g_last[3]
-  double rec[R];
-  for (int k = 0; k < R; ++k) rec[k] = 0.0;
-  rec[0] = out->cost; rec[1] = out->gmax;
-  if (s->halo) HIP_TRY(hipMemcpyAsync(rec + 2, s->halo_out.p, 21 * sizeof(double), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(rec + 23, s->gvec[buf].p + 3 * (size_t)(n - 1), 3 * sizeof(double), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  std::vector<double> all((size_t)R * W);
-  TRY(comm_allgather(s, rec, all.data(), R * sizeof(double)));
+  const int W = s->world;
+  double rec[2] = {out->cost, out->gmax};
+  std::vector<double> all((size_t)2 * W);
+  TRY(comm_allgather(s, rec, all.data(), sizeof(rec)));
   double cost = 0.0, gmax = 0.0;
   for (int r = 0; r < W; ++r) {          // rank order on every rank: identical sums everywhere
-    cost += all[(size_t)R * r];
-    double gm = all[(size_t)R * r + 1];
-    if (r < W - 1) {
-      for (int c = 0; c < 3; ++c) gm = nan_max(gm, std::fabs(all[(size_t)R * r + 23 + c] + all[(size_t)R * (r + 1) + 2 + 9 + c]));
-    } else {
-      for (int c = 0; c < 3; ++c) gm = nan_max(gm, std::fabs(all[(size_t)R * r + 23 + c]));
-    }
-    gmax = nan_max(gmax, gm);
-    if (r >= 1) for (int q = 0; q < 9; ++q) s->cut_C[buf][(size_t)9 * r + q] = all[(size_t)R * r + 2 + 12 + q];
+    cost += all[(size_t)2 * r];
+    gmax = nan_max(gmax, all[(size_t)2 * r + 1]);
   }
-  if (s->rank < W - 1)
-    launch_add_halo(st, n, fv.band_poses, s->Hband[buf].p, s->gvec[buf].p, &all[(size_t)R * (s->rank + 1) + 2]);
   out->cost = cost;
   out->gmax = gmax;
   return HITL_OK;
 }
 
-// dense solve with partial pivoting (the 6*world interface system)
+// dense solve with partial pivoting (the interface system, 6 * band * world unknowns)
 static bool solve_dense(int n, std::vector<double>& A, std::vector<double>& b) {
   for (int c = 0; c < n; ++c) {
     int piv = c;
@@ -495,10 +490,36 @@ static int prepare(hitl_solver* s, int mode, const float* poses_ref, const float
   TRY(ensure_work(s, Wb));
   TRY(setup_factors(s, poses_ref, poses_global, mode != HITL_MODE_STF_ONLY));
   if (s->world > 1) {
-    TRY(s->halo_out.resize(21)); TRY(s->iface_dev.resize(48));
-    TRY(s->rhs6.resize((size_t)7 * s->npad)); TRY(s->z6.resize((size_t)7 * s->npad));
-    TRY(s->halo_out.zero(s->stream));
-    for (int k = 0; k < 2; ++k) s->cut_C[k].assign((size_t)s->world * 9, 0.0);
+    // interface width = how deep (in poses) any factor reaches across a cut, maximised over all
+    // ranks: 1 when only the odometry edges straddle the cuts, up to the pose band otherwise
+    int wi_local = 1;
+    if (mode != HITL_MODE_ODOM_HC)
+      for (int p = 0; p < s->n_pairs; ++p) {
+        const int a = std::min(s->h_pair_src[p], s->h_pair_tgt[p]), b = std::max(s->h_pair_src[p], s->h_pair_tgt[p]);
+        if (a < s->own_lo && b >= s->own_lo) wi_local = std::max(wi_local, std::max(s->own_lo - a, b - s->own_lo + 1));
+        if (a < s->own_hi && b >= s->own_hi) wi_local = std::max(wi_local, std::max(s->own_hi - a, b - s->own_hi + 1));
+      }
+    {
+      double mine = (double)wi_local;
+      std::vector<double> all((size_t)s->world);
+      TRY(comm_allgather(s, &mine, all.data(), sizeof(double)));
+      for (int r = 0; r < s->world; ++r) wi_local = std::max(wi_local, (int)all[r]);
+    }
+    s->Wi = wi_local;
+    const int Wi = s->Wi, nc = 6 * Wi;
+    if (Wi > Wb) return fail(HITL_ERR_UNSUPPORTED, "a factor reaches further across a cut than the pose band");
+    std::vector<int> cols(nc), hidx;
+    for (int p = 0; p < Wi; ++p)
+      for (int c = 0; c < 3; ++c) { cols[3 * p + c] = 3 * (s->own_lo + p) + c; cols[3 * Wi + 3 * p + c] = 3 * (s->own_hi - Wi + p) + c; }
+    if (s->rank > 0) for (int p = 0; p < Wi; ++p) for (int c = 0; c < 3; ++c) hidx.push_back(3 * (s->own_lo - Wi + p) + c);
+    if (s->rank < s->world - 1) for (int p = 0; p < Wi; ++p) for (int c = 0; c < 3; ++c) hidx.push_back(3 * (s->own_hi + p) + c);
+    TRY(s->if_cols.upload(cols, s->stream));
+    if (hidx.empty()) hidx.push_back(0);
+    TRY(s->halo_idx.upload(hidx, s->stream));
+    TRY(s->iface_dev.resize((size_t)nc * (nc + 2)));
+    TRY(s->rhsN.resize((size_t)(1 + nc) * s->npad)); TRY(s->zN.resize((size_t)(1 + nc) * s->npad));
+    TRY(s->coef_dev.resize(nc)); TRY(s->halo_val.resize(nc)); TRY(s->halo_sc.resize(nc));
+    HIP_TRY(hipStreamSynchronize(s->stream));
   }
   *fv = factor_view(s, mode, Wb);
   return HITL_OK;
@@ -534,7 +555,7 @@ static int linear_solve_and_step(hitl_solver* s, const FactorView& fv, int buf, 
   const double mind = s->opt.min_lm_diagonal, maxd = s->opt.max_lm_diagonal;
   const int npad = s->npad;
   const double tol = std::max(s->opt.linear_solver_tolerance, 1e-15);
-  launch_build_system(st, s->n, fv.band_poses, lv, s->scale.p, mu, mind, maxd, cr, s->rhs.p);
+  launch_build_system(st, s->n, fv.band_poses, lv, s->scale.p, s->fixed.p, mu, mind, maxd, cr, s->rhs.p);
   launch_copy(st, npad, s->rhs.p, s->wv.p);
   launch_cr_factor_solve(st, cr, s->wv.p, s->dt.p);   // x0 = M^{-1} b
   *iters = 1;
@@ -593,10 +614,16 @@ static int linear_solve_and_step(hitl_solver* s, const FactorView& fv, int buf, 
   return HITL_OK;
 }
 
-// Submap version: every rank factorises its own banded block (the previous rank's last pose is
-// a locally constant halo), solves for its right-hand side AND for the 6 unit vectors of its
-// first/last pose, and the cross-cut coupling blocks are eliminated exactly through the
-// 6*world interface system every rank solves identically on the host.
+// Submap version.  Rank g's unknowns x_g (owned poses) satisfy
+//     M_g x_g + E_F C_lo,g v_{g-1} + E_L C_up,g u_{g+1} = b_g
+// with M_g its own banded block (halo poses are constant locally), v_{g-1} / u_{g+1} the steps of
+// the previous rank's last Wi poses / the next rank's first Wi poses, and C_lo, C_up the cross-cut
+// Hessian blocks (assembled locally: every rank evaluates all factors touching its owned poses).
+// Each rank solves M_g Z = [b_g, E_F, E_L] in ONE multi-rhs cyclic-reduction pass, the ranks
+// all-gather the 2m interface rows (m = 3 Wi) of Z, their Jacobi scales and C_lo / C_up, and every
+// rank solves the same 2m*world dense interface system on the host:
+//     y_g + ZF_g (C~_lo,g v_{g-1}) + ZL_g (C~_up,g u_{g+1}) = z0_g ,   y_g = (u_g, v_g).
+// The coupling is eliminated exactly; no Schwarz / extra PCG iterations.
 static int linear_solve_and_step_dist(hitl_solver* s, const FactorView& fv, int buf, double mu, const double* xcur,
                                       double* xcand, int* iters, bool* ok, StepScalars* ss) {
   hipStream_t st = s->stream;
@@ -604,84 +631,110 @@ static int linear_solve_and_step_dist(hitl_solver* s, const FactorView& fv, int 
   const CrView cr = s->cr_view();
   const double mind = s->opt.min_lm_diagonal, maxd = s->opt.max_lm_diagonal;
   const int npad = s->npad, n = s->n, W = s->world, me = s->rank;
+  const int Wb = fv.band_poses, Wi = s->Wi, m = 3 * Wi, nc = 2 * m, W1 = Wb + 1;
   *iters = 1;
   *ok = true;
-  launch_build_system(st, n, fv.band_poses, lv, s->scale.p, mu, mind, maxd, cr, s->rhs.p);
-  // 7 right-hand sides ride through ONE factorisation: b and the unit vectors of the first/last pose
-  const int cols[6] = {3 * s->halo, 3 * s->halo + 1, 3 * s->halo + 2, 3 * (n - 1), 3 * (n - 1) + 1, 3 * (n - 1) + 2};
-  launch_copy(st, npad, s->rhs.p, s->rhs6.p);
-  launch_unit_rhs(st, npad, s->rhs6.p + npad, (size_t)npad, cols);
-  launch_cr_factor_solve(st, cr, s->rhs6.p, s->z6.p, 7, (size_t)npad);     // z0 = M^{-1} b, Z = M^{-1} [E_first, E_last]
-  launch_copy(st, npad, s->z6.p, s->dt.p);
-  const double* Z = s->z6.p + npad;
-  launch_gather_iface(st, s->dt.p, Z, (size_t)npad, s->scale.p, cols, s->iface_dev.p);
-  double rec[48];
-  HIP_TRY(hipMemcpyAsync(rec, s->iface_dev.p, sizeof(rec), hipMemcpyDeviceToHost, st));
+  launch_build_system(st, n, Wb, lv, s->scale.p, s->fixed.p, mu, mind, maxd, cr, s->rhs.p);
+  launch_copy(st, npad, s->rhs.p, s->rhsN.p);
+  launch_unit_rhs(st, npad, s->rhsN.p + npad, (size_t)npad, s->if_cols.p, nc);
+  launch_cr_factor_solve(st, cr, s->rhsN.p, s->zN.p, 1 + nc, (size_t)npad);   // z0 and Z = M^{-1} [E_F, E_L]
+  launch_copy(st, npad, s->zN.p, s->dt.p);
+  const double* Z = s->zN.p + npad;
+  launch_gather_iface(st, s->dt.p, Z, (size_t)npad, s->scale.p, s->if_cols.p, nc, s->iface_dev.p);
+  const int RI = nc * (nc + 2), RC = m * m, R = RI + 2 * RC;
+  std::vector<double> rec((size_t)R, 0.0);
+  HIP_TRY(hipMemcpyAsync(rec.data(), s->iface_dev.p, sizeof(double) * RI, hipMemcpyDeviceToHost, st));
+  // cross-cut blocks from the band: block (i, i+d) lives at Hband[i][d]
+  std::vector<double> hb_lo((size_t)Wi * W1 * 9, 0.0), hb_up((size_t)Wi * W1 * 9, 0.0);
+  if (me > 0) HIP_TRY(hipMemcpyAsync(hb_lo.data(), lv.Hband + (size_t)(s->own_lo - Wi) * W1 * 9, sizeof(double) * hb_lo.size(), hipMemcpyDeviceToHost, st));
+  if (me < W - 1) HIP_TRY(hipMemcpyAsync(hb_up.data(), lv.Hband + (size_t)(s->own_hi - Wi) * W1 * 9, sizeof(double) * hb_up.size(), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
-  std::vector<double> all((size_t)48 * W);
-  TRY(comm_allgather(s, rec, all.data(), sizeof(rec)));
-  // scaled coupling blocks  Ct_g = diag(s_last of g-1) * C_g * diag(s_first of g),  g = 1..W-1
-  std::vector<double> Ct((size_t)9 * W, 0.0);
-  for (int g = 1; g < W; ++g)
-    for (int a = 0; a < 3; ++a)
-      for (int b = 0; b < 3; ++b)
-        Ct[(size_t)9 * g + 3 * a + b] = all[(size_t)48 * (g - 1) + 45 + a] * s->cut_C[buf][(size_t)9 * g + 3 * a + b] * all[(size_t)48 * g + 42 + b];
-  // interface system: y_g + ZF_g Ct_g^T v_{g-1} + ZL_g Ct_{g+1} u_{g+1} = z0_g,  y_g = (u_g, v_g)
-  const int NI = 6 * W;
-  std::vector<double> A((size_t)NI * NI, 0.0), y(NI, 0.0);
+  double* Clo = rec.data() + RI;        // rows: first Wi owned poses, cols: the Wi halo poses below
+  double* Cup = Clo + RC;               // rows: last Wi owned poses,  cols: the Wi halo poses above
+  if (me > 0)
+    for (int ap = 0; ap < Wi; ++ap)
+      for (int bp = 0; bp < Wi; ++bp) {
+        const int d = (Wi + ap) - bp;   // a = own_lo + ap, b = own_lo - Wi + bp
+        if (d > Wb) continue;
+        const double* blk = &hb_lo[((size_t)bp * W1 + d) * 9];   // block (b, a): transpose it
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Clo[(size_t)(3 * ap + r) * m + 3 * bp + c] = blk[c * 3 + r];
+      }
+  if (me < W - 1)
+    for (int ap = 0; ap < Wi; ++ap)
+      for (int bp = 0; bp < Wi; ++bp) {
+        const int d = (Wi + bp) - ap;   // a = own_hi - Wi + ap, b = own_hi + bp
+        if (d > Wb) continue;
+        const double* blk = &hb_up[((size_t)ap * W1 + d) * 9];   // block (a, b)
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Cup[(size_t)(3 * ap + r) * m + 3 * bp + c] = blk[r * 3 + c];
+      }
+  std::vector<double> all((size_t)R * W);
+  TRY(comm_allgather(s, rec.data(), all.data(), sizeof(double) * R));
+  auto z0_of = [&](int g) { return &all[(size_t)R * g]; };
+  auto Z_of = [&](int g) { return &all[(size_t)R * g + nc]; };              // Z[c][r] = Z_of[nc*c + r]
+  auto sc_of = [&](int g) { return &all[(size_t)R * g + nc + nc * nc]; };   // [0,m): first Wi poses, [m,2m): last Wi
+  auto Clo_of = [&](int g) { return &all[(size_t)R * g + RI]; };
+  auto Cup_of = [&](int g) { return &all[(size_t)R * g + RI + RC]; };
+  // interface system
+  const int NI = nc * W;
+  std::vector<double> A((size_t)NI * NI, 0.0), y(NI, 0.0), Ct((size_t)m * m);
   for (int g = 0; g < W; ++g) {
-    const double* rg = &all[(size_t)48 * g];
-    for (int r = 0; r < 6; ++r) {
-      A[(size_t)(6 * g + r) * NI + 6 * g + r] = 1.0;
-      y[6 * g + r] = rg[r];
-      if (g >= 1)
-        for (int k = 0; k < 3; ++k) {      // column of v_{g-1}[k]
+    for (int r = 0; r < nc; ++r) { A[(size_t)(nc * g + r) * NI + nc * g + r] = 1.0; y[nc * g + r] = z0_of(g)[r]; }
+    if (g >= 1) {       // C~_lo,g = diag(s_first,g) C_lo,g diag(s_last,g-1); columns of v_{g-1}
+      for (int a = 0; a < m; ++a) for (int k = 0; k < m; ++k) Ct[(size_t)a * m + k] = sc_of(g)[a] * Clo_of(g)[(size_t)a * m + k] * sc_of(g - 1)[m + k];
+      for (int r = 0; r < nc; ++r)
+        for (int k = 0; k < m; ++k) {
           double v = 0.0;
-          for (int c = 0; c < 3; ++c) v += rg[6 + 6 * c + r] * Ct[(size_t)9 * g + 3 * k + c];       // ZF[r][c] * Ct_g[k][c]
-          A[(size_t)(6 * g + r) * NI + 6 * (g - 1) + 3 + k] += v;
+          for (int c = 0; c < m; ++c) v += Z_of(g)[(size_t)nc * c + r] * Ct[(size_t)c * m + k];
+          A[(size_t)(nc * g + r) * NI + nc * (g - 1) + m + k] += v;
         }
-      if (g + 1 < W)
-        for (int k = 0; k < 3; ++k) {      // column of u_{g+1}[k]
+    }
+    if (g + 1 < W) {    // C~_up,g = diag(s_last,g) C_up,g diag(s_first,g+1); columns of u_{g+1}
+      for (int a = 0; a < m; ++a) for (int k = 0; k < m; ++k) Ct[(size_t)a * m + k] = sc_of(g)[m + a] * Cup_of(g)[(size_t)a * m + k] * sc_of(g + 1)[k];
+      for (int r = 0; r < nc; ++r)
+        for (int k = 0; k < m; ++k) {
           double v = 0.0;
-          for (int c = 0; c < 3; ++c) v += rg[6 + 6 * (3 + c) + r] * Ct[(size_t)9 * (g + 1) + 3 * c + k];  // ZL[r][c] * Ct_{g+1}[c][k]
-          A[(size_t)(6 * g + r) * NI + 6 * (g + 1) + k] += v;
+          for (int c = 0; c < m; ++c) v += Z_of(g)[(size_t)nc * (m + c) + r] * Ct[(size_t)c * m + k];
+          A[(size_t)(nc * g + r) * NI + nc * (g + 1) + k] += v;
         }
     }
   }
-  if (!solve_dense(NI, A, y)) { *ok = false; }
-  double coef[6] = {0, 0, 0, 0, 0, 0};
-  double cross = 0.0;
+  if (!solve_dense(NI, A, y)) *ok = false;
+  // this rank's correction coefficients, and the neighbours' steps / scales for its halo poses
+  std::vector<double> coef(nc, 0.0), hval, hsc;
   if (me >= 1) {
-    const double* vprev = &y[6 * (me - 1) + 3];
-    for (int c = 0; c < 3; ++c)
-      for (int k = 0; k < 3; ++k) coef[c] += Ct[(size_t)9 * me + 3 * k + c] * vprev[k];             // Ct_g^T v_{g-1}
-    // 2 v_{g-1}^T Ct_g u_g : the straddling edge's share of dt^T (S H S) dt, counted by its owner
-    for (int a = 0; a < 3; ++a)
-      for (int b = 0; b < 3; ++b) cross += 2.0 * vprev[a] * Ct[(size_t)9 * me + 3 * a + b] * y[6 * me + b];
+    const double* vprev = &y[nc * (me - 1) + m];
+    for (int a = 0; a < m; ++a)
+      for (int k = 0; k < m; ++k) coef[a] += sc_of(me)[a] * Clo_of(me)[(size_t)a * m + k] * sc_of(me - 1)[m + k] * vprev[k];
+    for (int k = 0; k < m; ++k) { hval.push_back(vprev[k]); hsc.push_back(sc_of(me - 1)[m + k]); }
   }
   if (me + 1 < W) {
-    const double* unext = &y[6 * (me + 1)];
-    for (int c = 0; c < 3; ++c)
-      for (int k = 0; k < 3; ++k) coef[3 + c] += Ct[(size_t)9 * (me + 1) + 3 * c + k] * unext[k];   // Ct_{g+1} u_{g+1}
+    const double* unext = &y[nc * (me + 1)];
+    for (int a = 0; a < m; ++a)
+      for (int k = 0; k < m; ++k) coef[m + a] += sc_of(me)[m + a] * Cup_of(me)[(size_t)a * m + k] * sc_of(me + 1)[k] * unext[k];
+    for (int k = 0; k < m; ++k) { hval.push_back(unext[k]); hsc.push_back(sc_of(me + 1)[k]); }
   }
-  launch_combine6(st, npad, s->dt.p, Z, (size_t)npad, coef, s->dt.p);
+  const int nh = (int)hval.size();
+  HIP_TRY(hipMemcpyAsync(s->coef_dev.p, coef.data(), sizeof(double) * nc, hipMemcpyHostToDevice, st));
+  if (nh) {
+    HIP_TRY(hipMemcpyAsync(s->halo_val.p, hval.data(), sizeof(double) * nh, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->halo_sc.p, hsc.data(), sizeof(double) * nh, hipMemcpyHostToDevice, st));
+  }
+  launch_combine(st, npad, s->dt.p, Z, (size_t)npad, s->coef_dev.p, nc, s->dt.p);
+  launch_scatter_halo(st, nh, s->halo_idx.p, s->halo_val.p, s->halo_sc.p, s->dt.p, s->scale.p);
+  // model-cost pieces over the owned rows (halo columns carry the neighbours' steps), candidate state
   launch_spmv_step(st, n, npad, fv, lv, s->scale.p, s->dt.p, s->rhs.p, xcur, s->qv.p, xcand, s->step_partials.p);
+  launch_halo_candidate(st, nh, s->halo_idx.p, xcur, s->scale.p, s->dt.p, xcand);
   HIP_TRY(hipGetLastError());
   StepScalars loc;
-  double tail[3];
-  HIP_TRY(hipMemcpyAsync(tail, xcand + 3 * (size_t)(n - 1), sizeof(tail), hipMemcpyDeviceToHost, st));
-  TRY(read_step_partials(s, nullptr, nullptr, &loc));    // synchronises the stream
-  double r2[8] = {loc.dt_rhs, loc.dt_q + cross, loc.step2, loc.xn2, loc.bad, tail[0], tail[1], tail[2]};
-  std::vector<double> all2((size_t)8 * W);
+  TRY(read_step_partials(s, nullptr, nullptr, &loc));    // synchronises the stream (host vectors above stay alive until here)
+  double r2[5] = {loc.dt_rhs, loc.dt_q, loc.step2, loc.xn2, loc.bad};
+  std::vector<double> all2((size_t)5 * W);
   TRY(comm_allgather(s, r2, all2.data(), sizeof(r2)));
   ss->dt_rhs = ss->dt_q = ss->step2 = ss->xn2 = ss->bad = 0.0;
   for (int g = 0; g < W; ++g) {
-    ss->dt_rhs += all2[(size_t)8 * g]; ss->dt_q += all2[(size_t)8 * g + 1]; ss->step2 += all2[(size_t)8 * g + 2];
-    ss->xn2 += all2[(size_t)8 * g + 3]; ss->bad += all2[(size_t)8 * g + 4];
+    ss->dt_rhs += all2[(size_t)5 * g]; ss->dt_q += all2[(size_t)5 * g + 1]; ss->step2 += all2[(size_t)5 * g + 2];
+    ss->xn2 += all2[(size_t)5 * g + 3]; ss->bad += all2[(size_t)5 * g + 4];
   }
-  if (s->halo)   // the candidate state of the previous rank's last pose feeds the straddling edge
-    HIP_TRY(hipMemcpyAsync(xcand, &all2[(size_t)8 * (me - 1) + 5], 3 * sizeof(double), hipMemcpyHostToDevice, st));
-  HIP_TRY(hipStreamSynchronize(st));
   return HITL_OK;
 }
 
@@ -718,13 +771,15 @@ static int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float
   S.linearize_ms += lr.stf_ms; S.linearize_calls++;
   double cost = lr.cost, gmax = lr.gmax;
   S.initial_cost = cost;
-  S.num_pairs = fv.with_stf ? s->n_pairs : 0;
-  S.num_matches = fv.with_stf ? s->n_matches : 0;
+  S.num_pairs = fv.with_stf ? s->n_pairs_owned : 0;
+  S.num_matches = fv.with_stf ? s->n_matches_owned : 0;
   S.num_offband_pairs = fv.n_offband;
   S.band_poses = fv.band_poses;
   S.num_hc_residuals = s->num_hc_residuals;
-  S.num_residuals = (fv.with_stf ? 2 * s->n_pairs : 0) + (fv.with_odom ? 3 * (n - 1) : 0) + (fv.with_hc ? s->num_hc_residuals : 0);
-  launch_jacobi_scale(st, n, s->npad, fv.band_poses, s->Hband[cur].p, o.jacobi_scaling, s->scale.p);
+  // odometry edges are owned by the rank owning their second pose
+  const int n_edges = (s->own_hi - s->own_lo) - ((s->g_begin == 0) ? 1 : 0);
+  S.num_residuals = (fv.with_stf ? 2 * s->n_pairs_owned : 0) + (fv.with_odom ? 3 * n_edges : 0) + (fv.with_hc ? s->num_hc_residuals : 0);
+  launch_jacobi_scale(st, n, s->npad, fv.band_poses, s->Hband[cur].p, o.jacobi_scaling, s->fixed.p, s->scale.p);
   double radius = o.initial_trust_region_radius, decrease_factor = 2.0;
   int iter = 0, invalid_run = 0;
   int term = HITL_NO_CONVERGENCE;
@@ -863,7 +918,9 @@ static int find_correspondences(hitl_solver* s, const float* poses, int64_t wind
   for (int i = 0; i < n; ++i)
     for (int sl = 0; sl < slots; ++sl) {
       const size_t c = (size_t)i * slots + sl;
-      if (cand_tgt[c] >= 0 && counts[c] > s->opt.min_inter_pose_correspondence) {
+      const int jt = cand_tgt[c];
+      const bool relevant = (i >= s->own_lo && i < s->own_hi) || (jt >= s->own_lo && jt < s->own_hi);   // halo-halo pairs belong to other ranks
+      if (jt >= 0 && relevant && counts[c] > s->opt.min_inter_pose_correspondence) {
         kept.push_back((int)c);
         s->h_pair_src.push_back(i); s->h_pair_tgt.push_back(cand_tgt[c]);
         s->h_match_off.push_back(s->h_match_off.back() + counts[c]);
@@ -997,7 +1054,8 @@ void hitl_solver_destroy(hitl_solver* s) {
     v->release();
   s->matches.release(); s->odom_A.release(); s->hc_tgt.release(); s->odom_rr.release(); s->hc_type.release();
   if (s->nccl) (void)ncclCommDestroy(s->nccl);
-  s->comm_send.release(); s->comm_recv.release(); s->halo_out.release(); s->iface_dev.release(); s->rhs6.release(); s->z6.release();
+  s->comm_send.release(); s->comm_recv.release(); s->fixed.release(); s->if_cols.release(); s->halo_idx.release();
+  s->iface_dev.release(); s->rhsN.release(); s->zN.release(); s->coef_dev.release(); s->halo_val.release(); s->halo_sc.release();
   if (s->h_scalars) (void)hipHostFree(s->h_scalars);
   for (hipEvent_t e : {s->ev0, s->ev1, s->ev2, s->ev3}) if (e) (void)hipEventDestroy(e);
   if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -1023,13 +1081,16 @@ int hitl_solver_comm_selftest(hitl_solver* s) {
   return HITL_OK;
 }
 
-int hitl_solver_set_partition(hitl_solver* s, int64_t global_begin, int64_t n_global_poses) {
+int hitl_solver_set_partition(hitl_solver* s, int64_t global_begin, int64_t n_global_poses, int32_t halo_poses) {
   if (!s || global_begin < 0 || n_global_poses < 1 || global_begin >= n_global_poses) return fail(HITL_ERR_INVALID_ARGUMENT, "set_partition: bad range");
   if (s->world == 1 && (global_begin != 0)) return fail(HITL_ERR_INVALID_ARGUMENT, "set_partition: a single-GPU solver owns the whole map");
   if (s->world > 1 && ((s->rank == 0) != (global_begin == 0))) return fail(HITL_ERR_INVALID_ARGUMENT, "set_partition: rank 0 (and only rank 0) starts at pose 0");
+  if (s->world > 1 && (halo_poses < 1 || (s->rank > 0 && global_begin < halo_poses))) return fail(HITL_ERR_INVALID_ARGUMENT, "set_partition: halo_poses must be >= 1 and not reach below pose 0");
   s->g_begin = global_begin;
   s->g_n = n_global_poses;
-  s->halo = (s->world > 1 && s->rank > 0) ? 1 : 0;
+  s->halo_req = (s->world > 1) ? halo_poses : 0;
+  s->hl = (s->world > 1 && s->rank > 0) ? halo_poses : 0;
+  s->hh = (s->world > 1 && s->rank < s->world - 1) ? halo_poses : 0;
   s->n = 0;   // a map must be (re)installed for this range
   return HITL_OK;
 }
@@ -1039,8 +1100,10 @@ int hitl_solver_set_map(hitl_solver* s, int64_t n_poses, const int64_t* obs_offs
   if (!s || !obs_offset || n_poses < 1) return fail(HITL_ERR_INVALID_ARGUMENT, "set_map: null solver/offsets or n_poses < 1");
   if (n_poses > (int64_t)1 << 30) return fail(HITL_ERR_UNSUPPORTED, "set_map: more than 2^30 poses");
   if (s->world > 1 && s->g_n == 0) return fail(HITL_ERR_NOT_READY, "set_map: call hitl_solver_set_partition first when world_size > 1");
-  if (s->world > 1 && s->g_begin + n_poses > s->g_n) return fail(HITL_ERR_INVALID_ARGUMENT, "set_map: owned range exceeds the global pose count");
-  if (s->world == 1) { s->g_begin = 0; s->g_n = n_poses; s->halo = 0; }
+  if (s->world == 1) { s->g_begin = 0; s->g_n = n_poses; s->hl = s->hh = 0; }
+  // submap rank: n_poses = hl halo poses + owned poses + hh halo poses, i.e. global [g_begin - hl, ...)
+  if (s->world > 1 && (n_poses <= s->hl + s->hh || s->g_begin - s->hl + n_poses > s->g_n)) return fail(HITL_ERR_INVALID_ARGUMENT, "set_map: the local range [begin - halo, end + halo) does not fit the global pose count");
+  if (s->world > 1 && s->rank == s->world - 1 && s->g_begin - s->hl + n_poses != s->g_n) return fail(HITL_ERR_INVALID_ARGUMENT, "set_map: the last rank's range must end at the last global pose");
   const int64_t O = obs_offset[n_poses];
   if (obs_offset[0] != 0 || O < 0 || (O > 0 && (!px || !py || !nx || !ny))) return fail(HITL_ERR_INVALID_ARGUMENT, "set_map: bad offsets or null scan arrays");
   int max_scan = 0;
@@ -1052,11 +1115,15 @@ int hitl_solver_set_map(hitl_solver* s, int64_t n_poses, const int64_t* obs_offs
   }
   HIP_TRY(hipSetDevice(s->device));
   hipStream_t st = s->stream;
-  // local pose list = [halo pose with an empty scan (rank > 0)] + owned poses
-  s->n = (int)n_poses + s->halo; s->n_obs = O; s->max_scan = std::max(max_scan, 1);
-  s->h_obs_off.assign((size_t)s->n + 1, 0);
-  for (int64_t i = 0; i <= n_poses; ++i) s->h_obs_off[(size_t)i + s->halo] = obs_offset[i];
+  s->n = (int)n_poses; s->n_obs = O; s->max_scan = std::max(max_scan, 1);
+  s->own_lo = s->hl; s->own_hi = (int)n_poses - s->hh;
+  s->h_obs_off.assign(obs_offset, obs_offset + n_poses + 1);
   TRY(s->obs_off.upload(s->h_obs_off, st));
+  {  // constant poses: global pose 0 (JointOptimization.cpp:824, :1197) and the halos
+    std::vector<unsigned char> fx((size_t)n_poses, 0);
+    for (int i = 0; i < (int)n_poses; ++i) fx[i] = (i < s->own_lo || i >= s->own_hi || (s->g_begin - s->hl + i) == 0) ? 1 : 0;
+    TRY(s->fixed.upload(fx, st));
+  }
   {  // the caller's SoA arrays are packed into one float4 per observation on the device
     DevArray<float> t0, t1, t2, t3;
     int rc = t0.upload(px, O, st);
@@ -1082,7 +1149,7 @@ int hitl_solver_set_map(hitl_solver* s, int64_t n_poses, const int64_t* obs_offs
 int hitl_solver_set_human_constraints(hitl_solver* s, int64_t n, const hitl_human_constraint_t* rows) {
   if (!s || n < 0 || (n > 0 && !rows)) return fail(HITL_ERR_INVALID_ARGUMENT, "set_human_constraints: bad arguments");
   if (s->n <= 0) return fail(HITL_ERR_NOT_READY, "set_human_constraints before set_map");
-  const int64_t own_lo = s->g_begin, own_hi = s->g_begin + (s->n - s->halo);
+  const int64_t own_lo = s->g_begin, own_hi = s->g_begin + (s->own_hi - s->own_lo);
   for (int64_t h = 0; h < n; ++h)
     if (rows[h].constrained_pose_id < 0 || rows[h].constrained_pose_id >= s->g_n || rows[h].anchor_pose_id < 0 || rows[h].anchor_pose_id >= s->g_n)
       return fail(HITL_ERR_INVALID_ARGUMENT, "set_human_constraints: pose id out of range");
@@ -1090,7 +1157,7 @@ int hitl_solver_set_human_constraints(hitl_solver* s, int64_t n, const hitl_huma
   for (int64_t h = 0; h < n; ++h) {
     if (rows[h].constrained_pose_id < own_lo || rows[h].constrained_pose_id >= own_hi) continue;   // another rank's row
     hitl_human_constraint_t r = rows[h];
-    r.constrained_pose_id = (int32_t)(r.constrained_pose_id - s->g_begin + s->halo);                // local; the anchor stays global
+    r.constrained_pose_id = (int32_t)(r.constrained_pose_id - s->g_begin + s->hl);                  // local; the anchor stays global
     s->h_hc.push_back(r);
   }
   return HITL_OK;
@@ -1100,7 +1167,7 @@ int hitl_solver_find_correspondences(hitl_solver* s, const float* poses_xyt, int
   if (!s || !poses_xyt) return fail(HITL_ERR_INVALID_ARGUMENT, "find_correspondences: null argument");
   if (s->n <= 0) return fail(HITL_ERR_NOT_READY, "find_correspondences before set_map");
   // poses_xyt is the GLOBAL array; the local list starts at the halo pose (rank > 0)
-  return find_correspondences(s, poses_xyt + 3 * (size_t)(s->g_begin - s->halo), window);
+  return find_correspondences(s, poses_xyt + 3 * (size_t)(s->g_begin - s->hl), window);
 }
 
 int hitl_solver_set_correspondences(hitl_solver* s, int64_t n_pairs, const int32_t* pair_src, const int32_t* pair_tgt,
@@ -1110,10 +1177,10 @@ int hitl_solver_set_correspondences(hitl_solver* s, int64_t n_pairs, const int32
   if (n_pairs > 0 && (!pair_src || !pair_tgt || !match_offset || !src_idx || !tgt_idx)) return fail(HITL_ERR_INVALID_ARGUMENT, "set_correspondences: null array");
   HIP_TRY(hipSetDevice(s->device));
   const int P = (int)n_pairs;
-  const int shift = s->halo - (int)s->g_begin;   // GLOBAL pose id -> local index
+  const int shift = s->hl - (int)s->g_begin;   // GLOBAL pose id -> local index
   for (int p = 0; p < P; ++p) {
     const int a = pair_src[p] + shift, b = pair_tgt[p] + shift;
-    if (a < s->halo || a >= s->n || b < s->halo || b >= s->n || a == b) return fail(s->world > 1 ? HITL_ERR_UNSUPPORTED : HITL_ERR_INVALID_ARGUMENT, "set_correspondences: pose index outside this solver's owned range, or src == tgt");
+    if (a < 0 || a >= s->n || b < 0 || b >= s->n || a == b) return fail(HITL_ERR_INVALID_ARGUMENT, "set_correspondences: pose index outside this solver's local range, or src == tgt");
     if (match_offset[p + 1] <= match_offset[p]) return fail(HITL_ERR_INVALID_ARGUMENT, "set_correspondences: every pair needs >= 1 match (residual_functors.h:783)");
     const int64_t ma = s->h_obs_off[a + 1] - s->h_obs_off[a], mb = s->h_obs_off[b + 1] - s->h_obs_off[b];
     for (int64_t m = match_offset[p]; m < match_offset[p + 1]; ++m)
@@ -1165,7 +1232,7 @@ int hitl_solver_get_correspondences(hitl_solver* s, int32_t* pair_src, int32_t* 
   match_offset[0] = 0;
   for (int p = 0; p < P; ++p) {
     const int q = inv[p];
-    pair_src[p] = s->h_pair_src[q] - (s->halo - (int)s->g_begin); pair_tgt[p] = s->h_pair_tgt[q] - (s->halo - (int)s->g_begin);
+    pair_src[p] = s->h_pair_src[q] - (s->hl - (int)s->g_begin); pair_tgt[p] = s->h_pair_tgt[q] - (s->hl - (int)s->g_begin);
     for (int64_t m = s->h_match_off[q]; m < s->h_match_off[q + 1]; ++m) {
       src_idx[w] = (int32_t)(packed[m] & 0xffffu); tgt_idx[w] = (int32_t)(packed[m] >> 16); ++w;
     }
@@ -1183,13 +1250,13 @@ int hitl_solver_solve(hitl_solver* s, int32_t mode, const float* poses_in_xyt, f
   }
   // submap rank: poses are GLOBAL arrays; this rank solves [halo pose +] its owned range
   if (mode == HITL_MODE_STF_ONLY) return fail(HITL_ERR_UNSUPPORTED, "submap solves need the odometry chain (mode A or C)");
-  const size_t n = (size_t)s->n, first = (size_t)(s->g_begin - s->halo);
+  const size_t n = (size_t)s->n, first = (size_t)(s->g_begin - s->hl);
   std::vector<float> in(poses_in_xyt + 3 * first, poses_in_xyt + 3 * (first + n)), out(3 * n);
   hitl_summary S;
   const int rc = lm_solve(s, mode, in.data(), poses_in_xyt, out.data(), &S);
   if (poses_out_xyt != poses_in_xyt) std::memcpy(poses_out_xyt, poses_in_xyt, sizeof(float) * 3 * (size_t)s->g_n);
   if (rc == HITL_OK || rc == HITL_ERR_SOLVER_FAILURE)
-    std::memcpy(poses_out_xyt + 3 * (size_t)s->g_begin, out.data() + 3 * (size_t)s->halo, sizeof(float) * 3 * (n - s->halo));
+    std::memcpy(poses_out_xyt + 3 * (size_t)s->g_begin, out.data() + 3 * (size_t)s->own_lo, sizeof(float) * 3 * (size_t)(s->own_hi - s->own_lo));
   // problem-size counters are global sums
   double cnt[4] = {(double)S.num_residuals, (double)S.num_hc_residuals, (double)S.num_pairs, (double)S.num_matches};
   std::vector<double> all((size_t)4 * s->world);

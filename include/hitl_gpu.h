@@ -201,23 +201,29 @@ int hitl_solver_linearize(hitl_solver*, int32_t mode, const float* poses_ref_xyt
                           double* pair_jacobians);
 
 /* ---- pose-range submaps across GPUs (world_size > 1; nothing in the reference) ------------
- * One process per GPU; rank r owns the contiguous GLOBAL pose range [begin, begin + n_local).
- * Cuts must fall where the trajectory shards naturally: the only factor that may straddle a
- * cut is the odometry edge (begin-1, begin); a scan-to-scan pair across a cut is rejected
- * with HITL_ERR_UNSUPPORTED.  Protocol per rank:
+ * One process per GPU; rank r owns the contiguous GLOBAL pose range [begin, end) and also holds
+ * the scans and state of `halo_poses` poses on each side (fewer at the trajectory's ends), so it
+ * can evaluate EVERY factor that touches one of its own poses -- the odometry edges across its
+ * cuts and the scan-to-scan pairs within the matching window of a cut included.  Its rows of the
+ * normal equations are therefore complete without exchanging any Hessian data; the shared
+ * blocks are simply computed on both sides.  halo_poses must be >= the pose band of the
+ * correspondence set (<= 4) and should be 2 x the matching window, so that the per-point cap of
+ * the correspondence search (counted across targets) sees the same targets as a global search.
+ * Protocol per rank:
  *   hitl_solver_create(opt with rank/world_size [+ rccl_unique_id])
- *   hitl_solver_set_partition(begin, n_global)          -- before set_map
- *   hitl_solver_set_map(n_local, ...)                   -- scans of the OWNED poses only
- *   hitl_solver_set_human_constraints(rows)             -- GLOBAL pose ids; rows constraining a
- *                                                          pose of another rank are ignored here
+ *   hitl_solver_set_partition(begin, n_global, halo_poses)        -- before set_map
+ *   hitl_solver_set_map(n_local, ...)   -- scans of GLOBAL poses [begin - hl, end + hh), hl = halo_poses
+ *                                          on rank > 0 else 0, hh = halo_poses on rank < world-1 else 0
+ *   hitl_solver_set_human_constraints(rows)   -- GLOBAL pose ids; rows constraining another rank's
+ *                                                pose are ignored here
  *   hitl_solver_find_correspondences(poses GLOBAL n_global*3, window)
  *   hitl_solver_solve(mode, poses_in GLOBAL, poses_out GLOBAL, summary)
  *        every rank takes identical LM decisions; poses_out receives the owned range (other
  *        entries are copied from poses_in); summary costs/iterations are global.
- * Per LM iteration the ranks exchange three tiny all-gathers (<= 400 bytes per rank): the
- * straddling edge's contribution to the previous rank's last pose ("shared-pose gradient /
- * Hessian blocks"), the 6x7 interface rows of the local cyclic-reduction solves (the cross-cut
- * coupling is then eliminated exactly on every rank), and the step scalars + boundary state.
+ * Per LM iteration the ranks exchange three small all-gathers: (cost, |g|max) after a
+ * linearisation; the interface rows of the local multi-rhs cyclic-reduction solve + Jacobi
+ * scales + cross-cut blocks (<= 5 KB per rank; the coupling is then eliminated exactly by a
+ * 6*band*world interface system solved identically on every rank); the step scalars.
  * The all-gather is either the built-in RCCL one (opt.rccl_unique_id != NULL) or a caller
  * supplied callback on HOST buffers (tests use torch.distributed/gloo). */
 typedef int (*hitl_allgather_fn)(void* ctx, const void* send, void* recv, int64_t bytes_per_rank);
@@ -226,7 +232,7 @@ typedef struct hitl_comm_ops {
   void* ctx;
 } hitl_comm_ops;
 int hitl_solver_set_comm(hitl_solver*, const hitl_comm_ops* ops);
-int hitl_solver_set_partition(hitl_solver*, int64_t global_begin, int64_t n_global_poses);
+int hitl_solver_set_partition(hitl_solver*, int64_t global_begin, int64_t n_global_poses, int32_t halo_poses);
 /* one small all-gather through the active communicator, payload verified (bring-up check) */
 int hitl_solver_comm_selftest(hitl_solver*);
 

@@ -15,16 +15,17 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def main():
-    out_path, mode = sys.argv[1], int(sys.argv[2])
+    out_path, mode, ppf = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
     dist.init_process_group(backend="gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     import hitl_slam_amd as H
     from hitl_slam_amd.api import torch_allgather_ops
     from conftest import Problem
 
-    n_per, ppf = 60, 30
+    n_per, halo = 60, 6                 # halo = 2 x matching window
     prob = Problem(n_per * world, 48, ppf=ppf, groups=2, kind=0)
     b, e = rank * n_per, (rank + 1) * n_per
+    lo, hi = b - (halo if rank > 0 else 0), e + (halo if rank < world - 1 else 0)
     M = 48
     opt = H.default_options()
     opt.rank, opt.world_size = rank, world
@@ -32,15 +33,17 @@ def main():
     s = H.Solver(opt)
     ops, keep = torch_allgather_ops()
     s.set_comm(ops, keep)
-    s.set_partition(b, prob.n)
-    sl = slice(b * M, e * M)
-    s.set_map(np.arange(n_per + 1, dtype=np.int64) * M, prob.px[sl], prob.py[sl], prob.nx[sl], prob.ny[sl], prob.cov[b:e])
+    s.set_partition(b, prob.n, halo)
+    sl = slice(lo * M, hi * M)
+    s.set_map(np.arange(hi - lo + 1, dtype=np.int64) * M, prob.px[sl], prob.py[sl], prob.nx[sl], prob.ny[sl], prob.cov[lo:hi])
     s.set_human_constraints(prob.rows)
     s.find_correspondences(prob.init, 3)
     corr = s.get_correspondences()
+    own = (corr[0] >= b) & (corr[0] < e)             # every pair is reported by the rank owning its source pose
+    lens = corr[2][1:] - corr[2][:-1]
     poses, summ = s.solve(mode, prob.init)
     res = dict(rank=rank, begin=b, end=e, poses=poses.tolist(), summary=summ.as_dict(),
-               pairs=[corr[0].tolist(), corr[1].tolist()], n_matches=int(len(corr[3])))
+               pairs=[corr[0][own].tolist(), corr[1][own].tolist()], n_matches=int(lens[own].sum()))
     json.dump(res, open("%s.%d" % (out_path, rank), "w"))
     s.close()
     dist.destroy_process_group()

@@ -1,6 +1,7 @@
 """N > 1 path on CPU (gloo, world_size 2): the product's pose-range partitioner plus a numpy
-mirror of the submap exchange -- one all-gather of the 6x7 interface rows and cut blocks, the
-6*world interface system, rank-ordered scalar sums -- on systems assembled by the oracle.  The
+mirror of the submap exchange (interface width 1: only the odometry edge couples the ranks) --
+one all-gather of the interface rows and cut blocks, the 6*world interface system, rank-ordered
+scalar sums -- on systems assembled by the oracle.  The
 HIP implementation of the same algebra is checked end-to-end in tests/test_submap_gpu.py."""
 import json
 import os

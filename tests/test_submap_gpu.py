@@ -1,7 +1,9 @@
-"""Pose-range submaps (the N > 1 path) on the real HIP solver: two ranks, one submap each, cut
-at a floor boundary (only the odometry edge straddles it).  The exchange runs through the
-host-buffer all-gather callback over gloo, so both ranks can share the single GPU of the test
-box.  The distributed result must equal the oracle's GLOBAL solve."""
+"""Pose-range submaps (the N > 1 path) on the real HIP solver: two ranks, one submap each.
+ppf=30: the cut falls between two floors (only the odometry edge straddles it).  ppf=120: ONE
+corridor cut in the middle, so scan-to-scan pairs within the matching window straddle the cut
+and the 6-pose halos matter.  The exchange runs through the host-buffer all-gather callback
+over gloo, so both ranks can share the single GPU of the test box.  The distributed result must
+equal the oracle's GLOBAL solve."""
 import json
 import os
 import subprocess
@@ -16,25 +18,27 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("mode", [0, 2])
-def test_two_submaps_equal_the_global_solve(tmp_path, mode):
+@pytest.mark.parametrize("mode,ppf", [(0, 30), (2, 30), (2, 120), (0, 120)])
+def test_two_submaps_equal_the_global_solve(tmp_path, mode, ppf):
     from oracle import hitl_oracle as O
     out = str(tmp_path / "res")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(29500 + mode), os.path.join(ROOT, "tests", "_submap_worker.py"), out, str(mode)]
+           "--master-port", str(29500 + mode + ppf // 30), os.path.join(ROOT, "tests", "_submap_worker.py"), out, str(mode), str(ppf)]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     res = [json.load(open("%s.%d" % (out, k))) for k in range(2)]
 
-    prob = Problem(120, 48, ppf=30, groups=2, kind=0)
+    prob = Problem(120, 48, ppf=ppf, groups=2, kind=0)
     o = prob.load(O.OracleSolver())
     o.find_correspondences(prob.init, 3, 0)
     ops = o.get_correspondences()
-    # the ranks' local correspondence sets (global ids) tile the global set: no pair crosses the cut
+    # the pairs reported by the ranks owning their source pose tile the global set exactly
     src = np.concatenate([np.array(x["pairs"][0], np.int32) for x in res])
     tgt = np.concatenate([np.array(x["pairs"][1], np.int32) for x in res])
     assert np.array_equal(src, ops[0]) and np.array_equal(tgt, ops[1])
+    if ppf == 120:
+        assert np.any((ops[0] < 60) != (ops[1] < 60))          # pairs really straddle the cut
     assert sum(x["n_matches"] for x in res) == len(ops[3])
     po, so = o.solve(mode, prob.init)
     for x in res:
