@@ -22,7 +22,7 @@ def main():
     from hitl_slam_amd.api import torch_allgather_ops
     from conftest import Problem
 
-    n_per, halo = 60, 6                 # halo = 2 x matching window
+    n_per, halo = (60 if world == 2 else 40), 6     # halo = 2 x matching window
     prob = Problem(n_per * world, 48, ppf=ppf, groups=2, kind=0)
     b, e = rank * n_per, (rank + 1) * n_per
     lo, hi = b - (halo if rank > 0 else 0), e + (halo if rank < world - 1 else 0)

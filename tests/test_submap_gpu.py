@@ -18,16 +18,16 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("mode,ppf", [(0, 30), (2, 30), (2, 120), (0, 120)])
-def test_two_submaps_equal_the_global_solve(tmp_path, mode, ppf):
+@pytest.mark.parametrize("mode,ppf,world", [(0, 30, 2), (2, 30, 2), (2, 120, 2), (0, 120, 2), (2, 120, 3), (2, 40, 3)])
+def test_submaps_equal_the_global_solve(tmp_path, mode, ppf, world):
     from oracle import hitl_oracle as O
     out = str(tmp_path / "res")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(29500 + mode + ppf // 30), os.path.join(ROOT, "tests", "_submap_worker.py"), out, str(mode), str(ppf)]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(29500 + mode + ppf // 10 + 7 * world), os.path.join(ROOT, "tests", "_submap_worker.py"), out, str(mode), str(ppf)]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    res = [json.load(open("%s.%d" % (out, k))) for k in range(2)]
+    res = [json.load(open("%s.%d" % (out, k))) for k in range(world)]
 
     prob = Problem(120, 48, ppf=ppf, groups=2, kind=0)
     o = prob.load(O.OracleSolver())
@@ -38,7 +38,10 @@ def test_two_submaps_equal_the_global_solve(tmp_path, mode, ppf):
     tgt = np.concatenate([np.array(x["pairs"][1], np.int32) for x in res])
     assert np.array_equal(src, ops[0]) and np.array_equal(tgt, ops[1])
     if ppf == 120:
-        assert np.any((ops[0] < 60) != (ops[1] < 60))          # pairs really straddle the cut
+        cut = 120 // world
+        assert np.any((ops[0] < cut) != (ops[1] < cut))        # pairs really straddle the cut
+    if world == 3:
+        assert res[1]["begin"] == 40 and res[1]["end"] == 80   # the middle rank has halos on both sides
     assert sum(x["n_matches"] for x in res) == len(ops[3])
     po, so = o.solve(mode, prob.init)
     for x in res:
