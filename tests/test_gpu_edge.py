@@ -1,0 +1,126 @@
+"""Edge cases through the C ABI against the oracle: tiny maps, degenerate odometry edges,
+every human-constraint type, option variations, windows wider than the band (off-band PCG)."""
+import numpy as np
+import pytest
+
+from conftest import Problem, oracle_corr
+
+pytestmark = pytest.mark.gpu
+TOL_M = TOL_RAD = 1e-4
+
+
+def _both(opt=None):
+    import hitl_slam_amd as H
+    from oracle import hitl_oracle as O
+    return H.Solver(opt), O.OracleSolver(opt)
+
+
+def _check(g, o, mode, init, exact_iters=True):
+    pg, sg = g.solve(mode, init)
+    po, so = o.solve(mode, init)
+    assert sg.termination == so.termination
+    if exact_iters:
+        assert sg.iterations == so.iterations
+    assert abs(sg.final_cost - so.final_cost) <= 1e-7 * max(so.final_cost, 1e-9)
+    assert np.abs(pg[:, :2] - po[:, :2]).max() <= TOL_M and np.abs(pg[:, 2] - po[:, 2]).max() <= TOL_RAD
+    return pg, sg
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5])
+def test_tiny_maps(n):
+    import hitl_slam_amd as H
+    g, o = _both()
+    off = np.arange(n + 1, dtype=np.int64) * 4
+    rng = np.random.default_rng(n)
+    px, py = rng.uniform(1, 3, 4 * n).astype(np.float32), rng.uniform(-1, 1, 4 * n).astype(np.float32)
+    nx, ny = -np.ones(4 * n, np.float32), np.zeros(4 * n, np.float32)
+    init = np.cumsum(rng.uniform(0.1, 0.3, (n, 3)), 0).astype(np.float32)
+    rows = [(2, n - 1, 0, 0.5, 0.1, 0.05, 0.0)] if n > 1 else []
+    for s in (g, o):
+        s.set_map(off, px, py, nx, ny)
+        s.set_human_constraints(rows)
+    pg, sg = _check(g, o, H.MODE_ODOM_HC, init)
+    assert np.array_equal(pg[0], init[0])
+
+
+def test_degenerate_odometry_edges_and_large_angles():
+    """Zero-translation edges take the |dx|,|dy| < 1e-6 branch (JointOptimization.cpp:756-762);
+    headings beyond +-pi exercise angle_mod / atan2 wrapping."""
+    import hitl_slam_amd as H
+    g, o = _both()
+    n = 12
+    init = np.zeros((n, 3), np.float32)
+    init[:, 0] = [0, 0.3, 0.3, 0.3, 0.6, 0.9, 0.9, 1.2, 1.5, 1.5, 1.5, 1.8]      # repeated positions: pure rotations
+    init[:, 2] = np.linspace(2.5, 9.0, n)                                         # passes pi, 2 pi
+    off = np.arange(n + 1, dtype=np.int64) * 2
+    z = np.ones(2 * n, np.float32)
+    rows = [(4, 10, 1, 1.0, 0.2, 0.3, 1.2), (5, 7, 2, 0, 0, -0.4, 0), (6, 5, 3, 0, 0, 0.2, 0), (2, 11, 0, 1.9, 0.1, 6.2, 0),
+            (0, 4, 1, 9, 9, 9, 9), (1, 4, 1, 9, 9, 9, 9), (3, 4, 1, 9, 9, 9, 9)]     # types 0,1,3 add nothing
+    for s in (g, o):
+        s.set_map(off, z, 0 * z, -z, 0 * z)
+        s.set_human_constraints(rows)
+    pg, sg = _check(g, o, H.MODE_ODOM_HC, init)
+    assert sg.num_hc_residuals == 2 + 1 + 1 + 3
+    assert np.all(np.abs(pg[:, 2]) <= np.pi + 1e-6)                               # CopyParams wraps theta
+
+
+@pytest.mark.parametrize("variant", ["no_jacobi", "sigmas", "skip2_cap1", "tight"])
+def test_option_variants(variant):
+    import hitl_slam_amd as H
+    opt = H.default_options()
+    if variant == "no_jacobi":
+        opt.jacobi_scaling = 0
+    elif variant == "sigmas":
+        opt.odom_radial_std_dev, opt.odom_tangential_std_dev, opt.odom_angular_std_dev = 0.05, 0.02, 0.03
+        opt.laser_std_dev, opt.point_correlation_factor = 0.03, 0.1
+    elif variant == "skip2_cap1":
+        opt.num_skip_readings, opt.max_correspondences_per_point, opt.min_inter_pose_correspondence = 2, 1, 5
+    elif variant == "tight":
+        opt.function_tolerance, opt.max_num_iterations = 1e-12, 40
+    prob = Problem(40, 64, ppf=20, groups=1, kind=0)
+    g, o = _both(opt)
+    for s in (g, o):
+        prob.load(s)
+    g.find_correspondences(prob.init, 3)
+    o.find_correspondences(prob.init, 3, 0)
+    for a, b in zip(g.get_correspondences(), o.get_correspondences()):
+        assert np.array_equal(a, b)
+    _check(g, o, H.MODE_JOINT, prob.init)
+
+
+def test_window_wider_than_band_uses_offband_pcg():
+    """Window 6 > max_band_poses 4: pairs at distance 5..6 go to the off-band list and the PCG
+    (preconditioned by the exact band factorisation) has to converge to the oracle's exact step."""
+    import hitl_slam_amd as H
+    prob = Problem(48, 64, ppf=48, groups=1, kind=4)
+    corr = oracle_corr(prob, window=6)
+    assert np.abs(corr[0] - corr[1]).max() == 6
+    g, o = _both()
+    prob.load(g, corr=corr), prob.load(o, corr=corr)
+    pg, sg = _check(g, o, H.MODE_JOINT, prob.init)
+    assert sg.band_poses == 4 and sg.num_offband_pairs > 0 and sg.linear_iterations > sg.iterations
+
+
+def test_repeated_solves_and_constraint_undo():
+    """A session: solve, add a constraint group, solve, undo it (the caller passes a shorter list,
+    HitLSLAM.cpp:262-276), solve again -- the map stays resident and results are reproducible."""
+    import hitl_slam_amd as H
+    prob = Problem(40, 48, ppf=20, groups=2, kind=0)
+    g, o = _both()
+    for s in (g, o):
+        s.set_map(prob.off, prob.px, prob.py, prob.nx, prob.ny, prob.cov)
+    g.find_correspondences(prob.init, 3)
+    o.set_correspondences(*g.get_correspondences())
+    rows, n = prob.rows
+    first = [(rows[k].type, rows[k].constrained_pose_id, rows[k].anchor_pose_id, rows[k].delta_parallel,
+              rows[k].delta_perpendicular, rows[k].delta_angle, rows[k].relative_penalty_dir) for k in range(n)]
+    for s in (g, o):
+        s.set_human_constraints(first[:25])
+    p1, _ = _check(g, o, H.MODE_JOINT, prob.init)
+    for s in (g, o):
+        s.set_human_constraints(first)
+    p2, _ = _check(g, o, H.MODE_JOINT, p1)
+    for s in (g, o):
+        s.set_human_constraints(first[:25])                 # undo
+    p3, _ = _check(g, o, H.MODE_JOINT, prob.init)
+    assert np.array_equal(p1, p3)
