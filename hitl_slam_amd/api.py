@@ -175,6 +175,47 @@ class SolverBase(object):
                                          _ptr(i0, _i32p), _ptr(i1, _i32p)), "get_corr")
         return ps[:P], pt[:P], mo, i0[:Cn], i1[:Cn]
 
+    # -- observation scans either side of the solve -------------------
+    def _scan_fn(self, key):
+        return getattr(self._lib, self._scan_names[key])
+
+    def transform_scans(self, poses_xyt):
+        """== HitLSLAM::transformPointCloudsToWorldFrame: (world_x, world_y), one value per observation."""
+        pin = _as(poses_xyt, np.float32).reshape(-1)
+        n_obs = int(self.obs_offset[-1])
+        wx, wy = np.zeros(max(n_obs, 1), np.float32), np.zeros(max(n_obs, 1), np.float32)
+        f = self._scan_fn("transform")
+        f.argtypes = [C.c_void_p, _f32p, _f32p, _f32p]
+        f.restype = C.c_int
+        self._check(f(self._h, _ptr(pin, _f32p), _ptr(wx, _f32p), _ptr(wy, _f32p)), "solve")
+        return wx[:n_obs], wy[:n_obs]
+
+    def verify_points(self, poses_xyt, points_xy, threshold=0.05):
+        """== the scan of HitLSLAM::verifyUserInput: flags[q] = some observation within threshold of point q."""
+        pin = _as(poses_xyt, np.float32).reshape(-1)
+        pts = _as(points_xy, np.float32).reshape(-1, 2)
+        seen = np.zeros(max(len(pts), 1), np.int32)
+        f = self._scan_fn("verify")
+        f.argtypes = [C.c_void_p, _f32p, C.c_int32, _f32p, C.c_float, _i32p]
+        f.restype = C.c_int
+        self._check(f(self._h, _ptr(pin, _f32p), len(pts), _ptr(pts, _f32p), C.c_float(threshold), _ptr(seen, _i32p)), "solve")
+        return seen[:len(pts)]
+
+    def observation_sets(self, poses_xyt, seg_xy8, threshold=0.03, want_mask=True):
+        """== EMInput::EstablishObservationSets: (counts int32 [n,2], mask uint8 [n_obs] or None)."""
+        pin = _as(poses_xyt, np.float32).reshape(-1)
+        seg = _as(seg_xy8, np.float32).reshape(-1)
+        assert seg.size == 8
+        counts = np.zeros((self.n_poses, 2), np.int32)
+        n_obs = int(self.obs_offset[-1])
+        mask = np.zeros(max(n_obs, 1), np.uint8) if want_mask else None
+        f = self._scan_fn("obs_sets")
+        f.argtypes = [C.c_void_p, _f32p, _f32p, C.c_double, _i32p, C.POINTER(C.c_uint8)]
+        f.restype = C.c_int
+        self._check(f(self._h, _ptr(pin, _f32p), _ptr(seg, _f32p), C.c_double(threshold), _ptr(counts, _i32p),
+                      _ptr(mask, C.POINTER(C.c_uint8))), "solve")
+        return counts, (mask[:n_obs] if want_mask else None)
+
     # -- the path --------------------------------------------------------------------------
     def solve(self, mode, poses_xyt, allow_failure=False):
         """Returns (poses_out float32 [n,3], Summary)."""
@@ -268,6 +309,8 @@ class Solver(SolverBase):
                   get_corr="hitl_solver_get_correspondences", solve="hitl_solver_solve",
                   evaluate="hitl_solver_evaluate", linearize="hitl_solver_linearize",
                   find_corr="hitl_solver_find_correspondences")
+    _scan_names = dict(transform="hitl_solver_transform_scans", verify="hitl_solver_verify_points",
+                       obs_sets="hitl_solver_observation_sets")
 
     def __init__(self, options=None, lib_path=None):
         lib = load_library(lib_path)

@@ -128,6 +128,12 @@ void launch_compact(hipStream_t st, const MapView& map, int max_scan, int slots,
                     const int* kept_cand /* index into n*slots */, const int64_t* match_off, const uint16_t* table,
                     uint32_t* matches);
 
+// observation scans (hitl_obs.hip); T4 = n x (cos, sin, tx, ty) fp32 computed on the host
+void launch_transform(hipStream_t st, const MapView& map, const float* T4, float2* world);
+void launch_verify(hipStream_t st, const MapView& map, const float* T4, int n, const float* pts_xy, float thr, int* seen);
+void launch_obs_sets(hipStream_t st, const MapView& map, const float* T4, const float* seg8, double thr, int* counts,
+                     unsigned char* mask);
+
 const char* kernels_build_info();
 
 }  // namespace hitl

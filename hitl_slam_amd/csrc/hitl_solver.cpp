@@ -1305,6 +1305,79 @@ int hitl_solver_evaluate(hitl_solver* s, int32_t mode, const float* poses_xyt, d
   return hitl_solver_linearize(s, mode, poses_xyt, x.data(), cost, gradient, nullptr, nullptr);
 }
 
+// ---- observation scans either side of the solve -------------------------
+namespace {
+int obs_scan_prepare(hitl_solver* s, const float* poses, DevArray<float>* T4) {
+  if (!s || !poses) return fail(HITL_ERR_INVALID_ARGUMENT, "observation scan: null argument");
+  if (s->n <= 0) return fail(HITL_ERR_NOT_READY, "observation scan before set_map");
+  if (s->world > 1) return fail(HITL_ERR_UNSUPPORTED, "observation scans are single-GPU entry points");
+  HIP_TRY(hipSetDevice(s->device));
+  std::vector<float> t((size_t)4 * s->n);
+  for (int i = 0; i < s->n; ++i) {      // Rotation2Df(angle), Translation2f: fp32 trig on the host
+    t[4 * i] = cosf(poses[3 * i + 2]); t[4 * i + 1] = sinf(poses[3 * i + 2]); t[4 * i + 2] = poses[3 * i]; t[4 * i + 3] = poses[3 * i + 1];
+  }
+  TRY(T4->upload(t, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return HITL_OK;
+}
+}  // namespace
+
+int hitl_solver_transform_scans(hitl_solver* s, const float* poses_xyt, float* world_x, float* world_y) {
+  DevArray<float> T4;
+  DevArray<float2> w;
+  int rc = obs_scan_prepare(s, poses_xyt, &T4);
+  if (rc == HITL_OK && (!world_x || !world_y)) rc = fail(HITL_ERR_INVALID_ARGUMENT, "transform_scans: null output");
+  if (rc == HITL_OK) rc = w.resize((size_t)s->n_obs);
+  if (rc == HITL_OK) {
+    launch_transform(s->stream, s->map_view(), T4.p, w.p);
+    std::vector<float2> h((size_t)s->n_obs);
+    if (hipMemcpyAsync(h.data(), w.p, sizeof(float2) * h.size(), hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
+        hipStreamSynchronize(s->stream) != hipSuccess) rc = fail(HITL_ERR_HIP, "transform_scans failed");
+    else for (size_t k = 0; k < h.size(); ++k) { world_x[k] = h[k].x; world_y[k] = h[k].y; }
+  }
+  T4.release(); w.release();
+  return rc;
+}
+
+int hitl_solver_verify_points(hitl_solver* s, const float* poses_xyt, int32_t n_points, const float* points_xy,
+                              float threshold, int32_t* seen) {
+  if (n_points < 0 || n_points > 16 || (n_points > 0 && (!points_xy || !seen))) return fail(HITL_ERR_INVALID_ARGUMENT, "verify_points: 0..16 points");
+  DevArray<float> T4;
+  DevArray<int> d_seen;
+  int rc = obs_scan_prepare(s, poses_xyt, &T4);
+  if (rc == HITL_OK) rc = d_seen.resize(16);
+  if (rc == HITL_OK) rc = d_seen.zero(s->stream);
+  if (rc == HITL_OK) {
+    launch_verify(s->stream, s->map_view(), T4.p, n_points, points_xy, threshold, d_seen.p);
+    int h[16];
+    if (hipMemcpyAsync(h, d_seen.p, sizeof(h), hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
+        hipStreamSynchronize(s->stream) != hipSuccess) rc = fail(HITL_ERR_HIP, "verify_points failed");
+    else for (int q = 0; q < n_points; ++q) seen[q] = h[q];
+  }
+  T4.release(); d_seen.release();
+  return rc;
+}
+
+int hitl_solver_observation_sets(hitl_solver* s, const float* poses_xyt, const float* seg_xy8, double threshold,
+                                 int32_t* counts, uint8_t* mask) {
+  if (!seg_xy8 || !counts) return fail(HITL_ERR_INVALID_ARGUMENT, "observation_sets: null argument");
+  DevArray<float> T4;
+  DevArray<int> d_cnt;
+  DevArray<unsigned char> d_mask;
+  int rc = obs_scan_prepare(s, poses_xyt, &T4);
+  if (rc == HITL_OK) rc = d_cnt.resize((size_t)2 * s->n);
+  if (rc == HITL_OK) rc = d_cnt.zero(s->stream);
+  if (rc == HITL_OK && mask) rc = d_mask.resize((size_t)s->n_obs);
+  if (rc == HITL_OK) {
+    launch_obs_sets(s->stream, s->map_view(), T4.p, seg_xy8, threshold, d_cnt.p, mask ? d_mask.p : nullptr);
+    hipError_t e = hipMemcpyAsync(counts, d_cnt.p, sizeof(int) * 2 * (size_t)s->n, hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess && mask) e = hipMemcpyAsync(mask, d_mask.p, (size_t)s->n_obs, hipMemcpyDeviceToHost, s->stream);
+    if (e != hipSuccess || hipStreamSynchronize(s->stream) != hipSuccess) rc = fail(HITL_ERR_HIP, "observation_sets failed");
+  }
+  T4.release(); d_cnt.release(); d_mask.release();
+  return rc;
+}
+
 int hitl_comm_unique_id(void* out128) {
   if (!out128) return fail(HITL_ERR_INVALID_ARGUMENT, "null buffer");
   ncclUniqueId id;

@@ -192,6 +192,25 @@ int hitl_solver_solve(hitl_solver*, int32_t mode, const float* poses_in_xyt,
 int hitl_solver_evaluate(hitl_solver*, int32_t mode, const float* poses_xyt,
                          double* cost, double* gradient);
 
+/* ---- the O(N*M) observation scans either side of the solve ----------
+ * They run over the resident scans with the robot->world transform fused in, so the
+ * WORLD_FRAME_point_clouds_ copies of the reference never have to exist.  fp32 like the
+ * reference; results are bit-identical to the CPU restatement.  Single-GPU entry points.
+ * hitl_solver_transform_scans  == HitLSLAM::transformPointCloudsToWorldFrame (HitLSLAM.cpp:245-254):
+ *     world_x/world_y receive n_obs values each (pose_transform * point).
+ * hitl_solver_verify_points    == the scan of HitLSLAM::verifyUserInput (HitLSLAM.cpp:218-243):
+ *     seen[q] = 1 iff some world-frame observation lies within `threshold` of points_xy[q]
+ *     (the caller sums them and applies the two equality checks of :237-241).  n_points <= 16.
+ * hitl_solver_observation_sets == EMInput::EstablishObservationSets (EMinput.cpp:281-323) with
+ *     distToLineSeg (:268-279): seg_xy8 = selected_points_[0..3]; counts[2*i + s] = number of
+ *     observations of pose i within `threshold` (0.03 in the reference) of selection s; mask (may be
+ *     NULL) gets bit s set per observation.  The caller keeps poses with counts > 5 (:309-316). */
+int hitl_solver_transform_scans(hitl_solver*, const float* poses_xyt, float* world_x, float* world_y);
+int hitl_solver_verify_points(hitl_solver*, const float* poses_xyt, int32_t n_points, const float* points_xy,
+                              float threshold, int32_t* seen);
+int hitl_solver_observation_sets(hitl_solver*, const float* poses_xyt, const float* seg_xy8, double threshold,
+                                 int32_t* counts, uint8_t* mask);
+
 /* Debug / parity: linearise at double-precision poses x (3*n_poses) with the odometry
  * measurements and human targets derived from the fp32 poses_ref_xyt; returns the cost, the
  * gradient (3n), the per-pair STF residuals (2 per pair) and Jacobians (12 per pair,

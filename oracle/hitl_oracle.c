@@ -1019,3 +1019,64 @@ int orc_solve(orc_solver* s, int32_t mode, const float* poses_in, float* poses_o
   free(x);
   return st;
 }
+
+/* ===================================================================================== */
+/* observation scans either side of the solve (fp32, like the reference)                  */
+/* ===================================================================================== */
+static void world_point(const float* pose, float px, float py, float* wx, float* wy) {
+  /* HitLSLAM.cpp:247-252: Affine2f pose_transform = translation * rotation; pose_transform * p */
+  const float c = cosf(pose[2]), s = sinf(pose[2]);
+  *wx = (c * px - s * py) + pose[0];
+  *wy = (s * px + c * py) + pose[1];
+}
+
+int orc_transform_scans(orc_solver* s, const float* poses, float* wx, float* wy) {
+  if (!s || !s->obs_offset) return HITL_ERR_NOT_READY;
+#pragma omp parallel for schedule(static, 64)
+  for (int64_t i = 0; i < s->n; ++i)
+    for (int64_t k = s->obs_offset[i]; k < s->obs_offset[i + 1]; ++k) world_point(poses + 3 * i, s->px[k], s->py[k], &wx[k], &wy[k]);
+  return HITL_OK;
+}
+
+int orc_verify_points(orc_solver* s, const float* poses, int32_t n_points, const float* pts, float thr, int32_t* seen) {
+  /* HitLSLAM.cpp:222-235: (cloud point - selected point).norm() < local_select_thresh */
+  if (!s || !s->obs_offset) return HITL_ERR_NOT_READY;
+  for (int q = 0; q < n_points; ++q) seen[q] = 0;
+  for (int64_t i = 0; i < s->n; ++i)
+    for (int64_t k = s->obs_offset[i]; k < s->obs_offset[i + 1]; ++k) {
+      float wx, wy; world_point(poses + 3 * i, s->px[k], s->py[k], &wx, &wy);
+      for (int q = 0; q < n_points; ++q) {
+        const float dx = wx - pts[2 * q], dy = wy - pts[2 * q + 1];
+        if (sqrtf(dx * dx + dy * dy) < thr) seen[q] = 1;
+      }
+    }
+  return HITL_OK;
+}
+
+static float dist_to_line_seg(const float* p1, const float* p2, float px, float py) {
+  /* EMInput::distToLineSeg, EMinput.cpp:268-279 */
+  const float ex = p2[0] - p1[0], ey = p2[1] - p1[1], dx = px - p1[0], dy = py - p1[1];
+  const float t = (dx * ex + dy * ey) / (ex * ex + ey * ey);
+  if (t < 0.0f) return sqrtf(dx * dx + dy * dy);
+  if (t > 1.0f) { const float fx = px - p2[0], fy = py - p2[1]; return sqrtf(fx * fx + fy * fy); }
+  const float qx = px - (p1[0] + t * ex), qy = py - (p1[1] + t * ey);
+  return sqrtf(qx * qx + qy * qy);
+}
+
+int orc_observation_sets(orc_solver* s, const float* poses, const float* seg, double thr, int32_t* counts, uint8_t* mask) {
+  /* EMInput::EstablishObservationSets, EMinput.cpp:281-323 (the > 5 filter is the caller's) */
+  if (!s || !s->obs_offset) return HITL_ERR_NOT_READY;
+#pragma omp parallel for schedule(static, 64)
+  for (int64_t i = 0; i < s->n; ++i) {
+    int c0 = 0, c1 = 0;
+    for (int64_t k = s->obs_offset[i]; k < s->obs_offset[i + 1]; ++k) {
+      float wx, wy; world_point(poses + 3 * i, s->px[k], s->py[k], &wx, &wy);
+      const int in0 = (double)dist_to_line_seg(seg, seg + 2, wx, wy) < thr;
+      const int in1 = (double)dist_to_line_seg(seg + 4, seg + 6, wx, wy) < thr;
+      c0 += in0; c1 += in1;
+      if (mask) mask[k] = (uint8_t)(in0 | (in1 << 1));
+    }
+    counts[2 * i] = c0; counts[2 * i + 1] = c1;
+  }
+  return HITL_OK;
+}

@@ -50,6 +50,14 @@ int orc_linearize(orc_solver*, int32_t mode, const float* poses_ref_xyt, const d
 /* dense J^T J (3n x 3n row-major, pose-0 rows/cols replaced by identity) and gradient */
 int orc_assemble_dense(orc_solver*, int32_t mode, const float* poses_ref_xyt, const double* x,
                        double* H, double* g, double* cost);
+/* the O(N*M) observation scans either side of the solve, fp32 like the reference:
+ * HitLSLAM::transformPointCloudsToWorldFrame (HitLSLAM.cpp:245-254), the scan of
+ * HitLSLAM::verifyUserInput (:218-243), EMInput::EstablishObservationSets (EMinput.cpp:268-323) */
+int orc_transform_scans(orc_solver*, const float* poses_xyt, float* world_x, float* world_y);
+int orc_verify_points(orc_solver*, const float* poses_xyt, int32_t n_points, const float* points_xy, float threshold,
+                      int32_t* seen);
+int orc_observation_sets(orc_solver*, const float* poses_xyt, const float* seg_xy8, double threshold, int32_t* counts,
+                         uint8_t* mask);
 /* use forward-mode dual numbers (what ceres::AutoDiffCostFunction does) instead of the
  * analytic Jacobians inside linearize/solve: 0 = analytic (default), 1 = jets */
 int orc_set_use_jets(orc_solver*, int use);

@@ -117,6 +117,7 @@ class OracleSolver(SolverBase):
                   set_hc="orc_set_human_constraints", set_corr="orc_set_correspondences",
                   get_corr_counts="orc_get_correspondence_counts", get_corr="orc_get_correspondences",
                   solve="orc_solve", evaluate="orc_evaluate", linearize="orc_linearize")
+    _scan_names = dict(transform="orc_transform_scans", verify="orc_verify_points", obs_sets="orc_observation_sets")
 
     def __init__(self, options=None):
         super().__init__(lib(), options)
