@@ -578,13 +578,6 @@ __device__ __forceinline__ void cr_eliminate_node(const CrView& cr, int s, int k
   }
 }
 
-template <int B>
-__global__ __launch_bounds__(WAVE) void k_cr_eliminate(CrView cr, int s) {
-  const int k = s * (2 * blockIdx.x + 1);
-  if (k >= cr.nsb) return;
-  cr_eliminate_node<B>(cr, s, k, threadIdx.x);
-}
-
 // Schur-complement update of survivor j at level stride s (LDS-free):
 //   D_j  -= L_j Gr[k1] + L_{k2}^T Gl[k2]        L'_j = -L_j Gl[k1]
 // Lane (grp, c) owns column c of the right operands (grp 0: Gr[k1], Gl[k2] -> D_j; grp 1: Gl[k1]
@@ -648,100 +641,114 @@ __device__ __forceinline__ void cr_update_node(const CrView& cr, int s, int j, i
   }
 }
 
+// One launch per big level (instead of eliminate + update): the workgroup of survivor j
+//  1. forms, from the inverses Dinv[k1], Dinv[k2] of its two eliminated neighbours (computed by
+//     the PREVIOUS level's launch, step 3 below), the products
+//        Gr[k1] = Dinv_k1 L_j^T     Gl[k1] = Dinv_k1 L_k1     Gl[k2] = Dinv_k2 L_k2
+//     (Gr/Gl of node k are stored by its right-hand survivor; the back substitution reads them),
+//  2. applies the Schur complement  D_j -= L_j Gr[k1] + L_k2^T Gl[k2],  L'_j = -L_j Gl[k1]  and the
+//     right-hand-side sweep  w_j -= Gr[k1]^T w_k1 + Gl[k2]^T w_k2,
+//  3. if j itself is eliminated at the next level, inverts its new D_j (register-resident
+//     Gauss-Jordan) so that level needs no separate inversion launch either.
 template <int B>
-__device__ __forceinline__ void lds_load(double* dst, const double* __restrict__ src) {
+__device__ __forceinline__ void lds_load(double* dst, const double* src) {
   for (int e = threadIdx.x; e < B * B; e += WAVE) dst[e] = src[e];
 }
 
-// Standalone (one workgroup per survivor) version for the big levels: the left matrices are
-// staged through LDS once per workgroup, which beats 2*B*B uniform global loads per lane.
-// With w != nullptr the right-hand side rides along (w_j -= Gr[k1]^T w_k1 + Gl[k2]^T w_k2), which
-// saves the separate forward sweep when a factorisation is followed by exactly one solve.
+// C = A * Bm (TA: use A^T, TB: use Bm^T), all B x B tiles in LDS, one wave
+template <int B, bool TA, bool TB>
+__device__ __forceinline__ void lds_matmul(double* C, const double* A, const double* Bm) {
+  for (int e = threadIdx.x; e < B * B; e += WAVE) {
+    const int r = e / B, c = e % B;
+    double v = 0.0;
+#pragma unroll
+    for (int q = 0; q < B; ++q) v += (TA ? A[q * B + r] : A[r * B + q]) * (TB ? Bm[c * B + q] : Bm[q * B + c]);
+    C[e] = v;
+  }
+}
+
 template <int B>
-__global__ __launch_bounds__(WAVE) void k_cr_update(CrView cr, int s, double* __restrict__ w, int nrhs, size_t stride) {
-  __shared__ double sLj[B * B], sG[B * B], sL2[B * B];
-  constexpr int NE = (B * B + WAVE - 1) / WAVE;
+__global__ __launch_bounds__(WAVE) void k_cr_level(CrView cr, int s, int invert_next, double* w, int nrhs, size_t stride) {
+  __shared__ double sLj[B * B], sL1[B * B], sL2[B * B], sI1[B * B], sI2[B * B], sGr1[B * B], sGl1[B * B], sGl2[B * B], sD[B * B];
   const int j = 2 * s * blockIdx.x;
   if (j >= cr.nsb) return;
-  const size_t off = (size_t)j * B * B;
+  const size_t BB = (size_t)B * B, off = (size_t)j * BB;
   const int k1 = j - s, k2 = j + s;
-  double acc[NE];
-#pragma unroll
-  for (int it = 0; it < NE; ++it) {
-    const int e = threadIdx.x + it * WAVE;
-    acc[it] = (e < B * B) ? cr.D[off + e] : 0.0;
+  const bool has1 = k1 >= 0, has2 = k2 < cr.nsb, has_ll = (k1 - s) >= 0;
+  lds_load<B>(sD, cr.D + off);
+  if (has1) { lds_load<B>(sLj, cr.L + off); lds_load<B>(sL1, cr.L + (size_t)k1 * BB); lds_load<B>(sI1, cr.Dinv + (size_t)k1 * BB); }
+  if (has2) { lds_load<B>(sL2, cr.L + (size_t)k2 * BB); lds_load<B>(sI2, cr.Dinv + (size_t)k2 * BB); }
+  __syncthreads();
+  if (has1) {
+    lds_matmul<B, false, true>(sGr1, sI1, sLj);       // Dinv_k1 * L_j^T
+    if (has_ll) lds_matmul<B, false, false>(sGl1, sI1, sL1);   // Dinv_k1 * L_k1
+    else for (int e = threadIdx.x; e < B * B; e += WAVE) sGl1[e] = 0.0;
   }
-  const bool do_w = (w != nullptr) && ((int)threadIdx.x < B);
-  if (k1 >= 0) {
-    lds_load<B>(sLj, cr.L + off);
-    lds_load<B>(sG, cr.Gr + (size_t)k1 * B * B);
-    __syncthreads();
-    if (do_w) {
-      for (int v = 0; v < nrhs; ++v) {     // each lane read-modify-writes its own entry of w_j
-        double* wv = w + stride * v;
-        const double* wk = wv + (size_t)k1 * B;
-        double acc_w = wv[(size_t)j * B + threadIdx.x];
+  if (has2) lds_matmul<B, false, false>(sGl2, sI2, sL2);       // Dinv_k2 * L_k2
+  __syncthreads();
+  // factors of the eliminated neighbours, for the back substitution
+  if (has1) for (int e = threadIdx.x; e < B * B; e += WAVE) { cr.Gr[(size_t)k1 * BB + e] = sGr1[e]; cr.Gl[(size_t)k1 * BB + e] = sGl1[e]; }
+  if (has2 && (k2 + s) >= cr.nsb)      // k2 has no right-hand survivor: its Gl comes from here, its Gr is zero
+    for (int e = threadIdx.x; e < B * B; e += WAVE) { cr.Gl[(size_t)k2 * BB + e] = sGl2[e]; cr.Gr[(size_t)k2 * BB + e] = 0.0; }
+  // right-hand-side sweep
+  if (w != nullptr && (int)threadIdx.x < B) {
+    for (int v = 0; v < nrhs; ++v) {
+      double* wv = w + stride * v;
+      double acc_w = wv[(size_t)j * B + threadIdx.x];
+      if (has1) { const double* wk = wv + (size_t)k1 * B;
 #pragma unroll
-        for (int r = 0; r < B; ++r) acc_w -= sG[r * B + threadIdx.x] * wk[r];
-        wv[(size_t)j * B + threadIdx.x] = acc_w;
-      }
-    }
+        for (int r = 0; r < B; ++r) acc_w -= sGr1[r * B + threadIdx.x] * wk[r]; }
+      if (has2) { const double* wk = wv + (size_t)k2 * B;
 #pragma unroll
-    for (int it = 0; it < NE; ++it) {
-      const int e = threadIdx.x + it * WAVE;
-      if (e < B * B) {
-        const int r = e / B, c = e % B;
-        double v = 0.0;
-#pragma unroll
-        for (int q = 0; q < B; ++q) v += sLj[r * B + q] * sG[q * B + c];   // L_j * Gr[k1]
-        acc[it] -= v;
-      }
-    }
-    __syncthreads();
-    lds_load<B>(sG, cr.Gl + (size_t)k1 * B * B);
-    __syncthreads();
-    const bool has_ll = (k1 - s) >= 0;
-    for (int e = threadIdx.x; e < B * B; e += WAVE) {
-      const int r = e / B, c = e % B;
-      double v = 0.0;
-      if (has_ll) {
-#pragma unroll
-        for (int q = 0; q < B; ++q) v -= sLj[r * B + q] * sG[q * B + c];  // -L_j * Gl[k1]
-      }
-      cr.L[off + e] = v;
+        for (int r = 0; r < B; ++r) acc_w -= sGl2[r * B + threadIdx.x] * wk[r]; }
+      wv[(size_t)j * B + threadIdx.x] = acc_w;
     }
   }
-  if (k2 < cr.nsb) {
-    __syncthreads();
-    lds_load<B>(sL2, cr.L + (size_t)k2 * B * B);
-    lds_load<B>(sG, cr.Gl + (size_t)k2 * B * B);
-    __syncthreads();
-    if (do_w) {
-      for (int v = 0; v < nrhs; ++v) {
-        double* wv = w + stride * v;
-        const double* wk = wv + (size_t)k2 * B;
-        double acc_w = wv[(size_t)j * B + threadIdx.x];
+  // Schur complement
+  for (int e = threadIdx.x; e < B * B; e += WAVE) {
+    const int r = e / B, c = e % B;
+    double d = sD[e], l = 0.0;
+    if (has1) {
 #pragma unroll
-        for (int r = 0; r < B; ++r) acc_w -= sG[r * B + threadIdx.x] * wk[r];
-        wv[(size_t)j * B + threadIdx.x] = acc_w;
-      }
+      for (int q = 0; q < B; ++q) { d -= sLj[r * B + q] * sGr1[q * B + c]; l -= sLj[r * B + q] * sGl1[q * B + c]; }
     }
+    if (has2) {
 #pragma unroll
-    for (int it = 0; it < NE; ++it) {
-      const int e = threadIdx.x + it * WAVE;
-      if (e < B * B) {
-        const int r = e / B, c = e % B;
-        double v = 0.0;
+      for (int q = 0; q < B; ++q) d -= sL2[q * B + r] * sGl2[q * B + c];
+    }
+    cr.D[off + e] = d;
+    if (has1) cr.L[off + e] = l;
+    sI1[e] = d;                       // reuse: new D_j for the inversion below (sI1 is dead after the matmuls... see barrier)
+  }
+  // inversion of the new D_j when j is eliminated at the next level
+  if (invert_next && (blockIdx.x & 1)) {
+    __syncthreads();
+    const int grp = threadIdx.x / B, c = threadIdx.x % B;
+    double col[B];
 #pragma unroll
-        for (int q = 0; q < B; ++q) v += sL2[q * B + r] * sG[q * B + c];   // L_{k2}^T * Gl[k2]
-        acc[it] -= v;
-      }
+    for (int r = 0; r < B; ++r) col[r] = (grp == 0) ? sI1[r * B + c] : ((grp == 1 && r == c) ? 1.0 : 0.0);
+    gauss_jordan_cols<B>(col);
+    if (grp == 1) {
+#pragma unroll
+      for (int r = 0; r < B; ++r) cr.Dinv[off + r * B + c] = col[r];
     }
   }
+}
+
+// Dinv of the nodes eliminated at the first level (one wave per node)
+template <int B>
+__global__ __launch_bounds__(WAVE) void k_cr_invert(CrView cr, int s) {
+  const int k = s * (2 * blockIdx.x + 1);
+  if (k >= cr.nsb) return;
+  const size_t off = (size_t)k * B * B;
+  const int grp = threadIdx.x / B, c = threadIdx.x % B;
+  double col[B];
 #pragma unroll
-  for (int it = 0; it < NE; ++it) {
-    const int e = threadIdx.x + it * WAVE;
-    if (e < B * B) cr.D[off + e] = acc[it];
+  for (int r = 0; r < B; ++r) col[r] = (grp == 0) ? cr.D[off + r * B + c] : ((grp == 1 && r == c) ? 1.0 : 0.0);
+  gauss_jordan_cols<B>(col);
+  if (grp == 1) {
+#pragma unroll
+    for (int r = 0; r < B; ++r) cr.Dinv[off + r * B + c] = col[r];
   }
 }
 
@@ -887,11 +894,14 @@ static int cr_top_start(int nsb) {
 template <int B>
 static void cr_factor_t(hipStream_t st, const CrView& cr, double* w, double* x, int nrhs, size_t stride) {
   const int s_top = cr_top_start(cr.nsb);
+  if (s_top > 1) {
+    const int n_elim = (cr.nsb - 1 + 1) / 2;
+    hipLaunchKernelGGL(k_cr_invert<B>, dim3(n_elim), dim3(WAVE), 0, st, cr, 1);
+  }
   for (int s = 1; s < s_top; s *= 2) {
-    const int n_elim = (cr.nsb - s + 2 * s - 1) / (2 * s);
     const int n_surv = (cr.nsb + 2 * s - 1) / (2 * s);
-    hipLaunchKernelGGL(k_cr_eliminate<B>, dim3(n_elim), dim3(WAVE), 0, st, cr, s);
-    hipLaunchKernelGGL(k_cr_update<B>, dim3(n_surv), dim3(WAVE), 0, st, cr, s, w, nrhs, stride);
+    const int invert_next = (2 * s < s_top) ? 1 : 0;    // the fused top kernel inverts its own nodes
+    hipLaunchKernelGGL(k_cr_level<B>, dim3(n_surv), dim3(WAVE), 0, st, cr, s, invert_next, w, nrhs, stride);
   }
   hipLaunchKernelGGL(k_cr_top<B>, dim3(1), dim3(kCrTopThreads), 0, st, cr, s_top, w, x, nrhs, stride);
   if (x != nullptr) {
