@@ -530,8 +530,10 @@ void launch_build_system(hipStream_t st, int n_poses, int Wb, const LinView& lin
 
 // ===========================================================================================
 // block cyclic reduction.  One 64-lane workgroup per super-block; B x B tiles live in LDS.
-// Level stride s: nodes s, 3s, 5s.. are eliminated (k_cr_eliminate), nodes 0, 2s, 4s..
-// survive and absorb the Schur complement (k_cr_update).
+// Level stride s: nodes s, 3s, 5s.. are eliminated, nodes 0, 2s, 4s.. survive and absorb the
+// Schur complement.  k_cr_invert inverts the level-0 odd nodes; k_cr_level then does one whole
+// level per launch (survivor update + rhs sweep + inverse of the next level's odd nodes) and
+// k_cr_top finishes the last kCrTopNodes nodes, the root and their back-substitution.
 // ===========================================================================================
 // Register-resident Gauss-Jordan sweep of one SPD super-block: lane (grp, c) owns column c of
 // the augmented matrix [D | I | L_k | L_{k+s}^T]; for pivot p the pivot column is broadcast from
