@@ -49,6 +49,13 @@ class HumanConstraint(C.Structure):
     ]
 
 
+# numpy view of the same 28-byte row
+import numpy as _np
+HC_DTYPE = _np.dtype([("type", "<u4"), ("constrained_pose_id", "<i4"), ("anchor_pose_id", "<i4"), ("delta_parallel", "<f4"),
+                      ("delta_perpendicular", "<f4"), ("delta_angle", "<f4"), ("relative_penalty_dir", "<f4")])
+assert HC_DTYPE.itemsize == 28
+
+
 class Options(C.Structure):
     _fields_ = [
         ("abi_version", C.c_int32),

@@ -142,7 +142,11 @@ class SolverBase(object):
         self.obs_offset = obs_offset
 
     def set_human_constraints(self, rows):
-        if isinstance(rows, tuple) and len(rows) == 2 and isinstance(rows[1], int):
+        if isinstance(rows, np.ndarray) and rows.dtype == abi.HC_DTYPE:
+            rows = np.ascontiguousarray(rows)
+            self._hc_keepalive = rows
+            arr, n = C.cast(rows.ctypes.data_as(C.c_void_p), C.POINTER(abi.HumanConstraint)), int(rows.size)
+        elif isinstance(rows, tuple) and len(rows) == 2 and isinstance(rows[1], int):
             arr, n = rows
         else:
             arr, n = hc_rows(rows)
@@ -215,6 +219,117 @@ class SolverBase(object):
         self._check(f(self._h, _ptr(pin, _f32p), _ptr(seg, _f32p), C.c_double(threshold), _ptr(counts, _i32p),
                       _ptr(mask, C.POINTER(C.c_uint8))), "solve")
         return counts, (mask[:n_obs] if want_mask else None)
+
+    # -- the correction cycle around the solve (HitLSLAM::Run) ------------------------------
+    def _cycle_fn(self, key):
+        return getattr(self._lib, self._cycle_names[key])
+
+    def _cycle_check(self, st, key):
+        if st != abi.OK:
+            raise HitlError(st, self._cycle_names[key], self._detail())
+
+    def fit_segments(self, poses_xyt, segments_xy4):
+        """== EMInput::AutomaticEndpointAdjustment: (segments [k,4], inliers [k], passes [k], lm iterations [k])."""
+        pin = _as(poses_xyt, np.float32).reshape(-1)
+        seg = np.array(segments_xy4, np.float32).reshape(-1, 4).copy()
+        k = seg.shape[0]
+        inl, pas, its = np.zeros(k, np.int32), np.zeros(k, np.int32), np.zeros(k, np.int32)
+        f = self._cycle_fn("fit")
+        f.argtypes = [C.c_void_p, _f32p, C.c_int32, _f32p, _i32p, _i32p, _i32p]
+        f.restype = C.c_int
+        self._cycle_check(f(self._h, _ptr(pin, _f32p), k, _ptr(seg, _f32p), _ptr(inl, _i32p), _ptr(pas, _i32p), _ptr(its, _i32p)), "fit")
+        return seg, inl, pas, its
+
+    def order_user_input(self, counts, seg_xy8):
+        """== EMInput::OrderAndFilterUserInput: dict(corrected, anchor, bounds, seg_xy8)."""
+        counts = _as(counts, np.int32).reshape(-1, 2)
+        n = counts.shape[0]
+        seg = np.array(seg_xy8, np.float32).reshape(-1).copy()
+        assert seg.size == 8
+        corr, anch = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32)
+        nc, na = C.c_int32(), C.c_int32()
+        bounds = np.zeros(2, np.int32)
+        f = self._cycle_fn("order")
+        f.argtypes = [C.c_int64, _i32p, _f32p, _i32p, C.POINTER(C.c_int32), _i32p, C.POINTER(C.c_int32), _i32p]
+        f.restype = C.c_int
+        self._cycle_check(f(n, _ptr(counts, _i32p), _ptr(seg, _f32p), _ptr(corr, _i32p), C.byref(nc), _ptr(anch, _i32p), C.byref(na),
+                            _ptr(bounds, _i32p)), "order")
+        return dict(corrected=corr[:nc.value].copy(), anchor=anch[:na.value].copy(), bounds=(int(bounds[0]), int(bounds[1])),
+                    seg_xy8=seg)
+
+    def apply_explicit_correction(self, ctype, seg_xy8, poses_xyt, corrected, anchor):
+        """== AppExpCorrect::Run: (poses [n,3], correction [3], rows as abi.HC_DTYPE [n_anchor*n_corrected])."""
+        poses = np.array(poses_xyt, np.float32).reshape(-1).copy()
+        n = poses.size // 3
+        seg = _as(seg_xy8, np.float32).reshape(-1)
+        corr, anch = _as(corrected, np.int32).reshape(-1), _as(anchor, np.int32).reshape(-1)
+        rows = np.zeros(max(corr.size * anch.size, 1), abi.HC_DTYPE)
+        cvec = np.zeros(3, np.float32)
+        f = self._cycle_fn("explicit")
+        head = [C.c_void_p] if self._cycle_handle else []
+        f.argtypes = head + [C.c_uint32, _f32p, C.c_int64, _f32p, C.c_int32, _i32p, C.c_int32, _i32p, _f32p, C.c_void_p]
+        f.restype = C.c_int
+        args = ([self._h] if self._cycle_handle else []) + [
+            int(ctype), _ptr(seg, _f32p), n, _ptr(poses, _f32p), corr.size, _ptr(corr, _i32p), anch.size, _ptr(anch, _i32p),
+            _ptr(cvec, _f32p), rows.ctypes.data_as(C.c_void_p)]
+        self._cycle_check(f(*args), "explicit")
+        return poses.reshape(-1, 3), cvec, rows[:corr.size * anch.size]
+
+    def backprop(self, poses_xyt, cov9, lo, hi, correction):
+        """== Backprop::Run: (poses [n,3], cov9 [n,9])."""
+        poses = np.array(poses_xyt, np.float32).reshape(-1).copy()
+        cov = np.array(cov9, np.float32).reshape(-1).copy()
+        n = poses.size // 3
+        assert cov.size == 9 * n
+        cvec = _as(correction, np.float32).reshape(-1)
+        f = self._cycle_fn("backprop")
+        head = [C.c_void_p] if self._cycle_handle else []
+        tail = [] if self._cycle_handle else [_f64p]
+        f.argtypes = head + [C.c_int64, _f32p, _f32p, C.c_int32, C.c_int32, _f32p] + tail
+        f.restype = C.c_int
+        args = ([self._h] if self._cycle_handle else []) + [n, _ptr(poses, _f32p), _ptr(cov, _f32p), int(lo), int(hi), _ptr(cvec, _f32p)]
+        if not self._cycle_handle:
+            args.append(None)
+        self._cycle_check(f(*args), "backprop")
+        return poses.reshape(-1, 3), cov.reshape(-1, 9)
+
+    def normalize_angles(self, poses_xyt):
+        poses = np.array(poses_xyt, np.float32).reshape(-1).copy()
+        f = self._cycle_fn("normalize")
+        f.argtypes = [C.c_int64, _f32p]
+        f.restype = None if not self._cycle_handle else C.c_int
+        f(poses.size // 3, _ptr(poses, _f32p))
+        return poses.reshape(-1, 3)
+
+    def run_correction(self, ctype, selected_points_xy8, poses_xyt, cov9, constraint_groups, mode=abi.MODE_ODOM_HC,
+                       select_threshold=0.05):
+        """One whole HitLSLAM::Run (HitLSLAM.cpp:380-480) on this backend.  constraint_groups is the session's list of
+        row arrays (human_constraints_); returns dict(poses, cov9, constraint_groups, summary, status, ...)."""
+        poses = np.array(poses_xyt, np.float32).reshape(-1, 3)
+        cov = np.array(cov9, np.float32).reshape(-1, 9)
+        pts = np.array(selected_points_xy8, np.float32).reshape(-1)
+        out = dict(poses=poses, cov9=cov, constraint_groups=list(constraint_groups), summary=None, status="ok")
+        seen = self.verify_points(poses, pts.reshape(-1, 2), select_threshold)
+        if int(seen.sum()) != pts.size // 2:                    # verifyUserInput: every clicked point must be near a scan point
+            out["status"] = "not verified"
+            return out
+        seg, inl, pas, its = self.fit_segments(poses, pts.reshape(2, 4))
+        counts, _ = self.observation_sets(poses, seg.reshape(-1), 0.03, want_mask=False)
+        od = self.order_user_input(counts, seg.reshape(-1))
+        out.update(fitted=seg, order=od)
+        lo, hi = od["bounds"]
+        if not (lo >= 0 and hi >= 1):
+            out["status"] = "selection overlap"
+            return out
+        poses, correction, rows = self.apply_explicit_correction(ctype, od["seg_xy8"], poses, od["corrected"], od["anchor"])
+        out["constraint_groups"].append(rows)
+        poses, cov = self.backprop(poses, cov, lo, hi, correction)
+        poses = self.normalize_angles(poses)
+        allrows = np.concatenate(out["constraint_groups"]) if out["constraint_groups"] else np.zeros(0, abi.HC_DTYPE)
+        self.set_human_constraints(allrows)
+        poses, summ = self.solve(mode, poses)
+        out.update(poses=poses, cov9=cov, summary=summ, correction=correction)
+        return out
 
     # -- the path --------------------------------------------------------------------------
     def solve(self, mode, poses_xyt, allow_failure=False):
@@ -311,6 +426,10 @@ class Solver(SolverBase):
                   find_corr="hitl_solver_find_correspondences")
     _scan_names = dict(transform="hitl_solver_transform_scans", verify="hitl_solver_verify_points",
                        obs_sets="hitl_solver_observation_sets")
+    _cycle_names = dict(fit="hitl_solver_fit_segments", order="hitl_order_user_input",
+                        explicit="hitl_solver_apply_explicit_correction", backprop="hitl_solver_backprop",
+                        normalize="hitl_normalize_angles")
+    _cycle_handle = True
 
     def __init__(self, options=None, lib_path=None):
         lib = load_library(lib_path)

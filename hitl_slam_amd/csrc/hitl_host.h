@@ -1,0 +1,74 @@
+// hitl_host.h -- host-side helpers shared by the .cpp files of libhitlgpu.so (error slot, HIP call checks,
+// device arrays, a narrow view of the solver object for the files that do not own it).
+#pragma once
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "hitl_internal.h"
+
+struct hitl_solver;
+
+namespace hitl {
+
+int fail(int code, const std::string& msg);   // records the message behind hitl_last_error(); returns code
+
+#define HIP_TRY(expr)                                                                           \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess)                                                                       \
+      return fail(e_ == hipErrorOutOfMemory ? HITL_ERR_OUT_OF_MEMORY : HITL_ERR_HIP,             \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                           \
+  } while (0)
+
+#define TRY(expr)            \
+  do {                       \
+    int s_ = (expr);         \
+    if (s_ != HITL_OK) return s_; \
+  } while (0)
+
+template <typename T>
+struct DevArray {
+  T* p = nullptr;
+  size_t cap = 0;
+  size_t n = 0;
+  int resize(size_t count) {
+    n = count;
+    if (count <= cap && p) return HITL_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    const size_t want = std::max<size_t>(count, 1);
+    HIP_TRY(hipMalloc((void**)&p, want * sizeof(T)));
+    cap = want;
+    return HITL_OK;
+  }
+  int upload(const T* src, size_t count, hipStream_t st) {
+    TRY(resize(count));
+    if (count) HIP_TRY(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, st));
+    return HITL_OK;
+  }
+  int upload(const std::vector<T>& v, hipStream_t st) { return upload(v.data(), v.size(), st); }
+  int zero(hipStream_t st) {
+    if (n) HIP_TRY(hipMemsetAsync(p, 0, n * sizeof(T), st));
+    return HITL_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = n = 0;
+  }
+};
+
+// what hitl_cycle.cpp needs from a solver (defined in hitl_solver.cpp)
+struct SolverCtx {
+  int device;
+  hipStream_t stream;
+  int n;             // poses of the resident map
+  int64_t n_obs;
+  int world;
+  MapView map;
+};
+int solver_ctx(hitl_solver* s, SolverCtx* out);
+
+}  // namespace hitl

@@ -134,6 +134,22 @@ void launch_verify(hipStream_t st, const MapView& map, const float* T4, int n, c
 void launch_obs_sets(hipStream_t st, const MapView& map, const float* T4, const float* seg8, double thr, int* counts,
                      unsigned char* mask);
 
+// endpoint fit (hitl_obs.hip): inlier scan of one segment (counts per pose, or -- with offsets -- the inliers' world
+// points in reading order) and one evaluation of the 1-parameter line problem over them
+void launch_fit_inliers(hipStream_t st, const MapView& map, const float* T4, const float* seg4, int* counts, const int64_t* offsets,
+                        float2* points);
+int fit_eval_blocks(int64_t m);
+void launch_fit_eval(hipStream_t st, const float2* pts, int64_t m, double cmx, double cmy, double len, double c, double s,
+                     double* partial);
+
+// pose-chain stages of the correction cycle (hitl_cycle.hip)
+void launch_explicit_apply(hipStream_t st, float* poses, const float* args14, int n, int g0, int g1);
+void launch_constraint_rows(hipStream_t st, const float* poses, const void* anchors, const int* corrected, int n_anchor, int n_corr,
+                            unsigned type, void* rows);
+int backprop_blocks(int L);
+void launch_backprop(hipStream_t st, float* poses, float* cov9, int lo, int hi, const float* piv4, const float* tw, float* xf, int* sync,
+                     float destx, float desty, float trans_beta, float rot_beta, float* trans2);
+
 const char* kernels_build_info();
 
 }  // namespace hitl

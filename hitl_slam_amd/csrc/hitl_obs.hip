@@ -99,6 +99,111 @@ __global__ __launch_bounds__(kObsBlock) void k_obs_sets(MapView map, int chunk, 
   if (threadIdx.x < 2) counts[2 * i + threadIdx.x] = s_cnt[threadIdx.x];
 }
 
+// ---- EMInput::AutomaticEndpointAdjustment (EMinput.cpp:195-250): inlier scan + ordered gather ----------------
+__device__ __forceinline__ float distance_to_line_segment(float p0x, float p0y, float p1x, float p1y, float px, float py) {
+  // Eigen::DistanceToLineSegment (shared/math/eigen_helper.h:66-81), fp32.  t is a length along the UNIT direction
+  // and is compared with 1.0 there, so beyond 1 m along the segment the distance is taken to p1 -- kept as is.
+  const float dx = p1x - p0x, dy = p1y - p0y;
+  const float nrm = __fsqrt_rn(dx * dx + dy * dy);
+  const float ux = dx / nrm, uy = dy / nrm;
+  const float qx = px - p0x, qy = py - p0y;
+  const float t = qx * ux + qy * uy;
+  if (t < 0.0f) return __fsqrt_rn(qx * qx + qy * qy);
+  if (t > 1.0f) { const float ex = px - p1x, ey = py - p1y; return __fsqrt_rn(ex * ex + ey * ey); }
+  return fabsf(-uy * qx + ux * qy);
+}
+
+struct FitSeg { float s[4]; };
+
+// pass 1: inliers per pose.  pass 2 (offsets != nullptr): world points of the inliers, in (pose, observation) order.
+__global__ __launch_bounds__(kObsBlock) void k_fit_inliers(MapView map, int chunk, const PoseRT* __restrict__ T, FitSeg fs,
+                                                           int* __restrict__ counts, const int64_t* __restrict__ offsets,
+                                                           float2* __restrict__ points) {
+  __shared__ int s_wave[kObsBlock / 64];
+  __shared__ int s_base;
+  const int i = pose_of_block(map.n_poses, chunk);
+  if (i < 0) return;
+  const PoseRT t = T[i];
+  const int64_t o = map.obs_off[i];
+  const int m = (int)(map.obs_off[i + 1] - o);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) s_base = 0;
+  __syncthreads();
+  for (int k0 = 0; k0 < m; k0 += kObsBlock) {
+    const int k = k0 + threadIdx.x;
+    bool in = false;
+    float2 w = make_float2(0.f, 0.f);
+    if (k < m) {
+      const float4 a = map.obs[o + k];
+      w = to_world(t, a.x, a.y);
+      in = (double)distance_to_line_segment(fs.s[0], fs.s[1], fs.s[2], fs.s[3], w.x, w.y) < 0.03;
+    }
+    const unsigned long long bal = __ballot(in);
+    if (lane == 0) s_wave[wave] = __popcll(bal);
+    __syncthreads();
+    int before = s_base;
+    for (int v = 0; v < wave; ++v) before += s_wave[v];
+    if (in && offsets) points[offsets[i] + before + __popcll(bal & ((1ull << lane) - 1ull))] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) { int tot = 0; for (int v = 0; v < kObsBlock / 64; ++v) tot += s_wave[v]; s_base += tot; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && counts) counts[i] = s_base;
+}
+
+// segDistResidualEM (EMinput.cpp:107-150) and its derivative in closed form.  With a = (cos, sin), u = p - cm,
+// along = u.a, perp = u.perp(a):  inside the segment r = |perp|, dr = -sign(perp) along;  beyond the +len end
+// r = |(along - len, perp)|, dr = -len perp / r;  beyond the -len end r = |(along + len, perp)|, dr = len perp / r.
+// partial[g] = (sum r^2, sum dr r, sum dr^2) of a fixed contiguous slice, summed in a fixed order.
+constexpr int kFitBlock = 256;
+struct FitLine { double cmx, cmy, len, c, s; };
+
+__global__ __launch_bounds__(kFitBlock) void k_fit_eval(const float2* __restrict__ pts, int64_t m, int64_t per_block, FitLine fl,
+                                                        double* __restrict__ partial) {
+  __shared__ double s_red[3][kFitBlock / 64];
+  const int64_t b0 = (int64_t)blockIdx.x * per_block, b1 = (b0 + per_block < m) ? b0 + per_block : m;
+  double a0 = 0, a1 = 0, a2 = 0;
+  for (int64_t q = b0 + threadIdx.x; q < b1; q += kFitBlock) {
+    const float2 p = pts[q];
+    const double ux = (double)p.x - fl.cmx, uy = (double)p.y - fl.cmy;
+    const double along = ux * fl.c + uy * fl.s, perp = -ux * fl.s + uy * fl.c;
+    double r, dr;
+    if (along > fl.len) { const double e = along - fl.len; r = sqrt(e * e + perp * perp); dr = -fl.len * perp / r; }
+    else if (along < -fl.len) { const double e = along + fl.len; r = sqrt(e * e + perp * perp); dr = fl.len * perp / r; }
+    else { r = fabs(perp); dr = (perp < 0.0) ? along : -along; }
+    a0 += r * r; a1 += dr * r; a2 += dr * dr;
+  }
+  for (int sft = 32; sft >= 1; sft >>= 1) { a0 += __shfl_xor(a0, sft, 64); a1 += __shfl_xor(a1, sft, 64); a2 += __shfl_xor(a2, sft, 64); }
+  if ((threadIdx.x & 63) == 0) { s_red[0][threadIdx.x >> 6] = a0; s_red[1][threadIdx.x >> 6] = a1; s_red[2][threadIdx.x >> 6] = a2; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    double t = 0;
+    for (int v = 0; v < kFitBlock / 64; ++v) t += s_red[threadIdx.x][v];
+    partial[3 * blockIdx.x + threadIdx.x] = t;
+  }
+}
+
+void launch_fit_inliers(hipStream_t st, const MapView& map, const float* T4, const float* seg4, int* counts, const int64_t* offsets,
+                        float2* points) {
+  FitSeg fs;
+  for (int q = 0; q < 4; ++q) fs.s[q] = seg4[q];
+  const int chunk = (map.n_poses + 7) / 8;
+  hipLaunchKernelGGL(k_fit_inliers, dim3(8 * chunk), dim3(kObsBlock), 0, st, map, chunk, (const PoseRT*)T4, fs, counts, offsets, points);
+}
+
+int fit_eval_blocks(int64_t m) {
+  const int64_t want = (m + 4 * kFitBlock - 1) / (4 * kFitBlock);
+  return (int)(want < 1 ? 1 : (want > 256 ? 256 : want));
+}
+
+void launch_fit_eval(hipStream_t st, const float2* pts, int64_t m, double cmx, double cmy, double len, double c, double s,
+                     double* partial /* 3 * fit_eval_blocks(m) */) {
+  const int g = fit_eval_blocks(m);
+  const int64_t per = (m + g - 1) / g;
+  FitLine fl{cmx, cmy, len, c, s};
+  hipLaunchKernelGGL(k_fit_eval, dim3(g), dim3(kFitBlock), 0, st, pts, m, per, fl, partial);
+}
+
 void launch_transform(hipStream_t st, const MapView& map, const float* T4, float2* world) {
   const int chunk = (map.n_poses + 7) / 8;
   hipLaunchKernelGGL(k_transform, dim3(8 * chunk), dim3(kObsBlock), 0, st, map, chunk, (const PoseRT*)T4, world);

@@ -18,62 +18,16 @@
 #include <rccl/rccl.h>
 
 #include "hitl_internal.h"
+#include "hitl_host.h"
 
 namespace hitl {
 
 static thread_local std::string g_last_error;
 
-static int fail(int code, const std::string& msg) {
+int fail(int code, const std::string& msg) {
   g_last_error = msg;
   return code;
 }
-
-#define HIP_TRY(expr)                                                                           \
-  do {                                                                                          \
-    hipError_t e_ = (expr);                                                                     \
-    if (e_ != hipSuccess)                                                                       \
-      return fail(e_ == hipErrorOutOfMemory ? HITL_ERR_OUT_OF_MEMORY : HITL_ERR_HIP,             \
-                  std::string(#expr) + ": " + hipGetErrorString(e_));                           \
-  } while (0)
-
-#define TRY(expr)            \
-  do {                       \
-    int s_ = (expr);         \
-    if (s_ != HITL_OK) return s_; \
-  } while (0)
-
-template <typename T>
-struct DevArray {
-  T* p = nullptr;
-  size_t cap = 0;
-  size_t n = 0;
-  int resize(size_t count) {
-    n = count;
-    if (count <= cap && p) return HITL_OK;
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    cap = 0;
-    const size_t want = std::max<size_t>(count, 1);
-    HIP_TRY(hipMalloc((void**)&p, want * sizeof(T)));
-    cap = want;
-    return HITL_OK;
-  }
-  int upload(const T* src, size_t count, hipStream_t st) {
-    TRY(resize(count));
-    if (count) HIP_TRY(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, st));
-    return HITL_OK;
-  }
-  int upload(const std::vector<T>& v, hipStream_t st) { return upload(v.data(), v.size(), st); }
-  int zero(hipStream_t st) {
-    if (n) HIP_TRY(hipMemsetAsync(p, 0, n * sizeof(T), st));
-    return HITL_OK;
-  }
-  void release() {
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    cap = n = 0;
-  }
-};
 
 static inline double angle_mod(double a) {  // shared/math/util.h:433-439
   return a - 6.28318530717958647692 * std::rint(a / 6.28318530717958647692);
@@ -177,6 +131,13 @@ struct hitl_solver {
 };
 
 namespace hitl {
+
+int solver_ctx(hitl_solver* s, SolverCtx* out) {
+  if (!s) return fail(HITL_ERR_INVALID_ARGUMENT, "null solver");
+  out->device = s->device; out->stream = s->stream; out->n = s->n; out->n_obs = s->n_obs; out->world = s->world;
+  out->map = s->map_view();
+  return HITL_OK;
+}
 
 // ---------------------------------------------------------------------------------------
 // derived pair structures (host, O(P)); called whenever the correspondence set changes

@@ -211,6 +211,36 @@ int hitl_solver_verify_points(hitl_solver*, const float* poses_xyt, int32_t n_po
 int hitl_solver_observation_sets(hitl_solver*, const float* poses_xyt, const float* seg_xy8, double threshold,
                                  int32_t* counts, uint8_t* mask);
 
+/* ---- the correction cycle around the solve (HitLSLAM::Run, HitLSLAM.cpp:380-480) -----
+ * One user correction is: verify_points -> fit_segments -> observation_sets -> order_user_input ->
+ * apply_explicit_correction -> backprop -> normalize_angles -> set_human_constraints + solve -> transform_scans.
+ * fp32 like the reference; float transcendental scalars are the C library's.  Single-GPU entry points.
+ *
+ * hitl_solver_fit_segments == EMInput::AutomaticEndpointAdjustment + SegFitEM (EMinput.cpp:153-250): each of the
+ *     n_segments rows of seg_xy4 (x0,y0,x1,y1; in/out) is re-fitted to the world-frame observations within 3 cm of it
+ *     (Eigen::DistanceToLineSegment as written, shared/math/eigen_helper.h:66-81) by a 1-parameter trust-region solve
+ *     (25 iterations, Ceres defaults), repeated until both endpoints move less than 5 cm.  Outputs (may be NULL):
+ *     inliers of the last pass, number of passes, total LM iterations per segment.
+ * hitl_order_user_input == EMInput::OrderAndFilterUserInput (EMinput.cpp:325-455), pure index logic on the counts
+ *     of hitl_solver_observation_sets: corrected / anchor pose ids (capacity n_poses each), backprop bounds
+ *     ((-1,-1) on overlap); seg_xy8 is swapped in place when the selections came in the wrong order.
+ * hitl_solver_apply_explicit_correction == AppExpCorrect::Run (ApplyExplicitCorrection.cpp:150-180, 229-494) for
+ *     types 2, 4, 5, 6: moves the first contiguous group of corrected poses and everything after it (poses_xyt in/out),
+ *     returns correction_ and the n_anchor x n_corrected new_human_constraints_ rows (anchor-major).
+ * hitl_solver_backprop == Backprop::Run (Backprop.cpp:98-213): poses in [lo, hi] and covariances in [lo, hi) are
+ *     updated in place; the two O(span^2) loops are reproduced update by update (bit-identical fp32 poses).
+ * hitl_normalize_angles == HitLSLAM.cpp:442-447. */
+int hitl_solver_fit_segments(hitl_solver*, const float* poses_xyt, int32_t n_segments, float* seg_xy4, int32_t* n_inliers,
+                             int32_t* passes, int32_t* lm_iterations);
+int hitl_order_user_input(int64_t n_poses, const int32_t* counts, float* seg_xy8, int32_t* corrected, int32_t* n_corrected,
+                          int32_t* anchor, int32_t* n_anchor, int32_t bounds[2]);
+int hitl_solver_apply_explicit_correction(hitl_solver*, uint32_t type, const float* seg_xy8, int64_t n_poses, float* poses_xyt,
+                                          int32_t n_corrected, const int32_t* corrected, int32_t n_anchor, const int32_t* anchor,
+                                          float correction[3], hitl_human_constraint_t* rows);
+int hitl_solver_backprop(hitl_solver*, int64_t n_poses, float* poses_xyt, float* cov9, int32_t lo, int32_t hi,
+                         const float correction[3]);
+int hitl_normalize_angles(int64_t n_poses, float* poses_xyt);
+
 /* Debug / parity: linearise at double-precision poses x (3*n_poses) with the odometry
  * measurements and human targets derived from the fp32 poses_ref_xyt; returns the cost, the
  * gradient (3n), the per-pair STF residuals (2 per pair) and Jacobians (12 per pair,

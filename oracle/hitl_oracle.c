@@ -1080,3 +1080,328 @@ int orc_observation_sets(orc_solver* s, const float* poses, const float* seg, do
   }
   return HITL_OK;
 }
+
+/* ===================================================================================== */
+/* the correction cycle around the solve: EMInput, AppExpCorrect,       */
+/* Backprop and the angle normalisation of HitLSLAM::Run.  fp32 where the reference is    */
+/* fp32; libm float overloads (acosf, atan2f, sinf, cosf) as a GCC >= 6 build resolves the */
+/* unqualified calls on float arguments; no fp contraction.                               */
+/* ===================================================================================== */
+
+/* Eigen::DistanceToLineSegment, shared/math/eigen_helper.h:66-81.  NOTE the reference tests
+ * t > 1 against the UNIT direction, i.e. "more than 1 m along the segment", not "past p1". */
+static float distance_to_line_segment(const float* p0, const float* p1, float px, float py) {
+  const float dx = p1[0] - p0[0], dy = p1[1] - p0[1];
+  const float nrm = sqrtf(dx * dx + dy * dy);
+  const float ux = dx / nrm, uy = dy / nrm;
+  const float qx = px - p0[0], qy = py - p0[1];
+  const float t = qx * ux + qy * uy;
+  if (t < 0.0f) return sqrtf(qx * qx + qy * qy);
+  if (t > 1.0f) { const float ex = px - p1[0], ey = py - p1[1]; return sqrtf(ex * ex + ey * ey); }
+  return fabsf(-uy * qx + ux * qy);
+}
+
+/* segDistResidualEM, EMinput.cpp:107-150, evaluated on duals (d[0] = d/dtheta). */
+static void seg_residual_em(double theta, double px, double py, double cmx, double cmy, double len, double* r, double* dr) {
+  jet th = jvar(theta, 0);
+  jet ax = jcos(th), ay = jsin(th);
+  jet nrm = jsqrt(jadd(jmul(ax, ax), jmul(ay, ay)));   /* alpha.normalize() */
+  ax = jdiv(ax, nrm); ay = jdiv(ay, nrm);
+  jet p1x = jadd(jconst(cmx), jmul(jconst(len), ax)), p1y = jadd(jconst(cmy), jmul(jconst(len), ay));
+  jet p2x = jsub(jconst(cmx), jmul(jconst(len), ax)), p2y = jsub(jconst(cmy), jmul(jconst(len), ay));
+  jet ex = jsub(p2x, p1x), ey = jsub(p2y, p1y);
+  jet qx = jsub(jconst(px), p1x), qy = jsub(jconst(py), p1y);
+  jet t = jdiv(jadd(jmul(qx, ex), jmul(qy, ey)), jadd(jmul(ex, ex), jmul(ey, ey)));
+  jet res;
+  if (t.v < 0.0) res = jsqrt(jadd(jmul(qx, qx), jmul(qy, qy)));
+  else if (t.v > 1.0) { jet fx = jsub(jconst(px), p2x), fy = jsub(jconst(py), p2y); res = jsqrt(jadd(jmul(fx, fx), jmul(fy, fy))); }
+  else {
+    jet gx = jsub(jconst(px), jadd(p1x, jmul(t, ex))), gy = jsub(jconst(py), jadd(p1y, jmul(t, ey)));
+    res = jsqrt(jadd(jmul(gx, gx), jmul(gy, gy)));
+  }
+  *r = res.v; *dr = res.d[0];
+}
+
+static void seg_fit_eval(double theta, const double* data, int64_t n, double cmx, double cmy, double len, double* cost, double* g, double* h) {
+  double c = 0, gg = 0, hh = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    double r, dr; seg_residual_em(theta, data[2 * i], data[2 * i + 1], cmx, cmy, len, &r, &dr);
+    c += r * r; gg += dr * r; hh += dr * dr;
+  }
+  *cost = 0.5 * c; *g = gg; *h = hh;
+}
+
+/* EMInput::SegFitEM, EMinput.cpp:153-191: ceres::Solve, DENSE_QR, 25 iterations, one parameter.
+ * Same trust-region semantics as orc_solve_f64 above, specialised to a 1x1 system. */
+static int seg_fit_em(const double p1[2], const double p2[2], const double* data, int64_t n, float ep[4], int* iterations) {
+  const double icx = (p1[0] + p2[0]) / 2.0, icy = (p1[1] + p2[1]) / 2.0;
+  const double hy = sqrt((p1[0] - p2[0]) * (p1[0] - p2[0]) + (p1[1] - p2[1]) * (p1[1] - p2[1]));
+  const double ad = fabs(p1[0] - p2[0]);
+  double theta = acos(ad / hy);
+  const double len = hy / 2.0;
+  double cost, g, h;
+  seg_fit_eval(theta, data, n, icx, icy, len, &cost, &g, &h);
+  const double scale = 1.0 / (1.0 + sqrt(h));
+  double radius = 1e4, decrease_factor = 2.0;
+  int iter = 0, invalid_run = 0, failed = 0;
+  int done = fabs(g) <= 1e-10;
+  while (!done) {
+    if (iter >= 25) break;
+    ++iter;
+    const double hs = h * scale * scale;
+    double dg = hs; if (dg < 1e-6) dg = 1e-6; if (dg > 1e32) dg = 1e32;
+    const double dt = -scale * g / (hs + dg / radius);
+    const double mcc = -dt * scale * g - 0.5 * dt * dt * hs;
+    if (!isfinite(dt) || mcc < 0.0) {
+      if (++invalid_run >= 5) { failed = 1; break; }
+      radius /= decrease_factor; decrease_factor *= 2.0;
+      continue;
+    }
+    invalid_run = 0;
+    const double step = scale * dt, cand = theta + step;
+    double cc, cg, ch;
+    seg_fit_eval(cand, data, n, icx, icy, len, &cc, &cg, &ch);
+    if (fabs(step) <= 1e-8 * (fabs(theta) + 1e-8)) break;
+    const double cost_change = cost - cc;
+    if (fabs(cost_change) <= 1e-6 * cost) break;
+    const double rho = cost_change / mcc;
+    if (rho > 1e-3) {
+      theta = cand; cost = cc; g = cg; h = ch;
+      if (fabs(g) <= 1e-10) break;
+      const double q = 2.0 * rho - 1.0;
+      double f = 1.0 - q * q * q; if (f < 1.0 / 3.0) f = 1.0 / 3.0;
+      radius = radius / f; if (radius > 1e16) radius = 1e16;
+      decrease_factor = 2.0;
+    } else {
+      radius /= decrease_factor; decrease_factor *= 2.0;
+      if (radius < 1e-32) break;
+    }
+  }
+  if (iterations) *iterations = iter;
+  double ax = cos(theta), ay = sin(theta);
+  const double nrm = sqrt(ax * ax + ay * ay); ax /= nrm; ay /= nrm;
+  ep[0] = (float)(icx + len * ax); ep[1] = (float)(icy + len * ay);
+  ep[2] = (float)(icx - len * ax); ep[3] = (float)(icy - len * ay);
+  return failed;
+}
+
+int orc_fit_segments(orc_solver* s, const float* poses, int32_t n_seg, float* seg, int32_t* n_inliers, int32_t* passes, int32_t* lm_iterations) {
+  /* EMInput::AutomaticEndpointAdjustment, EMinput.cpp:195-250 (world points re-derived from the poses as
+   * HitLSLAM::transformPointCloudsToWorldFrame made them, HitLSLAM.cpp:245-254) */
+  if (!s || !s->obs_offset) return HITL_ERR_NOT_READY;
+  const int64_t total = s->obs_offset[s->n];
+  float* wx = (float*)malloc((size_t)total * 4 + 4); float* wy = (float*)malloc((size_t)total * 4 + 4);
+  double* data = (double*)malloc((size_t)total * 16 + 16);
+  orc_transform_scans(s, poses, wx, wy);
+  int st = HITL_OK;
+  for (int k = 0; k < n_seg && st == HITL_OK; ++k) {
+    float* sp = seg + 4 * k;
+    const double thresh = 0.05;
+    double adj1 = 2 * thresh, adj2 = 2 * thresh;
+    int pass = 0, it_total = 0; int64_t m = 0;
+    while (adj1 > thresh || adj2 > thresh) {
+      if (sp[0] == sp[2] && sp[1] == sp[3]) { st = HITL_ERR_INVALID_ARGUMENT; break; }
+      if (++pass > 64) { st = HITL_ERR_SOLVER_FAILURE; break; }
+      m = 0;
+      for (int64_t q = 0; q < total; ++q)
+        if ((double)distance_to_line_segment(sp, sp + 2, wx[q], wy[q]) < 0.03) { data[2 * m] = wx[q]; data[2 * m + 1] = wy[q]; ++m; }
+      const double P1[2] = {sp[0], sp[1]}, P2[2] = {sp[2], sp[3]};
+      float ep[4]; int it = 0;
+      if (seg_fit_em(P1, P2, data, m, ep, &it)) { st = HITL_ERR_SOLVER_FAILURE; break; }
+      it_total += it;
+      const float a0 = sp[0] - ep[0], a1 = sp[1] - ep[1], b0 = sp[2] - ep[2], b1 = sp[3] - ep[3];
+      adj1 = sqrtf(a0 * a0 + a1 * a1); adj2 = sqrtf(b0 * b0 + b1 * b1);
+      memcpy(sp, ep, sizeof(ep));
+    }
+    if (n_inliers) n_inliers[k] = (int32_t)m;
+    if (passes) passes[k] = pass;
+    if (lm_iterations) lm_iterations[k] = it_total;
+  }
+  free(wx); free(wy); free(data);
+  return st;
+}
+
+/* EMInput::OrderAndFilterUserInput, EMinput.cpp:325-455.  counts = orc_observation_sets output. */
+static int32_t erase_values(int32_t* v, int32_t n, const int32_t* drop, int32_t nd) {
+  for (int32_t d = 0; d < nd; ++d) { int32_t w = 0; for (int32_t i = 0; i < n; ++i) if (v[i] != drop[d]) v[w++] = v[i]; n = w; }
+  return n;
+}
+
+int orc_order_user_input(int64_t n_poses, const int32_t* counts, float* seg8, int32_t* corrected, int32_t* n_corrected,
+                         int32_t* anchor, int32_t* n_anchor, int32_t bounds[2]) {
+  int32_t* first = (int32_t*)malloc((size_t)n_poses * 4 + 4); int32_t* second = (int32_t*)malloc((size_t)n_poses * 4 + 4);
+  int32_t* over = (int32_t*)malloc((size_t)n_poses * 4 + 4);
+  int32_t nf = 0, ns = 0, no = 0;
+  for (int64_t i = 0; i < n_poses; ++i) { if (counts[2 * i] > 5) first[nf++] = (int32_t)i; if (counts[2 * i + 1] > 5) second[ns++] = (int32_t)i; }
+  for (int32_t i = 0; i < ns; ++i) for (int32_t j = 0; j < nf; ++j) if (second[i] == first[j]) over[no++] = first[j];
+  int start = 0, end = 0, st = HITL_OK;
+  *n_corrected = 0; *n_anchor = 0;
+  if (no == nf && no == ns) { start = end = -1; }
+  else if (no == nf) ns = erase_values(second, ns, over, no);
+  else if (no == ns) nf = erase_values(first, nf, over, no);
+  else if (no > 0) { nf = erase_values(first, nf, over, no); ns = erase_values(second, ns, over, no); }
+  if (nf == 0 || ns == 0) { start = end = -1; st = HITL_ERR_INVALID_ARGUMENT; }   /* the reference indexes [0] of an empty vector here */
+  else {
+    const int fmin = first[0], fmax = first[nf - 1], smin = second[0], smax = second[ns - 1];
+    if (fmin > smax) { /* "user was good" */
+      memcpy(corrected, first, (size_t)nf * 4); *n_corrected = nf; memcpy(anchor, second, (size_t)ns * 4); *n_anchor = ns;
+      start = smax + 1; end = fmin - 1;
+    } else if (fmax < smin) { /* "bad user": swap the two selections */
+      float t[4]; memcpy(t, seg8, 16); memcpy(seg8, seg8 + 4, 16); memcpy(seg8 + 4, t, 16);
+      memcpy(corrected, second, (size_t)ns * 4); *n_corrected = ns; memcpy(anchor, first, (size_t)nf * 4); *n_anchor = nf;
+      start = fmax + 1; end = smin - 1;
+    } else { start = end = -1; }
+  }
+  bounds[0] = start; bounds[1] = end;
+  free(first); free(second); free(over);
+  return st;
+}
+
+/* AppExpCorrect::Run, ApplyExplicitCorrection.cpp:150-180, 229-494. */
+static void normalized2(float x, float y, float* ox, float* oy) { const float n = sqrtf(x * x + y * y); *ox = x / n; *oy = y / n; }
+
+int orc_explicit_correction(uint32_t type, const float* sp /* 4 points */, int64_t n_poses, float* poses, int32_t n_corr,
+                            const int32_t* corr, int32_t n_anchor, const int32_t* anchor, float correction[3],
+                            hitl_human_constraint_t* rows) {
+  if (type != 2 && type != 4 && type != 5 && type != 6) return HITL_ERR_UNSUPPORTED;  /* "not currently supported" :325,334 */
+  if (n_corr <= 0) return HITL_ERR_INVALID_ARGUMENT;
+  float Ax, Ay, Bx, By;
+  normalized2(sp[2] - sp[0], sp[3] - sp[1], &Ax, &Ay);
+  normalized2(sp[6] - sp[4], sp[7] - sp[5], &Bx, &By);
+  const float cmAx = (sp[2] + sp[0]) * 0.5f, cmAy = (sp[3] + sp[1]) * 0.5f;   /* /2.0 and 0.5* are both exact */
+  const float cmBx = (sp[6] + sp[4]) * 0.5f, cmBy = (sp[7] + sp[5]) * 0.5f;
+  const float dot = Ax * Bx + Ay * By, cross = Ax * By - Ay * Bx;
+  float theta, pivx = cmAx, pivy = cmAy, dstx, dsty;
+  if (type == 2) {            /* AddLineToLineHumanConstraint :150-180 */
+    theta = acosf(dot); if (cross < 0.0f) theta = -theta;
+    dstx = cmBx; dsty = cmBy;
+  } else if (type == 4) {     /* AddColinearHumanConstraint :229-257 */
+    theta = (cross >= 0.0f) ? acosf(dot) : -acosf(dot);
+    const float alpha = (cmAx - cmBx) * Bx + (cmAy - cmBy) * By;
+    dstx = cmBx + alpha * Bx; dsty = cmBy + alpha * By;
+  } else if (type == 5) {     /* AddPerpendicularHumanConstraint :259-293 (theta is a double there) */
+    double th = (cross < 0.0f) ? -(double)acosf(dot) : (double)acosf(dot);
+    if (th == M_PI / 2.0 || th == -M_PI / 2.0) th = 0.0;
+    else if (th > 0.0) th = -(-th + M_PI / 2.0);
+    else th = -(-th - M_PI / 2.0);
+    theta = (float)th; dstx = cmAx; dsty = cmAy;
+  } else {                    /* AddParallelHumanConstraint :295-316 */
+    theta = (cross >= 0.0f) ? acosf(dot) : -acosf(dot);
+    dstx = cmAx; dsty = cmAy;
+  }
+  const float c = cosf(theta), s = sinf(theta);
+  /* FindContiguousGroups :358-385 with min=0, max=n-1: group 0 = the first run of consecutive corrected ids */
+  uint8_t* member = (uint8_t*)calloc((size_t)n_poses, 1);
+  for (int32_t j = 0; j < n_corr; ++j) { if (corr[j] < 0 || corr[j] >= n_poses) { free(member); return HITL_ERR_INVALID_ARGUMENT; } member[corr[j]] = 1; }
+  int64_t g0 = 0; while (!member[g0]) ++g0;
+  int64_t g1 = g0; while (g1 + 1 < n_poses && member[g1 + 1]) ++g1;
+  free(member);
+  /* corrections are computed from the poses BEFORE anything moves (:171-178) */
+  float c0[3] = {0, 0, 0}, clast[3] = {0, 0, 0};
+  for (int64_t i = g0; i <= g1; ++i) {
+    const float p0x = poses[3 * i], p0y = poses[3 * i + 1];
+    const float qx = p0x - pivx, qy = p0y - pivy;
+    const float p1x = dstx + (c * qx - s * qy), p1y = dsty + (s * qx + c * qy);
+    const float T[3] = {p1x - p0x, p1y - p0y, theta};
+    if (i == g0) memcpy(c0, T, sizeof(T));
+    if (i == g1) memcpy(clast, T, sizeof(T));
+    poses[3 * i] += T[0]; poses[3 * i + 1] += T[1]; poses[3 * i + 2] += T[2];   /* ApplyExplicitCorrections :391-398 */
+  }
+  { /* tail :404-413 (poses_[last_pose] has already moved) */
+    const float lx = poses[3 * g1], ly = poses[3 * g1 + 1];
+    const float cl = cosf(clast[2]), sl = sinf(clast[2]);
+    for (int64_t k = g1 + 1; k < n_poses; ++k) {
+      poses[3 * k + 2] += clast[2];
+      const float abx = poses[3 * k] - lx, aby = poses[3 * k + 1] - ly;
+      const float nx = cl * abx - sl * aby, ny = sl * abx + cl * aby;
+      poses[3 * k] = (lx + nx) + clast[0]; poses[3 * k + 1] = (ly + ny) + clast[1];
+    }
+  }
+  memcpy(correction, c0, sizeof(c0));
+  /* calculateConstraintTargets :447-487 */
+  const float dirx = sp[6] - sp[4], diry = sp[7] - sp[5];
+  const float corr_angle = atan2f(diry, dirx);
+  for (int32_t a = 0; a < n_anchor; ++a) {
+    const float aa = poses[3 * anchor[a] + 2];
+    const float rel = (float)((double)atan2f(sinf(corr_angle - aa), cosf(corr_angle - aa)) + M_PI / 2.0);
+    const float alx = poses[3 * anchor[a]], aly = poses[3 * anchor[a] + 1];
+    const float px = cosf(aa), py = sinf(aa);
+    for (int32_t j = 0; j < n_corr; ++j) {
+      const float rx = poses[3 * corr[j]] - alx, ry = poses[3 * corr[j] + 1] - aly;
+      hitl_human_constraint_t* r = rows + (int64_t)a * n_corr + j;
+      r->type = type; r->anchor_pose_id = anchor[a]; r->constrained_pose_id = corr[j];
+      const float da = poses[3 * corr[j] + 2] - aa;
+      r->delta_angle = atan2f(sinf(da), cosf(da));
+      r->delta_parallel = px * rx + py * ry;
+      r->delta_perpendicular = -py * rx + px * ry;
+      r->relative_penalty_dir = rel;
+    }
+  }
+  return HITL_OK;
+}
+
+/* Backprop::Run / BackPropagateError, Backprop.cpp:98-213 (the literal O(span^2) loops).  When x64 != NULL the same
+ * loops also run in fp64 from the same inputs (3 doubles per pose) -- the yardstick for the fp32 rounding noise. */
+int orc_backprop(int64_t n, float* poses, float* cov9, int32_t lo, int32_t hi, const float corr[3], double* x64) {
+  if (!(lo < hi)) return HITL_OK;   /* "No poses between bounds. Cannot run backprop." */
+  if (lo < 0 || hi >= n) return HITL_ERR_INVALID_ARGUMENT;
+  const int64_t L = hi - lo;
+  const float destx = poses[3 * hi] + corr[0], desty = poses[3 * hi + 1] + corr[1];
+  const float drv = 0.0001f, dtv = 0.001f;
+  float* rs = (float*)malloc((size_t)n * 4); float* ts = (float*)malloc((size_t)n * 4);
+  for (int64_t i = 0; i < n; ++i) { rs[i] = cov9[9 * i + 8]; ts[i] = (float)((double)(cov9[9 * i] + cov9[9 * i + 4]) / 2.0); }
+  float sum_r = 0.0f, sum_t = 0.0f;
+  for (int64_t i = lo; i <= hi; ++i) { sum_r += rs[i]; sum_t += ts[i]; }
+  sum_r += drv; sum_t += dtv;
+  float* rw = (float*)malloc((size_t)(L + 1) * 4); float* tw = (float*)malloc((size_t)(L + 1) * 4);
+  for (int64_t i = lo; i <= hi; ++i) { rw[i - lo] = rs[i] / sum_r; tw[i - lo] = ts[i] / sum_t; }
+  const float rot_beta = 1 / (1 + (rs[hi - 1] / drv)), trans_beta = 1 / (1 + (ts[hi - 1] / dtv));
+  for (int64_t i = lo; i < hi; ++i) {   /* :156-169, including the (0,2)-twice / (1,2)-never slip */
+    float* c = cov9 + 9 * i;
+    c[0] *= trans_beta; c[1] *= trans_beta; c[3] *= trans_beta; c[4] *= trans_beta;
+    c[2] *= rot_beta; c[2] *= rot_beta; c[6] *= rot_beta; c[7] *= rot_beta; c[8] *= rot_beta;
+  }
+  if (x64) for (int64_t i = 0; i < 3 * n; ++i) x64[i] = poses[i];
+  const float theta = corr[2];
+  for (int64_t i = lo; i < hi; ++i) {
+    const float dth = rw[i - lo] * theta;
+    const float c = cosf(dth), s = sinf(dth);
+    const float px = poses[3 * i], py = poses[3 * i + 1];
+    const float tx = px + (c * -px + -s * -py), ty = py + (s * -px + c * -py);   /* T(p) * R * T(-p) */
+    poses[3 * i + 2] += dth;
+    for (int64_t k = i + 1; k <= hi; ++k) {
+      poses[3 * k + 2] += dth;
+      const float x = poses[3 * k], y = poses[3 * k + 1];
+      poses[3 * k] = (c * x + -s * y) + tx; poses[3 * k + 1] = (s * x + c * y) + ty;
+    }
+    if (x64) {
+      const double d = (double)rs[i] / ((double)sum_r) * (double)theta, cd = cos(d), sd = sin(d);
+      const double qx = x64[3 * i], qy = x64[3 * i + 1];
+      x64[3 * i + 2] += d;
+      for (int64_t k = i + 1; k <= hi; ++k) {
+        x64[3 * k + 2] += d;
+        const double x = x64[3 * k] - qx, y = x64[3 * k + 1] - qy;
+        x64[3 * k] = qx + (cd * x - sd * y); x64[3 * k + 1] = qy + (sd * x + cd * y);
+      }
+    }
+  }
+  const float trx = destx - poses[3 * hi], try_ = desty - poses[3 * hi + 1];
+  for (int64_t i = lo; i < hi; ++i) {
+    const float dx = tw[i - lo] * trx, dy = tw[i - lo] * try_;
+    for (int64_t k = i + 1; k <= hi; ++k) { poses[3 * k] += dx; poses[3 * k + 1] += dy; }
+  }
+  if (x64) {
+    const double tx = (double)destx - x64[3 * hi], ty = (double)desty - x64[3 * hi + 1];
+    for (int64_t i = lo; i < hi; ++i) {
+      const double w = (double)ts[i] / (double)sum_t;
+      for (int64_t k = i + 1; k <= hi; ++k) { x64[3 * k] += w * tx; x64[3 * k + 1] += w * ty; }
+    }
+  }
+  free(rs); free(ts); free(rw); free(tw);
+  return HITL_OK;
+}
+
+/* HitLSLAM.cpp:442-447: angle = atan2(sin(angle), cos(angle)) for every pose before the solve */
+void orc_normalize_angles(int64_t n, float* poses) {
+  for (int64_t i = 0; i < n; ++i) { const float a = poses[3 * i + 2]; poses[3 * i + 2] = atan2f(sinf(a), cosf(a)); }
+}

@@ -58,6 +58,23 @@ int orc_verify_points(orc_solver*, const float* poses_xyt, int32_t n_points, con
                       int32_t* seen);
 int orc_observation_sets(orc_solver*, const float* poses_xyt, const float* seg_xy8, double threshold, int32_t* counts,
                          uint8_t* mask);
+/* ---- the correction cycle around the solve ------------------------- */
+/* EMInput::AutomaticEndpointAdjustment + SegFitEM (EMinput.cpp:153-250): seg = n_seg x (x0,y0,x1,y1), in/out */
+int orc_fit_segments(orc_solver*, const float* poses_xyt, int32_t n_seg, float* seg_xy4, int32_t* n_inliers,
+                     int32_t* passes, int32_t* lm_iterations);
+/* EMInput::OrderAndFilterUserInput (EMinput.cpp:325-455) on the counts of orc_observation_sets; seg_xy8 is swapped
+ * in place for a "bad user"; bounds = backprop_bounds_ (-1,-1 on overlap) */
+int orc_order_user_input(int64_t n_poses, const int32_t* counts, float* seg_xy8, int32_t* corrected, int32_t* n_corrected,
+                         int32_t* anchor, int32_t* n_anchor, int32_t bounds[2]);
+/* AppExpCorrect::Run (ApplyExplicitCorrection.cpp:150-180, 229-494): moves poses in place, returns correction_ and
+ * the n_anchor x n_corrected new_human_constraints_ rows (anchor-major) */
+int orc_explicit_correction(uint32_t type, const float* seg_xy8, int64_t n_poses, float* poses_xyt, int32_t n_corrected,
+                            const int32_t* corrected, int32_t n_anchor, const int32_t* anchor, float correction[3],
+                            hitl_human_constraint_t* rows);
+/* Backprop::Run (Backprop.cpp:98-213), literal fp32 loops; x64 (3n doubles, may be NULL) receives the same loops in fp64 */
+int orc_backprop(int64_t n_poses, float* poses_xyt, float* cov9, int32_t lo, int32_t hi, const float correction[3], double* x64);
+/* HitLSLAM.cpp:442-447 */
+void orc_normalize_angles(int64_t n_poses, float* poses_xyt);
 /* use forward-mode dual numbers (what ceres::AutoDiffCostFunction does) instead of the
  * analytic Jacobians inside linearize/solve: 0 = analytic (default), 1 = jets */
 int orc_set_use_jets(orc_solver*, int use);

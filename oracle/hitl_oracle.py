@@ -118,6 +118,9 @@ class OracleSolver(SolverBase):
                   get_corr_counts="orc_get_correspondence_counts", get_corr="orc_get_correspondences",
                   solve="orc_solve", evaluate="orc_evaluate", linearize="orc_linearize")
     _scan_names = dict(transform="orc_transform_scans", verify="orc_verify_points", obs_sets="orc_observation_sets")
+    _cycle_names = dict(fit="orc_fit_segments", order="orc_order_user_input", explicit="orc_explicit_correction",
+                        backprop="orc_backprop", normalize="orc_normalize_angles")
+    _cycle_handle = False
 
     def __init__(self, options=None):
         super().__init__(lib(), options)
@@ -152,3 +155,19 @@ class OracleSolver(SolverBase):
                                           _ptr(g, _f64p), C.byref(cost))
         self._check(st, "linearize")
         return H, g, cost.value
+
+
+def backprop_f64(poses_xyt, cov9, lo, hi, correction):
+    """Backprop::Run twice from the same inputs: the literal fp32 loops and the same loops in fp64.
+    Returns (poses_f32 [n,3], cov9 [n,9], poses_f64 [n,3])."""
+    poses = np.array(poses_xyt, np.float32).reshape(-1).copy()
+    cov = np.array(cov9, np.float32).reshape(-1).copy()
+    n = poses.size // 3
+    cvec = _as(correction, np.float32).reshape(-1)
+    x64 = np.zeros(3 * n, np.float64)
+    f = lib().orc_backprop
+    f.argtypes = [C.c_int64, _f32p, _f32p, C.c_int32, C.c_int32, _f32p, _f64p]
+    f.restype = C.c_int
+    st = f(n, _ptr(poses, _f32p), _ptr(cov, _f32p), int(lo), int(hi), _ptr(cvec, _f32p), _ptr(x64, _f64p))
+    assert st == 0, st
+    return poses.reshape(-1, 3), cov.reshape(-1, 9), x64.reshape(-1, 3)
