@@ -331,6 +331,19 @@ class SolverBase(object):
         out.update(poses=poses, cov9=cov, summary=summ, correction=correction)
         return out
 
+    def pose_covariances(self, mode, poses_xyt):
+        """== ceres::Covariance + robot-frame rotation (vector_mapping.cpp:2772-2812): float64 [n,3,3]."""
+        pin = _as(poses_xyt, np.float32).reshape(-1)
+        assert pin.size == 3 * self.n_poses
+        out = np.zeros(9 * self.n_poses, np.float64)
+        f = getattr(self._lib, self._cov_name)
+        f.argtypes = [C.c_void_p, C.c_int32, _f32p, _f64p]
+        f.restype = C.c_int
+        st = f(self._h, int(mode), _ptr(pin, _f32p), _ptr(out, _f64p))
+        if st != abi.OK:
+            raise HitlError(st, self._cov_name, self._detail())
+        return out.reshape(-1, 3, 3)
+
     # -- the path --------------------------------------------------------------------------
     def solve(self, mode, poses_xyt, allow_failure=False):
         """Returns (poses_out float32 [n,3], Summary)."""
@@ -430,6 +443,7 @@ class Solver(SolverBase):
                         explicit="hitl_solver_apply_explicit_correction", backprop="hitl_solver_backprop",
                         normalize="hitl_normalize_angles")
     _cycle_handle = True
+    _cov_name = "hitl_solver_pose_covariances"
 
     def __init__(self, options=None, lib_path=None):
         lib = load_library(lib_path)

@@ -134,6 +134,11 @@ void launch_verify(hipStream_t st, const MapView& map, const float* T4, int n, c
 void launch_obs_sets(hipStream_t st, const MapView& map, const float* T4, const float* seg8, double thr, int* counts,
                      unsigned char* mask);
 
+// diagonal super-blocks of the inverse from the cyclic-reduction factors; per-pose 3x3 covariance in the robot frame
+void launch_cr_selinv(hipStream_t st, const CrView& cr, double* Sd, double* So);
+void launch_cov_extract(hipStream_t st, int n_poses, int Wb, int B, const double* Sd, const double* scale, const unsigned char* fixed,
+                        const float2* rot, double* out);
+
 // endpoint fit (hitl_obs.hip): inlier scan of one segment (counts per pose, or -- with offsets -- the inliers' world
 // points in reading order) and one evaluation of the 1-parameter line problem over them
 void launch_fit_inliers(hipStream_t st, const MapView& map, const float* T4, const float* seg4, int* counts, const int64_t* offsets,

@@ -973,6 +973,99 @@ void launch_cr_solve(hipStream_t st, const CrView& cr, double* w, double* x) {
 }
 
 // ===========================================================================================
+// Selected inversion through the cyclic-reduction factors: the diagonal super-blocks of A^-1.
+// A node k eliminated at stride s between survivors a = k - s and b = k + s satisfies
+//     x_k = Dinv_k w_k - Gl_k x_a - Gr_k x_b ,
+// so with Sigma = A^-1 and the blocks of the coarser level (Sigma_aa, Sigma_bb, Sigma_ab) known,
+//     M1 = Gl Sigma_aa + Gr Sigma_ab^T        M2 = Gl Sigma_ab + Gr Sigma_bb
+//     Sigma_kk = Dinv_k + M1 Gl^T + M2 Gr^T    Sigma_ak = -M1^T      Sigma_kb = -M2
+// which are exactly the blocks the next finer level needs (a,k and k,b are adjacent there).
+// Sd[node] = Sigma_node,node; So[node] = Sigma between node and its right neighbour at the level
+// processed last.  One launch per level, one wave per eliminated node; ~log2(nsb) launches.
+// ===========================================================================================
+template <int B>
+__global__ __launch_bounds__(WAVE) void k_cr_selinv_level(CrView cr, int s, double* Sd, double* So) {
+  __shared__ double sGl[B * B], sGr[B * B], sAA[B * B], sBB[B * B], sAB[B * B], sM1[B * B], sM2[B * B];
+  const int k = s * (2 * blockIdx.x + 1);
+  if (k >= cr.nsb) return;
+  const size_t BB = (size_t)B * B;
+  const int a = k - s, b = k + s;
+  const bool has_b = b < cr.nsb;
+  lds_load<B>(sGl, cr.Gl + (size_t)k * BB);
+  lds_load<B>(sAA, Sd + (size_t)a * BB);
+  if (has_b) { lds_load<B>(sGr, cr.Gr + (size_t)k * BB); lds_load<B>(sBB, Sd + (size_t)b * BB); lds_load<B>(sAB, So + (size_t)a * BB); }
+  else for (int e = threadIdx.x; e < B * B; e += WAVE) { sGr[e] = 0.0; sBB[e] = 0.0; sAB[e] = 0.0; }
+  __syncthreads();
+  for (int e = threadIdx.x; e < B * B; e += WAVE) {
+    const int r = e / B, c = e % B;
+    double m1 = 0.0, m2 = 0.0;
+#pragma unroll
+    for (int q = 0; q < B; ++q) {
+      m1 += sGl[r * B + q] * sAA[q * B + c] + sGr[r * B + q] * sAB[c * B + q];
+      m2 += sGl[r * B + q] * sAB[q * B + c] + sGr[r * B + q] * sBB[q * B + c];
+    }
+    sM1[e] = m1; sM2[e] = m2;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < B * B; e += WAVE) {
+    const int r = e / B, c = e % B;
+    double v = cr.Dinv[(size_t)k * BB + e];
+#pragma unroll
+    for (int q = 0; q < B; ++q) v += sM1[r * B + q] * sGl[c * B + q] + sM2[r * B + q] * sGr[c * B + q];
+    Sd[(size_t)k * BB + e] = v;
+    So[(size_t)a * BB + e] = -sM1[c * B + r];
+    if (has_b) So[(size_t)k * BB + e] = -sM2[e];
+  }
+}
+
+template <int B>
+static void cr_selinv_t(hipStream_t st, const CrView& cr, double* Sd, double* So) {
+  (void)hipMemcpyAsync(Sd, cr.Dinv, sizeof(double) * B * B, hipMemcpyDeviceToDevice, st);   // root
+  int s_last = 0;
+  for (int s = 1; s < cr.nsb; s *= 2) s_last = s;
+  for (int s = s_last; s >= 1; s /= 2) {
+    const int n_elim = (cr.nsb - s + 2 * s - 1) / (2 * s);
+    hipLaunchKernelGGL(k_cr_selinv_level<B>, dim3(n_elim), dim3(WAVE), 0, st, cr, s, Sd, So);
+  }
+}
+
+void launch_cr_selinv(hipStream_t st, const CrView& cr, double* Sd, double* So) {
+  switch (cr.B) {
+    case 3: cr_selinv_t<3>(st, cr, Sd, So); break;
+    case 6: cr_selinv_t<6>(st, cr, Sd, So); break;
+    case 9: cr_selinv_t<9>(st, cr, Sd, So); break;
+    default: cr_selinv_t<12>(st, cr, Sd, So); break;
+  }
+}
+
+// pose i: its 3x3 block of S Sigma S, rotated into the robot frame as vector_mapping.cpp:2792-2801 does
+// (transform = blockdiag(Rotation2Df(-angle).cast<double>(), 1); one_cov = transform * one_cov * transform^T)
+__global__ void k_cov_extract(int n_poses, int Wb, int B, const double* __restrict__ Sd, const double* __restrict__ scale,
+                              const unsigned char* __restrict__ fixed, const float2* __restrict__ rot, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_poses) return;
+  double* o = out + 9 * (size_t)i;
+  if (fixed[i]) { for (int e = 0; e < 9; ++e) o[e] = 0.0; return; }
+  const int k = i / Wb, a0 = 3 * (i % Wb);
+  const double* blk = Sd + (size_t)k * B * B;
+  double S[3][3];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) S[r][c] = blk[(a0 + r) * B + a0 + c] * scale[3 * i + r] * scale[3 * i + c];
+  const double c = (double)rot[i].x, sn = (double)rot[i].y;     // cos, sin of -angle (fp32 values)
+  const double T[3][3] = {{c, -sn, 0.0}, {sn, c, 0.0}, {0.0, 0.0, 1.0}};
+  double M[3][3];
+  for (int r = 0; r < 3; ++r)
+    for (int q = 0; q < 3; ++q) M[r][q] = T[r][0] * S[0][q] + T[r][1] * S[1][q] + T[r][2] * S[2][q];
+  for (int r = 0; r < 3; ++r)
+    for (int q = 0; q < 3; ++q) o[3 * r + q] = M[r][0] * T[q][0] + M[r][1] * T[q][1] + M[r][2] * T[q][2];
+}
+
+void launch_cov_extract(hipStream_t st, int n_poses, int Wb, int B, const double* Sd, const double* scale, const unsigned char* fixed,
+                        const float2* rot, double* out) {
+  hipLaunchKernelGGL(k_cov_extract, dim3((n_poses + 127) / 128), dim3(128), 0, st, n_poses, Wb, B, Sd, scale, fixed, rot, out);
+}
+
+// ===========================================================================================
 // y = (S H S [+ D^2]) v : band blocks (both triangles) + off-band blocks, one thread per pose.
 // MODE 0: plain product (PCG).
 // MODE 1: residual check after the cyclic-reduction solve: y -> r = rhs - A v, per-workgroup

@@ -1266,6 +1266,49 @@ int hitl_solver_evaluate(hitl_solver* s, int32_t mode, const float* poses_xyt, d
   return hitl_solver_linearize(s, mode, poses_xyt, x.data(), cost, gradient, nullptr, nullptr);
 }
 
+// ---- pose covariances: what ceres::Covariance + the robot-frame rotation produce at
+// episodic_non_markov_localization/vector_mapping.cpp:2772-2812, from the cyclic-reduction factors ----
+int hitl_solver_pose_covariances(hitl_solver* s, int32_t mode, const float* poses_xyt, double* cov9) {
+  TRY(check_ready(s, mode));
+  if (!poses_xyt || !cov9) return fail(HITL_ERR_INVALID_ARGUMENT, "pose_covariances: null argument");
+  if (s->world > 1) return fail(HITL_ERR_UNSUPPORTED, "pose_covariances is a single-GPU entry point");
+  FactorView fv;
+  TRY(prepare(s, mode, poses_xyt, poses_xyt, &fv));
+  if (fv.n_offband > 0) return fail(HITL_ERR_UNSUPPORTED, "pose_covariances: pose pairs outside the band (raise max_band_poses)");
+  hipStream_t st = s->stream;
+  const int n = s->n, n3 = 3 * n;
+  std::vector<double> hx((size_t)s->npad, 0.0);
+  for (int t = 0; t < n3; ++t) hx[t] = (double)poses_xyt[t];
+  HIP_TRY(hipMemcpyAsync(s->x.p, hx.data(), sizeof(double) * s->npad, hipMemcpyHostToDevice, st));
+  LinResult lr;
+  TRY(run_linearize(s, fv, s->x.p, 0, &lr));
+  launch_jacobi_scale(st, n, s->npad, fv.band_poses, s->Hband[0].p, s->opt.jacobi_scaling, s->fixed.p, s->scale.p);
+  const CrView cr = s->cr_view();
+  // J^T J itself: no trust-region diagonal (clamp(..) / infinity == 0)
+  launch_build_system(st, n, fv.band_poses, s->lin_view(0), s->scale.p, s->fixed.p, INFINITY, s->opt.min_lm_diagonal,
+                      s->opt.max_lm_diagonal, cr, s->rhs.p);
+  launch_cr_factor(st, cr);
+  DevArray<double> Sd, So, d_out;
+  DevArray<float2> d_rot;
+  std::vector<float2> rot((size_t)n);
+  for (int i = 0; i < n; ++i) { const float a = -poses_xyt[3 * i + 2]; rot[i] = make_float2(cosf(a), sinf(a)); }   // Rotation2Df(-angle)
+  int rc = Sd.resize((size_t)cr.nsb * cr.B * cr.B);
+  if (rc == HITL_OK) rc = So.resize((size_t)cr.nsb * cr.B * cr.B);
+  if (rc == HITL_OK) rc = d_out.resize((size_t)9 * n);
+  if (rc == HITL_OK) rc = d_rot.upload(rot, st);
+  if (rc == HITL_OK) {
+    launch_cr_selinv(st, cr, Sd.p, So.p);
+    launch_cov_extract(st, n, fv.band_poses, cr.B, Sd.p, s->scale.p, s->fixed.p, d_rot.p, d_out.p);
+    if (hipMemcpyAsync(cov9, d_out.p, sizeof(double) * 9 * (size_t)n, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) rc = fail(HITL_ERR_HIP, "pose_covariances: kernels failed");
+  }
+  if (rc == HITL_OK)
+    for (size_t t = 0; t < (size_t)9 * n; ++t)
+      if (!(cov9[t] == cov9[t])) { rc = fail(HITL_ERR_SOLVER_FAILURE, "pose_covariances: J^T J is singular at these poses"); break; }
+  Sd.release(); So.release(); d_out.release(); d_rot.release();
+  return rc;
+}
+
 // ---- observation scans either side of the solve -------------------------
 namespace {
 int obs_scan_prepare(hitl_solver* s, const float* poses, DevArray<float>* T4) {

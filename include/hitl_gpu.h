@@ -241,6 +241,14 @@ int hitl_solver_backprop(hitl_solver*, int64_t n_poses, float* poses_xyt, float*
                          const float correction[3]);
 int hitl_normalize_angles(int64_t n_poses, float* poses_xyt);
 
+/* Pose covariances == the ceres::Covariance block at
+ * episodic_non_markov_localization/vector_mapping.cpp:2772-2812: for every pose the 3x3 diagonal block of (J^T J)^-1 at
+ * poses_xyt (constant poses removed, no trust-region diagonal), rotated into the robot frame with
+ * transform = blockdiag(Rotation2Df(-angle), 1).  cov9 = n_poses*9 doubles, row-major; zeros for constant poses
+ * (the reference never writes pose min_poses).  Computed from the cyclic-reduction factors by selected inversion --
+ * no dense inverse, no SVD.  Needs every pose pair inside the band.  Single-GPU entry point. */
+int hitl_solver_pose_covariances(hitl_solver*, int32_t mode, const float* poses_xyt, double* cov9);
+
 /* Debug / parity: linearise at double-precision poses x (3*n_poses) with the odometry
  * measurements and human targets derived from the fp32 poses_ref_xyt; returns the cost, the
  * gradient (3n), the per-pair STF residuals (2 per pair) and Jacobians (12 per pair,

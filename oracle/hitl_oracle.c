@@ -1405,3 +1405,59 @@ int orc_backprop(int64_t n, float* poses, float* cov9, int32_t lo, int32_t hi, c
 void orc_normalize_angles(int64_t n, float* poses) {
   for (int64_t i = 0; i < n; ++i) { const float a = poses[3 * i + 2]; poses[3 * i + 2] = atan2f(sinf(a), cosf(a)); }
 }
+
+/* ===================================================================================== */
+/* pose covariances: the ceres::Covariance block of                                       */
+/* episodic_non_markov_localization/vector_mapping.cpp:2772-2812 (DENSE_SVD there; for a  */
+/* full-rank J the pseudo-inverse of J^T J is its inverse), then                          */
+/* one_cov = transform * one_cov * transform^T with transform = diag(Rotation2Df(-angle),1) */
+/* ===================================================================================== */
+int orc_pose_covariances(orc_solver* s, int32_t mode, const float* poses, double* cov9) {
+  int st = check_problem(s, mode); if (st) return st;
+  const int64_t n = s->n, d = 3 * n;
+  if (n < 1 || n > 1200) return HITL_ERR_UNSUPPORTED;   /* dense O(d^3) checker */
+  double* H = (double*)malloc((size_t)d * (size_t)d * 8);
+  double* x = (double*)calloc((size_t)d, 8);
+  double* y = (double*)malloc((size_t)d * 3 * 8);
+  for (int64_t i = 0; i < d; ++i) x[i] = (double)poses[i];
+  st = orc_assemble_dense(s, mode, poses, x, H, NULL, NULL);
+  if (st == HITL_OK) { /* dense Cholesky, lower triangle in place */
+    for (int64_t j = 0; j < d && st == HITL_OK; ++j) {
+      double v = H[j * d + j];
+      for (int64_t k = 0; k < j; ++k) v -= H[j * d + k] * H[j * d + k];
+      if (!(v > 0.0)) { st = HITL_ERR_SOLVER_FAILURE; break; }
+      const double l = sqrt(v); H[j * d + j] = l;
+      for (int64_t i = j + 1; i < d; ++i) {   /* serial on purpose: d tiny parallel regions cost more than the work */
+        double t = H[i * d + j];
+        for (int64_t k = 0; k < j; ++k) t -= H[i * d + k] * H[j * d + k];
+        H[i * d + j] = t / l;
+      }
+    }
+  }
+  for (int64_t e = 0; e < 9; ++e) cov9[e] = 0.0;   /* pose 0 is constant: the reference loop starts at min_poses + 1 */
+  for (int64_t i = 1; i < n && st == HITL_OK; ++i) {
+    /* Sigma_ab = (L^-1 e_a) . (L^-1 e_b); L^-1 e_a is zero above row a */
+    const int64_t r0 = 3 * i;
+    for (int c = 0; c < 3; ++c) {
+      double* yc = y + (size_t)c * d;
+      for (int64_t r = r0; r < d; ++r) {
+        double t = (r == r0 + c) ? 1.0 : 0.0;
+        for (int64_t k = r0; k < r; ++k) t -= H[r * d + k] * yc[k];
+        yc[r] = t / H[r * d + r];
+      }
+    }
+    double S[3][3];
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) {
+      double t = 0; for (int64_t r = r0; r < d; ++r) t += y[(size_t)a * d + r] * y[(size_t)b * d + r];
+      S[a][b] = t;
+    }
+    const float ang = -poses[3 * i + 2];
+    const double c = (double)cosf(ang), sn = (double)sinf(ang);
+    const double T[3][3] = {{c, -sn, 0}, {sn, c, 0}, {0, 0, 1}};
+    double M[3][3];
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) M[a][b] = T[a][0] * S[0][b] + T[a][1] * S[1][b] + T[a][2] * S[2][b];
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) cov9[9 * i + 3 * a + b] = M[a][0] * T[b][0] + M[a][1] * T[b][1] + M[a][2] * T[b][2];
+  }
+  free(H); free(x); free(y);
+  return st;
+}

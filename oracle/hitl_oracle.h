@@ -58,6 +58,9 @@ int orc_verify_points(orc_solver*, const float* poses_xyt, int32_t n_points, con
                       int32_t* seen);
 int orc_observation_sets(orc_solver*, const float* poses_xyt, const float* seg_xy8, double threshold, int32_t* counts,
                          uint8_t* mask);
+/* ceres::Covariance + robot-frame rotation, episodic_non_markov_localization/vector_mapping.cpp:2772-2812 (dense checker,
+ * n_poses <= 1200): cov9 = n*9 doubles row-major, zeros for pose 0 */
+int orc_pose_covariances(orc_solver*, int32_t mode, const float* poses_xyt, double* cov9);
 /* ---- the correction cycle around the solve ------------------------- */
 /* EMInput::AutomaticEndpointAdjustment + SegFitEM (EMinput.cpp:153-250): seg = n_seg x (x0,y0,x1,y1), in/out */
 int orc_fit_segments(orc_solver*, const float* poses_xyt, int32_t n_seg, float* seg_xy4, int32_t* n_inliers,

@@ -121,6 +121,7 @@ class OracleSolver(SolverBase):
     _cycle_names = dict(fit="orc_fit_segments", order="orc_order_user_input", explicit="orc_explicit_correction",
                         backprop="orc_backprop", normalize="orc_normalize_angles")
     _cycle_handle = False
+    _cov_name = "orc_pose_covariances"
 
     def __init__(self, options=None):
         super().__init__(lib(), options)

@@ -1,0 +1,65 @@
+"""Pose covariance recovery on the GPU: selected inversion through the cyclic-reduction factors
+vs the dense CPU checker (ceres::Covariance + robot-frame rotation, vector_mapping.cpp:2772-2812)."""
+import numpy as np
+import pytest
+
+from hitl_slam_amd import abi
+from tests.conftest import Problem, oracle_corr
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(prob, corr=None):
+    from hitl_slam_amd import Solver
+    from oracle import hitl_oracle as O
+    g, o = Solver(), O.OracleSolver()
+    prob.load(g, corr=corr)
+    prob.load(o, corr=corr)
+    return g, o
+
+
+def _check(Sg, So, rel=1e-6):
+    assert Sg.shape == So.shape
+    assert np.array_equal(Sg[0], np.zeros((3, 3)))            # pose 0 is constant
+    scale = np.abs(So).max(axis=(1, 2))[:, None, None] + 1e-300
+    assert (np.abs(Sg - So) / scale).max() < rel, (np.abs(Sg - So) / scale).max()
+    assert np.abs(Sg - Sg.transpose(0, 2, 1)).max() <= 1e-9 * np.abs(Sg).max()
+    for i in range(1, Sg.shape[0]):
+        assert np.linalg.eigvalsh(0.5 * (Sg[i] + Sg[i].T)).min() > 0.0
+
+
+@pytest.mark.parametrize("n,obs,ppf,window", [(60, 90, 30, 3), (97, 64, 97, 2), (33, 80, 33, 1), (130, 48, 50, 4)])
+def test_joint_mode_matches_dense_inverse(n, obs, ppf, window):
+    prob = Problem(n, obs, ppf=ppf, window=window)
+    corr = oracle_corr(prob)
+    g, o = _pair(prob, corr)
+    _check(g.pose_covariances(abi.MODE_JOINT, prob.init), o.pose_covariances(abi.MODE_JOINT, prob.init))
+    # at the solved poses too (what vector_mapping.cpp does: after the solve)
+    sol, _ = g.solve(abi.MODE_JOINT, prob.init)
+    _check(g.pose_covariances(abi.MODE_JOINT, sol), o.pose_covariances(abi.MODE_JOINT, sol))
+    g.close(); o.close()
+
+
+@pytest.mark.parametrize("n", [2, 3, 7, 64, 65, 300])
+def test_odometry_and_constraints_mode(n):
+    prob = Problem(n, 24, ppf=max(n, 8), groups=1 if n > 8 else 0)
+    g, o = _pair(prob)
+    _check(g.pose_covariances(abi.MODE_ODOM_HC, prob.init), o.pose_covariances(abi.MODE_ODOM_HC, prob.init))
+    g.close(); o.close()
+
+
+def test_odometry_chain_closed_form_at_size():
+    """20 000 poses, odometry only: pose 0 fixed, so uncertainty can only grow along the chain, and pose 1's block is
+    the inverse of its single edge: diag(sigma_r^2, sigma_t^2, sigma_a^2) in the frame of the edge."""
+    n = 20000
+    prob = Problem(n, 8, ppf=n, groups=0)
+    from hitl_slam_amd import Solver
+    g = Solver()
+    prob.load(g)
+    S = g.pose_covariances(abi.MODE_ODOM_HC, prob.init)
+    tr = np.trace(S, axis1=1, axis2=2)
+    assert (np.diff(tr[1:]) > -1e-9 * tr[1:-1]).all()
+    ev = np.sort(np.linalg.eigvalsh(S[1]))
+    assert np.allclose(ev, np.sort([np.float32(0.03) ** 2, np.float32(0.03) ** 2, np.float32(0.01) ** 2]), rtol=1e-6)
+    assert np.isfinite(S).all() and tr[-1] > 100 * tr[1]
+    g.close()
