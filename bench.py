@@ -265,6 +265,35 @@ def main():
         "synth_gen_s": gen_s,
     }
 
+    # ---- one interactive correction cycle on the same resident map, reported alongside ----
+    if world == 1:
+        try:
+            def timed(fn, *a, **k):
+                t0 = time.perf_counter()
+                r = fn(*a, **k)
+                return r, (time.perf_counter() - t0) * 1e3
+            clicks = S.correction_clicks(gt, init_l, off, px, py)
+            cyc = {}
+            poses0 = np.ascontiguousarray(init_l)
+            seen, cyc["verify_points_ms"] = timed(solver.verify_points, poses0, clicks.reshape(-1, 2), 0.05)
+            (seg, inl, pas, its), cyc["fit_segments_ms"] = timed(solver.fit_segments, poses0, clicks.reshape(2, 4))
+            (counts, _), cyc["observation_sets_ms"] = timed(solver.observation_sets, poses0, seg.reshape(-1), 0.03, False)
+            od, cyc["order_user_input_ms"] = timed(solver.order_user_input, counts, seg.reshape(-1))
+            (p2, corr_v, new_rows), cyc["explicit_correction_ms"] = timed(solver.apply_explicit_correction, 4, od["seg_xy8"], poses0,
+                                                                         od["corrected"], od["anchor"])
+            (p3, cov3), cyc["backprop_ms"] = timed(solver.backprop, p2, cov, od["bounds"][0], od["bounds"][1], corr_v)
+            # the worst case of the O(span^2) stage: bounds at the two ends of the whole trajectory
+            _, cyc["backprop_full_span_ms"] = timed(solver.backprop, poses0, cov, 1, n_local - 2, corr_v)
+            _, cyc["transform_scans_ms"] = timed(solver.transform_scans, poses0)
+            _, cyc["pose_covariances_ms"] = timed(solver.pose_covariances, H.MODE_JOINT, out)
+            cyc.update(all_points_verified=bool(int(seen.sum()) == 4), fit_passes=[int(v) for v in pas], fit_inliers=[int(v) for v in inl],
+                       anchors=int(od["anchor"].size), corrected=int(od["corrected"].size), new_rows=int(new_rows.size),
+                       backprop_bounds=[int(od["bounds"][0]), int(od["bounds"][1])],
+                       note="wall-clock per C-ABI call including its host<->device copies; the re-solve itself is ms_per_step")
+            result["correction_cycle"] = cyc
+        except Exception as e:
+            result["correction_cycle"] = {"failed": repr(e)}
+
     # ---- CPU baseline: the oracle (a port, not the reference binary) on a bounded sample ----------
     if not args.no_cpu_baseline and args.cpu_sample_poses > 0 and world == 1:
         try:

@@ -76,3 +76,28 @@ def constraints(p, gt, n_groups, kind=4, begin=0, end=None):
     n = lib().synth_constraints(C.byref(p), gt.ctypes.data_as(C.c_void_p), C.c_int64(begin), C.c_int64(end),
                                 C.c_int32(n_groups), C.c_int32(kind), rows)
     return rows, int(n)
+
+
+def correction_clicks(gt, init, off, px, py, first_piece=(18.5, 25.5), second_piece=(2.5, 9.5)):
+    """Four 'clicked' points (selected_points_, float32 [8]) for one colinear correction on floor 0: two observations of
+    the +y side wall piece `first_piece` as drawn by the drifted map from the pose standing in front of it, then two of
+    `second_piece`.  Pieces are floor-local x ranges between alcoves (see build_floor in hitl_synth.c)."""
+    gt = np.asarray(gt, np.float64).reshape(-1, 3)
+    init = np.asarray(init, np.float32).reshape(-1, 3)
+    x0, y0 = gt[0, 0] - 0.15, gt[0, 1] + 0.7          # local_pose(0) = (0.15, -LANE_AMP)
+    out = []
+    for xa, xb in (first_piece, second_piece):
+        j = int(round((0.5 * (xa + xb) - 0.15) / 0.3))
+        k = slice(int(off[j]), int(off[j + 1]))
+        c, s = np.cos(gt[j, 2]), np.sin(gt[j, 2])
+        lx = c * px[k] - s * py[k] + gt[j, 0] - x0
+        ly = s * px[k] + c * py[k] + gt[j, 1] - y0
+        sel = np.where((np.abs(ly - 1.2) < 0.04) & (lx > xa + 0.3) & (lx < xb - 0.3))[0]
+        if sel.size < 6:
+            raise ValueError("pose %d sees too little of wall piece (%g, %g)" % (j, xa, xb))
+        ci, si = np.cos(init[j, 2]), np.sin(init[j, 2])
+        wx = ci * px[k] - si * py[k] + init[j, 0]
+        wy = si * px[k] + ci * py[k] + init[j, 1]
+        a, b = sel[np.argmin(lx[sel])], sel[np.argmax(lx[sel])]
+        out += [wx[a], wy[a], wx[b], wy[b]]
+    return np.array(out, np.float32)
