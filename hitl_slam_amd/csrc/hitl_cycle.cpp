@@ -37,8 +37,8 @@ int fit_eval(const SolverCtx& cx, const float2* pts, int64_t m, double icx, doub
   out->cost = out->g = out->h = 0.0;
   if (m == 0) return HITL_OK;
   double ax = cos(theta), ay = sin(theta);
-  const double nrm = sqrt(ax * ax + ay * ay);   // alpha.normalize()
-  ax /= nrm; ay /= nrm;
+  const double inv = 1.0 / sqrt(ax * ax + ay * ay);   // alpha.normalize() on Jets: f * (1 / g)
+  ax *= inv; ay *= inv;
   const int g = fit_eval_blocks(m);
   TRY(partial->resize((size_t)3 * g));
   launch_fit_eval(cx.stream, pts, m, icx, icy, len, ax, ay, partial->p);
@@ -58,15 +58,20 @@ int seg_fit_em(const SolverCtx& cx, const float2* pts, int64_t m, const float* s
   const double icx = (p1x + p2x) / 2.0, icy = (p1y + p2y) / 2.0;
   const double hy = sqrt((p1x - p2x) * (p1x - p2x) + (p1y - p2y) * (p1y - p2y));
   const double ad = fabs(p1x - p2x);
-  double theta = acos(ad / hy);          // sign of the slope is dropped here, as in the reference
+  const double theta0 = acos(ad / hy);   // sign of the slope is dropped here, as in the reference
+  double theta = theta0;
   const double len = hy / 2.0;
   FitEval cur, cand;
   TRY(fit_eval(cx, pts, m, icx, icy, len, theta, partial, &cur));
+  // A residual that is exactly 0 (a clicked point that is a scan point and an endpoint) has derivative 0 * inf = NaN,
+  // under Jet sqrt as much as in the closed form.  Ceres then terminates with FAILURE and leaves the user's parameter
+  // untouched (Summary::IsSolutionUsable); SegFitEM never reads the summary, so the fit silently keeps its initial
+  // angle.  Same after 5 invalid steps in a row.  A candidate is judged on its cost alone (Ceres evaluates cost-only).
+  bool failed = !(std::isfinite(cur.cost) && std::isfinite(cur.g) && std::isfinite(cur.h));
   const double scale = 1.0 / (1.0 + sqrt(cur.h));
   double radius = 1e4, decrease_factor = 2.0;
   int iter = 0, invalid_run = 0;
-  bool failed = false;
-  bool done = std::fabs(cur.g) <= 1e-10;
+  bool done = failed || std::fabs(cur.g) <= 1e-10;
   while (!done) {
     if (iter >= 25) break;
     ++iter;
@@ -85,11 +90,13 @@ int seg_fit_em(const SolverCtx& cx, const float2* pts, int64_t m, const float* s
     const double step = scale * dt, cth = theta + step;
     TRY(fit_eval(cx, pts, m, icx, icy, len, cth, partial, &cand));
     if (std::fabs(step) <= 1e-8 * (std::fabs(theta) + 1e-8)) break;
+    if (!std::isfinite(cand.cost)) cand.cost = 1.7976931348623157e308;   // "a step with infinite cost"
     const double cost_change = cur.cost - cand.cost;
     if (std::fabs(cost_change) <= 1e-6 * cur.cost) break;
     const double rho = cost_change / mcc;
     if (rho > 1e-3) {
       theta = cth; cur = cand;
+      if (!(std::isfinite(cur.g) && std::isfinite(cur.h))) { failed = true; break; }
       if (std::fabs(cur.g) <= 1e-10) break;
       const double q = 2.0 * rho - 1.0;
       double f = 1.0 - q * q * q;
@@ -103,7 +110,7 @@ int seg_fit_em(const SolverCtx& cx, const float2* pts, int64_t m, const float* s
     }
   }
   if (iterations) *iterations = iter;
-  if (failed) return fail(HITL_ERR_SOLVER_FAILURE, "fit_segments: the endpoint fit produced no valid step");
+  if (failed) theta = theta0;
   double ax = cos(theta), ay = sin(theta);
   const double nrm = sqrt(ax * ax + ay * ay);
   ax /= nrm; ay /= nrm;

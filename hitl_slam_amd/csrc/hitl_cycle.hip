@@ -96,7 +96,7 @@ __device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_
 __global__ __launch_bounds__(kBpBlock) void k_backprop_rotate(float* __restrict__ poses, int lo, int L, const float4* __restrict__ piv,
                                                               float* xf, int* sync, float destx, float desty,
                                                               float* __restrict__ trans_out) {
-  __shared__ float4 s_xf[kBpBlock];
+  __shared__ float4 s_xf[kBpBlock], s_out[kBpBlock];
   __shared__ float s_dth[kBpBlock];
   __shared__ float2 s_piv[2];
   __shared__ int s_ticket;
@@ -142,13 +142,19 @@ __global__ __launch_bounds__(kBpBlock) void k_backprop_rotate(float* __restrict_
     const float tx = P.x + (c * -P.x + -s * -P.y), ty = P.y + (s * -P.x + c * -P.y);
     if ((int)threadIdx.x == p) {
       th += pr.x;
-      float* dst = xf + 4 * (size_t)(b * kBpBlock + p);
-      dst[0] = c; dst[1] = s; dst[2] = tx; dst[3] = ty;
+      s_out[p] = make_float4(c, s, tx, ty);      // published in one coalesced pass below: a global store here would
+                                                 // put its completion latency inside every barrier of this loop
     } else if ((int)threadIdx.x > p && live) {
       th += pr.x;
       const float nx = (c * x + -s * y) + tx, ny = (s * x + c * y) + ty;
       x = nx; y = ny;
     }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < npiv) {
+    const float4 t = s_out[threadIdx.x];
+    float* dst = xf + 4 * (size_t)(b * kBpBlock + (int)threadIdx.x);
+    dst[0] = t.x; dst[1] = t.y; dst[2] = t.z; dst[3] = t.w;
   }
   __threadfence();
   __syncthreads();

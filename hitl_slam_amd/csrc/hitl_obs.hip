@@ -151,9 +151,13 @@ __global__ __launch_bounds__(kObsBlock) void k_fit_inliers(MapView map, int chun
   if (threadIdx.x == 0 && counts) counts[i] = s_base;
 }
 
-// segDistResidualEM (EMinput.cpp:107-150) and its derivative in closed form.  With a = (cos, sin), u = p - cm,
-// along = u.a, perp = u.perp(a):  inside the segment r = |perp|, dr = -sign(perp) along;  beyond the +len end
-// r = |(along - len, perp)|, dr = -len perp / r;  beyond the -len end r = |(along + len, perp)|, dr = len perp / r.
+// segDistResidualEM (EMinput.cpp:107-150).  The VALUE is computed with the functor's own expressions in its own order
+// (p1 = cm + len a, p2 = cm - len a, t = (p - p1).(p2 - p1) / |p2 - p1|^2, three branches, sqrt of a sum of squares), so
+// r -- and with it the branch taken and the r == 0 case -- is the number the Jet evaluation produces.  The derivative is
+// the closed form of that branch, with n = (-sin, cos):
+//     t < 0 : dr = -len (q.n) / r, q = p - p1      t > 1 : dr = len (f.n) / r, f = p - p2
+//     else  : dr = -sign(q.n) (len + q.a)
+// and NaN when r == 0, which is what Jet sqrt yields there (1 / (2 sqrt(0)) * 0) and what makes Ceres give up.
 // partial[g] = (sum r^2, sum dr r, sum dr^2) of a fixed contiguous slice, summed in a fixed order.
 constexpr int kFitBlock = 256;
 struct FitLine { double cmx, cmy, len, c, s; };
@@ -165,12 +169,27 @@ __global__ __launch_bounds__(kFitBlock) void k_fit_eval(const float2* __restrict
   double a0 = 0, a1 = 0, a2 = 0;
   for (int64_t q = b0 + threadIdx.x; q < b1; q += kFitBlock) {
     const float2 p = pts[q];
-    const double ux = (double)p.x - fl.cmx, uy = (double)p.y - fl.cmy;
-    const double along = ux * fl.c + uy * fl.s, perp = -ux * fl.s + uy * fl.c;
+    const double px = (double)p.x, py = (double)p.y;
+    const double p1x = fl.cmx + fl.len * fl.c, p1y = fl.cmy + fl.len * fl.s;
+    const double p2x = fl.cmx - fl.len * fl.c, p2y = fl.cmy - fl.len * fl.s;
+    const double ex = p2x - p1x, ey = p2y - p1y;
+    const double qx = px - p1x, qy = py - p1y;
+    const double t = (qx * ex + qy * ey) * (1.0 / (ex * ex + ey * ey));   // Jet division: f * (1 / g)
     double r, dr;
-    if (along > fl.len) { const double e = along - fl.len; r = sqrt(e * e + perp * perp); dr = -fl.len * perp / r; }
-    else if (along < -fl.len) { const double e = along + fl.len; r = sqrt(e * e + perp * perp); dr = fl.len * perp / r; }
-    else { r = fabs(perp); dr = (perp < 0.0) ? along : -along; }
+    if (t < 0.0) {
+      r = sqrt(qx * qx + qy * qy);
+      dr = -fl.len * (-qx * fl.s + qy * fl.c) / r;
+    } else if (t > 1.0) {
+      const double fx = px - p2x, fy = py - p2y;
+      r = sqrt(fx * fx + fy * fy);
+      dr = fl.len * (-fx * fl.s + fy * fl.c) / r;
+    } else {
+      const double gx = px - (p1x + t * ex), gy = py - (p1y + t * ey);
+      r = sqrt(gx * gx + gy * gy);
+      const double qn = -qx * fl.s + qy * fl.c;
+      dr = (qn < 0.0) ? (fl.len + (qx * fl.c + qy * fl.s)) : -(fl.len + (qx * fl.c + qy * fl.s));
+    }
+    if (r == 0.0) dr = __longlong_as_double(0x7ff8000000000000ll);
     a0 += r * r; a1 += dr * r; a2 += dr * dr;
   }
   for (int sft = 32; sft >= 1; sft >>= 1) { a0 += __shfl_xor(a0, sft, 64); a1 += __shfl_xor(a1, sft, 64); a2 += __shfl_xor(a2, sft, 64); }

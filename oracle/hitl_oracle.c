@@ -1137,14 +1137,20 @@ static int seg_fit_em(const double p1[2], const double p2[2], const double* data
   const double icx = (p1[0] + p2[0]) / 2.0, icy = (p1[1] + p2[1]) / 2.0;
   const double hy = sqrt((p1[0] - p2[0]) * (p1[0] - p2[0]) + (p1[1] - p2[1]) * (p1[1] - p2[1]));
   const double ad = fabs(p1[0] - p2[0]);
-  double theta = acos(ad / hy);
+  const double theta0 = acos(ad / hy);
+  double theta = theta0;
   const double len = hy / 2.0;
   double cost, g, h;
   seg_fit_eval(theta, data, n, icx, icy, len, &cost, &g, &h);
+  /* A residual that is exactly 0 (a clicked point that IS a scan point and an endpoint) has the derivative 0 * inf = NaN
+   * under Jet sqrt: Ceres then reports FAILURE ("Residual and Jacobian evaluation failed"), leaves the user's
+   * parameter untouched (Summary::IsSolutionUsable), and SegFitEM never looks at the summary.  Same for 5 invalid
+   * steps in a row.  The candidate evaluation inside an iteration is cost-only, so only its cost has to be finite. */
+  int failed = !(isfinite(cost) && isfinite(g) && isfinite(h));
   const double scale = 1.0 / (1.0 + sqrt(h));
   double radius = 1e4, decrease_factor = 2.0;
-  int iter = 0, invalid_run = 0, failed = 0;
-  int done = fabs(g) <= 1e-10;
+  int iter = 0, invalid_run = 0;
+  int done = failed || fabs(g) <= 1e-10;
   while (!done) {
     if (iter >= 25) break;
     ++iter;
@@ -1162,11 +1168,13 @@ static int seg_fit_em(const double p1[2], const double p2[2], const double* data
     double cc, cg, ch;
     seg_fit_eval(cand, data, n, icx, icy, len, &cc, &cg, &ch);
     if (fabs(step) <= 1e-8 * (fabs(theta) + 1e-8)) break;
+    if (!isfinite(cc)) cc = DBL_MAX;   /* "Step failed to evaluate. Treating it as a step with infinite cost" */
     const double cost_change = cost - cc;
     if (fabs(cost_change) <= 1e-6 * cost) break;
     const double rho = cost_change / mcc;
     if (rho > 1e-3) {
       theta = cand; cost = cc; g = cg; h = ch;
+      if (!(isfinite(g) && isfinite(h))) { failed = 1; break; }
       if (fabs(g) <= 1e-10) break;
       const double q = 2.0 * rho - 1.0;
       double f = 1.0 - q * q * q; if (f < 1.0 / 3.0) f = 1.0 / 3.0;
@@ -1178,11 +1186,12 @@ static int seg_fit_em(const double p1[2], const double p2[2], const double* data
     }
   }
   if (iterations) *iterations = iter;
+  if (failed) theta = theta0;
   double ax = cos(theta), ay = sin(theta);
   const double nrm = sqrt(ax * ax + ay * ay); ax /= nrm; ay /= nrm;
   ep[0] = (float)(icx + len * ax); ep[1] = (float)(icy + len * ay);
   ep[2] = (float)(icx - len * ax); ep[3] = (float)(icy - len * ay);
-  return failed;
+  return 0;
 }
 
 int orc_fit_segments(orc_solver* s, const float* poses, int32_t n_seg, float* seg, int32_t* n_inliers, int32_t* passes, int32_t* lm_iterations) {

@@ -11,7 +11,9 @@ import pytest
 from hitl_slam_amd import abi
 from hitl_slam_amd.api import hc_rows
 
-GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "*.npz")))
+_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GOLDEN = sorted(p for p in glob.glob(os.path.join(_DIR, "*.npz")) if not os.path.basename(p).startswith("cycle_"))
+CYCLE = os.path.join(_DIR, "cycle_corridor.npz")     # made by tests/golden/make_golden_cycle.py
 POSE_TOL_M = 1e-4
 POSE_TOL_RAD = 1e-4
 
@@ -77,4 +79,55 @@ def test_hip_path_reproduces_golden(path):
     z = np.load(path)
     s = _load(H.Solver(), z, with_corr=False)
     _check(s, z, 1e-10, lambda sv, zz: sv.find_correspondences(zz["init"], int(zz["window"])))
+    s.close()
+
+
+def _cycle_check(s, z, exact_libm):
+    """One whole user correction (HitLSLAM::Run) stage by stage against the fixture."""
+    s.set_map(z["obs_offset"], z["px"], z["py"], z["nx"], z["ny"], z["cov9"])
+    eq = lambda a, b: np.array_equal(np.asarray(a).view(np.uint32), np.asarray(b).view(np.uint32))
+    assert np.array_equal(s.verify_points(z["init"], z["clicks"].reshape(-1, 2), 0.05), z["seen"])
+    seg, inl, pas, its = s.fit_segments(z["init"], z["clicks"].reshape(2, 4))
+    assert np.array_equal(inl, z["fit_inliers"]) and np.array_equal(pas, z["fit_passes"]) and np.array_equal(its, z["fit_iterations"])
+    assert np.abs(seg - z["fitted"]).max() <= 2e-6
+    counts, _ = s.observation_sets(z["init"], z["fitted"].reshape(-1), 0.03, want_mask=False)
+    assert np.array_equal(counts, z["counts"])
+    od = s.order_user_input(counts, z["fitted"].reshape(-1))
+    assert np.array_equal(od["corrected"], z["corrected"]) and np.array_equal(od["anchor"], z["anchor"])
+    assert tuple(z["bounds"]) == od["bounds"] and eq(od["seg_xy8"], z["seg_ordered"])
+    p2, corr, rows = s.apply_explicit_correction(int(z["ctype"]), z["seg_ordered"], z["init"], z["corrected"], z["anchor"])
+    assert eq(p2, z["poses_explicit"]) and eq(corr, z["correction"])
+    for f in ("type", "constrained_pose_id", "anchor_pose_id"):
+        assert np.array_equal(rows[f], z["rows"][f])
+    for f in ("delta_parallel", "delta_perpendicular", "relative_penalty_dir"):
+        assert eq(rows[f], z["rows"][f])
+    if exact_libm:
+        assert eq(rows["delta_angle"], z["rows"]["delta_angle"])
+    else:     # three device libm calls deep
+        assert (np.abs(rows["delta_angle"].astype(np.float64) - z["rows"]["delta_angle"]) <= 4 * np.spacing(np.abs(z["rows"]["delta_angle"])) + 1e-12).all()
+    p3, cov3 = s.backprop(z["poses_explicit"], z["cov9"], int(z["bounds"][0]), int(z["bounds"][1]), z["correction"])
+    assert eq(p3, z["poses_backprop"]) and eq(cov3, z["cov_backprop"])
+    assert eq(s.normalize_angles(z["poses_backprop"]), z["poses_normalized"])
+    s.set_human_constraints(z["rows"])
+    p5, summ = s.solve(abi.MODE_ODOM_HC, z["poses_normalized"])
+    assert summ.termination == int(z["termination"]) and summ.iterations == int(z["iterations"])
+    assert np.abs(p5[:, :2] - z["poses_solved"][:, :2]).max() <= POSE_TOL_M
+    assert np.abs(p5[:, 2] - z["poses_solved"][:, 2]).max() <= POSE_TOL_RAD
+    S = s.pose_covariances(abi.MODE_ODOM_HC, z["poses_solved"])
+    scale = np.abs(z["pose_covariances"]).max(axis=(1, 2))[:, None, None] + 1e-300
+    assert (np.abs(S - z["pose_covariances"]) / scale).max() < 1e-6
+
+
+def test_oracle_reproduces_cycle_golden():
+    from oracle import hitl_oracle as O
+    s = O.OracleSolver()
+    _cycle_check(s, np.load(CYCLE), exact_libm=True)
+    s.close()
+
+
+@pytest.mark.gpu
+def test_hip_path_reproduces_cycle_golden():
+    import hitl_slam_amd as H
+    s = H.Solver()
+    _cycle_check(s, np.load(CYCLE), exact_libm=False)
     s.close()

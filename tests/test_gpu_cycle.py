@@ -47,6 +47,47 @@ def test_fit_segments_parity(both, sc):
         g.fit_segments(sc.poses, [[1.0, 2.0, 1.0, 2.0]])
 
 
+@pytest.mark.parametrize("alpha", [-0.5, 0.7, 2.0, -2.6])
+def test_fit_segments_parity_on_a_rotated_world(both, sc, alpha):
+    """Walls that are not axis-aligned: SegFitEM starts from acos(|dx| / length), which drops the sign of the slope, so
+    for a falling wall the fit has to swing the segment through a large angle (or settles in whatever minimum the
+    reference would).  The map is rotated by moving the poses; the robot-frame scans stay as they are."""
+    g, o = both
+    c, s_ = np.cos(alpha), np.sin(alpha)
+    R = np.array([[c, -s_], [s_, c]])
+    poses = sc.poses.astype(np.float64).copy()
+    poses[:, :2] = poses[:, :2] @ R.T
+    poses[:, 2] += alpha
+    poses = poses.astype(np.float32)
+    wx, wy = o.transform_scans(poses)
+    W = np.c_[wx, wy]
+    clicks = (sc.selected.reshape(4, 2).astype(np.float64) @ R.T)
+    # snap every click to the nearest point of the rotated map, like a user would click
+    clicks = np.array([W[np.argmin(((W - q) ** 2).sum(1))] for q in clicks], np.float32)
+    sg, ig, pg, tg = g.fit_segments(poses, clicks.reshape(2, 4))
+    so, io, po, to = o.fit_segments(poses, clicks.reshape(2, 4))
+    assert np.array_equal(ig, io) and np.array_equal(pg, po) and np.array_equal(tg, to), (ig, io, pg, po, tg, to)
+    assert np.abs(sg - so).max() <= 4e-6, (sg, so)
+
+
+@pytest.mark.parametrize("seed", [20260111, 20260112, 20260113])
+def test_full_cycle_parity_other_maps(seed):
+    from hitl_slam_amd import Solver
+    from oracle import hitl_oracle as O
+    sc2 = Scenario(n_poses=100, obs=96, seed=seed)
+    g, o = Solver(), O.OracleSolver()
+    sc2.prob.load(g)
+    sc2.prob.load(o)
+    rg = g.run_correction(4, sc2.selected, sc2.poses, sc2.cov, [])
+    ro = o.run_correction(4, sc2.selected, sc2.poses, sc2.cov, [])
+    assert rg["status"] == ro["status"] == "ok"
+    assert rg["order"]["bounds"] == ro["order"]["bounds"] and np.array_equal(rg["order"]["corrected"], ro["order"]["corrected"])
+    d = rg["poses"].astype(np.float64) - ro["poses"]
+    d[:, 2] = np.angle(np.exp(1j * d[:, 2]))
+    assert np.abs(d[:, :2]).max() < 1e-4 and np.abs(d[:, 2]).max() < 1e-4
+    g.close(); o.close()
+
+
 @pytest.mark.parametrize("ctype", [2, 4, 5, 6])
 def test_explicit_correction_parity(both, sc, ctype):
     g, o = both
