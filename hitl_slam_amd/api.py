@@ -302,7 +302,7 @@ class SolverBase(object):
         return poses.reshape(-1, 3)
 
     def run_correction(self, ctype, selected_points_xy8, poses_xyt, cov9, constraint_groups, mode=abi.MODE_ODOM_HC,
-                       select_threshold=0.05):
+                       select_threshold=0.05, stf_window=3, find_corr_kwargs=None):
         """One whole HitLSLAM::Run (HitLSLAM.cpp:380-480) on this backend.  constraint_groups is the session's list of
         row arrays (human_constraints_); returns dict(poses, cov9, constraint_groups, summary, status, ...)."""
         poses = np.array(poses_xyt, np.float32).reshape(-1, 3)
@@ -327,6 +327,8 @@ class SolverBase(object):
         poses = self.normalize_angles(poses)
         allrows = np.concatenate(out["constraint_groups"]) if out["constraint_groups"] else np.zeros(0, abi.HC_DTYPE)
         self.set_human_constraints(allrows)
+        if mode != abi.MODE_ODOM_HC:     # the observation solve the reference keeps commented out (JointOptimization.cpp:1353-1373)
+            self.find_correspondences(poses, stf_window, **(find_corr_kwargs or {}))
         poses, summ = self.solve(mode, poses)
         out.update(poses=poses, cov9=cov, summary=summ, correction=correction)
         return out
@@ -343,6 +345,23 @@ class SolverBase(object):
         if st != abi.OK:
             raise HitlError(st, self._cov_name, self._detail())
         return out.reshape(-1, 3, 3)
+
+    def replay_log(self, entries, poses_xyt, cov9, mode=abi.MODE_ODOM_HC, **kw):
+        """== the replay loop of HitLSLAM_main.cpp:880-905 over hitl_slam_amd.io.load_input_log(path): one correction
+        cycle per logged entry (HitLSLAM::replayLog), entries marked undone included, as in the reference.  Returns
+        (poses, cov9, constraint_groups, [status per entry])."""
+        poses = np.array(poses_xyt, np.float32).reshape(-1, 3)
+        cov = np.array(cov9, np.float32).reshape(-1, 9)
+        groups, statuses = [], []
+        for e in entries:
+            if e["type"] not in (2, 4, 5, 6) or len(e["points"]) != 4:
+                statuses.append("unsupported")     # point / corner / unknown: "not supported yet" (EMinput.cpp:467-469)
+                continue
+            r = self.run_correction(e["type"], np.asarray(e["points"], np.float32).reshape(-1), poses, cov, groups, mode=mode, **kw)
+            statuses.append(r["status"])
+            if r["status"] == "ok":
+                poses, cov, groups = r["poses"], r["cov9"], r["constraint_groups"]
+        return poses, cov, groups, statuses
 
     # -- the path --------------------------------------------------------------------------
     def solve(self, mode, poses_xyt, allow_failure=False):

@@ -4,12 +4,17 @@
 //  * .stfs.covars reader  == loadPoseGraph            (HitLSLAM_main.cpp:192-300)
 //  * .stfs.covars writer  == SaveStfsandCovars         (vector_mapping_main.cpp:1855-1901)
 //  * results writer       == saveHitLResults           (HitLSLAM_main.cpp:572-581)
+//  * input-log reader     == LoadLogFile               (HitLSLAM_main.cpp:676-764)
+//  * input-log writer     == LogActivity               (HitLSLAM_main.cpp:776-822)
 //
 // Bug-compatibility: the reference loader (1) brings NORMALS into the robot
 // frame with the POINT transform R(-theta)(n - t), leaving non-unit "normals" away from the
 // origin, (2) starts a new pose on ANY bit difference of consecutive (x, y, theta) rows and
 // keeps the covariance of the group's first row.  Both are reproduced by default;
 // fix_normals != 0 rotates normals only.
+// The log reader (3) recognises a parallel correction by the number 7, while the writer (and the enum,
+// human_constraints.h:15) use 6: a logged parallel correction reads its 4 points but comes back with an
+// uninitialised type.  Reproduced as type UNKNOWN unless fix_parallel != 0.
 
 #include <cmath>
 #include <cstdio>
@@ -27,6 +32,13 @@ struct hitl_posegraph {
   std::vector<float> cov9;         // n*9 row-major
   std::vector<int64_t> obs_offset; // n+1
   std::vector<float> px, py, nx, ny;   // robot frame
+};
+
+struct hitl_input_log {
+  std::vector<uint32_t> type;
+  std::vector<int32_t> undone;
+  std::vector<int64_t> point_off;   // entries + 1
+  std::vector<float> points;        // x, y interleaved
 };
 
 namespace {
@@ -134,6 +146,94 @@ int hitl_io_save_results(const char* path, int64_t n_poses, const float* poses_x
   FILE* fid = fopen(path, "w");
   if (!fid) return HITL_ERR_INVALID_ARGUMENT;
   for (int64_t i = 0; i < n_poses; ++i) fprintf(fid, "%f %f %f\n", poses_xyt[3 * i], poses_xyt[3 * i + 1], poses_xyt[3 * i + 2]);
+  fclose(fid);
+  return HITL_OK;
+}
+
+// ---- input log ("recording") -------------------------------------------------------------------------------
+// Line 1: number of entries.  Per entry: "type, undone", then one "x, y" line per selected point: 2 points for
+// type 1, 8 for type 3, 4 for types 2, 4, 5, 6, none otherwise.  Reading stops quietly at end of file.
+int hitl_io_load_input_log(const char* path, int fix_parallel, hitl_input_log** out) {
+  if (!path || !out) return HITL_ERR_INVALID_ARGUMENT;
+  FILE* fid = fopen(path, "r");
+  if (!fid) return HITL_ERR_INVALID_ARGUMENT;
+  hitl_input_log* g = new (std::nothrow) hitl_input_log();
+  if (!g) { fclose(fid); return HITL_ERR_OUT_OF_MEMORY; }
+  g->point_off.push_back(0);
+  char line[512];
+  int rc = HITL_OK;
+  auto field = [](const char* s, int which, char* dst, size_t cap) {   // == getline(iss, line, ',') twice
+    const char* b = s;
+    for (int k = 0; k < which; ++k) { const char* c = strchr(b, ','); if (!c) { b = s + strlen(s); break; } b = c + 1; }
+    size_t n = 0;
+    while (b[n] && b[n] != ',' && b[n] != '\n' && n + 1 < cap) { dst[n] = b[n]; ++n; }
+    dst[n] = 0;
+  };
+  auto to_int = [](const char* s, long* v) { char* e; *v = strtol(s, &e, 10); return e != s; };          // std::stoi
+  auto to_float = [](const char* s, float* v) { char* e; *v = strtof(s, &e); return e != s; };          // std::stof
+  long num_entries = 0;
+  if (!fgets(line, sizeof(line), fid) || !to_int(line, &num_entries) || num_entries < 0) rc = HITL_ERR_INVALID_ARGUMENT;
+  for (long i = 0; rc == HITL_OK && i < num_entries; ++i) {
+    if (!fgets(line, sizeof(line), fid)) break;
+    char tok[128];
+    long ctype = 0, undone = 0;
+    field(line, 0, tok, sizeof(tok));
+    if (!to_int(tok, &ctype)) { rc = HITL_ERR_INVALID_ARGUMENT; break; }
+    field(line, 1, tok, sizeof(tok));
+    if (!to_int(tok, &undone)) { rc = HITL_ERR_INVALID_ARGUMENT; break; }
+    int npts = 0;
+    uint32_t t = HITL_HC_UNKNOWN;
+    if (ctype == 1) { npts = 2; t = HITL_HC_POINT; }
+    else if (ctype == 3) { npts = 8; t = HITL_HC_CORNER; }
+    else if (ctype == 2 || ctype == 4 || ctype == 5 || ctype == 6) {
+      npts = 4;
+      if (ctype == 2) t = HITL_HC_LINE_SEGMENT;
+      else if (ctype == 4) t = HITL_HC_COLINEAR;
+      else if (ctype == 5) t = HITL_HC_PERPENDICULAR;
+      else t = fix_parallel ? HITL_HC_PARALLEL : HITL_HC_UNKNOWN;     // the reference tests "== 7" here
+    }
+    for (int j = 0; j < npts && rc == HITL_OK; ++j) {
+      float x = 0.f, y = 0.f;
+      if (!fgets(line, sizeof(line), fid)) { line[0] = 0; }
+      field(line, 0, tok, sizeof(tok));
+      if (!to_float(tok, &x)) { rc = HITL_ERR_INVALID_ARGUMENT; break; }
+      field(line, 1, tok, sizeof(tok));
+      if (!to_float(tok, &y)) { rc = HITL_ERR_INVALID_ARGUMENT; break; }
+      g->points.push_back(x); g->points.push_back(y);
+    }
+    if (rc != HITL_OK) break;
+    g->type.push_back(t);
+    g->undone.push_back((int32_t)undone);
+    g->point_off.push_back((int64_t)(g->points.size() / 2));
+  }
+  fclose(fid);
+  if (rc != HITL_OK) { delete g; return rc; }
+  *out = g;
+  return HITL_OK;
+}
+
+void hitl_input_log_free(hitl_input_log* g) { delete g; }
+int32_t hitl_input_log_num_entries(const hitl_input_log* g) { return g ? (int32_t)g->type.size() : 0; }
+int hitl_input_log_entry(const hitl_input_log* g, int32_t i, uint32_t* type, int32_t* undone, int32_t* n_points, const float** points_xy) {
+  if (!g || i < 0 || i >= (int32_t)g->type.size()) return HITL_ERR_INVALID_ARGUMENT;
+  if (type) *type = g->type[i];
+  if (undone) *undone = g->undone[i];
+  if (n_points) *n_points = (int32_t)(g->point_off[i + 1] - g->point_off[i]);
+  if (points_xy) *points_xy = g->points.data() + 2 * g->point_off[i];
+  return HITL_OK;
+}
+
+int hitl_io_save_input_log(const char* path, int32_t n_entries, const uint32_t* types, const int32_t* undone,
+                           const int32_t* n_points, const float* points_xy) {
+  if (!path || n_entries < 0 || (n_entries > 0 && (!types || !undone || !n_points))) return HITL_ERR_INVALID_ARGUMENT;
+  FILE* fid = fopen(path, "w");
+  if (!fid) return HITL_ERR_INVALID_ARGUMENT;
+  fprintf(fid, "%d \n", n_entries);
+  size_t at = 0;
+  for (int32_t i = 0; i < n_entries; ++i) {
+    fprintf(fid, "%d, %d\n", (int)types[i], undone[i]);
+    for (int32_t j = 0; j < n_points[i]; ++j, ++at) fprintf(fid, "%.4f, %.4f\n", points_xy[2 * at], points_xy[2 * at + 1]);
+  }
   fclose(fid);
   return HITL_OK;
 }

@@ -1,7 +1,8 @@
 """ctypes mirror of the hitl_io_* entry points (include/hitl_gpu.h): the file formats either
 side of the re-solve -- .stfs.covars reader (== loadPoseGraph, HitLSLAM_main.cpp:192-300) and
 writer (== SaveStfsandCovars, vector_mapping_main.cpp:1855-1901), results writer
-(== saveHitLResults, HitLSLAM_main.cpp:572-581).  Host-only: works without a GPU."""
+(== saveHitLResults, HitLSLAM_main.cpp:572-581), input-log reader/writer (== LoadLogFile / LogActivity,
+HitLSLAM_main.cpp:676-822).  Host-only: works without a GPU."""
 import ctypes as C
 
 import numpy as np
@@ -26,6 +27,15 @@ def _lib():
         L.hitl_io_save_stfs_covars.argtypes = [C.c_char_p, C.c_char_p, C.c_double, C.c_int64, _f32p, _i64p, _f32p, _f32p,
                                                _f32p, _f32p, _f32p]
         L.hitl_io_save_results.argtypes = [C.c_char_p, C.c_int64, _f32p]
+        L.hitl_io_load_input_log.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
+        L.hitl_input_log_free.argtypes = [vp]
+        L.hitl_input_log_free.restype = None
+        L.hitl_input_log_num_entries.argtypes = [vp]
+        L.hitl_input_log_num_entries.restype = C.c_int32
+        L.hitl_input_log_entry.argtypes = [vp, C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                           C.POINTER(_f32p)]
+        L.hitl_io_save_input_log.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_int32),
+                                             C.POINTER(C.c_int32), _f32p]
         L._io_bound = True
     return L
 
@@ -73,3 +83,35 @@ def save_results(path, poses):
     st = L.hitl_io_save_results(str(path).encode(), poses.size // 3, _ptr(poses, _f32p))
     if st != abi.OK:
         raise HitlError(st, "hitl_io_save_results", "cannot write %s" % path)
+
+
+def load_input_log(path, fix_parallel=False):
+    """Returns a list of dict(type, undone, points float32 [k,2]) == the reference's input_log_ (vector<SingleInput>)."""
+    L = _lib()
+    h = C.c_void_p()
+    st = L.hitl_io_load_input_log(str(path).encode(), int(bool(fix_parallel)), C.byref(h))
+    if st != abi.OK:
+        raise HitlError(st, "hitl_io_load_input_log", "cannot read %s" % path)
+    out = []
+    try:
+        for i in range(L.hitl_input_log_num_entries(h)):
+            t, u, k, p = C.c_uint32(), C.c_int32(), C.c_int32(), _f32p()
+            L.hitl_input_log_entry(h, i, C.byref(t), C.byref(u), C.byref(k), C.byref(p))
+            pts = np.ctypeslib.as_array(p, shape=(2 * k.value,)).astype(np.float32, copy=True).reshape(-1, 2) if k.value else np.zeros((0, 2), np.float32)
+            out.append(dict(type=int(t.value), undone=int(u.value), points=pts))
+    finally:
+        L.hitl_input_log_free(h)
+    return out
+
+
+def save_input_log(path, entries):
+    L = _lib()
+    n = len(entries)
+    types = (C.c_uint32 * max(n, 1))(*[int(e["type"]) for e in entries])
+    undone = (C.c_int32 * max(n, 1))(*[int(e["undone"]) for e in entries])
+    npts = (C.c_int32 * max(n, 1))(*[len(e["points"]) for e in entries])
+    pts = np.concatenate([np.asarray(e["points"], np.float32).reshape(-1) for e in entries]) if n else np.zeros(0, np.float32)
+    pts = np.ascontiguousarray(pts if pts.size else np.zeros(1, np.float32))
+    st = L.hitl_io_save_input_log(str(path).encode(), n, types, undone, npts, _ptr(pts, _f32p))
+    if st != abi.OK:
+        raise HitlError(st, "hitl_io_save_input_log", "cannot write %s" % path)

@@ -309,6 +309,7 @@ int hitl_partition_range(int64_t n_poses, const int64_t* obs_offset, int32_t ran
  * hitl_io_save_stfs_covars   == SaveStfsandCovars  (vector_mapping_main.cpp:1855-1901), "%.4f" x7, "%f" x9.
  * hitl_io_save_results       == saveHitLResults    (HitLSLAM_main.cpp:572-581), "%f %f %f\n" per pose. */
 typedef struct hitl_posegraph hitl_posegraph;
+typedef struct hitl_input_log hitl_input_log;
 int hitl_io_load_stfs_covars(const char* path, int fix_normals, hitl_posegraph** out);
 void hitl_posegraph_free(hitl_posegraph*);
 int64_t hitl_posegraph_num_poses(const hitl_posegraph*);
@@ -326,6 +327,19 @@ int hitl_io_save_stfs_covars(const char* path, const char* map_name, double time
                              const float* poses_xyt, const int64_t* obs_offset, const float* px, const float* py,
                              const float* nx, const float* ny, const float* cov9 /* may be NULL */);
 int hitl_io_save_results(const char* path, int64_t n_poses, const float* poses_xyt);
+/* The recording of a session's corrections: hitl_io_load_input_log == LoadLogFile (HitLSLAM_main.cpp:676-764),
+ * hitl_io_save_input_log == LogActivity (:776-822; "%d \n", "%d, %d\n", "%.4f, %.4f\n").  An entry is
+ * (type, undone, its clicked points); 2 points for type 1, 8 for type 3, 4 for types 2, 4, 5, 6.  The reference reader
+ * maps the number 7 (never written) to the parallel type and leaves a logged 6 uninitialised: reproduced as
+ * HITL_HC_UNKNOWN unless fix_parallel != 0.  Each entry is replayed by one correction cycle (HitLSLAM::replayLog,
+ * HitLSLAM.cpp:278-360), whether or not it is marked undone (the skip at HitLSLAM_main.cpp:889-896 is commented out). */
+int hitl_io_load_input_log(const char* path, int fix_parallel, hitl_input_log** out);
+void hitl_input_log_free(hitl_input_log*);
+int32_t hitl_input_log_num_entries(const hitl_input_log*);
+int hitl_input_log_entry(const hitl_input_log*, int32_t i, uint32_t* type, int32_t* undone, int32_t* n_points,
+                         const float** points_xy);
+int hitl_io_save_input_log(const char* path, int32_t n_entries, const uint32_t* types, const int32_t* undone,
+                           const int32_t* n_points, const float* points_xy);
 
 const char* hitl_status_string(int status);
 const char* hitl_last_error(void);       /* thread-local detail of the last failure      */

@@ -182,3 +182,43 @@ def test_full_cycle_parity(both, sc, ctype):
     bad = sc.selected.copy()
     bad[1] += 40.0
     assert g.run_correction(ctype, bad, sc.poses, sc.cov, [])["status"] == "not verified"
+
+
+def test_full_cycle_with_the_joint_observation_solve(both, sc):
+    """The same cycle ending in mode C (odometry + human rows + scan-to-scan factors matched at the corrected poses):
+    what HitLSLAM::Run would do with PostHumanOptimization enabled (JointOptimization.cpp:1353-1373)."""
+    g, o = both
+    rg = g.run_correction(4, sc.selected, sc.poses, sc.cov, [], mode=abi.MODE_JOINT, stf_window=3)
+    ro = o.run_correction(4, sc.selected, sc.poses, sc.cov, [], mode=abi.MODE_JOINT, stf_window=3)
+    assert rg["status"] == ro["status"] == "ok"
+    cg, co = g.get_correspondences(), o.get_correspondences()
+    for a, b in zip(cg, co):
+        assert np.array_equal(a, b)                       # matched at bit-identical poses: identical index sets
+    assert rg["summary"].num_matches == ro["summary"].num_matches > 1000
+    assert rg["summary"].termination == ro["summary"].termination
+    assert rg["summary"].iterations == ro["summary"].iterations
+    d = rg["poses"].astype(np.float64) - ro["poses"]
+    d[:, 2] = np.angle(np.exp(1j * d[:, 2]))
+    assert np.abs(d[:, :2]).max() < 1e-4 and np.abs(d[:, 2]).max() < 1e-4
+    assert abs(rg["summary"].final_cost - ro["summary"].final_cost) <= 1e-6 * ro["summary"].final_cost
+
+
+def test_replaying_a_recorded_session(both, sc, tmp_path):
+    """Write a two-correction recording with the product's writer, read it back, replay it on both backends."""
+    from hitl_slam_amd import io as HIO
+    g, o = both
+    sc2 = Scenario(first_piece=(10.5, 17.5))
+    entries = [dict(type=4, undone=0, points=sc.selected.reshape(4, 2)), dict(type=1, undone=0, points=sc.selected.reshape(4, 2)[:2]),
+               dict(type=4, undone=1, points=sc2.selected.reshape(4, 2))]
+    path = str(tmp_path / "rec.log")
+    HIO.save_input_log(path, entries)
+    log = HIO.load_input_log(path)
+    assert len(log) == 3
+    pg, cg, gg, sg = g.replay_log(log, sc.poses, sc.cov)
+    po, co, go, so = o.replay_log(log, sc.poses, sc.cov)
+    assert sg == so and sg[0] == "ok" and sg[1] == "unsupported"
+    assert len(gg) == len(go) == sg.count("ok")
+    assert np.array_equal(cg.view(np.uint32), co.view(np.uint32))
+    d = pg.astype(np.float64) - po
+    d[:, 2] = np.angle(np.exp(1j * d[:, 2]))
+    assert np.abs(d[:, :2]).max() < 2e-4 and np.abs(d[:, 2]).max() < 2e-4
