@@ -241,7 +241,8 @@ static int ensure_work(hitl_solver* s, int Wb) {
   TRY(s->step_partials.resize((size_t)spmv_blocks(s->npad) * 8));
   TRY(s->pose_cs.resize((size_t)n));
   {
-    const size_t need = std::max<size_t>((size_t)assemble_blocks(n) * 2, (size_t)spmv_blocks(s->npad) * 8);
+    // step partials at offset 0, linearisation partials behind them: one iteration reads both with one sync
+    const size_t need = (size_t)assemble_blocks(n) * 2 + (size_t)spmv_blocks(s->npad) * 8;
     if (need > s->h_partials_cap) {
       if (s->h_partials) (void)hipHostFree(s->h_partials);
       s->h_partials = nullptr; s->h_partials_cap = 0;
@@ -341,8 +342,10 @@ static FactorView factor_view(hitl_solver* s, int mode, int Wb) {
 
 struct LinResult { double cost, gmax; float stf_ms; };
 
-// one pass over every factor at state xdev: residuals, Jacobians, J^T J blocks, gradient, cost
-static int run_linearize(hitl_solver* s, const FactorView& fv, const double* xdev, int buf, LinResult* out) {
+// one pass over every factor at state xdev: residuals, Jacobians, J^T J blocks, gradient, cost.
+// enqueue_linearize only queues the kernels and the copy of the per-workgroup partials (behind the step partials in
+// the pinned buffer); finish_linearize adds them up once the stream has been synchronised.
+static int enqueue_linearize(hitl_solver* s, const FactorView& fv, const double* xdev, int buf) {
   hipStream_t st = s->stream;
   const MapView mv = s->map_view();
   const PairView pv = s->pair_view();
@@ -355,12 +358,18 @@ static int run_linearize(hitl_solver* s, const FactorView& fv, const double* xde
   launch_assemble(st, mv, pv, fv, xdev, lv);
   HIP_TRY(hipGetLastError());
   const int nblk = assemble_blocks(s->n);
-  HIP_TRY(hipMemcpyAsync(s->h_partials, lv.partials, sizeof(double) * 2 * nblk, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
+  double* host = s->h_partials + (size_t)spmv_blocks(s->npad) * 8;
+  HIP_TRY(hipMemcpyAsync(host, lv.partials, sizeof(double) * 2 * nblk, hipMemcpyDeviceToHost, st));
+  return HITL_OK;
+}
+
+static int finish_linearize(hitl_solver* s, const FactorView& fv, LinResult* out) {
+  const int nblk = assemble_blocks(s->n);
+  const double* host = s->h_partials + (size_t)spmv_blocks(s->npad) * 8;
   double cost = 0.0, gmax = 0.0;
   for (int b = 0; b < nblk; ++b) {   // fixed order: bit-reproducible
-    cost += s->h_partials[2 * b];
-    const double g = s->h_partials[2 * b + 1];
+    cost += host[2 * b];
+    const double g = host[2 * b + 1];
     if (g > gmax || g != g) gmax = g;
   }
   out->cost = cost;
@@ -368,6 +377,12 @@ static int run_linearize(hitl_solver* s, const FactorView& fv, const double* xde
   out->stf_ms = 0.f;
   if (fv.with_stf) HIP_TRY(hipEventElapsedTime(&out->stf_ms, s->ev0, s->ev1));
   return HITL_OK;
+}
+
+static int run_linearize(hitl_solver* s, const FactorView& fv, const double* xdev, int buf, LinResult* out) {
+  TRY(enqueue_linearize(s, fv, xdev, buf));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return finish_linearize(s, fv, out);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -493,10 +508,22 @@ static int prepare(hitl_solver* s, int mode, const float* poses_ref, const float
 // ---------------------------------------------------------------------------------------
 struct StepScalars { double dt_rhs, dt_q, step2, xn2, bad; };
 
-static int read_step_partials(hitl_solver* s, double* rr, double* bb, StepScalars* ss) {
+static int enqueue_step_partials(hitl_solver* s) {
   const int nblk = spmv_blocks(s->npad);
   HIP_TRY(hipMemcpyAsync(s->h_partials, s->step_partials.p, sizeof(double) * 8 * nblk, hipMemcpyDeviceToHost, s->stream));
+  return HITL_OK;
+}
+
+static int finish_step_partials(hitl_solver* s, double* rr, double* bb, StepScalars* ss);
+
+static int read_step_partials(hitl_solver* s, double* rr, double* bb, StepScalars* ss) {
+  TRY(enqueue_step_partials(s));
   HIP_TRY(hipStreamSynchronize(s->stream));
+  return finish_step_partials(s, rr, bb, ss);
+}
+
+static int finish_step_partials(hitl_solver* s, double* rr, double* bb, StepScalars* ss) {
+  const int nblk = spmv_blocks(s->npad);
   double acc[7] = {0, 0, 0, 0, 0, 0, 0};
   for (int b = 0; b < nblk; ++b)
     for (int k = 0; k < 7; ++k) acc[k] += s->h_partials[8 * b + k];
@@ -573,6 +600,24 @@ static int linear_solve_and_step(hitl_solver* s, const FactorView& fv, int buf, 
   HIP_TRY(hipGetLastError());
   TRY(read_step_partials(s, nullptr, nullptr, ss));
   return HITL_OK;
+}
+
+// Banded single-GPU case, queue only: the exact step, its residual check and the trust-region bookkeeping.  The caller
+// queues the linearisation at the candidate right behind it and synchronises once for both (the candidate does not
+// depend on any host decision; if the step turns out invalid the speculative linearisation is simply dropped).
+static int enqueue_linear_solve_banded(hitl_solver* s, const FactorView& fv, int buf, double mu, const double* xcur, double* xcand) {
+  hipStream_t st = s->stream;
+  const LinView lv = s->lin_view(buf);
+  const CrView cr = s->cr_view();
+  const double mind = s->opt.min_lm_diagonal, maxd = s->opt.max_lm_diagonal;
+  const int npad = s->npad;
+  launch_build_system(st, s->n, fv.band_poses, lv, s->scale.p, s->fixed.p, mu, mind, maxd, cr, s->rhs.p);
+  launch_copy(st, npad, s->rhs.p, s->wv.p);
+  launch_cr_factor_solve(st, cr, s->wv.p, s->dt.p);
+  launch_spmv_residual(st, s->n, npad, fv, lv, s->scale.p, mu, mind, maxd, s->dt.p, s->rhs.p, s->rv.p, s->step_partials.p);
+  launch_spmv_step(st, s->n, npad, fv, lv, s->scale.p, s->dt.p, s->rhs.p, xcur, s->qv.p, xcand, s->step_partials.p);
+  HIP_TRY(hipGetLastError());
+  return enqueue_step_partials(s);
 }
 
 // Submap version.  Rank g's unknowns x_g (owned poses) satisfy
@@ -754,11 +799,24 @@ static int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float
     bool ok = true;
     HIP_TRY(hipEventRecord(s->ev2, st));
     StepScalars ss;
-    if (s->world > 1) TRY(linear_solve_and_step_dist(s, fv, cur, radius, xcur, xcand, &lin_iters, &ok, &ss));
-    else TRY(linear_solve_and_step(s, fv, cur, radius, xcur, xcand, &lin_iters, &ok, &ss));
+    const bool fused = (s->world == 1 && fv.n_offband == 0);   // one host synchronisation per LM iteration
+    if (fused) {
+      TRY(enqueue_linear_solve_banded(s, fv, cur, radius, xcur, xcand));
+      HIP_TRY(hipEventRecord(s->ev3, st));
+      TRY(enqueue_linearize(s, fv, xcand, cur ^ 1));
+      HIP_TRY(hipStreamSynchronize(st));
+      double rr, bb;
+      TRY(finish_step_partials(s, &rr, &bb, &ss));
+      const double guard = std::max(std::max(o.linear_solver_tolerance, 1e-15), 1e-9);
+      if (!(rr == rr) || rr > guard * guard * bb) ok = false;   // the factorisation broke down
+      lin_iters = 1;
+    } else {
+      if (s->world > 1) TRY(linear_solve_and_step_dist(s, fv, cur, radius, xcur, xcand, &lin_iters, &ok, &ss));
+      else TRY(linear_solve_and_step(s, fv, cur, radius, xcur, xcand, &lin_iters, &ok, &ss));
+      HIP_TRY(hipEventRecord(s->ev3, st));
+      HIP_TRY(hipEventSynchronize(s->ev3));
+    }
     S.linear_iterations += lin_iters;
-    HIP_TRY(hipEventRecord(s->ev3, st));
-    HIP_TRY(hipEventSynchronize(s->ev3));
     {
       float ms = 0.f;
       HIP_TRY(hipEventElapsedTime(&ms, s->ev2, s->ev3));
@@ -774,7 +832,8 @@ static int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float
       continue;
     }
     invalid_run = 0;
-    TRY(run_linearize_dist(s, fv, xcand, cur ^ 1, &lr));
+    if (fused) TRY(finish_linearize(s, fv, &lr));
+    else TRY(run_linearize_dist(s, fv, xcand, cur ^ 1, &lr));
     S.linearize_ms += lr.stf_ms; S.linearize_calls++;
     if (std::sqrt(step2) <= o.parameter_tolerance * (std::sqrt(xn2) + o.parameter_tolerance)) { term = HITL_CONVERGENCE; break; }
     const double cost_change = cost - lr.cost;
