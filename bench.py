@@ -294,6 +294,35 @@ def main():
         except Exception as e:
             result["correction_cycle"] = {"failed": repr(e)}
 
+    # ---- opt-in moments mode on the same problem (NOT the headline: `value` above streams every match every iteration) ----
+    if world == 1:
+        try:
+            opt2 = H.default_options()
+            opt2.device = dev_index
+            opt2.stf_moments = 1
+            s2 = H.Solver(opt2)
+            s2.set_map(off, px, py, nx, ny, cov)
+            s2.set_human_constraints(rows)
+            s2.set_correspondences(*solver.get_correspondences())
+            out2, summ2 = s2.solve(H.MODE_JOINT, init_l)                 # includes summing the moments once
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                out2, summ2 = s2.solve(H.MODE_JOINT, init_l)
+            torch.cuda.synchronize()
+            ms2 = (time.perf_counter() - t0) * 1e3 / args.steps
+            d = out2.astype(np.float64) - out
+            d[:, 2] = np.angle(np.exp(1j * d[:, 2]))
+            result["stf_moments_mode"] = {
+                "resolve_ms": ms2, "lm_iterations_per_resolve": int(summ2.iterations), "final_cost": summ2.final_cost,
+                "max_pose_difference_vs_streaming": float(np.abs(d).max()),
+                "linearize_stf_ms_per_launch": summ2.linearize_ms / max(summ2.linearize_calls, 1),
+                "note": "hitl_options.stf_moments=1: scan-to-scan factors from 2x15 moments per pose pair summed once per "
+                        "correspondence set; same algebra, per-iteration cost independent of the number of matches"}
+            s2.close()
+        except Exception as e:
+            result["stf_moments_mode"] = {"failed": repr(e)}
+
     # ---- CPU baseline: the oracle (a port, not the reference binary) on a bounded sample ----------
     if not args.no_cpu_baseline and args.cpu_sample_poses > 0 and world == 1:
         try:

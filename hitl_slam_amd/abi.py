@@ -87,7 +87,8 @@ class Options(C.Structure):
         ("rank", C.c_int32),
         ("world_size", C.c_int32),
         ("rccl_unique_id", C.c_void_p),
-        ("reserved", C.c_int64 * 4),
+        ("stf_moments", C.c_int64),
+        ("reserved", C.c_int64 * 3),
     ]
 
 

@@ -74,6 +74,11 @@ struct CrView {             // block-tridiagonal system + cyclic-reduction facto
 
 // ---- kernel launchers (hitl_kernels.hip) -------------------------------------------------
 void launch_pose_trig(hipStream_t st, int n_poses, const double* x, double2* cs);   // cs[i] = (cos, sin) of pose i
+// opt-in: the scan-to-scan factors through their 2 x 15 moments per pair (32 doubles per pair in pairM)
+constexpr int kPairMomStride = 32;
+void launch_stf_moments(hipStream_t st, const MapView& map, const PairView& pr, double* pairM);
+void launch_linearize_stf_moments(hipStream_t st, const PairView& pr, const double* pairM, const double* x, const double2* cs, double corr,
+                                  double sd, double* pairRJ);
 void launch_linearize_stf(hipStream_t st, const MapView& map, const PairView& pr, int max_scan,
                           const double* x, const double2* cs, float corr, float std_dev, double* pairRJ);
 void launch_pack_obs(hipStream_t st, int64_t n, const float* px, const float* py, const float* nx, const float* ny,

@@ -194,6 +194,105 @@ __global__ __launch_bounds__(kStfBlock, 6) void k_linearize_stf(MapView map, Pai
   }
 }
 
+// ===========================================================================================
+// Opt-in (hitl_options.stf_moments): the scan-to-scan factor through its sufficient statistics.
+// In the source frame  e0_i / k = m_i . z  with  m_i = (n0.p1, n0 x p1, n0x, n0y, -n0.p0)  and
+// z = (cos D, sin D, tau_x, tau_y, 1),  D = theta1 - theta0,  tau = R0^T (t1 - t0);  in the target frame
+// e1_i / k = m'_i . z'  with  m'_i = (-n1.p0, -(n1 x p0), n1x, n1y, n1.p1),  z' = (cos D, sin D, tau'_x, tau'_y, 1),
+// tau' = R1^T (t1 - t0).  So  sum e0^2 = k^2 z^T M0 z  with  M0 = sum m m^T  (5x5, 15 numbers) -- the point data enter
+// only through M0, M1, which do not depend on the poses.  k_stf_moments forms them once per correspondence set;
+// k_linearize_stf_moments then evaluates r and J of every pair from 30 doubles, whatever the number of matches.
+// Same algebra as k_linearize_stf, different summation order: results agree to ~1e-10 relative.
+// ===========================================================================================
+constexpr int kMomStride = 32;     // doubles per pair: M0 (15, upper triangle by rows), M1 (15), 2 spare
+
+__global__ __launch_bounds__(256) void k_stf_moments(MapView map, PairView pr, double* __restrict__ pairM) {
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (p >= pr.n_pairs) return;
+  const float4* __restrict__ src = map.obs + map.obs_off[pr.pair_src[p]];
+  const float4* __restrict__ tgt = map.obs + map.obs_off[pr.pair_tgt[p]];
+  const int64_t m_begin = pr.match_off[p], m_end = pr.match_off[p + 1];
+  double acc[30];
+#pragma unroll
+  for (int q = 0; q < 30; ++q) acc[q] = 0.0;
+  for (int64_t m = m_begin + lane; m < m_end; m += 64) {
+    const uint32_t u = pr.matches[m];
+    const float4 a = src[u & 0xffffu], b = tgt[u >> 16];
+    const double ax = a.x, ay = a.y, anx = a.z, any = a.w, bx = b.x, by = b.y, bnx = b.z, bny = b.w;
+    const double v0[5] = {anx * bx + any * by, any * bx - anx * by, anx, any, -(anx * ax + any * ay)};
+    const double v1[5] = {-(bnx * ax + bny * ay), -(bnx * ay - bny * ax), bnx, bny, bnx * bx + bny * by};
+    int q = 0;
+#pragma unroll
+    for (int r = 0; r < 5; ++r)
+#pragma unroll
+      for (int c = r; c < 5; ++c) { acc[q] += v0[r] * v0[c]; acc[15 + q] += v1[r] * v1[c]; ++q; }
+  }
+#pragma unroll
+  for (int q = 0; q < 30; ++q) {
+    double v = acc[q];
+    for (int sft = 32; sft >= 1; sft >>= 1) v += __shfl_xor(v, sft, WAVE);
+    if (lane == 0) pairM[(size_t)p * kMomStride + q] = v;
+  }
+}
+
+__device__ __forceinline__ void sym5_mul(const double* __restrict__ M, const double (&z)[5], double (&g)[5]) {
+  // M = upper triangle by rows: 00 01 02 03 04 | 11 12 13 14 | 22 23 24 | 33 34 | 44
+  g[0] = M[0] * z[0] + M[1] * z[1] + M[2] * z[2] + M[3] * z[3] + M[4] * z[4];
+  g[1] = M[1] * z[0] + M[5] * z[1] + M[6] * z[2] + M[7] * z[3] + M[8] * z[4];
+  g[2] = M[2] * z[0] + M[6] * z[1] + M[9] * z[2] + M[10] * z[3] + M[11] * z[4];
+  g[3] = M[3] * z[0] + M[7] * z[1] + M[10] * z[2] + M[12] * z[3] + M[13] * z[4];
+  g[4] = M[4] * z[0] + M[8] * z[1] + M[11] * z[2] + M[13] * z[3] + M[14] * z[4];
+}
+
+__global__ __launch_bounds__(128) void k_linearize_stf_moments(PairView pr, const double* __restrict__ pairM, const double* __restrict__ x,
+                                                               const double2* __restrict__ cs, double corr, double sd,
+                                                               double* __restrict__ pairRJ) {
+  const int p = blockIdx.x * 128 + threadIdx.x;
+  if (p >= pr.n_pairs) return;
+  const int i = pr.pair_src[p], j = pr.pair_tgt[p];
+  const double2 cs0 = cs[i], cs1 = cs[j];
+  const double c0 = cs0.x, s0 = cs0.y, c1 = cs1.x, s1 = cs1.y;
+  const double c = c0 * c1 + s0 * s1, s = c0 * s1 - s0 * c1;             // cos, sin of theta1 - theta0
+  const double dx = x[3 * j] - x[3 * i], dy = x[3 * j + 1] - x[3 * i + 1];
+  const double tx = c0 * dx + s0 * dy, ty = c0 * dy - s0 * dx;            // R0^T (t1 - t0)
+  const double ux = c1 * dx + s1 * dy, uy = c1 * dy - s1 * dx;            // R1^T (t1 - t0)
+  const double z0[5] = {c, s, tx, ty, 1.0}, z1[5] = {c, s, ux, uy, 1.0};
+  double M[30];
+  const double* __restrict__ src = pairM + (size_t)p * kMomStride;
+#pragma unroll
+  for (int q = 0; q < 30; ++q) M[q] = src[q];
+  double g0[5], g1[5];
+  sym5_mul(M, z0, g0);
+  sym5_mul(M + 15, z1, g1);
+  double S0 = 0.0, S1 = 0.0;
+#pragma unroll
+  for (int q = 0; q < 5; ++q) { S0 += z0[q] * g0[q]; S1 += z1[q] * g1[q]; }
+  S0 = fmax(S0, 0.0); S1 = fmax(S1, 0.0);                                 // a sum of squares; cancellation can leave -eps
+  const double dn = (double)(pr.match_off[p + 1] - pr.match_off[p]), inv_n = 1.0 / dn, kf = corr / sd;
+  const double a0 = S0 * inv_n, a1 = S1 * inv_n;
+  const double i0 = (S0 != 0.0) ? rsqrt(a0) : 0.0, i1 = (S1 != 0.0) ? rsqrt(a1) : 0.0;
+  const double f0 = kf * inv_n * i0, f1 = kf * inv_n * i1;
+  double* o = pairRJ + (size_t)kPairRJ * p;
+  o[0] = kf * a0 * i0; o[1] = kf * a1 * i1;
+  const double gx0 = c0 * g0[2] - s0 * g0[3], gy0 = s0 * g0[2] + c0 * g0[3];   // world-frame sum e0 n0
+  o[2] = -f0 * gx0; o[3] = -f0 * gy0; o[4] = f0 * (s * g0[0] - c * g0[1] + ty * g0[2] - tx * g0[3]);
+  o[5] = f0 * gx0; o[6] = f0 * gy0; o[7] = f0 * (-s * g0[0] + c * g0[1]);
+  const double gx1 = c1 * g1[2] - s1 * g1[3], gy1 = s1 * g1[2] + c1 * g1[3];
+  o[8] = -f1 * gx1; o[9] = -f1 * gy1; o[10] = f1 * (s * g1[0] - c * g1[1]);
+  o[11] = f1 * gx1; o[12] = f1 * gy1; o[13] = f1 * (-s * g1[0] + c * g1[1] + uy * g1[2] - ux * g1[3]);
+}
+
+void launch_stf_moments(hipStream_t st, const MapView& map, const PairView& pr, double* pairM) {
+  if (pr.n_pairs == 0) return;
+  hipLaunchKernelGGL(k_stf_moments, dim3((pr.n_pairs + 3) / 4), dim3(256), 0, st, map, pr, pairM);
+}
+
+void launch_linearize_stf_moments(hipStream_t st, const PairView& pr, const double* pairM, const double* x, const double2* cs, double corr,
+                                  double sd, double* pairRJ) {
+  if (pr.n_pairs == 0) return;
+  hipLaunchKernelGGL(k_linearize_stf_moments, dim3((pr.n_pairs + 127) / 128), dim3(128), 0, st, pr, pairM, x, cs, corr, sd, pairRJ);
+}
+
 void launch_pose_trig(hipStream_t st, int n_poses, const double* x, double2* cs) {
   hipLaunchKernelGGL(k_pose_trig, dim3((n_poses + 255) / 256), dim3(256), 0, st, n_poses, x, cs);
 }
@@ -836,6 +935,90 @@ __global__ __launch_bounds__(kCrTopThreads) void k_cr_top(CrView cr, int s_start
   }
 }
 
+// The same top of the tree with every tile resident in LDS: the M = ceil(nsb / s_start) nodes alive at stride s_start
+// are copied in once (D, L, right-hand sides), all levels, the root and the back-substitution run on a LOCAL system of
+// M nodes with local strides 1, 2, 4 .. through the very same node routines (they only see a CrView whose arrays
+// happen to live in LDS), and Dinv / Gl / Gr / w / x go back out once.  Global memory is touched twice instead of at
+// every one of the ~20 dependent phases.
+template <int B>
+__global__ __launch_bounds__(kCrTopThreads) void k_cr_top_lds(CrView cr, int s_start, int M, double* w, double* x, int nrhs, size_t stride) {
+  extern __shared__ double lds[];
+  constexpr int BB = B * B;
+  double* sD = lds;
+  double* sL = sD + (size_t)M * BB;
+  double* sDinv = sL + (size_t)M * BB;
+  double* sGl = sDinv + (size_t)M * BB;
+  double* sGr = sGl + (size_t)M * BB;
+  double* sw = sGr + (size_t)M * BB;                 // nrhs vectors of M * B, lstride apart
+  double* sx = sw + (size_t)M * B * nrhs;
+  const size_t lstride = (size_t)M * B;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  constexpr int NW = kCrTopThreads / WAVE;
+  for (int e = threadIdx.x; e < M * BB; e += kCrTopThreads) {
+    const int m = e / BB, q = e % BB;
+    const size_t g = (size_t)m * s_start * BB + q;
+    sD[e] = cr.D[g]; sL[e] = cr.L[g]; sGl[e] = 0.0; sGr[e] = 0.0; sDinv[e] = 0.0;
+  }
+  if (w != nullptr)
+    for (int e = threadIdx.x; e < M * B * nrhs; e += kCrTopThreads) {
+      const int v = e / (M * B), r = e % (M * B);
+      sw[(size_t)v * lstride + r] = w[stride * v + (size_t)(r / B) * s_start * B + (r % B)];
+    }
+  __syncthreads();
+  CrView lc;
+  lc.nsb = M; lc.B = B; lc.D = sD; lc.L = sL; lc.Dinv = sDinv; lc.Gl = sGl; lc.Gr = sGr;
+  double* lw = (w != nullptr) ? sw : nullptr;
+  int s_last = 0;
+  for (int s = 1; s < M; s *= 2) {
+    for (int q = wave;; q += NW) {
+      const int k = s * (2 * q + 1);
+      if (k >= M) break;
+      cr_eliminate_node<B>(lc, s, k, lane);
+    }
+    __syncthreads();
+    for (int q = wave;; q += NW) {
+      const int j = 2 * s * q;
+      if (j >= M) break;
+      cr_update_node<B>(lc, s, j, lane, lw, nrhs, lstride);
+    }
+    __syncthreads();
+    s_last = s;
+  }
+  if (wave == 0) cr_root_node<B>(lc, lane);
+  __syncthreads();
+  if (x != nullptr) {
+    if ((int)threadIdx.x < B * nrhs) {
+      const int vv = threadIdx.x / B, r = threadIdx.x % B;
+      double v = 0.0;
+#pragma unroll
+      for (int c = 0; c < B; ++c) v += sDinv[r * B + c] * sw[lstride * vv + c];
+      sx[lstride * vv + r] = v;
+    }
+    __syncthreads();
+    for (int s = s_last; s >= 1; s /= 2) {
+      for (int vv = 0; vv < nrhs; ++vv)
+        for (int t = threadIdx.x;; t += kCrTopThreads) {
+          const int k = s * (2 * (t / B) + 1);
+          if (k >= M) break;
+          cr_backward_row<B>(lc, s, k, t % B, sw + lstride * vv, sx + lstride * vv);
+        }
+      __syncthreads();
+    }
+  }
+  for (int e = threadIdx.x; e < M * BB; e += kCrTopThreads) {
+    const int m = e / BB, q = e % BB;
+    const size_t g = (size_t)m * s_start * BB + q;
+    cr.Dinv[g] = sDinv[e]; cr.Gl[g] = sGl[e]; cr.Gr[g] = sGr[e];
+  }
+  if (w != nullptr)
+    for (int e = threadIdx.x; e < M * B * nrhs; e += kCrTopThreads) {
+      const int v = e / (M * B), r = e % (M * B);
+      const size_t g = stride * v + (size_t)(r / B) * s_start * B + (r % B);
+      w[g] = sw[(size_t)v * lstride + r];
+      if (x != nullptr) x[g] = sx[(size_t)v * lstride + r];
+    }
+}
+
 // forward sweep on right-hand sides (blockIdx.y selects the rhs, `stride` doubles apart):
 // w_j -= Gr[k1]^T w_k1 + Gl[k2]^T w_k2
 template <int B>
@@ -872,6 +1055,39 @@ __global__ void k_cr_backward(CrView cr, int s, const double* __restrict__ w, do
   cr_backward_row<B>(cr, s, k, r, w + stride * blockIdx.y, x + stride * blockIdx.y);
 }
 
+// The back-substitution is top-down, so once x is known at every multiple of S the S - 1 nodes between two such
+// neighbours form an independent subtree: one workgroup walks it through strides S/2 .. 1 with a barrier per level.
+// Replaces log2(S) latency-bound launches by one.
+constexpr int kCrTreeThreads = 256;
+template <int B>
+__global__ __launch_bounds__(kCrTreeThreads) void k_cr_backward_tree(CrView cr, int S, const double* w, double* x, int nrhs, size_t stride) {
+  const int base = blockIdx.x * S;
+  for (int s = S / 2; s >= 1; s /= 2) {
+    const int per = S / (2 * s);                         // nodes of this stride inside the interval
+    for (int t = threadIdx.x; t < per * B * nrhs; t += kCrTreeThreads) {
+      const int vv = t / (per * B), u = t % (per * B);
+      const int k = base + s * (2 * (u / B) + 1);
+      if (k < cr.nsb) cr_backward_row<B>(cr, s, k, u % B, w + stride * vv, x + stride * vv);
+    }
+    __syncthreads();
+  }
+}
+
+template <int B>
+static void cr_backward_levels(hipStream_t st, const CrView& cr, int s_from, const double* w, double* x, int nrhs, size_t stride) {
+  // strides s_from, s_from / 2 .. 1: wide levels one launch each, the subtrees below stride kTree in one launch
+  constexpr int kTree = 64;
+  int s = s_from;
+  for (; s >= kTree; s /= 2) {
+    const int n_elim = (cr.nsb - s + 2 * s - 1) / (2 * s);
+    hipLaunchKernelGGL(k_cr_backward<B>, dim3((n_elim * B + 127) / 128, nrhs), dim3(128), 0, st, cr, s, w, x, stride);
+  }
+  if (s >= 1) {
+    const int S = 2 * s;
+    hipLaunchKernelGGL(k_cr_backward_tree<B>, dim3((cr.nsb + S - 1) / S), dim3(kCrTreeThreads), 0, st, cr, S, w, x, nrhs, stride);
+  }
+}
+
 template <int B>
 __global__ void k_cr_root_solve(CrView cr, const double* __restrict__ w, double* __restrict__ x, size_t stride) {
   const int r = threadIdx.x;
@@ -884,18 +1100,22 @@ __global__ void k_cr_root_solve(CrView cr, const double* __restrict__ w, double*
   x[r] = v;
 }
 
-// first stride handled by the fused single-workgroup kernel: at most kCrTopNodes eliminations
-constexpr int kCrTopNodes = 6;
-static int cr_top_start(int nsb) {
+// first stride handled by the fused single-workgroup kernel: at most kCrTopNodes eliminations at that stride (one
+// per wave) and every tile of the nodes alive there resident in LDS
+constexpr int kCrTopNodes = 16;
+constexpr size_t kCrTopLdsBytes = 144 * 1024;
+static size_t cr_top_lds_bytes(int M, int B, int nrhs) { return sizeof(double) * ((size_t)5 * M * B * B + (size_t)2 * M * B * nrhs); }
+static int cr_top_start(int nsb, int B, int nrhs) {
   int s = 1;
-  while (s < nsb && (nsb - s + 2 * s - 1) / (2 * s) > kCrTopNodes) s *= 2;
+  while (s < nsb && ((nsb - s + 2 * s - 1) / (2 * s) > kCrTopNodes || cr_top_lds_bytes((nsb + s - 1) / s, B, nrhs) > kCrTopLdsBytes)) s *= 2;
   return s;
 }
 
 // x == nullptr: factorise only (w, if given, still receives the forward sweep)
 template <int B>
 static void cr_factor_t(hipStream_t st, const CrView& cr, double* w, double* x, int nrhs, size_t stride) {
-  const int s_top = cr_top_start(cr.nsb);
+  const int nr = (w != nullptr) ? nrhs : 0;
+  const int s_top = cr_top_start(cr.nsb, B, nr);
   if (s_top > 1) {
     const int n_elim = (cr.nsb - 1 + 1) / 2;
     hipLaunchKernelGGL(k_cr_invert<B>, dim3(n_elim), dim3(WAVE), 0, st, cr, 1);
@@ -905,13 +1125,21 @@ static void cr_factor_t(hipStream_t st, const CrView& cr, double* w, double* x, 
     const int invert_next = (2 * s < s_top) ? 1 : 0;    // the fused top kernel inverts its own nodes
     hipLaunchKernelGGL(k_cr_level<B>, dim3(n_surv), dim3(WAVE), 0, st, cr, s, invert_next, w, nrhs, stride);
   }
-  hipLaunchKernelGGL(k_cr_top<B>, dim3(1), dim3(kCrTopThreads), 0, st, cr, s_top, w, x, nrhs, stride);
-  if (x != nullptr) {
-    for (int s = s_top / 2; s >= 1; s /= 2) {
-      const int n_elim = (cr.nsb - s + 2 * s - 1) / (2 * s);
-      hipLaunchKernelGGL(k_cr_backward<B>, dim3((n_elim * B + 127) / 128, nrhs), dim3(128), 0, st, cr, s, w, x, stride);
+  {
+    const int M = (cr.nsb + s_top - 1) / s_top;
+    const size_t lds_bytes = cr_top_lds_bytes(M, B, nr);
+    static bool raised = false;      // more than the default 64 KB of dynamic LDS needs to be asked for once
+    if (!raised) {
+      raised = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cr_top_lds<B>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)kCrTopLdsBytes) == hipSuccess;
+      if (!raised) (void)hipGetLastError();
     }
+    if (lds_bytes <= (raised ? kCrTopLdsBytes : (size_t)64 * 1024))
+      hipLaunchKernelGGL(k_cr_top_lds<B>, dim3(1), dim3(kCrTopThreads), lds_bytes, st, cr, s_top, M, w, x, nr, stride);
+    else
+      hipLaunchKernelGGL(k_cr_top<B>, dim3(1), dim3(kCrTopThreads), 0, st, cr, s_top, w, x, nrhs, stride);
   }
+  if (x != nullptr && s_top >= 2) cr_backward_levels<B>(st, cr, s_top / 2, w, x, nrhs, stride);
 }
 
 // back substitution only, any number of right-hand sides (after cr_fwd_t)
@@ -920,10 +1148,7 @@ static void cr_back_t(hipStream_t st, const CrView& cr, const double* w, double*
   int s_last = 0;
   for (int s = 1; s < cr.nsb; s *= 2) s_last = s;
   hipLaunchKernelGGL(k_cr_root_solve<B>, dim3(nrhs), dim3(WAVE), 0, st, cr, w, x, stride);
-  for (int s = s_last; s >= 1; s /= 2) {
-    const int n_elim = (cr.nsb - s + 2 * s - 1) / (2 * s);
-    hipLaunchKernelGGL(k_cr_backward<B>, dim3((n_elim * B + 127) / 128, nrhs), dim3(128), 0, st, cr, s, w, x, stride);
-  }
+  if (s_last >= 1) cr_backward_levels<B>(st, cr, s_last, w, x, nrhs, stride);
 }
 
 template <int B>

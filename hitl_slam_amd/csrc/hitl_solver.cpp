@@ -89,6 +89,9 @@ struct hitl_solver {
   DevArray<uint32_t> matches;
   // derived
   int band_pairs_Wb = 1;                       // Wb implied by the pair set
+  DevArray<double> pairM;                      // opt-in (stf_moments): 2 x 15 moments per pair
+  int64_t moments_of = -1;                     // correspondence-set generation the moments belong to
+  int64_t corr_generation = 0;                 // bumped whenever the pair tables change
   int n_offband = 0;
   DevArray<int> inc_off, inc_ent, band_pair, ob_lo, ob_hi, ob_fwd, ob_rev, obadj_off, obadj_ent;
 
@@ -143,6 +146,7 @@ int solver_ctx(hitl_solver* s, SolverCtx* out) {
 // derived pair structures (host, O(P)); called whenever the correspondence set changes
 // ---------------------------------------------------------------------------------------
 static int build_pair_structures(hitl_solver* s) {
+  ++s->corr_generation;
   const int n = s->n, P = s->n_pairs;
   int maxd = 1;
   for (int p = 0; p < P; ++p) maxd = std::max(maxd, std::abs(s->h_pair_src[p] - s->h_pair_tgt[p]));
@@ -352,8 +356,12 @@ static int enqueue_linearize(hitl_solver* s, const FactorView& fv, const double*
   const LinView lv = s->lin_view(buf);
   if (fv.with_stf) launch_pose_trig(st, s->n, xdev, s->pose_cs.p);
   HIP_TRY(hipEventRecord(s->ev0, st));   // ev0..ev1 brackets exactly the k_linearize_stf launch
-  if (fv.with_stf)
-    launch_linearize_stf(st, mv, pv, s->max_scan, xdev, s->pose_cs.p, s->opt.point_correlation_factor, s->opt.laser_std_dev, lv.pairRJ);
+  if (fv.with_stf) {
+    if (s->opt.stf_moments)
+      launch_linearize_stf_moments(st, pv, s->pairM.p, xdev, s->pose_cs.p, s->opt.point_correlation_factor, s->opt.laser_std_dev, lv.pairRJ);
+    else
+      launch_linearize_stf(st, mv, pv, s->max_scan, xdev, s->pose_cs.p, s->opt.point_correlation_factor, s->opt.laser_std_dev, lv.pairRJ);
+  }
   HIP_TRY(hipEventRecord(s->ev1, st));
   launch_assemble(st, mv, pv, fv, xdev, lv);
   HIP_TRY(hipGetLastError());
@@ -464,6 +472,13 @@ static int prepare(hitl_solver* s, int mode, const float* poses_ref, const float
     // mode A reads no pair table: a 1-pose band; the pair-derived band_pair table is unused
   }
   TRY(ensure_work(s, Wb));
+  if (s->opt.stf_moments && mode != HITL_MODE_ODOM_HC && s->moments_of != s->corr_generation) {
+    // once per correspondence set: the point data enter the scan-to-scan factors only through these sums
+    TRY(s->pairM.resize((size_t)std::max(s->n_pairs, 1) * kPairMomStride));
+    launch_stf_moments(s->stream, s->map_view(), s->pair_view(), s->pairM.p);
+    HIP_TRY(hipGetLastError());
+    s->moments_of = s->corr_generation;
+  }
   TRY(setup_factors(s, poses_ref, poses_global, mode != HITL_MODE_STF_ONLY));
   if (s->world > 1) {
     // interface width = how deep (in poses) any factor reaches across a cut, maximised over all

@@ -108,7 +108,12 @@ typedef struct hitl_options {
   int32_t rank;
   int32_t world_size;
   const void* rccl_unique_id;             /* 128-byte ncclUniqueId from hitl_comm_unique_id, same on all ranks */
-  int64_t reserved[4];
+  /* 0 (default): every linearisation streams all point matches, as the reference's functor does
+   * (residual_functors.h:786-830).  1: the scan-to-scan factors are evaluated from 2 x 15 moments per pose pair that
+   * are summed once per correspondence set -- the same algebra (sum e^2 = k^2 z^T M z), a different summation order
+   * (agreement ~1e-10 relative), and a linearisation cost that no longer depends on the number of matches. */
+  int64_t stf_moments;
+  int64_t reserved[3];
 } hitl_options;
 
 /* Per-solve report (what Ceres' Solver::Summary gives the caller at
