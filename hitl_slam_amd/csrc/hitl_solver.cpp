@@ -14,6 +14,7 @@
 #include <cstring>
 #include <map>
 #include <numeric>
+#include <thread>
 
 #include <rccl/rccl.h>
 
@@ -890,10 +891,11 @@ static int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float
 // ---------------------------------------------------------------------------------------
 // correspondence search driver
 // ---------------------------------------------------------------------------------------
-static void make_rel_tf(const float* pi, const float* pj, float* t) {
+static void make_rel_tf(const float* pi, const float* pj, const float* csi, const float* csj, float* t) {
   // RelativePoseTransform (JointOptimization.cpp:296-305) and the normal rotation at :603-605
   // in fp32; R_j^T stands in for Eigen's general 2x2 inverse (fp32-rounding-level deviation).
-  const float ci = cosf(pi[2]), si = sinf(pi[2]), cj = cosf(pj[2]), sj = sinf(pj[2]);
+  // cs = (cosf, sinf) of each pose angle, computed once per pose by the caller.
+  const float ci = csi[0], si = csi[1], cj = csj[0], sj = csj[1];
   t[0] = cj * ci + sj * si; t[1] = sj * ci - cj * si;
   t[2] = cj * si - sj * ci; t[3] = sj * si + cj * ci;
   const float dx = pi[0] - pj[0], dy = pi[1] - pj[1];
@@ -904,6 +906,14 @@ static void make_rel_tf(const float* pi, const float* pj, float* t) {
 
 static int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
   HIP_TRY(hipSetDevice(s->device));
+  const bool timing = std::getenv("HITL_TIMING") != nullptr;
+  auto t_prev = std::chrono::steady_clock::now();
+  auto mark = [&](const char* what) {
+    if (!timing) return;
+    const auto t = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "find_correspondences: %-22s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+    t_prev = t;
+  };
   const int n = s->n;
   if (window <= 0 || window > n) window = n;
   const int slots = (int)std::min<int64_t>(2 * window, std::max(n - 1, 1));
@@ -912,16 +922,31 @@ static int find_correspondences(hitl_solver* s, const float* poses, int64_t wind
     return fail(HITL_ERR_OUT_OF_MEMORY, "candidate table would exceed 64 GiB; use a smaller window");
   std::vector<int> cand_tgt((size_t)n * slots, -1);
   std::vector<float> cand_tf((size_t)n * slots * 8, 0.f);
-  for (int i = 0; i < n; ++i) {
-    int slot = 0;
-    const int j0 = (int)std::max<int64_t>(0, i - window), j1 = (int)std::min<int64_t>(n - 1, i + window);
-    for (int j = j0; j <= j1; ++j) {
-      if (j == i) continue;
-      cand_tgt[(size_t)i * slots + slot] = j;
-      make_rel_tf(poses + 3 * i, poses + 3 * j, &cand_tf[((size_t)i * slots + slot) * 8]);
-      ++slot;
-    }
+  std::vector<float> cs((size_t)2 * n);
+  {
+    // candidate transforms: fp32 host libm (bit-identical to the CPU restatement), spread over a few threads
+    const int nt = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    auto run = [&](auto&& body) {
+      std::vector<std::thread> th;
+      for (int t = 1; t < nt; ++t) th.emplace_back([&, t]() { body((int64_t)n * t / nt, (int64_t)n * (t + 1) / nt); });
+      body(0, (int64_t)n / nt);
+      for (auto& x : th) x.join();
+    };
+    run([&](int64_t a, int64_t b) { for (int64_t i = a; i < b; ++i) { cs[2 * i] = cosf(poses[3 * i + 2]); cs[2 * i + 1] = sinf(poses[3 * i + 2]); } });
+    run([&](int64_t a, int64_t b) {
+      for (int64_t i = a; i < b; ++i) {
+        int slot = 0;
+        const int64_t j0 = std::max<int64_t>(0, i - window), j1 = std::min<int64_t>(n - 1, i + window);
+        for (int64_t j = j0; j <= j1; ++j) {
+          if (j == i) continue;
+          cand_tgt[(size_t)i * slots + slot] = (int)j;
+          make_rel_tf(poses + 3 * i, poses + 3 * j, &cs[2 * i], &cs[2 * j], &cand_tf[((size_t)i * slots + slot) * 8]);
+          ++slot;
+        }
+      }
+    });
   }
+  mark("candidate transforms");
   hipStream_t st = s->stream;
   DevArray<int> d_tgt, d_counts, d_kept;
   DevArray<float> d_tf;
@@ -934,6 +959,7 @@ static int find_correspondences(hitl_solver* s, const float* poses, int64_t wind
   TRYC(d_counts.resize((size_t)n * slots));
   TRYC(d_counts.zero(st));
   TRYC(d_table.resize(table_entries));
+  mark("uploads + table alloc");
   MatchParams mp;
   mp.thr = s->opt.point_match_threshold;
   mp.min_cos = cosf(s->opt.max_stf_angle_error);   // JointOptimization.cpp:564
@@ -947,6 +973,7 @@ static int find_correspondences(hitl_solver* s, const float* poses, int64_t wind
     cleanup();
     return fail(HITL_ERR_HIP, std::string("match kernel: ") + hipGetErrorString(hipGetLastError()));
   }
+  mark("k_match + counts");
   // keep pairs with more than kMinInterPoseCorrespondence matches (:632-634), pose order (:636-641)
   std::vector<int> kept;
   s->h_pair_src.clear(); s->h_pair_tgt.clear(); s->h_match_off.assign(1, 0);
@@ -961,6 +988,7 @@ static int find_correspondences(hitl_solver* s, const float* poses, int64_t wind
         s->h_match_off.push_back(s->h_match_off.back() + counts[c]);
       }
     }
+  mark("pair filter");
   s->n_pairs = (int)kept.size();
   s->n_matches = s->h_match_off.back();
   s->h_perm.resize(s->n_pairs);
@@ -972,9 +1000,13 @@ static int find_correspondences(hitl_solver* s, const float* poses, int64_t wind
   TRYC(s->matches.resize((size_t)s->n_matches));
   launch_compact(st, mv, s->max_scan, slots, s->n_pairs, d_kept.p, s->match_off.p, d_table.p, s->matches.p);
   if (hipStreamSynchronize(st) != hipSuccess) { cleanup(); return fail(HITL_ERR_HIP, "compact kernel failed"); }
+  mark("uploads + k_compact");
   cleanup();
+  mark("free");
 #undef TRYC
-  return build_pair_structures(s);
+  rc = build_pair_structures(s);
+  mark("pair structures");
+  return rc;
 }
 
 }  // namespace hitl
