@@ -647,7 +647,7 @@ static int enqueue_linear_solve_banded(hitl_solver* s, const FactorView& fv, int
 //     y_g + ZF_g (C~_lo,g v_{g-1}) + ZL_g (C~_up,g u_{g+1}) = z0_g ,   y_g = (u_g, v_g).
 // The coupling is eliminated exactly; no Schwarz / extra PCG iterations.
 static int linear_solve_and_step_dist(hitl_solver* s, const FactorView& fv, int buf, double mu, const double* xcur,
-                                      double* xcand, int* iters, bool* ok, StepScalars* ss) {
+                                      double* xcand, int* iters, bool* ok, StepScalars* ss, LinResult* spec) {
   hipStream_t st = s->stream;
   const LinView lv = s->lin_view(buf);
   const CrView cr = s->cr_view();
@@ -747,16 +747,27 @@ static int linear_solve_and_step_dist(hitl_solver* s, const FactorView& fv, int 
   launch_spmv_step(st, n, npad, fv, lv, s->scale.p, s->dt.p, s->rhs.p, xcur, s->qv.p, xcand, s->step_partials.p);
   launch_halo_candidate(st, nh, s->halo_idx.p, xcur, s->scale.p, s->dt.p, xcand);
   HIP_TRY(hipGetLastError());
+  // The candidate does not depend on any host decision, so its linearisation is queued right here and its two scalars
+  // ride in the same all-gather as the step scalars (exchanges 3 and 1 merged: 7 doubles per rank).
+  if (spec) TRY(enqueue_linearize(s, fv, xcand, buf ^ 1));
+  TRY(enqueue_step_partials(s));
+  HIP_TRY(hipStreamSynchronize(st));                     // host vectors above stay alive until here
   StepScalars loc;
-  TRY(read_step_partials(s, nullptr, nullptr, &loc));    // synchronises the stream (host vectors above stay alive until here)
-  double r2[5] = {loc.dt_rhs, loc.dt_q, loc.step2, loc.xn2, loc.bad};
-  std::vector<double> all2((size_t)5 * W);
+  TRY(finish_step_partials(s, nullptr, nullptr, &loc));
+  LinResult lloc = {0.0, 0.0, 0.f};
+  if (spec) TRY(finish_linearize(s, fv, &lloc));
+  double r2[7] = {loc.dt_rhs, loc.dt_q, loc.step2, loc.xn2, loc.bad, lloc.cost, lloc.gmax};
+  std::vector<double> all2((size_t)7 * W);
   TRY(comm_allgather(s, r2, all2.data(), sizeof(r2)));
   ss->dt_rhs = ss->dt_q = ss->step2 = ss->xn2 = ss->bad = 0.0;
-  for (int g = 0; g < W; ++g) {
-    ss->dt_rhs += all2[(size_t)5 * g]; ss->dt_q += all2[(size_t)5 * g + 1]; ss->step2 += all2[(size_t)5 * g + 2];
-    ss->xn2 += all2[(size_t)5 * g + 3]; ss->bad += all2[(size_t)5 * g + 4];
+  double cost = 0.0, gmax = 0.0;
+  for (int g = 0; g < W; ++g) {          // rank order on every rank: identical sums everywhere
+    ss->dt_rhs += all2[(size_t)7 * g]; ss->dt_q += all2[(size_t)7 * g + 1]; ss->step2 += all2[(size_t)7 * g + 2];
+    ss->xn2 += all2[(size_t)7 * g + 3]; ss->bad += all2[(size_t)7 * g + 4];
+    cost += all2[(size_t)7 * g + 5];
+    gmax = nan_max(gmax, all2[(size_t)7 * g + 6]);
   }
+  if (spec) { spec->cost = cost; spec->gmax = gmax; spec->stf_ms = lloc.stf_ms; }
   return HITL_OK;
 }
 
@@ -816,6 +827,8 @@ static int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float
     HIP_TRY(hipEventRecord(s->ev2, st));
     StepScalars ss;
     const bool fused = (s->world == 1 && fv.n_offband == 0);   // one host synchronisation per LM iteration
+    LinResult lr_spec = {0.0, 0.0, 0.f};
+    bool have_spec = false;
     if (fused) {
       TRY(enqueue_linear_solve_banded(s, fv, cur, radius, xcur, xcand));
       HIP_TRY(hipEventRecord(s->ev3, st));
@@ -827,7 +840,7 @@ static int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float
       if (!(rr == rr) || rr > guard * guard * bb) ok = false;   // the factorisation broke down
       lin_iters = 1;
     } else {
-      if (s->world > 1) TRY(linear_solve_and_step_dist(s, fv, cur, radius, xcur, xcand, &lin_iters, &ok, &ss));
+      if (s->world > 1) { TRY(linear_solve_and_step_dist(s, fv, cur, radius, xcur, xcand, &lin_iters, &ok, &ss, &lr_spec)); have_spec = true; }
       else TRY(linear_solve_and_step(s, fv, cur, radius, xcur, xcand, &lin_iters, &ok, &ss));
       HIP_TRY(hipEventRecord(s->ev3, st));
       HIP_TRY(hipEventSynchronize(s->ev3));
@@ -849,6 +862,7 @@ static int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float
     }
     invalid_run = 0;
     if (fused) TRY(finish_linearize(s, fv, &lr));
+    else if (have_spec) lr = lr_spec;
     else TRY(run_linearize_dist(s, fv, xcand, cur ^ 1, &lr));
     S.linearize_ms += lr.stf_ms; S.linearize_calls++;
     if (std::sqrt(step2) <= o.parameter_tolerance * (std::sqrt(xn2) + o.parameter_tolerance)) { term = HITL_CONVERGENCE; break; }
