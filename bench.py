@@ -62,6 +62,8 @@ def main():
     ap.add_argument("--obs", type=int, default=0, help="override observations per pose")
     ap.add_argument("--cpu-sample-poses", type=int, default=6000, help="poses in the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--timing-level", type=int, default=1, help="hitl_options.timing_level: 1 = every 4th stf launch bracketed by "
+                    "HIP events (default), 2 = all launches + linear-solver timing")
     ap.add_argument("--comm", default="rccl", choices=["rccl", "torch"], help="N>1 exchange: in-library RCCL or torch.distributed")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo lets several ranks share one GPU (debugging on a 1-GPU box)")
@@ -116,6 +118,7 @@ def main():
 
     opt = H.default_options()
     opt.device = dev_index
+    opt.timing_level = args.timing_level
     comm_kind = "none"
     keep = []
     if use_dist:
@@ -188,12 +191,14 @@ def main():
     iters = 0
     stf_ms = 0.0
     stf_calls = 0
+    stf_launches = 0
     lin_solver_ms = 0.0
     for _ in range(args.steps):
         out, summ = solver.solve(H.MODE_JOINT, pose_arg)
         iters += summ.iterations
         stf_ms += summ.linearize_ms
-        stf_calls += summ.linearize_calls
+        stf_calls += summ.linearize_timed_calls
+        stf_launches += summ.linearize_calls
         lin_solver_ms += summ.linear_solver_ms
     torch.cuda.synchronize()
     if use_dist:
@@ -260,7 +265,7 @@ def main():
         "max_xy_error_vs_ground_truth_m": err_gt,
         "roofline": {"bound": "hbm", "kernel": "k_linearize_stf", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_stf_ms, "launches": stf_calls,
+                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_stf_ms, "launches": stf_launches, "launches_bracketed_by_hip_events": stf_calls,
                      "compulsory_bytes_this_layout": 16 * n_obs + 4 * int(n_matches_l) + 24 * n_local + 112 * int(n_pairs_l)},
         "synth_gen_s": gen_s,
     }
@@ -316,7 +321,7 @@ def main():
             result["stf_moments_mode"] = {
                 "resolve_ms": ms2, "lm_iterations_per_resolve": int(summ2.iterations), "final_cost": summ2.final_cost,
                 "max_pose_difference_vs_streaming": float(np.abs(d).max()),
-                "linearize_stf_ms_per_launch": summ2.linearize_ms / max(summ2.linearize_calls, 1),
+                "linearize_stf_ms_per_launch": summ2.linearize_ms / max(summ2.linearize_timed_calls, 1),
                 "note": "hitl_options.stf_moments=1: scan-to-scan factors from 2x15 moments per pose pair summed once per "
                         "correspondence set; same algebra, per-iteration cost independent of the number of matches"}
             s2.close()

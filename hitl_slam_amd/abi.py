@@ -88,7 +88,8 @@ class Options(C.Structure):
         ("world_size", C.c_int32),
         ("rccl_unique_id", C.c_void_p),
         ("stf_moments", C.c_int64),
-        ("reserved", C.c_int64 * 3),
+        ("timing_level", C.c_int64),
+        ("reserved", C.c_int64 * 2),
     ]
 
 
@@ -113,7 +114,7 @@ class Summary(C.Structure):
         ("linearize_ms", C.c_double),
         ("linear_solver_ms", C.c_double),
         ("linearize_calls", C.c_int32),
-        ("reserved_i", C.c_int32),
+        ("linearize_timed_calls", C.c_int32),
         ("reserved", C.c_double * 6),
     ]
 
@@ -157,6 +158,7 @@ def default_options():
     o.max_band_poses = 4
     o.rank = 0
     o.world_size = 1
+    o.timing_level = 1
     o.rccl_unique_id = None
     return o
 

@@ -42,7 +42,9 @@ struct hitl_solver {
   hitl_options opt;
   int device = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr, ev_sync = nullptr;
+  int64_t lin_launches = 0;     // linearisations queued so far (every 4th is bracketed by events at timing_level 1)
+  bool lin_timed = false;       // the linearisation in flight is bracketed
   double* h_scalars = nullptr;  // pinned, kNumScalars
   double* h_partials = nullptr; // pinned, h_partials_cap doubles
   size_t h_partials_cap = 0;
@@ -345,7 +347,7 @@ static FactorView factor_view(hitl_solver* s, int mode, int Wb) {
   return f;
 }
 
-struct LinResult { double cost, gmax; float stf_ms; };
+struct LinResult { double cost, gmax; float stf_ms; int timed; };
 
 // one pass over every factor at state xdev: residuals, Jacobians, J^T J blocks, gradient, cost.
 // enqueue_linearize only queues the kernels and the copy of the per-workgroup partials (behind the step partials in
@@ -356,14 +358,19 @@ static int enqueue_linearize(hitl_solver* s, const FactorView& fv, const double*
   const PairView pv = s->pair_view();
   const LinView lv = s->lin_view(buf);
   if (fv.with_stf) launch_pose_trig(st, s->n, xdev, s->pose_cs.p);
-  HIP_TRY(hipEventRecord(s->ev0, st));   // ev0..ev1 brackets exactly the k_linearize_stf launch
+  // ev0..ev1 brackets exactly the k_linearize_stf launch.  An event record drains the queue (~6 us each), so at the
+  // default timing level only every 4th linearisation is bracketed; level 2 brackets all, level 0 none.
+  const int64_t tl = s->opt.timing_level;
+  s->lin_timed = fv.with_stf && (tl >= 2 || (tl == 1 && (s->lin_launches & 3) == 0));
+  ++s->lin_launches;
+  if (s->lin_timed) HIP_TRY(hipEventRecord(s->ev0, st));
   if (fv.with_stf) {
     if (s->opt.stf_moments)
       launch_linearize_stf_moments(st, pv, s->pairM.p, xdev, s->pose_cs.p, s->opt.point_correlation_factor, s->opt.laser_std_dev, lv.pairRJ);
     else
       launch_linearize_stf(st, mv, pv, s->max_scan, xdev, s->pose_cs.p, s->opt.point_correlation_factor, s->opt.laser_std_dev, lv.pairRJ);
   }
-  HIP_TRY(hipEventRecord(s->ev1, st));
+  if (s->lin_timed) HIP_TRY(hipEventRecord(s->ev1, st));
   launch_assemble(st, mv, pv, fv, xdev, lv);
   HIP_TRY(hipGetLastError());
   const int nblk = assemble_blocks(s->n);
@@ -384,8 +391,19 @@ static int finish_linearize(hitl_solver* s, const FactorView& fv, LinResult* out
   out->cost = cost;
   out->gmax = gmax;
   out->stf_ms = 0.f;
-  if (fv.with_stf) HIP_TRY(hipEventElapsedTime(&out->stf_ms, s->ev0, s->ev1));
+  out->timed = s->lin_timed ? 1 : 0;
+  if (s->lin_timed) HIP_TRY(hipEventElapsedTime(&out->stf_ms, s->ev0, s->ev1));
   return HITL_OK;
+}
+
+// wait for the stream without sleeping on an interrupt: the LM loop turns around in tens of microseconds
+static int spin_sync(hitl_solver* s) {
+  HIP_TRY(hipEventRecord(s->ev_sync, s->stream));
+  for (;;) {
+    const hipError_t e = hipEventQuery(s->ev_sync);
+    if (e == hipSuccess) return HITL_OK;
+    if (e != hipErrorNotReady) return fail(HITL_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(e));
+  }
 }
 
 static int run_linearize(hitl_solver* s, const FactorView& fv, const double* xdev, int buf, LinResult* out) {
@@ -633,7 +651,7 @@ static int enqueue_linear_solve_banded(hitl_solver* s, const FactorView& fv, int
   launch_spmv_residual(st, s->n, npad, fv, lv, s->scale.p, mu, mind, maxd, s->dt.p, s->rhs.p, s->rv.p, s->step_partials.p);
   launch_spmv_step(st, s->n, npad, fv, lv, s->scale.p, s->dt.p, s->rhs.p, xcur, s->qv.p, xcand, s->step_partials.p);
   HIP_TRY(hipGetLastError());
-  return enqueue_step_partials(s);
+  return HITL_OK;
 }
 
 // Submap version.  Rank g's unknowns x_g (owned poses) satisfy
@@ -754,7 +772,7 @@ static int linear_solve_and_step_dist(hitl_solver* s, const FactorView& fv, int 
   HIP_TRY(hipStreamSynchronize(st));                     // host vectors above stay alive until here
   StepScalars loc;
   TRY(finish_step_partials(s, nullptr, nullptr, &loc));
-  LinResult lloc = {0.0, 0.0, 0.f};
+  LinResult lloc = {0.0, 0.0, 0.f, 0};
   if (spec) TRY(finish_linearize(s, fv, &lloc));
   double r2[7] = {loc.dt_rhs, loc.dt_q, loc.step2, loc.xn2, loc.bad, lloc.cost, lloc.gmax};
   std::vector<double> all2((size_t)7 * W);
@@ -767,7 +785,7 @@ static int linear_solve_and_step_dist(hitl_solver* s, const FactorView& fv, int 
     cost += all2[(size_t)7 * g + 5];
     gmax = nan_max(gmax, all2[(size_t)7 * g + 6]);
   }
-  if (spec) { spec->cost = cost; spec->gmax = gmax; spec->stf_ms = lloc.stf_ms; }
+  if (spec) { spec->cost = cost; spec->gmax = gmax; spec->stf_ms = lloc.stf_ms; spec->timed = lloc.timed; }
   return HITL_OK;
 }
 
@@ -801,7 +819,7 @@ static int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float
   int cur = 0;
   LinResult lr;
   TRY(run_linearize_dist(s, fv, xcur, cur, &lr));
-  S.linearize_ms += lr.stf_ms; S.linearize_calls++;
+  S.linearize_ms += lr.stf_ms; S.linearize_calls++; S.linearize_timed_calls += lr.timed;
   double cost = lr.cost, gmax = lr.gmax;
   S.initial_cost = cost;
   S.num_pairs = fv.with_stf ? s->n_pairs_owned : 0;
@@ -824,16 +842,18 @@ static int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float
     ++iter;
     int lin_iters = 0;
     bool ok = true;
-    HIP_TRY(hipEventRecord(s->ev2, st));
+    const bool time_solver = o.timing_level >= 2;
+    if (time_solver) HIP_TRY(hipEventRecord(s->ev2, st));
     StepScalars ss;
     const bool fused = (s->world == 1 && fv.n_offband == 0);   // one host synchronisation per LM iteration
-    LinResult lr_spec = {0.0, 0.0, 0.f};
+    LinResult lr_spec = {0.0, 0.0, 0.f, 0};
     bool have_spec = false;
     if (fused) {
       TRY(enqueue_linear_solve_banded(s, fv, cur, radius, xcur, xcand));
-      HIP_TRY(hipEventRecord(s->ev3, st));
+      if (time_solver) HIP_TRY(hipEventRecord(s->ev3, st));
       TRY(enqueue_linearize(s, fv, xcand, cur ^ 1));
-      HIP_TRY(hipStreamSynchronize(st));
+      TRY(enqueue_step_partials(s));            // both copies at the tail: no copy-engine hand-over in mid-stream
+      TRY(spin_sync(s));
       double rr, bb;
       TRY(finish_step_partials(s, &rr, &bb, &ss));
       const double guard = std::max(std::max(o.linear_solver_tolerance, 1e-15), 1e-9);
@@ -842,11 +862,10 @@ static int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float
     } else {
       if (s->world > 1) { TRY(linear_solve_and_step_dist(s, fv, cur, radius, xcur, xcand, &lin_iters, &ok, &ss, &lr_spec)); have_spec = true; }
       else TRY(linear_solve_and_step(s, fv, cur, radius, xcur, xcand, &lin_iters, &ok, &ss));
-      HIP_TRY(hipEventRecord(s->ev3, st));
-      HIP_TRY(hipEventSynchronize(s->ev3));
+      if (time_solver) { HIP_TRY(hipEventRecord(s->ev3, st)); HIP_TRY(hipEventSynchronize(s->ev3)); }
     }
     S.linear_iterations += lin_iters;
-    {
+    if (time_solver) {
       float ms = 0.f;
       HIP_TRY(hipEventElapsedTime(&ms, s->ev2, s->ev3));
       S.linear_solver_ms += ms;
@@ -864,7 +883,7 @@ static int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float
     if (fused) TRY(finish_linearize(s, fv, &lr));
     else if (have_spec) lr = lr_spec;
     else TRY(run_linearize_dist(s, fv, xcand, cur ^ 1, &lr));
-    S.linearize_ms += lr.stf_ms; S.linearize_calls++;
+    S.linearize_ms += lr.stf_ms; S.linearize_calls++; S.linearize_timed_calls += lr.timed;
     if (std::sqrt(step2) <= o.parameter_tolerance * (std::sqrt(xn2) + o.parameter_tolerance)) { term = HITL_CONVERGENCE; break; }
     const double cost_change = cost - lr.cost;
     if (std::fabs(cost_change) <= o.function_tolerance * cost) { term = HITL_CONVERGENCE; break; }
@@ -1061,6 +1080,7 @@ void hitl_options_default(hitl_options* o) {
   o->max_band_poses = 4;
   o->rank = 0;
   o->world_size = 1;
+  o->timing_level = 1;
   o->rccl_unique_id = nullptr;
 }
 
@@ -1101,7 +1121,7 @@ int hitl_solver_create(const hitl_options* opt, hitl_solver** out) {
   s->device = o.device;
   auto bail = [&](int code, const std::string& m) { hitl_solver_destroy(s); return fail(code, m); };
   if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) return bail(HITL_ERR_HIP, "hipStreamCreate failed");
-  for (hipEvent_t* e : {&s->ev0, &s->ev1, &s->ev2, &s->ev3})
+  for (hipEvent_t* e : {&s->ev0, &s->ev1, &s->ev2, &s->ev3, &s->ev_sync})
     if (hipEventCreate(e) != hipSuccess) return bail(HITL_ERR_HIP, "hipEventCreate failed");
   if (hipHostMalloc((void**)&s->h_scalars, sizeof(double) * kNumScalars) != hipSuccess) return bail(HITL_ERR_HIP, "hipHostMalloc failed");
   if (s->d_scalars.resize(kNumScalars) != HITL_OK) return bail(HITL_ERR_OUT_OF_MEMORY, "hipMalloc failed");
@@ -1138,7 +1158,7 @@ void hitl_solver_destroy(hitl_solver* s) {
   s->comm_send.release(); s->comm_recv.release(); s->fixed.release(); s->if_cols.release(); s->halo_idx.release();
   s->iface_dev.release(); s->rhsN.release(); s->zN.release(); s->coef_dev.release(); s->halo_val.release(); s->halo_sc.release();
   if (s->h_scalars) (void)hipHostFree(s->h_scalars);
-  for (hipEvent_t e : {s->ev0, s->ev1, s->ev2, s->ev3}) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : {s->ev0, s->ev1, s->ev2, s->ev3, s->ev_sync}) if (e) (void)hipEventDestroy(e);
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
 }

@@ -113,7 +113,11 @@ typedef struct hitl_options {
    * are summed once per correspondence set -- the same algebra (sum e^2 = k^2 z^T M z), a different summation order
    * (agreement ~1e-10 relative), and a linearisation cost that no longer depends on the number of matches. */
   int64_t stf_moments;
-  int64_t reserved[3];
+  /* device timings in hitl_summary.  An event record drains the queue (~6 us each on this stack), so: 0 = none;
+   * 1 (default) = every 4th k_linearize_stf launch is bracketed (linearize_ms over linearize_timed_calls launches),
+   * no linear-solver timing; 2 = every launch bracketed and linear_solver_ms filled. */
+  int64_t timing_level;
+  int64_t reserved[2];
 } hitl_options;
 
 /* Per-solve report (what Ceres' Solver::Summary gives the caller at
@@ -135,10 +139,10 @@ typedef struct hitl_summary {
   double final_gradient_max_norm;
   double final_trust_region_radius;
   double total_ms;              /* wall clock of hitl_solver_solve                      */
-  double linearize_ms;          /* sum of device time in linearize passes               */
+  double linearize_ms;          /* device time of the linearize_timed_calls bracketed k_linearize_stf launches */
   double linear_solver_ms;
   int32_t linearize_calls;
-  int32_t reserved_i;
+  int32_t linearize_timed_calls; /* how many of them were bracketed by events (hitl_options.timing_level) */
   double reserved[6];
 } hitl_summary;
 

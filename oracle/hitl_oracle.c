@@ -64,6 +64,7 @@ static void orc_options_default(hitl_options* o) {
   o->max_band_poses = 4;
   o->rank = 0;
   o->world_size = 1;
+  o->timing_level = 1;
 }
 
 double orc_angle_mod(double a) { /* shared/math/util.h:433-439 */
