@@ -90,7 +90,7 @@ void launch_jacobi_scale(hipStream_t st, int n_poses, int npad, int Wb, const do
                          const unsigned char* fixed, double* scale);
 void launch_build_system(hipStream_t st, int n_poses, int Wb, const LinView& lin, const double* scale,
                          const unsigned char* fixed, double mu, double min_diag, double max_diag, const CrView& cr,
-                         double* rhs);
+                         double* rhs, double* rhs_work = nullptr);
 void launch_cr_factor(hipStream_t st, const CrView& cr);
 void launch_cr_solve_multi(hipStream_t st, const CrView& cr, double* w, double* x, int nrhs, size_t stride);
 void launch_unit_rhs(hipStream_t st, int npad, double* w, size_t stride, const int* cols_dev, int ncols);
@@ -115,6 +115,9 @@ void launch_spmv_residual(hipStream_t st, int n_poses, int npad, const FactorVie
                           const double* scale, double mu, double min_diag, double max_diag, const double* v,
                           const double* rhs, double* r_out, double* partials);
 // q = (S H S) dt ; xc = x + s*dt ; partials[blk*8 + 2..6] = (dt.rhs, dt.q, |s dt|^2, |x|^2, #non-finite)
+void launch_spmv_residual_step(hipStream_t st, int n_poses, int npad, const FactorView& fv, const LinView& lin, const double* scale, double mu,
+                               double min_diag, double max_diag, const double* v, const double* rhs, const double* x, double* q, double* xc,
+                               double* partials);
 void launch_spmv_step(hipStream_t st, int n_poses, int npad, const FactorView& fv, const LinView& lin,
                       const double* scale, const double* dt, const double* rhs, const double* x, double* q, double* xc,
                       double* partials);

@@ -586,7 +586,7 @@ void launch_jacobi_scale(hipStream_t st, int n_poses, int npad, int Wb, const do
 // one thread per (super-block k, row a, column b): coalesced stores of D and L
 __global__ void k_build_system(int n_poses, int Wb, const double* __restrict__ Hband, const double* __restrict__ g,
                                const double* __restrict__ scale, const unsigned char* __restrict__ fixed, double mu,
-                               double min_diag, double max_diag, CrView cr, double* __restrict__ rhs) {
+                               double min_diag, double max_diag, CrView cr, double* __restrict__ rhs, double* __restrict__ rhs_work) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int B = cr.B, BB = B * B;
   if (t >= cr.nsb * BB) return;
@@ -595,7 +595,7 @@ __global__ void k_build_system(int n_poses, int Wb, const double* __restrict__ H
   if (i >= n_poses || fixed[i]) {     // padding rows and constant poses: identity
     cr.D[t] = (b == a) ? 1.0 : 0.0;
     cr.L[t] = 0.0;
-    if (b == 0) rhs[k * B + a] = 0.0;
+    if (b == 0) { rhs[k * B + a] = 0.0; if (rhs_work) rhs_work[k * B + a] = 0.0; }
     return;
   }
   const int W1 = Wb + 1;
@@ -616,15 +616,19 @@ __global__ void k_build_system(int n_poses, int Wb, const double* __restrict__ H
     if (d <= Wb && !fixed[i3]) l = Hband[((size_t)i3 * W1 + d) * 9 + cb * 3 + ca] * sa * scale[3 * i3 + cb];
   }
   cr.L[t] = l;
-  if (b == 0) rhs[k * B + a] = -sa * g[3 * i + ca];
+  if (b == 0) {
+    const double v = -sa * g[3 * i + ca];
+    rhs[k * B + a] = v;
+    if (rhs_work) rhs_work[k * B + a] = v;      // the copy the factor-solve consumes in place
+  }
 }
 
 void launch_build_system(hipStream_t st, int n_poses, int Wb, const LinView& lin, const double* scale,
                          const unsigned char* fixed, double mu, double min_diag, double max_diag, const CrView& cr,
-                         double* rhs) {
+                         double* rhs, double* rhs_work) {
   const int tot = cr.nsb * cr.B * cr.B;
   hipLaunchKernelGGL(k_build_system, dim3((tot + 255) / 256), dim3(256), 0, st, n_poses, Wb, lin.Hband, lin.g, scale, fixed,
-                     mu, min_diag, max_diag, cr, rhs);
+                     mu, min_diag, max_diag, cr, rhs, rhs_work);
 }
 
 // ===========================================================================================
@@ -1061,13 +1065,42 @@ __global__ void k_cr_backward(CrView cr, int s, const double* __restrict__ w, do
 constexpr int kCrTreeThreads = 256;
 template <int B>
 __global__ __launch_bounds__(kCrTreeThreads) void k_cr_backward_tree(CrView cr, int S, const double* w, double* x, int nrhs, size_t stride) {
+  // x of the interval's S + 1 nodes lives in LDS between the levels (one right-hand side at a time), so a level only
+  // waits for its own tile loads, not for the previous level's stores to come back from L2
+  extern __shared__ double sx[];                       // (S + 1) * B
   const int base = blockIdx.x * S;
-  for (int s = S / 2; s >= 1; s /= 2) {
-    const int per = S / (2 * s);                         // nodes of this stride inside the interval
-    for (int t = threadIdx.x; t < per * B * nrhs; t += kCrTreeThreads) {
-      const int vv = t / (per * B), u = t % (per * B);
-      const int k = base + s * (2 * (u / B) + 1);
-      if (k < cr.nsb) cr_backward_row<B>(cr, s, k, u % B, w + stride * vv, x + stride * vv);
+  for (int vv = 0; vv < nrhs; ++vv) {
+    const double* wv = w + stride * vv;
+    double* xv = x + stride * vv;
+    for (int t = threadIdx.x; t < 2 * B; t += kCrTreeThreads) {            // the two boundary nodes (known)
+      const int node = (t < B) ? base : base + S, r = t % B;
+      sx[(size_t)(node - base) * B + r] = (node < cr.nsb) ? xv[(size_t)node * B + r] : 0.0;
+    }
+    __syncthreads();
+    for (int s = S / 2; s >= 1; s /= 2) {
+      const int per = S / (2 * s);
+      for (int t = threadIdx.x; t < per * B; t += kCrTreeThreads) {
+        const int k = base + s * (2 * (t / B) + 1), r = t % B;
+        if (k < cr.nsb) {
+          const size_t off = (size_t)k * B * B;
+          const double* wk = wv + (size_t)k * B;
+          const double* xl = sx + (size_t)(k - s - base) * B;
+          const double* xr = sx + (size_t)(k + s - base) * B;             // zero-filled beyond the last node
+          double v = 0.0;
+#pragma unroll
+          for (int c = 0; c < B; ++c) {
+            v += cr.Dinv[off + r * B + c] * wk[c];
+            v -= cr.Gl[off + r * B + c] * xl[c];
+            if (k + s < cr.nsb) v -= cr.Gr[off + r * B + c] * xr[c];
+          }
+          sx[(size_t)(k - base) * B + r] = v;
+        }
+      }
+      __syncthreads();
+    }
+    for (int t = threadIdx.x; t < (S - 1) * B; t += kCrTreeThreads) {       // interior nodes go out once
+      const int node = base + 1 + t / B;
+      if (node < cr.nsb) xv[(size_t)node * B + t % B] = sx[(size_t)(node - base) * B + t % B];
     }
     __syncthreads();
   }
@@ -1084,7 +1117,8 @@ static void cr_backward_levels(hipStream_t st, const CrView& cr, int s_from, con
   }
   if (s >= 1) {
     const int S = 2 * s;
-    hipLaunchKernelGGL(k_cr_backward_tree<B>, dim3((cr.nsb + S - 1) / S), dim3(kCrTreeThreads), 0, st, cr, S, w, x, nrhs, stride);
+    hipLaunchKernelGGL(k_cr_backward_tree<B>, dim3((cr.nsb + S - 1) / S), dim3(kCrTreeThreads), sizeof(double) * (S + 1) * B, st, cr, S, w, x, nrhs,
+                       stride);
   }
 }
 
@@ -1314,15 +1348,18 @@ __global__ __launch_bounds__(128) void k_spmv(int n_poses, int npad, FactorView 
                                                double max_diag, const double* __restrict__ v, double* __restrict__ y,
                                                SpmvAux aux) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  double part[5] = {0, 0, 0, 0, 0};
+  // MODE 3 = MODE 1 and MODE 2 in one pass (banded single-GPU solve: v is exactly 0 on constant poses, so including
+  // their columns changes nothing): residual partials in slots 0,1 and the step bookkeeping in slots 2..6
+  constexpr bool kRes = (MODE == 1 || MODE == 3), kStep = (MODE == 2 || MODE == 3);
+  double part[7] = {0, 0, 0, 0, 0, 0, 0};
   if (3 * i < npad) {
     if (i >= n_poses || fv.fixed[i]) {  // padding rows and constant poses: identity rows
       for (int c = 0; c < 3; ++c) {
         const int t = 3 * i + c;
         if (t < npad) {
           if (MODE == 0) y[t] = v[t];
-          if (MODE == 1) { const double r = aux.rhs[t] - v[t]; aux.r_out[t] = r; part[0] += r * r; part[1] += aux.rhs[t] * aux.rhs[t]; }
-          if (MODE == 2) { y[t] = v[t]; if (i < n_poses) aux.xc[t] = aux.x[t]; }
+          if (kRes) { const double r = aux.rhs[t] - v[t]; if (MODE == 1) aux.r_out[t] = r; part[0] += r * r; part[1] += aux.rhs[t] * aux.rhs[t]; }
+          if (kStep) { y[t] = v[t]; if (i < n_poses) aux.xc[t] = aux.x[t]; }
         }
       }
     } else {
@@ -1334,7 +1371,7 @@ __global__ __launch_bounds__(128) void k_spmv(int n_poses, int npad, FactorView 
       const double* Hi = lin.Hband + (size_t)i * W1 * 9;
       for (int d = 0; d <= Wb && i + d < n_poses; ++d) {
         const int j = i + d;
-        if (MODE != 2 && fv.fixed[j]) continue;
+        if (!kStep && fv.fixed[j]) continue;
         const double* blk = Hi + d * 9;
         const double v0 = scale[3 * j] * v[3 * j], v1 = scale[3 * j + 1] * v[3 * j + 1], v2 = scale[3 * j + 2] * v[3 * j + 2];
 #pragma unroll
@@ -1342,7 +1379,7 @@ __global__ __launch_bounds__(128) void k_spmv(int n_poses, int npad, FactorView 
       }
       for (int d = 1; d <= Wb && i - d >= 0; ++d) {
         const int j = i - d;
-        if (MODE != 2 && fv.fixed[j]) continue;
+        if (!kStep && fv.fixed[j]) continue;
         const double* blk = lin.Hband + ((size_t)j * W1 + d) * 9;  // block (j, i), used transposed
         const double v0 = scale[3 * j] * v[3 * j], v1 = scale[3 * j + 1] * v[3 * j + 1], v2 = scale[3 * j + 2] * v[3 * j + 2];
 #pragma unroll
@@ -1354,7 +1391,7 @@ __global__ __launch_bounds__(128) void k_spmv(int n_poses, int npad, FactorView 
           const int en = ent >> 1, tr = ent & 1;
           const double* blk = lin.obblk + (size_t)en * 9;
           const int j = tr ? fv.ob_lo[en] : fv.ob_hi[en];
-          if (MODE != 2 && fv.fixed[j]) continue;
+          if (!kStep && fv.fixed[j]) continue;
           const double v0 = scale[3 * j] * v[3 * j], v1 = scale[3 * j + 1] * v[3 * j + 1], v2 = scale[3 * j + 2] * v[3 * j + 2];
           if (!tr) {
             for (int a = 0; a < 3; ++a) acc[a] += blk[a * 3] * v0 + blk[a * 3 + 1] * v1 + blk[a * 3 + 2] * v2;
@@ -1367,41 +1404,43 @@ __global__ __launch_bounds__(128) void k_spmv(int n_poses, int npad, FactorView 
       for (int a = 0; a < 3; ++a) {
         const int t = 3 * i + a;
         const double sa = scale[t];
-        double r = sa * acc[a];
+        const double rq = sa * acc[a];              // (S H S v)[t]
+        double r = rq;
         if (MODE != 2 && mu > 0.0) {
           const double dg = sa * sa * Hi[a * 3 + a];
           r += fmin(fmax(dg, min_diag), max_diag) / mu * v[t];
         }
         if (MODE == 0) y[t] = r;
-        if (MODE == 1) {
+        if (kRes) {
           const double b = aux.rhs[t], res = b - r;
-          aux.r_out[t] = res;
+          if (MODE == 1) aux.r_out[t] = res;
           part[0] += res * res; part[1] += b * b;
         }
-        if (MODE == 2) {
+        if (kStep) {
+          constexpr int o = (MODE == 3) ? 2 : 0;
           const double vt = v[t];
           const double dl = sa * vt, xt = aux.x[t];
-          y[t] = r;
-          part[0] += vt * aux.rhs[t];
-          part[1] += vt * r;
-          part[2] += dl * dl; part[3] += xt * xt;
+          y[t] = rq;
+          part[o + 0] += vt * aux.rhs[t];
+          part[o + 1] += vt * rq;
+          part[o + 2] += dl * dl; part[o + 3] += xt * xt;
           aux.xc[t] = xt + dl;
-          if (!isfinite(vt)) part[4] += 1.0;
+          if (!isfinite(vt)) part[o + 4] += 1.0;
         }
       }
     }
   }
   if (MODE != 0) {
-    __shared__ double sm[2][5];
+    __shared__ double sm[2][7];
     const int wv = threadIdx.x >> 6;
-    constexpr int NP = (MODE == 1) ? 2 : 5;
+    constexpr int NP = (MODE == 1) ? 2 : (MODE == 2 ? 5 : 7);
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
       const double t = wave_sum(part[k]);
       if ((threadIdx.x & 63) == 0) sm[wv][k] = t;
     }
     __syncthreads();
-    if (threadIdx.x < NP) aux.partials[(size_t)blockIdx.x * 8 + (MODE == 1 ? 0 : 2) + threadIdx.x] = sm[0][threadIdx.x] + sm[1][threadIdx.x];
+    if (threadIdx.x < NP) aux.partials[(size_t)blockIdx.x * 8 + (MODE == 2 ? 2 : 0) + threadIdx.x] = sm[0][threadIdx.x] + sm[1][threadIdx.x];
   }
 }
 
@@ -1420,6 +1459,13 @@ void launch_spmv_residual(hipStream_t st, int n_poses, int npad, const FactorVie
   SpmvAux aux = {rhs, r_out, nullptr, nullptr, partials};
   hipLaunchKernelGGL(k_spmv<1>, dim3(spmv_blocks(npad)), dim3(128), 0, st, n_poses, npad, fv, lin, scale, mu, min_diag,
                      max_diag, v, (double*)nullptr, aux);
+}
+
+void launch_spmv_residual_step(hipStream_t st, int n_poses, int npad, const FactorView& fv, const LinView& lin, const double* scale, double mu,
+                               double min_diag, double max_diag, const double* v, const double* rhs, const double* x, double* q, double* xc,
+                               double* partials) {
+  SpmvAux aux = {rhs, nullptr, x, xc, partials};
+  hipLaunchKernelGGL(k_spmv<3>, dim3(spmv_blocks(npad)), dim3(128), 0, st, n_poses, npad, fv, lin, scale, mu, min_diag, max_diag, v, q, aux);
 }
 
 void launch_spmv_step(hipStream_t st, int n_poses, int npad, const FactorView& fv, const LinView& lin,

@@ -645,11 +645,10 @@ static int enqueue_linear_solve_banded(hitl_solver* s, const FactorView& fv, int
   const CrView cr = s->cr_view();
   const double mind = s->opt.min_lm_diagonal, maxd = s->opt.max_lm_diagonal;
   const int npad = s->npad;
-  launch_build_system(st, s->n, fv.band_poses, lv, s->scale.p, s->fixed.p, mu, mind, maxd, cr, s->rhs.p);
-  launch_copy(st, npad, s->rhs.p, s->wv.p);
+  launch_build_system(st, s->n, fv.band_poses, lv, s->scale.p, s->fixed.p, mu, mind, maxd, cr, s->rhs.p, s->wv.p);
   launch_cr_factor_solve(st, cr, s->wv.p, s->dt.p);
-  launch_spmv_residual(st, s->n, npad, fv, lv, s->scale.p, mu, mind, maxd, s->dt.p, s->rhs.p, s->rv.p, s->step_partials.p);
-  launch_spmv_step(st, s->n, npad, fv, lv, s->scale.p, s->dt.p, s->rhs.p, xcur, s->qv.p, xcand, s->step_partials.p);
+  // residual check of the factorisation and the trust-region bookkeeping in one pass over the band
+  launch_spmv_residual_step(st, s->n, npad, fv, lv, s->scale.p, mu, mind, maxd, s->dt.p, s->rhs.p, xcur, s->qv.p, xcand, s->step_partials.p);
   HIP_TRY(hipGetLastError());
   return HITL_OK;
 }
