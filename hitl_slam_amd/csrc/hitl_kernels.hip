@@ -129,13 +129,29 @@ __global__ __launch_bounds__(kStfBlock, 6) void k_linearize_stf(MapView map, Pai
     //   sum e1 cross(n1', t01-p0)  = cross(A1, t01) - T10
     double S0 = 0, A0x = 0, A0y = 0, T01 = 0;
     double S1 = 0, A1x = 0, A1y = 0, T10 = 0;
+    // the index words of the NEXT trip are requested before this trip's arithmetic, so a trip waits for one memory
+    // round (the gathers) instead of two dependent ones (index, then gather)
+    uint32_t un[kStfUnroll];
+    {
+      const int64_t m0 = m_begin + hl;
+#pragma unroll
+      for (int q = 0; q < kStfUnroll; ++q) {
+        const int64_t mq = m0 + (int64_t)q * kStfSub;
+        un[q] = (mq < m_end) ? mt[mq] : 0u;
+      }
+    }
     for (int64_t m = m_begin + hl; m < m_end; m += kStfSub * kStfUnroll) {
       uint32_t uu[kStfUnroll];
       float4 av[kStfUnroll], tv[kStfUnroll];
 #pragma unroll
-      for (int q = 0; q < kStfUnroll; ++q) {
-        const int64_t mq = m + (int64_t)q * kStfSub;
-        uu[q] = mt[mq < m_end ? mq : m];               // tail lanes re-read a valid entry, weighted 0 below
+      for (int q = 0; q < kStfUnroll; ++q) uu[q] = un[q];   // tail lanes carry index 0 (valid), weighted 0 below
+      {
+        const int64_t mn = m + kStfSub * kStfUnroll;
+#pragma unroll
+        for (int q = 0; q < kStfUnroll; ++q) {
+          const int64_t mq = mn + (int64_t)q * kStfSub;
+          un[q] = (mq < m_end) ? mt[mq] : 0u;
+        }
       }
 #pragma unroll
       for (int q = 0; q < kStfUnroll; ++q) {
