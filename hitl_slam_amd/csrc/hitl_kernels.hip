@@ -80,6 +80,8 @@ __global__ void k_pose_trig(int n, const double* __restrict__ x, double2* __rest
 //  * 2 matches per lane in flight at <= 80 VGPRs (6 waves/SIMD) beats deeper unrolling at lower
 //    occupancy; staging the target scans in LDS too (50 KB/workgroup) or software-pipelining the
 //    gathers by hand were both slower (LDS-limited occupancy / register spills).
+//  * requesting the NEXT trip's index words before this trip's arithmetic (2 VGPRs) took 376 -> 344 us; going one
+//    step further (next trip's gathers in flight too, 8 more VGPRs) spills at the 80-VGPR budget: 539 us.
 //  * VALU and TA are each ~55 % busy: the kernel is balanced between fp64 issue and L1/L2
 //    gather handling, at 2x the HBM floor of its compulsory bytes.
 constexpr int kStfUnroll = 2;
