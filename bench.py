@@ -123,7 +123,7 @@ def main():
     keep = []
     if use_dist:
         # pose-range submaps: rank r owns global poses [begin, end); the cut falls between two floors,
-        # so only the odometry edge straddles it.  Exchange = 3 tiny all-gathers per LM iteration.
+        # so only the odometry edge straddles it.  Exchange = 2 tiny all-gathers per LM iteration.
         opt.rank, opt.world_size = rank, world
         solver = None
         if args.comm == "rccl":
