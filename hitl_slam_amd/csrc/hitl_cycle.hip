@@ -9,8 +9,9 @@
 // so the only way to return the reference's poses bit for bit is to apply the same span-many updates to each pose in
 // the same order.  That is still parallel: every pose is independent once the pivots before it are final.
 // k_backprop_rotate runs it as a chained scan over blocks of kBpBlock poses -- a block first applies the published
-// transforms of all earlier blocks (parallel over its poses), then resolves its own pivots one after the other
-// (one barrier each), publishes them and raises its flag -- so the critical path is span x one small step instead of
+// transforms of all earlier blocks (parallel over its poses), then resolves its own pivots wave by wave (inside a wave
+// the pivot position travels by v_readlane: no LDS round trip, no barrier, no branch per pivot), publishes them with
+// agent-scope atomic stores and raises its flag -- so the critical path is span x one small step (~70 ns) instead of
 // span^2.  All transcendental values (cos/sin of each pivot's share of the rotation) come from the host's libm.
 
 #include "hitl_internal.h"
@@ -98,7 +99,6 @@ __global__ __launch_bounds__(kBpBlock) void k_backprop_rotate(float* __restrict_
                                                               float* __restrict__ trans_out) {
   __shared__ float4 s_xf[kBpBlock], s_out[kBpBlock];
   __shared__ float s_dth[kBpBlock];
-  __shared__ float2 s_piv[2];
   __shared__ int s_ticket;
   if (threadIdx.x == 0) s_ticket = atomicAdd(&sync[0], 1);
   __syncthreads();
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(kBpBlock) void k_backprop_rotate(float* __restrict_
 
   for (int pb = 0; pb < b; ++pb) {            // earlier blocks, in order
     if (threadIdx.x == 0)
-      while (__hip_atomic_load(&sync[1 + pb], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(1);
+      while (__hip_atomic_load(&sync[1 + pb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(1);
     __syncthreads();
     const int pq = pb * kBpBlock + (int)threadIdx.x;    // always < L here
     const float* src = xf + 4 * (size_t)pq;
@@ -132,33 +132,60 @@ __global__ __launch_bounds__(kBpBlock) void k_backprop_rotate(float* __restrict_
   const float4 mine = (q < L) ? piv[q] : make_float4(0.f, 1.f, 0.f, 0.f);
   s_xf[threadIdx.x] = mine;                                // (dth, c, s) of this block's pivots
   __syncthreads();
-  for (int p = 0; p < npiv; ++p) {
-    if ((int)threadIdx.x == p) s_piv[p & 1] = make_float2(x, y);
-    __syncthreads();
-    const float2 P = s_piv[p & 1];
-    const float4 pr = s_xf[p];
-    const float c = pr.y, s = pr.z;
-    // Translation(P) * Rotation(dth) * Translation(-P):  translation = P + R (-P)
-    const float tx = P.x + (c * -P.x + -s * -P.y), ty = P.y + (s * -P.x + c * -P.y);
-    if ((int)threadIdx.x == p) {
-      th += pr.x;
-      s_out[p] = make_float4(c, s, tx, ty);      // published in one coalesced pass below: a global store here would
-                                                 // put its completion latency inside every barrier of this loop
-    } else if ((int)threadIdx.x > p && live) {
-      th += pr.x;
-      const float nx = (c * x + -s * y) + tx, ny = (s * x + c * y) + ty;
-      x = nx; y = ny;
+  // Wave by wave: the 64 pivots of a wave are resolved inside the wave (the pivot position travels by v_readlane, no
+  // LDS round trip and no barrier per pivot); the waves behind it then apply those 64 finished transforms from LDS.
+  {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int wv = 0; wv * 64 < npiv; ++wv) {
+      const int cnt = min(64, npiv - wv * 64);
+      if (wave == wv) {
+        // Branch-free inner step: (tx, ty) is the same number in every lane, lane p keeps it for the block's output,
+        // lanes behind p take the update through selects.  Only the pivot position is on the dependent chain
+        // (two v_readlane); the pivot's (dth, c, s) come from LDS.
+        float keep_tx = 0.f, keep_ty = 0.f;
+        float4 pr_next = s_xf[wv * 64];
+        for (int p = 0; p < cnt; ++p) {
+          const float4 pr = pr_next;
+          pr_next = s_xf[wv * 64 + min(p + 1, 63)];          // next pivot's parameters: off the dependent chain
+          const float dth = pr.x, c = pr.y, s = pr.z;
+          const float Px = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), p));
+          const float Py = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y), p));
+          // Translation(P) * Rotation(dth) * Translation(-P):  translation = P + R (-P)
+          const float tx = Px + (c * -Px + -s * -Py), ty = Py + (s * -Px + c * -Py);
+          const float nx = (c * x + -s * y) + tx, ny = (s * x + c * y) + ty;
+          const bool behind = lane > p;
+          x = behind ? nx : x; y = behind ? ny : y;
+          th = (lane >= p) ? th + dth : th;
+          keep_tx = (lane == p) ? tx : keep_tx; keep_ty = (lane == p) ? ty : keep_ty;
+        }
+        if (lane < cnt) s_out[wv * 64 + lane] = make_float4(mine.y, mine.z, keep_tx, keep_ty);
+      }
+      __syncthreads();
+      if (wave > wv && live) {
+        for (int p = 0; p < cnt; ++p) {
+          const float4 t = s_out[wv * 64 + p];
+          th += s_xf[wv * 64 + p].x;
+          const float nx = (t.x * x + -t.y * y) + t.z, ny = (t.y * x + t.x * y) + t.w;
+          x = nx; y = ny;
+        }
+      }
     }
   }
   __syncthreads();
   if ((int)threadIdx.x < npiv) {
     const float4 t = s_out[threadIdx.x];
+    // Publication without a release fence (an agent-scope fence writes back the whole L2 of this XCD, ~25 us per
+    // block here): the transforms go out as agent-scope atomic stores, which are performed at the device-wide
+    // coherence point, the barrier below waits for their completion (s_waitcnt vmcnt(0) precedes s_barrier), and only
+    // then is the flag raised.  Readers use agent-scope atomic loads for flag and data alike.
     float* dst = xf + 4 * (size_t)(b * kBpBlock + (int)threadIdx.x);
-    dst[0] = t.x; dst[1] = t.y; dst[2] = t.z; dst[3] = t.w;
+    __hip_atomic_store(dst + 0, t.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(dst + 1, t.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(dst + 2, t.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(dst + 3, t.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  __threadfence();
   __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_store(&sync[1 + b], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) __hip_atomic_store(&sync[1 + b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (live) { poses[3 * (lo + q)] = x; poses[3 * (lo + q) + 1] = y; poses[3 * (lo + q) + 2] = th; }
   if (q == L) { trans_out[0] = destx - x; trans_out[1] = desty - y; }   // trans = destination - poses_[max].translation
 }
