@@ -85,7 +85,7 @@ void launch_pack_obs(hipStream_t st, int64_t n, const float* px, const float* py
                      float4* obs);
 void launch_assemble(hipStream_t st, const MapView& map, const PairView& pr, const FactorView& fv,
                      const double* x, const LinView& lin);
-inline int assemble_blocks(int n_poses) { return (n_poses + 127) / 128; }
+inline int assemble_blocks(int n_poses) { return (n_poses + 63) / 64; }   // k_assemble: 4 lanes per pose, 256 threads
 void launch_jacobi_scale(hipStream_t st, int n_poses, int npad, int Wb, const double* Hband, int enable,
                          const unsigned char* fixed, double* scale);
 void launch_build_system(hipStream_t st, int n_poses, int Wb, const LinView& lin, const double* scale,

@@ -372,19 +372,30 @@ __device__ __forceinline__ void eval_odom(const double* x1, const double* x2, fl
   o.J[12 + 5] = 1.0 / sa;
 }
 
-__global__ __launch_bounds__(128) void k_assemble(MapView map, PairView pr, FactorView fv, const double* __restrict__ x,
-                                                   LinView lin) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ double quad_sum(double v) {     // fixed order: (l0 + l1) + (l2 + l3) in every lane of the quad
+  v += __shfl_xor(v, 1, WAVE);
+  v += __shfl_xor(v, 2, WAVE);
+  return v;
+}
+
+// Four lanes per pose (there are too few poses to fill the machine with one thread each, and a single thread's chain of
+// dependent loads is what the kernel waits for): lane r of the quad takes the incidence entries e = r (mod 4), lane 0
+// the odometry edge (i-1, i), lane 1 the edge (i, i+1), lane 2 the human rows, lane d-1 the band block (i, i+d); the
+// diagonal block, gradient and cost are then summed across the quad in a fixed order.  No atomics: bit-reproducible.
+constexpr int kAsmBlock = 256;     // 64 poses per workgroup
+__global__ __launch_bounds__(kAsmBlock) void k_assemble(MapView map, PairView pr, FactorView fv, const double* __restrict__ x,
+                                                         LinView lin) {
+  const int i = (blockIdx.x * kAsmBlock + (int)threadIdx.x) >> 2;
+  const int r = threadIdx.x & 3;
   const int n = map.n_poses;
-  double pose_cost = 0.0, pose_gmax = 0.0;
-  if (i < n) {
+  const bool act = i < n;
   const int Wb = fv.band_poses;
   double Hd[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   double gi[3] = {0, 0, 0};
-  double H1[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // odometry part of block (i, i+1)
+  double H1[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // odometry part of block (i, i+1), produced by lane 1
   double cost = 0.0;
-  if (fv.with_stf) {
-    for (int e = fv.inc_off[i]; e < fv.inc_off[i + 1]; ++e) {
+  if (act && fv.with_stf) {
+    for (int e = fv.inc_off[i] + r; e < fv.inc_off[i + 1]; e += 4) {
       const int ent = fv.inc_ent[e];
       const double* RJ = lin.pairRJ + (size_t)kPairRJ * (ent >> 1);
       const int co = 2 + 3 * (ent & 1);
@@ -396,15 +407,12 @@ __global__ __launch_bounds__(128) void k_assemble(MapView map, PairView pr, Fact
 #pragma unroll
         for (int c = 0; c < 3; ++c) Hd[a * 3 + c] += ja0 * RJ[co + c] + ja1 * RJ[6 + co + c];
       }
-    }
-    for (int p = pr.pose_pair_off[i]; p < pr.pose_pair_off[i + 1]; ++p) {
-      const double r0 = lin.pairRJ[(size_t)kPairRJ * p], r1 = lin.pairRJ[(size_t)kPairRJ * p + 1];
-      cost += 0.5 * (r0 * r0 + r1 * r1);
+      if ((ent & 1) == 0) cost += 0.5 * (r0 * r0 + r1 * r1);      // a pair's cost is counted at its source pose
     }
   }
-  if (fv.with_odom) {
+  if (act && fv.with_odom) {
     OdomEval o;
-    if (i >= 1) {  // edge (i-1, i): this pose is pose2 (columns 3..5)
+    if (r == 0 && i >= 1) {  // edge (i-1, i): this pose is pose2 (columns 3..5)
       eval_odom(x + 3 * (i - 1), x + 3 * i, fv.odom_A[i], fv.odom_rr[i], fv.sig_r, fv.sig_t, fv.sig_a, o);
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
@@ -417,7 +425,7 @@ __global__ __launch_bounds__(128) void k_assemble(MapView map, PairView pr, Fact
       }
       cost += 0.5 * (o.r[0] * o.r[0] + o.r[1] * o.r[1] + o.r[2] * o.r[2]);
     }
-    if (i + 1 < n) {  // edge (i, i+1): this pose is pose1 (columns 0..2)
+    if (r == 1 && i + 1 < n) {  // edge (i, i+1): this pose is pose1 (columns 0..2)
       eval_odom(x + 3 * i, x + 3 * (i + 1), fv.odom_A[i + 1], fv.odom_rr[i + 1], fv.sig_r, fv.sig_t, fv.sig_a, o);
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
@@ -433,7 +441,7 @@ __global__ __launch_bounds__(128) void k_assemble(MapView map, PairView pr, Fact
       }
     }
   }
-  if (fv.with_hc) {
+  if (act && fv.with_hc && r == 2) {
     for (int h = fv.hc_off[i]; h < fv.hc_off[i + 1]; ++h) {  // residual_functors.h:1305-1411
       const uint32_t type = fv.hc_type[h];
       const float4 tg = fv.hc_tgt[h];
@@ -456,53 +464,66 @@ __global__ __launch_bounds__(128) void k_assemble(MapView map, PairView pr, Fact
       }
     }
   }
-  // Constant poses (global pose 0: JointOptimization.cpp:824, :1197; submap halos) keep their
-  // assembled blocks here; k_build_system / k_spmv / k_jacobi_scale treat them as fixed.  Their
-  // rows are only meaningful as COLUMNS of free neighbours (cross-cut coupling blocks).
-  const bool is_fixed = fv.fixed[i] != 0;
-  const bool is_owned = (i >= fv.own_lo) && (i < fv.own_hi);
-  if (is_fixed) { gi[0] = gi[1] = gi[2] = 0.0; }
-  if (!is_owned) cost = 0.0;        // every factor's cost is counted once: by the rank owning it
-  double* Hrow = lin.Hband + (size_t)i * (Wb + 1) * 9;
+  // quad totals (all four lanes take part, active or not)
 #pragma unroll
-  for (int q = 0; q < 9; ++q) Hrow[q] = Hd[q];
-  lin.g[3 * i] = gi[0]; lin.g[3 * i + 1] = gi[1]; lin.g[3 * i + 2] = gi[2];
-  pose_cost = cost;
-  pose_gmax = fmax(fabs(gi[0]), fmax(fabs(gi[1]), fabs(gi[2])));
-  if (gi[0] != gi[0] || gi[1] != gi[1] || gi[2] != gi[2]) pose_gmax = gi[0] + gi[1] + gi[2];  // NaN propagates
-  if (!is_owned) pose_gmax = 0.0;
-  for (int d = 1; d <= Wb; ++d) {
-    double blk[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (i + d < n) {
-      if (fv.with_stf) {
-        const int fwd = fv.band_pair[((size_t)i * Wb + (d - 1)) * 2];
-        const int rev = fv.band_pair[((size_t)i * Wb + (d - 1)) * 2 + 1];
-        if (fwd >= 0) {  // pair (i -> i+d): block = J0^T J1
-          const double* J = lin.pairRJ + (size_t)kPairRJ * fwd + 2;
+  for (int q = 0; q < 9; ++q) Hd[q] = quad_sum(Hd[q]);
 #pragma unroll
-          for (int a = 0; a < 3; ++a)
+  for (int q = 0; q < 3; ++q) gi[q] = quad_sum(gi[q]);
+  cost = quad_sum(cost);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) blk[a * 3 + c] += J[a] * J[3 + c] + J[6 + a] * J[9 + c];
-        }
-        if (rev >= 0) {  // pair (i+d -> i): block (i, i+d) = J1^T J0
-          const double* J = lin.pairRJ + (size_t)kPairRJ * rev + 2;
+  for (int q = 0; q < 9; ++q) H1[q] = __shfl(H1[q], (threadIdx.x & 60) + 1, WAVE);   // lane 1's odometry block, for lane 0
+  double pose_cost = 0.0, pose_gmax = 0.0;
+  if (act) {
+    // Constant poses (global pose 0: JointOptimization.cpp:824, :1197; submap halos) keep their
+    // assembled blocks here; k_build_system / k_spmv / k_jacobi_scale treat them as fixed.  Their
+    // rows are only meaningful as COLUMNS of free neighbours (cross-cut coupling blocks).
+    const bool is_fixed = fv.fixed[i] != 0;
+    const bool is_owned = (i >= fv.own_lo) && (i < fv.own_hi);
+    if (is_fixed) { gi[0] = gi[1] = gi[2] = 0.0; }
+    if (!is_owned) cost = 0.0;        // every factor's cost is counted once: by the rank owning it
+    double* Hrow = lin.Hband + (size_t)i * (Wb + 1) * 9;
+    if (r == 0) {
 #pragma unroll
-          for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) blk[a * 3 + c] += J[3 + a] * J[c] + J[9 + a] * J[6 + c];
-        }
-      }
-      if (d == 1 && fv.with_odom) {
-#pragma unroll
-        for (int q = 0; q < 9; ++q) blk[q] += H1[q];
-      }
+      for (int q = 0; q < 9; ++q) Hrow[q] = Hd[q];
+      lin.g[3 * i] = gi[0]; lin.g[3 * i + 1] = gi[1]; lin.g[3 * i + 2] = gi[2];
+      pose_cost = cost;
+      pose_gmax = fmax(fabs(gi[0]), fmax(fabs(gi[1]), fabs(gi[2])));
+      if (gi[0] != gi[0] || gi[1] != gi[1] || gi[2] != gi[2]) pose_gmax = gi[0] + gi[1] + gi[2];  // NaN propagates
+      if (!is_owned) pose_gmax = 0.0;
     }
+    const int d = r + 1;             // this lane's band block (i, i+d)
+    if (d <= Wb) {
+      double blk[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      if (i + d < n) {
+        if (fv.with_stf) {
+          const int fwd = fv.band_pair[((size_t)i * Wb + (d - 1)) * 2];
+          const int rev = fv.band_pair[((size_t)i * Wb + (d - 1)) * 2 + 1];
+          if (fwd >= 0) {  // pair (i -> i+d): block = J0^T J1
+            const double* J = lin.pairRJ + (size_t)kPairRJ * fwd + 2;
 #pragma unroll
-    for (int q = 0; q < 9; ++q) Hrow[d * 9 + q] = blk[q];
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+              for (int c = 0; c < 3; ++c) blk[a * 3 + c] += J[a] * J[3 + c] + J[6 + a] * J[9 + c];
+          }
+          if (rev >= 0) {  // pair (i+d -> i): block (i, i+d) = J1^T J0
+            const double* J = lin.pairRJ + (size_t)kPairRJ * rev + 2;
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+              for (int c = 0; c < 3; ++c) blk[a * 3 + c] += J[3 + a] * J[c] + J[9 + a] * J[6 + c];
+          }
+        }
+        if (d == 1 && fv.with_odom) {
+#pragma unroll
+          for (int q = 0; q < 9; ++q) blk[q] += H1[q];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 9; ++q) Hrow[d * 9 + q] = blk[q];
+    }
   }
-  }  // i < n
   // per-workgroup partials (fixed order => bit-reproducible); the host adds the few hundred partials
-  __shared__ double sm_c[2], sm_g[2];
+  __shared__ double sm_c[kAsmBlock / WAVE], sm_g[kAsmBlock / WAVE];
   double c = wave_sum(pose_cost), gm = pose_gmax;
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) { const double o = __shfl_xor(gm, m, WAVE); gm = (o > gm || o != o) ? o : gm; }
@@ -510,9 +531,10 @@ __global__ __launch_bounds__(128) void k_assemble(MapView map, PairView pr, Fact
   if ((threadIdx.x & 63) == 0) { sm_c[wv] = c; sm_g[wv] = gm; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    const double g1 = sm_g[1];
-    lin.partials[2 * blockIdx.x] = sm_c[0] + sm_c[1];
-    lin.partials[2 * blockIdx.x + 1] = (g1 > sm_g[0] || g1 != g1) ? g1 : sm_g[0];
+    double cs = sm_c[0], gs = sm_g[0];
+    for (int k = 1; k < kAsmBlock / WAVE; ++k) { cs += sm_c[k]; const double g1 = sm_g[k]; gs = (g1 > gs || g1 != g1) ? g1 : gs; }
+    lin.partials[2 * blockIdx.x] = cs;
+    lin.partials[2 * blockIdx.x + 1] = gs;
   }
 }
 
@@ -539,7 +561,7 @@ __global__ __launch_bounds__(128) void k_assemble_offband(FactorView fv, LinView
 void launch_assemble(hipStream_t st, const MapView& map, const PairView& pr, const FactorView& fv, const double* x,
                      const LinView& lin) {
   const int n = map.n_poses;
-  hipLaunchKernelGGL(k_assemble, dim3((n + 127) / 128), dim3(128), 0, st, map, pr, fv, x, lin);
+  hipLaunchKernelGGL(k_assemble, dim3(assemble_blocks(n)), dim3(kAsmBlock), 0, st, map, pr, fv, x, lin);
   if (fv.with_stf && fv.n_offband > 0)
     hipLaunchKernelGGL(k_assemble_offband, dim3((fv.n_offband + 127) / 128), dim3(128), 0, st, fv, lin);
 }
