@@ -18,6 +18,7 @@
 namespace hitl {
 
 constexpr int kMatchBlock = 256;
+constexpr int kMatchGroup = 16;    // target points per bounding box
 
 __global__ __launch_bounds__(kMatchBlock) void k_match(MapView map, int chunk, int max_scan, int slots,
                                                         const int* __restrict__ cand_tgt,
@@ -25,6 +26,7 @@ __global__ __launch_bounds__(kMatchBlock) void k_match(MapView map, int chunk, i
                                                         uint16_t* __restrict__ table, int* __restrict__ counts) {
   extern __shared__ float4 s_tgt[];                 // [max_scan]
   int* s_cnt = (int*)(s_tgt + max_scan);            // [max_scan] accepted matches per source point
+  float4* s_box = (float4*)(s_cnt + ((max_scan + 3) & ~3));   // [ceil(max_scan / kMatchGroup)] (min x, min y, max x, max y), 16-byte aligned
   __shared__ int s_pair_count;
   const int b = blockIdx.x;
   const int idx = b >> 3;
@@ -43,6 +45,21 @@ __global__ __launch_bounds__(kMatchBlock) void k_match(MapView map, int chunk, i
     if (threadIdx.x == 0) s_pair_count = 0;
     for (int t = threadIdx.x; t < mj; t += kMatchBlock) s_tgt[t] = map.obs[oj + t];
     __syncthreads();
+    // Bounding box of every run of kMatchGroup consecutive target points (a scan is ordered by bearing, so a run is a
+    // short piece of wall).  A source point farther than the gate from a box cannot pass the gate for any point in
+    // it -- exactly so in fp32 too: rounding is monotone, so every dsq of the run is >= the box's -- and the run is
+    // skipped.  The points that are tested are still visited in ascending order: same winner, same ties.
+    const int ngrp = (mj + kMatchGroup - 1) / kMatchGroup;
+    for (int g = threadIdx.x; g < ngrp; g += kMatchBlock) {
+      float4 bx = make_float4(3.402823466e+38f, 3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f);
+      const int t1 = min(mj, (g + 1) * kMatchGroup);
+      for (int t = g * kMatchGroup; t < t1; ++t) {
+        const float4 v = s_tgt[t];
+        bx.x = fminf(bx.x, v.x); bx.y = fminf(bx.y, v.y); bx.z = fmaxf(bx.z, v.x); bx.w = fmaxf(bx.w, v.y);
+      }
+      s_box[g] = bx;
+    }
+    __syncthreads();
     const float* tf = cand_tf + ((size_t)i * slots + slot) * 8;
     const float m00 = tf[0], m01 = tf[1], m10 = tf[2], m11 = tf[3], tx = tf[4], ty = tf[5], cr = tf[6], sr = tf[7];
     uint16_t* row = table + ((size_t)i * slots + slot) * max_scan;
@@ -56,13 +73,21 @@ __global__ __launch_bounds__(kMatchBlock) void k_match(MapView map, int chunk, i
         const float qy = (m10 * ax + m11 * ay) + ty;
         float best = 3.402823466e+38f;
         int bi = -1;
-        for (int t = 0; t < mj; ++t) {
-          const float4 g = s_tgt[t];
-          const float dx = qx - g.x, dy = qy - g.y;
-          const float dsq = dx * dx + dy * dy;
-          if (dsq < thr2) {
-            const float sc = fabsf(g.z * dx + g.w * dy);
-            if (sc < best) { best = sc; bi = t; }
+        for (int gi = 0; gi < ngrp; ++gi) {
+          const float4 bx = s_box[gi];
+          // distance from q to the box, with the same subtractions the point test uses (q - coordinate)
+          const float ex = fmaxf(fmaxf(qx - bx.z, -(qx - bx.x)), 0.0f);
+          const float ey = fmaxf(fmaxf(qy - bx.w, -(qy - bx.y)), 0.0f);
+          if (!(ex * ex + ey * ey < thr2)) continue;
+          const int t1 = min(mj, (gi + 1) * kMatchGroup);
+          for (int t = gi * kMatchGroup; t < t1; ++t) {
+            const float4 g = s_tgt[t];
+            const float dx = qx - g.x, dy = qy - g.y;
+            const float dsq = dx * dx + dy * dy;
+            if (dsq < thr2) {
+              const float sc = fabsf(g.z * dx + g.w * dy);
+              if (sc < best) { best = sc; bi = t; }
+            }
           }
         }
         if (bi >= 0 && best < thr) {
@@ -84,7 +109,8 @@ __global__ __launch_bounds__(kMatchBlock) void k_match(MapView map, int chunk, i
 void launch_match(hipStream_t st, const MapView& map, int max_scan, int slots, const int* cand_tgt, const float* cand_tf,
                   MatchParams mp, uint16_t* table, int* counts) {
   const int chunk = (map.n_poses + 7) / 8;
-  const size_t lds = (size_t)max_scan * (sizeof(float4) + sizeof(int));
+  const size_t lds = (size_t)max_scan * sizeof(float4) + (size_t)((max_scan + 3) & ~3) * sizeof(int) +
+                     (size_t)((max_scan + kMatchGroup - 1) / kMatchGroup) * sizeof(float4);
   hipLaunchKernelGGL(k_match, dim3(8 * chunk), dim3(kMatchBlock), lds, st, map, chunk, max_scan, slots, cand_tgt, cand_tf,
                      mp, table, counts);
 }
