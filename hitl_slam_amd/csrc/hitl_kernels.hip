@@ -1109,7 +1109,8 @@ __global__ __launch_bounds__(kCrTreeThreads) void k_cr_backward_tree(CrView cr, 
   // waits for its own tile loads, not for the previous level's stores to come back from L2
   extern __shared__ double sx[];                       // (S + 1) * B
   const int base = blockIdx.x * S;
-  for (int vv = 0; vv < nrhs; ++vv) {
+  {
+    const int vv = blockIdx.y;                          // one right-hand side per workgroup row
     const double* wv = w + stride * vv;
     double* xv = x + stride * vv;
     for (int t = threadIdx.x; t < 2 * B; t += kCrTreeThreads) {            // the two boundary nodes (known)
@@ -1142,7 +1143,6 @@ __global__ __launch_bounds__(kCrTreeThreads) void k_cr_backward_tree(CrView cr, 
       const int node = base + 1 + t / B;
       if (node < cr.nsb) xv[(size_t)node * B + t % B] = sx[(size_t)(node - base) * B + t % B];
     }
-    __syncthreads();
   }
 }
 
@@ -1157,8 +1157,8 @@ static void cr_backward_levels(hipStream_t st, const CrView& cr, int s_from, con
   }
   if (s >= 1) {
     const int S = 2 * s;
-    hipLaunchKernelGGL(k_cr_backward_tree<B>, dim3((cr.nsb + S - 1) / S), dim3(kCrTreeThreads), sizeof(double) * (S + 1) * B, st, cr, S, w, x, nrhs,
-                       stride);
+    hipLaunchKernelGGL(k_cr_backward_tree<B>, dim3((cr.nsb + S - 1) / S, nrhs), dim3(kCrTreeThreads), sizeof(double) * (S + 1) * B, st, cr, S, w, x,
+                       nrhs, stride);
   }
 }
 
