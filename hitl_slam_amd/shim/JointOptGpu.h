@@ -27,7 +27,7 @@ namespace hitl {
 template <class Pose2Df, class Vec2f, class Mat3f, class HumanConstraint>
 class JointOptGpuT {
  public:
-  JointOptGpuT() : num_hc_residuals_(0), mode_(HITL_MODE_ODOM_HC), stf_window_(80), solver_(NULL), map_poses_(0) {
+  JointOptGpuT() : num_hc_residuals_(0), mode_(HITL_MODE_ODOM_HC), stf_window_(80), solver_(NULL), map_poses_(0), stf_moments_(false) {
     std::memset(&summary_, 0, sizeof(summary_));
   }
   virtual ~JointOptGpuT() { if (solver_) hitl_solver_destroy(solver_); }
@@ -59,13 +59,23 @@ class JointOptGpuT {
   const hitl_summary& Summary() const { return summary_; }
   bool want_gradients = false;     // fill gradients_ like problem.Evaluate at :1247-1252
 
-  int RunStatus() {
+  // The session's solver (created on first use): the correction-cycle entry points (hitl_solver_fit_segments,
+  // hitl_solver_apply_explicit_correction, hitl_solver_backprop ...) run on the same resident map.
+  hitl_solver* Solver() {
     if (!solver_) {
       hitl_options opt;
       hitl_options_default(&opt);
-      const int st = hitl_solver_create(&opt, &solver_);
-      if (st != HITL_OK) return st;
+      opt.stf_moments = stf_moments_ ? 1 : 0;
+      create_status_ = hitl_solver_create(&opt, &solver_);
+      if (create_status_ != HITL_OK) solver_ = NULL;
     }
+    return solver_;
+  }
+  // opt-in moments form of the scan-to-scan factors (hitl_options.stf_moments); call before the first Run()
+  void SetStfMoments(bool on) { stf_moments_ = on; }
+
+  int RunStatus() {
+    if (!Solver()) return create_status_;
     const size_t n = poses_.size();
     if (n == 0 || robot_frame_point_clouds_.size() != n || robot_frame_normal_clouds_.size() != n) return HITL_ERR_INVALID_ARGUMENT;
     if (map_poses_ != n) {   // == BuildKDTrees on the first call (:1307): the scans never change afterwards
@@ -121,6 +131,8 @@ class JointOptGpuT {
   int64_t stf_window_;
   hitl_solver* solver_;
   size_t map_poses_;
+  bool stf_moments_;
+  int create_status_ = HITL_OK;
   hitl_summary summary_;
 };
 
