@@ -1,0 +1,776 @@
+// hitl_cr.hip -- the linear solve of the LM step on gfx950:
+//   k_jacobi_scale, k_build_system : Jacobi scaling + LM diagonal -> block-tridiagonal super-block system.
+//   k_cr_*           : K7b block cyclic reduction = recursive red/black Schur complement of the
+//                      banded normal equations (what Ceres SPARSE_SCHUR does on a chain,
+//                      JointOptimization.cpp:148), exact preconditioner of the PCG.
+//   k_cr_selinv_level, k_cov_extract : diagonal blocks of the inverse from the same factors (pose covariances).
+// All arithmetic is fp64.
+
+#include "hitl_device.h"
+
+namespace hitl {
+
+__global__ void k_jacobi_scale(int n_poses, int npad, int Wb, const double* __restrict__ Hband, int enable,
+                               const unsigned char* __restrict__ fixed, double* __restrict__ scale) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= npad) return;
+  double s = 1.0;
+  if (enable && a < 3 * n_poses && !fixed[a / 3]) {
+    const int i = a / 3, c = a % 3;
+    s = 1.0 / (1.0 + sqrt(Hband[(size_t)i * (Wb + 1) * 9 + c * 3 + c]));
+  }
+  scale[a] = s;
+}
+
+void launch_jacobi_scale(hipStream_t st, int n_poses, int npad, int Wb, const double* Hband, int enable,
+                         const unsigned char* fixed, double* scale) {
+  hipLaunchKernelGGL(k_jacobi_scale, dim3((npad + 255) / 256), dim3(256), 0, st, n_poses, npad, Wb, Hband, enable, fixed, scale);
+}
+
+// ===========================================================================================
+// build_system: banded 3x3-block Hessian -> block-tridiagonal system of B x B super-blocks
+// (Wb consecutive poses each) in the Jacobi-scaled space with the LM diagonal
+//   D^2 = clamp(diag(S H S), min, max) / mu     
+// ===========================================================================================
+// one thread per (super-block k, row a, column b): coalesced stores of D and L
+__global__ void k_build_system(int n_poses, int Wb, const double* __restrict__ Hband, const double* __restrict__ g,
+                               const double* __restrict__ scale, const unsigned char* __restrict__ fixed, double mu,
+                               double min_diag, double max_diag, CrView cr, double* __restrict__ rhs, double* __restrict__ rhs_work) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int B = cr.B, BB = B * B;
+  if (t >= cr.nsb * BB) return;
+  const int k = t / BB, e = t % BB, a = e / B, b = e % B;
+  const int i = k * Wb + a / 3, ca = a % 3;
+  if (i >= n_poses || fixed[i]) {     // padding rows and constant poses: identity
+    cr.D[t] = (b == a) ? 1.0 : 0.0;
+    cr.L[t] = 0.0;
+    if (b == 0) { rhs[k * B + a] = 0.0; if (rhs_work) rhs_work[k * B + a] = 0.0; }
+    return;
+  }
+  const int W1 = Wb + 1;
+  const double sa = scale[3 * i + ca];
+  const int i2 = k * Wb + b / 3, cb = b % 3;
+  double v = 0.0;
+  if (i2 < n_poses && !fixed[i2]) {
+    v = (i2 >= i) ? Hband[((size_t)i * W1 + (i2 - i)) * 9 + ca * 3 + cb]
+                  : Hband[((size_t)i2 * W1 + (i - i2)) * 9 + cb * 3 + ca];
+    v *= sa * scale[3 * i2 + cb];
+  }
+  if (b == a) v += fmin(fmax(v, min_diag), max_diag) / mu;
+  cr.D[t] = v;
+  double l = 0.0;
+  if (k > 0) {
+    const int i3 = (k - 1) * Wb + b / 3;
+    const int d = i - i3;
+    if (d <= Wb && !fixed[i3]) l = Hband[((size_t)i3 * W1 + d) * 9 + cb * 3 + ca] * sa * scale[3 * i3 + cb];
+  }
+  cr.L[t] = l;
+  if (b == 0) {
+    const double v = -sa * g[3 * i + ca];
+    rhs[k * B + a] = v;
+    if (rhs_work) rhs_work[k * B + a] = v;      // the copy the factor-solve consumes in place
+  }
+}
+
+void launch_build_system(hipStream_t st, int n_poses, int Wb, const LinView& lin, const double* scale,
+                         const unsigned char* fixed, double mu, double min_diag, double max_diag, const CrView& cr,
+                         double* rhs, double* rhs_work) {
+  const int tot = cr.nsb * cr.B * cr.B;
+  hipLaunchKernelGGL(k_build_system, dim3((tot + 255) / 256), dim3(256), 0, st, n_poses, Wb, lin.Hband, lin.g, scale, fixed,
+                     mu, min_diag, max_diag, cr, rhs, rhs_work);
+}
+
+// ===========================================================================================
+// block cyclic reduction.  One 64-lane workgroup per super-block; B x B tiles live in LDS.
+// Level stride s: nodes s, 3s, 5s.. are eliminated, nodes 0, 2s, 4s.. survive and absorb the
+// Schur complement.  k_cr_invert inverts the level-0 odd nodes; k_cr_level then does one whole
+// level per launch (survivor update + rhs sweep + inverse of the next level's odd nodes) and
+// k_cr_top finishes the last kCrTopNodes nodes, the root and their back-substitution.
+// ===========================================================================================
+// Register-resident Gauss-Jordan sweep of one SPD super-block: lane (grp, c) owns column c of
+// the augmented matrix [D | I | L_k | L_{k+s}^T]; for pivot p the pivot column is broadcast from
+// lane p with v_readlane (no LDS, no barriers, no pivoting needed for SPD tiles).  Result:
+// [I | Dinv | Gl = Dinv L_k | Gr = Dinv L_{k+s}^T].
+template <int B>
+__device__ __forceinline__ void gauss_jordan_cols(double (&col)[B]) {
+#pragma unroll
+  for (int p = 0; p < B; ++p) {
+    double m[B];
+#pragma unroll
+    for (int r = 0; r < B; ++r) m[r] = readlane_f64(col[r], p);   // current column p (lane p, group 0)
+    const double inv = 1.0 / m[p];
+    const double vk = col[p] * inv;
+#pragma unroll
+    for (int r = 0; r < B; ++r) col[r] = (r == p) ? vk : col[r] - m[r] * vk;
+  }
+}
+
+template <int B>
+__device__ __forceinline__ void cr_eliminate_node(const CrView& cr, int s, int k, int lane) {
+  static_assert(4 * B <= WAVE, "four column groups must fit one wave");
+  const size_t off = (size_t)k * B * B;
+  const bool has_right = (k + s) < cr.nsb;
+  const int grp = lane / B, c = lane % B;
+  const double* Dk = cr.D + off;
+  const double* Lk = cr.L + off;
+  const double* Lr = cr.L + (size_t)(has_right ? (k + s) : k) * B * B;
+  double col[B];
+#pragma unroll
+  for (int r = 0; r < B; ++r) {
+    double v = 0.0;
+    if (grp == 0) v = Dk[r * B + c];
+    else if (grp == 1) v = (r == c) ? 1.0 : 0.0;
+    else if (grp == 2) v = Lk[r * B + c];
+    else if (grp == 3 && has_right) v = Lr[c * B + r];      // column c of L_{k+s}^T
+    col[r] = v;
+  }
+  gauss_jordan_cols<B>(col);
+  double* dst = (grp == 1) ? cr.Dinv + off : (grp == 2) ? cr.Gl + off : cr.Gr + off;
+  if (grp >= 1 && grp <= 3) {
+#pragma unroll
+    for (int r = 0; r < B; ++r) dst[r * B + c] = col[r];
+  }
+}
+
+// Schur-complement update of survivor j at level stride s (LDS-free):
+//   D_j  -= L_j Gr[k1] + L_{k2}^T Gl[k2]        L'_j = -L_j Gl[k1]
+// Lane (grp, c) owns column c of the right operands (grp 0: Gr[k1], Gl[k2] -> D_j; grp 1: Gl[k1]
+// -> L'_j); the left matrices L_j and L_{k2}^T are the same for every lane (uniform loads).
+// With w != nullptr the right-hand side rides along (w_j -= Gr[k1]^T w_k1 + Gl[k2]^T w_k2), which
+// saves the separate forward sweep when a factorisation is followed by exactly one solve.
+template <int B>
+__device__ __forceinline__ void cr_update_node(const CrView& cr, int s, int j, int lane, double* w, int nrhs, size_t stride) {
+  const size_t off = (size_t)j * B * B;
+  const int k1 = j - s, k2 = j + s;
+  const bool has1 = k1 >= 0, has2 = k2 < cr.nsb, has_ll = (k1 - s) >= 0;
+  const int grp = lane / B, c = lane % B;
+  if (grp > 1) return;
+  const double* Lj = cr.L + off;                                   // overwritten below: no __restrict__
+  const double* L2 = cr.L + (size_t)(has2 ? k2 : j) * B * B;
+  double b1[B], b2[B], acc[B];
+  const double* B1 = (grp == 0 ? cr.Gr : cr.Gl) + (size_t)(has1 ? k1 : j) * B * B;
+  const double* B2 = cr.Gl + (size_t)(has2 ? k2 : j) * B * B;
+#pragma unroll
+  for (int r = 0; r < B; ++r) {
+    b1[r] = has1 ? B1[r * B + c] : 0.0;
+    b2[r] = (has2 && grp == 0) ? B2[r * B + c] : 0.0;
+    acc[r] = 0.0;
+  }
+  if (has1) {
+#pragma unroll
+    for (int r = 0; r < B; ++r)
+#pragma unroll
+      for (int q = 0; q < B; ++q) acc[r] += Lj[r * B + q] * b1[q];          // (L_j * B1)[r][c]
+  }
+  if (has2) {
+#pragma unroll
+    for (int r = 0; r < B; ++r)
+#pragma unroll
+      for (int q = 0; q < B; ++q) acc[r] += L2[q * B + r] * b2[q];          // (L_{k2}^T * Gl[k2])[r][c]
+  }
+  if (grp == 0) {
+    if (w != nullptr) {   // rhs forward sweep: w_j[c] -= Gr[k1][:,c] . w_k1 + Gl[k2][:,c] . w_k2
+      for (int v = 0; v < nrhs; ++v) {
+        double* wv = w + stride * v;
+        double wacc = wv[(size_t)j * B + c];
+        if (has1) {
+          const double* wk = wv + (size_t)k1 * B;
+#pragma unroll
+          for (int r = 0; r < B; ++r) wacc -= b1[r] * wk[r];
+        }
+        if (has2) {
+          const double* wk = wv + (size_t)k2 * B;
+#pragma unroll
+          for (int r = 0; r < B; ++r) wacc -= b2[r] * wk[r];
+        }
+        wv[(size_t)j * B + c] = wacc;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < B; ++r) cr.D[off + r * B + c] -= acc[r];
+  } else if (has1) {
+    // every read of the old L_j happened above (same wave, in order); now it is replaced
+#pragma unroll
+    for (int r = 0; r < B; ++r) cr.L[off + r * B + c] = has_ll ? -acc[r] : 0.0;
+  }
+}
+
+// One launch per big level (instead of eliminate + update): the workgroup of survivor j
+//  1. forms, from the inverses Dinv[k1], Dinv[k2] of its two eliminated neighbours (computed by
+//     the PREVIOUS level's launch, step 3 below), the products
+//        Gr[k1] = Dinv_k1 L_j^T     Gl[k1] = Dinv_k1 L_k1     Gl[k2] = Dinv_k2 L_k2
+//     (Gr/Gl of node k are stored by its right-hand survivor; the back substitution reads them),
+//  2. applies the Schur complement  D_j -= L_j Gr[k1] + L_k2^T Gl[k2],  L'_j = -L_j Gl[k1]  and the
+//     right-hand-side sweep  w_j -= Gr[k1]^T w_k1 + Gl[k2]^T w_k2,
+//  3. if j itself is eliminated at the next level, inverts its new D_j (register-resident
+//     Gauss-Jordan) so that level needs no separate inversion launch either.
+template <int B>
+__device__ __forceinline__ void lds_load(double* dst, const double* src) {
+  for (int e = threadIdx.x; e < B * B; e += WAVE) dst[e] = src[e];
+}
+
+// C = A * Bm (TA: use A^T, TB: use Bm^T), all B x B tiles in LDS, one wave
+template <int B, bool TA, bool TB>
+__device__ __forceinline__ void lds_matmul(double* C, const double* A, const double* Bm) {
+  for (int e = threadIdx.x; e < B * B; e += WAVE) {
+    const int r = e / B, c = e % B;
+    double v = 0.0;
+#pragma unroll
+    for (int q = 0; q < B; ++q) v += (TA ? A[q * B + r] : A[r * B + q]) * (TB ? Bm[c * B + q] : Bm[q * B + c]);
+    C[e] = v;
+  }
+}
+
+template <int B>
+__global__ __launch_bounds__(WAVE) void k_cr_level(CrView cr, int s, int invert_next, double* w, int nrhs, size_t stride) {
+  __shared__ double sLj[B * B], sL1[B * B], sL2[B * B], sI1[B * B], sI2[B * B], sGr1[B * B], sGl1[B * B], sGl2[B * B], sD[B * B];
+  const int j = 2 * s * blockIdx.x;
+  if (j >= cr.nsb) return;
+  const size_t BB = (size_t)B * B, off = (size_t)j * BB;
+  const int k1 = j - s, k2 = j + s;
+  const bool has1 = k1 >= 0, has2 = k2 < cr.nsb, has_ll = (k1 - s) >= 0;
+  lds_load<B>(sD, cr.D + off);
+  if (has1) { lds_load<B>(sLj, cr.L + off); lds_load<B>(sL1, cr.L + (size_t)k1 * BB); lds_load<B>(sI1, cr.Dinv + (size_t)k1 * BB); }
+  if (has2) { lds_load<B>(sL2, cr.L + (size_t)k2 * BB); lds_load<B>(sI2, cr.Dinv + (size_t)k2 * BB); }
+  __syncthreads();
+  if (has1) {
+    lds_matmul<B, false, true>(sGr1, sI1, sLj);       // Dinv_k1 * L_j^T
+    if (has_ll) lds_matmul<B, false, false>(sGl1, sI1, sL1);   // Dinv_k1 * L_k1
+    else for (int e = threadIdx.x; e < B * B; e += WAVE) sGl1[e] = 0.0;
+  }
+  if (has2) lds_matmul<B, false, false>(sGl2, sI2, sL2);       // Dinv_k2 * L_k2
+  __syncthreads();
+  // factors of the eliminated neighbours, for the back substitution
+  if (has1) for (int e = threadIdx.x; e < B * B; e += WAVE) { cr.Gr[(size_t)k1 * BB + e] = sGr1[e]; cr.Gl[(size_t)k1 * BB + e] = sGl1[e]; }
+  if (has2 && (k2 + s) >= cr.nsb)      // k2 has no right-hand survivor: its Gl comes from here, its Gr is zero
+    for (int e = threadIdx.x; e < B * B; e += WAVE) { cr.Gl[(size_t)k2 * BB + e] = sGl2[e]; cr.Gr[(size_t)k2 * BB + e] = 0.0; }
+  // right-hand-side sweep
+  if (w != nullptr && (int)threadIdx.x < B) {
+    for (int v = 0; v < nrhs; ++v) {
+      double* wv = w + stride * v;
+      double acc_w = wv[(size_t)j * B + threadIdx.x];
+      if (has1) { const double* wk = wv + (size_t)k1 * B;
+#pragma unroll
+        for (int r = 0; r < B; ++r) acc_w -= sGr1[r * B + threadIdx.x] * wk[r]; }
+      if (has2) { const double* wk = wv + (size_t)k2 * B;
+#pragma unroll
+        for (int r = 0; r < B; ++r) acc_w -= sGl2[r * B + threadIdx.x] * wk[r]; }
+      wv[(size_t)j * B + threadIdx.x] = acc_w;
+    }
+  }
+  // Schur complement
+  for (int e = threadIdx.x; e < B * B; e += WAVE) {
+    const int r = e / B, c = e % B;
+    double d = sD[e], l = 0.0;
+    if (has1) {
+#pragma unroll
+      for (int q = 0; q < B; ++q) { d -= sLj[r * B + q] * sGr1[q * B + c]; l -= sLj[r * B + q] * sGl1[q * B + c]; }
+    }
+    if (has2) {
+#pragma unroll
+      for (int q = 0; q < B; ++q) d -= sL2[q * B + r] * sGl2[q * B + c];
+    }
+    cr.D[off + e] = d;
+    if (has1) cr.L[off + e] = l;
+    sI1[e] = d;                       // reuse: new D_j for the inversion below (sI1 is dead after the matmuls... see barrier)
+  }
+  // inversion of the new D_j when j is eliminated at the next level
+  if (invert_next && (blockIdx.x & 1)) {
+    __syncthreads();
+    const int grp = threadIdx.x / B, c = threadIdx.x % B;
+    double col[B];
+#pragma unroll
+    for (int r = 0; r < B; ++r) col[r] = (grp == 0) ? sI1[r * B + c] : ((grp == 1 && r == c) ? 1.0 : 0.0);
+    gauss_jordan_cols<B>(col);
+    if (grp == 1) {
+#pragma unroll
+      for (int r = 0; r < B; ++r) cr.Dinv[off + r * B + c] = col[r];
+    }
+  }
+}
+
+// Dinv of the nodes eliminated at the first level (one wave per node)
+template <int B>
+__global__ __launch_bounds__(WAVE) void k_cr_invert(CrView cr, int s) {
+  const int k = s * (2 * blockIdx.x + 1);
+  if (k >= cr.nsb) return;
+  const size_t off = (size_t)k * B * B;
+  const int grp = threadIdx.x / B, c = threadIdx.x % B;
+  double col[B];
+#pragma unroll
+  for (int r = 0; r < B; ++r) col[r] = (grp == 0) ? cr.D[off + r * B + c] : ((grp == 1 && r == c) ? 1.0 : 0.0);
+  gauss_jordan_cols<B>(col);
+  if (grp == 1) {
+#pragma unroll
+    for (int r = 0; r < B; ++r) cr.Dinv[off + r * B + c] = col[r];
+  }
+}
+
+template <int B>
+__device__ __forceinline__ void cr_root_node(const CrView& cr, int lane) {
+  const int grp = lane / B, c = lane % B;
+  double col[B];
+#pragma unroll
+  for (int r = 0; r < B; ++r) col[r] = (grp == 0) ? cr.D[r * B + c] : ((grp == 1 && r == c) ? 1.0 : 0.0);
+  gauss_jordan_cols<B>(col);
+  if (grp == 1) {
+#pragma unroll
+    for (int r = 0; r < B; ++r) cr.Dinv[r * B + c] = col[r];
+  }
+}
+
+template <int B>
+__global__ __launch_bounds__(WAVE) void k_cr_root(CrView cr) { cr_root_node<B>(cr, threadIdx.x); }
+
+// back substitution of one row: x_k[r] = (Dinv_k w_k - Gl_k x_{k-s} - Gr_k x_{k+s})[r]
+template <int B>
+__device__ __forceinline__ void cr_backward_row(const CrView& cr, int s, int k, int r, const double* w, double* x) {
+  const size_t off = (size_t)k * B * B;
+  const double* wk = w + (size_t)k * B;
+  const double* xl = x + (size_t)(k - s) * B;
+  const bool has_right = (k + s) < cr.nsb;
+  const double* xr = x + (size_t)(has_right ? (k + s) : k) * B;
+  double v = 0.0;
+#pragma unroll
+  for (int c = 0; c < B; ++c) {
+    v += cr.Dinv[off + r * B + c] * wk[c];
+    v -= cr.Gl[off + r * B + c] * xl[c];
+    if (has_right) v -= cr.Gr[off + r * B + c] * xr[c];
+  }
+  x[(size_t)k * B + r] = v;
+}
+
+// All levels from stride s_start up to the root, the root itself and (x != nullptr) the
+// matching back-substitution levels in ONE single-workgroup launch: these levels hold at most a
+// few hundred super-blocks, so they are pure launch latency when issued as 3 kernels per level.
+// 16 waves, one super-block per wave per step, __syncthreads between phases (all traffic is
+// workgroup-local global memory).
+constexpr int kCrTopThreads = 1024;
+template <int B>
+__global__ __launch_bounds__(kCrTopThreads) void k_cr_top(CrView cr, int s_start, double* w, double* x, int nrhs, size_t stride) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  constexpr int NW = kCrTopThreads / WAVE;
+  int s_last = 0;
+  for (int s = s_start; s < cr.nsb; s *= 2) {
+    for (int q = wave;; q += NW) {
+      const int k = s * (2 * q + 1);
+      if (k >= cr.nsb) break;
+      cr_eliminate_node<B>(cr, s, k, lane);
+    }
+    __syncthreads();
+    for (int q = wave;; q += NW) {
+      const int j = 2 * s * q;
+      if (j >= cr.nsb) break;
+      cr_update_node<B>(cr, s, j, lane, w, nrhs, stride);
+    }
+    __syncthreads();
+    s_last = s;
+  }
+  if (wave == 0) cr_root_node<B>(cr, lane);
+  __syncthreads();
+  if (x == nullptr) return;
+  if ((int)threadIdx.x < B * nrhs) {
+    const int vv = threadIdx.x / B, r = threadIdx.x % B;
+    double v = 0.0;
+#pragma unroll
+    for (int c = 0; c < B; ++c) v += cr.Dinv[r * B + c] * w[stride * vv + c];
+    x[stride * vv + r] = v;
+  }
+  __syncthreads();
+  for (int s = s_last; s >= s_start && s >= 1; s /= 2) {
+    for (int vv = 0; vv < nrhs; ++vv)
+      for (int t = threadIdx.x;; t += kCrTopThreads) {
+        const int k = s * (2 * (t / B) + 1);
+        if (k >= cr.nsb) break;
+        cr_backward_row<B>(cr, s, k, t % B, w + stride * vv, x + stride * vv);
+      }
+    __syncthreads();
+  }
+}
+
+// The same top of the tree with every tile resident in LDS: the M = ceil(nsb / s_start) nodes alive at stride s_start
+// are copied in once (D, L, right-hand sides), all levels, the root and the back-substitution run on a LOCAL system of
+// M nodes with local strides 1, 2, 4 .. through the very same node routines (they only see a CrView whose arrays
+// happen to live in LDS), and Dinv / Gl / Gr / w / x go back out once.  Global memory is touched twice instead of at
+// every one of the ~20 dependent phases.
+template <int B>
+__global__ __launch_bounds__(kCrTopThreads) void k_cr_top_lds(CrView cr, int s_start, int M, double* w, double* x, int nrhs, size_t stride) {
+  extern __shared__ double lds[];
+  constexpr int BB = B * B;
+  double* sD = lds;
+  double* sL = sD + (size_t)M * BB;
+  double* sDinv = sL + (size_t)M * BB;
+  double* sGl = sDinv + (size_t)M * BB;
+  double* sGr = sGl + (size_t)M * BB;
+  double* sw = sGr + (size_t)M * BB;                 // nrhs vectors of M * B, lstride apart
+  double* sx = sw + (size_t)M * B * nrhs;
+  const size_t lstride = (size_t)M * B;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  constexpr int NW = kCrTopThreads / WAVE;
+  for (int e = threadIdx.x; e < M * BB; e += kCrTopThreads) {
+    const int m = e / BB, q = e % BB;
+    const size_t g = (size_t)m * s_start * BB + q;
+    sD[e] = cr.D[g]; sL[e] = cr.L[g]; sGl[e] = 0.0; sGr[e] = 0.0; sDinv[e] = 0.0;
+  }
+  if (w != nullptr)
+    for (int e = threadIdx.x; e < M * B * nrhs; e += kCrTopThreads) {
+      const int v = e / (M * B), r = e % (M * B);
+      sw[(size_t)v * lstride + r] = w[stride * v + (size_t)(r / B) * s_start * B + (r % B)];
+    }
+  __syncthreads();
+  CrView lc;
+  lc.nsb = M; lc.B = B; lc.D = sD; lc.L = sL; lc.Dinv = sDinv; lc.Gl = sGl; lc.Gr = sGr;
+  double* lw = (w != nullptr) ? sw : nullptr;
+  int s_last = 0;
+  for (int s = 1; s < M; s *= 2) {
+    for (int q = wave;; q += NW) {
+      const int k = s * (2 * q + 1);
+      if (k >= M) break;
+      cr_eliminate_node<B>(lc, s, k, lane);
+    }
+    __syncthreads();
+    for (int q = wave;; q += NW) {
+      const int j = 2 * s * q;
+      if (j >= M) break;
+      cr_update_node<B>(lc, s, j, lane, lw, nrhs, lstride);
+    }
+    __syncthreads();
+    s_last = s;
+  }
+  if (wave == 0) cr_root_node<B>(lc, lane);
+  __syncthreads();
+  if (x != nullptr) {
+    if ((int)threadIdx.x < B * nrhs) {
+      const int vv = threadIdx.x / B, r = threadIdx.x % B;
+      double v = 0.0;
+#pragma unroll
+      for (int c = 0; c < B; ++c) v += sDinv[r * B + c] * sw[lstride * vv + c];
+      sx[lstride * vv + r] = v;
+    }
+    __syncthreads();
+    for (int s = s_last; s >= 1; s /= 2) {
+      for (int vv = 0; vv < nrhs; ++vv)
+        for (int t = threadIdx.x;; t += kCrTopThreads) {
+          const int k = s * (2 * (t / B) + 1);
+          if (k >= M) break;
+          cr_backward_row<B>(lc, s, k, t % B, sw + lstride * vv, sx + lstride * vv);
+        }
+      __syncthreads();
+    }
+  }
+  for (int e = threadIdx.x; e < M * BB; e += kCrTopThreads) {
+    const int m = e / BB, q = e % BB;
+    const size_t g = (size_t)m * s_start * BB + q;
+    cr.Dinv[g] = sDinv[e]; cr.Gl[g] = sGl[e]; cr.Gr[g] = sGr[e];
+  }
+  if (w != nullptr)
+    for (int e = threadIdx.x; e < M * B * nrhs; e += kCrTopThreads) {
+      const int v = e / (M * B), r = e % (M * B);
+      const size_t g = stride * v + (size_t)(r / B) * s_start * B + (r % B);
+      w[g] = sw[(size_t)v * lstride + r];
+      if (x != nullptr) x[g] = sx[(size_t)v * lstride + r];
+    }
+}
+
+// forward sweep on right-hand sides (blockIdx.y selects the rhs, `stride` doubles apart):
+// w_j -= Gr[k1]^T w_k1 + Gl[k2]^T w_k2
+template <int B>
+__global__ void k_cr_forward(CrView cr, int s, double* __restrict__ w, size_t stride) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int q = t / B, c = t % B;
+  const int j = 2 * s * q;
+  if (j >= cr.nsb) return;
+  w += stride * blockIdx.y;
+  const int k1 = j - s, k2 = j + s;
+  double v = w[(size_t)j * B + c];
+  if (k1 >= 0) {
+    const double* G = cr.Gr + (size_t)k1 * B * B;
+    const double* wk = w + (size_t)k1 * B;
+#pragma unroll
+    for (int r = 0; r < B; ++r) v -= G[r * B + c] * wk[r];
+  }
+  if (k2 < cr.nsb) {
+    const double* G = cr.Gl + (size_t)k2 * B * B;
+    const double* wk = w + (size_t)k2 * B;
+#pragma unroll
+    for (int r = 0; r < B; ++r) v -= G[r * B + c] * wk[r];
+  }
+  w[(size_t)j * B + c] = v;
+}
+
+// back substitution: x_k = Dinv_k w_k - Gl_k x_{k-s} - Gr_k x_{k+s}
+template <int B>
+__global__ void k_cr_backward(CrView cr, int s, const double* __restrict__ w, double* __restrict__ x, size_t stride) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int q = t / B, r = t % B;
+  const int k = s * (2 * q + 1);
+  if (k >= cr.nsb) return;
+  cr_backward_row<B>(cr, s, k, r, w + stride * blockIdx.y, x + stride * blockIdx.y);
+}
+
+// The back-substitution is top-down, so once x is known at every multiple of S the S - 1 nodes between two such
+// neighbours form an independent subtree: one workgroup walks it through strides S/2 .. 1 with a barrier per level.
+// Replaces log2(S) latency-bound launches by one.
+constexpr int kCrTreeThreads = 256;
+template <int B>
+__global__ __launch_bounds__(kCrTreeThreads) void k_cr_backward_tree(CrView cr, int S, const double* w, double* x, int nrhs, size_t stride) {
+  // x of the interval's S + 1 nodes lives in LDS between the levels (one right-hand side at a time), so a level only
+  // waits for its own tile loads, not for the previous level's stores to come back from L2
+  extern __shared__ double sx[];                       // (S + 1) * B
+  const int base = blockIdx.x * S;
+  {
+    const int vv = blockIdx.y;                          // one right-hand side per workgroup row
+    const double* wv = w + stride * vv;
+    double* xv = x + stride * vv;
+    for (int t = threadIdx.x; t < 2 * B; t += kCrTreeThreads) {            // the two boundary nodes (known)
+      const int node = (t < B) ? base : base + S, r = t % B;
+      sx[(size_t)(node - base) * B + r] = (node < cr.nsb) ? xv[(size_t)node * B + r] : 0.0;
+    }
+    __syncthreads();
+    for (int s = S / 2; s >= 1; s /= 2) {
+      const int per = S / (2 * s);
+      for (int t = threadIdx.x; t < per * B; t += kCrTreeThreads) {
+        const int k = base + s * (2 * (t / B) + 1), r = t % B;
+        if (k < cr.nsb) {
+          const size_t off = (size_t)k * B * B;
+          const double* wk = wv + (size_t)k * B;
+          const double* xl = sx + (size_t)(k - s - base) * B;
+          const double* xr = sx + (size_t)(k + s - base) * B;             // zero-filled beyond the last node
+          double v = 0.0;
+#pragma unroll
+          for (int c = 0; c < B; ++c) {
+            v += cr.Dinv[off + r * B + c] * wk[c];
+            v -= cr.Gl[off + r * B + c] * xl[c];
+            if (k + s < cr.nsb) v -= cr.Gr[off + r * B + c] * xr[c];
+          }
+          sx[(size_t)(k - base) * B + r] = v;
+        }
+      }
+      __syncthreads();
+    }
+    for (int t = threadIdx.x; t < (S - 1) * B; t += kCrTreeThreads) {       // interior nodes go out once
+      const int node = base + 1 + t / B;
+      if (node < cr.nsb) xv[(size_t)node * B + t % B] = sx[(size_t)(node - base) * B + t % B];
+    }
+  }
+}
+
+template <int B>
+static void cr_backward_levels(hipStream_t st, const CrView& cr, int s_from, const double* w, double* x, int nrhs, size_t stride) {
+  // strides s_from, s_from / 2 .. 1: wide levels one launch each, the subtrees below stride kTree in one launch
+  constexpr int kTree = 64;
+  int s = s_from;
+  for (; s >= kTree; s /= 2) {
+    const int n_elim = (cr.nsb - s + 2 * s - 1) / (2 * s);
+    hipLaunchKernelGGL(k_cr_backward<B>, dim3((n_elim * B + 127) / 128, nrhs), dim3(128), 0, st, cr, s, w, x, stride);
+  }
+  if (s >= 1) {
+    const int S = 2 * s;
+    hipLaunchKernelGGL(k_cr_backward_tree<B>, dim3((cr.nsb + S - 1) / S, nrhs), dim3(kCrTreeThreads), sizeof(double) * (S + 1) * B, st, cr, S, w, x,
+                       nrhs, stride);
+  }
+}
+
+template <int B>
+__global__ void k_cr_root_solve(CrView cr, const double* __restrict__ w, double* __restrict__ x, size_t stride) {
+  const int r = threadIdx.x;
+  if (r >= B) return;
+  w += stride * blockIdx.x;
+  x += stride * blockIdx.x;
+  double v = 0.0;
+#pragma unroll
+  for (int c = 0; c < B; ++c) v += cr.Dinv[r * B + c] * w[c];
+  x[r] = v;
+}
+
+// first stride handled by the fused single-workgroup kernel: at most kCrTopNodes eliminations at that stride (one
+// per wave) and every tile of the nodes alive there resident in LDS
+constexpr int kCrTopNodes = 16;
+constexpr size_t kCrTopLdsBytes = 144 * 1024;
+static size_t cr_top_lds_bytes(int M, int B, int nrhs) { return sizeof(double) * ((size_t)5 * M * B * B + (size_t)2 * M * B * nrhs); }
+static int cr_top_start(int nsb, int B, int nrhs) {
+  int s = 1;
+  while (s < nsb && ((nsb - s + 2 * s - 1) / (2 * s) > kCrTopNodes || cr_top_lds_bytes((nsb + s - 1) / s, B, nrhs) > kCrTopLdsBytes)) s *= 2;
+  return s;
+}
+
+// x == nullptr: factorise only (w, if given, still receives the forward sweep)
+template <int B>
+static void cr_factor_t(hipStream_t st, const CrView& cr, double* w, double* x, int nrhs, size_t stride) {
+  const int nr = (w != nullptr) ? nrhs : 0;
+  const int s_top = cr_top_start(cr.nsb, B, nr);
+  if (s_top > 1) {
+    const int n_elim = (cr.nsb - 1 + 1) / 2;
+    hipLaunchKernelGGL(k_cr_invert<B>, dim3(n_elim), dim3(WAVE), 0, st, cr, 1);
+  }
+  for (int s = 1; s < s_top; s *= 2) {
+    const int n_surv = (cr.nsb + 2 * s - 1) / (2 * s);
+    const int invert_next = (2 * s < s_top) ? 1 : 0;    // the fused top kernel inverts its own nodes
+    hipLaunchKernelGGL(k_cr_level<B>, dim3(n_surv), dim3(WAVE), 0, st, cr, s, invert_next, w, nrhs, stride);
+  }
+  {
+    const int M = (cr.nsb + s_top - 1) / s_top;
+    const size_t lds_bytes = cr_top_lds_bytes(M, B, nr);
+    static bool raised = false;      // more than the default 64 KB of dynamic LDS needs to be asked for once
+    if (!raised) {
+      raised = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cr_top_lds<B>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)kCrTopLdsBytes) == hipSuccess;
+      if (!raised) (void)hipGetLastError();
+    }
+    if (lds_bytes <= (raised ? kCrTopLdsBytes : (size_t)64 * 1024))
+      hipLaunchKernelGGL(k_cr_top_lds<B>, dim3(1), dim3(kCrTopThreads), lds_bytes, st, cr, s_top, M, w, x, nr, stride);
+    else
+      hipLaunchKernelGGL(k_cr_top<B>, dim3(1), dim3(kCrTopThreads), 0, st, cr, s_top, w, x, nrhs, stride);
+  }
+  if (x != nullptr && s_top >= 2) cr_backward_levels<B>(st, cr, s_top / 2, w, x, nrhs, stride);
+}
+
+// back substitution only, any number of right-hand sides (after cr_fwd_t)
+template <int B>
+static void cr_back_t(hipStream_t st, const CrView& cr, const double* w, double* x, int nrhs, size_t stride) {
+  int s_last = 0;
+  for (int s = 1; s < cr.nsb; s *= 2) s_last = s;
+  hipLaunchKernelGGL(k_cr_root_solve<B>, dim3(nrhs), dim3(WAVE), 0, st, cr, w, x, stride);
+  if (s_last >= 1) cr_backward_levels<B>(st, cr, s_last, w, x, nrhs, stride);
+}
+
+template <int B>
+static void cr_fwd_t(hipStream_t st, const CrView& cr, double* w, int nrhs, size_t stride) {
+  for (int s = 1; s < cr.nsb; s *= 2) {
+    const int n_surv = (cr.nsb + 2 * s - 1) / (2 * s);
+    hipLaunchKernelGGL(k_cr_forward<B>, dim3((n_surv * B + 127) / 128, nrhs), dim3(128), 0, st, cr, s, w, stride);
+  }
+}
+
+template <int B>
+static void cr_solve_t(hipStream_t st, const CrView& cr, double* w, double* x, int nrhs, size_t stride) {
+  cr_fwd_t<B>(st, cr, w, nrhs, stride);
+  cr_back_t<B>(st, cr, w, x, nrhs, stride);
+}
+
+void launch_cr_factor(hipStream_t st, const CrView& cr) {
+  switch (cr.B) {
+    case 3: cr_factor_t<3>(st, cr, nullptr, nullptr, 0, 0); break;
+    case 6: cr_factor_t<6>(st, cr, nullptr, nullptr, 0, 0); break;
+    case 9: cr_factor_t<9>(st, cr, nullptr, nullptr, 0, 0); break;
+    default: cr_factor_t<12>(st, cr, nullptr, nullptr, 0, 0); break;
+  }
+}
+
+void launch_cr_factor_solve(hipStream_t st, const CrView& cr, double* w, double* x, int nrhs, size_t stride) {
+  // nrhs right-hand sides `stride` doubles apart ride through the factorisation
+  switch (cr.B) {
+    case 3: cr_factor_t<3>(st, cr, w, x, nrhs, stride); break;
+    case 6: cr_factor_t<6>(st, cr, w, x, nrhs, stride); break;
+    case 9: cr_factor_t<9>(st, cr, w, x, nrhs, stride); break;
+    default: cr_factor_t<12>(st, cr, w, x, nrhs, stride); break;
+  }
+}
+
+void launch_cr_solve_multi(hipStream_t st, const CrView& cr, double* w, double* x, int nrhs, size_t stride) {
+  switch (cr.B) {
+    case 3: cr_solve_t<3>(st, cr, w, x, nrhs, stride); break;
+    case 6: cr_solve_t<6>(st, cr, w, x, nrhs, stride); break;
+    case 9: cr_solve_t<9>(st, cr, w, x, nrhs, stride); break;
+    default: cr_solve_t<12>(st, cr, w, x, nrhs, stride); break;
+  }
+}
+
+void launch_cr_solve(hipStream_t st, const CrView& cr, double* w, double* x) {
+  launch_cr_solve_multi(st, cr, w, x, 1, 0);
+}
+
+// ===========================================================================================
+// Selected inversion through the cyclic-reduction factors: the diagonal super-blocks of A^-1.
+// A node k eliminated at stride s between survivors a = k - s and b = k + s satisfies
+//     x_k = Dinv_k w_k - Gl_k x_a - Gr_k x_b ,
+// so with Sigma = A^-1 and the blocks of the coarser level (Sigma_aa, Sigma_bb, Sigma_ab) known,
+//     M1 = Gl Sigma_aa + Gr Sigma_ab^T        M2 = Gl Sigma_ab + Gr Sigma_bb
+//     Sigma_kk = Dinv_k + M1 Gl^T + M2 Gr^T    Sigma_ak = -M1^T      Sigma_kb = -M2
+// which are exactly the blocks the next finer level needs (a,k and k,b are adjacent there).
+// Sd[node] = Sigma_node,node; So[node] = Sigma between node and its right neighbour at the level
+// processed last.  One launch per level, one wave per eliminated node; ~log2(nsb) launches.
+// ===========================================================================================
+template <int B>
+__global__ __launch_bounds__(WAVE) void k_cr_selinv_level(CrView cr, int s, double* Sd, double* So) {
+  __shared__ double sGl[B * B], sGr[B * B], sAA[B * B], sBB[B * B], sAB[B * B], sM1[B * B], sM2[B * B];
+  const int k = s * (2 * blockIdx.x + 1);
+  if (k >= cr.nsb) return;
+  const size_t BB = (size_t)B * B;
+  const int a = k - s, b = k + s;
+  const bool has_b = b < cr.nsb;
+  lds_load<B>(sGl, cr.Gl + (size_t)k * BB);
+  lds_load<B>(sAA, Sd + (size_t)a * BB);
+  if (has_b) { lds_load<B>(sGr, cr.Gr + (size_t)k * BB); lds_load<B>(sBB, Sd + (size_t)b * BB); lds_load<B>(sAB, So + (size_t)a * BB); }
+  else for (int e = threadIdx.x; e < B * B; e += WAVE) { sGr[e] = 0.0; sBB[e] = 0.0; sAB[e] = 0.0; }
+  __syncthreads();
+  for (int e = threadIdx.x; e < B * B; e += WAVE) {
+    const int r = e / B, c = e % B;
+    double m1 = 0.0, m2 = 0.0;
+#pragma unroll
+    for (int q = 0; q < B; ++q) {
+      m1 += sGl[r * B + q] * sAA[q * B + c] + sGr[r * B + q] * sAB[c * B + q];
+      m2 += sGl[r * B + q] * sAB[q * B + c] + sGr[r * B + q] * sBB[q * B + c];
+    }
+    sM1[e] = m1; sM2[e] = m2;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < B * B; e += WAVE) {
+    const int r = e / B, c = e % B;
+    double v = cr.Dinv[(size_t)k * BB + e];
+#pragma unroll
+    for (int q = 0; q < B; ++q) v += sM1[r * B + q] * sGl[c * B + q] + sM2[r * B + q] * sGr[c * B + q];
+    Sd[(size_t)k * BB + e] = v;
+    So[(size_t)a * BB + e] = -sM1[c * B + r];
+    if (has_b) So[(size_t)k * BB + e] = -sM2[e];
+  }
+}
+
+template <int B>
+static void cr_selinv_t(hipStream_t st, const CrView& cr, double* Sd, double* So) {
+  (void)hipMemcpyAsync(Sd, cr.Dinv, sizeof(double) * B * B, hipMemcpyDeviceToDevice, st);   // root
+  int s_last = 0;
+  for (int s = 1; s < cr.nsb; s *= 2) s_last = s;
+  for (int s = s_last; s >= 1; s /= 2) {
+    const int n_elim = (cr.nsb - s + 2 * s - 1) / (2 * s);
+    hipLaunchKernelGGL(k_cr_selinv_level<B>, dim3(n_elim), dim3(WAVE), 0, st, cr, s, Sd, So);
+  }
+}
+
+void launch_cr_selinv(hipStream_t st, const CrView& cr, double* Sd, double* So) {
+  switch (cr.B) {
+    case 3: cr_selinv_t<3>(st, cr, Sd, So); break;
+    case 6: cr_selinv_t<6>(st, cr, Sd, So); break;
+    case 9: cr_selinv_t<9>(st, cr, Sd, So); break;
+    default: cr_selinv_t<12>(st, cr, Sd, So); break;
+  }
+}
+
+// pose i: its 3x3 block of S Sigma S, rotated into the robot frame as vector_mapping.cpp:2792-2801 does
+// (transform = blockdiag(Rotation2Df(-angle).cast<double>(), 1); one_cov = transform * one_cov * transform^T)
+__global__ void k_cov_extract(int n_poses, int Wb, int B, const double* __restrict__ Sd, const double* __restrict__ scale,
+                              const unsigned char* __restrict__ fixed, const float2* __restrict__ rot, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_poses) return;
+  double* o = out + 9 * (size_t)i;
+  if (fixed[i]) { for (int e = 0; e < 9; ++e) o[e] = 0.0; return; }
+  const int k = i / Wb, a0 = 3 * (i % Wb);
+  const double* blk = Sd + (size_t)k * B * B;
+  double S[3][3];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) S[r][c] = blk[(a0 + r) * B + a0 + c] * scale[3 * i + r] * scale[3 * i + c];
+  const double c = (double)rot[i].x, sn = (double)rot[i].y;     // cos, sin of -angle (fp32 values)
+  const double T[3][3] = {{c, -sn, 0.0}, {sn, c, 0.0}, {0.0, 0.0, 1.0}};
+  double M[3][3];
+  for (int r = 0; r < 3; ++r)
+    for (int q = 0; q < 3; ++q) M[r][q] = T[r][0] * S[0][q] + T[r][1] * S[1][q] + T[r][2] * S[2][q];
+  for (int r = 0; r < 3; ++r)
+    for (int q = 0; q < 3; ++q) o[3 * r + q] = M[r][0] * T[q][0] + M[r][1] * T[q][1] + M[r][2] * T[q][2];
+}
+
+void launch_cov_extract(hipStream_t st, int n_poses, int Wb, int B, const double* Sd, const double* scale, const unsigned char* fixed,
+                        const float2* rot, double* out) {
+  hipLaunchKernelGGL(k_cov_extract, dim3((n_poses + 127) / 128), dim3(128), 0, st, n_poses, Wb, B, Sd, scale, fixed, rot, out);
+}
+
+}  // namespace hitl

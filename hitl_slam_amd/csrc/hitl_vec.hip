@@ -1,0 +1,274 @@
+// hitl_vec.hip -- band products and vector kernels around the cyclic-reduction solve: k_spmv (PCG product, residual
+// check, trust-region bookkeeping), the submap interface helpers (unit right-hand sides, interface gather, combine,
+// halo scatter), dots / axpby / copy for the PCG.  fp64.
+
+#include "hitl_device.h"
+
+namespace hitl {
+
+// ===========================================================================================
+// y = (S H S [+ D^2]) v : band blocks (both triangles) + off-band blocks, one thread per pose.
+// MODE 0: plain product (PCG).
+// MODE 1: residual check after the cyclic-reduction solve: y -> r = rhs - A v, per-workgroup
+//         partials (r.r, rhs.rhs) in slots 0,1 of the 8-wide record.
+// MODE 2: trust-region step bookkeeping, fused: q = (S H S) v (no damping), partials
+//         (v.rhs, v.q, sum (s v)^2 over free poses, sum x^2 over free poses, #non-finite) in
+//         slots 2..6, and the candidate state xc = x + s*v.
+// The host adds the few hundred per-workgroup partials in index order (bit-reproducible).
+// ===========================================================================================
+struct SpmvAux {
+  const double* rhs;   // MODE 1, 2
+  double* r_out;       // MODE 1
+  const double* x;     // MODE 2
+  double* xc;          // MODE 2
+  double* partials;    // MODE 1, 2 : [gridDim.x][8]
+};
+
+template <int MODE>
+__global__ __launch_bounds__(128) void k_spmv(int n_poses, int npad, FactorView fv, LinView lin,
+                                               const double* __restrict__ scale, double mu, double min_diag,
+                                               double max_diag, const double* __restrict__ v, double* __restrict__ y,
+                                               SpmvAux aux) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  // MODE 3 = MODE 1 and MODE 2 in one pass (banded single-GPU solve: v is exactly 0 on constant poses, so including
+  // their columns changes nothing): residual partials in slots 0,1 and the step bookkeeping in slots 2..6
+  constexpr bool kRes = (MODE == 1 || MODE == 3), kStep = (MODE == 2 || MODE == 3);
+  double part[7] = {0, 0, 0, 0, 0, 0, 0};
+  if (3 * i < npad) {
+    if (i >= n_poses || fv.fixed[i]) {  // padding rows and constant poses: identity rows
+      for (int c = 0; c < 3; ++c) {
+        const int t = 3 * i + c;
+        if (t < npad) {
+          if (MODE == 0) y[t] = v[t];
+          if (kRes) { const double r = aux.rhs[t] - v[t]; if (MODE == 1) aux.r_out[t] = r; part[0] += r * r; part[1] += aux.rhs[t] * aux.rhs[t]; }
+          if (kStep) { y[t] = v[t]; if (i < n_poses) aux.xc[t] = aux.x[t]; }
+        }
+      }
+    } else {
+      // Columns of constant poses are not part of the linear system (MODE 0/1).  In MODE 2 they
+      // ARE included: v then carries the neighbouring submap's step on the halo poses (0 for pose 0),
+      // so owned rows see the cross-cut coupling in the model cost change.
+      const int Wb = fv.band_poses, W1 = Wb + 1;
+      double acc[3] = {0, 0, 0};
+      const double* Hi = lin.Hband + (size_t)i * W1 * 9;
+      for (int d = 0; d <= Wb && i + d < n_poses; ++d) {
+        const int j = i + d;
+        if (!kStep && fv.fixed[j]) continue;
+        const double* blk = Hi + d * 9;
+        const double v0 = scale[3 * j] * v[3 * j], v1 = scale[3 * j + 1] * v[3 * j + 1], v2 = scale[3 * j + 2] * v[3 * j + 2];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) acc[a] += blk[a * 3] * v0 + blk[a * 3 + 1] * v1 + blk[a * 3 + 2] * v2;
+      }
+      for (int d = 1; d <= Wb && i - d >= 0; ++d) {
+        const int j = i - d;
+        if (!kStep && fv.fixed[j]) continue;
+        const double* blk = lin.Hband + ((size_t)j * W1 + d) * 9;  // block (j, i), used transposed
+        const double v0 = scale[3 * j] * v[3 * j], v1 = scale[3 * j + 1] * v[3 * j + 1], v2 = scale[3 * j + 2] * v[3 * j + 2];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) acc[a] += blk[a] * v0 + blk[3 + a] * v1 + blk[6 + a] * v2;
+      }
+      if (fv.with_stf && fv.n_offband > 0) {
+        for (int e = fv.obadj_off[i]; e < fv.obadj_off[i + 1]; ++e) {
+          const int ent = fv.obadj_ent[e];
+          const int en = ent >> 1, tr = ent & 1;
+          const double* blk = lin.obblk + (size_t)en * 9;
+          const int j = tr ? fv.ob_lo[en] : fv.ob_hi[en];
+          if (!kStep && fv.fixed[j]) continue;
+          const double v0 = scale[3 * j] * v[3 * j], v1 = scale[3 * j + 1] * v[3 * j + 1], v2 = scale[3 * j + 2] * v[3 * j + 2];
+          if (!tr) {
+            for (int a = 0; a < 3; ++a) acc[a] += blk[a * 3] * v0 + blk[a * 3 + 1] * v1 + blk[a * 3 + 2] * v2;
+          } else {
+            for (int a = 0; a < 3; ++a) acc[a] += blk[a] * v0 + blk[3 + a] * v1 + blk[6 + a] * v2;
+          }
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const int t = 3 * i + a;
+        const double sa = scale[t];
+        const double rq = sa * acc[a];              // (S H S v)[t]
+        double r = rq;
+        if (MODE != 2 && mu > 0.0) {
+          const double dg = sa * sa * Hi[a * 3 + a];
+          r += fmin(fmax(dg, min_diag), max_diag) / mu * v[t];
+        }
+        if (MODE == 0) y[t] = r;
+        if (kRes) {
+          const double b = aux.rhs[t], res = b - r;
+          if (MODE == 1) aux.r_out[t] = res;
+          part[0] += res * res; part[1] += b * b;
+        }
+        if (kStep) {
+          constexpr int o = (MODE == 3) ? 2 : 0;
+          const double vt = v[t];
+          const double dl = sa * vt, xt = aux.x[t];
+          y[t] = rq;
+          part[o + 0] += vt * aux.rhs[t];
+          part[o + 1] += vt * rq;
+          part[o + 2] += dl * dl; part[o + 3] += xt * xt;
+          aux.xc[t] = xt + dl;
+          if (!isfinite(vt)) part[o + 4] += 1.0;
+        }
+      }
+    }
+  }
+  if (MODE != 0) {
+    __shared__ double sm[2][7];
+    const int wv = threadIdx.x >> 6;
+    constexpr int NP = (MODE == 1) ? 2 : (MODE == 2 ? 5 : 7);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const double t = wave_sum(part[k]);
+      if ((threadIdx.x & 63) == 0) sm[wv][k] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < NP) aux.partials[(size_t)blockIdx.x * 8 + (MODE == 2 ? 2 : 0) + threadIdx.x] = sm[0][threadIdx.x] + sm[1][threadIdx.x];
+  }
+}
+
+int spmv_blocks(int npad) { return ((npad + 2) / 3 + 127) / 128; }
+
+void launch_spmv(hipStream_t st, int n_poses, int npad, const FactorView& fv, const LinView& lin, const double* scale,
+                 double mu, double min_diag, double max_diag, const double* v, double* y) {
+  SpmvAux aux = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipLaunchKernelGGL(k_spmv<0>, dim3(spmv_blocks(npad)), dim3(128), 0, st, n_poses, npad, fv, lin, scale, mu, min_diag,
+                     max_diag, v, y, aux);
+}
+
+void launch_spmv_residual(hipStream_t st, int n_poses, int npad, const FactorView& fv, const LinView& lin,
+                          const double* scale, double mu, double min_diag, double max_diag, const double* v,
+                          const double* rhs, double* r_out, double* partials) {
+  SpmvAux aux = {rhs, r_out, nullptr, nullptr, partials};
+  hipLaunchKernelGGL(k_spmv<1>, dim3(spmv_blocks(npad)), dim3(128), 0, st, n_poses, npad, fv, lin, scale, mu, min_diag,
+                     max_diag, v, (double*)nullptr, aux);
+}
+
+void launch_spmv_residual_step(hipStream_t st, int n_poses, int npad, const FactorView& fv, const LinView& lin, const double* scale, double mu,
+                               double min_diag, double max_diag, const double* v, const double* rhs, const double* x, double* q, double* xc,
+                               double* partials) {
+  SpmvAux aux = {rhs, nullptr, x, xc, partials};
+  hipLaunchKernelGGL(k_spmv<3>, dim3(spmv_blocks(npad)), dim3(128), 0, st, n_poses, npad, fv, lin, scale, mu, min_diag, max_diag, v, q, aux);
+}
+
+void launch_spmv_step(hipStream_t st, int n_poses, int npad, const FactorView& fv, const LinView& lin,
+                      const double* scale, const double* dt, const double* rhs, const double* x, double* q, double* xc,
+                      double* partials) {
+  SpmvAux aux = {rhs, nullptr, x, xc, partials};
+  hipLaunchKernelGGL(k_spmv<2>, dim3(spmv_blocks(npad)), dim3(128), 0, st, n_poses, npad, fv, lin, scale, 0.0, 0.0, 0.0, dt,
+                     q, aux);
+}
+
+// ===========================================================================================
+// small vector kernels
+// ===========================================================================================
+// submap exchange helpers --------------------------------------------------------------------
+// unit right-hand sides for the interface solve: w[r][*] = 0 except w[r][cols[r]] = 1  (r < ncols)
+__global__ void k_unit_rhs(int npad, double* __restrict__ w, size_t stride, const int* __restrict__ cols) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= npad) return;
+  const int r = blockIdx.y;
+  w[stride * r + t] = (t == cols[r]) ? 1.0 : 0.0;
+}
+
+void launch_unit_rhs(hipStream_t st, int npad, double* w, size_t stride, const int* cols_dev, int ncols) {
+  hipLaunchKernelGGL(k_unit_rhs, dim3((npad + 255) / 256, ncols), dim3(256), 0, st, npad, w, stride, cols_dev);
+}
+
+// interface rows of z0, of the ncols unit-rhs solutions and of the Jacobi scale:
+// out[0..nc) = z0[cols], out[nc + nc*c + r] = Z[c][cols[r]], out[nc + nc*nc + r] = scale[cols[r]]
+__global__ void k_gather_iface(const double* __restrict__ z0, const double* __restrict__ Z, size_t stride,
+                               const double* __restrict__ scale, const int* __restrict__ cols, int nc,
+                               double* __restrict__ out) {
+  for (int t = threadIdx.x; t < nc * (nc + 2); t += blockDim.x) {
+    if (t < nc) out[t] = z0[cols[t]];
+    else if (t < nc + nc * nc) { const int c = (t - nc) / nc, r = (t - nc) % nc; out[t] = Z[stride * c + cols[r]]; }
+    else out[t] = scale[cols[t - nc - nc * nc]];
+  }
+}
+
+void launch_gather_iface(hipStream_t st, const double* z0, const double* Z, size_t stride, const double* scale,
+                         const int* cols_dev, int ncols, double* out) {
+  hipLaunchKernelGGL(k_gather_iface, dim3(1), dim3(256), 0, st, z0, Z, stride, scale, cols_dev, ncols, out);
+}
+
+// dt = z0 - sum_k coef[k] * Z[k]   (Z: ncols columns, `stride` apart; coef in device memory)
+__global__ void k_combine(int npad, const double* __restrict__ z0, const double* __restrict__ Z, size_t stride,
+                          const double* __restrict__ coef, int ncols, double* __restrict__ dt) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= npad) return;
+  double v = z0[t];
+  for (int k = 0; k < ncols; ++k) v -= coef[k] * Z[stride * k + t];
+  dt[t] = v;
+}
+
+void launch_combine(hipStream_t st, int npad, const double* z0, const double* Z, size_t stride, const double* coef_dev,
+                    int ncols, double* dt) {
+  hipLaunchKernelGGL(k_combine, dim3((npad + 255) / 256), dim3(256), 0, st, npad, z0, Z, stride, coef_dev, ncols, dt);
+}
+
+// halo poses (constant in the local system) take the neighbouring submap's step:
+// dt[idx[k]] = val[k], scale[idx[k]] = sc[k]  (k < cnt)
+__global__ void k_scatter_halo(int cnt, const int* __restrict__ idx, const double* __restrict__ val,
+                               const double* __restrict__ sc, double* __restrict__ dt, double* __restrict__ scale) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= cnt) return;
+  dt[idx[k]] = val[k];
+  scale[idx[k]] = sc[k];
+}
+
+void launch_scatter_halo(hipStream_t st, int cnt, const int* idx, const double* val, const double* sc, double* dt,
+                         double* scale) {
+  if (cnt <= 0) return;
+  hipLaunchKernelGGL(k_scatter_halo, dim3((cnt + 63) / 64), dim3(64), 0, st, cnt, idx, val, sc, dt, scale);
+}
+
+// candidate state of the halo poses: xc = x + scale * dt  (k_spmv<2> leaves xc = x on constant poses)
+__global__ void k_halo_candidate(int cnt, const int* __restrict__ idx, const double* __restrict__ x,
+                                 const double* __restrict__ scale, const double* __restrict__ dt, double* __restrict__ xc) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= cnt) return;
+  const int t = idx[k];
+  xc[t] = x[t] + scale[t] * dt[t];
+}
+
+void launch_halo_candidate(hipStream_t st, int cnt, const int* idx, const double* x, const double* scale, const double* dt,
+                           double* xc) {
+  if (cnt <= 0) return;
+  hipLaunchKernelGGL(k_halo_candidate, dim3((cnt + 63) / 64), dim3(64), 0, st, cnt, idx, x, scale, dt, xc);
+}
+
+struct DotArgs { const double* a[4]; const double* b[4]; };
+
+__global__ __launch_bounds__(kRedBlock) void k_dots(int n, int ndots, DotArgs args, double* out) {
+  __shared__ double sm[kRedBlock / WAVE];
+  for (int k = 0; k < ndots; ++k) {
+    double s = 0.0;
+    const double* a = args.a[k];
+    const double* b = args.b[k];
+    for (int t = threadIdx.x; t < n; t += kRedBlock) s += a[t] * b[t];
+    s = block_sum(s, sm);
+    if (threadIdx.x == 0) out[k] = s;
+  }
+}
+
+void launch_dots(hipStream_t st, int n, int ndots, const double* const* a, const double* const* b, double* out) {
+  DotArgs args;
+  for (int k = 0; k < 4; ++k) { args.a[k] = a[k < ndots ? k : 0]; args.b[k] = b[k < ndots ? k : 0]; }
+  hipLaunchKernelGGL(k_dots, dim3(1), dim3(kRedBlock), 0, st, n, ndots, args, out);
+}
+
+__global__ void k_axpby(int n, double alpha, const double* __restrict__ x, double beta, double* __restrict__ y) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  y[t] = alpha * x[t] + ((beta != 0.0) ? beta * y[t] : 0.0);
+}
+
+void launch_axpby(hipStream_t st, int n, double alpha, const double* x, double beta, double* y) {
+  hipLaunchKernelGGL(k_axpby, dim3((n + 255) / 256), dim3(256), 0, st, n, alpha, x, beta, y);
+}
+
+void launch_copy(hipStream_t st, int n, const double* src, double* dst) {
+  (void)hipMemcpyAsync(dst, src, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st);
+}
+
+}  // namespace hitl
