@@ -1,0 +1,140 @@
+// hitl_corr.cpp -- host driver of the correspondence search (FindSTFCorrespondences, JointOptimization.cpp:561-642):
+// candidate pose pairs and their fp32 relative transforms (host libm, bit-identical to the CPU restatement), k_match,
+// the pair filter and the ordered compaction into the packed match list.
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <thread>
+
+#include "hitl_solver_impl.h"
+
+using namespace hitl;
+
+namespace hitl {
+
+// ---------------------------------------------------------------------------------------
+// correspondence search driver
+// ---------------------------------------------------------------------------------------
+static void make_rel_tf(const float* pi, const float* pj, const float* csi, const float* csj, float* t) {
+  // RelativePoseTransform (JointOptimization.cpp:296-305) and the normal rotation at :603-605
+  // in fp32; R_j^T stands in for Eigen's general 2x2 inverse (fp32-rounding-level deviation).
+  // cs = (cosf, sinf) of each pose angle, computed once per pose by the caller.
+  const float ci = csi[0], si = csi[1], cj = csj[0], sj = csj[1];
+  t[0] = cj * ci + sj * si; t[1] = sj * ci - cj * si;
+  t[2] = cj * si - sj * ci; t[3] = sj * si + cj * ci;
+  const float dx = pi[0] - pj[0], dy = pi[1] - pj[1];
+  t[4] = cj * dx + sj * dy; t[5] = cj * dy - sj * dx;
+  const float dth = (float)((double)pj[2] - (double)pi[2]);
+  t[6] = cosf(dth); t[7] = sinf(dth);
+}
+
+int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
+  HIP_TRY(hipSetDevice(s->device));
+  const bool timing = std::getenv("HITL_TIMING") != nullptr;
+  auto t_prev = std::chrono::steady_clock::now();
+  auto mark = [&](const char* what) {
+    if (!timing) return;
+    const auto t = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "find_correspondences: %-22s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+    t_prev = t;
+  };
+  const int n = s->n;
+  if (window <= 0 || window > n) window = n;
+  const int slots = (int)std::min<int64_t>(2 * window, std::max(n - 1, 1));
+  const size_t table_entries = (size_t)n * slots * s->max_scan;
+  if (table_entries * sizeof(uint16_t) > (size_t)64 << 30)
+    return fail(HITL_ERR_OUT_OF_MEMORY, "candidate table would exceed 64 GiB; use a smaller window");
+  std::vector<int> cand_tgt((size_t)n * slots, -1);
+  std::vector<float> cand_tf((size_t)n * slots * 8, 0.f);
+  std::vector<float> cs((size_t)2 * n);
+  {
+    // candidate transforms: fp32 host libm (bit-identical to the CPU restatement), spread over a few threads
+    const int nt = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    auto run = [&](auto&& body) {
+      std::vector<std::thread> th;
+      for (int t = 1; t < nt; ++t) th.emplace_back([&, t]() { body((int64_t)n * t / nt, (int64_t)n * (t + 1) / nt); });
+      body(0, (int64_t)n / nt);
+      for (auto& x : th) x.join();
+    };
+    run([&](int64_t a, int64_t b) { for (int64_t i = a; i < b; ++i) { cs[2 * i] = cosf(poses[3 * i + 2]); cs[2 * i + 1] = sinf(poses[3 * i + 2]); } });
+    run([&](int64_t a, int64_t b) {
+      for (int64_t i = a; i < b; ++i) {
+        int slot = 0;
+        const int64_t j0 = std::max<int64_t>(0, i - window), j1 = std::min<int64_t>(n - 1, i + window);
+        for (int64_t j = j0; j <= j1; ++j) {
+          if (j == i) continue;
+          cand_tgt[(size_t)i * slots + slot] = (int)j;
+          make_rel_tf(poses + 3 * i, poses + 3 * j, &cs[2 * i], &cs[2 * j], &cand_tf[((size_t)i * slots + slot) * 8]);
+          ++slot;
+        }
+      }
+    });
+  }
+  mark("candidate transforms");
+  hipStream_t st = s->stream;
+  DevArray<int> d_tgt, d_counts, d_kept;
+  DevArray<float> d_tf;
+  DevArray<uint16_t> d_table;
+  int rc = HITL_OK;
+  auto cleanup = [&]() { d_tgt.release(); d_counts.release(); d_kept.release(); d_tf.release(); d_table.release(); };
+#define TRYC(expr) do { rc = (expr); if (rc != HITL_OK) { cleanup(); return rc; } } while (0)
+  TRYC(d_tgt.upload(cand_tgt, st));
+  TRYC(d_tf.upload(cand_tf, st));
+  TRYC(d_counts.resize((size_t)n * slots));
+  TRYC(d_counts.zero(st));
+  TRYC(d_table.resize(table_entries));
+  mark("uploads + table alloc");
+  MatchParams mp;
+  mp.thr = s->opt.point_match_threshold;
+  mp.min_cos = cosf(s->opt.max_stf_angle_error);   // JointOptimization.cpp:564
+  mp.cap = s->opt.max_correspondences_per_point;
+  mp.skip = std::max(s->opt.num_skip_readings, 1);
+  const MapView mv = s->map_view();
+  launch_match(st, mv, s->max_scan, slots, d_tgt.p, d_tf.p, mp, d_table.p, d_counts.p);
+  std::vector<int> counts((size_t)n * slots);
+  if (hipMemcpyAsync(counts.data(), d_counts.p, counts.size() * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess) {
+    cleanup();
+    return fail(HITL_ERR_HIP, std::string("match kernel: ") + hipGetErrorString(hipGetLastError()));
+  }
+  mark("k_match + counts");
+  // keep pairs with more than kMinInterPoseCorrespondence matches (:632-634), pose order (:636-641)
+  std::vector<int> kept;
+  s->h_pair_src.clear(); s->h_pair_tgt.clear(); s->h_match_off.assign(1, 0);
+  for (int i = 0; i < n; ++i)
+    for (int sl = 0; sl < slots; ++sl) {
+      const size_t c = (size_t)i * slots + sl;
+      const int jt = cand_tgt[c];
+      const bool relevant = (i >= s->own_lo && i < s->own_hi) || (jt >= s->own_lo && jt < s->own_hi);   // halo-halo pairs belong to other ranks
+      if (jt >= 0 && relevant && counts[c] > s->opt.min_inter_pose_correspondence) {
+        kept.push_back((int)c);
+        s->h_pair_src.push_back(i); s->h_pair_tgt.push_back(cand_tgt[c]);
+        s->h_match_off.push_back(s->h_match_off.back() + counts[c]);
+      }
+    }
+  mark("pair filter");
+  s->n_pairs = (int)kept.size();
+  s->n_matches = s->h_match_off.back();
+  s->h_perm.resize(s->n_pairs);
+  std::iota(s->h_perm.begin(), s->h_perm.end(), 0);
+  TRYC(d_kept.upload(kept, st));
+  TRYC(s->pair_src.upload(s->h_pair_src, st));
+  TRYC(s->pair_tgt.upload(s->h_pair_tgt, st));
+  TRYC(s->match_off.upload(s->h_match_off, st));
+  TRYC(s->matches.resize((size_t)s->n_matches));
+  launch_compact(st, mv, s->max_scan, slots, s->n_pairs, d_kept.p, s->match_off.p, d_table.p, s->matches.p);
+  if (hipStreamSynchronize(st) != hipSuccess) { cleanup(); return fail(HITL_ERR_HIP, "compact kernel failed"); }
+  mark("uploads + k_compact");
+  cleanup();
+  mark("free");
+#undef TRYC
+  rc = build_pair_structures(s);
+  mark("pair structures");
+  return rc;
+}
+
+}  // namespace hitl

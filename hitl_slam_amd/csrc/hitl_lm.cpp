@@ -1,0 +1,531 @@
+// hitl_lm.cpp -- the Levenberg-Marquardt loop of libhitlgpu.so with Ceres' trust-region semantics:
+// linearisation passes, the linear solves (exact banded cyclic reduction, PCG for off-band pairs, the submap interface
+// system), the tiny all-gathers of the pose-range submaps.  Every O(N), O(P) or O(C) step is a HIP kernel; only a
+// handful of scalars per iteration cross to the host.  There is no CPU fallback anywhere in this file.
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "hitl_solver_impl.h"
+
+using namespace hitl;
+
+namespace hitl {
+
+
+// one pass over every factor at state xdev: residuals, Jacobians, J^T J blocks, gradient, cost.
+// enqueue_linearize only queues the kernels and the copy of the per-workgroup partials (behind the step partials in
+// the pinned buffer); finish_linearize adds them up once the stream has been synchronised.
+static int enqueue_linearize(hitl_solver* s, const FactorView& fv, const double* xdev, int buf) {
+  hipStream_t st = s->stream;
+  const MapView mv = s->map_view();
+  const PairView pv = s->pair_view();
+  const LinView lv = s->lin_view(buf);
+  if (fv.with_stf) launch_pose_trig(st, s->n, xdev, s->pose_cs.p);
+  // ev0..ev1 brackets exactly the k_linearize_stf launch.  An event record drains the queue (~6 us each), so at the
+  // default timing level only every 4th linearisation is bracketed; level 2 brackets all, level 0 none.
+  const int64_t tl = s->opt.timing_level;
+  s->lin_timed = fv.with_stf && (tl >= 2 || (tl == 1 && (s->lin_launches & 3) == 0));
+  ++s->lin_launches;
+  if (s->lin_timed) HIP_TRY(hipEventRecord(s->ev0, st));
+  if (fv.with_stf) {
+    if (s->opt.stf_moments)
+      launch_linearize_stf_moments(st, pv, s->pairM.p, xdev, s->pose_cs.p, s->opt.point_correlation_factor, s->opt.laser_std_dev, lv.pairRJ);
+    else
+      launch_linearize_stf(st, mv, pv, s->max_scan, xdev, s->pose_cs.p, s->opt.point_correlation_factor, s->opt.laser_std_dev, lv.pairRJ);
+  }
+  if (s->lin_timed) HIP_TRY(hipEventRecord(s->ev1, st));
+  launch_assemble(st, mv, pv, fv, xdev, lv);
+  HIP_TRY(hipGetLastError());
+  const int nblk = assemble_blocks(s->n);
+  double* host = s->h_partials + (size_t)spmv_blocks(s->npad) * 8;
+  HIP_TRY(hipMemcpyAsync(host, lv.partials, sizeof(double) * 2 * nblk, hipMemcpyDeviceToHost, st));
+  return HITL_OK;
+}
+
+static int finish_linearize(hitl_solver* s, const FactorView& fv, LinResult* out) {
+  const int nblk = assemble_blocks(s->n);
+  const double* host = s->h_partials + (size_t)spmv_blocks(s->npad) * 8;
+  double cost = 0.0, gmax = 0.0;
+  for (int b = 0; b < nblk; ++b) {   // fixed order: bit-reproducible
+    cost += host[2 * b];
+    const double g = host[2 * b + 1];
+    if (g > gmax || g != g) gmax = g;
+  }
+  out->cost = cost;
+  out->gmax = gmax;
+  out->stf_ms = 0.f;
+  out->timed = s->lin_timed ? 1 : 0;
+  if (s->lin_timed) HIP_TRY(hipEventElapsedTime(&out->stf_ms, s->ev0, s->ev1));
+  return HITL_OK;
+}
+
+// wait for the stream without sleeping on an interrupt: the LM loop turns around in tens of microseconds
+static int spin_sync(hitl_solver* s) {
+  HIP_TRY(hipEventRecord(s->ev_sync, s->stream));
+  for (;;) {
+    const hipError_t e = hipEventQuery(s->ev_sync);
+    if (e == hipSuccess) return HITL_OK;
+    if (e != hipErrorNotReady) return fail(HITL_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(e));
+  }
+}
+
+int run_linearize(hitl_solver* s, const FactorView& fv, const double* xdev, int buf, LinResult* out) {
+  TRY(enqueue_linearize(s, fv, xdev, buf));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return finish_linearize(s, fv, out);
+}
+
+// ---------------------------------------------------------------------------------------
+// pose-range submaps: tiny all-gathers on host buffers (RCCL built in, or a caller callback)
+// ---------------------------------------------------------------------------------------
+int comm_allgather(hitl_solver* s, const void* send, void* recv, int64_t bytes) {
+  if (s->world == 1 && !s->nccl && !s->comm.allgather) { std::memcpy(recv, send, (size_t)bytes); return HITL_OK; }
+  if (s->comm.allgather) {
+    const int rc = s->comm.allgather(s->comm.ctx, send, recv, bytes);
+    return rc == 0 ? HITL_OK : fail(HITL_ERR_COMM, "all-gather callback failed");
+  }
+  if (!s->nccl) return fail(HITL_ERR_NOT_READY, "world_size > 1 needs hitl_options.rccl_unique_id or hitl_solver_set_comm");
+  hipStream_t st = s->stream;
+  TRY(s->comm_send.resize((size_t)bytes));
+  TRY(s->comm_recv.resize((size_t)bytes * s->world));
+  HIP_TRY(hipMemcpyAsync(s->comm_send.p, send, (size_t)bytes, hipMemcpyHostToDevice, st));
+  const ncclResult_t r = ncclAllGather(s->comm_send.p, s->comm_recv.p, (size_t)bytes, ncclChar, s->nccl, st);
+  if (r != ncclSuccess) return fail(HITL_ERR_COMM, std::string("ncclAllGather: ") + ncclGetErrorString(r));
+  HIP_TRY(hipMemcpyAsync(recv, s->comm_recv.p, (size_t)bytes * s->world, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return HITL_OK;
+}
+
+static inline double nan_max(double a, double b) { return (b > a || b != b) ? b : a; }
+
+// local linearisation (every rank evaluates all factors touching its owned poses, so its rows are
+// complete) + the global cost and gradient max-norm
+static int run_linearize_dist(hitl_solver* s, const FactorView& fv, const double* xdev, int buf, LinResult* out) {
+  TRY(run_linearize(s, fv, xdev, buf, out));
+  if (s->world == 1) return HITL_OK;
+  const int W = s->world;
+  double rec[2] = {out->cost, out->gmax};
+  std::vector<double> all((size_t)2 * W);
+  TRY(comm_allgather(s, rec, all.data(), sizeof(rec)));
+  double cost = 0.0, gmax = 0.0;
+  for (int r = 0; r < W; ++r) {          // rank order on every rank: identical sums everywhere
+    cost += all[(size_t)2 * r];
+    gmax = nan_max(gmax, all[(size_t)2 * r + 1]);
+  }
+  out->cost = cost;
+  out->gmax = gmax;
+  return HITL_OK;
+}
+
+// dense solve with partial pivoting (the interface system, 6 * band * world unknowns)
+static bool solve_dense(int n, std::vector<double>& A, std::vector<double>& b) {
+  for (int c = 0; c < n; ++c) {
+    int piv = c;
+    for (int r = c + 1; r < n; ++r) if (std::fabs(A[(size_t)r * n + c]) > std::fabs(A[(size_t)piv * n + c])) piv = r;
+    if (!(std::fabs(A[(size_t)piv * n + c]) > 0.0)) return false;
+    if (piv != c) { for (int k = 0; k < n; ++k) std::swap(A[(size_t)c * n + k], A[(size_t)piv * n + k]); std::swap(b[c], b[piv]); }
+    for (int r = c + 1; r < n; ++r) {
+      const double f = A[(size_t)r * n + c] / A[(size_t)c * n + c];
+      if (f == 0.0) continue;
+      for (int k = c; k < n; ++k) A[(size_t)r * n + k] -= f * A[(size_t)c * n + k];
+      b[r] -= f * b[c];
+    }
+  }
+  for (int r = n - 1; r >= 0; --r) {
+    double v = b[r];
+    for (int k = r + 1; k < n; ++k) v -= A[(size_t)r * n + k] * b[k];
+    b[r] = v / A[(size_t)r * n + r];
+  }
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------
+// linear solve: PCG on (S H S + D^2) preconditioned by the exact block-cyclic-reduction
+// factorisation of its in-band part.  With no off-band pose pairs the preconditioner IS the
+// matrix and the first iterate is the exact LM step (what Ceres' sparse Cholesky returns).
+// ---------------------------------------------------------------------------------------
+struct StepScalars { double dt_rhs, dt_q, step2, xn2, bad; };
+
+static int enqueue_step_partials(hitl_solver* s) {
+  const int nblk = spmv_blocks(s->npad);
+  HIP_TRY(hipMemcpyAsync(s->h_partials, s->step_partials.p, sizeof(double) * 8 * nblk, hipMemcpyDeviceToHost, s->stream));
+  return HITL_OK;
+}
+
+static int finish_step_partials(hitl_solver* s, double* rr, double* bb, StepScalars* ss);
+
+static int read_step_partials(hitl_solver* s, double* rr, double* bb, StepScalars* ss) {
+  TRY(enqueue_step_partials(s));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return finish_step_partials(s, rr, bb, ss);
+}
+
+static int finish_step_partials(hitl_solver* s, double* rr, double* bb, StepScalars* ss) {
+  const int nblk = spmv_blocks(s->npad);
+  double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (int b = 0; b < nblk; ++b)
+    for (int k = 0; k < 7; ++k) acc[k] += s->h_partials[8 * b + k];
+  if (rr) *rr = acc[0];
+  if (bb) *bb = acc[1];
+  if (ss) { ss->dt_rhs = acc[2]; ss->dt_q = acc[3]; ss->step2 = acc[4]; ss->xn2 = acc[5]; ss->bad = acc[6]; }
+  return HITL_OK;
+}
+
+// Solve (S H S + D^2) dt = rhs, then form the trust-region bookkeeping (model cost change
+// pieces, step norm, candidate state) -- one host synchronisation in the banded case.
+static int linear_solve_and_step(hitl_solver* s, const FactorView& fv, int buf, double mu, const double* xcur,
+                                 double* xcand, int* iters, bool* ok, StepScalars* ss) {
+  hipStream_t st = s->stream;
+  const LinView lv = s->lin_view(buf);
+  const CrView cr = s->cr_view();
+  const double mind = s->opt.min_lm_diagonal, maxd = s->opt.max_lm_diagonal;
+  const int npad = s->npad;
+  const double tol = std::max(s->opt.linear_solver_tolerance, 1e-15);
+  launch_build_system(st, s->n, fv.band_poses, lv, s->scale.p, s->fixed.p, mu, mind, maxd, cr, s->rhs.p);
+  launch_copy(st, npad, s->rhs.p, s->wv.p);
+  launch_cr_factor_solve(st, cr, s->wv.p, s->dt.p);   // x0 = M^{-1} b
+  *iters = 1;
+  *ok = true;
+  // r = b - A x0 (partials of r.r and b.b); banded systems: x0 is the exact step up to rounding
+  launch_spmv_residual(st, s->n, npad, fv, lv, s->scale.p, mu, mind, maxd, s->dt.p, s->rhs.p, s->rv.p, s->step_partials.p);
+  if (fv.n_offband == 0) {
+    launch_spmv_step(st, s->n, npad, fv, lv, s->scale.p, s->dt.p, s->rhs.p, xcur, s->qv.p, xcand, s->step_partials.p);
+    HIP_TRY(hipGetLastError());
+    double rr, bb;
+    TRY(read_step_partials(s, &rr, &bb, ss));
+    const double guard = std::max(tol, 1e-9);
+    if (!(rr == rr) || rr > guard * guard * bb) *ok = false;   // the factorisation broke down
+    return HITL_OK;
+  }
+  // off-band pose pairs present: PCG on the full matrix from x0, preconditioned by the band factorisation
+  double rr, bb;
+  TRY(read_step_partials(s, &rr, &bb, nullptr));
+  const double target = tol * tol * bb;
+  if (!(rr == rr)) { *ok = false; return HITL_OK; }
+  double rz_old = 0.0;
+  for (int it = 0; it < s->opt.max_linear_iterations && rr > target; ++it) {
+    launch_copy(st, npad, s->rv.p, s->wv.p);
+    launch_cr_solve(st, cr, s->wv.p, s->zv.p);
+    const double* a1[4] = {s->rv.p, s->rv.p, s->rv.p, s->rv.p};
+    const double* b1[4] = {s->zv.p, s->zv.p, s->zv.p, s->zv.p};
+    launch_dots(st, npad, 1, a1, b1, s->d_scalars.p + 8);
+    HIP_TRY(hipMemcpyAsync(s->h_scalars + 8, s->d_scalars.p + 8, sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const double rz = s->h_scalars[8];
+    if (it == 0) launch_copy(st, npad, s->zv.p, s->pv.p);
+    else launch_axpby(st, npad, 1.0, s->zv.p, rz / rz_old, s->pv.p);
+    rz_old = rz;
+    launch_spmv(st, s->n, npad, fv, lv, s->scale.p, mu, mind, maxd, s->pv.p, s->qv.p);
+    const double* a2[4] = {s->pv.p, s->rv.p, s->pv.p, s->pv.p};
+    const double* b2[4] = {s->qv.p, s->rv.p, s->qv.p, s->qv.p};
+    launch_dots(st, npad, 1, a2, b2, s->d_scalars.p + 8);
+    HIP_TRY(hipMemcpyAsync(s->h_scalars + 8, s->d_scalars.p + 8, sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const double pq = s->h_scalars[8];
+    if (!(pq > 0.0)) { *ok = false; return HITL_OK; }
+    const double alpha = rz / pq;
+    launch_axpby(st, npad, alpha, s->pv.p, 1.0, s->dt.p);
+    launch_axpby(st, npad, -alpha, s->qv.p, 1.0, s->rv.p);
+    const double* a3[4] = {s->rv.p, s->rv.p, s->rv.p, s->rv.p};
+    launch_dots(st, npad, 1, a3, a3, s->d_scalars.p + 8);
+    HIP_TRY(hipMemcpyAsync(s->h_scalars + 8, s->d_scalars.p + 8, sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    rr = s->h_scalars[8];
+    ++*iters;
+    if (!(rr == rr)) { *ok = false; return HITL_OK; }
+  }
+  launch_spmv_step(st, s->n, npad, fv, lv, s->scale.p, s->dt.p, s->rhs.p, xcur, s->qv.p, xcand, s->step_partials.p);
+  HIP_TRY(hipGetLastError());
+  TRY(read_step_partials(s, nullptr, nullptr, ss));
+  return HITL_OK;
+}
+
+// Banded single-GPU case, queue only: the exact step, its residual check and the trust-region bookkeeping.  The caller
+// queues the linearisation at the candidate right behind it and synchronises once for both (the candidate does not
+// depend on any host decision; if the step turns out invalid the speculative linearisation is simply dropped).
+static int enqueue_linear_solve_banded(hitl_solver* s, const FactorView& fv, int buf, double mu, const double* xcur, double* xcand) {
+  hipStream_t st = s->stream;
+  const LinView lv = s->lin_view(buf);
+  const CrView cr = s->cr_view();
+  const double mind = s->opt.min_lm_diagonal, maxd = s->opt.max_lm_diagonal;
+  const int npad = s->npad;
+  launch_build_system(st, s->n, fv.band_poses, lv, s->scale.p, s->fixed.p, mu, mind, maxd, cr, s->rhs.p, s->wv.p);
+  launch_cr_factor_solve(st, cr, s->wv.p, s->dt.p);
+  // residual check of the factorisation and the trust-region bookkeeping in one pass over the band
+  launch_spmv_residual_step(st, s->n, npad, fv, lv, s->scale.p, mu, mind, maxd, s->dt.p, s->rhs.p, xcur, s->qv.p, xcand, s->step_partials.p);
+  HIP_TRY(hipGetLastError());
+  return HITL_OK;
+}
+
+// Submap version.  Rank g's unknowns x_g (owned poses) satisfy
+//     M_g x_g + E_F C_lo,g v_{g-1} + E_L C_up,g u_{g+1} = b_g
+// with M_g its own banded block (halo poses are constant locally), v_{g-1} / u_{g+1} the steps of
+// the previous rank's last Wi poses / the next rank's first Wi poses, and C_lo, C_up the cross-cut
+// Hessian blocks (assembled locally: every rank evaluates all factors touching its owned poses).
+// Each rank solves M_g Z = [b_g, E_F, E_L] in ONE multi-rhs cyclic-reduction pass, the ranks
+// all-gather the 2m interface rows (m = 3 Wi) of Z, their Jacobi scales and C_lo / C_up, and every
+// rank solves the same 2m*world dense interface system on the host:
+//     y_g + ZF_g (C~_lo,g v_{g-1}) + ZL_g (C~_up,g u_{g+1}) = z0_g ,   y_g = (u_g, v_g).
+// The coupling is eliminated exactly; no Schwarz / extra PCG iterations.
+static int linear_solve_and_step_dist(hitl_solver* s, const FactorView& fv, int buf, double mu, const double* xcur,
+                                      double* xcand, int* iters, bool* ok, StepScalars* ss, LinResult* spec) {
+  hipStream_t st = s->stream;
+  const LinView lv = s->lin_view(buf);
+  const CrView cr = s->cr_view();
+  const double mind = s->opt.min_lm_diagonal, maxd = s->opt.max_lm_diagonal;
+  const int npad = s->npad, n = s->n, W = s->world, me = s->rank;
+  const int Wb = fv.band_poses, Wi = s->Wi, m = 3 * Wi, nc = 2 * m, W1 = Wb + 1;
+  *iters = 1;
+  *ok = true;
+  launch_build_system(st, n, Wb, lv, s->scale.p, s->fixed.p, mu, mind, maxd, cr, s->rhs.p);
+  launch_copy(st, npad, s->rhs.p, s->rhsN.p);
+  launch_unit_rhs(st, npad, s->rhsN.p + npad, (size_t)npad, s->if_cols.p, nc);
+  launch_cr_factor_solve(st, cr, s->rhsN.p, s->zN.p, 1 + nc, (size_t)npad);   // z0 and Z = M^{-1} [E_F, E_L]
+  launch_copy(st, npad, s->zN.p, s->dt.p);
+  const double* Z = s->zN.p + npad;
+  launch_gather_iface(st, s->dt.p, Z, (size_t)npad, s->scale.p, s->if_cols.p, nc, s->iface_dev.p);
+  const int RI = nc * (nc + 2), RC = m * m, R = RI + 2 * RC;
+  std::vector<double> rec((size_t)R, 0.0);
+  HIP_TRY(hipMemcpyAsync(rec.data(), s->iface_dev.p, sizeof(double) * RI, hipMemcpyDeviceToHost, st));
+  // cross-cut blocks from the band: block (i, i+d) lives at Hband[i][d]
+  std::vector<double> hb_lo((size_t)Wi * W1 * 9, 0.0), hb_up((size_t)Wi * W1 * 9, 0.0);
+  if (me > 0) HIP_TRY(hipMemcpyAsync(hb_lo.data(), lv.Hband + (size_t)(s->own_lo - Wi) * W1 * 9, sizeof(double) * hb_lo.size(), hipMemcpyDeviceToHost, st));
+  if (me < W - 1) HIP_TRY(hipMemcpyAsync(hb_up.data(), lv.Hband + (size_t)(s->own_hi - Wi) * W1 * 9, sizeof(double) * hb_up.size(), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  double* Clo = rec.data() + RI;        // rows: first Wi owned poses, cols: the Wi halo poses below
+  double* Cup = Clo + RC;               // rows: last Wi owned poses,  cols: the Wi halo poses above
+  if (me > 0)
+    for (int ap = 0; ap < Wi; ++ap)
+      for (int bp = 0; bp < Wi; ++bp) {
+        const int d = (Wi + ap) - bp;   // a = own_lo + ap, b = own_lo - Wi + bp
+        if (d > Wb) continue;
+        const double* blk = &hb_lo[((size_t)bp * W1 + d) * 9];   // block (b, a): transpose it
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Clo[(size_t)(3 * ap + r) * m + 3 * bp + c] = blk[c * 3 + r];
+      }
+  if (me < W - 1)
+    for (int ap = 0; ap < Wi; ++ap)
+      for (int bp = 0; bp < Wi; ++bp) {
+        const int d = (Wi + bp) - ap;   // a = own_hi - Wi + ap, b = own_hi + bp
+        if (d > Wb) continue;
+        const double* blk = &hb_up[((size_t)ap * W1 + d) * 9];   // block (a, b)
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Cup[(size_t)(3 * ap + r) * m + 3 * bp + c] = blk[r * 3 + c];
+      }
+  std::vector<double> all((size_t)R * W);
+  TRY(comm_allgather(s, rec.data(), all.data(), sizeof(double) * R));
+  auto z0_of = [&](int g) { return &all[(size_t)R * g]; };
+  auto Z_of = [&](int g) { return &all[(size_t)R * g + nc]; };              // Z[c][r] = Z_of[nc*c + r]
+  auto sc_of = [&](int g) { return &all[(size_t)R * g + nc + nc * nc]; };   // [0,m): first Wi poses, [m,2m): last Wi
+  auto Clo_of = [&](int g) { return &all[(size_t)R * g + RI]; };
+  auto Cup_of = [&](int g) { return &all[(size_t)R * g + RI + RC]; };
+  // interface system
+  const int NI = nc * W;
+  std::vector<double> A((size_t)NI * NI, 0.0), y(NI, 0.0), Ct((size_t)m * m);
+  for (int g = 0; g < W; ++g) {
+    for (int r = 0; r < nc; ++r) { A[(size_t)(nc * g + r) * NI + nc * g + r] = 1.0; y[nc * g + r] = z0_of(g)[r]; }
+    if (g >= 1) {       // C~_lo,g = diag(s_first,g) C_lo,g diag(s_last,g-1); columns of v_{g-1}
+      for (int a = 0; a < m; ++a) for (int k = 0; k < m; ++k) Ct[(size_t)a * m + k] = sc_of(g)[a] * Clo_of(g)[(size_t)a * m + k] * sc_of(g - 1)[m + k];
+      for (int r = 0; r < nc; ++r)
+        for (int k = 0; k < m; ++k) {
+          double v = 0.0;
+          for (int c = 0; c < m; ++c) v += Z_of(g)[(size_t)nc * c + r] * Ct[(size_t)c * m + k];
+          A[(size_t)(nc * g + r) * NI + nc * (g - 1) + m + k] += v;
+        }
+    }
+    if (g + 1 < W) {    // C~_up,g = diag(s_last,g) C_up,g diag(s_first,g+1); columns of u_{g+1}
+      for (int a = 0; a < m; ++a) for (int k = 0; k < m; ++k) Ct[(size_t)a * m + k] = sc_of(g)[m + a] * Cup_of(g)[(size_t)a * m + k] * sc_of(g + 1)[k];
+      for (int r = 0; r < nc; ++r)
+        for (int k = 0; k < m; ++k) {
+          double v = 0.0;
+          for (int c = 0; c < m; ++c) v += Z_of(g)[(size_t)nc * (m + c) + r] * Ct[(size_t)c * m + k];
+          A[(size_t)(nc * g + r) * NI + nc * (g + 1) + k] += v;
+        }
+    }
+  }
+  if (!solve_dense(NI, A, y)) *ok = false;
+  // this rank's correction coefficients, and the neighbours' steps / scales for its halo poses
+  std::vector<double> coef(nc, 0.0), hval, hsc;
+  if (me >= 1) {
+    const double* vprev = &y[nc * (me - 1) + m];
+    for (int a = 0; a < m; ++a)
+      for (int k = 0; k < m; ++k) coef[a] += sc_of(me)[a] * Clo_of(me)[(size_t)a * m + k] * sc_of(me - 1)[m + k] * vprev[k];
+    for (int k = 0; k < m; ++k) { hval.push_back(vprev[k]); hsc.push_back(sc_of(me - 1)[m + k]); }
+  }
+  if (me + 1 < W) {
+    const double* unext = &y[nc * (me + 1)];
+    for (int a = 0; a < m; ++a)
+      for (int k = 0; k < m; ++k) coef[m + a] += sc_of(me)[m + a] * Cup_of(me)[(size_t)a * m + k] * sc_of(me + 1)[k] * unext[k];
+    for (int k = 0; k < m; ++k) { hval.push_back(unext[k]); hsc.push_back(sc_of(me + 1)[k]); }
+  }
+  const int nh = (int)hval.size();
+  HIP_TRY(hipMemcpyAsync(s->coef_dev.p, coef.data(), sizeof(double) * nc, hipMemcpyHostToDevice, st));
+  if (nh) {
+    HIP_TRY(hipMemcpyAsync(s->halo_val.p, hval.data(), sizeof(double) * nh, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->halo_sc.p, hsc.data(), sizeof(double) * nh, hipMemcpyHostToDevice, st));
+  }
+  launch_combine(st, npad, s->dt.p, Z, (size_t)npad, s->coef_dev.p, nc, s->dt.p);
+  launch_scatter_halo(st, nh, s->halo_idx.p, s->halo_val.p, s->halo_sc.p, s->dt.p, s->scale.p);
+  // model-cost pieces over the owned rows (halo columns carry the neighbours' steps), candidate state
+  launch_spmv_step(st, n, npad, fv, lv, s->scale.p, s->dt.p, s->rhs.p, xcur, s->qv.p, xcand, s->step_partials.p);
+  launch_halo_candidate(st, nh, s->halo_idx.p, xcur, s->scale.p, s->dt.p, xcand);
+  HIP_TRY(hipGetLastError());
+  // The candidate does not depend on any host decision, so its linearisation is queued right here and its two scalars
+  // ride in the same all-gather as the step scalars (exchanges 3 and 1 merged: 7 doubles per rank).
+  if (spec) TRY(enqueue_linearize(s, fv, xcand, buf ^ 1));
+  TRY(enqueue_step_partials(s));
+  HIP_TRY(hipStreamSynchronize(st));                     // host vectors above stay alive until here
+  StepScalars loc;
+  TRY(finish_step_partials(s, nullptr, nullptr, &loc));
+  LinResult lloc = {0.0, 0.0, 0.f, 0};
+  if (spec) TRY(finish_linearize(s, fv, &lloc));
+  double r2[7] = {loc.dt_rhs, loc.dt_q, loc.step2, loc.xn2, loc.bad, lloc.cost, lloc.gmax};
+  std::vector<double> all2((size_t)7 * W);
+  TRY(comm_allgather(s, r2, all2.data(), sizeof(r2)));
+  ss->dt_rhs = ss->dt_q = ss->step2 = ss->xn2 = ss->bad = 0.0;
+  double cost = 0.0, gmax = 0.0;
+  for (int g = 0; g < W; ++g) {          // rank order on every rank: identical sums everywhere
+    ss->dt_rhs += all2[(size_t)7 * g]; ss->dt_q += all2[(size_t)7 * g + 1]; ss->step2 += all2[(size_t)7 * g + 2];
+    ss->xn2 += all2[(size_t)7 * g + 3]; ss->bad += all2[(size_t)7 * g + 4];
+    cost += all2[(size_t)7 * g + 5];
+    gmax = nan_max(gmax, all2[(size_t)7 * g + 6]);
+  }
+  if (spec) { spec->cost = cost; spec->gmax = gmax; spec->stf_ms = lloc.stf_ms; spec->timed = lloc.timed; }
+  return HITL_OK;
+}
+
+static double now_ms() {
+  using namespace std::chrono;
+  return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+// ---------------------------------------------------------------------------------------
+// Levenberg-Marquardt with Ceres trust-region semantics (DESIGN.md "LM")
+// ---------------------------------------------------------------------------------------
+int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float* poses_global, float* poses_out,
+                    hitl_summary* summary) {
+  const double t_start = now_ms();
+  const hitl_options& o = s->opt;
+  FactorView fv;
+  TRY(prepare(s, mode, poses_in, poses_global, &fv));
+  if (s->world > 1 && fv.n_offband > 0) return fail(HITL_ERR_UNSUPPORTED, "submap solves need every pose pair inside the band");
+  hipStream_t st = s->stream;
+  const int n = s->n, n3 = 3 * n;
+  hitl_summary S;
+  std::memset(&S, 0, sizeof(S));
+  {  // SetParams (JointOptimization.cpp:392-402): fp32 -> fp64
+    std::vector<double> hx(s->npad, 0.0);
+    for (int t = 0; t < n3; ++t) hx[t] = (double)poses_in[t];
+    HIP_TRY(hipMemcpyAsync(s->x.p, hx.data(), sizeof(double) * s->npad, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  double* xcur = s->x.p;
+  double* xcand = s->xc.p;
+  int cur = 0;
+  LinResult lr;
+  TRY(run_linearize_dist(s, fv, xcur, cur, &lr));
+  S.linearize_ms += lr.stf_ms; S.linearize_calls++; S.linearize_timed_calls += lr.timed;
+  double cost = lr.cost, gmax = lr.gmax;
+  S.initial_cost = cost;
+  S.num_pairs = fv.with_stf ? s->n_pairs_owned : 0;
+  S.num_matches = fv.with_stf ? s->n_matches_owned : 0;
+  S.num_offband_pairs = fv.n_offband;
+  S.band_poses = fv.band_poses;
+  S.num_hc_residuals = s->num_hc_residuals;
+  // odometry edges are owned by the rank owning their second pose
+  const int n_edges = (s->own_hi - s->own_lo) - ((s->g_begin == 0) ? 1 : 0);
+  S.num_residuals = (fv.with_stf ? 2 * s->n_pairs_owned : 0) + (fv.with_odom ? 3 * n_edges : 0) + (fv.with_hc ? s->num_hc_residuals : 0);
+  launch_jacobi_scale(st, n, s->npad, fv.band_poses, s->Hband[cur].p, o.jacobi_scaling, s->fixed.p, s->scale.p);
+  double radius = o.initial_trust_region_radius, decrease_factor = 2.0;
+  int iter = 0, invalid_run = 0;
+  int term = HITL_NO_CONVERGENCE;
+  bool done = false;
+  if (!(cost == cost) || !(gmax == gmax)) { term = HITL_FAILURE; done = true; }
+  else if (gmax <= o.gradient_tolerance) { term = HITL_CONVERGENCE; done = true; }
+  while (!done) {
+    if (iter >= o.max_num_iterations) { term = HITL_NO_CONVERGENCE; break; }
+    ++iter;
+    int lin_iters = 0;
+    bool ok = true;
+    const bool time_solver = o.timing_level >= 2;
+    if (time_solver) HIP_TRY(hipEventRecord(s->ev2, st));
+    StepScalars ss;
+    const bool fused = (s->world == 1 && fv.n_offband == 0);   // one host synchronisation per LM iteration
+    LinResult lr_spec = {0.0, 0.0, 0.f, 0};
+    bool have_spec = false;
+    if (fused) {
+      TRY(enqueue_linear_solve_banded(s, fv, cur, radius, xcur, xcand));
+      if (time_solver) HIP_TRY(hipEventRecord(s->ev3, st));
+      TRY(enqueue_linearize(s, fv, xcand, cur ^ 1));
+      TRY(enqueue_step_partials(s));            // both copies at the tail: no copy-engine hand-over in mid-stream
+      TRY(spin_sync(s));
+      double rr, bb;
+      TRY(finish_step_partials(s, &rr, &bb, &ss));
+      const double guard = std::max(std::max(o.linear_solver_tolerance, 1e-15), 1e-9);
+      if (!(rr == rr) || rr > guard * guard * bb) ok = false;   // the factorisation broke down
+      lin_iters = 1;
+    } else {
+      if (s->world > 1) { TRY(linear_solve_and_step_dist(s, fv, cur, radius, xcur, xcand, &lin_iters, &ok, &ss, &lr_spec)); have_spec = true; }
+      else TRY(linear_solve_and_step(s, fv, cur, radius, xcur, xcand, &lin_iters, &ok, &ss));
+      if (time_solver) { HIP_TRY(hipEventRecord(s->ev3, st)); HIP_TRY(hipEventSynchronize(s->ev3)); }
+    }
+    S.linear_iterations += lin_iters;
+    if (time_solver) {
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, s->ev2, s->ev3));
+      S.linear_solver_ms += ms;
+    }
+    // model_cost_change = -dt.(S g) - 1/2 dt.(S H S) dt
+    const double dt_rhs = ss.dt_rhs, dt_q = ss.dt_q, step2 = ss.step2, xn2 = ss.xn2;
+    const double mcc = dt_rhs - 0.5 * dt_q;  // rhs = -S g
+    if (!ok || ss.bad > 0.0 || !(mcc == mcc) || mcc < 0.0) {  // invalid step
+      ++S.unsuccessful_steps;
+      if (++invalid_run >= 5) { term = HITL_FAILURE; break; }
+      radius /= decrease_factor; decrease_factor *= 2.0;
+      continue;
+    }
+    invalid_run = 0;
+    if (fused) TRY(finish_linearize(s, fv, &lr));
+    else if (have_spec) lr = lr_spec;
+    else TRY(run_linearize_dist(s, fv, xcand, cur ^ 1, &lr));
+    S.linearize_ms += lr.stf_ms; S.linearize_calls++; S.linearize_timed_calls += lr.timed;
+    if (std::sqrt(step2) <= o.parameter_tolerance * (std::sqrt(xn2) + o.parameter_tolerance)) { term = HITL_CONVERGENCE; break; }
+    const double cost_change = cost - lr.cost;
+    if (std::fabs(cost_change) <= o.function_tolerance * cost) { term = HITL_CONVERGENCE; break; }
+    const double rho = cost_change / mcc;
+    if (rho > o.min_relative_decrease) {
+      ++S.successful_steps;
+      std::swap(xcur, xcand);
+      cur ^= 1;
+      cost = lr.cost; gmax = lr.gmax;
+      if (gmax <= o.gradient_tolerance) { term = HITL_CONVERGENCE; break; }
+      const double q = 2.0 * rho - 1.0;
+      radius = std::min(o.max_trust_region_radius, radius / std::max(1.0 / 3.0, 1.0 - q * q * q));
+      decrease_factor = 2.0;
+    } else {
+      ++S.unsuccessful_steps;
+      radius /= decrease_factor; decrease_factor *= 2.0;
+      if (radius < o.min_trust_region_radius) { term = HITL_CONVERGENCE; break; }
+    }
+  }
+  S.termination = term; S.iterations = iter;
+  S.final_cost = cost; S.final_gradient_max_norm = gmax; S.final_trust_region_radius = radius;
+  {  // CopyParams (JointOptimization.cpp:380-390): fp64 -> fp32, theta through angle_mod
+    std::vector<double> hx(n3);
+    HIP_TRY(hipMemcpyAsync(hx.data(), xcur, sizeof(double) * n3, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int i = 0; i < n; ++i) {
+      poses_out[3 * i] = (float)hx[3 * i];
+      poses_out[3 * i + 1] = (float)hx[3 * i + 1];
+      poses_out[3 * i + 2] = (float)angle_mod(hx[3 * i + 2]);
+    }
+  }
+  S.total_ms = now_ms() - t_start;
+  if (summary) *summary = S;
+  if (term == HITL_FAILURE) return fail(HITL_ERR_SOLVER_FAILURE, "Levenberg-Marquardt terminated with FAILURE");
+  return HITL_OK;
+}
+
+}  // namespace hitl

@@ -1,0 +1,136 @@
+// hitl_solver_impl.h -- the solver object behind the opaque hitl_solver handle and the internal entry points shared by
+// hitl_solver.cpp (set-up, C ABI), hitl_lm.cpp (Levenberg-Marquardt loop, linear solves, submap exchange) and
+// hitl_corr.cpp (correspondence search driver).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include <rccl/rccl.h>
+
+#include "hitl_host.h"
+
+using namespace hitl;   // the handle type itself is global (C ABI); its members are hitl:: types
+
+struct hitl_solver {
+  hitl_options opt;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr, ev_sync = nullptr;
+  int64_t lin_launches = 0;     // linearisations queued so far (every 4th is bracketed by events at timing_level 1)
+  bool lin_timed = false;       // the linearisation in flight is bracketed
+  double* h_scalars = nullptr;  // pinned, kNumScalars
+  double* h_partials = nullptr; // pinned, h_partials_cap doubles
+  size_t h_partials_cap = 0;
+  DevArray<double> step_partials;   // spmv workgroups x 8
+  DevArray<double> d_scalars;
+
+  // ---- map ----
+  int n = 0;
+  int64_t n_obs = 0;
+  int max_scan = 0;
+  std::vector<int64_t> h_obs_off;
+  DevArray<int64_t> obs_off;
+  DevArray<float4> obs;                        // (px, py, nx, ny) per observation
+  DevArray<float> cov9;
+
+  // ---- pose-range submap (world_size > 1) ----
+  // local pose list = [hl halo poses | owned poses | hh halo poses]; halos carry scans and state
+  // of the neighbouring ranks' nearest poses and are constant in the local linear system.
+  int rank = 0, world = 1;
+  int64_t g_begin = 0, g_n = 0;      // first owned GLOBAL pose, global pose count
+  int halo_req = 0;                  // halo width asked for at set_partition
+  int hl = 0, hh = 0;                // halo poses actually present below / above the owned range
+  int own_lo = 0, own_hi = 0;        // owned local range [own_lo, own_hi)
+  hitl_comm_ops comm = {nullptr, nullptr};
+  ncclComm_t nccl = nullptr;
+  DevArray<char> comm_send, comm_recv;
+  DevArray<unsigned char> fixed;     // n : constant poses (global pose 0, halos)
+  DevArray<int> if_cols, halo_idx;   // interface column indices (2m) ; scalar indices of the nearest halo poses
+  DevArray<double> iface_dev, rhsN, zN, coef_dev, halo_val, halo_sc;
+  int Wi = 1;                        // interface width in poses: deepest reach of a factor across any cut (global max)
+  int n_pairs_owned = 0;             // pairs whose SOURCE pose is owned (each pair is counted by one rank)
+  int64_t n_matches_owned = 0;
+
+  // ---- human rows: constrained_pose_id is LOCAL, anchor_pose_id stays GLOBAL ----
+  std::vector<hitl_human_constraint_t> h_hc;
+
+  // ---- correspondences ----
+  int n_pairs = 0;
+  int64_t n_matches = 0;
+  std::vector<int> h_pair_src, h_pair_tgt;     // internal order: sorted by (src)
+  std::vector<int> h_perm;                     // internal index -> caller index
+  std::vector<int64_t> h_match_off;            // internal order
+  DevArray<int> pair_src, pair_tgt, pose_pair_off;
+  DevArray<int64_t> match_off;
+  DevArray<uint32_t> matches;
+  // derived
+  int band_pairs_Wb = 1;                       // Wb implied by the pair set
+  DevArray<double> pairM;                      // opt-in (stf_moments): 2 x 15 moments per pair
+  int64_t moments_of = -1;                     // correspondence-set generation the moments belong to
+  int64_t corr_generation = 0;                 // bumped whenever the pair tables change
+  int n_offband = 0;
+  DevArray<int> inc_off, inc_ent, band_pair, ob_lo, ob_hi, ob_fwd, ob_rev, obadj_off, obadj_ent;
+
+  // ---- per-solve factor tables ----
+  DevArray<float4> odom_A, hc_tgt;
+  DevArray<float2> odom_rr;
+  DevArray<int> hc_off;
+  DevArray<uint32_t> hc_type;
+  int num_hc_residuals = 0;
+
+  // ---- work buffers ----
+  int wb_Wb = 0, wb_n = 0, wb_pairs = -1, wb_offband = -1;
+  int nsb = 0, B = 0, npad = 0;
+  DevArray<double> x, xc, scale, rhs, dt, wv, qv, rv, zv, pv;
+  DevArray<double> pairRJ[2], Hband[2], gvec[2], obblk[2], lin_partials[2];
+  DevArray<double2> pose_cs;        // (cos, sin) of every pose at the state being linearised
+  DevArray<double> crD, crL, crDinv, crGl, crGr;
+
+  MapView map_view() const {
+    MapView m;
+    m.n_poses = n; m.obs_off = obs_off.p; m.obs = obs.p;
+    return m;
+  }
+  PairView pair_view() const {
+    PairView p;
+    p.n_pairs = n_pairs; p.pose_pair_off = pose_pair_off.p; p.pair_src = pair_src.p; p.pair_tgt = pair_tgt.p;
+    p.match_off = match_off.p; p.matches = matches.p;
+    return p;
+  }
+  LinView lin_view(int k) {
+    LinView l;
+    l.pairRJ = pairRJ[k].p; l.Hband = Hband[k].p; l.g = gvec[k].p; l.obblk = obblk[k].p; l.partials = lin_partials[k].p;
+    return l;
+  }
+  CrView cr_view() {
+    CrView c;
+    c.nsb = nsb; c.B = B; c.D = crD.p; c.L = crL.p; c.Dinv = crDinv.p; c.Gl = crGl.p; c.Gr = crGr.p;
+    return c;
+  }
+};
+
+namespace hitl {
+
+struct LinResult { double cost, gmax; float stf_ms; int timed; };
+
+static inline double angle_mod(double a) {  // shared/math/util.h:433-439
+  return a - 6.28318530717958647692 * std::rint(a / 6.28318530717958647692);
+}
+
+// hitl_solver.cpp
+int build_pair_structures(hitl_solver* s);
+int ensure_empty_pair_tables(hitl_solver* s);
+int ensure_work(hitl_solver* s, int Wb);
+int setup_factors(hitl_solver* s, const float* poses, const float* poses_global, bool with_odom_hc);
+FactorView factor_view(hitl_solver* s, int mode, int Wb);
+int check_ready(hitl_solver* s, int mode);
+int prepare(hitl_solver* s, int mode, const float* poses_ref, const float* poses_global, FactorView* fv);
+// hitl_lm.cpp
+int run_linearize(hitl_solver* s, const FactorView& fv, const double* xdev, int buf, LinResult* out);
+int comm_allgather(hitl_solver* s, const void* send, void* recv, int64_t bytes);
+int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float* poses_global, float* poses_out, hitl_summary* summary);
+// hitl_corr.cpp
+int find_correspondences(hitl_solver* s, const float* poses, int64_t window);
+
+}  // namespace hitl

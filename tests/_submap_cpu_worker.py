@@ -1,5 +1,5 @@
 """Worker of tests/test_submap_cpu.py (gloo, no GPU): the exchange pattern and interface
-algebra of the pose-range submap solve (hitl_solver.cpp: linear_solve_and_step_dist), mirrored
+algebra of the pose-range submap solve (hitl_lm.cpp: linear_solve_and_step_dist), mirrored
 in numpy on systems assembled by the oracle."""
 import json
 import os
