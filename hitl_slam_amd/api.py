@@ -14,6 +14,7 @@ There is no CPU fallback: constructing a Solver raises if libhitlgpu.so is missi
 HIP device is usable.
 """
 import ctypes as C
+import sys
 import os
 
 import numpy as np
@@ -120,6 +121,8 @@ class SolverBase(object):
 
     def __del__(self):
         try:
+            if sys.is_finalizing():      # interpreter shutdown: the HIP runtime may already be gone; the OS reclaims the rest
+                return
             self.close()
         except Exception:
             pass
@@ -517,6 +520,17 @@ class Solver(SolverBase):
     def find_correspondences(self, poses_xyt, window):
         pin = _as(poses_xyt, np.float32).reshape(-1)
         self._check(self._fn("find_corr")(self._h, _ptr(pin, _f32p), int(window)), "find_corr")
+
+
+def device_memory(device=0, lib_path=None):
+    """(free, total) bytes of a HIP device."""
+    lib = load_library(lib_path)
+    f, t = C.c_int64(), C.c_int64()
+    lib.hitl_device_memory.argtypes = [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    st = lib.hitl_device_memory(int(device), C.byref(f), C.byref(t))
+    if st != abi.OK:
+        raise HitlError(st, "hitl_device_memory", "")
+    return f.value, t.value
 
 
 def comm_unique_id(lib_path=None):

@@ -346,6 +346,17 @@ void hitl_options_default(hitl_options* o) {
 
 int hitl_abi_version(void) { return HITL_ABI_VERSION; }
 
+int hitl_device_memory(int32_t device, int64_t* free_bytes, int64_t* total_bytes) {
+  if (!free_bytes || !total_bytes) return fail(HITL_ERR_INVALID_ARGUMENT, "device_memory: null argument");
+  size_t f = 0, t = 0;
+  if (hipSetDevice(device) != hipSuccess || hipMemGetInfo(&f, &t) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(HITL_ERR_NO_DEVICE, "device_memory: no such HIP device (there is no CPU fallback)");
+  }
+  *free_bytes = (int64_t)f; *total_bytes = (int64_t)t;
+  return HITL_OK;
+}
+
 const char* hitl_last_error(void) { return g_last_error.c_str(); }
 
 const char* hitl_status_string(int st) {

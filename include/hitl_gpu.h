@@ -350,6 +350,8 @@ int hitl_input_log_entry(const hitl_input_log*, int32_t i, uint32_t* type, int32
 int hitl_io_save_input_log(const char* path, int32_t n_entries, const uint32_t* types, const int32_t* undone,
                            const int32_t* n_points, const float* points_xy);
 
+/* Free / total memory of a HIP device in bytes (hipMemGetInfo); for leak checks and capacity planning. */
+int hitl_device_memory(int32_t device, int64_t* free_bytes, int64_t* total_bytes);
 const char* hitl_status_string(int status);
 const char* hitl_last_error(void);       /* thread-local detail of the last failure      */
 int hitl_abi_version(void);

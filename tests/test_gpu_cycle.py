@@ -222,3 +222,21 @@ def test_replaying_a_recorded_session(both, sc, tmp_path):
     d = pg.astype(np.float64) - po
     d[:, 2] = np.angle(np.exp(1j * d[:, 2]))
     assert np.abs(d[:, :2]).max() < 2e-4 and np.abs(d[:, 2]).max() < 2e-4
+
+
+def test_repeated_calls_do_not_grow_device_memory(both, sc):
+    """Every entry point allocates its scratch per call and must give it back: 40 whole cycles + covariances later the
+    device has as much free memory as after the first one."""
+    from hitl_slam_amd.api import device_memory
+    g, _ = both
+
+    def once():
+        r = g.run_correction(4, sc.selected, sc.poses, sc.cov, [], mode=abi.MODE_JOINT, stf_window=2)
+        g.pose_covariances(abi.MODE_JOINT, r["poses"])
+        g.transform_scans(r["poses"])
+    once()
+    free0, total = device_memory()
+    for _ in range(40):
+        once()
+    free1, _ = device_memory()
+    assert total > 0 and free0 - free1 < 32 * 1024 * 1024, (free0, free1)

@@ -186,18 +186,28 @@ def test_errors_are_loud():
     s.close()
 
 
-def test_in_library_rccl_allgather_world1(monkeypatch):
+def test_in_library_rccl_allgather_world1():
     """Bring-up check of the built-in RCCL exchange (ncclGetUniqueId, ncclCommInitRank,
-    ncclAllGather on the solver's stream) on the single GPU of the test box."""
-    import ctypes as C
-    import hitl_slam_amd as H
-    from hitl_slam_amd.api import comm_unique_id
-    monkeypatch.setenv("HITL_FORCE_RCCL", "1")
-    uid = comm_unique_id()
-    assert len(uid) == 128 and any(uid)
-    buf = (C.c_char * 128).from_buffer_copy(uid)
-    opt = H.default_options()
-    opt.rccl_unique_id = C.cast(buf, C.c_void_p)
-    s = H.Solver(opt)
-    s.comm_selftest()
-    s.close()
+    ncclAllGather on the solver's stream) on the single GPU of the test box.  Runs in its own process, like every rank
+    of a real job does: a process that has initialised RCCL should end when its work does, not live on inside a
+    long test session that keeps creating and destroying other solvers."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import ctypes as C\n"
+        "import hitl_slam_amd as H\n"
+        "from hitl_slam_amd.api import comm_unique_id\n"
+        "uid = comm_unique_id()\n"
+        "assert len(uid) == 128 and any(uid)\n"
+        "buf = (C.c_char * 128).from_buffer_copy(uid)\n"
+        "opt = H.default_options()\n"
+        "opt.rccl_unique_id = C.cast(buf, C.c_void_p)\n"
+        "s = H.Solver(opt)\n"
+        "s.comm_selftest()\n"
+        "s.close()\n"
+        "print('rccl self-test ok')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HITL_FORCE_RCCL="1", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=root, timeout=300)
+    assert r.returncode == 0 and "rccl self-test ok" in r.stdout, (r.returncode, r.stdout[-400:], r.stderr[-800:])
