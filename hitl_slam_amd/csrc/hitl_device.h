@@ -12,6 +12,13 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// a value that is the same in every lane, moved to scalar registers
+__device__ __forceinline__ double uniform_f64(double v) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+  const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);

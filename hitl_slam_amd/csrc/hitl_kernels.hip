@@ -72,7 +72,7 @@ constexpr int kStfUnroll = 2;
 template <bool USE_LDS>
 __global__ __launch_bounds__(kStfBlock, 6) void k_linearize_stf(MapView map, PairView pr, int chunk, int lds_cap,
                                                                  const double* __restrict__ x,
-                                                                 const double2* __restrict__ cs, double corr, double sd,
+                                                                 const double2* __restrict__ cs, double kf, double /*unused*/,
                                                                  double* __restrict__ pairRJ) {
   extern __shared__ float4 s_scan[];  // [lds_cap] : (px, py, nx, ny) of the source scan
   const int b = blockIdx.x;
@@ -90,10 +90,11 @@ __global__ __launch_bounds__(kStfBlock, 6) void k_linearize_stf(MapView map, Pai
   const int lane = threadIdx.x & 63;
   const int sub = threadIdx.x / kStfSub;        // pair slot of this half-wave within the workgroup
   const int hl = threadIdx.x & (kStfSub - 1);   // lane within the half-wave
-  const double xi = x[3 * i], yi = x[3 * i + 1];
+  // workgroup-uniform values are pinned to SGPRs (v_readfirstlane): kept in VGPRs across the match loop they are what
+  // the register allocator spills at the 80-VGPR budget (5 VGPRs = ~0.37 GB of scratch traffic per launch)
+  const double xi = uniform_f64(x[3 * i]), yi = uniform_f64(x[3 * i + 1]);
   const double2 cs0 = cs[i];
-  const double c0 = cs0.x, s0 = cs0.y;
-  const double kf = corr / sd;
+  const double c0 = uniform_f64(cs0.x), s0 = uniform_f64(cs0.y);
   const float4* __restrict__ src_g = map.obs + oi;
   const uint32_t* __restrict__ mt = pr.matches;
   constexpr int kSlots = kStfBlock / kStfSub;
@@ -115,28 +116,27 @@ __global__ __launch_bounds__(kStfBlock, 6) void k_linearize_stf(MapView map, Pai
     double S0 = 0, A0x = 0, A0y = 0, T01 = 0;
     double S1 = 0, A1x = 0, A1y = 0, T10 = 0;
     // the index words of the NEXT trip are requested before this trip's arithmetic, so a trip waits for one memory
-    // round (the gathers) instead of two dependent ones (index, then gather)
+    // round (the gathers) instead of two dependent ones (index, then gather).  Positions inside the pair's list are
+    // 32-bit (a pair holds at most one match per source point, < 65536): 64-bit loop state costs VGPRs that this
+    // kernel does not have at its 80-register budget -- with them, and with k = corr / sigma divided on the device, the
+    // allocator spilled 5 VGPRs to scratch (~0.37 GB of extra HBM traffic per launch).
+    const uint32_t* __restrict__ mp = mt + m_begin;
+    const int len = (int)(m_end - m_begin);
     uint32_t un[kStfUnroll];
-    {
-      const int64_t m0 = m_begin + hl;
 #pragma unroll
-      for (int q = 0; q < kStfUnroll; ++q) {
-        const int64_t mq = m0 + (int64_t)q * kStfSub;
-        un[q] = (mq < m_end) ? mt[mq] : 0u;
-      }
+    for (int q = 0; q < kStfUnroll; ++q) {
+      const int mq = hl + q * kStfSub;
+      un[q] = (mq < len) ? mp[mq] : 0u;
     }
-    for (int64_t m = m_begin + hl; m < m_end; m += kStfSub * kStfUnroll) {
+    for (int m = hl; m < len; m += kStfSub * kStfUnroll) {
       uint32_t uu[kStfUnroll];
       float4 av[kStfUnroll], tv[kStfUnroll];
 #pragma unroll
       for (int q = 0; q < kStfUnroll; ++q) uu[q] = un[q];   // tail lanes carry index 0 (valid), weighted 0 below
-      {
-        const int64_t mn = m + kStfSub * kStfUnroll;
 #pragma unroll
-        for (int q = 0; q < kStfUnroll; ++q) {
-          const int64_t mq = mn + (int64_t)q * kStfSub;
-          un[q] = (mq < m_end) ? mt[mq] : 0u;
-        }
+      for (int q = 0; q < kStfUnroll; ++q) {
+        const int mq = m + (kStfUnroll + q) * kStfSub;
+        un[q] = (mq < len) ? mp[mq] : 0u;
       }
 #pragma unroll
       for (int q = 0; q < kStfUnroll; ++q) {
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(kStfBlock, 6) void k_linearize_stf(MapView map, Pai
       }
 #pragma unroll
       for (int q = 0; q < kStfUnroll; ++q) {
-        const double wgt = (m + (int64_t)q * kStfSub < m_end) ? 1.0 : 0.0;
+        const double wgt = (m + q * kStfSub < len) ? 1.0 : 0.0;
         const double ax = av[q].x, ay = av[q].y, anx = av[q].z, any = av[q].w;
         const double bx = tv[q].x, by = tv[q].y, bnx = tv[q].z, bny = tv[q].w;
         const double ux = cR * bx - sR * by, uy = sR * bx + cR * by;        // u = R01 p1
@@ -306,10 +306,10 @@ void launch_linearize_stf(hipStream_t st, const MapView& map, const PairView& pr
   if ((size_t)lds_cap * 16 > 64 * 1024) lds_cap = 0;  // oversized scans read the source from global memory
   if (lds_cap > 0)
     hipLaunchKernelGGL(k_linearize_stf<true>, dim3(8 * chunk), dim3(kStfBlock), (size_t)lds_cap * 16, st, map, pr, chunk,
-                       lds_cap, x, cs, (double)corr, (double)std_dev, pairRJ);
+                       lds_cap, x, cs, (double)corr / (double)std_dev, 0.0, pairRJ);   // k = corr / sigma, divided here once
   else
     hipLaunchKernelGGL(k_linearize_stf<false>, dim3(8 * chunk), dim3(kStfBlock), 0, st, map, pr, chunk, 0, x, cs,
-                       (double)corr, (double)std_dev, pairRJ);
+                       (double)corr / (double)std_dev, 0.0, pairRJ);
 }
 
 // SoA (the caller's layout, JointOptimization.h:62-68) -> device-resident float4 per observation
