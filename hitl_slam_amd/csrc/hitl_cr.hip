@@ -393,8 +393,10 @@ __global__ __launch_bounds__(kCrTopThreads) void k_cr_top(CrView cr, int s_start
 // M nodes with local strides 1, 2, 4 .. through the very same node routines (they only see a CrView whose arrays
 // happen to live in LDS), and Dinv / Gl / Gr / w / x go back out once.  Global memory is touched twice instead of at
 // every one of the ~20 dependent phases.
+// 512 threads: with 1024 the 128-VGPR cap makes the node routines spill (7 VGPRs at B = 9, 55 at B = 12)
+constexpr int kCrTopLdsThreads = 512;
 template <int B>
-__global__ __launch_bounds__(kCrTopThreads) void k_cr_top_lds(CrView cr, int s_start, int M, double* w, double* x, int nrhs, size_t stride) {
+__global__ __launch_bounds__(kCrTopLdsThreads) void k_cr_top_lds(CrView cr, int s_start, int M, double* w, double* x, int nrhs, size_t stride) {
   extern __shared__ double lds[];
   constexpr int BB = B * B;
   double* sD = lds;
@@ -406,14 +408,14 @@ __global__ __launch_bounds__(kCrTopThreads) void k_cr_top_lds(CrView cr, int s_s
   double* sx = sw + (size_t)M * B * nrhs;
   const size_t lstride = (size_t)M * B;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  constexpr int NW = kCrTopThreads / WAVE;
-  for (int e = threadIdx.x; e < M * BB; e += kCrTopThreads) {
+  constexpr int NW = kCrTopLdsThreads / WAVE;
+  for (int e = threadIdx.x; e < M * BB; e += kCrTopLdsThreads) {
     const int m = e / BB, q = e % BB;
     const size_t g = (size_t)m * s_start * BB + q;
     sD[e] = cr.D[g]; sL[e] = cr.L[g]; sGl[e] = 0.0; sGr[e] = 0.0; sDinv[e] = 0.0;
   }
   if (w != nullptr)
-    for (int e = threadIdx.x; e < M * B * nrhs; e += kCrTopThreads) {
+    for (int e = threadIdx.x; e < M * B * nrhs; e += kCrTopLdsThreads) {
       const int v = e / (M * B), r = e % (M * B);
       sw[(size_t)v * lstride + r] = w[stride * v + (size_t)(r / B) * s_start * B + (r % B)];
     }
@@ -450,7 +452,7 @@ __global__ __launch_bounds__(kCrTopThreads) void k_cr_top_lds(CrView cr, int s_s
     __syncthreads();
     for (int s = s_last; s >= 1; s /= 2) {
       for (int vv = 0; vv < nrhs; ++vv)
-        for (int t = threadIdx.x;; t += kCrTopThreads) {
+        for (int t = threadIdx.x;; t += kCrTopLdsThreads) {
           const int k = s * (2 * (t / B) + 1);
           if (k >= M) break;
           cr_backward_row<B>(lc, s, k, t % B, sw + lstride * vv, sx + lstride * vv);
@@ -458,13 +460,13 @@ __global__ __launch_bounds__(kCrTopThreads) void k_cr_top_lds(CrView cr, int s_s
       __syncthreads();
     }
   }
-  for (int e = threadIdx.x; e < M * BB; e += kCrTopThreads) {
+  for (int e = threadIdx.x; e < M * BB; e += kCrTopLdsThreads) {
     const int m = e / BB, q = e % BB;
     const size_t g = (size_t)m * s_start * BB + q;
     cr.Dinv[g] = sDinv[e]; cr.Gl[g] = sGl[e]; cr.Gr[g] = sGr[e];
   }
   if (w != nullptr)
-    for (int e = threadIdx.x; e < M * B * nrhs; e += kCrTopThreads) {
+    for (int e = threadIdx.x; e < M * B * nrhs; e += kCrTopLdsThreads) {
       const int v = e / (M * B), r = e % (M * B);
       const size_t g = stride * v + (size_t)(r / B) * s_start * B + (r % B);
       w[g] = sw[(size_t)v * lstride + r];
@@ -618,7 +620,7 @@ static void cr_factor_t(hipStream_t st, const CrView& cr, double* w, double* x, 
       if (!raised) (void)hipGetLastError();
     }
     if (lds_bytes <= (raised ? kCrTopLdsBytes : (size_t)64 * 1024))
-      hipLaunchKernelGGL(k_cr_top_lds<B>, dim3(1), dim3(kCrTopThreads), lds_bytes, st, cr, s_top, M, w, x, nr, stride);
+      hipLaunchKernelGGL(k_cr_top_lds<B>, dim3(1), dim3(kCrTopLdsThreads), lds_bytes, st, cr, s_top, M, w, x, nr, stride);
     else
       hipLaunchKernelGGL(k_cr_top<B>, dim3(1), dim3(kCrTopThreads), 0, st, cr, s_top, w, x, nrhs, stride);
   }
