@@ -137,7 +137,7 @@ void launch_compact(hipStream_t st, const MapView& map, int max_scan, int slots,
                     uint32_t* matches);
 
 // observation scans (hitl_obs.hip); T4 = n x (cos, sin, tx, ty) fp32 computed on the host
-void launch_transform(hipStream_t st, const MapView& map, const float* T4, float2* world);
+void launch_transform(hipStream_t st, const MapView& map, const float* T4, float* world_x, float* world_y);
 void launch_verify(hipStream_t st, const MapView& map, const float* T4, int n, const float* pts_xy, float thr, int* seen);
 void launch_obs_sets(hipStream_t st, const MapView& map, const float* T4, const float* seg8, double thr, int* counts,
                      unsigned char* mask);

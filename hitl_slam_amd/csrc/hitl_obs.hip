@@ -28,7 +28,7 @@ __device__ __forceinline__ int pose_of_block(int n_poses, int chunk) {
 }
 
 __global__ __launch_bounds__(kObsBlock) void k_transform(MapView map, int chunk, const PoseRT* __restrict__ T,
-                                                         float2* __restrict__ world) {
+                                                         float* __restrict__ world_x, float* __restrict__ world_y) {
   const int i = pose_of_block(map.n_poses, chunk);
   if (i < 0) return;
   const PoseRT t = T[i];
@@ -36,7 +36,8 @@ __global__ __launch_bounds__(kObsBlock) void k_transform(MapView map, int chunk,
   const int m = (int)(map.obs_off[i + 1] - o);
   for (int k = threadIdx.x; k < m; k += kObsBlock) {
     const float4 a = map.obs[o + k];
-    world[o + k] = to_world(t, a.x, a.y);
+    const float2 w = to_world(t, a.x, a.y);
+    world_x[o + k] = w.x; world_y[o + k] = w.y;      // SoA, the layout the caller's two arrays have
   }
 }
 
@@ -223,9 +224,9 @@ void launch_fit_eval(hipStream_t st, const float2* pts, int64_t m, double cmx, d
   hipLaunchKernelGGL(k_fit_eval, dim3(g), dim3(kFitBlock), 0, st, pts, m, per, fl, partial);
 }
 
-void launch_transform(hipStream_t st, const MapView& map, const float* T4, float2* world) {
+void launch_transform(hipStream_t st, const MapView& map, const float* T4, float* world_x, float* world_y) {
   const int chunk = (map.n_poses + 7) / 8;
-  hipLaunchKernelGGL(k_transform, dim3(8 * chunk), dim3(kObsBlock), 0, st, map, chunk, (const PoseRT*)T4, world);
+  hipLaunchKernelGGL(k_transform, dim3(8 * chunk), dim3(kObsBlock), 0, st, map, chunk, (const PoseRT*)T4, world_x, world_y);
 }
 
 void launch_verify(hipStream_t st, const MapView& map, const float* T4, int n, const float* pts_xy, float thr, int* seen) {

@@ -739,16 +739,15 @@ int obs_scan_prepare(hitl_solver* s, const float* poses, DevArray<float>* T4) {
 
 int hitl_solver_transform_scans(hitl_solver* s, const float* poses_xyt, float* world_x, float* world_y) {
   DevArray<float> T4;
-  DevArray<float2> w;
+  DevArray<float> w;           // world x of every observation, then world y: copied straight into the caller's two arrays
   int rc = obs_scan_prepare(s, poses_xyt, &T4);
   if (rc == HITL_OK && (!world_x || !world_y)) rc = fail(HITL_ERR_INVALID_ARGUMENT, "transform_scans: null output");
-  if (rc == HITL_OK) rc = w.resize((size_t)s->n_obs);
+  if (rc == HITL_OK) rc = w.resize((size_t)2 * s->n_obs);
   if (rc == HITL_OK) {
-    launch_transform(s->stream, s->map_view(), T4.p, w.p);
-    std::vector<float2> h((size_t)s->n_obs);
-    if (hipMemcpyAsync(h.data(), w.p, sizeof(float2) * h.size(), hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
+    launch_transform(s->stream, s->map_view(), T4.p, w.p, w.p + s->n_obs);
+    if (hipMemcpyAsync(world_x, w.p, sizeof(float) * (size_t)s->n_obs, hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
+        hipMemcpyAsync(world_y, w.p + s->n_obs, sizeof(float) * (size_t)s->n_obs, hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
         hipStreamSynchronize(s->stream) != hipSuccess) rc = fail(HITL_ERR_HIP, "transform_scans failed");
-    else for (size_t k = 0; k < h.size(); ++k) { world_x[k] = h[k].x; world_y[k] = h[k].y; }
   }
   T4.release(); w.release();
   return rc;
