@@ -8,6 +8,14 @@ import os
 import subprocess
 import sys
 
+
+def _free_port():
+    """A port nobody is listening on (rendezvous of the worker processes on 127.0.0.1)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -15,7 +23,7 @@ def test_interface_solve_reproduces_the_global_step(tmp_path):
     out = str(tmp_path / "res")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29531", os.path.join(ROOT, "tests", "_submap_cpu_worker.py"), out]
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_submap_cpu_worker.py"), out]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     res = [json.load(open("%s.%d" % (out, k))) for k in range(2)]

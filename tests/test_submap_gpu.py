@@ -14,6 +14,14 @@ import pytest
 
 from conftest import Problem
 
+
+def _free_port():
+    """A port nobody is listening on (rendezvous of the worker processes on 127.0.0.1)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -24,7 +32,7 @@ def test_submaps_equal_the_global_solve(tmp_path, mode, ppf, world):
     out = str(tmp_path / "res")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-           "--master-port", str(29500 + mode + ppf // 10 + 7 * world), os.path.join(ROOT, "tests", "_submap_worker.py"), out, str(mode), str(ppf)]
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_submap_worker.py"), out, str(mode), str(ppf)]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     res = [json.load(open("%s.%d" % (out, k))) for k in range(world)]
