@@ -233,6 +233,13 @@ def main():
                 traffic = tj.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
+    pmc = None
+    ppath = os.path.join(ROOT, "profiles", "pmc_%s.json" % args.workload)
+    if os.path.exists(ppath):
+        try:
+            pmc = json.load(open(ppath))
+        except Exception:
+            pmc = None
     out_l = out[begin:end] if use_dist else out
     err_gt = float(np.abs(out_l[:, :2].astype(np.float64) - gt[begin:end, :2]).max())
 
@@ -266,7 +273,8 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "k_linearize_stf", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_stf_ms, "launches": stf_launches, "launches_bracketed_by_hip_events": stf_calls,
-                     "compulsory_bytes_this_layout": 16 * n_obs + 4 * int(n_matches_l) + 24 * n_local + 112 * int(n_pairs_l)},
+                     "compulsory_bytes_this_layout": 16 * n_obs + 4 * int(n_matches_l) + 24 * n_local + 112 * int(n_pairs_l),
+                     "utilisation_counters": pmc},
         "synth_gen_s": gen_s,
     }
 
