@@ -120,6 +120,9 @@ __global__ __launch_bounds__(kStfBlock, 6) void k_linearize_stf(MapView map, Pai
     // 32-bit (a pair holds at most one match per source point, < 65536): 64-bit loop state costs VGPRs that this
     // kernel does not have at its 80-register budget -- with them, and with k = corr / sigma divided on the device, the
     // allocator spilled 5 VGPRs to scratch (~0.37 GB of extra HBM traffic per launch).
+    // (The compiler hoists `table base + lane offset` out of the pair loop and, at the 80-VGPR budget, spills that one
+    // 64-bit address to scratch: 8 bytes written once per thread.  Making the base opaque removes the spill but puts
+    // two 64-bit adds back into every trip: 330 us instead of 308 us.  The kernel is VALU-bound, so the spill stays.)
     const uint32_t* __restrict__ mp = mt + m_begin;
     const int len = (int)(m_end - m_begin);
     uint32_t un[kStfUnroll];
@@ -169,8 +172,11 @@ __global__ __launch_bounds__(kStfBlock, 6) void k_linearize_stf(MapView map, Pai
     tot += __shfl_xor(tot, 2, WAVE);
     tot += __shfl_xor(tot, 1, WAVE);
     // lane base + 4*id now holds the pair total of value id (base = 0 or 32)
-    const bool hi = (lane & 32) != 0;
-#define HITL_PICK(id) (hi ? readlane_f64(tot, 32 + 4 * (id)) : readlane_f64(tot, 4 * (id)))
+    // picks through the cross-lane network (ds_bpermute): half the instructions of v_readlane pairs + selects.  The lane
+    // index is formed here (the empty asm keeps it from being hoisted over the match loop, where it would cost a VGPR).
+    int pick_base = lane & 32;
+    asm volatile("" : "+v"(pick_base));
+#define HITL_PICK(id) __shfl(tot, pick_base + 4 * (id), WAVE)
     S0 = HITL_PICK(0); A0x = HITL_PICK(1); A0y = HITL_PICK(2); T01 = HITL_PICK(3);
     S1 = HITL_PICK(4); A1x = HITL_PICK(5); A1y = HITL_PICK(6); T10 = HITL_PICK(7);
 #undef HITL_PICK
