@@ -302,3 +302,47 @@ def test_order_user_input_product_equals_oracle_on_random_counts():
             agree += 1
     assert agree > 100
     o.close()
+
+
+def test_endpoint_fit_reaches_the_minimum_scipy_finds(orc, sc):
+    """Independent check of AutomaticEndpointAdjustment: the same EM loop in numpy with scipy.optimize.least_squares as
+    the M step (same residuals, same start acos(|dx| / length), same inlier rule with the reference's 't > 1'), against
+    the restated Ceres loop.  Ceres stops on its 1e-6 function tolerance, so the endpoints agree to a millimetre, and
+    the number of EM passes is the same."""
+    from scipy.optimize import least_squares
+    wx, wy = sc.world
+    W32 = np.c_[wx, wy].astype(np.float32)
+    for k in range(2):
+        p0 = sc.selected[4 * k:4 * k + 2].astype(np.float32)
+        p1 = sc.selected[4 * k + 2:4 * k + 4].astype(np.float32)
+        seg, inl, passes, its = orc.fit_segments(sc.poses, [np.r_[p0, p1]])
+        a0, a1, n_pass = p0.copy(), p1.copy(), 0
+        adj = (1.0, 1.0)
+        while max(adj) > 0.05:
+            n_pass += 1
+            assert n_pass < 20
+            d = a1 - a0
+            u = d / np.float32(np.sqrt(np.float32(d @ d)))
+            q = W32 - a0
+            t = q @ u
+            dist = np.where(t < 0, np.linalg.norm(q, axis=1),
+                            np.where(t > 1, np.linalg.norm(W32 - a1, axis=1), np.abs(q @ np.array([-u[1], u[0]], np.float32))))
+            pts = W32[dist.astype(np.float64) < 0.03].astype(np.float64)
+            e0, e1 = a0.astype(np.float64), a1.astype(np.float64)
+            cm, hy = (e0 + e1) / 2.0, float(np.linalg.norm(e0 - e1))
+            length = hy / 2.0
+
+            def resid(th):
+                a = np.array([np.cos(th[0]), np.sin(th[0])])
+                s1, s2 = cm + length * a, cm - length * a
+                dd = s2 - s1
+                tt = ((pts - s1) @ dd) / (dd @ dd)
+                return np.linalg.norm(pts - (s1 + np.clip(tt, 0.0, 1.0)[:, None] * dd), axis=1)
+            th0 = np.arccos(abs(e0[0] - e1[0]) / hy)
+            th = least_squares(resid, [th0], method="trf", xtol=1e-12, ftol=1e-12, gtol=1e-12).x[0] if len(pts) else th0
+            a = np.array([np.cos(th), np.sin(th)])
+            n0, n1 = (cm + length * a).astype(np.float32), (cm - length * a).astype(np.float32)
+            adj = (float(np.linalg.norm(a0 - n0)), float(np.linalg.norm(a1 - n1)))
+            a0, a1 = n0, n1
+        assert n_pass == int(passes[0])
+        assert np.abs(np.r_[a0, a1] - seg[0]).max() < 1e-3, (np.r_[a0, a1], seg[0])
