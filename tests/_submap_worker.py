@@ -30,6 +30,7 @@ def main():
     opt = H.default_options()
     opt.rank, opt.world_size = rank, world
     opt.device = rank % max(torch.cuda.device_count(), 1)
+    opt.stf_moments = int(os.environ.get("HITL_TEST_STF_MOMENTS", "0"))
     s = H.Solver(opt)
     ops, keep = torch_allgather_ops()
     s.set_comm(ops, keep)

@@ -26,11 +26,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("mode,ppf,world", [(0, 30, 2), (2, 30, 2), (2, 120, 2), (0, 120, 2), (2, 120, 3), (2, 40, 3)])
-def test_submaps_equal_the_global_solve(tmp_path, mode, ppf, world):
+@pytest.mark.parametrize("mode,ppf,world,moments", [(0, 30, 2, 0), (2, 30, 2, 0), (2, 120, 2, 0), (0, 120, 2, 0), (2, 120, 3, 0), (2, 40, 3, 0),
+                                                    (2, 120, 2, 1)])
+def test_submaps_equal_the_global_solve(tmp_path, mode, ppf, world, moments):
     from oracle import hitl_oracle as O
     out = str(tmp_path / "res")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", HITL_TEST_STF_MOMENTS=str(moments))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_submap_worker.py"), out, str(mode), str(ppf)]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
