@@ -48,12 +48,16 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
   const size_t table_entries = (size_t)n * slots * s->max_scan;
   if (table_entries * sizeof(uint16_t) > (size_t)64 << 30)
     return fail(HITL_ERR_OUT_OF_MEMORY, "candidate table would exceed 64 GiB; use a smaller window");
-  std::vector<int> cand_tgt((size_t)n * slots, -1);
-  std::vector<float> cand_tf((size_t)n * slots * 8, 0.f);
-  std::vector<float> cs((size_t)2 * n);
+  // scratch kept in the solver between calls (no 10 MB allocate-and-clear per search)
+  std::vector<int>& cand_tgt = s->h_cand_tgt;
+  std::vector<float>& cand_tf = s->h_cand_tf;
+  std::vector<float>& cs = s->h_cand_cs;
+  if (cand_tgt.size() != (size_t)n * slots) cand_tgt.resize((size_t)n * slots);
+  if (cand_tf.size() != (size_t)n * slots * 8) cand_tf.resize((size_t)n * slots * 8);
+  if (cs.size() != (size_t)2 * n) cs.resize((size_t)2 * n);
   {
     // candidate transforms: fp32 host libm (bit-identical to the CPU restatement), spread over a few threads
-    const int nt = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const int nt = (int)std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
     auto run = [&](auto&& body) {
       std::vector<std::thread> th;
       for (int t = 1; t < nt; ++t) th.emplace_back([&, t]() { body((int64_t)n * t / nt, (int64_t)n * (t + 1) / nt); });
@@ -71,16 +75,17 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
           make_rel_tf(poses + 3 * i, poses + 3 * j, &cs[2 * i], &cs[2 * j], &cand_tf[((size_t)i * slots + slot) * 8]);
           ++slot;
         }
+        for (; slot < slots; ++slot) cand_tgt[(size_t)i * slots + slot] = -1;     // unused slots of poses near the ends
       }
     });
   }
   mark("candidate transforms");
   hipStream_t st = s->stream;
-  DevArray<int> d_tgt, d_counts, d_kept;
-  DevArray<float> d_tf;
-  DevArray<uint16_t> d_table;
+  DevArray<int>&d_tgt = s->d_cand_tgt, &d_counts = s->d_cand_counts, &d_kept = s->d_cand_kept;   // device scratch, kept too
+  DevArray<float>& d_tf = s->d_cand_tf;
+  DevArray<uint16_t>& d_table = s->d_cand_table;
   int rc = HITL_OK;
-  auto cleanup = [&]() { d_tgt.release(); d_counts.release(); d_kept.release(); d_tf.release(); d_table.release(); };
+  auto cleanup = [&]() {};
 #define TRYC(expr) do { rc = (expr); if (rc != HITL_OK) { cleanup(); return rc; } } while (0)
   TRYC(d_tgt.upload(cand_tgt, st));
   TRYC(d_tf.upload(cand_tf, st));
@@ -104,7 +109,9 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
   mark("k_match + counts");
   // keep pairs with more than kMinInterPoseCorrespondence matches (:632-634), pose order (:636-641)
   std::vector<int> kept;
+  kept.reserve(cand_tgt.size());
   s->h_pair_src.clear(); s->h_pair_tgt.clear(); s->h_match_off.assign(1, 0);
+  s->h_pair_src.reserve(cand_tgt.size()); s->h_pair_tgt.reserve(cand_tgt.size()); s->h_match_off.reserve(cand_tgt.size() + 1);
   for (int i = 0; i < n; ++i)
     for (int sl = 0; sl < slots; ++sl) {
       const size_t c = (size_t)i * slots + sl;

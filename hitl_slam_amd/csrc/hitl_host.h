@@ -32,6 +32,10 @@ struct DevArray {
   T* p = nullptr;
   size_t cap = 0;
   size_t n = 0;
+  DevArray() = default;
+  DevArray(const DevArray&) = delete;              // owns device memory: no copies
+  DevArray& operator=(const DevArray&) = delete;
+  ~DevArray() { release(); }                       // whatever a code path forgot to release() goes with the object
   int resize(size_t count) {
     n = count;
     if (count <= cap && p) return HITL_OK;

@@ -424,6 +424,8 @@ void hitl_solver_destroy(hitl_solver* s) {
   for (DevArray<int>* v : {&s->pair_src, &s->pair_tgt, &s->pose_pair_off, &s->inc_off, &s->inc_ent, &s->band_pair, &s->ob_lo,
                            &s->ob_hi, &s->ob_fwd, &s->ob_rev, &s->obadj_off, &s->obadj_ent, &s->hc_off})
     v->release();
+  s->d_cand_tgt.release(); s->d_cand_counts.release(); s->d_cand_kept.release(); s->d_cand_tf.release(); s->d_cand_table.release();
+  s->pairM.release();
   s->matches.release(); s->odom_A.release(); s->hc_tgt.release(); s->odom_rr.release(); s->hc_type.release();
   if (s->nccl) (void)ncclCommDestroy(s->nccl);
   s->comm_send.release(); s->comm_recv.release(); s->fixed.release(); s->if_cols.release(); s->halo_idx.release();

@@ -66,6 +66,12 @@ struct hitl_solver {
   DevArray<uint32_t> matches;
   // derived
   int band_pairs_Wb = 1;                       // Wb implied by the pair set
+  // scratch of the correspondence search, kept between calls
+  std::vector<int> h_cand_tgt;
+  std::vector<float> h_cand_tf, h_cand_cs;
+  DevArray<int> d_cand_tgt, d_cand_counts, d_cand_kept;
+  DevArray<float> d_cand_tf;
+  DevArray<uint16_t> d_cand_table;
   DevArray<double> pairM;                      // opt-in (stf_moments): 2 x 15 moments per pair
   int64_t moments_of = -1;                     // correspondence-set generation the moments belong to
   int64_t corr_generation = 0;                 // bumped whenever the pair tables change

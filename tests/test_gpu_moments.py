@@ -59,3 +59,25 @@ def test_solve_matches_the_streaming_path_and_the_oracle(n, obs, ppf, window):
     pb2, sb2 = b.solve(abi.MODE_JOINT, pb)
     assert sa2.iterations == sb2.iterations and np.abs(pa2 - pb2).max() <= 1e-5
     a.close(); b.close(); o.close()
+
+
+def test_create_solve_destroy_gives_all_device_memory_back():
+    from hitl_slam_amd.api import device_memory
+    prob = Problem(60, 90, ppf=30, window=3)
+    corr = oracle_corr(prob)
+
+    def once(moments):
+        o = H.default_options()
+        o.stf_moments = moments
+        s = H.Solver(o)
+        prob.load(s, corr=corr)
+        s.find_correspondences(prob.init, 3)
+        s.solve(abi.MODE_JOINT, prob.init)
+        s.pose_covariances(abi.MODE_JOINT, prob.init)
+        s.close()
+    once(0); once(1)
+    free0, _ = device_memory()
+    for k in range(12):
+        once(k & 1)
+    free1, _ = device_memory()
+    assert free0 - free1 < 16 * 1024 * 1024, (free0, free1)
