@@ -28,7 +28,7 @@ def _check(Sg, So, rel=1e-6):
         assert np.linalg.eigvalsh(0.5 * (Sg[i] + Sg[i].T)).min() > 0.0
 
 
-@pytest.mark.parametrize("n,obs,ppf,window", [(60, 90, 30, 3), (97, 64, 97, 2), (33, 80, 33, 1), (130, 48, 50, 4)])
+@pytest.mark.parametrize("n,obs,ppf,window", [(60, 90, 30, 3), (97, 64, 97, 2), (33, 80, 33, 1), (130, 48, 50, 4), (700, 36, 175, 3)])
 def test_joint_mode_matches_dense_inverse(n, obs, ppf, window):
     prob = Problem(n, obs, ppf=ppf, window=window)
     corr = oracle_corr(prob)
