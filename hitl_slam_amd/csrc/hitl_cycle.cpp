@@ -294,23 +294,24 @@ int hitl_solver_apply_explicit_correction(hitl_solver* s, uint32_t type, const f
   float c0[3], cl[3];
   corr_of(g0, c0);
   corr_of(g1, cl);
-  float args[14];
-  args[0] = c; args[1] = sn; args[2] = theta; args[3] = cmAx; args[4] = cmAy; args[5] = dstx; args[6] = dsty;
-  args[7] = poses[3 * g1] + cl[0]; args[8] = poses[3 * g1 + 1] + cl[1];      // poses_[last_pose] after its own correction
-  args[9] = cosf(cl[2]); args[10] = sinf(cl[2]); args[11] = cl[0]; args[12] = cl[1]; args[13] = cl[2];
+  ExplicitArgs ea;
+  ea.n = (int)n_poses; ea.g0 = (int)g0; ea.g1 = (int)g1;
+  ea.c = c; ea.s = sn; ea.theta = theta; ea.pivx = cmAx; ea.pivy = cmAy; ea.dstx = dstx; ea.dsty = dsty;
+  ea.lx = poses[3 * g1] + cl[0]; ea.ly = poses[3 * g1 + 1] + cl[1];      // poses_[last_pose] after its own correction
+  ea.cl = cosf(cl[2]); ea.sl = sinf(cl[2]); ea.ltx = cl[0]; ea.lty = cl[1]; ea.lth = cl[2];
   DevArray<float> d_poses;
-  DevArray<char> d_anchor, d_rows;
+  DevArray<AnchorRow> d_anchor;
+  DevArray<hitl_human_constraint_t> d_rows;
   DevArray<int> d_corr;
   int rc = d_poses.upload(poses, (size_t)3 * n_poses, cx.stream);
   if (rc == HITL_OK) {
-    launch_explicit_apply(cx.stream, d_poses.p, args, (int)n_poses, (int)g0, (int)g1);
+    launch_explicit_apply(cx.stream, d_poses.p, ea);
     if (hipMemcpyAsync(poses, d_poses.p, sizeof(float) * 3 * (size_t)n_poses, hipMemcpyDeviceToHost, cx.stream) != hipSuccess ||
         hipStreamSynchronize(cx.stream) != hipSuccess) rc = fail(HITL_ERR_HIP, "apply_explicit_correction: kernel failed");
   }
   std::memcpy(correction, c0, sizeof(c0));
   // ---- calculateConstraintTargets (:447-487): per-anchor scalars here, the anchors x corrected table on the device ----
   if (rc == HITL_OK && n_anchor > 0) {
-    struct AnchorRow { float x, y, angle, c, s, rel; int id; int pad; };
     std::vector<AnchorRow> at((size_t)n_anchor);
     const float corr_angle = atan2f(sp[7] - sp[5], sp[6] - sp[4]);
     for (int32_t a = 0; a < n_anchor; ++a) {
@@ -322,9 +323,9 @@ int hitl_solver_apply_explicit_correction(hitl_solver* s, uint32_t type, const f
       r.id = anchor[a]; r.pad = 0;
     }
     const size_t n_rows = (size_t)n_anchor * n_corr;
-    rc = d_anchor.upload((const char*)at.data(), at.size() * sizeof(AnchorRow), cx.stream);
+    rc = d_anchor.upload(at, cx.stream);
     if (rc == HITL_OK) rc = d_corr.upload(corr, (size_t)n_corr, cx.stream);
-    if (rc == HITL_OK) rc = d_rows.resize(n_rows * sizeof(hitl_human_constraint_t));
+    if (rc == HITL_OK) rc = d_rows.resize(n_rows);
     if (rc == HITL_OK) {
       launch_constraint_rows(cx.stream, d_poses.p, d_anchor.p, d_corr.p, n_anchor, n_corr, type, d_rows.p);
       if (hipMemcpyAsync(rows, d_rows.p, n_rows * sizeof(hitl_human_constraint_t), hipMemcpyDeviceToHost, cx.stream) != hipSuccess ||

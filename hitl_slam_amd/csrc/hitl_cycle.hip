@@ -19,16 +19,6 @@
 namespace hitl {
 
 // ------------------------------------------------------------------------------------------------------------
-struct ExplicitArgs {
-  int n, g0, g1;             // poses; first contiguous group of corrected poses [g0, g1]
-  float c, s, theta;         // Rotation2Df(theta) of the correction
-  float pivx, pivy;          // cmA
-  float dstx, dsty;          // cmB / new_cmA / cmA
-  float lx, ly;              // poses_[last_pose] AFTER its own correction
-  float cl, sl;              // Rotation2Df(last_correction(2))
-  float ltx, lty, lth;       // last_correction
-};
-
 __global__ __launch_bounds__(256) void k_explicit_apply(float* __restrict__ poses, ExplicitArgs a) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= a.n || i < a.g0) return;
@@ -48,17 +38,13 @@ __global__ __launch_bounds__(256) void k_explicit_apply(float* __restrict__ pose
   poses[3 * i] = x; poses[3 * i + 1] = y; poses[3 * i + 2] = th;
 }
 
-void launch_explicit_apply(hipStream_t st, float* poses, const float* args14, int n, int g0, int g1) {
-  ExplicitArgs a;
-  a.n = n; a.g0 = g0; a.g1 = g1;
-  a.c = args14[0]; a.s = args14[1]; a.theta = args14[2]; a.pivx = args14[3]; a.pivy = args14[4]; a.dstx = args14[5]; a.dsty = args14[6];
-  a.lx = args14[7]; a.ly = args14[8]; a.cl = args14[9]; a.sl = args14[10]; a.ltx = args14[11]; a.lty = args14[12]; a.lth = args14[13];
-  hipLaunchKernelGGL(k_explicit_apply, dim3((n + 255) / 256), dim3(256), 0, st, poses, a);
+void launch_explicit_apply(hipStream_t st, float* poses, const ExplicitArgs& a) {
+  hipLaunchKernelGGL(k_explicit_apply, dim3((a.n + 255) / 256), dim3(256), 0, st, poses, a);
 }
 
-// anchor table (host, libm): (x, y, angle, cos(angle), sin(angle), relative_penalty_dir, id) per anchor
-struct AnchorRow { float x, y, angle, c, s, rel; int id; int pad; };
-struct RowOut { unsigned type; int constrained, anchor; float dpar, dperp, dang, rel; };   // == hitl_human_constraint_t
+// anchor table (host, libm): AnchorRow per anchor pose.  RowOut == hitl_human_constraint_t, field by field.
+struct RowOut { unsigned type; int constrained, anchor; float dpar, dperp, dang, rel; };
+static_assert(sizeof(RowOut) == sizeof(hitl_human_constraint_t), "row layout");
 
 __global__ __launch_bounds__(256) void k_constraint_rows(const float* __restrict__ poses, const AnchorRow* __restrict__ anchors,
                                                          const int* __restrict__ corrected, int n_anchor, int n_corr, unsigned type,
@@ -79,12 +65,12 @@ __global__ __launch_bounds__(256) void k_constraint_rows(const float* __restrict
   rows[t] = r;
 }
 
-void launch_constraint_rows(hipStream_t st, const float* poses, const void* anchors, const int* corrected, int n_anchor, int n_corr,
-                            unsigned type, void* rows) {
+void launch_constraint_rows(hipStream_t st, const float* poses, const AnchorRow* anchors, const int* corrected, int n_anchor, int n_corr,
+                            unsigned type, hitl_human_constraint_t* rows) {
   const int64_t tot = (int64_t)n_anchor * n_corr;
   if (tot == 0) return;
-  hipLaunchKernelGGL(k_constraint_rows, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, poses, (const AnchorRow*)anchors, corrected,
-                     n_anchor, n_corr, type, (RowOut*)rows);
+  hipLaunchKernelGGL(k_constraint_rows, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, poses, anchors, corrected, n_anchor, n_corr,
+                     type, reinterpret_cast<RowOut*>(rows));
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -156,9 +156,19 @@ void launch_fit_eval(hipStream_t st, const float2* pts, int64_t m, double cmx, d
                      double* partial);
 
 // pose-chain stages of the correction cycle (hitl_cycle.hip)
-void launch_explicit_apply(hipStream_t st, float* poses, const float* args14, int n, int g0, int g1);
-void launch_constraint_rows(hipStream_t st, const float* poses, const void* anchors, const int* corrected, int n_anchor, int n_corr,
-                            unsigned type, void* rows);
+struct ExplicitArgs {        // AppExpCorrect::ApplyExplicitCorrections (ApplyExplicitCorrection.cpp:387-415), scalars from the host's libm
+  int n, g0, g1;             // poses; first contiguous group of corrected poses [g0, g1]
+  float c, s, theta;         // Rotation2Df(theta) of the correction
+  float pivx, pivy;          // cmA
+  float dstx, dsty;          // cmB / new_cmA / cmA
+  float lx, ly;              // poses_[last_pose] AFTER its own correction
+  float cl, sl;              // Rotation2Df(last_correction(2))
+  float ltx, lty, lth;       // last_correction
+};
+struct AnchorRow { float x, y, angle, c, s, rel; int id; int pad; };   // per anchor pose: position, angle, cos/sin, relative_penalty_dir
+void launch_explicit_apply(hipStream_t st, float* poses, const ExplicitArgs& args);
+void launch_constraint_rows(hipStream_t st, const float* poses, const AnchorRow* anchors, const int* corrected, int n_anchor, int n_corr,
+                            unsigned type, hitl_human_constraint_t* rows);
 int backprop_blocks(int L);
 void launch_backprop(hipStream_t st, float* poses, float* cov9, int lo, int hi, const float* piv4, const float* tw, float* xf, int* sync,
                      float destx, float desty, float trans_beta, float rot_beta, float* trans2);
