@@ -97,7 +97,7 @@ int comm_allgather(hitl_solver* s, const void* send, void* recv, int64_t bytes) 
   const ncclResult_t r = ncclAllGather(s->comm_send.p, s->comm_recv.p, (size_t)bytes, ncclChar, s->nccl, st);
   if (r != ncclSuccess) return fail(HITL_ERR_COMM, std::string("ncclAllGather: ") + ncclGetErrorString(r));
   HIP_TRY(hipMemcpyAsync(recv, s->comm_recv.p, (size_t)bytes * s->world, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
+  TRY(spin_sync(s));
   return HITL_OK;
 }
 
@@ -296,7 +296,7 @@ static int linear_solve_and_step_dist(hitl_solver* s, const FactorView& fv, int 
   std::vector<double> hb_lo((size_t)Wi * W1 * 9, 0.0), hb_up((size_t)Wi * W1 * 9, 0.0);
   if (me > 0) HIP_TRY(hipMemcpyAsync(hb_lo.data(), lv.Hband + (size_t)(s->own_lo - Wi) * W1 * 9, sizeof(double) * hb_lo.size(), hipMemcpyDeviceToHost, st));
   if (me < W - 1) HIP_TRY(hipMemcpyAsync(hb_up.data(), lv.Hband + (size_t)(s->own_hi - Wi) * W1 * 9, sizeof(double) * hb_up.size(), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
+  TRY(spin_sync(s));
   double* Clo = rec.data() + RI;        // rows: first Wi owned poses, cols: the Wi halo poses below
   double* Cup = Clo + RC;               // rows: last Wi owned poses,  cols: the Wi halo poses above
   if (me > 0)
@@ -377,7 +377,7 @@ static int linear_solve_and_step_dist(hitl_solver* s, const FactorView& fv, int 
   // ride in the same all-gather as the step scalars (exchanges 3 and 1 merged: 7 doubles per rank).
   if (spec) TRY(enqueue_linearize(s, fv, xcand, buf ^ 1));
   TRY(enqueue_step_partials(s));
-  HIP_TRY(hipStreamSynchronize(st));                     // host vectors above stay alive until here
+  TRY(spin_sync(s));                     // host vectors above stay alive until here
   StepScalars loc;
   TRY(finish_step_partials(s, nullptr, nullptr, &loc));
   LinResult lloc = {0.0, 0.0, 0.f, 0};
