@@ -45,6 +45,9 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
   const int n = s->n;
   if (window <= 0 || window > n) window = n;
   const int slots = (int)std::min<int64_t>(2 * window, std::max(n - 1, 1));
+  if (match_lds_bytes(s->max_scan) > (size_t)160 * 1024)
+    return fail(HITL_ERR_UNSUPPORTED, "find_correspondences: a scan of " + std::to_string(s->max_scan) +
+                " points does not fit the 160 KB of LDS the matcher stages a target scan in (limit ~7900 points)");
   const size_t table_entries = (size_t)n * slots * s->max_scan;
   if (table_entries * sizeof(uint16_t) > (size_t)64 << 30)
     return fail(HITL_ERR_OUT_OF_MEMORY, "candidate table would exceed 64 GiB; use a smaller window");
@@ -100,6 +103,7 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
   mp.skip = std::max(s->opt.num_skip_readings, 1);
   const MapView mv = s->map_view();
   launch_match(st, mv, s->max_scan, slots, d_tgt.p, d_tf.p, mp, d_table.p, d_counts.p);
+  if (hipGetLastError() != hipSuccess) { cleanup(); return fail(HITL_ERR_HIP, "find_correspondences: the match kernel could not be launched"); }
   std::vector<int> counts((size_t)n * slots);
   if (hipMemcpyAsync(counts.data(), d_counts.p, counts.size() * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
       hipStreamSynchronize(st) != hipSuccess) {

@@ -129,6 +129,7 @@ void launch_copy(hipStream_t st, int n, const double* src, double* dst);
 
 // correspondence search (JointOptimization.cpp:561-642)
 struct MatchParams { float thr, min_cos; int cap, skip; };
+size_t match_lds_bytes(int max_scan);     // dynamic LDS of k_match: the target scan, per-point counters, bounding boxes
 void launch_match(hipStream_t st, const MapView& map, int max_scan, int slots, const int* cand_tgt /* n*slots, -1 = none */,
                   const float* cand_tf /* n*slots*8 */, MatchParams mp, uint16_t* table /* n*slots*max_scan */,
                   int* counts /* n*slots */);

@@ -106,11 +106,16 @@ __global__ __launch_bounds__(kMatchBlock) void k_match(MapView map, int chunk, i
   }
 }
 
+size_t match_lds_bytes(int max_scan) {
+  return (size_t)max_scan * sizeof(float4) + (size_t)((max_scan + 3) & ~3) * sizeof(int) +
+         (size_t)((max_scan + kMatchGroup - 1) / kMatchGroup) * sizeof(float4);
+}
+
 void launch_match(hipStream_t st, const MapView& map, int max_scan, int slots, const int* cand_tgt, const float* cand_tf,
                   MatchParams mp, uint16_t* table, int* counts) {
   const int chunk = (map.n_poses + 7) / 8;
-  const size_t lds = (size_t)max_scan * sizeof(float4) + (size_t)((max_scan + 3) & ~3) * sizeof(int) +
-                     (size_t)((max_scan + kMatchGroup - 1) / kMatchGroup) * sizeof(float4);
+  const size_t lds = match_lds_bytes(max_scan);
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_match), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k_match, dim3(8 * chunk), dim3(kMatchBlock), lds, st, map, chunk, max_scan, slots, cand_tgt, cand_tf,
                      mp, table, counts);
 }

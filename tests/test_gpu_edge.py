@@ -124,3 +124,30 @@ def test_repeated_solves_and_constraint_undo():
         s.set_human_constraints(first[:25])                 # undo
     p3, _ = _check(g, o, H.MODE_JOINT, prob.init)
     assert np.array_equal(p1, p3)
+
+
+def test_long_scans():
+    """Scans far longer than any 2-D lidar's: 5000 points still match and solve like the oracle (the source scan of the
+    linearisation then comes from global memory instead of LDS); 9000 points exceed the LDS the matcher stages a target
+    scan in and are refused with a message, not with a failed launch somewhere later."""
+    import hitl_slam_amd as H
+    from oracle import hitl_oracle as O
+    prob = Problem(12, 5000, ppf=12, groups=1, kind=4, window=2)
+    g, o = H.Solver(), O.OracleSolver()
+    prob.load(g); prob.load(o)
+    g.find_correspondences(prob.init, 2)
+    o.find_correspondences(prob.init, 2, 0)
+    for a, b in zip(g.get_correspondences(), o.get_correspondences()):
+        assert np.array_equal(a, b)
+    pg, sg = g.solve(H.MODE_JOINT, prob.init)
+    po, so = o.solve(H.MODE_JOINT, prob.init)
+    assert sg.iterations == so.iterations and np.abs(pg - po).max() < 1e-4
+    g.close(); o.close()
+    prob = Problem(6, 9000, ppf=6, groups=0, window=1)
+    g = H.Solver()
+    prob.load(g)
+    with pytest.raises(H.HitlError) as e:
+        g.find_correspondences(prob.init, 1)
+    assert "LDS" in str(e.value)
+    g.solve(H.MODE_ODOM_HC, prob.init)        # the solver is still usable
+    g.close()
