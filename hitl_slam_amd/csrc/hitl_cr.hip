@@ -206,13 +206,13 @@ __device__ __forceinline__ void cr_update_node(const CrView& cr, int s, int j, i
 //     Gauss-Jordan) so that level needs no separate inversion launch either.
 template <int B>
 __device__ __forceinline__ void lds_load(double* dst, const double* src) {
-  for (int e = threadIdx.x; e < B * B; e += WAVE) dst[e] = src[e];
+  for (int e = threadIdx.x; e < B * B; e += blockDim.x) dst[e] = src[e];
 }
 
 // C = A * Bm (TA: use A^T, TB: use Bm^T), all B x B tiles in LDS, one wave
 template <int B, bool TA, bool TB>
 __device__ __forceinline__ void lds_matmul(double* C, const double* A, const double* Bm) {
-  for (int e = threadIdx.x; e < B * B; e += WAVE) {
+  for (int e = threadIdx.x; e < B * B; e += blockDim.x) {
     const int r = e / B, c = e % B;
     double v = 0.0;
 #pragma unroll
@@ -221,8 +221,10 @@ __device__ __forceinline__ void lds_matmul(double* C, const double* A, const dou
   }
 }
 
+// two waves per survivor: the 81-element tile loops (loads, three products, Schur update) take one pass instead of two
+constexpr int kCrLevelThreads = 128;
 template <int B>
-__global__ __launch_bounds__(WAVE) void k_cr_level(CrView cr, int s, int invert_next, double* w, int nrhs, size_t stride) {
+__global__ __launch_bounds__(kCrLevelThreads) void k_cr_level(CrView cr, int s, int invert_next, double* w, int nrhs, size_t stride) {
   __shared__ double sLj[B * B], sL1[B * B], sL2[B * B], sI1[B * B], sI2[B * B], sGr1[B * B], sGl1[B * B], sGl2[B * B], sD[B * B];
   const int j = 2 * s * blockIdx.x;
   if (j >= cr.nsb) return;
@@ -236,14 +238,14 @@ __global__ __launch_bounds__(WAVE) void k_cr_level(CrView cr, int s, int invert_
   if (has1) {
     lds_matmul<B, false, true>(sGr1, sI1, sLj);       // Dinv_k1 * L_j^T
     if (has_ll) lds_matmul<B, false, false>(sGl1, sI1, sL1);   // Dinv_k1 * L_k1
-    else for (int e = threadIdx.x; e < B * B; e += WAVE) sGl1[e] = 0.0;
+    else for (int e = threadIdx.x; e < B * B; e += kCrLevelThreads) sGl1[e] = 0.0;
   }
   if (has2) lds_matmul<B, false, false>(sGl2, sI2, sL2);       // Dinv_k2 * L_k2
   __syncthreads();
   // factors of the eliminated neighbours, for the back substitution
-  if (has1) for (int e = threadIdx.x; e < B * B; e += WAVE) { cr.Gr[(size_t)k1 * BB + e] = sGr1[e]; cr.Gl[(size_t)k1 * BB + e] = sGl1[e]; }
+  if (has1) for (int e = threadIdx.x; e < B * B; e += kCrLevelThreads) { cr.Gr[(size_t)k1 * BB + e] = sGr1[e]; cr.Gl[(size_t)k1 * BB + e] = sGl1[e]; }
   if (has2 && (k2 + s) >= cr.nsb)      // k2 has no right-hand survivor: its Gl comes from here, its Gr is zero
-    for (int e = threadIdx.x; e < B * B; e += WAVE) { cr.Gl[(size_t)k2 * BB + e] = sGl2[e]; cr.Gr[(size_t)k2 * BB + e] = 0.0; }
+    for (int e = threadIdx.x; e < B * B; e += kCrLevelThreads) { cr.Gl[(size_t)k2 * BB + e] = sGl2[e]; cr.Gr[(size_t)k2 * BB + e] = 0.0; }
   // right-hand-side sweep
   if (w != nullptr && (int)threadIdx.x < B) {
     for (int v = 0; v < nrhs; ++v) {
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(WAVE) void k_cr_level(CrView cr, int s, int invert_
     }
   }
   // Schur complement
-  for (int e = threadIdx.x; e < B * B; e += WAVE) {
+  for (int e = threadIdx.x; e < B * B; e += kCrLevelThreads) {
     const int r = e / B, c = e % B;
     double d = sD[e], l = 0.0;
     if (has1) {
@@ -277,6 +279,7 @@ __global__ __launch_bounds__(WAVE) void k_cr_level(CrView cr, int s, int invert_
   // inversion of the new D_j when j is eliminated at the next level
   if (invert_next && (blockIdx.x & 1)) {
     __syncthreads();
+    if (threadIdx.x >= WAVE) return;             // the register-resident inverse lives in the first wave
     const int grp = threadIdx.x / B, c = threadIdx.x % B;
     double col[B];
 #pragma unroll
@@ -608,7 +611,7 @@ static void cr_factor_t(hipStream_t st, const CrView& cr, double* w, double* x, 
   for (int s = 1; s < s_top; s *= 2) {
     const int n_surv = (cr.nsb + 2 * s - 1) / (2 * s);
     const int invert_next = (2 * s < s_top) ? 1 : 0;    // the fused top kernel inverts its own nodes
-    hipLaunchKernelGGL(k_cr_level<B>, dim3(n_surv), dim3(WAVE), 0, st, cr, s, invert_next, w, nrhs, stride);
+    hipLaunchKernelGGL(k_cr_level<B>, dim3(n_surv), dim3(kCrLevelThreads), 0, st, cr, s, invert_next, w, nrhs, stride);
   }
   {
     const int M = (cr.nsb + s_top - 1) / s_top;
