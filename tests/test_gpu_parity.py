@@ -211,3 +211,26 @@ def test_in_library_rccl_allgather_world1():
     env = dict(os.environ, HITL_FORCE_RCCL="1", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=root, timeout=300)
     assert r.returncode == 0 and "rccl self-test ok" in r.stdout, (r.returncode, r.stdout[-400:], r.stderr[-800:])
+
+
+def test_timing_levels_do_not_change_results(small_problem):
+    """hitl_options.timing_level only decides how many device-timing events a solve records (0: none, 1: every 4th
+    linearisation, 2: all + linear-solver time): poses, cost and iteration count are identical, the timers behave as
+    documented."""
+    import hitl_slam_amd as H
+    prob = small_problem
+    corr = oracle_corr(prob)
+    res = []
+    for level in (0, 1, 2):
+        o = H.default_options()
+        o.timing_level = level
+        s = H.Solver(o)
+        prob.load(s, corr=corr)
+        p, summ = s.solve(H.MODE_JOINT, prob.init)
+        res.append((p, summ.final_cost, summ.iterations, summ.linearize_timed_calls, summ.linearize_calls, summ.linear_solver_ms, summ.linearize_ms))
+        s.close()
+    for r in res[1:]:
+        assert np.array_equal(r[0], res[0][0]) and r[1] == res[0][1] and r[2] == res[0][2]
+    assert res[0][3] == 0 and res[0][5] == 0.0 and res[0][6] == 0.0
+    assert 0 < res[1][3] <= (res[1][4] + 3) // 4 + 1 and res[1][5] == 0.0 and res[1][6] > 0.0
+    assert res[2][3] == res[2][4] and res[2][5] > 0.0
