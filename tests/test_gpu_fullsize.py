@@ -60,6 +60,41 @@ def test_fullsize_solve_properties(big):
     assert np.isfinite(c_stf_out) and c_stf_out > 0 and c_stf_out < 10 * c_stf_in
 
 
+def _pose_diff(a, b):
+    d = np.asarray(a, np.float64) - np.asarray(b, np.float64)
+    d[:, 2] = np.angle(np.exp(1j * d[:, 2]))
+    return float(np.abs(d[:, :2]).max()), float(np.abs(d[:, 2]).max())
+
+
+def test_fullsize_solve_matches_oracle(big):
+    """The whole mode-C re-solve (JointOptimization.cpp:1064-1138 + :1156-1256 as one problem) at the size the north
+    star quotes: 50 000 poses x 400 obs, the GPU's own correspondence set handed to the oracle.  Same termination, same
+    LM iteration and accepted-step counts, final cost to 1e-8 relative, poses to 1e-4 m / 1e-4 rad."""
+    import os
+    import time
+    import hitl_slam_amd as H
+    from oracle import hitl_oracle as O
+    s = big["s"]
+    pg, sg = s.solve(H.MODE_JOINT, big["init"])
+    o = O.OracleSolver()
+    o.set_map(*big["map"])
+    o.set_human_constraints(big["rows"])
+    o.set_correspondences(*s.get_correspondences())
+    O.set_num_threads(len(os.sched_getaffinity(0)))
+    t0 = time.time()
+    po, so = o.solve(H.MODE_JOINT, big["init"])
+    dt = time.time() - t0
+    o.close()
+    dxy, dth = _pose_diff(pg, po)
+    print("\nC4 full-size solve: gpu iters=%d ok=%d cost=%.12g | oracle iters=%d ok=%d cost=%.12g (%.1f s on %d threads) | "
+          "max|dxy|=%.3g m max|dth|=%.3g rad" % (sg.iterations, sg.successful_steps, sg.final_cost, so.iterations,
+                                                  so.successful_steps, so.final_cost, dt, len(os.sched_getaffinity(0)), dxy, dth))
+    assert sg.termination == so.termination
+    assert sg.iterations == so.iterations and sg.successful_steps == so.successful_steps
+    assert abs(sg.final_cost - so.final_cost) <= 1e-8 * so.final_cost
+    assert dxy <= 1e-4 and dth <= 1e-4
+
+
 def test_fullsize_correction_cycle_matches_oracle(big):
     """One whole user correction on the 20 M-observation map: every pre-solve stage against the oracle (index sets and
     fp32 poses bit for bit), then the longest possible back-propagation (both ends of the 50 000-pose trajectory:
