@@ -60,11 +60,16 @@ def main():
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--poses", type=int, default=0, help="override poses per GPU")
     ap.add_argument("--obs", type=int, default=0, help="override observations per pose")
-    ap.add_argument("--cpu-sample-poses", type=int, default=6000, help="poses in the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample-poses", type=int, default=6000, help="poses in the 1-thread sample of the cpu_baseline leg")
+    ap.add_argument("--cpu-budget-s", type=float, default=30.0, help="CPU seconds the cpu_baseline leg may spend on repeats of the full workload")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N>1: weak = N x the workload's poses (default), strong = the SAME map split into N pose-range submaps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--timing-level", type=int, default=1, help="hitl_options.timing_level: 1 = every 4th stf launch bracketed by "
                     "HIP events (default), 2 = all launches + linear-solver timing")
-    ap.add_argument("--comm", default="rccl", choices=["rccl", "torch"], help="N>1 exchange: in-library RCCL or torch.distributed")
+    ap.add_argument("--comm", default="auto", choices=["auto", "rccl", "torch"],
+                    help="N>1 exchange: rccl = in-library ncclAllGather (exit non-zero if it cannot be used), torch = "
+                         "torch.distributed all_gather callback, auto = rccl, else torch -- the transport used is in the JSON")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo lets several ranks share one GPU (debugging on a 1-GPU box)")
     args = ap.parse_args()
@@ -99,16 +104,27 @@ def main():
         wl["poses"] = args.poses
     if args.obs:
         wl["obs"] = args.obs
-    n_local, M = wl["poses"], wl["obs"]
-    ppf = 200 if n_local >= 400 else max(n_local // 2, 8)
-    n_global = n_local * world
+    M = wl["obs"]
+    ppf = 200 if wl["poses"] >= 400 else max(wl["poses"] // 2, 8)
+    if args.scaling == "strong" and world > 1:
+        # the SAME map on N GPUs (BASELINE configs[3]: 50k poses on 4; configs[4]: --workload c5 --poses 200000 on 8);
+        # cuts fall between floors where possible, so only an odometry edge straddles them
+        n_global = wl["poses"]
+        cuts = [0] + [int(round(r * n_global / world / ppf)) * ppf for r in range(1, world)] + [n_global]
+        if any(cuts[r + 1] - cuts[r] < 4 * wl["window"] + 2 for r in range(world)):
+            cuts = [r * n_global // world for r in range(world)] + [n_global]
+        wl["groups"] = max(1, wl["groups"] // world)
+    else:
+        n_global = wl["poses"] * world
+        cuts = [r * wl["poses"] for r in range(world + 1)]
+    n_local = cuts[rank + 1] - cuts[rank]
     seed = 20260102 + 1000 * {"c2": 2, "c4": 4, "c5": 5}[args.workload]
 
     # ---- synthetic map: this rank's pose-range submap of the global trajectory ------------------
     t0 = time.time()
     p = S.params(n_global, M, seed=seed, poses_per_floor=ppf)
     gt, init, cov = S.poses(p)
-    begin, end = rank * n_local, (rank + 1) * n_local        # this rank's owned pose range
+    begin, end = cuts[rank], cuts[rank + 1]                  # this rank's owned pose range
     halo = 2 * wl["window"] if use_dist else 0               # scans + state of the neighbours' nearest poses
     lo, hi = begin - (halo if rank > 0 else 0), end + (halo if rank < world - 1 else 0)
     off, px, py, nx, ny = S.scans(p, lo, hi)
@@ -120,13 +136,15 @@ def main():
     opt.device = dev_index
     opt.timing_level = args.timing_level
     comm_kind = "none"
+    comm_ranks = 1
     keep = []
     if use_dist:
         # pose-range submaps: rank r owns global poses [begin, end); the cut falls between two floors,
         # so only the odometry edge straddles it.  Exchange = 2 tiny all-gathers per LM iteration.
         opt.rank, opt.world_size = rank, world
         solver = None
-        if args.comm == "rccl":
+        rccl_error = None
+        if args.comm in ("rccl", "auto"):
             ok = 1
             try:
                 from hitl_slam_amd.api import comm_unique_id
@@ -139,6 +157,7 @@ def main():
                 opt.rccl_unique_id = C.cast(buf, C.c_void_p)
                 solver = H.Solver(opt)
             except Exception as e:
+                rccl_error = repr(e)
                 sys.stderr.write("rank %d: in-library RCCL unavailable (%r)\n" % (rank, e))
                 ok, solver = 0, None
             # the choice of transport must be the same on every rank
@@ -147,24 +166,34 @@ def main():
             if int(flag.item()) == 1:
                 try:
                     solver.comm_selftest()
+                    comm_ranks = solver.comm_ranks()
+                    if comm_ranks != world:
+                        raise RuntimeError("RCCL communicator holds %d ranks, expected %d" % (comm_ranks, world))
                 except Exception as e:
+                    rccl_error = repr(e)
                     sys.stderr.write("rank %d: RCCL self-test failed (%r)\n" % (rank, e))
                     ok = 0
                 flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 1:
-                comm_kind = "rccl (in-library ncclAllGather)"
+                comm_kind = "rccl (in-library ncclAllGather, %d ranks in the communicator)" % comm_ranks
             else:
                 if solver is not None:
                     solver.close()
                 solver = None
+                if args.comm == "rccl":      # asked for explicitly: no silent change of transport
+                    sys.stderr.write("rank %d: --comm rccl requested but in-library RCCL is not usable (%s)\n" % (rank, rccl_error))
+                    dist.destroy_process_group()
+                    sys.exit(3)
         if solver is None:
             from hitl_slam_amd.api import torch_allgather_ops
             opt.rccl_unique_id = None
             solver = H.Solver(opt)
             ops, fn = torch_allgather_ops(device=torch.device("cuda", dev_index) if args.backend == "nccl" else None)
             solver.set_comm(ops, fn)
-            comm_kind = "torch.distributed all_gather (%s backend)" % ("nccl = RCCL" if args.backend == "nccl" else "gloo")
+            comm_kind = "torch.distributed all_gather callback (%s backend)%s" % (
+                "nccl = RCCL" if args.backend == "nccl" else "gloo",
+                "; in-library RCCL was tried first and failed" if args.comm == "auto" and args.backend == "nccl" else "")
         solver.set_partition(begin, n_global, halo)
         solver.set_map(off, px, py, nx, ny, cov[lo:hi])
         solver.set_human_constraints(rows)          # global pose ids
@@ -223,14 +252,20 @@ def main():
     ms_per_step = elapsed * 1e3 / args.steps
     avg_stf_ms = stf_ms / max(stf_calls, 1)
     alg_bytes = algorithmic_bytes_stf(n_obs, n_matches_l, n_local, n_pairs_l)
-    achieved = alg_bytes / (avg_stf_ms * 1e-3) / 1e9 if avg_stf_ms > 0 else 0.0
-    traffic = None
+    alg_achieved = alg_bytes / (avg_stf_ms * 1e-3) / 1e9 if avg_stf_ms > 0 else 0.0
+    compulsory = 16 * n_obs + 4 * int(n_matches_l) + 24 * n_local + 112 * int(n_pairs_l)
+    # HBM bytes per launch are NOT measured in this run: they come from the committed PMC passes of the same command
+    # (tools/profile_bench.sh: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, separate rocprofv3 --pmc runs)
+    # and are used only when that profile was taken on exactly this workload; otherwise the layout's compulsory bytes.
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            if tj.get("n_obs") == n_obs:
+            if tj.get("n_obs") == n_obs and (tj.get("n_matches") in (None, int(n_matches_l))):
                 traffic = tj.get("hbm_bytes_per_launch")
+                traffic_source = "profiles/traffic_%s.json (%s; kernel-trace average %.1f us in that run)" % (
+                    args.workload, tj.get("source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py"), tj.get("stf_avg_us", 0.0))
         except Exception:
             traffic = None
     pmc = None
@@ -240,6 +275,8 @@ def main():
             pmc = json.load(open(ppath))
         except Exception:
             pmc = None
+    moved = traffic if traffic else compulsory
+    achieved = moved / (avg_stf_ms * 1e-3) / 1e9 if avg_stf_ms > 0 else 0.0
     out_l = out[begin:end] if use_dist else out
     err_gt = float(np.abs(out_l[:, :2].astype(np.float64) - gt[begin:end, :2]).max())
 
@@ -268,15 +305,39 @@ def main():
         "termination": int(summ.termination),
         "final_cost": summ.final_cost,
         "correspondence_search_ms": match_ms,
-        "linear_solver_ms_per_resolve": lin_solver_ms / args.steps,
-        "max_xy_error_vs_ground_truth_m": err_gt,
+        "residual_drift_vs_ground_truth_m": err_gt,
+        "residual_drift_note": "max |xy - ground truth| after the re-solve; the synthetic odometry drift is only removed where "
+                               "human constraints and scan overlap observe it, so this is a property of the input, not an error",
+        # frac = bytes this kernel really moves through HBM per launch (PMC-measured when a matching profile is
+        # committed, else the layout's compulsory bytes) / live HIP-event launch time / 8 TB/s.  The SURVEY 8(d)
+        # algorithmic-byte figure (24 B per match) is kept beside it: this layout moves 4 B per match and serves the
+        # target gathers from L2, so that figure can exceed the peak and is not a bandwidth.
         "roofline": {"bound": "hbm", "kernel": "k_linearize_stf", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_stf_ms, "launches": stf_launches, "launches_bracketed_by_hip_events": stf_calls,
-                     "compulsory_bytes_this_layout": 16 * n_obs + 4 * int(n_matches_l) + 24 * n_local + 112 * int(n_pairs_l),
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                     "bytes_per_launch_used_for_achieved": moved,
+                     "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_achieved": alg_achieved,
+                     "algorithmic_frac": alg_achieved / HBM_PEAK_GBS,
+                     "compulsory_bytes_this_layout": compulsory,
+                     "avg_launch_ms": avg_stf_ms, "launches": stf_launches, "launches_bracketed_by_hip_events": stf_calls,
+                     "limiter": "VALU issue (fp64 + address arithmetic), not HBM: see utilisation_counters",
                      "utilisation_counters": pmc},
         "synth_gen_s": gen_s,
     }
+
+    # ---- side leg (untimed): every launch bracketed, linear solve of every LM iteration timed (timing_level 2) ----
+    if world == 1:
+        try:
+            solver.set_timing_level(2)
+            _, sm2 = solver.solve(H.MODE_JOINT, pose_arg)
+            solver.set_timing_level(args.timing_level)
+            result["phase_breakdown_timing_level_2"] = {
+                "linear_solver_ms_per_resolve": sm2.linear_solver_ms, "linear_solver_ms_per_lm_iteration": sm2.linear_solver_ms / max(sm2.iterations, 1),
+                "linearize_stf_ms_per_launch_all_launches": sm2.linearize_ms / max(sm2.linearize_timed_calls, 1),
+                "lm_iterations": int(sm2.iterations), "resolve_ms_with_event_overhead": sm2.total_ms,
+                "note": "one extra re-solve after the timed region with hitl_options.timing_level = 2 (an event record drains the "
+                        "queue, so this leg is slower than ms_per_step and is not part of `value`)"}
+        except Exception as e:
+            result["phase_breakdown_timing_level_2"] = {"failed": repr(e)}
 
     # ---- one interactive correction cycle on the same resident map, reported alongside ----
     if world == 1:
@@ -336,47 +397,85 @@ def main():
         except Exception as e:
             result["stf_moments_mode"] = {"failed": repr(e)}
 
-    # ---- CPU baseline: the oracle (a port, not the reference binary) on a bounded sample ----------
-    if not args.no_cpu_baseline and args.cpu_sample_poses > 0 and world == 1:
+    # ---- CPU baseline: the oracle (a port, not the reference binary) on the WHOLE bench workload ----------------
+    # Same map, same correspondences, same human rows, same mode; threads = the cores this process may really use
+    # (affinity mask capped by the cgroup CPU quota -- os.cpu_count() is neither); warm-up + best of up to 5 within
+    # --cpu-budget-s; a 1-thread figure on a bounded sample beside it.  `make native` build of the oracle for this host.
+    if not args.no_cpu_baseline and world == 1:
         try:
+            os.environ["HITL_ORACLE_NATIVE"] = "1"
             from oracle import hitl_oracle as O
-            ns = min(args.cpu_sample_poses, n_local)
-            ns = max((ns // ppf) * ppf, min(ppf, n_local))
-            ps, pt, mo, i0, i1 = solver.get_correspondences()
-            sel = (ps < ns) & (pt < ns)
-            keep_idx = np.nonzero(sel)[0]
-            lens = (mo[1:] - mo[:-1])[keep_idx]
-            mo_s = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
-            take = np.concatenate([np.arange(mo[k], mo[k + 1]) for k in keep_idx]) if len(keep_idx) else np.zeros(0, np.int64)
-            groups_s = max(1, int(round(wl["groups"] * ns / n_local)))
-            # the sample IS the first ns poses of the GPU workload (same scans, poses, matches)
-            rows_s = S.constraints(p, gt, groups_s, kind=wl["kind"], begin=0, end=ns)
-            init_s, cov_s = np.ascontiguousarray(init_l[:ns]), cov[:ns]
+            from tools import probe_host
+            cores = probe_host.usable_cores()
+            host = probe_host.probe()
+            corr = solver.get_correspondences()
             orc = O.OracleSolver()
-            orc.set_map(off[:ns + 1], px[:off[ns]], py[:off[ns]], nx[:off[ns]], ny[:off[ns]], cov_s)
-            orc.set_human_constraints(rows_s)
-            orc.set_correspondences(ps[keep_idx], pt[keep_idx], mo_s, i0[take], i1[take])
-            cores = os.cpu_count() or 1
+            orc.set_map(off, px, py, nx, ny, cov)
+            orc.set_human_constraints(rows)
+            orc.set_correspondences(*corr)
             O.set_num_threads(cores)
-            orc.solve(H.MODE_JOINT, init_s)                       # warm-up
-            best = None
-            for _ in range(3):
+            t0 = time.perf_counter()
+            oout, so = orc.solve(H.MODE_JOINT, init_l)                       # warm-up (page faults, thread pool)
+            first = time.perf_counter() - t0
+            reps = int(max(1, min(5, (args.cpu_budget_s - first) // max(first, 1e-3))))
+            times, phases = [], None
+            for _ in range(reps):
                 t0 = time.perf_counter()
-                _, so = orc.solve(H.MODE_JOINT, init_s)
+                oout, so = orc.solve(H.MODE_JOINT, init_l)
                 dt = time.perf_counter() - t0
-                best = dt if best is None else min(best, dt)
-            n_obs_s = int(off[ns])
+                if not times or dt < min(times):
+                    phases = orc.phase_ms()
+                times.append(dt)
+            best = min(times)
+            d = oout.astype(np.float64) - out
+            d[:, 2] = np.angle(np.exp(1j * d[:, 2]))
+            evals = float(n_matches_l) * so.linearize_calls
             result["cpu_baseline"] = {
-                "value": n_obs_s * so.iterations / best, "unit": "obs-iters/s", "cores": cores, "kind": "port",
-                "sample": "oracle (C/OpenMP restatement, analytic Jacobians, exact banded Cholesky) on the first %d poses "
-                          "x %d obs (%d matches, %d constraint rows), same mode C, best of 3: %.1f ms per re-solve, %d LM iterations"
-                          % (ns, M, int(mo_s[-1]), rows_s[1], best * 1e3, so.iterations),
-                "resolve_ms_sample": best * 1e3, "sample_obs": n_obs_s,
-                "resolve_ms_extrapolated_to_workload": best * 1e3 * n_obs / n_obs_s,
+                "value": n_obs * so.iterations / best, "unit": "obs-iters/s", "cores": cores, "kind": "port",
+                "sample": "the WHOLE bench workload (%d poses x %d obs, %d matches, %d constraint rows, mode C), oracle = C/OpenMP "
+                          "restatement (analytic Jacobians, exact banded Cholesky; -O3 -march=native), %d threads, 1 warm-up + best "
+                          "of %d: %.1f ms per re-solve, %d LM iterations (GPU: %d)" % (n_local, M, int(n_matches_l), rows[1], cores,
+                                                                                     reps, best * 1e3, so.iterations, summ.iterations),
+                "resolve_ms": best * 1e3, "resolve_ms_all_repeats": [t * 1e3 for t in times], "warmup_ms": first * 1e3,
+                "lm_iterations": int(so.iterations), "lm_iterations_gpu": int(summ.iterations),
+                "final_cost": so.final_cost, "final_cost_gpu": summ.final_cost,
+                "max_pose_difference_vs_gpu_m_rad": [float(np.abs(d[:, :2]).max()), float(np.abs(d[:, 2]).max())],
+                "phase_ms_best_run": phases,
+                "match_evaluations_per_s_per_core": evals / (phases["evaluate"] * 1e-3) / cores if phases and phases["evaluate"] > 0 else None,
+                "host": {"cpu_model": host.get("cpu_model"), "os_cpu_count": host.get("os_cpu_count"), "affinity": host.get("affinity"),
+                         "cgroup_cpu_max": host.get("/sys/fs/cgroup/cpu.max"), "threads_used": cores,
+                         "OMP_PROC_BIND": host.get("OMP_PROC_BIND"), "OMP_NUM_THREADS_env": host.get("OMP_NUM_THREADS")},
             }
             result["speedup_vs_cpu_port"] = result["value"] / result["cpu_baseline"]["value"]
+            result["resolve_ms_cpu_port_over_gpu"] = best * 1e3 / ms_per_step
+            # 1 thread, bounded sample: the first ns poses of the same workload (pairs inside the sample)
+            ns = min(args.cpu_sample_poses, n_local)
+            ns = max((ns // ppf) * ppf, min(ppf, n_local))
+            if ns > 0:
+                ps, pt, mo, i0, i1 = corr
+                keep_idx = np.nonzero((ps < ns) & (pt < ns))[0]
+                lens = (mo[1:] - mo[:-1])[keep_idx]
+                mo_s = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+                take = np.concatenate([np.arange(mo[k], mo[k + 1]) for k in keep_idx]) if len(keep_idx) else np.zeros(0, np.int64)
+                rows_s = S.constraints(p, gt, max(1, int(round(wl["groups"] * ns / n_local))), kind=wl["kind"], begin=0, end=ns)
+                o1 = O.OracleSolver()
+                o1.set_map(off[:ns + 1], px[:off[ns]], py[:off[ns]], nx[:off[ns]], ny[:off[ns]], cov[:ns])
+                o1.set_human_constraints(rows_s)
+                o1.set_correspondences(ps[keep_idx], pt[keep_idx], mo_s, i0[take], i1[take])
+                O.set_num_threads(1)
+                t0 = time.perf_counter()
+                _, s1 = o1.solve(H.MODE_JOINT, np.ascontiguousarray(init_l[:ns]))
+                t1 = time.perf_counter() - t0
+                ph1 = o1.phase_ms()
+                result["cpu_baseline"]["one_thread_sample"] = {
+                    "poses": ns, "matches": int(mo_s[-1]), "resolve_ms": t1 * 1e3, "lm_iterations": int(s1.iterations),
+                    "obs_iters_per_s": float(off[ns]) * s1.iterations / t1,
+                    "match_evaluations_per_s": float(mo_s[-1]) * s1.linearize_calls / (ph1["evaluate"] * 1e-3) if ph1["evaluate"] > 0 else None}
+                o1.close()
+                O.set_num_threads(cores)
+            orc.close()
         except Exception as e:  # the baseline is a reported extra; never fail the bench line on it
-            result["cpu_baseline"] = {"value": None, "unit": "obs-iters/s", "cores": os.cpu_count(), "kind": "port",
+            result["cpu_baseline"] = {"value": None, "unit": "obs-iters/s", "cores": None, "kind": "port",
                                       "sample": "failed: %r" % (e,)}
     print(json.dumps(result))
     sys.stdout.flush()

@@ -503,6 +503,25 @@ class Solver(SolverBase):
         if st != abi.OK:
             raise HitlError(st, "hitl_solver_comm_selftest", self._detail())
 
+    def set_timing_level(self, level):
+        f = self._lib.hitl_solver_set_timing_level
+        f.argtypes = [C.c_void_p, C.c_int32]
+        f.restype = C.c_int
+        st = f(self._h, int(level))
+        if st != abi.OK:
+            raise HitlError(st, "hitl_solver_set_timing_level", self._detail())
+
+    def comm_ranks(self, want_kind=False):
+        """Ranks the active transport holds (ncclCommCount for the built-in RCCL communicator)."""
+        f = self._lib.hitl_solver_comm_ranks
+        f.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        f.restype = C.c_int
+        n, k = C.c_int32(), C.c_int32()
+        st = f(self._h, C.byref(n), C.byref(k))
+        if st != abi.OK:
+            raise HitlError(st, "hitl_solver_comm_ranks", self._detail())
+        return (n.value, k.value) if want_kind else n.value
+
     def set_comm(self, ops, keepalive=None):
         f = self._lib.hitl_solver_set_comm
         f.argtypes = [C.c_void_p, C.POINTER(CommOps)]

@@ -484,7 +484,7 @@ int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float* poses
     if (!ok || ss.bad > 0.0 || !(mcc == mcc) || mcc < 0.0) {  // invalid step
       ++S.unsuccessful_steps;
       if (++invalid_run >= 5) { term = HITL_FAILURE; break; }
-      radius /= decrease_factor; decrease_factor *= 2.0;
+      radius *= 0.5;   // LevenbergMarquardtStrategy::StepIsInvalid: halve; decrease_factor is untouched
       continue;
     }
     invalid_run = 0;

@@ -455,6 +455,26 @@ int hitl_solver_comm_selftest(hitl_solver* s) {
   return HITL_OK;
 }
 
+int hitl_solver_set_timing_level(hitl_solver* s, int32_t level) {
+  if (!s || level < 0 || level > 2) return fail(HITL_ERR_INVALID_ARGUMENT, "set_timing_level: level must be 0, 1 or 2");
+  s->opt.timing_level = level;
+  return HITL_OK;
+}
+
+int hitl_solver_comm_ranks(hitl_solver* s, int32_t* ranks, int32_t* kind) {
+  if (!s || !ranks) return fail(HITL_ERR_INVALID_ARGUMENT, "comm_ranks: null argument");
+  int n = 1, k = 0;
+  if (s->comm.allgather) { n = s->world; k = 2; }
+  else if (s->nccl) {
+    const ncclResult_t r = ncclCommCount(s->nccl, &n);
+    if (r != ncclSuccess) return fail(HITL_ERR_COMM, std::string("ncclCommCount: ") + ncclGetErrorString(r));
+    k = 1;
+  }
+  *ranks = n;
+  if (kind) *kind = k;
+  return HITL_OK;
+}
+
 int hitl_solver_set_partition(hitl_solver* s, int64_t global_begin, int64_t n_global_poses, int32_t halo_poses) {
   if (!s || global_begin < 0 || n_global_poses < 1 || global_begin >= n_global_poses) return fail(HITL_ERR_INVALID_ARGUMENT, "set_partition: bad range");
   if (s->world == 1 && (global_begin != 0)) return fail(HITL_ERR_INVALID_ARGUMENT, "set_partition: a single-GPU solver owns the whole map");

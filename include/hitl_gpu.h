@@ -286,10 +286,12 @@ int hitl_solver_linearize(hitl_solver*, int32_t mode, const float* poses_ref_xyt
  *   hitl_solver_solve(mode, poses_in GLOBAL, poses_out GLOBAL, summary)
  *        every rank takes identical LM decisions; poses_out receives the owned range (other
  *        entries are copied from poses_in); summary costs/iterations are global.
- * Per LM iteration the ranks exchange three small all-gathers: (cost, |g|max) after a
- * linearisation; the interface rows of the local multi-rhs cyclic-reduction solve + Jacobi
- * scales + cross-cut blocks (<= 5 KB per rank; the coupling is then eliminated exactly by a
- * 6*band*world interface system solved identically on every rank); the step scalars.
+ * Per LM iteration the ranks exchange TWO small all-gathers: the interface rows of the local
+ * multi-rhs cyclic-reduction solve + Jacobi scales + cross-cut blocks (<= 5 KB per rank; the
+ * coupling is then eliminated exactly by a 6*band*world interface system solved identically on
+ * every rank); then 7 doubles per rank: the step scalars together with (cost, |g|max) of the
+ * candidate, whose linearisation is queued speculatively behind the step.  (cost, |g|max) of the
+ * initial linearisation travel once, before the loop.
  * The all-gather is either the built-in RCCL one (opt.rccl_unique_id != NULL) or a caller
  * supplied callback on HOST buffers (tests use torch.distributed/gloo). */
 typedef int (*hitl_allgather_fn)(void* ctx, const void* send, void* recv, int64_t bytes_per_rank);
@@ -301,6 +303,9 @@ int hitl_solver_set_comm(hitl_solver*, const hitl_comm_ops* ops);
 int hitl_solver_set_partition(hitl_solver*, int64_t global_begin, int64_t n_global_poses, int32_t halo_poses);
 /* one small all-gather through the active communicator, payload verified (bring-up check) */
 int hitl_solver_comm_selftest(hitl_solver*);
+/* ranks the active transport really holds: ncclCommCount of the built-in RCCL communicator, world_size for a caller
+ * callback, 1 when neither is installed.  kind (may be NULL): 0 = none, 1 = built-in RCCL, 2 = caller callback. */
+int hitl_solver_comm_ranks(hitl_solver*, int32_t* ranks, int32_t* kind);
 
 /* Multi-GPU helpers.  hitl_comm_unique_id: rank 0 calls it and broadcasts the 128 bytes.
  * hitl_partition_range: the contiguous pose range rank r of w owns for n_poses poses,
@@ -349,6 +354,10 @@ int hitl_input_log_entry(const hitl_input_log*, int32_t i, uint32_t* type, int32
                          const float** points_xy);
 int hitl_io_save_input_log(const char* path, int32_t n_entries, const uint32_t* types, const int32_t* undone,
                            const int32_t* n_points, const float* points_xy);
+
+/* Changes hitl_options.timing_level of a live solver (0 none, 1 every 4th scan-to-scan launch bracketed by HIP
+ * events, 2 every launch + the linear solve of every LM iteration: adds ~20 us of queue drain per iteration). */
+int hitl_solver_set_timing_level(hitl_solver*, int32_t level);
 
 /* Free / total memory of a HIP device in bytes (hipMemGetInfo); for leak checks and capacity planning. */
 int hitl_device_memory(int32_t device, int64_t* free_bytes, int64_t* total_bytes);

@@ -242,6 +242,9 @@ void orc_stf_eval(const double x0[3], const double x1[3], int64_t n, const float
   const double c0 = cos(x0[2]), s0 = sin(x0[2]), c1 = cos(x1[2]), s1 = sin(x1[2]);
   const double corr = (double)corr_factor, sd = (double)std_dev;
   double S0 = 0, S1 = 0, G0[6] = {0, 0, 0, 0, 0, 0}, G1[6] = {0, 0, 0, 0, 0, 0};
+#ifdef ORC_SIMD   /* cpu_baseline build only (make native): same arithmetic per match, vector-lane summation order */
+#pragma omp simd reduction(+ : S0, S1, G0[:6], G1[:6])
+#endif
   for (int64_t i = 0; i < n; ++i) {
     const double ax = p0x[i], ay = p0y[i], bx = p1x[i], by = p1y[i];
     const double rp0x = c0 * ax - s0 * ay, rp0y = s0 * ax + c0 * ay;   /* R0 p0 */
@@ -314,6 +317,7 @@ struct orc_solver {
   int64_t n;            /* poses */
   int64_t* obs_offset;  /* n+1 */
   float *px, *py, *nx, *ny;
+  float* obs4;          /* (px, py, nx, ny) per observation: one cache line per gathered point in gather_pair */
   float* cov9;
   int64_t n_hc;
   hitl_human_constraint_t* hc;
@@ -321,12 +325,25 @@ struct orc_solver {
   int32_t *pair_src, *pair_tgt;
   int64_t* match_offset;
   int32_t *m0, *m1;
+  /* pose -> incident pair entries (2*pair + side), ascending pair index; built on first use */
+  int64_t* inc_off;
+  int64_t* inc_ent;
+  /* wall-clock per phase of the last orc_solve (ms): 0 residual/Jacobian evaluation of the scan-to-scan pairs,
+   * 1 accumulation of J^T J / gradient, 2 scaling + LM diagonal, 3 banded Cholesky, 4 step bookkeeping */
+  double phase_ms[8];
 };
 
 static void free_pairs(orc_solver* s) {
   free(s->pair_src); free(s->pair_tgt); free(s->match_offset); free(s->m0); free(s->m1);
   s->pair_src = s->pair_tgt = NULL; s->match_offset = NULL; s->m0 = s->m1 = NULL;
+  free(s->inc_off); free(s->inc_ent); s->inc_off = s->inc_ent = NULL;
   s->n_pairs = s->n_matches = 0;
+}
+
+int orc_get_phase_ms(orc_solver* s, double out[8]) {
+  if (!s || !out) return HITL_ERR_INVALID_ARGUMENT;
+  memcpy(out, s->phase_ms, sizeof(s->phase_ms));
+  return HITL_OK;
 }
 
 int orc_create(const hitl_options* opt, orc_solver** out) {
@@ -340,7 +357,7 @@ int orc_create(const hitl_options* opt, orc_solver** out) {
 
 void orc_destroy(orc_solver* s) {
   if (!s) return;
-  free(s->obs_offset); free(s->px); free(s->py); free(s->nx); free(s->ny); free(s->cov9);
+  free(s->obs_offset); free(s->px); free(s->py); free(s->nx); free(s->ny); free(s->cov9); free(s->obs4);
   free(s->hc); free_pairs(s); free(s);
 }
 
@@ -365,14 +382,16 @@ static void* dup_mem(const void* src, size_t bytes) {
 int orc_set_map(orc_solver* s, int64_t n, const int64_t* off, const float* px, const float* py,
                 const float* nx, const float* ny, const float* cov9) {
   if (!s || n < 1 || !off) return HITL_ERR_INVALID_ARGUMENT;
-  free(s->obs_offset); free(s->px); free(s->py); free(s->nx); free(s->ny); free(s->cov9);
-  s->cov9 = NULL;
+  free(s->obs_offset); free(s->px); free(s->py); free(s->nx); free(s->ny); free(s->cov9); free(s->obs4);
+  s->cov9 = NULL; s->obs4 = NULL;
   s->n = n;
   const int64_t O = off[n];
   s->obs_offset = (int64_t*)dup_mem(off, (size_t)(n + 1) * sizeof(int64_t));
   s->px = (float*)dup_mem(px, (size_t)O * 4); s->py = (float*)dup_mem(py, (size_t)O * 4);
   s->nx = (float*)dup_mem(nx, (size_t)O * 4); s->ny = (float*)dup_mem(ny, (size_t)O * 4);
   if (cov9) s->cov9 = (float*)dup_mem(cov9, (size_t)n * 9 * 4);
+  s->obs4 = (float*)malloc((size_t)(O ? O : 1) * 16);
+  for (int64_t k = 0; k < O; ++k) { s->obs4[4 * k] = px[k]; s->obs4[4 * k + 1] = py[k]; s->obs4[4 * k + 2] = nx[k]; s->obs4[4 * k + 3] = ny[k]; }
   free_pairs(s);
   return HITL_OK;
 }
@@ -671,15 +690,27 @@ static void lin_alloc(lin_sys* L, int64_t n, int64_t band_poses, int64_t n_pairs
 }
 static void lin_free(lin_sys* L) { free(L->H); free(L->g); free(L->pair_r); free(L->pair_J); }
 
+static double now_ms(void) {
+#ifdef _OPENMP
+  return omp_get_wtime() * 1e3;
+#else
+  return 0.0;
+#endif
+}
+
 /* add J^T J and J^T r of one residual block touching poses a (cols 0..2) and b (cols 3..5);
- * b < 0 for unary blocks (J is nres x 3).  Pose 0 is constant: its columns are dropped. */
-static void accumulate_block(lin_sys* L, int64_t a, int64_t b, int nres, const double* r, const double* J) {
+ * b < 0 for unary blocks (J is nres x 3).  Pose 0 is constant: its columns are dropped.
+ * only >= 0 restricts the update to the rows (columns p) of that pose: the per-pose gather below calls it once per
+ * incident block, in the order a serial sweep over all blocks would reach that pose, so every entry of H and g sees the
+ * same additions in the same order as the serial sweep (bit-identical, thread count does not matter). */
+static void accumulate_block(lin_sys* L, int64_t a, int64_t b, int nres, const double* r, const double* J, int64_t only) {
   const int ncol = (b >= 0) ? 6 : 3;
   int64_t gi[6];
   for (int k = 0; k < 3; ++k) { gi[k] = 3 * a + k; if (b >= 0) gi[3 + k] = 3 * b + k; }
   for (int p = 0; p < ncol; ++p) {
     const int64_t ip = gi[p];
     if (ip < 3) continue;
+    if (only >= 0 && ip / 3 != only) continue;
     double gs = 0;
     for (int q = 0; q < nres; ++q) gs += J[q * ncol + p] * r[q];
     L->g[ip] += gs;
@@ -691,7 +722,6 @@ static void accumulate_block(lin_sys* L, int64_t a, int64_t b, int nres, const d
       *Hat(L, ip, iq) += hs;
     }
   }
-  for (int q = 0; q < nres; ++q) L->cost += 0.5 * r[q] * r[q];
 }
 
 typedef struct { float A[4]; float rho, rot; } odom_meas;
@@ -710,25 +740,39 @@ static void gather_pair(const orc_solver* s, int64_t p, float** buf, int64_t* ca
   if (m > *cap) { *cap = m * 2; *buf = (float*)realloc(*buf, (size_t)(*cap) * 8 * sizeof(float)); }
   float* b = *buf; const int64_t cp = *cap;
   const int64_t o0 = s->obs_offset[s->pair_src[p]], o1 = s->obs_offset[s->pair_tgt[p]];
+  const int32_t* i0 = s->m0 + s->match_offset[p]; const int32_t* i1 = s->m1 + s->match_offset[p];
   for (int64_t q = 0; q < m; ++q) {
-    const int64_t k0 = o0 + s->m0[s->match_offset[p] + q], k1 = o1 + s->m1[s->match_offset[p] + q];
-    b[0 * cp + q] = s->px[k0]; b[1 * cp + q] = s->py[k0];
-    b[2 * cp + q] = s->px[k1]; b[3 * cp + q] = s->py[k1];
-    b[4 * cp + q] = s->nx[k0]; b[5 * cp + q] = s->ny[k0];
-    b[6 * cp + q] = s->nx[k1]; b[7 * cp + q] = s->ny[k1];
+    const float* a = s->obs4 + 4 * (o0 + i0[q]); const float* c = s->obs4 + 4 * (o1 + i1[q]);
+    b[0 * cp + q] = a[0]; b[1 * cp + q] = a[1];
+    b[2 * cp + q] = c[0]; b[3 * cp + q] = c[1];
+    b[4 * cp + q] = a[2]; b[5 * cp + q] = a[3];
+    b[6 * cp + q] = c[2]; b[7 * cp + q] = c[3];
   }
 }
 
-static void linearize(const orc_solver* s, int mode, const odom_meas* om, const float* hc_tgt,
+/* pose -> (pair, side) incidence, ascending pair index within a pose; also human rows per pose in row order */
+static void build_incidence(orc_solver* s) {
+  if (s->inc_off) return;
+  const int64_t n = s->n, P = s->n_pairs;
+  s->inc_off = (int64_t*)calloc((size_t)n + 1, sizeof(int64_t));
+  s->inc_ent = (int64_t*)malloc((size_t)(2 * P + 1) * sizeof(int64_t));
+  for (int64_t p = 0; p < P; ++p) { s->inc_off[s->pair_src[p] + 1]++; s->inc_off[s->pair_tgt[p] + 1]++; }
+  for (int64_t i = 0; i < n; ++i) s->inc_off[i + 1] += s->inc_off[i];
+  int64_t* fill = (int64_t*)malloc((size_t)(n + 1) * sizeof(int64_t));
+  memcpy(fill, s->inc_off, (size_t)(n + 1) * sizeof(int64_t));
+  for (int64_t p = 0; p < P; ++p) { s->inc_ent[fill[s->pair_src[p]]++] = 2 * p; s->inc_ent[fill[s->pair_tgt[p]]++] = 2 * p + 1; }
+  free(fill);
+}
+
+static void linearize(orc_solver* s, int mode, const odom_meas* om, const float* hc_tgt,
                       const double* x, lin_sys* L) {
   const int64_t n = s->n;
-  memset(L->H, 0, (size_t)L->dim * (size_t)(L->bw + 1) * sizeof(double));
-  memset(L->g, 0, (size_t)L->dim * sizeof(double));
-  L->cost = 0; L->num_residuals = 0; L->num_hc_residuals = 0;
-  const int with_stf = (mode == HITL_MODE_STF_ONLY || mode == HITL_MODE_JOINT);
+  const int with_stf = (mode == HITL_MODE_STF_ONLY || mode == HITL_MODE_JOINT) && s->n_pairs > 0;
   const int with_odom_hc = (mode == HITL_MODE_ODOM_HC || mode == HITL_MODE_JOINT);
+  L->cost = 0; L->num_residuals = 0; L->num_hc_residuals = 0;
+  double t0 = now_ms();
 
-  if (with_stf && s->n_pairs > 0) {
+  if (with_stf) {
     /* per-pair residual blocks in parallel (the reference: OpenMP inside the functor,
      * residual_functors.h:801) */
 #pragma omp parallel
@@ -750,32 +794,80 @@ static void linearize(const orc_solver* s, int mode, const odom_meas* om, const 
       }
       free(buf);
     }
-    for (int64_t p = 0; p < s->n_pairs; ++p) {
-      accumulate_block(L, s->pair_src[p], s->pair_tgt[p], 2, L->pair_r + 2 * p, L->pair_J + 12 * p);
-      L->num_residuals += 2;
-    }
+    build_incidence(s);
   }
+  double t1 = now_ms();
+  s->phase_ms[0] += t1 - t0;
+
+  /* odometry edges (AddOdometryConstraints :743-823) and human rows (AddHumanConstraints :975-1052), evaluated once */
+  double *od_r = NULL, *od_J = NULL, *hc_r = NULL, *hc_J = NULL;
+  int* hc_n = NULL; int64_t *hc_poff = NULL, *hc_pent = NULL;
   if (with_odom_hc) {
     const float sig[3] = {s->opt.odom_radial_std_dev, s->opt.odom_tangential_std_dev, s->opt.odom_angular_std_dev};
-    for (int64_t i = 1; i < n; ++i) { /* AddOdometryConstraints :743-823 */
-      double r[3], J[18];
-      if (s->use_jets) orc_odom_eval_jet(x + 3 * (i - 1), x + 3 * i, om[i].A, om[i].rho, om[i].rot, sig, r, J);
-      else orc_odom_eval(x + 3 * (i - 1), x + 3 * i, om[i].A, om[i].rho, om[i].rot, sig, r, J);
-      accumulate_block(L, i - 1, i, 3, r, J);
+    od_r = (double*)malloc((size_t)n * 3 * sizeof(double)); od_J = (double*)malloc((size_t)n * 18 * sizeof(double));
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 1; i < n; ++i) {
+      if (s->use_jets) orc_odom_eval_jet(x + 3 * (i - 1), x + 3 * i, om[i].A, om[i].rho, om[i].rot, sig, od_r + 3 * i, od_J + 18 * i);
+      else orc_odom_eval(x + 3 * (i - 1), x + 3 * i, om[i].A, om[i].rho, om[i].rot, sig, od_r + 3 * i, od_J + 18 * i);
+    }
+    const int64_t Hn = s->n_hc;
+    hc_r = (double*)malloc((size_t)(Hn + 1) * 3 * sizeof(double)); hc_J = (double*)malloc((size_t)(Hn + 1) * 9 * sizeof(double));
+    hc_n = (int*)malloc((size_t)(Hn + 1) * sizeof(int));
+    hc_poff = (int64_t*)calloc((size_t)n + 1, sizeof(int64_t)); hc_pent = (int64_t*)malloc((size_t)(Hn + 1) * sizeof(int64_t));
+    for (int64_t h = 0; h < Hn; ++h) {
+      const int64_t c = s->hc[h].constrained_pose_id;
+      hc_n[h] = s->use_jets ? orc_hc_eval_jet(s->hc[h].type, hc_tgt + 4 * h, x + 3 * c, hc_r + 3 * h, hc_J + 9 * h)
+                            : orc_hc_eval(s->hc[h].type, hc_tgt + 4 * h, x + 3 * c, hc_r + 3 * h, hc_J + 9 * h);
+      hc_poff[c + 1]++;
+    }
+    for (int64_t i = 0; i < n; ++i) hc_poff[i + 1] += hc_poff[i];
+    int64_t* fill = (int64_t*)malloc((size_t)(n + 1) * sizeof(int64_t));
+    memcpy(fill, hc_poff, (size_t)(n + 1) * sizeof(int64_t));
+    for (int64_t h = 0; h < Hn; ++h) hc_pent[fill[s->hc[h].constrained_pose_id]++] = h;   /* row order within a pose */
+    free(fill);
+  }
+
+  /* J^T J and gradient, gathered per pose: every pose's rows are written by one thread, blocks arrive in the order
+   * of a serial sweep (pairs by index, edge (i-1,i), edge (i,i+1), human rows) */
+  const int64_t w = L->bw + 1;
+#pragma omp parallel for schedule(dynamic, 256)
+  for (int64_t i = 0; i < n; ++i) {
+    memset(L->H + (size_t)(3 * i) * (size_t)w, 0, (size_t)3 * (size_t)w * sizeof(double));
+    L->g[3 * i] = L->g[3 * i + 1] = L->g[3 * i + 2] = 0.0;
+    if (with_stf)
+      for (int64_t e = s->inc_off[i]; e < s->inc_off[i + 1]; ++e) {
+        const int64_t p = s->inc_ent[e] >> 1;
+        accumulate_block(L, s->pair_src[p], s->pair_tgt[p], 2, L->pair_r + 2 * p, L->pair_J + 12 * p, i);
+      }
+    if (with_odom_hc) {
+      if (i >= 1) accumulate_block(L, i - 1, i, 3, od_r + 3 * i, od_J + 18 * i, i);
+      if (i + 1 < n) accumulate_block(L, i, i + 1, 3, od_r + 3 * (i + 1), od_J + 18 * (i + 1), i);
+      for (int64_t e = hc_poff[i]; e < hc_poff[i + 1]; ++e) {
+        const int64_t h = hc_pent[e];
+        if (hc_n[h] > 0) accumulate_block(L, i, -1, hc_n[h], hc_r + 3 * h, hc_J + 9 * h, i);
+      }
+    }
+  }
+  /* cost = 1/2 sum r^2 in block order (serial: a few hundred thousand additions) */
+  if (with_stf)
+    for (int64_t p = 0; p < s->n_pairs; ++p) {
+      for (int q = 0; q < 2; ++q) L->cost += 0.5 * L->pair_r[2 * p + q] * L->pair_r[2 * p + q];
+      L->num_residuals += 2;
+    }
+  if (with_odom_hc) {
+    for (int64_t i = 1; i < n; ++i) {
+      for (int q = 0; q < 3; ++q) L->cost += 0.5 * od_r[3 * i + q] * od_r[3 * i + q];
       L->num_residuals += 3;
     }
-    for (int64_t h = 0; h < s->n_hc; ++h) { /* AddHumanConstraints :975-1052 */
-      double r[3], J[9];
-      const int64_t c = s->hc[h].constrained_pose_id;
-      const int nres = s->use_jets ? orc_hc_eval_jet(s->hc[h].type, hc_tgt + 4 * h, x + 3 * c, r, J)
-                                   : orc_hc_eval(s->hc[h].type, hc_tgt + 4 * h, x + 3 * c, r, J);
-      if (nres == 0) continue;
-      accumulate_block(L, c, -1, nres, r, J);
-      L->num_residuals += nres; L->num_hc_residuals += nres;
+    for (int64_t h = 0; h < s->n_hc; ++h) {
+      for (int q = 0; q < hc_n[h]; ++q) L->cost += 0.5 * hc_r[3 * h + q] * hc_r[3 * h + q];
+      L->num_residuals += hc_n[h]; L->num_hc_residuals += hc_n[h];
     }
+    free(od_r); free(od_J); free(hc_r); free(hc_J); free(hc_n); free(hc_poff); free(hc_pent);
   }
   /* pose 0 constant: identity block so the banded factorisation stays well posed */
   for (int k = 0; k < 3; ++k) { *Hat(L, k, k) = 1.0; L->g[k] = 0.0; }
+  s->phase_ms[1] += now_ms() - t1;
 }
 
 static int check_problem(const orc_solver* s, int mode) {
@@ -876,38 +968,40 @@ static int band_cholesky_solve(int64_t dim, int64_t bw, double* A /* lower band,
   return 0;
 }
 
-/* y = H x for the symmetric lower-band matrix */
+/* y = H x for the symmetric lower-band matrix.  Row i walks its columns in ascending order (lower band, then the
+ * transposed entries below the diagonal): the same order of additions per y[i] as a serial sweep over the lower
+ * triangle, so the result does not depend on the thread count. */
 static void band_symv(const lin_sys* L, const double* S /* column scale or NULL */, const double* x, double* y) {
   const int64_t d = L->dim, bw = L->bw, w = bw + 1;
-  for (int64_t i = 0; i < d; ++i) y[i] = 0;
+#pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < d; ++i) {
+    double acc = 0;
     const int64_t j0 = (i - bw < 0) ? 0 : i - bw;
     for (int64_t j = j0; j <= i; ++j) {
       double h = L->H[i * w + (j - i + bw)];
       if (S) h *= S[i] * S[j];
-      y[i] += h * x[j];
-      if (j != i) y[j] += h * x[i];
+      acc += h * x[j];
     }
+    const int64_t j1 = (i + bw > d - 1) ? d - 1 : i + bw;
+    for (int64_t j = i + 1; j <= j1; ++j) {
+      double h = L->H[j * w + (i - j + bw)];
+      if (S) h *= S[j] * S[i];
+      acc += h * x[j];
+    }
+    y[i] = acc;
   }
 }
 
 /* ===================================================================================== */
 /* Levenberg-Marquardt with Ceres trust-region semantics                 */
 /* ===================================================================================== */
-static double now_ms(void) {
-#ifdef _OPENMP
-  return omp_get_wtime() * 1e3;
-#else
-  return 0.0;
-#endif
-}
-
 int orc_solve_f64(orc_solver* s, int32_t mode, const float* poses_in, double* x_out, hitl_summary* sum) {
   int st = check_problem(s, mode); if (st) return st;
   const double t_start = now_ms();
   const hitl_options* o = &s->opt;
   const int64_t n = s->n, d = 3 * n;
   hitl_summary S; memset(&S, 0, sizeof(S));
+  memset(s->phase_ms, 0, sizeof(s->phase_ms));
   odom_meas* om; float* tgt; setup_factors(s, poses_in, &om, &tgt);
   const int64_t band = (mode == HITL_MODE_ODOM_HC) ? 1 : max_pair_distance(s);
   lin_sys La, Lb; lin_alloc(&La, n, band, s->n_pairs); lin_alloc(&Lb, n, band, s->n_pairs);
@@ -941,6 +1035,7 @@ int orc_solve_f64(orc_solver* s, int32_t mode, const float* poses_in, double* x_
     ++iter;
     /* LevenbergMarquardtStrategy::ComputeStep in the Jacobi-scaled space */
     double tls = now_ms();
+#pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < d; ++i) {
       const int64_t j0 = (i - bw < 0) ? 0 : i - bw;
       for (int64_t j = j0; j <= i; ++j) Hs[i * w + (j - i + bw)] = cur->H[i * w + (j - i + bw)] * scale[i] * scale[j];
@@ -952,8 +1047,12 @@ int orc_solve_f64(orc_solver* s, int32_t mode, const float* poses_in, double* x_
       }
       dt[i] = -scale[i] * cur->g[i];
     }
+    const double tch = now_ms();
+    s->phase_ms[2] += tch - tls;
     int bad = band_cholesky_solve(d, bw, Hs, dt);
+    s->phase_ms[3] += now_ms() - tch;
     S.linear_solver_ms += now_ms() - tls; S.linear_iterations++;
+    const double tbk = now_ms();
     double mcc = 0;
     if (!bad) {
       band_symv(cur, scale, dt, tmp);
@@ -965,7 +1064,7 @@ int orc_solve_f64(orc_solver* s, int32_t mode, const float* poses_in, double* x_
     if (bad) { /* invalid step */
       ++S.unsuccessful_steps;
       if (++invalid_run >= 5) { term = HITL_FAILURE; break; }
-      radius /= decrease_factor; decrease_factor *= 2.0;
+      radius *= 0.5;   /* LevenbergMarquardtStrategy::StepIsInvalid: halve, decrease_factor untouched */
       continue;
     }
     invalid_run = 0;
@@ -975,6 +1074,7 @@ int orc_solve_f64(orc_solver* s, int32_t mode, const float* poses_in, double* x_
       xc[i] = x[i] + dl;
       if (i >= 3) { step2 += dl * dl; xn2 += x[i] * x[i]; }
     }
+    s->phase_ms[4] += now_ms() - tbk;
     tl = now_ms();
     linearize(s, mode, om, tgt, xc, cand);
     S.linearize_ms += now_ms() - tl; S.linearize_calls++;

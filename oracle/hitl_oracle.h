@@ -28,6 +28,9 @@ typedef struct orc_solver orc_solver;
 int orc_create(const hitl_options* opt, orc_solver** out);
 void orc_destroy(orc_solver*);
 int orc_set_num_threads(int n);   /* OpenMP threads used by linearize / matching; returns previous */
+/* wall-clock of the last orc_solve by phase (ms): [0] scan-to-scan residual/Jacobian evaluation, [1] J^T J / gradient
+ * accumulation (+ odometry, human rows), [2] Jacobi scaling + LM diagonal, [3] banded Cholesky, [4] step bookkeeping */
+int orc_get_phase_ms(orc_solver*, double out[8]);
 int orc_set_map(orc_solver*, int64_t n_poses, const int64_t* obs_offset, const float* px,
                 const float* py, const float* nx, const float* ny, const float* cov9);
 int orc_set_human_constraints(orc_solver*, int64_t n, const hitl_human_constraint_t* rows);

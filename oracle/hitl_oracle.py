@@ -26,10 +26,17 @@ def build(force=False):
 
 
 def lib():
+    """The checker build; with HITL_ORACLE_NATIVE=1 in the environment (bench.py's cpu_baseline leg only) the
+    `make native` build for the host it runs on (-O3 -march=native, vectorised match loop)."""
     global _lib
     if _lib is None:
-        build()          # no-op when the .so is newer than its source
-        _lib = C.CDLL(LIB_PATH)
+        if os.environ.get("HITL_ORACLE_NATIVE") == "1":
+            path = os.path.join(_HERE, "_build", "libhitl_oracle_native.so")
+            subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "native"])   # always for THIS host's ISA
+        else:
+            build()          # no-op when the .so is newer than its source
+            path = LIB_PATH
+        _lib = C.CDLL(path)
         _bind_functors(_lib)
     return _lib
 
@@ -135,6 +142,13 @@ class OracleSolver(SolverBase):
         pin = _as(poses_xyt, np.float32).reshape(-1)
         st = self._lib.orc_find_correspondences(self._h, _ptr(pin, _f32p), int(window), int(method))
         self._check(st, "create")
+
+    def phase_ms(self):
+        """Wall-clock of the last solve by phase: dict(evaluate, accumulate, scale, cholesky, bookkeeping) in ms."""
+        out = (C.c_double * 8)()
+        self._lib.orc_get_phase_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        self._lib.orc_get_phase_ms(self._h, out)
+        return dict(evaluate=out[0], accumulate=out[1], scale=out[2], cholesky=out[3], bookkeeping=out[4])
 
     def set_use_jets(self, use):
         self._lib.orc_set_use_jets(self._h, int(bool(use)))

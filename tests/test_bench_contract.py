@@ -38,5 +38,5 @@ def test_bench_source_keeps_the_oracle_in_its_lane():
     # the oracle is imported exactly once, inside the cpu_baseline leg
     assert len(re.findall(r"from oracle import", src)) == 1
     i = src.index("from oracle import")
-    assert "CPU baseline" in src[max(0, i - 400):i]
+    assert "CPU baseline" in src[max(0, i - 900):i]
     assert "no CPU fallback" in src          # a missing GPU is an error, not a detour
