@@ -136,7 +136,8 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
   TRYC(s->pair_src.upload(s->h_pair_src, st));
   TRYC(s->pair_tgt.upload(s->h_pair_tgt, st));
   TRYC(s->match_off.upload(s->h_match_off, st));
-  TRYC(s->matches.resize((size_t)s->n_matches));
+  TRYC(s->matches.resize((size_t)s->n_matches + kMatchPad));      // k_linearize_stf prefetches index words unguarded
+  if (hipMemsetAsync(s->matches.p + s->n_matches, 0, sizeof(uint32_t) * kMatchPad, st) != hipSuccess) { cleanup(); return fail(HITL_ERR_HIP, "find_correspondences: padding the match array failed"); }
   launch_compact(st, mv, s->max_scan, slots, s->n_pairs, d_kept.p, s->match_off.p, d_table.p, s->matches.p);
   if (hipStreamSynchronize(st) != hipSuccess) { cleanup(); return fail(HITL_ERR_HIP, "compact kernel failed"); }
   mark("uploads + k_compact");

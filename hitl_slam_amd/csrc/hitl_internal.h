@@ -16,6 +16,7 @@ namespace hitl {
 constexpr int kMaxBandPoses = 4;          // super-block size B = 3*Wb <= 12
 constexpr int kPairRJ = 14;               // r0, r1, J[2][6] per directed STF pair
 constexpr int kNumScalars = 16;           // device scalar scratch (doubles)
+constexpr int kMatchPad = 256;            // readable words behind the last match (k_linearize_stf fetches one trip ahead)
 
 // ---- view structs passed to kernels by value ------------------------------------------
 struct MapView {            // SoA robot-frame scans (JointOptimization.h:62-68)
@@ -79,7 +80,7 @@ constexpr int kPairMomStride = 32;
 void launch_stf_moments(hipStream_t st, const MapView& map, const PairView& pr, double* pairM);
 void launch_linearize_stf_moments(hipStream_t st, const PairView& pr, const double* pairM, const double* x, const double2* cs, double corr,
                                   double sd, double* pairRJ);
-void launch_linearize_stf(hipStream_t st, const MapView& map, const PairView& pr, int max_scan,
+void launch_linearize_stf(hipStream_t st, const MapView& map, const PairView& pr, int max_scan, int64_t map_obs_count,
                           const double* x, const double2* cs, float corr, float std_dev, double* pairRJ);
 void launch_pack_obs(hipStream_t st, int64_t n, const float* px, const float* py, const float* nx, const float* ny,
                      float4* obs);

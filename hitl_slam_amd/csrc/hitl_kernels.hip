@@ -11,31 +11,49 @@
 // products, PCG pieces, submap interface helpers).
 // All arithmetic is fp64 (T = double in the reference functors); observations stay fp32.
 
+#include <cstdlib>
+
 #include "hitl_device.h"
 
 namespace hitl {
 
 // ===========================================================================================
-// linearize_stf: one workgroup per SOURCE pose (its scan staged once in LDS as float4), one
-// wave per directed pair (i -> j), lanes stride the pair's matches.
+// linearize_stf: one workgroup per SOURCE pose (its scan staged once in LDS, already widened to fp64), one 32-lane
+// half-wave per directed pair (i -> j), lanes stride the pair's matches two at a time.
 //
 // All per-match arithmetic is done in the SOURCE pose's frame: with R01 = R0^T R1 and
 // t01 = R0^T (t1 - t0),   u = R01 p1,  w = u + t01,  q = w - p0  (= R0^T delta),  n1' = R01 n1,
 //   e0/k = n0 . q                      e1/k = n1' . q
 //   d(e0/k)/dtheta0 = cross(n0, w)     d(e0/k)/dtheta1 = -cross(n0, u)
 //   d(e1/k)/dtheta0 = cross(n1', p0)   d(e1/k)/dtheta1 = cross(n1', t01 - p0)
-// (identical to SURVEY.md A.2 after rotating by R0^T; cross(a,b) = ax*by - ay*bx), and the
-// translation partials -+k R0 n0, -+k R0 n1' are rotated once per pair after the reduction.
-// 38 fp64 operations per match instead of ~110 for the world-frame form.
+// (identical to SURVEY.md A.2 after rotating by R0^T; cross(a,b) = ax*by - ay*bx).  30 fp64 operations per match.
 //
-// The 10 sums are reduced with a reduce-scatter butterfly (17 64-bit shuffles per pair
-// instead of 60): at each step a lane keeps half of its values and ships the other half.
+// The kernel only SUMS: 8 numbers per pair (S0, A0 = sum e0 n0, T01 = sum e0 d01, S1, A1 = sum e1 n1', T10), reduced
+// across the half-wave with a reduce-scatter butterfly (7 64-bit shuffles for both pairs of a wave) and stored by the 8
+// lanes that end up holding them.  Residual, square roots and the 2x6 Jacobian are formed by k_stf_finalize, one thread
+// per pair: a wave's worth of finishing arithmetic per pair pair became one lane's worth.
+//
+// Round-2 instruction diet (rocprofv3 PMC, C4: 845 VALU instructions per wave before):
+//  * full trips carry no tail weights; the last partial trip is a separate copy of the body with weights,
+//  * the source scan sits in LDS as fp64 (4 conversions per match instead of 8),
+//  * next-trip index words are fetched unguarded (the match array carries 64 words of padding),
+//  * the per-pair epilogue (rsqrt, division, 40 fp64 operations, 14 stores, 16 cross-lane picks) left the kernel.
 //
 // blockIdx -> pose mapping keeps consecutive poses on one XCD (blocks b and b+8 share an
 // XCD) so the target scans i+-1..W, which the neighbouring workgroups stage as THEIR source,
 // are served from that XCD's L2.
 // ===========================================================================================
 constexpr int kStfBlock = 192;
+
+// value of lane (l ^ M) within each group of 32 lanes: ds_swizzle in bit mode (and 0x1f, or 0, xor M).  Unlike
+// ds_bpermute (__shfl_xor) it needs no lane-address register, and this kernel has none to spare at 80 VGPRs.
+template <int M>
+__device__ __forceinline__ double swz_xor(double v) {
+  static_assert(M > 0 && M < 32, "bit-mode swizzle stays inside 32 lanes");
+  const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), (M << 10) | 0x1f);
+  const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), (M << 10) | 0x1f);
+  return __hiloint2double(hi, lo);
+}
 
 // v[0..2h) -> v[0..h): lanes with bit `mask` set keep the upper half
 #define HITL_XSTEP(mask, h)                                        \
@@ -44,11 +62,12 @@ constexpr int kStfBlock = 192;
     _Pragma("unroll") for (int q_ = 0; q_ < (h); ++q_) {           \
       const double send_ = up ? v[q_] : v[q_ + (h)];               \
       const double keep_ = up ? v[q_ + (h)] : v[q_];               \
-      v[q_] = keep_ + __shfl_xor(send_, (mask), WAVE);             \
+      v[q_] = keep_ + swz_xor<(mask)>(send_);                      \
     }                                                              \
   }
 
 constexpr int kStfSub = 32;     // lanes per directed pair: two pairs per wave
+constexpr int kStfSums = 8;     // S0, A0x, A0y, T01, S1, A1x, A1y, T10 (of e / k)
 
 // per-pose (cos theta, sin theta), computed once per linearisation instead of per pair
 __global__ void k_pose_trig(int n, const double* __restrict__ x, double2* __restrict__ cs) {
@@ -59,22 +78,51 @@ __global__ void k_pose_trig(int n, const double* __restrict__ x, double2* __rest
   cs[i] = make_double2(c, s);
 }
 
-// Tuning notes (MI355X, C4 workload, rocprofv3 PMC; see DESIGN.md "k_linearize_stf"):
-//  * 2 matches per lane in flight at <= 80 VGPRs (6 waves/SIMD) beats deeper unrolling at lower
-//    occupancy; staging the target scans in LDS too (50 KB/workgroup) or software-pipelining the
-//    gathers by hand were both slower (LDS-limited occupancy / register spills).
-//  * requesting the NEXT trip's index words before this trip's arithmetic (2 VGPRs) took 376 -> 344 us; going one
-//    step further (next trip's gathers in flight too, 8 more VGPRs) spills at the 80-VGPR budget: 539 us.
-//  * VALU and TA are each ~55 % busy: the kernel is balanced between fp64 issue and L1/L2
-//    gather handling, at 2x the HBM floor of its compulsory bytes.
-constexpr int kStfUnroll = 2;
+struct StfAcc { double S0, A0x, A0y, T01, S1, A1x, A1y, T10; };
 
-template <bool USE_LDS>
-__global__ __launch_bounds__(kStfBlock, 6) void k_linearize_stf(MapView map, PairView pr, int chunk, int lds_cap,
-                                                                 const double* __restrict__ x,
-                                                                 const double2* __restrict__ cs, double kf, double /*unused*/,
-                                                                 double* __restrict__ pairRJ) {
-  extern __shared__ float4 s_scan[];  // [lds_cap] : (px, py, nx, ny) of the source scan
+// one match: source point (ax, ay) + normal (anx, any) already fp64, target observation tv fp32
+template <bool WEIGHTED>
+__device__ __forceinline__ void stf_match(StfAcc& a, double ax, double ay, double anx, double any, const float4 tv, double cR, double sR,
+                                          double t01x, double t01y, double wgt) {
+  const double bx = tv.x, by = tv.y, bnx = tv.z, bny = tv.w;
+  const double ux = cR * bx - sR * by, uy = sR * bx + cR * by;        // u = R01 p1
+  const double mx = cR * bnx - sR * bny, my = sR * bnx + cR * bny;    // n1' = R01 n1
+  const double qx = (ux + t01x) - ax, qy = (uy + t01y) - ay;          // q = R0^T delta
+  double e0 = anx * qx + any * qy;                                    // e0 / k
+  double e1 = mx * qx + my * qy;                                      // e1 / k
+  if (WEIGHTED) { e0 *= wgt; e1 *= wgt; }
+  const double d01 = any * ux - anx * uy;                             // -cross(n0, u)
+  const double d10 = mx * ay - my * ax;                               //  cross(n1', p0)
+  a.S0 += e0 * e0; a.A0x += e0 * anx; a.A0y += e0 * any; a.T01 += e0 * d01;
+  a.S1 += e1 * e1; a.A1x += e1 * mx; a.A1y += e1 * my; a.T10 += e1 * d10;
+}
+
+// SRC: 0 = source scan read from global memory (scans beyond the LDS budget), 1 = staged in LDS as float4 (<= 4096
+// points), 2 = staged in LDS widened to fp64 (<= 2048 points)
+// OFF32: every observation lies within 4 GB of map.obs, so a target gather is `scalar base + 32-bit lane offset`
+// (global_load with an SGPR base: no 64-bit address arithmetic per match)
+// PIPE: 1 = the target gathers of trip t+1 are issued before the arithmetic of trip t (and the index words of trip t+2):
+// a workgroup's life is a chain of dependent memory rounds, and this takes one round out of every trip
+template <int SRC>
+__device__ __forceinline__ void stf_source(const double2* s_scan8, const float4* s_scan4, const float4* __restrict__ src_g, uint32_t u,
+                                           double& ax, double& ay, double& anx, double& any) {
+  const int k0 = (int)__builtin_amdgcn_ubfe(u, 0, 16);
+  if (SRC == 2) {
+    const double2 a = s_scan8[2 * k0], b = s_scan8[2 * k0 + 1];
+    ax = a.x; ay = a.y; anx = b.x; any = b.y;
+  } else {
+    const float4 a = (SRC == 1) ? s_scan4[k0] : src_g[k0];
+    ax = a.x; ay = a.y; anx = a.z; any = a.w;
+  }
+}
+
+template <int SRC, bool OFF32, int PIPE, int MINB, int ABL = 0>
+__global__ __launch_bounds__(kStfBlock, MINB) void k_linearize_stf(MapView map, PairView pr, int chunk,
+                                                                    const double* __restrict__ x, const double2* __restrict__ cs,
+                                                                    double* __restrict__ pairRJ) {
+  extern __shared__ double s_scan_raw[];
+  float4* s_scan4 = reinterpret_cast<float4*>(s_scan_raw);            // SRC == 1
+  double2* s_scan8 = reinterpret_cast<double2*>(s_scan_raw);          // SRC == 2: (px, py), (nx, ny) per point
   const int b = blockIdx.x;
   const int idx = b >> 3;
   const int i = (b & 7) * chunk + idx;
@@ -83,19 +131,25 @@ __global__ __launch_bounds__(kStfBlock, 6) void k_linearize_stf(MapView map, Pai
   if (p_begin == p_end) return;
   const int64_t oi = map.obs_off[i];
   const int mi = (int)(map.obs_off[i + 1] - oi);
-  if (USE_LDS) {
-    for (int k = threadIdx.x; k < mi; k += kStfBlock) s_scan[k] = map.obs[oi + k];
+  const float4* __restrict__ src_g = map.obs + oi;
+  if (SRC == 1) {
+    for (int k = threadIdx.x; k < mi; k += kStfBlock) s_scan4[k] = src_g[k];
+    __syncthreads();
+  } else if (SRC == 2) {
+    for (int k = threadIdx.x; k < mi; k += kStfBlock) {
+      const float4 o = src_g[k];
+      s_scan8[2 * k] = make_double2((double)o.x, (double)o.y);
+      s_scan8[2 * k + 1] = make_double2((double)o.z, (double)o.w);
+    }
     __syncthreads();
   }
   const int lane = threadIdx.x & 63;
   const int sub = threadIdx.x / kStfSub;        // pair slot of this half-wave within the workgroup
   const int hl = threadIdx.x & (kStfSub - 1);   // lane within the half-wave
-  // workgroup-uniform values are pinned to SGPRs (v_readfirstlane): kept in VGPRs across the match loop they are what
-  // the register allocator spills at the 80-VGPR budget (5 VGPRs = ~0.37 GB of scratch traffic per launch)
+  // workgroup-uniform values pinned to SGPRs
   const double xi = uniform_f64(x[3 * i]), yi = uniform_f64(x[3 * i + 1]);
   const double2 cs0 = cs[i];
   const double c0 = uniform_f64(cs0.x), s0 = uniform_f64(cs0.y);
-  const float4* __restrict__ src_g = map.obs + oi;
   const uint32_t* __restrict__ mt = pr.matches;
   constexpr int kSlots = kStfBlock / kStfSub;
   for (int pb = p_begin; pb < p_end; pb += kSlots) {   // workgroup-uniform trip count
@@ -103,102 +157,125 @@ __global__ __launch_bounds__(kStfBlock, 6) void k_linearize_stf(MapView map, Pai
     const bool live = p < p_end;
     const int pc = live ? p : p_begin;
     const int j = pr.pair_tgt[pc];
-    const float4* __restrict__ tgt_g = map.obs + map.obs_off[j];
+    const int64_t oj = map.obs_off[j];
+    const float4* __restrict__ tgt_g = map.obs + oj;
+    const uint32_t tgt_b = (uint32_t)oj << 4;                                   // OFF32: byte offset of the target scan
+    const char* __restrict__ obs_b = reinterpret_cast<const char*>(map.obs);
+#define HITL_TGT(u) (OFF32 ? *reinterpret_cast<const float4*>(obs_b + (tgt_b + (__builtin_amdgcn_ubfe((u), 16, 16) << 4))) : tgt_g[(u) >> 16])
     const double ddx = x[3 * j] - xi, ddy = x[3 * j + 1] - yi;
     const double2 cs1 = cs[j];
     const double cR = c0 * cs1.x + s0 * cs1.y, sR = c0 * cs1.y - s0 * cs1.x;   // R01 = R0^T R1
     const double t01x = c0 * ddx + s0 * ddy, t01y = c0 * ddy - s0 * ddx;       // R0^T (t1 - t0)
     const int64_t m_begin = pr.match_off[pc];
-    const int64_t m_end = live ? pr.match_off[pc + 1] : m_begin;
-    // 8 running sums; the two remaining theta partials follow from them after the reduction:
-    //   sum e0 cross(n0, w)        = -T01 + cross(A0, t01)     (w = u + t01)
-    //   sum e1 cross(n1', t01-p0)  = cross(A1, t01) - T10
-    double S0 = 0, A0x = 0, A0y = 0, T01 = 0;
-    double S1 = 0, A1x = 0, A1y = 0, T10 = 0;
-    // the index words of the NEXT trip are requested before this trip's arithmetic, so a trip waits for one memory
-    // round (the gathers) instead of two dependent ones (index, then gather).  Positions inside the pair's list are
-    // 32-bit (a pair holds at most one match per source point, < 65536): 64-bit loop state costs VGPRs that this
-    // kernel does not have at its 80-register budget -- with them, and with k = corr / sigma divided on the device, the
-    // allocator spilled 5 VGPRs to scratch (~0.37 GB of extra HBM traffic per launch).
-    // (The compiler hoists `table base + lane offset` out of the pair loop and, at the 80-VGPR budget, spills that one
-    // 64-bit address to scratch: 8 bytes written once per thread.  Making the base opaque removes the spill but puts
-    // two 64-bit adds back into every trip: 330 us instead of 308 us.  The kernel is VALU-bound, so the spill stays.)
-    const uint32_t* __restrict__ mp = mt + m_begin;
-    const int len = (int)(m_end - m_begin);
-    uint32_t un[kStfUnroll];
-#pragma unroll
-    for (int q = 0; q < kStfUnroll; ++q) {
-      const int mq = hl + q * kStfSub;
-      un[q] = (mq < len) ? mp[mq] : 0u;
+    const int len = live ? (int)(pr.match_off[pc + 1] - m_begin) : 0;          // a pair holds < 65536 matches
+    StfAcc acc = {0, 0, 0, 0, 0, 0, 0, 0};
+    const uint32_t* __restrict__ mp = mt + m_begin + hl;
+    const int nfull = (ABL == 5) ? 0 : (ABL == 6) ? 1 : (len >> 6), rem = (ABL >= 5) ? 0 : (len & 63);   // ABL 5: prologue + epilogue only; 6: one trip
+    double ax0, ay0, anx0, any0, ax1, ay1, anx1, any1;
+    if (PIPE == 0) {
+      // The index words of the NEXT trip are requested before this trip's arithmetic, so a trip waits for one memory
+      // round (the gathers) instead of two dependent ones.  Unguarded: the array ends with kMatchPad words of padding.
+      uint32_t un0 = mp[0], un1 = mp[kStfSub];
+      for (int t = 0; t < nfull; ++t) {
+        const uint32_t u0 = un0, u1 = un1;
+        mp += 2 * kStfSub;
+        // ABL (development ablations, results are wrong): 1 no target gathers, 2 no source reads, 3 no arithmetic, 4 no index stream
+        float4 tv0, tv1;
+        if (ABL == 1) { tv0 = make_float4(__uint_as_float(u0), 1.f, 0.f, 1.f); tv1 = make_float4(__uint_as_float(u1), 1.f, 0.f, 1.f); }
+        else { tv0 = HITL_TGT(u0); tv1 = HITL_TGT(u1); }
+        if (ABL == 2) { ax0 = (double)u0; ay0 = 1.0; anx0 = 0.0; any0 = 1.0; ax1 = (double)u1; ay1 = 1.0; anx1 = 0.0; any1 = 1.0; }
+        else {
+          stf_source<SRC>(s_scan8, s_scan4, src_g, u0, ax0, ay0, anx0, any0);
+          stf_source<SRC>(s_scan8, s_scan4, src_g, u1, ax1, ay1, anx1, any1);
+        }
+        if (ABL == 4) { un0 = (u0 + 0x10001u) & 0x00ff00ffu; un1 = (u1 + 0x10001u) & 0x00ff00ffu; }
+        else { un0 = mp[0]; un1 = mp[kStfSub]; }
+        __builtin_amdgcn_sched_barrier(0);      // keep the index prefetch ahead of the arithmetic (the scheduler sinks it otherwise)
+        if (ABL == 3) { acc.S0 += (ax0 + ax1) + (double)(tv0.x + tv1.x); acc.S1 += (any0 + any1) + (double)(tv0.w + tv1.w); }
+        else {
+          stf_match<false>(acc, ax0, ay0, anx0, any0, tv0, cR, sR, t01x, t01y, 1.0);
+          stf_match<false>(acc, ax1, ay1, anx1, any1, tv1, cR, sR, t01x, t01y, 1.0);
+        }
+      }
+      if (rem > 0) {      // the last, partial trip: lanes past the end take index 0 (valid) with weight 0
+        const bool v0 = hl < rem, v1 = hl + kStfSub < rem;
+        const uint32_t u0 = v0 ? un0 : 0u, u1 = v1 ? un1 : 0u;
+        const float4 tv0 = HITL_TGT(u0), tv1 = HITL_TGT(u1);
+        stf_source<SRC>(s_scan8, s_scan4, src_g, u0, ax0, ay0, anx0, any0);
+        stf_source<SRC>(s_scan8, s_scan4, src_g, u1, ax1, ay1, anx1, any1);
+        stf_match<true>(acc, ax0, ay0, anx0, any0, tv0, cR, sR, t01x, t01y, v0 ? 1.0 : 0.0);
+        stf_match<true>(acc, ax1, ay1, anx1, any1, tv1, cR, sR, t01x, t01y, v1 ? 1.0 : 0.0);
+      }
+    } else {
+      // two-stage pipeline: (ua, ub, ta, tb) = index words and gathered targets of the CURRENT trip; (na, nb) = index
+      // words of the next one.  Words past the pair's end are replaced by 0 (a valid index) before they address anything.
+      uint32_t ua = mp[0], ub = mp[kStfSub];
+      uint32_t na = mp[2 * kStfSub], nb = mp[3 * kStfSub];
+      ua = (hl < len) ? ua : 0u; ub = (hl + kStfSub < len) ? ub : 0u;
+      float4 ta = HITL_TGT(ua), tb = HITL_TGT(ub);
+      int pos = hl + 2 * kStfSub;                      // list position of na
+      for (int t = 0; t < nfull; ++t) {
+        const uint32_t ca = (pos < len) ? na : 0u, cb = (pos + kStfSub < len) ? nb : 0u;
+        const float4 nta = HITL_TGT(ca), ntb = HITL_TGT(cb);        // next trip's gathers, in flight during this trip's arithmetic
+        mp += 2 * kStfSub; pos += 2 * kStfSub;
+        if (ABL == 4) { na = (ca + 0x10001u) & 0x00ff00ffu; nb = (cb + 0x10001u) & 0x00ff00ffu; }   // development ablation: no index stream
+        else { na = mp[2 * kStfSub]; nb = mp[3 * kStfSub]; }        // index words two trips ahead
+        stf_source<SRC>(s_scan8, s_scan4, src_g, ua, ax0, ay0, anx0, any0);
+        stf_source<SRC>(s_scan8, s_scan4, src_g, ub, ax1, ay1, anx1, any1);
+        __builtin_amdgcn_sched_barrier(0);
+        stf_match<false>(acc, ax0, ay0, anx0, any0, ta, cR, sR, t01x, t01y, 1.0);
+        stf_match<false>(acc, ax1, ay1, anx1, any1, tb, cR, sR, t01x, t01y, 1.0);
+        ua = ca; ub = cb; ta = nta; tb = ntb;
+      }
+      if (rem > 0) {
+        stf_source<SRC>(s_scan8, s_scan4, src_g, ua, ax0, ay0, anx0, any0);
+        stf_source<SRC>(s_scan8, s_scan4, src_g, ub, ax1, ay1, anx1, any1);
+        stf_match<true>(acc, ax0, ay0, anx0, any0, ta, cR, sR, t01x, t01y, (hl < rem) ? 1.0 : 0.0);
+        stf_match<true>(acc, ax1, ay1, anx1, any1, tb, cR, sR, t01x, t01y, (hl + kStfSub < rem) ? 1.0 : 0.0);
+      }
     }
-    for (int m = hl; m < len; m += kStfSub * kStfUnroll) {
-      uint32_t uu[kStfUnroll];
-      float4 av[kStfUnroll], tv[kStfUnroll];
-#pragma unroll
-      for (int q = 0; q < kStfUnroll; ++q) uu[q] = un[q];   // tail lanes carry index 0 (valid), weighted 0 below
-#pragma unroll
-      for (int q = 0; q < kStfUnroll; ++q) {
-        const int mq = m + (kStfUnroll + q) * kStfSub;
-        un[q] = (mq < len) ? mp[mq] : 0u;
-      }
-#pragma unroll
-      for (int q = 0; q < kStfUnroll; ++q) {
-        const int k0 = (int)(uu[q] & 0xffffu), k1 = (int)(uu[q] >> 16);
-        av[q] = USE_LDS ? s_scan[k0] : src_g[k0];
-        tv[q] = tgt_g[k1];
-      }
-#pragma unroll
-      for (int q = 0; q < kStfUnroll; ++q) {
-        const double wgt = (m + q * kStfSub < len) ? 1.0 : 0.0;
-        const double ax = av[q].x, ay = av[q].y, anx = av[q].z, any = av[q].w;
-        const double bx = tv[q].x, by = tv[q].y, bnx = tv[q].z, bny = tv[q].w;
-        const double ux = cR * bx - sR * by, uy = sR * bx + cR * by;        // u = R01 p1
-        const double mx = cR * bnx - sR * bny, my = sR * bnx + cR * bny;    // n1' = R01 n1
-        const double qx = (ux + t01x) - ax, qy = (uy + t01y) - ay;          // q = R0^T delta
-        const double e0 = wgt * (anx * qx + any * qy);                      // e0 / k
-        const double e1 = wgt * (mx * qx + my * qy);                        // e1 / k
-        const double d01 = any * ux - anx * uy;                             // -cross(n0, u)
-        const double d10 = mx * ay - my * ax;                               //  cross(n1', p0)
-        S0 += e0 * e0; A0x += e0 * anx; A0y += e0 * any; T01 += e0 * d01;
-        S1 += e1 * e1; A1x += e1 * mx; A1y += e1 * my; T10 += e1 * d10;
-      }
-    }
-    // reduce-scatter over the 32 lanes of this pair: 8 64-bit shuffles for both pairs of the wave
-    double v[8] = {S0, A0x, A0y, T01, S1, A1x, A1y, T10};
+    // reduce-scatter over the 32 lanes of this pair: after the three exchange steps lane hl holds the 4-lane partial of
+    // value (hl >> 2); two more exchanges complete it
+    double v[kStfSums] = {acc.S0, acc.A0x, acc.A0y, acc.T01, acc.S1, acc.A1x, acc.A1y, acc.T10};
     HITL_XSTEP(16, 4)
     HITL_XSTEP(8, 2)
     HITL_XSTEP(4, 1)
     double tot = v[0];
-    tot += __shfl_xor(tot, 2, WAVE);
-    tot += __shfl_xor(tot, 1, WAVE);
-    // lane base + 4*id now holds the pair total of value id (base = 0 or 32)
-    // picks through the cross-lane network (ds_bpermute): half the instructions of v_readlane pairs + selects.  The lane
-    // index is formed here (the empty asm keeps it from being hoisted over the match loop, where it would cost a VGPR).
-    int pick_base = lane & 32;
-    asm volatile("" : "+v"(pick_base));
-#define HITL_PICK(id) __shfl(tot, pick_base + 4 * (id), WAVE)
-    S0 = HITL_PICK(0); A0x = HITL_PICK(1); A0y = HITL_PICK(2); T01 = HITL_PICK(3);
-    S1 = HITL_PICK(4); A1x = HITL_PICK(5); A1y = HITL_PICK(6); T10 = HITL_PICK(7);
-#undef HITL_PICK
-    const double T00 = (A0x * t01y - A0y * t01x) - T01;
-    const double T11 = (A1x * t01y - A1y * t01x) - T10;
-    if (hl == 0 && live) {
-      const double dn = (double)(m_end - m_begin);
-      const double inv_n = 1.0 / dn;
-      double* o = pairRJ + (size_t)kPairRJ * p;
-      // sums are of e/k: r = k sqrt(S/n) (residual_functors.h:822-827); dr/dq = k^2 (sum e' de')/(n r)
-      //                                                                       = k (sum e' de') / (n sqrt(S/n))
-      const double a0 = S0 * inv_n, a1 = S1 * inv_n;
-      const double i0 = (S0 != 0.0) ? rsqrt(a0) : 0.0, i1 = (S1 != 0.0) ? rsqrt(a1) : 0.0;
-      const double r0 = kf * a0 * i0, r1 = kf * a1 * i1;
-      const double f0 = kf * inv_n * i0, f1 = kf * inv_n * i1;
-      const double g0x = c0 * A0x - s0 * A0y, g0y = s0 * A0x + c0 * A0y;   // R0 * sum e0' n0
-      const double g1x = c0 * A1x - s0 * A1y, g1y = s0 * A1x + c0 * A1y;   // R0 * sum e1' n1'
-      o[0] = r0; o[1] = r1;
-      o[2] = -f0 * g0x; o[3] = -f0 * g0y; o[4] = f0 * T00; o[5] = f0 * g0x; o[6] = f0 * g0y; o[7] = f0 * T01;
-      o[8] = -f1 * g1x; o[9] = -f1 * g1y; o[10] = f1 * T10; o[11] = f1 * g1x; o[12] = f1 * g1y; o[13] = f1 * T11;
-    }
+    tot += swz_xor<2>(tot);
+    tot += swz_xor<1>(tot);
+    if (live && (hl & 3) == 0) pairRJ[(size_t)kPairRJ * p + (hl >> 2)] = tot;      // 8 lanes, 64 contiguous bytes
+#undef HITL_TGT
   }
+}
+
+// one thread per pair: the 8 sums (of e / k) -> r[2], J[2x6] in place.  r = k sqrt(S/n) (residual_functors.h:822-827),
+// dr/dq = k (sum e' de') / (n sqrt(S/n)); the two remaining theta partials follow from the sums:
+//   sum e0 cross(n0, w)        = cross(A0, t01) - T01     (w = u + t01)
+//   sum e1 cross(n1', t01-p0)  = cross(A1, t01) - T10
+__global__ __launch_bounds__(256) void k_stf_finalize(PairView pr, const double* __restrict__ x, const double2* __restrict__ cs, double kf,
+                                                      double* __restrict__ pairRJ) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= pr.n_pairs) return;
+  const int i = pr.pair_src[p], j = pr.pair_tgt[p];
+  const double2 cs0 = cs[i];
+  const double c0 = cs0.x, s0 = cs0.y;
+  const double ddx = x[3 * j] - x[3 * i], ddy = x[3 * j + 1] - x[3 * i + 1];
+  const double t01x = c0 * ddx + s0 * ddy, t01y = c0 * ddy - s0 * ddx;
+  double* o = pairRJ + (size_t)kPairRJ * p;
+  const double S0 = o[0], A0x = o[1], A0y = o[2], T01 = o[3], S1 = o[4], A1x = o[5], A1y = o[6], T10 = o[7];
+  const double T00 = (A0x * t01y - A0y * t01x) - T01;
+  const double T11 = (A1x * t01y - A1y * t01x) - T10;
+  const double dn = (double)(pr.match_off[p + 1] - pr.match_off[p]);
+  const double inv_n = 1.0 / dn;
+  const double a0 = S0 * inv_n, a1 = S1 * inv_n;
+  const double i0 = (S0 != 0.0) ? rsqrt(a0) : 0.0, i1 = (S1 != 0.0) ? rsqrt(a1) : 0.0;
+  const double r0 = kf * a0 * i0, r1 = kf * a1 * i1;
+  const double f0 = kf * inv_n * i0, f1 = kf * inv_n * i1;
+  const double g0x = c0 * A0x - s0 * A0y, g0y = s0 * A0x + c0 * A0y;   // R0 * sum e0' n0
+  const double g1x = c0 * A1x - s0 * A1y, g1y = s0 * A1x + c0 * A1y;   // R0 * sum e1' n1'
+  o[0] = r0; o[1] = r1;
+  o[2] = -f0 * g0x; o[3] = -f0 * g0y; o[4] = f0 * T00; o[5] = f0 * g0x; o[6] = f0 * g0y; o[7] = f0 * T01;
+  o[8] = -f1 * g1x; o[9] = -f1 * g1y; o[10] = f1 * T10; o[11] = f1 * g1x; o[12] = f1 * g1y; o[13] = f1 * T11;
 }
 
 // ===========================================================================================
@@ -304,18 +381,60 @@ void launch_pose_trig(hipStream_t st, int n_poses, const double* x, double2* cs)
   hipLaunchKernelGGL(k_pose_trig, dim3((n_poses + 255) / 256), dim3(256), 0, st, n_poses, x, cs);
 }
 
-void launch_linearize_stf(hipStream_t st, const MapView& map, const PairView& pr, int max_scan, const double* x,
+void launch_linearize_stf(hipStream_t st, const MapView& map, const PairView& pr, int max_scan, int64_t map_obs_count, const double* x,
                           const double2* cs, float corr, float std_dev, double* pairRJ) {
   if (pr.n_pairs == 0) return;
   const int chunk = (map.n_poses + 7) / 8;
-  int lds_cap = (max_scan + 63) & ~63;
-  if ((size_t)lds_cap * 16 > 64 * 1024) lds_cap = 0;  // oversized scans read the source from global memory
-  if (lds_cap > 0)
-    hipLaunchKernelGGL(k_linearize_stf<true>, dim3(8 * chunk), dim3(kStfBlock), (size_t)lds_cap * 16, st, map, pr, chunk,
-                       lds_cap, x, cs, (double)corr / (double)std_dev, 0.0, pairRJ);   // k = corr / sigma, divided here once
-  else
-    hipLaunchKernelGGL(k_linearize_stf<false>, dim3(8 * chunk), dim3(kStfBlock), 0, st, map, pr, chunk, 0, x, cs,
-                       (double)corr / (double)std_dev, 0.0, pairRJ);
+  const int cap = (max_scan + 63) & ~63;
+  const bool off32 = (uint64_t)map_obs_count * 16 < ((uint64_t)1 << 32);
+  const dim3 grid(8 * chunk), block(kStfBlock);
+  // HITL_STF_VARIANT (development switch): 3 decimal digits "src pipe minblocks", e.g. 116 = fp32 source in LDS, pipelined
+  // gathers, 6 workgroups per CU.  Unset: the default below.
+  static const int variant = [] { const char* e = std::getenv("HITL_STF_VARIANT"); return e ? std::atoi(e) : 0; }();
+  int src = ((size_t)cap * 32 <= 64 * 1024) ? 2 : ((size_t)cap * 16 <= 64 * 1024) ? 1 : 0;
+  int pipe = 0, minb = 6;
+  if (variant >= 1000) {     // ablations of the default kernel: 1000 + ABL
+    const int abl = variant - 1000;
+    if (src == 2 && off32) {
+      if (abl == 1) hipLaunchKernelGGL((k_linearize_stf<2, true, 0, 6, 1>), grid, block, (size_t)cap * 32, st, map, pr, chunk, x, cs, pairRJ);
+      else if (abl == 2) hipLaunchKernelGGL((k_linearize_stf<2, true, 0, 6, 2>), grid, block, (size_t)cap * 32, st, map, pr, chunk, x, cs, pairRJ);
+      else if (abl == 3) hipLaunchKernelGGL((k_linearize_stf<2, true, 0, 6, 3>), grid, block, (size_t)cap * 32, st, map, pr, chunk, x, cs, pairRJ);
+      else if (abl == 14) hipLaunchKernelGGL((k_linearize_stf<2, true, 1, 5, 4>), grid, block, (size_t)cap * 32, st, map, pr, chunk, x, cs, pairRJ);
+      else if (abl == 5) hipLaunchKernelGGL((k_linearize_stf<2, true, 0, 6, 5>), grid, block, (size_t)cap * 32, st, map, pr, chunk, x, cs, pairRJ);
+      else if (abl == 6) hipLaunchKernelGGL((k_linearize_stf<2, true, 0, 6, 6>), grid, block, (size_t)cap * 32, st, map, pr, chunk, x, cs, pairRJ);
+      else hipLaunchKernelGGL((k_linearize_stf<2, true, 0, 6, 4>), grid, block, (size_t)cap * 32, st, map, pr, chunk, x, cs, pairRJ);
+      hipLaunchKernelGGL(k_stf_finalize, dim3((pr.n_pairs + 255) / 256), dim3(256), 0, st, pr, x, cs, (double)corr / (double)std_dev, pairRJ);
+      return;
+    }
+  }
+  if (variant > 0 && variant < 1000) {
+    const int vs = variant / 100, vp = (variant / 10) % 10, vm = variant % 10;
+    if (vs <= src) src = vs;
+    pipe = vp ? 1 : 0;
+    minb = (vm == 5) ? 5 : (vm == 4) ? 4 : 6;
+  }
+  const size_t lds = (src == 2) ? (size_t)cap * 32 : (src == 1) ? (size_t)cap * 16 : 0;
+#define HITL_STF_GO(SRC, PIPE, MINB)                                                                                            \
+  {                                                                                                                            \
+    if (off32) hipLaunchKernelGGL((k_linearize_stf<SRC, true, PIPE, MINB>), grid, block, lds, st, map, pr, chunk, x, cs, pairRJ); \
+    else hipLaunchKernelGGL((k_linearize_stf<SRC, false, PIPE, MINB>), grid, block, lds, st, map, pr, chunk, x, cs, pairRJ);     \
+  }
+#define HITL_STF_PM(SRC)                                                                   \
+  {                                                                                        \
+    if (pipe == 0 && minb == 6) HITL_STF_GO(SRC, 0, 6)                                     \
+    else if (pipe == 0 && minb == 5) HITL_STF_GO(SRC, 0, 5)                                \
+    else if (pipe == 0) HITL_STF_GO(SRC, 0, 4)                                             \
+    else if (minb == 6) HITL_STF_GO(SRC, 1, 6)                                             \
+    else if (minb == 5) HITL_STF_GO(SRC, 1, 5)                                             \
+    else HITL_STF_GO(SRC, 1, 4)                                                            \
+  }
+  if (src == 2) HITL_STF_PM(2)
+  else if (src == 1) HITL_STF_PM(1)
+  else HITL_STF_PM(0)
+#undef HITL_STF_PM
+#undef HITL_STF_GO
+  // k = corr / sigma, divided here once
+  hipLaunchKernelGGL(k_stf_finalize, dim3((pr.n_pairs + 255) / 256), dim3(256), 0, st, pr, x, cs, (double)corr / (double)std_dev, pairRJ);
 }
 
 // SoA (the caller's layout, JointOptimization.h:62-68) -> device-resident float4 per observation

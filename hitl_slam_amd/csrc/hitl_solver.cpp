@@ -112,7 +112,7 @@ int ensure_empty_pair_tables(hitl_solver* s) {
   if (s->pose_pair_off.n == (size_t)s->n + 1) return HITL_OK;
   s->n_pairs = 0; s->n_matches = 0;
   s->h_pair_src.clear(); s->h_pair_tgt.clear(); s->h_perm.clear(); s->h_match_off.assign(1, 0);
-  TRY(s->pair_src.resize(0)); TRY(s->pair_tgt.resize(0)); TRY(s->matches.resize(0));
+  TRY(s->pair_src.resize(0)); TRY(s->pair_tgt.resize(0)); TRY(s->matches.resize(kMatchPad));
   std::vector<int64_t> mo(1, 0);
   TRY(s->match_off.upload(mo, s->stream));
   return build_pair_structures(s);
@@ -586,7 +586,7 @@ int hitl_solver_set_correspondences(hitl_solver* s, int64_t n_pairs, const int32
   s->h_perm = order;
   s->h_pair_src.resize(P); s->h_pair_tgt.resize(P); s->h_match_off.assign(P + 1, 0);
   const int64_t C = P ? match_offset[P] - match_offset[0] : 0;
-  std::vector<uint32_t> packed((size_t)C);
+  std::vector<uint32_t> packed((size_t)C + kMatchPad, 0u);   // k_linearize_stf prefetches index words unguarded
   int64_t w = 0;
   for (int q = 0; q < P; ++q) {
     const int p = order[q];
