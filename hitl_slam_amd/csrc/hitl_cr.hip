@@ -6,6 +6,9 @@
 //   k_cr_selinv_level, k_cov_extract : diagonal blocks of the inverse from the same factors (pose covariances).
 // All arithmetic is fp64.
 
+#include <cstdlib>
+#include <vector>
+
 #include "hitl_device.h"
 
 namespace hitl {
@@ -599,10 +602,378 @@ static int cr_top_start(int nsb, int B, int nrhs) {
   return s;
 }
 
+// ===========================================================================================
+// Fused cyclic reduction (round 2): the same elimination tree, Dinv / Gl / Gr per node and arithmetic as the level-per-launch
+// kernels above, but a whole run of levels per launch.  The nodes alive at stride S are cut into chunks of M = 2^q
+// consecutive ones; a workgroup keeps its chunk's tiles in LDS and eliminates the M - 1 interior nodes through q local
+// levels.  The two boundary nodes (local 0 and M) are NOT eliminated in this stage and -- because the Schur complement of
+// the interior onto a boundary never reads the boundary's own diagonal block -- need nothing from the neighbouring
+// chunks: a chunk only ACCUMULATES what its interior contributes to them (accR to node 0 from the right, accL to node M
+// from the left, the new coupling M <-> 0, and the same for the right-hand side).  The next stage (stride S*M) folds the two
+// contributions of every node into D and w in a fixed order when it loads them (left chunk's first): bit-reproducible,
+// no atomics.  C4 (16 667 super-blocks): stage (S=1, M=16) -> stage (S=16, M=32) -> top (33 nodes, root included):
+// 3 launches instead of 11, then 3 back-substitution launches instead of 5.
+//
+// Work split inside a level (local stride s): one wave per eliminated node u (neighbours a = u - s, b = u + s) does the
+// register-resident Gauss-Jordan [D_u | I | L_u | L_b^T] -> Dinv, Gl, Gr, stores them for the back-substitution, and forms
+// the three products its neighbours need while Gl / Gr are still in registers:
+//     P_a = L_u^T Gl   (into the slot of L_u)     P_b = L_b Gr   (into the slot of D_u)     L_b <- -L_b Gl
+// plus Gl^T w_u, Gr^T w_u; after one barrier the survivors subtract what their two neighbours left for them.
+// ===========================================================================================
+struct CrStage {
+  int S;          // global stride of this stage's nodes
+  int M;          // nodes per chunk (power of two); local node u <-> global node (chunk * M + u) * S
+  int top;        // 1: single chunk holding every remaining node, local 0 is the root (no right boundary)
+  int has_prev;   // contributions of the previous stage are pending in P / Pw (parity prev_par)
+  int prev_par, next_par;
+  int np;         // slots per contribution array
+  int nsl;        // LDS slots (local nodes 0 .. nsl-1 are addressable)
+  int abl;        // development ablations (HITL_CR_ABL): 1 skip Gauss-Jordan, 2 skip the products, 4 skip the survivor updates
+};
+
+// workgroup barrier that orders LDS traffic only: the Dinv / Gl / Gr stores of a level are read by LATER launches, never by
+// this one, so a level must not wait for them (__syncthreads() would: s_waitcnt vmcnt(0) costs 1-2 us per level here)
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+template <int B>
+__global__ __launch_bounds__(B >= 12 ? 512 : 1024) void k_cr_chunk(CrView cr, CrStage sg, double* w, double* x) {
+  extern __shared__ double lds[];
+  constexpr int BB = B * B;
+  const int M = sg.M, S = sg.S;
+  const int nsl = sg.nsl;                                 // local slots: 0 .. M (a chunk) / 0 .. alive-1 (the top)
+  double* sD = lds;                                       // nsl tiles: D_u, later P_a of an eliminated u
+  double* sL = sD + (size_t)nsl * BB;                     // nsl tiles: L_u (coupling u <-> u - s)
+  double* sPb = sL + (size_t)nsl * BB;                    // nsl tiles: P_b of an eliminated u
+  double* sG = sPb + (size_t)nsl * BB;                    // per wave: Gl, Gr of the node it is eliminating (2 tiles)
+  double* sW = sG + (size_t)(blockDim.x >> 6) * 2 * BB;   // nsl vectors: right-hand side
+  double* sCa = sW + (size_t)nsl * B;                     // nsl vectors: Gl_u^T w_u (for a)
+  double* sCb = sCa + (size_t)nsl * B;                    // nsl vectors: Gr_u^T w_u (for b)
+  double* accR = sCb + (size_t)nsl * B;                   // tile: contributions to local node 0
+  double* accL = accR + BB;                               // tile: contributions to local node M
+  double* accWR = accL + BB;                              // vectors
+  double* accWL = accWR + B;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int wave = tid >> 6, lane = tid & 63, NW = nthr >> 6;
+  const int64_t base = (int64_t)blockIdx.x * M;            // in stage nodes
+  const int64_t nst = ((int64_t)cr.nsb + S - 1) / S;       // stage nodes alive: 0 .. nst-1
+  // local slots that exist: u with base + u < nst
+  const int u_last = (int)((nst - 1 - base < M) ? (nst - 1 - base) : M);     // >= 0
+  const bool has_w = (w != nullptr);
+  const double* PLp = cr.P + (size_t)(sg.prev_par * 2 + 0) * sg.np * BB;
+  const double* PRp = cr.P + (size_t)(sg.prev_par * 2 + 1) * sg.np * BB;
+  const double* WLp = cr.Pw + (size_t)(sg.prev_par * 2 + 0) * sg.np * B;
+  const double* WRp = cr.Pw + (size_t)(sg.prev_par * 2 + 1) * sg.np * B;
+  // ---- load: D (folded with the previous stage's contributions), L, w of local 0 .. u_last ----
+  for (int e = tid; e < (u_last + 1) * BB; e += nthr) {
+    const int u = e / BB, q = e % BB;
+    const int64_t sn = base + u;                           // stage node index == slot of the previous stage's arrays
+    const size_t g = (size_t)(sn * S) * BB + q;
+    double d = cr.D[g];
+    if (sg.has_prev) d = (d - PLp[(size_t)sn * BB + q]) - PRp[(size_t)sn * BB + q];
+    sD[e] = d;
+    sL[e] = cr.L[g];
+    if (u == 0 && sg.has_prev && !sg.top) cr.D[g] = d;     // the left boundary stays alive: keep its folded value
+  }
+  if (has_w)
+    for (int e = tid; e < (u_last + 1) * B; e += nthr) {
+      const int u = e / B, q = e % B;
+      const int64_t sn = base + u;
+      const size_t g = (size_t)(sn * S) * B + q;
+      double v = w[g];
+      if (sg.has_prev) v = (v - WLp[(size_t)sn * B + q]) - WRp[(size_t)sn * B + q];
+      sW[e] = v;
+      if (sg.has_prev && (u == 0 || u == M) == false) w[g] = v;          // interior: the back-substitution reads the folded w
+      if (u == 0 && sg.has_prev && !sg.top) w[g] = v;
+    }
+  for (int e = tid; e < 2 * BB + 2 * B; e += nthr) accR[e] = 0.0;   // accR, accL, accWR, accWL are contiguous
+  lds_barrier();
+  const int u_hi = sg.top ? u_last : ((u_last < M) ? u_last : M - 1);    // largest local node that may be eliminated
+  for (int s = 1; s < M; s *= 2) {
+    // ---- eliminate u = s, 3s, 5s .. <= u_hi ----
+    for (int q = wave;; q += NW) {
+      const int u = s * (2 * q + 1);
+      if (u > u_hi) break;
+      const int b = u + s;
+      const bool has_b = (b <= u_last) && (sg.top ? true : true);
+      const int grp = lane / B, c = lane % B;
+      double* Du = sD + (size_t)u * BB;
+      double* Lu = sL + (size_t)u * BB;
+      double* Lb = sL + (size_t)(has_b ? b : u) * BB;
+      double col[B];
+#pragma unroll
+      for (int r = 0; r < B; ++r) {
+        double v = 0.0;
+        if (grp == 0) v = Du[r * B + c];
+        else if (grp == 1) v = (r == c) ? 1.0 : 0.0;
+        else if (grp == 2) v = Lu[r * B + c];
+        else if (grp == 3 && has_b) v = Lb[c * B + r];      // column c of L_b^T
+        col[r] = v;
+      }
+      if (!(sg.abl & 1)) gauss_jordan_cols<B>(col);
+      const size_t gn = (size_t)((base + u) * S) * BB;
+      if (grp >= 1 && grp <= 3) {
+        double* dst = (grp == 1) ? cr.Dinv + gn : (grp == 2) ? cr.Gl + gn : cr.Gr + gn;
+#pragma unroll
+        for (int r = 0; r < B; ++r) dst[r * B + c] = col[r];
+      }
+      // The three products its neighbours need, on three lane groups at once: Gl / Gr go to this wave's scratch tiles, then
+      // lane (g, c) forms column c of   g = 0: P_a = L_u^T Gl -> slot of D_u (dead since the load above)
+      //                                  g = 1: P_b = L_b Gr   -> sPb[u]
+      //                                  g = 2: -L_b Gl        -> L_b in place (new coupling b <-> a)
+      // The left operands are wave-uniform LDS reads per group.  In-place safety: every q-step reads column / row data of
+      // L_u and L_b, all writes happen after the last q-step (program order within the wave).
+      double cw = 0.0;
+      if (has_w && (grp == 2 || grp == 3)) {
+        const double* wu = sW + (size_t)u * B;
+#pragma unroll
+        for (int r = 0; r < B; ++r) cw += col[r] * wu[r];                          // (G^T w_u)[c]
+        if (grp == 2) sCa[(size_t)u * B + c] = cw; else sCb[(size_t)u * B + c] = cw;
+      }
+      double* Gs = sG + (size_t)wave * 2 * BB;
+      if (grp == 2 || grp == 3) {
+        double* dstg = Gs + (grp == 3 ? BB : 0);
+#pragma unroll
+        for (int r = 0; r < B; ++r) dstg[r * B + c] = col[r];
+      }
+      // (same wave: LDS operations complete in order, no barrier needed)
+      double acc[B];
+#pragma unroll
+      for (int r = 0; r < B; ++r) acc[r] = 0.0;
+      if (grp < 3 && !(sg.abl & 2)) {
+        const double* G = Gs + ((grp == 1) ? BB : 0);                              // Gr for P_b, Gl otherwise
+        const bool on = (grp == 0) || has_b;
+        // one instruction stream for the three groups: A(r, q) = Abase[r * sr + q * sq] is L_u^T for g = 0, L_b otherwise
+        const double* Abase = (grp == 0) ? Lu : Lb;
+        const int sr = (grp == 0) ? 1 : B, sq = (grp == 0) ? B : 1;
+#pragma unroll 3
+        for (int qq = 0; qq < B; ++qq) {
+          const double g = on ? G[qq * B + c] : 0.0;
+#pragma unroll
+          for (int r = 0; r < B; ++r) acc[r] += Abase[r * sr + qq * sq] * g;
+        }
+        double* dst = (grp == 0) ? Du : (grp == 1) ? (sPb + (size_t)u * BB) : Lb;
+        if (grp != 2 || has_b) {
+#pragma unroll
+          for (int r = 0; r < B; ++r) dst[r * B + c] = (grp == 2) ? -acc[r] : acc[r];
+        }
+      }
+    }
+    lds_barrier();
+    // ---- survivors j = 0, 2s, 4s .. subtract what their eliminated neighbours left (left one first) ----
+    const int nsv = (sg.abl & 4) ? 0 : M / (2 * s) + 1;
+    for (int e = tid; e < nsv * BB; e += nthr) {
+      const int j = 2 * s * (e / BB), q = e % BB;
+      if (j > u_last) continue;
+      const bool hl_ = (j - s >= 1), hr_ = (j + s <= u_hi) && (j + s < M || sg.top);
+      const double pl = hl_ ? sPb[(size_t)(j - s) * BB + q] : 0.0;                 // P_b of the left neighbour
+      const double pr = hr_ ? sD[(size_t)(j + s) * BB + q] : 0.0;                  // P_a of the right neighbour
+      if (j == 0) accR[q] += pr;
+      else if (j == M) accL[q] += pl;
+      else sD[(size_t)j * BB + q] = (sD[(size_t)j * BB + q] - pl) - pr;
+    }
+    if (has_w)
+      for (int e = tid; e < nsv * B; e += nthr) {
+        const int j = 2 * s * (e / B), q = e % B;
+        if (j > u_last) continue;
+        const bool hl_ = (j - s >= 1), hr_ = (j + s <= u_hi) && (j + s < M || sg.top);
+        const double pl = hl_ ? sCb[(size_t)(j - s) * B + q] : 0.0;
+        const double pr = hr_ ? sCa[(size_t)(j + s) * B + q] : 0.0;
+        if (j == 0) accWR[q] += pr;
+        else if (j == M) accWL[q] += pl;
+        else sW[(size_t)j * B + q] = (sW[(size_t)j * B + q] - pl) - pr;
+      }
+    lds_barrier();
+    // the right-hand side of a node is final once it is eliminated: the back-substitution reads it from global memory
+    if (has_w)
+      for (int e = tid; e < (M / (2 * s)) * B; e += nthr) {
+        const int u2 = 2 * s * (2 * (e / B) + 1), q = e % B;                       // nodes eliminated at the NEXT level
+        if (u2 <= u_hi && 2 * s < M) w[(size_t)((base + u2) * S) * B + q] = sW[(size_t)u2 * B + q];
+      }
+  }
+  if (!sg.top) {
+    // ---- hand the boundary contributions to the next stage (its node index = this chunk index (+1)) ----
+    double* PLn = cr.P + (size_t)(sg.next_par * 2 + 0) * sg.np * BB;
+    double* PRn = cr.P + (size_t)(sg.next_par * 2 + 1) * sg.np * BB;
+    double* WLn = cr.Pw + (size_t)(sg.next_par * 2 + 0) * sg.np * B;
+    double* WRn = cr.Pw + (size_t)(sg.next_par * 2 + 1) * sg.np * B;
+    const size_t c0 = (size_t)blockIdx.x, c1 = c0 + 1;
+    for (int e = tid; e < BB; e += nthr) {
+      PRn[c0 * BB + e] = accR[e];
+      if (blockIdx.x == 0) PLn[e] = 0.0;                                           // node 0 has no chunk on its left
+      if (u_last == M) { PLn[c1 * BB + e] = accL[e]; cr.L[(size_t)((base + M) * S) * BB + e] = sL[(size_t)M * BB + e]; }
+      if (u_last == M && base + M == nst - 1) PRn[c1 * BB + e] = 0.0;              // the last node has no chunk on its right
+    }
+    if (has_w)
+      for (int e = tid; e < B; e += nthr) {
+        WRn[c0 * B + e] = accWR[e];
+        if (blockIdx.x == 0) WLn[e] = 0.0;
+        if (u_last == M) WLn[c1 * B + e] = accWL[e];
+        if (u_last == M && base + M == nst - 1) WRn[c1 * B + e] = 0.0;
+      }
+    return;
+  }
+  // ---- top: the root ----
+  if (wave == 0) {
+    const int grp = lane / B, c = lane % B;
+    double col[B];
+#pragma unroll
+    for (int r = 0; r < B; ++r) col[r] = (grp == 0) ? (sD[r * B + c] - accR[r * B + c]) : ((grp == 1 && r == c) ? 1.0 : 0.0);
+    gauss_jordan_cols<B>(col);
+    if (grp == 1) {
+#pragma unroll
+      for (int r = 0; r < B; ++r) { cr.Dinv[r * B + c] = col[r]; sL[r * B + c] = col[r]; }   // slot of L_0 (unused: node 0 has no left)
+    }
+  }
+  lds_barrier();
+  if (has_w && tid < B) {
+    const double wr = sW[tid] - accWR[tid];
+    w[tid] = wr;                                                                  // folded root right-hand side (cr_back reads Dinv_0 w_0)
+    sW[tid] = wr;
+  }
+  lds_barrier();
+  if (has_w && x != nullptr && tid < B) {
+    double v = 0.0;
+#pragma unroll
+    for (int c = 0; c < B; ++c) v += sL[tid * B + c] * sW[c];
+    x[tid] = v;
+  }
+}
+
+// Back-substitution of one stage: x is known at the chunk's two boundary nodes; thread (u, r) owns row r of interior
+// node u, fetches its three coefficient rows ONCE (all loads of the launch are in flight together), forms
+// v = (Dinv_u w_u)[r] and then only touches LDS: x_u[r] = v - Gl_u[r,:] x_{u-s} - Gr_u[r,:] x_{u+s}, level by level.
+template <int B>
+__global__ __launch_bounds__(1024) void k_cr_chunk_back(CrView cr, int S, int M, int top, const double* __restrict__ w, double* __restrict__ x) {
+  extern __shared__ double sx[];                         // (M + 1) * B
+  const int tid = threadIdx.x;
+  const int64_t base = (int64_t)blockIdx.x * M;
+  const int64_t nst = ((int64_t)cr.nsb + S - 1) / S;
+  const int u_last = (int)((nst - 1 - base < M) ? (nst - 1 - base) : M);
+  const int u = 1 + tid / B, r = tid % B;
+  const bool mine = (u < M || top) && u <= u_last && (tid < (M - (top ? 0 : 1)) * B) && u <= M;
+  double gl[B], gr[B], v = 0.0;
+#pragma unroll
+  for (int c = 0; c < B; ++c) { gl[c] = 0.0; gr[c] = 0.0; }
+  if (mine) {
+    const size_t gn = (size_t)((base + u) * S);
+    const double* Di = cr.Dinv + gn * B * B + (size_t)r * B;
+    const double* Gl = cr.Gl + gn * B * B + (size_t)r * B;
+    const double* Gr = cr.Gr + gn * B * B + (size_t)r * B;
+    const double* wk = w + gn * B;
+#pragma unroll
+    for (int c = 0; c < B; ++c) { v += Di[c] * wk[c]; gl[c] = Gl[c]; gr[c] = Gr[c]; }
+  }
+  for (int e = tid; e < (M + 1) * B; e += blockDim.x) sx[e] = 0.0;
+  __syncthreads();
+  if (tid < 2 * B) {                                      // the two boundary nodes (known)
+    const int ub = (tid < B) ? 0 : M, rr = tid % B;
+    if (ub <= u_last && !(top && ub == M)) sx[(size_t)ub * B + rr] = x[(size_t)((base + ub) * S) * B + rr];
+  }
+  __syncthreads();
+  for (int s = M / 2; s >= 1; s /= 2) {
+    if (mine && (u & (2 * s - 1)) == s) {                 // u is eliminated at local stride s
+      const double* xl = sx + (size_t)(u - s) * B;
+      const double* xr = sx + (size_t)((u + s <= M) ? (u + s) : u) * B;
+      double acc = v;
+#pragma unroll
+      for (int c = 0; c < B; ++c) acc -= gl[c] * xl[c];
+      if (u + s <= M) {
+#pragma unroll
+        for (int c = 0; c < B; ++c) acc -= gr[c] * xr[c];   // zero-filled beyond the last node; Gr is zero there too
+      }
+      sx[(size_t)u * B + r] = acc;
+      x[(size_t)((base + u) * S) * B + r] = acc;
+    }
+    __syncthreads();
+  }
+}
+
+struct CrPlan { CrStage st[8]; int n; };
+
+static size_t cr_chunk_lds_bytes(int M, int B, int threads) {
+  return sizeof(double) * ((size_t)(M + 1) * (3 * B * B + 3 * B) + (size_t)(threads / 64) * 2 * B * B + 2 * B * B + 2 * B);
+}
+static int cr_chunk_threads(int M, int B) { return (M <= 2) ? 64 : (M <= 4) ? 128 : (M <= 8) ? 256 : (M >= 32 && B < 12) ? 1024 : 512; }
+
+// stages of the fused factorisation for nsb super-blocks (host): chunks of 16 at stride 1, chunks of 32 above, then the top.
+// (Chunks of M = 2 -- one wave per eliminated node, no barrier -- were measured for the wide first levels and are not
+// faster: a node costs a whole wave's instruction stream either way.)  HITL_CR_PLAN="2,2,16,32" (development) overrides
+// the chunk sizes of the first stages.
+static CrPlan cr_plan(int nsb, int B, int np) {
+  CrPlan pl;
+  pl.n = 0;
+  const size_t lds_cap = 128 * 1024;
+  static const std::vector<int> forced = [] {
+    std::vector<int> v;
+    if (const char* e = std::getenv("HITL_CR_PLAN")) {
+      for (const char* q = e; *q;) { v.push_back(std::atoi(q)); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
+    }
+    return v;
+  }();
+  static const int abl = [] { const char* e = std::getenv("HITL_CR_ABL"); return e ? std::atoi(e) : 0; }();
+  int S = 1, par = 0;
+  bool prev = false;
+  for (;;) {
+    const int64_t alive = ((int64_t)nsb + S - 1) / S;
+    int Mtop = 2;
+    while (Mtop < alive) Mtop *= 2;                        // interior u = 1 .. alive-1 < Mtop
+    const bool fits_top = alive <= 40 && cr_chunk_lds_bytes((int)alive, B, cr_chunk_threads(64, B)) <= lds_cap;
+    CrStage& g = pl.st[pl.n++];
+    g.abl = abl;
+    g.S = S; g.has_prev = prev ? 1 : 0; g.prev_par = par; g.next_par = par ^ 1; g.np = np;
+    if (fits_top || pl.n == 8) { g.M = Mtop; g.top = 1; g.nsl = (int)alive + 1; break; }
+    int M = (pl.n == 1) ? 16 : 32;       // measured on C4 (tools/cr_plans.sh): 16,32,top = 111 us; 2,2,16,.. = 117; 2,2,2,32,.. = 125
+    if ((size_t)pl.n <= forced.size() && forced[pl.n - 1] >= 2) M = forced[pl.n - 1];
+    g.M = M; g.top = 0; g.nsl = g.M + 1;
+    S *= g.M; par ^= 1; prev = true;
+  }
+  return pl;
+}
+
+int cr_contrib_slots(int nsb) { return nsb / 2 + 3; }     // boundary nodes of the finest chunk stage (M = 2)
+
+template <int B>
+static bool cr_factor_fused(hipStream_t st, const CrView& cr, double* w, double* x) {
+  if (cr.P == nullptr || cr.Pw == nullptr) return false;
+  static bool raised = false;
+  if (!raised) {
+    raised = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cr_chunk<B>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess;
+    if (!raised) { (void)hipGetLastError(); return false; }
+  }
+  const CrPlan pl = cr_plan(cr.nsb, B, cr.np);
+  for (int t = 0; t < pl.n; ++t) {
+    const CrStage& g = pl.st[t];
+    const int64_t alive = ((int64_t)cr.nsb + g.S - 1) / g.S;
+    const int chunks = g.top ? 1 : (int)((alive - 1 + g.M - 1) / g.M);       // chunks with at least one interior or boundary-M node
+    const int thr = cr_chunk_threads(g.M, B);
+    const size_t lds = cr_chunk_lds_bytes(g.nsl - 1, B, thr);
+    hipLaunchKernelGGL(k_cr_chunk<B>, dim3(chunks > 0 ? chunks : 1), dim3(thr), lds, st, cr, g, w, x);
+  }
+  if (w != nullptr && x != nullptr) {
+    for (int t = pl.n - 1; t >= 0; --t) {
+      const CrStage& g = pl.st[t];
+      const int64_t alive = ((int64_t)cr.nsb + g.S - 1) / g.S;
+      if (alive <= 1) continue;
+      const int chunks = g.top ? 1 : (int)((alive - 1 + g.M - 1) / g.M);
+      int thr = (g.M - (g.top ? 0 : 1)) * B;
+      thr = (thr + 63) & ~63;
+      if (thr > 1024) return false;                                          // never with the stage sizes above (M <= 64, B <= 12)
+      hipLaunchKernelGGL(k_cr_chunk_back<B>, dim3(chunks), dim3(thr), sizeof(double) * (g.M + 1) * B, st, cr, g.S, g.M, g.top, w, x);
+    }
+  }
+  return true;
+}
+
 // x == nullptr: factorise only (w, if given, still receives the forward sweep)
 template <int B>
 static void cr_factor_t(hipStream_t st, const CrView& cr, double* w, double* x, int nrhs, size_t stride) {
   const int nr = (w != nullptr) ? nrhs : 0;
+  static const bool legacy = std::getenv("HITL_CR_LEGACY") != nullptr;       // development switch: the level-per-launch path
+  if (!legacy && nr <= 1 && cr_factor_fused<B>(st, cr, nr ? w : nullptr, nr ? x : nullptr)) return;
   const int s_top = cr_top_start(cr.nsb, B, nr);
   if (s_top > 1) {
     const int n_elim = (cr.nsb - 1 + 1) / 2;

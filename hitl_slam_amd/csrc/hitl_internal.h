@@ -71,7 +71,12 @@ struct CrView {             // block-tridiagonal system + cyclic-reduction facto
   double* Dinv;               // nsb*B*B
   double* Gl;                 // nsb*B*B  Dinv_k * L_k
   double* Gr;                 // nsb*B*B  Dinv_k * L_{k+s}^T
+  // fused factorisation: what a chunk's interior contributes to its two boundary nodes, handed from stage to stage
+  double* P = nullptr;        // [parity 2][left/right 2][np][B*B]
+  double* Pw = nullptr;       // [parity 2][left/right 2][np][B]
+  int np = 0;                 // cr_contrib_slots(nsb)
 };
+int cr_contrib_slots(int nsb);
 
 // ---- kernel launchers (hitl_kernels.hip) -------------------------------------------------
 void launch_pose_trig(hipStream_t st, int n_poses, const double* x, double2* cs);   // cs[i] = (cos, sin) of pose i
@@ -80,7 +85,7 @@ constexpr int kPairMomStride = 32;
 void launch_stf_moments(hipStream_t st, const MapView& map, const PairView& pr, double* pairM);
 void launch_linearize_stf_moments(hipStream_t st, const PairView& pr, const double* pairM, const double* x, const double2* cs, double corr,
                                   double sd, double* pairRJ);
-void launch_linearize_stf(hipStream_t st, const MapView& map, const PairView& pr, int max_scan, int64_t map_obs_count,
+void launch_linearize_stf(hipStream_t st, const MapView& map, const PairView& pr, int max_scan, int64_t map_obs_count, int64_t n_matches,
                           const double* x, const double2* cs, float corr, float std_dev, double* pairRJ);
 void launch_pack_obs(hipStream_t st, int64_t n, const float* px, const float* py, const float* nx, const float* ny,
                      float4* obs);

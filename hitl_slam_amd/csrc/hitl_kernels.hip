@@ -28,16 +28,16 @@ namespace hitl {
 //   d(e1/k)/dtheta0 = cross(n1', p0)   d(e1/k)/dtheta1 = cross(n1', t01 - p0)
 // (identical to SURVEY.md A.2 after rotating by R0^T; cross(a,b) = ax*by - ay*bx).  30 fp64 operations per match.
 //
-// The kernel only SUMS: 8 numbers per pair (S0, A0 = sum e0 n0, T01 = sum e0 d01, S1, A1 = sum e1 n1', T10), reduced
-// across the half-wave with a reduce-scatter butterfly (7 64-bit shuffles for both pairs of a wave) and stored by the 8
-// lanes that end up holding them.  Residual, square roots and the 2x6 Jacobian are formed by k_stf_finalize, one thread
-// per pair: a wave's worth of finishing arithmetic per pair pair became one lane's worth.
+// Per match the kernel only SUMS: 8 numbers per pair (S0, A0 = sum e0 n0, T01 = sum e0 d01, S1, A1 = sum e1 n1', T10), reduced
+// across the half-wave with a reduce-scatter butterfly (7 64-bit swizzles for both pairs of a wave); the 8 lanes that end up
+// holding the totals pass them through LDS to lane 0 of the half-wave, which forms the residual, the square roots and the
+// 2x6 Jacobian.  (A separate one-thread-per-pair finishing kernel was measured at 21 us: strided 112-byte rows.)
 //
 // Round-2 instruction diet (rocprofv3 PMC, C4: 845 VALU instructions per wave before):
 //  * full trips carry no tail weights; the last partial trip is a separate copy of the body with weights,
 //  * the source scan sits in LDS as fp64 (4 conversions per match instead of 8),
 //  * next-trip index words are fetched unguarded (the match array carries 64 words of padding),
-//  * the per-pair epilogue (rsqrt, division, 40 fp64 operations, 14 stores, 16 cross-lane picks) left the kernel.
+//  * the 16 cross-lane picks of the per-pair epilogue became one LDS round trip.
 //
 // blockIdx -> pose mapping keeps consecutive poses on one XCD (blocks b and b+8 share an
 // XCD) so the target scans i+-1..W, which the neighbouring workgroups stage as THEIR source,
@@ -119,7 +119,8 @@ __device__ __forceinline__ void stf_source(const double2* s_scan8, const float4*
 template <int SRC, bool OFF32, int PIPE, int MINB, int ABL = 0>
 __global__ __launch_bounds__(kStfBlock, MINB) void k_linearize_stf(MapView map, PairView pr, int chunk,
                                                                     const double* __restrict__ x, const double2* __restrict__ cs,
-                                                                    double* __restrict__ pairRJ) {
+                                                                    double kf, double* __restrict__ pairRJ) {
+  __shared__ double s_tot[kStfBlock / kStfSub][kStfSums];           // the 8 totals of each half-wave's pair
   extern __shared__ double s_scan_raw[];
   float4* s_scan4 = reinterpret_cast<float4*>(s_scan_raw);            // SRC == 1
   double2* s_scan8 = reinterpret_cast<double2*>(s_scan_raw);          // SRC == 2: (px, py), (nx, ny) per point
@@ -169,16 +170,21 @@ __global__ __launch_bounds__(kStfBlock, MINB) void k_linearize_stf(MapView map, 
     const int64_t m_begin = pr.match_off[pc];
     const int len = live ? (int)(pr.match_off[pc + 1] - m_begin) : 0;          // a pair holds < 65536 matches
     StfAcc acc = {0, 0, 0, 0, 0, 0, 0, 0};
+    // index words: OFF32 reads them as `scalar base + 32-bit lane offset` as well (no 64-bit lane address to keep alive)
     const uint32_t* __restrict__ mp = mt + m_begin + hl;
+    uint32_t mo = ((uint32_t)m_begin + (uint32_t)hl) << 2;
+    const char* __restrict__ mtb = reinterpret_cast<const char*>(mt);
+#define HITL_IDX(k) (OFF32 ? *reinterpret_cast<const uint32_t*>(mtb + (mo + 4u * (uint32_t)(k))) : mp[(k)])
+#define HITL_IDX_ADVANCE(k) { if (OFF32) mo += 4u * (uint32_t)(k); else mp += (k); }
     const int nfull = (ABL == 5) ? 0 : (ABL == 6) ? 1 : (len >> 6), rem = (ABL >= 5) ? 0 : (len & 63);   // ABL 5: prologue + epilogue only; 6: one trip
     double ax0, ay0, anx0, any0, ax1, ay1, anx1, any1;
     if (PIPE == 0) {
       // The index words of the NEXT trip are requested before this trip's arithmetic, so a trip waits for one memory
       // round (the gathers) instead of two dependent ones.  Unguarded: the array ends with kMatchPad words of padding.
-      uint32_t un0 = mp[0], un1 = mp[kStfSub];
+      uint32_t un0 = HITL_IDX(0), un1 = HITL_IDX(kStfSub);
       for (int t = 0; t < nfull; ++t) {
         const uint32_t u0 = un0, u1 = un1;
-        mp += 2 * kStfSub;
+        HITL_IDX_ADVANCE(2 * kStfSub)
         // ABL (development ablations, results are wrong): 1 no target gathers, 2 no source reads, 3 no arithmetic, 4 no index stream
         float4 tv0, tv1;
         if (ABL == 1) { tv0 = make_float4(__uint_as_float(u0), 1.f, 0.f, 1.f); tv1 = make_float4(__uint_as_float(u1), 1.f, 0.f, 1.f); }
@@ -189,7 +195,7 @@ __global__ __launch_bounds__(kStfBlock, MINB) void k_linearize_stf(MapView map, 
           stf_source<SRC>(s_scan8, s_scan4, src_g, u1, ax1, ay1, anx1, any1);
         }
         if (ABL == 4) { un0 = (u0 + 0x10001u) & 0x00ff00ffu; un1 = (u1 + 0x10001u) & 0x00ff00ffu; }
-        else { un0 = mp[0]; un1 = mp[kStfSub]; }
+        else { un0 = HITL_IDX(0); un1 = HITL_IDX(kStfSub); }
         __builtin_amdgcn_sched_barrier(0);      // keep the index prefetch ahead of the arithmetic (the scheduler sinks it otherwise)
         if (ABL == 3) { acc.S0 += (ax0 + ax1) + (double)(tv0.x + tv1.x); acc.S1 += (any0 + any1) + (double)(tv0.w + tv1.w); }
         else {
@@ -209,17 +215,17 @@ __global__ __launch_bounds__(kStfBlock, MINB) void k_linearize_stf(MapView map, 
     } else {
       // two-stage pipeline: (ua, ub, ta, tb) = index words and gathered targets of the CURRENT trip; (na, nb) = index
       // words of the next one.  Words past the pair's end are replaced by 0 (a valid index) before they address anything.
-      uint32_t ua = mp[0], ub = mp[kStfSub];
-      uint32_t na = mp[2 * kStfSub], nb = mp[3 * kStfSub];
+      uint32_t ua = HITL_IDX(0), ub = HITL_IDX(kStfSub);
+      uint32_t na = HITL_IDX(2 * kStfSub), nb = HITL_IDX(3 * kStfSub);
       ua = (hl < len) ? ua : 0u; ub = (hl + kStfSub < len) ? ub : 0u;
       float4 ta = HITL_TGT(ua), tb = HITL_TGT(ub);
       int pos = hl + 2 * kStfSub;                      // list position of na
       for (int t = 0; t < nfull; ++t) {
         const uint32_t ca = (pos < len) ? na : 0u, cb = (pos + kStfSub < len) ? nb : 0u;
         const float4 nta = HITL_TGT(ca), ntb = HITL_TGT(cb);        // next trip's gathers, in flight during this trip's arithmetic
-        mp += 2 * kStfSub; pos += 2 * kStfSub;
+        HITL_IDX_ADVANCE(2 * kStfSub) pos += 2 * kStfSub;
         if (ABL == 4) { na = (ca + 0x10001u) & 0x00ff00ffu; nb = (cb + 0x10001u) & 0x00ff00ffu; }   // development ablation: no index stream
-        else { na = mp[2 * kStfSub]; nb = mp[3 * kStfSub]; }        // index words two trips ahead
+        else { na = HITL_IDX(2 * kStfSub); nb = HITL_IDX(3 * kStfSub); }        // index words two trips ahead
         stf_source<SRC>(s_scan8, s_scan4, src_g, ua, ax0, ay0, anx0, any0);
         stf_source<SRC>(s_scan8, s_scan4, src_g, ub, ax1, ay1, anx1, any1);
         __builtin_amdgcn_sched_barrier(0);
@@ -243,39 +249,31 @@ __global__ __launch_bounds__(kStfBlock, MINB) void k_linearize_stf(MapView map, 
     double tot = v[0];
     tot += swz_xor<2>(tot);
     tot += swz_xor<1>(tot);
-    if (live && (hl & 3) == 0) pairRJ[(size_t)kPairRJ * p + (hl >> 2)] = tot;      // 8 lanes, 64 contiguous bytes
+    // lane hl = 4 id now holds total id: through LDS to lane 0 of the half-wave (the kernel is not VALU-bound, and no
+    // lane-address register is needed this way), which finishes the pair: r = k sqrt(S/n) (residual_functors.h:822-827),
+    // dr/dq = k (sum e' de') / (n sqrt(S/n)); the two remaining theta partials follow from the sums:
+    //   sum e0 cross(n0, w) = cross(A0, t01) - T01 (w = u + t01),   sum e1 cross(n1', t01 - p0) = cross(A1, t01) - T10
+    if ((hl & 3) == 0) s_tot[sub][hl >> 2] = tot;
+    if (hl == 0 && live) {          // same wave: the LDS writes above are complete before these reads (in-order LDS queue)
+      const double S0 = s_tot[sub][0], A0x = s_tot[sub][1], A0y = s_tot[sub][2], T01 = s_tot[sub][3];
+      const double S1 = s_tot[sub][4], A1x = s_tot[sub][5], A1y = s_tot[sub][6], T10 = s_tot[sub][7];
+      const double T00 = (A0x * t01y - A0y * t01x) - T01;
+      const double T11 = (A1x * t01y - A1y * t01x) - T10;
+      const double inv_n = 1.0 / (double)len;
+      const double a0 = S0 * inv_n, a1 = S1 * inv_n;
+      const double i0 = (S0 != 0.0) ? rsqrt(a0) : 0.0, i1 = (S1 != 0.0) ? rsqrt(a1) : 0.0;
+      const double f0 = kf * inv_n * i0, f1 = kf * inv_n * i1;
+      const double g0x = c0 * A0x - s0 * A0y, g0y = s0 * A0x + c0 * A0y;   // R0 * sum e0' n0
+      const double g1x = c0 * A1x - s0 * A1y, g1y = s0 * A1x + c0 * A1y;   // R0 * sum e1' n1'
+      double* o = pairRJ + (size_t)kPairRJ * p;
+      o[0] = kf * a0 * i0; o[1] = kf * a1 * i1;
+      o[2] = -f0 * g0x; o[3] = -f0 * g0y; o[4] = f0 * T00; o[5] = f0 * g0x; o[6] = f0 * g0y; o[7] = f0 * T01;
+      o[8] = -f1 * g1x; o[9] = -f1 * g1y; o[10] = f1 * T10; o[11] = f1 * g1x; o[12] = f1 * g1y; o[13] = f1 * T11;
+    }
 #undef HITL_TGT
+#undef HITL_IDX
+#undef HITL_IDX_ADVANCE
   }
-}
-
-// one thread per pair: the 8 sums (of e / k) -> r[2], J[2x6] in place.  r = k sqrt(S/n) (residual_functors.h:822-827),
-// dr/dq = k (sum e' de') / (n sqrt(S/n)); the two remaining theta partials follow from the sums:
-//   sum e0 cross(n0, w)        = cross(A0, t01) - T01     (w = u + t01)
-//   sum e1 cross(n1', t01-p0)  = cross(A1, t01) - T10
-__global__ __launch_bounds__(256) void k_stf_finalize(PairView pr, const double* __restrict__ x, const double2* __restrict__ cs, double kf,
-                                                      double* __restrict__ pairRJ) {
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= pr.n_pairs) return;
-  const int i = pr.pair_src[p], j = pr.pair_tgt[p];
-  const double2 cs0 = cs[i];
-  const double c0 = cs0.x, s0 = cs0.y;
-  const double ddx = x[3 * j] - x[3 * i], ddy = x[3 * j + 1] - x[3 * i + 1];
-  const double t01x = c0 * ddx + s0 * ddy, t01y = c0 * ddy - s0 * ddx;
-  double* o = pairRJ + (size_t)kPairRJ * p;
-  const double S0 = o[0], A0x = o[1], A0y = o[2], T01 = o[3], S1 = o[4], A1x = o[5], A1y = o[6], T10 = o[7];
-  const double T00 = (A0x * t01y - A0y * t01x) - T01;
-  const double T11 = (A1x * t01y - A1y * t01x) - T10;
-  const double dn = (double)(pr.match_off[p + 1] - pr.match_off[p]);
-  const double inv_n = 1.0 / dn;
-  const double a0 = S0 * inv_n, a1 = S1 * inv_n;
-  const double i0 = (S0 != 0.0) ? rsqrt(a0) : 0.0, i1 = (S1 != 0.0) ? rsqrt(a1) : 0.0;
-  const double r0 = kf * a0 * i0, r1 = kf * a1 * i1;
-  const double f0 = kf * inv_n * i0, f1 = kf * inv_n * i1;
-  const double g0x = c0 * A0x - s0 * A0y, g0y = s0 * A0x + c0 * A0y;   // R0 * sum e0' n0
-  const double g1x = c0 * A1x - s0 * A1y, g1y = s0 * A1x + c0 * A1y;   // R0 * sum e1' n1'
-  o[0] = r0; o[1] = r1;
-  o[2] = -f0 * g0x; o[3] = -f0 * g0y; o[4] = f0 * T00; o[5] = f0 * g0x; o[6] = f0 * g0y; o[7] = f0 * T01;
-  o[8] = -f1 * g1x; o[9] = -f1 * g1y; o[10] = f1 * T10; o[11] = f1 * g1x; o[12] = f1 * g1y; o[13] = f1 * T11;
 }
 
 // ===========================================================================================
@@ -381,29 +379,29 @@ void launch_pose_trig(hipStream_t st, int n_poses, const double* x, double2* cs)
   hipLaunchKernelGGL(k_pose_trig, dim3((n_poses + 255) / 256), dim3(256), 0, st, n_poses, x, cs);
 }
 
-void launch_linearize_stf(hipStream_t st, const MapView& map, const PairView& pr, int max_scan, int64_t map_obs_count, const double* x,
+void launch_linearize_stf(hipStream_t st, const MapView& map, const PairView& pr, int max_scan, int64_t map_obs_count, int64_t n_matches, const double* x,
                           const double2* cs, float corr, float std_dev, double* pairRJ) {
   if (pr.n_pairs == 0) return;
   const int chunk = (map.n_poses + 7) / 8;
   const int cap = (max_scan + 63) & ~63;
-  const bool off32 = (uint64_t)map_obs_count * 16 < ((uint64_t)1 << 32);
+  const bool off32 = (uint64_t)map_obs_count * 16 < ((uint64_t)1 << 32) && ((uint64_t)n_matches + kMatchPad) * 4 < ((uint64_t)1 << 32);
+  const double kf = (double)corr / (double)std_dev;                       // k = corr / sigma, divided here once
   const dim3 grid(8 * chunk), block(kStfBlock);
   // HITL_STF_VARIANT (development switch): 3 decimal digits "src pipe minblocks", e.g. 116 = fp32 source in LDS, pipelined
   // gathers, 6 workgroups per CU.  Unset: the default below.
   static const int variant = [] { const char* e = std::getenv("HITL_STF_VARIANT"); return e ? std::atoi(e) : 0; }();
   int src = ((size_t)cap * 32 <= 64 * 1024) ? 2 : ((size_t)cap * 16 <= 64 * 1024) ? 1 : 0;
-  int pipe = 0, minb = 6;
+  int pipe = 0, minb = (src == 2 && off32) ? 6 : 5;     // the fallback layouts need > 80 VGPRs: 5 waves per SIMD instead of spilling
   if (variant >= 1000) {     // ablations of the default kernel: 1000 + ABL
     const int abl = variant - 1000;
     if (src == 2 && off32) {
-      if (abl == 1) hipLaunchKernelGGL((k_linearize_stf<2, true, 0, 6, 1>), grid, block, (size_t)cap * 32, st, map, pr, chunk, x, cs, pairRJ);
-      else if (abl == 2) hipLaunchKernelGGL((k_linearize_stf<2, true, 0, 6, 2>), grid, block, (size_t)cap * 32, st, map, pr, chunk, x, cs, pairRJ);
-      else if (abl == 3) hipLaunchKernelGGL((k_linearize_stf<2, true, 0, 6, 3>), grid, block, (size_t)cap * 32, st, map, pr, chunk, x, cs, pairRJ);
-      else if (abl == 14) hipLaunchKernelGGL((k_linearize_stf<2, true, 1, 5, 4>), grid, block, (size_t)cap * 32, st, map, pr, chunk, x, cs, pairRJ);
-      else if (abl == 5) hipLaunchKernelGGL((k_linearize_stf<2, true, 0, 6, 5>), grid, block, (size_t)cap * 32, st, map, pr, chunk, x, cs, pairRJ);
-      else if (abl == 6) hipLaunchKernelGGL((k_linearize_stf<2, true, 0, 6, 6>), grid, block, (size_t)cap * 32, st, map, pr, chunk, x, cs, pairRJ);
-      else hipLaunchKernelGGL((k_linearize_stf<2, true, 0, 6, 4>), grid, block, (size_t)cap * 32, st, map, pr, chunk, x, cs, pairRJ);
-      hipLaunchKernelGGL(k_stf_finalize, dim3((pr.n_pairs + 255) / 256), dim3(256), 0, st, pr, x, cs, (double)corr / (double)std_dev, pairRJ);
+      if (abl == 1) hipLaunchKernelGGL((k_linearize_stf<2, true, 0, 6, 1>), grid, block, (size_t)cap * 32, st, map, pr, chunk, x, cs, kf, pairRJ);
+      else if (abl == 2) hipLaunchKernelGGL((k_linearize_stf<2, true, 0, 6, 2>), grid, block, (size_t)cap * 32, st, map, pr, chunk, x, cs, kf, pairRJ);
+      else if (abl == 3) hipLaunchKernelGGL((k_linearize_stf<2, true, 0, 6, 3>), grid, block, (size_t)cap * 32, st, map, pr, chunk, x, cs, kf, pairRJ);
+      else if (abl == 14) hipLaunchKernelGGL((k_linearize_stf<2, true, 1, 5, 4>), grid, block, (size_t)cap * 32, st, map, pr, chunk, x, cs, kf, pairRJ);
+      else if (abl == 5) hipLaunchKernelGGL((k_linearize_stf<2, true, 0, 6, 5>), grid, block, (size_t)cap * 32, st, map, pr, chunk, x, cs, kf, pairRJ);
+      else if (abl == 6) hipLaunchKernelGGL((k_linearize_stf<2, true, 0, 6, 6>), grid, block, (size_t)cap * 32, st, map, pr, chunk, x, cs, kf, pairRJ);
+      else hipLaunchKernelGGL((k_linearize_stf<2, true, 0, 6, 4>), grid, block, (size_t)cap * 32, st, map, pr, chunk, x, cs, kf, pairRJ);
       return;
     }
   }
@@ -416,8 +414,8 @@ void launch_linearize_stf(hipStream_t st, const MapView& map, const PairView& pr
   const size_t lds = (src == 2) ? (size_t)cap * 32 : (src == 1) ? (size_t)cap * 16 : 0;
 #define HITL_STF_GO(SRC, PIPE, MINB)                                                                                            \
   {                                                                                                                            \
-    if (off32) hipLaunchKernelGGL((k_linearize_stf<SRC, true, PIPE, MINB>), grid, block, lds, st, map, pr, chunk, x, cs, pairRJ); \
-    else hipLaunchKernelGGL((k_linearize_stf<SRC, false, PIPE, MINB>), grid, block, lds, st, map, pr, chunk, x, cs, pairRJ);     \
+    if (off32) hipLaunchKernelGGL((k_linearize_stf<SRC, true, PIPE, MINB>), grid, block, lds, st, map, pr, chunk, x, cs, kf, pairRJ); \
+    else hipLaunchKernelGGL((k_linearize_stf<SRC, false, PIPE, MINB>), grid, block, lds, st, map, pr, chunk, x, cs, kf, pairRJ);     \
   }
 #define HITL_STF_PM(SRC)                                                                   \
   {                                                                                        \
@@ -433,8 +431,6 @@ void launch_linearize_stf(hipStream_t st, const MapView& map, const PairView& pr
   else HITL_STF_PM(0)
 #undef HITL_STF_PM
 #undef HITL_STF_GO
-  // k = corr / sigma, divided here once
-  hipLaunchKernelGGL(k_stf_finalize, dim3((pr.n_pairs + 255) / 256), dim3(256), 0, st, pr, x, cs, (double)corr / (double)std_dev, pairRJ);
 }
 
 // SoA (the caller's layout, JointOptimization.h:62-68) -> device-resident float4 per observation

@@ -37,7 +37,7 @@ static int enqueue_linearize(hitl_solver* s, const FactorView& fv, const double*
     if (s->opt.stf_moments)
       launch_linearize_stf_moments(st, pv, s->pairM.p, xdev, s->pose_cs.p, s->opt.point_correlation_factor, s->opt.laser_std_dev, lv.pairRJ);
     else
-      launch_linearize_stf(st, mv, pv, s->max_scan, s->n_obs, xdev, s->pose_cs.p, s->opt.point_correlation_factor, s->opt.laser_std_dev, lv.pairRJ);
+      launch_linearize_stf(st, mv, pv, s->max_scan, s->n_obs, s->n_matches, xdev, s->pose_cs.p, s->opt.point_correlation_factor, s->opt.laser_std_dev, lv.pairRJ);
   }
   if (s->lin_timed) HIP_TRY(hipEventRecord(s->ev1, st));
   launch_assemble(st, mv, pv, fv, xdev, lv);

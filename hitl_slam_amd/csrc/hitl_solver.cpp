@@ -155,6 +155,10 @@ int ensure_work(hitl_solver* s, int Wb) {
   }
   const size_t bb = (size_t)s->nsb * s->B * s->B;
   TRY(s->crD.resize(bb)); TRY(s->crL.resize(bb)); TRY(s->crDinv.resize(bb)); TRY(s->crGl.resize(bb)); TRY(s->crGr.resize(bb));
+  {
+    const size_t np = (size_t)cr_contrib_slots(s->nsb);
+    TRY(s->crP.resize(4 * np * s->B * s->B)); TRY(s->crPw.resize(4 * np * s->B));
+  }
   s->wb_Wb = Wb; s->wb_n = n; s->wb_pairs = s->n_pairs; s->wb_offband = s->n_offband;
   return HITL_OK;
 }
@@ -415,7 +419,7 @@ void hitl_solver_destroy(hitl_solver* s) {
   (void)hipSetDevice(s->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   for (DevArray<double>* v : {&s->d_scalars, &s->x, &s->xc, &s->scale, &s->rhs, &s->dt, &s->wv, &s->qv, &s->rv, &s->zv, &s->pv,
-                              &s->crD, &s->crL, &s->crDinv, &s->crGl, &s->crGr})
+                              &s->crD, &s->crL, &s->crDinv, &s->crGl, &s->crGr, &s->crP, &s->crPw})
     v->release();
   for (int k = 0; k < 2; ++k) { s->pairRJ[k].release(); s->Hband[k].release(); s->gvec[k].release(); s->obblk[k].release(); s->lin_partials[k].release(); }
   s->obs_off.release(); s->match_off.release();
