@@ -503,6 +503,25 @@ class Solver(SolverBase):
         if st != abi.OK:
             raise HitlError(st, "hitl_solver_comm_selftest", self._detail())
 
+    def evaluate_jacobian(self, poses_xyt):
+        """Problem::Evaluate of the scan-to-scan problem (JointOptimization.cpp:1247-1252): (cost, residuals[2P],
+        scipy-style CRS (indptr[2P+1], indices[12P], data[12P]) over 3*n_poses columns)."""
+        pin = _as(poses_xyt, np.float32).reshape(-1)
+        P, _ = self.correspondence_counts()
+        res = np.zeros(2 * P, np.float64)
+        rows = np.zeros(2 * P + 1, np.int32)
+        cols = np.zeros(12 * P, np.int32)
+        vals = np.zeros(12 * P, np.float64)
+        cost = C.c_double()
+        f = self._lib.hitl_solver_evaluate_jacobian
+        f.argtypes = [C.c_void_p, _f32p, C.POINTER(C.c_double), _f64p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _f64p]
+        f.restype = C.c_int
+        st = f(self._h, _ptr(pin, _f32p), C.byref(cost), _ptr(res, _f64p), rows.ctypes.data_as(C.POINTER(C.c_int32)),
+               cols.ctypes.data_as(C.POINTER(C.c_int32)), _ptr(vals, _f64p))
+        if st != abi.OK:
+            raise HitlError(st, "hitl_solver_evaluate_jacobian", self._detail())
+        return cost.value, res, (rows, cols, vals)
+
     def set_timing_level(self, level):
         f = self._lib.hitl_solver_set_timing_level
         f.argtypes = [C.c_void_p, C.c_int32]

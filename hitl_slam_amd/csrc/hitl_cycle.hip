@@ -162,14 +162,16 @@ __global__ __launch_bounds__(kBpBlock) void k_backprop_rotate(float* __restrict_
     const float4 t = s_out[threadIdx.x];
     // Publication without a release fence (an agent-scope fence writes back the whole L2 of this XCD, ~25 us per
     // block here): the transforms go out as agent-scope atomic stores, which are performed at the device-wide
-    // coherence point, the barrier below waits for their completion (s_waitcnt vmcnt(0) precedes s_barrier), and only
-    // then is the flag raised.  Readers use agent-scope atomic loads for flag and data alike.
+    // coherence point; every wave then waits for ITS stores explicitly (s_waitcnt vmcnt(0) below -- the barrier alone
+    // does not: the compiler emits no vmcnt wait for relaxed atomic stores before s_barrier), and only after the
+    // barrier is the flag raised.  Readers use agent-scope atomic loads for flag and data alike.
     float* dst = xf + 4 * (size_t)(b * kBpBlock + (int)threadIdx.x);
     __hip_atomic_store(dst + 0, t.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(dst + 1, t.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(dst + 2, t.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(dst + 3, t.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  __builtin_amdgcn_s_waitcnt(0x0070);     // vmcnt(0) expcnt(7) lgkmcnt(0): this wave's four stores above have been performed
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_store(&sync[1 + b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (live) { poses[3 * (lo + q)] = x; poses[3 * (lo + q) + 1] = y; poses[3 * (lo + q) + 2] = th; }

@@ -103,13 +103,13 @@ int64_t hitl_posegraph_num_poses(const hitl_posegraph* g) { return g ? (int64_t)
 int64_t hitl_posegraph_num_obs(const hitl_posegraph* g) { return g ? (int64_t)g->px.size() : 0; }
 double hitl_posegraph_timestamp(const hitl_posegraph* g) { return g ? g->timestamp : 0.0; }
 const char* hitl_posegraph_map_name(const hitl_posegraph* g) { return g ? g->map_name.c_str() : ""; }
-const float* hitl_posegraph_poses(const hitl_posegraph* g) { return g->poses.data(); }
-const float* hitl_posegraph_cov9(const hitl_posegraph* g) { return g->cov9.data(); }
-const int64_t* hitl_posegraph_obs_offset(const hitl_posegraph* g) { return g->obs_offset.data(); }
-const float* hitl_posegraph_px(const hitl_posegraph* g) { return g->px.data(); }
-const float* hitl_posegraph_py(const hitl_posegraph* g) { return g->py.data(); }
-const float* hitl_posegraph_nx(const hitl_posegraph* g) { return g->nx.data(); }
-const float* hitl_posegraph_ny(const hitl_posegraph* g) { return g->ny.data(); }
+const float* hitl_posegraph_poses(const hitl_posegraph* g) { return g ? g->poses.data() : nullptr; }
+const float* hitl_posegraph_cov9(const hitl_posegraph* g) { return g ? g->cov9.data() : nullptr; }
+const int64_t* hitl_posegraph_obs_offset(const hitl_posegraph* g) { return g ? g->obs_offset.data() : nullptr; }
+const float* hitl_posegraph_px(const hitl_posegraph* g) { return g ? g->px.data() : nullptr; }
+const float* hitl_posegraph_py(const hitl_posegraph* g) { return g ? g->py.data() : nullptr; }
+const float* hitl_posegraph_nx(const hitl_posegraph* g) { return g ? g->nx.data() : nullptr; }
+const float* hitl_posegraph_ny(const hitl_posegraph* g) { return g ? g->ny.data() : nullptr; }
 
 int hitl_io_save_stfs_covars(const char* path, const char* map_name, double timestamp, int64_t n_poses,
                              const float* poses_xyt, const int64_t* obs_offset, const float* px, const float* py,

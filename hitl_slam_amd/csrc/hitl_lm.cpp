@@ -412,7 +412,6 @@ int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float* poses
   FactorView fv;
   TRY(prepare(s, mode, poses_in, poses_global, &fv));
   if (std::getenv("HITL_TIMING")) std::fprintf(stderr, "lm_solve: prepare (factor tables)   %.3f ms\n", now_ms() - t_start);
-  if (s->world > 1 && fv.n_offband > 0) return fail(HITL_ERR_UNSUPPORTED, "submap solves need every pose pair inside the band");
   hipStream_t st = s->stream;
   const int n = s->n, n3 = 3 * n;
   hitl_summary S;

@@ -254,13 +254,10 @@ int check_ready(hitl_solver* s, int mode) {
   return HITL_OK;
 }
 
-int prepare(hitl_solver* s, int mode, const float* poses_ref, const float* poses_global, FactorView* fv) {
+// the rank-local part of prepare: everything that can fail before the ranks talk to each other
+static int prepare_local(hitl_solver* s, int mode, const float* poses_ref, const float* poses_global, int Wb) {
   HIP_TRY(hipSetDevice(s->device));
   TRY(ensure_empty_pair_tables(s));
-  const int Wb = (mode == HITL_MODE_ODOM_HC) ? 1 : s->band_pairs_Wb;
-  if (mode == HITL_MODE_ODOM_HC) {
-    // mode A reads no pair table: a 1-pose band; the pair-derived band_pair table is unused
-  }
   TRY(ensure_work(s, Wb));
   if (s->opt.stf_moments && mode != HITL_MODE_ODOM_HC && s->moments_of != s->corr_generation) {
     // once per correspondence set: the point data enter the scan-to-scan factors only through these sums
@@ -270,21 +267,42 @@ int prepare(hitl_solver* s, int mode, const float* poses_ref, const float* poses
     s->moments_of = s->corr_generation;
   }
   TRY(setup_factors(s, poses_ref, poses_global, mode != HITL_MODE_STF_ONLY));
+  return HITL_OK;
+}
+
+int prepare(hitl_solver* s, int mode, const float* poses_ref, const float* poses_global, FactorView* fv) {
+  // mode A reads no pair table: a 1-pose band; the pair-derived band_pair table is unused
+  const int Wb = (mode == HITL_MODE_ODOM_HC) ? 1 : s->band_pairs_Wb;
+  const int local_rc = prepare_local(s, mode, poses_ref, poses_global, Wb);
+  if (s->world == 1 && local_rc != HITL_OK) return local_rc;
   if (s->world > 1) {
     // interface width = how deep (in poses) any factor reaches across a cut, maximised over all
     // ranks: 1 when only the odometry edges straddle the cuts, up to the pose band otherwise
     int wi_local = 1;
-    if (mode != HITL_MODE_ODOM_HC)
+    if (mode != HITL_MODE_ODOM_HC && local_rc == HITL_OK)
       for (int p = 0; p < s->n_pairs; ++p) {
         const int a = std::min(s->h_pair_src[p], s->h_pair_tgt[p]), b = std::max(s->h_pair_src[p], s->h_pair_tgt[p]);
         if (a < s->own_lo && b >= s->own_lo) wi_local = std::max(wi_local, std::max(s->own_lo - a, b - s->own_lo + 1));
         if (a < s->own_hi && b >= s->own_hi) wi_local = std::max(wi_local, std::max(s->own_hi - a, b - s->own_hi + 1));
       }
     {
-      double mine = (double)wi_local;
-      std::vector<double> all((size_t)s->world);
-      TRY(comm_allgather(s, &mine, all.data(), sizeof(double)));
-      for (int r = 0; r < s->world; ++r) wi_local = std::max(wi_local, (int)all[r]);
+      // one exchange carries the interface width AND every rank's local verdict, so that all ranks leave at the same
+      // point: a rank that failed above (or holds pose pairs outside the band, which submap solves do not support yet)
+      // must not let the others walk into the collectives of the LM loop alone
+      const bool offband_here = (mode != HITL_MODE_ODOM_HC) && s->n_offband > 0;
+      double mine[3] = {(double)wi_local, (double)local_rc, offband_here ? 1.0 : 0.0};
+      std::vector<double> all((size_t)3 * s->world);
+      TRY(comm_allgather(s, mine, all.data(), sizeof(mine)));
+      int worst = HITL_OK;
+      bool any_offband = false;
+      for (int r = 0; r < s->world; ++r) {
+        wi_local = std::max(wi_local, (int)all[(size_t)3 * r]);
+        if ((int)all[(size_t)3 * r + 1] != HITL_OK && worst == HITL_OK) worst = (int)all[(size_t)3 * r + 1];
+        any_offband = any_offband || all[(size_t)3 * r + 2] != 0.0;
+      }
+      if (local_rc != HITL_OK) return local_rc;
+      if (worst != HITL_OK) return fail(worst, "another rank failed while preparing the solve");
+      if (any_offband) return fail(HITL_ERR_UNSUPPORTED, "submap solves need every pose pair inside the band (on every rank)");
     }
     s->Wi = wi_local;
     const int Wi = s->Wi, nc = 6 * Wi;
@@ -650,11 +668,12 @@ int hitl_solver_solve(hitl_solver* s, int32_t mode, const float* poses_in_xyt, f
   if (mode == HITL_MODE_STF_ONLY) return fail(HITL_ERR_UNSUPPORTED, "submap solves need the odometry chain (mode A or C)");
   const size_t n = (size_t)s->n, first = (size_t)(s->g_begin - s->hl);
   std::vector<float> in(poses_in_xyt + 3 * first, poses_in_xyt + 3 * (first + n)), out(3 * n);
-  hitl_summary S;
+  hitl_summary S = {};
   const int rc = lm_solve(s, mode, in.data(), poses_in_xyt, out.data(), &S);
   if (poses_out_xyt != poses_in_xyt) std::memcpy(poses_out_xyt, poses_in_xyt, sizeof(float) * 3 * (size_t)s->g_n);
   if (rc == HITL_OK || rc == HITL_ERR_SOLVER_FAILURE)
     std::memcpy(poses_out_xyt + 3 * (size_t)s->g_begin, out.data() + 3 * (size_t)s->own_lo, sizeof(float) * 3 * (size_t)(s->own_hi - s->own_lo));
+  if (rc != HITL_OK && rc != HITL_ERR_SOLVER_FAILURE) { if (summary) *summary = S; return rc; }   // every rank left at the same point (prepare)
   // problem-size counters are global sums
   double cnt[4] = {(double)S.num_residuals, (double)S.num_hc_residuals, (double)S.num_pairs, (double)S.num_matches};
   std::vector<double> all((size_t)4 * s->world);
@@ -701,6 +720,40 @@ int hitl_solver_evaluate(hitl_solver* s, int32_t mode, const float* poses_xyt, d
   std::vector<double> x((size_t)3 * s->n);
   for (size_t t = 0; t < x.size(); ++t) x[t] = (double)poses_xyt[t];
   return hitl_solver_linearize(s, mode, poses_xyt, x.data(), cost, gradient, nullptr, nullptr);
+}
+
+int hitl_solver_evaluate_jacobian(hitl_solver* s, const float* poses_xyt, double* cost, double* residuals, int32_t* crs_rows,
+                                  int32_t* crs_cols, double* crs_values) {
+  TRY(check_ready(s, HITL_MODE_STF_ONLY));
+  if (!poses_xyt) return fail(HITL_ERR_INVALID_ARGUMENT, "evaluate_jacobian: null pose array");
+  if (s->world > 1) return fail(HITL_ERR_UNSUPPORTED, "evaluate_jacobian is a single-GPU entry point");
+  const int P = s->n_pairs;
+  std::vector<double> x((size_t)3 * s->n), pr((size_t)2 * std::max(P, 1)), pj((size_t)12 * std::max(P, 1));
+  for (size_t t = 0; t < x.size(); ++t) x[t] = (double)poses_xyt[t];
+  double c = 0.0;
+  if (P > 0) TRY(hitl_solver_linearize(s, HITL_MODE_STF_ONLY, poses_xyt, x.data(), &c, nullptr, pr.data(), pj.data()));
+  if (cost) *cost = c;
+  if (residuals) std::memcpy(residuals, pr.data(), sizeof(double) * 2 * (size_t)P);
+  // caller order: pair p of the caller is internal pair q with h_perm[q] == p
+  std::vector<int> inv((size_t)P);
+  for (int q = 0; q < P; ++q) inv[s->h_perm[q]] = q;
+  for (int p = 0; p < P; ++p) {
+    const int q = inv[p];
+    const int a = s->h_pair_src[q], b = s->h_pair_tgt[q];
+    for (int r = 0; r < 2; ++r) {
+      const size_t row = (size_t)2 * p + r, at = 6 * row;
+      if (crs_rows) crs_rows[row] = (int32_t)at;
+      const double* J = &pj[(size_t)12 * p + 6 * r];            // (x0,y0,t0 | x1,y1,t1) = (source | target)
+      const int first = (a < b) ? 0 : 3, second = 3 - first;    // ascending column indices within the row
+      const int ca = (a < b) ? a : b, cb = (a < b) ? b : a;
+      for (int k = 0; k < 3; ++k) {
+        if (crs_cols) { crs_cols[at + k] = 3 * ca + k; crs_cols[at + 3 + k] = 3 * cb + k; }
+        if (crs_values) { crs_values[at + k] = J[first + k]; crs_values[at + 3 + k] = J[second + k]; }
+      }
+    }
+  }
+  if (crs_rows) crs_rows[(size_t)2 * P] = (int32_t)(12 * (size_t)P);
+  return HITL_OK;
 }
 
 // ---- pose covariances: what ceres::Covariance + the robot-frame rotation produce at

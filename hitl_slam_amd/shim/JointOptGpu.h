@@ -24,10 +24,18 @@
 
 namespace hitl {
 
+// same members as ceres::CRSMatrix (what JointOpt::ceres_jacobian_ is, JointOptimization.h:86)
+struct CRSMatrix {
+  CRSMatrix() : num_rows(0), num_cols(0) {}
+  int num_rows, num_cols;
+  std::vector<int> cols, rows;
+  std::vector<double> values;
+};
+
 template <class Pose2Df, class Vec2f, class Mat3f, class HumanConstraint>
 class JointOptGpuT {
  public:
-  JointOptGpuT() : num_hc_residuals_(0), mode_(HITL_MODE_ODOM_HC), stf_window_(80), solver_(NULL), map_poses_(0), stf_moments_(false) {
+  JointOptGpuT() : num_hc_residuals_(0), mode_(HITL_MODE_ODOM_HC), stf_window_(3), solver_(NULL), map_poses_(0), map_print_(0), stf_moments_(false) {
     std::memset(&summary_, 0, sizeof(summary_));
   }
   virtual ~JointOptGpuT() { if (solver_) hitl_solver_destroy(solver_); }
@@ -39,7 +47,11 @@ class JointOptGpuT {
   std::vector<Mat3f> covariances_;
   std::vector<std::vector<HumanConstraint> > human_constraints_;
   std::vector<double> gradients_;
+  CRSMatrix ceres_jacobian_;          // filled with gradients_ when want_gradients and the mode has scan-to-scan factors
   int num_hc_residuals_;
+  // JointOptimization.cpp:342-344 returns ceres_cost_, which nothing ever fills (its code at :836-838 is commented out):
+  // an empty vector, as in the reference
+  std::vector<float> GetCeresCost() { return ceres_cost_; }
 
   // Reference semantics: exit(1) on solver FAILURE (JointOptimization.cpp:1339-1342),
   // NO_CONVERGENCE accepted (:1343-1349).
@@ -48,14 +60,17 @@ class JointOptGpuT {
     if (st == HITL_ERR_SOLVER_FAILURE) { std::printf("\nCeres failure\n\n"); std::exit(1); }
     if (st != HITL_OK) { std::fprintf(stderr, "hitl-gpu: %s (%s)\n", hitl_status_string(st), hitl_last_error()); std::exit(1); }
   }
-  void ClearPoses() { poses_.clear(); robot_frame_point_clouds_.clear(); robot_frame_normal_clouds_.clear(); covariances_.clear(); map_poses_ = 0; }
+  void ClearPoses() { poses_.clear(); robot_frame_point_clouds_.clear(); robot_frame_normal_clouds_.clear(); covariances_.clear(); map_poses_ = 0; map_print_ = 0; }
   std::vector<Mat3f> GetPoseCovariances() { return covariances_; }
 
   // ---- extensions ------------------------------------------------------------------------
   // mode: HITL_MODE_ODOM_HC is what the shipped binary runs (SolveHumanConstraints, :1335);
   // HITL_MODE_JOINT adds the scan-to-scan factors of the commented-out PostHumanOptimization
-  // (:1353-1373), matched within +-stf_window poses (kMaxHistory-style window, default 80).
-  void SetMode(int mode, int64_t stf_window = 80) { mode_ = mode; stf_window_ = stf_window; }
+  // (:1353-1373), matched within +-stf_window poses.  Default 3: within hitl_options.max_band_poses (4) every pair stays
+  // in the block band, the linear solve is the exact cyclic reduction and pose_covariances works.  A wider window (the
+  // legacy kMaxHistory = 80, or 0 = all pairs like FindSTFCorrespondences) is allowed but takes the off-band PCG path
+  // (3 host synchronisations per CG iteration) and a candidate table of n * 2*window * max_scan * 2 bytes.
+  void SetMode(int mode, int64_t stf_window = 3) { mode_ = mode; stf_window_ = stf_window; }
   const hitl_summary& Summary() const { return summary_; }
   bool want_gradients = false;     // fill gradients_ like problem.Evaluate at :1247-1252
 
@@ -78,7 +93,21 @@ class JointOptGpuT {
     if (!Solver()) return create_status_;
     const size_t n = poses_.size();
     if (n == 0 || robot_frame_point_clouds_.size() != n || robot_frame_normal_clouds_.size() != n) return HITL_ERR_INVALID_ARGUMENT;
-    if (map_poses_ != n) {   // == BuildKDTrees on the first call (:1307): the scans never change afterwards
+    // == BuildKDTrees on the first call (:1307).  The scans normally never change afterwards; a different map (other
+    // pose count, other scan sizes, or other coordinates in a sample of every scan) is uploaded again.
+    unsigned long long print = 1469598103934665603ull;
+    for (size_t i = 0; i < n; ++i) {
+      const size_t m = robot_frame_point_clouds_[i].size();
+      print = (print ^ (unsigned long long)m) * 1099511628211ull;
+      if (m) {
+        const float probe[4] = {robot_frame_point_clouds_[i][0].x(), robot_frame_point_clouds_[i][0].y(),
+                                robot_frame_point_clouds_[i][m - 1].x(), robot_frame_point_clouds_[i][m / 2].y()};
+        unsigned int bits[4];
+        std::memcpy(bits, probe, sizeof(bits));
+        for (int k = 0; k < 4; ++k) print = (print ^ bits[k]) * 1099511628211ull;
+      }
+    }
+    if (map_poses_ != n || map_print_ != print) {
       std::vector<int64_t> off(n + 1, 0);
       for (size_t i = 0; i < n; ++i) off[i + 1] = off[i] + (int64_t)robot_frame_point_clouds_[i].size();
       std::vector<float> px(off[n]), py(off[n]), nx(off[n]), ny(off[n]), cov(9 * n, 0.f);
@@ -93,6 +122,7 @@ class JointOptGpuT {
       const int st = hitl_solver_set_map(solver_, (int64_t)n, off.data(), px.data(), py.data(), nx.data(), ny.data(), cov.data());
       if (st != HITL_OK) return st;
       map_poses_ = n;
+      map_print_ = print;
     }
     static_assert(sizeof(HumanConstraint) == sizeof(hitl_human_constraint_t), "HumanConstraint layout (human_constraints.h:29-41)");
     std::vector<hitl_human_constraint_t> rows;
@@ -122,6 +152,18 @@ class JointOptGpuT {
       double cost = 0.0;
       st = hitl_solver_evaluate(solver_, mode_, xyt.data(), &cost, gradients_.data());
       if (st != HITL_OK) return st;
+      if (mode_ != HITL_MODE_ODOM_HC) {   // ceres_jacobian_ of PostHumanOptimization's Problem::Evaluate (:1247-1252)
+        int64_t P = 0, Cn = 0;
+        st = hitl_solver_get_correspondence_counts(solver_, &P, &Cn);
+        if (st != HITL_OK) return st;
+        ceres_jacobian_.num_rows = (int)(2 * P); ceres_jacobian_.num_cols = (int)(3 * n);
+        ceres_jacobian_.rows.assign(2 * P + 1, 0); ceres_jacobian_.cols.assign(12 * P, 0); ceres_jacobian_.values.assign(12 * P, 0.0);
+        std::vector<int32_t> rows(2 * P + 1), cols(12 * P);
+        st = hitl_solver_evaluate_jacobian(solver_, xyt.data(), &cost, NULL, rows.data(), cols.data(), ceres_jacobian_.values.data());
+        if (st != HITL_OK) return st;
+        for (size_t k = 0; k < rows.size(); ++k) ceres_jacobian_.rows[k] = rows[k];
+        for (size_t k = 0; k < cols.size(); ++k) ceres_jacobian_.cols[k] = cols[k];
+      }
     }
     return HITL_OK;
   }
@@ -131,7 +173,9 @@ class JointOptGpuT {
   int64_t stf_window_;
   hitl_solver* solver_;
   size_t map_poses_;
+  unsigned long long map_print_;
   bool stf_moments_;
+  std::vector<float> ceres_cost_;
   int create_status_ = HITL_OK;
   hitl_summary summary_;
 };

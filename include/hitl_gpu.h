@@ -201,6 +201,17 @@ int hitl_solver_solve(hitl_solver*, int32_t mode, const float* poses_in_xyt,
 int hitl_solver_evaluate(hitl_solver*, int32_t mode, const float* poses_xyt,
                          double* cost, double* gradient);
 
+/* Replaces: problem.Evaluate(evalOptions, NULL, &residuals, &gradients_, &ceres_jacobian_) at the end of
+ * PostHumanOptimization (JointOptimization.cpp:1247-1252): the scan-to-scan problem's residual vector and its Jacobian
+ * as a ceres::CRSMatrix (members JointOptimization.h:79-86).  Rows: 2 per directed pose pair, in the order of the
+ * correspondence set as the caller installed / would read it back (hitl_solver_get_correspondences).  Columns: 3 per
+ * pose (x, y, theta), all n_poses poses -- the columns of the constant pose 0 are present and hold the block's
+ * partials (Ceres drops constant blocks from its column space; shift by 3 to compare).  Every row has 6 entries, column
+ * indices ascending.  Sizes: residuals 2P, crs_rows 2P + 1, crs_cols / crs_values 12P, P = number of pairs
+ * (hitl_solver_get_correspondence_counts); any output may be NULL.  Single-GPU entry point. */
+int hitl_solver_evaluate_jacobian(hitl_solver*, const float* poses_xyt, double* cost, double* residuals,
+                                  int32_t* crs_rows, int32_t* crs_cols, double* crs_values);
+
 /* ---- the O(N*M) observation scans either side of the solve ----------
  * They run over the resident scans with the robot->world transform fused in, so the
  * WORLD_FRAME_point_clouds_ copies of the reference never have to exist.  fp32 like the

@@ -47,7 +47,9 @@ int main(int argc, char** argv) {
   std::vector<float> xyt(3 * n);
   for (int64_t i = 0; i < n; ++i) { xyt[3 * i] = jo.poses_[i].translation.x(); xyt[3 * i + 1] = jo.poses_[i].translation.y(); xyt[3 * i + 2] = jo.poses_[i].angle; }
   if (hitl_io_save_results(argv[4], n, xyt.data()) != HITL_OK) return 67;
-  std::printf("iterations %d num_hc_residuals %d final_cost %.17g gradients %zu\n", jo.Summary().iterations, jo.num_hc_residuals_, jo.Summary().final_cost, jo.gradients_.size());
+  std::printf("iterations %d num_hc_residuals %d final_cost %.17g gradients %zu jacobian_rows %d jacobian_cols %d nnz %zu ceres_cost %zu\n",
+              jo.Summary().iterations, jo.num_hc_residuals_, jo.Summary().final_cost, jo.gradients_.size(), jo.ceres_jacobian_.num_rows,
+              jo.ceres_jacobian_.num_cols, jo.ceres_jacobian_.values.size(), jo.GetCeresCost().size());
   hitl_posegraph_free(g);
   return 0;
 }

@@ -45,15 +45,8 @@ def _check(solver, z, lin_rtol, matcher):
         ec = z["solve_cost_%d" % mode]
         assert abs(summ.initial_cost - ec[0]) <= 1e-9 * ec[0]
         assert [summ.num_residuals, summ.num_hc_residuals] == exp.tolist()[3:]
-        if mode == abi.MODE_STF_ONLY:
-            # The dormant STF-only solve (JointOptimization.cpp:1156-1256) has rank-<=2
-            # Gauss-Newton blocks and no odometry: ~100 LM iterations whose accept/reject
-            # sequence amplifies last-bit differences.  Long-run parity is therefore asserted
-            # on the cost level and a looser pose bar; the lock-step check is in
-            # tests/test_gpu_parity.py::test_stf_only_short_horizon_lockstep.
-            assert abs(summ.final_cost - ec[1]) <= 2e-3 * ec[1]
-            assert np.abs(poses - z["solve_poses_%d" % mode]).max() <= 1e-2
-            continue
+        # (mode B, the dormant STF-only solve of JointOptimization.cpp:1156-1256, is held to the same bar as A and C: the
+        # whole 100-iteration run reproduces the fixture's accept/reject sequence)
         assert [summ.termination, summ.iterations, summ.successful_steps] == exp.tolist()[:3]
         assert abs(summ.final_cost - ec[1]) <= 1e-7 * ec[1]
         assert np.abs(poses[:, :2] - z["solve_poses_%d" % mode][:, :2]).max() <= POSE_TOL_M

@@ -12,14 +12,14 @@ POSE_TOL_M = 1e-4     # north_star tolerance, metres
 POSE_TOL_RAD = 1e-4   # north_star tolerance, radians
 
 
-def _gpu():
+def _gpu(opt=None):
     import hitl_slam_amd as H
-    return H.Solver()
+    return H.Solver(opt) if opt is not None else H.Solver()
 
 
-def _oracle():
+def _oracle(opt=None):
     from oracle import hitl_oracle as O
-    return O.OracleSolver()
+    return O.OracleSolver(opt) if opt is not None else O.OracleSolver()
 
 
 def _relerr(a, b):
@@ -96,15 +96,77 @@ def test_stf_only_short_horizon_lockstep(small_problem):
     assert np.abs(pg - po).max() <= 1e-5
 
 
-def test_stf_only_full_run_reaches_the_same_cost_level(small_problem):
+def test_stf_only_full_run_on_a_connected_map(small_problem):
+    """PostHumanOptimization as written (JointOptimization.cpp:1156-1256: scan-to-scan factors only, pose 0 constant, 100
+    iterations).  On a map whose scan-overlap graph is connected the problem has full rank (checked on the oracle's dense
+    J^T J) and the whole 100-iteration run is held to the bar: same termination, same iteration and accepted-step counts,
+    final cost to 1e-8, poses to 1e-4 m / 1e-4 rad."""
     import hitl_slam_amd as H
-    prob = small_problem
+    prob = Problem(60, 90, ppf=60)          # one floor: every scan overlaps its neighbours
     corr = oracle_corr(prob)
     g, o = prob.load(_gpu(), corr=corr), prob.load(_oracle(), corr=corr)
     pg, sg = g.solve(H.MODE_STF_ONLY, prob.init)
     po, so = o.solve(H.MODE_STF_ONLY, prob.init)
-    assert abs(sg.final_cost - so.final_cost) <= 2e-3 * so.final_cost
-    assert np.abs(pg - po).max() <= 1e-2
+    Hd, _, _ = o.assemble_dense(H.MODE_STF_ONLY, prob.init, po.astype(np.float64))
+    ev = np.linalg.eigvalsh(Hd[3:, 3:])
+    assert (ev < 1e-9 * ev[-1]).sum() == 0                       # full rank once pose 0 is held
+    print("\nmode B, connected map: gpu iters=%d ok=%d cost=%.12g | oracle iters=%d ok=%d cost=%.12g | max|d|=%.3g" %
+          (sg.iterations, sg.successful_steps, sg.final_cost, so.iterations, so.successful_steps, so.final_cost, np.abs(pg - po).max()))
+    assert sg.termination == so.termination
+    assert (sg.iterations, sg.successful_steps) == (so.iterations, so.successful_steps)
+    assert abs(sg.final_cost - so.final_cost) <= 1e-8 * so.final_cost
+    assert np.abs(pg[:, :2] - po[:, :2]).max() <= POSE_TOL_M and np.abs(pg[:, 2] - po[:, 2]).max() <= POSE_TOL_RAD
+
+
+def test_stf_only_two_floors_is_rank_deficient_and_agrees_in_the_quotient(small_problem):
+    """The two floors of the default synthetic map share no scan overlap; mode B drops the odometry edge that joins them
+    (JointOptimization.cpp:1174-1177), so the second floor is a free rigid body: J^T J has a 3-dimensional null space
+    beyond the constant pose 0 (shown on the oracle's dense Hessian).  Poses of the component that holds pose 0 are
+    compared directly, poses of the free component relative to its first pose (the quotient by the rigid motion)."""
+    import hitl_slam_amd as H
+    prob = small_problem                     # 60 poses, 30 per floor
+    corr = oracle_corr(prob)
+    g, o = prob.load(_gpu(), corr=corr), prob.load(_oracle(), corr=corr)
+    pg, sg = g.solve(H.MODE_STF_ONLY, prob.init)
+    po, so = o.solve(H.MODE_STF_ONLY, prob.init)
+    Hd, _, _ = o.assemble_dense(H.MODE_STF_ONLY, prob.init, po.astype(np.float64))
+    ev = np.linalg.eigvalsh(Hd[3:, 3:])
+    assert (np.abs(ev) < 1e-9 * ev[-1]).sum() == 3
+
+    def rel(p, first):                       # poses of a component in the frame of its first pose
+        c, s_ = np.cos(p[first, 2]), np.sin(p[first, 2])
+        d = p[first:, :2].astype(np.float64) - p[first, :2]
+        return np.stack([c * d[:, 0] + s_ * d[:, 1], -s_ * d[:, 0] + c * d[:, 1], np.angle(np.exp(1j * (p[first:, 2] - p[first, 2])))], 1)
+    print("\nmode B, two floors: gpu iters=%d cost=%.12g | oracle iters=%d cost=%.12g | floor 1 max|d|=%.3g, floor 2 (quotient) max|d|=%.3g, floor 2 raw max|d|=%.3g"
+          % (sg.iterations, sg.final_cost, so.iterations, so.final_cost, np.abs(pg[:30] - po[:30]).max(),
+             np.abs(rel(pg, 30) - rel(po, 30)).max(), np.abs(pg[30:] - po[30:]).max()))
+    assert sg.termination == so.termination and (sg.iterations, sg.successful_steps) == (so.iterations, so.successful_steps)
+    assert abs(sg.final_cost - so.final_cost) <= 1e-8 * so.final_cost
+    assert np.abs(pg[:30] - po[:30]).max() <= POSE_TOL_M
+    assert np.abs(rel(pg, 30) - rel(po, 30)).max() <= POSE_TOL_M
+
+
+@pytest.mark.parametrize("mode", [2, 1])
+def test_solve_on_the_kd_walk_correspondence_set(mode):
+    """The reference's own correspondence sets come from the pruned KD-tree walk (perception_tools/kdtree.cpp:141-197),
+    which the oracle restates as method 1.  Installed through hitl_solver_set_correspondences, the GPU solve on THAT set
+    is held to the same bar against the oracle's solve on it (the matcher itself is compared with the brute-force
+    definition, method 0, elsewhere; DESIGN.md records how far the two sets move the converged poses)."""
+    import hitl_slam_amd as H
+    prob = Problem(120, 128, ppf=120, groups=2)
+    kd = oracle_corr(prob, method=1)
+    bf = oracle_corr(prob, method=0)
+    same = sum(int(np.array_equal(a, b)) for a, b in zip(kd, bf))
+    assert same < 5                                               # the two sets really differ on this map
+    opt = H.default_options()
+    if mode == 1:
+        opt.max_num_iterations = 12                               # lock-step horizon of the dormant mode (see above)
+    g, o = prob.load(_gpu(opt), corr=kd), prob.load(_oracle(opt), corr=kd)
+    pg, sg = g.solve(mode, prob.init)
+    po, so = o.solve(mode, prob.init)
+    assert sg.termination == so.termination and (sg.iterations, sg.successful_steps) == (so.iterations, so.successful_steps)
+    assert abs(sg.final_cost - so.final_cost) <= 1e-8 * so.final_cost
+    assert np.abs(pg[:, :2] - po[:, :2]).max() <= POSE_TOL_M and np.abs(pg[:, 2] - po[:, 2]).max() <= POSE_TOL_RAD
 
 
 def test_solve_with_offband_pairs_uses_pcg(small_problem):
@@ -234,3 +296,39 @@ def test_timing_levels_do_not_change_results(small_problem):
     assert res[0][3] == 0 and res[0][5] == 0.0 and res[0][6] == 0.0
     assert 0 < res[1][3] <= (res[1][4] + 3) // 4 + 1 and res[1][5] == 0.0 and res[1][6] > 0.0
     assert res[2][3] == res[2][4] and res[2][5] > 0.0
+
+
+def test_evaluate_jacobian_is_the_crs_form_of_the_pair_jacobians(small_problem):
+    """hitl_solver_evaluate_jacobian == Problem::Evaluate(..., &residuals, &gradients_, &ceres_jacobian_) of the scan-to-scan
+    problem (JointOptimization.cpp:1247-1252): against the oracle's per-pair blocks, and J^T r == the gradient."""
+    import hitl_slam_amd as H
+    from oracle import hitl_oracle as O
+    prob = small_problem
+    corr = oracle_corr(prob)
+    g = prob.load(H.Solver(), corr=corr)
+    o = prob.load(O.OracleSolver(), corr=corr)
+    rng = np.random.default_rng(3)
+    poses = (prob.init + 0.01 * rng.standard_normal(prob.init.shape)).astype(np.float32)
+    cost, res, (indptr, indices, data) = g.evaluate_jacobian(poses)
+    co, go, ro, jo = o.linearize(H.MODE_STF_ONLY, poses, poses.astype(np.float64))
+    P = len(corr[0])
+    assert indptr[-1] == 12 * P and np.array_equal(np.diff(indptr), np.full(2 * P, 6))
+    assert abs(cost - co) <= 1e-10 * co and np.abs(res - ro.reshape(-1)).max() <= 1e-10 * np.abs(ro).max()
+    n3 = 3 * prob.n
+    grad = np.zeros(n3)
+    for p in range(P):
+        a, b = int(corr[0][p]), int(corr[1][p])
+        for r in range(2):
+            row = 2 * p + r
+            cols, vals = indices[indptr[row]:indptr[row + 1]], data[indptr[row]:indptr[row + 1]]
+            assert np.all(np.diff(cols) > 0)                                       # CRS: ascending columns
+            want = np.zeros(n3)
+            want[3 * a:3 * a + 3] = jo[p, r, :3]
+            want[3 * b:3 * b + 3] = jo[p, r, 3:]
+            got = np.zeros(n3)
+            got[cols] = vals
+            assert np.abs(got - want).max() <= 1e-9 * max(np.abs(want).max(), 1e-30)
+            grad[cols] += vals * res[row]
+    grad[:3] = 0.0                                                                 # pose 0 is constant
+    assert np.abs(grad - go).max() <= 1e-9 * np.abs(go).max()
+    g.close(); o.close()

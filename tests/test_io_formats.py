@@ -194,3 +194,18 @@ def test_input_log_truncated_and_garbage(tmp_path):
     p.write_text("x\n")
     with pytest.raises(Exception):
         HIO.load_input_log(str(p))
+
+
+def test_posegraph_accessors_are_null_safe():
+    """Every hitl_posegraph_* accessor answers NULL / 0 for a NULL handle instead of dereferencing it."""
+    import ctypes as C
+    from hitl_slam_amd.api import load_library
+    L = load_library()
+    for name in ("poses", "cov9", "obs_offset", "px", "py", "nx", "ny"):
+        f = getattr(L, "hitl_posegraph_" + name)
+        f.restype = C.c_void_p
+        f.argtypes = [C.c_void_p]
+        assert f(None) is None
+    L.hitl_posegraph_num_poses.restype = C.c_int64
+    L.hitl_posegraph_num_poses.argtypes = [C.c_void_p]
+    assert L.hitl_posegraph_num_poses(None) == 0

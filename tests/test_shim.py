@@ -64,4 +64,8 @@ def test_shim_reproduces_the_oracle(driver, case, mode):
     po, so = o.solve(mode, g["poses"])
     fields = r.stdout.split()
     assert int(fields[1]) == so.iterations and int(fields[3]) == so.num_hc_residuals and int(fields[7]) == 3 * len(po)
+    # ceres_jacobian_ (JointOptimization.h:86): 2 rows per directed pair, 6 entries per row; GetCeresCost() is empty as in the reference
+    n_pairs = so.num_pairs if mode else 0
+    assert int(fields[9]) == 2 * n_pairs and int(fields[13]) == 12 * n_pairs and int(fields[15]) == 0
+    assert int(fields[11]) == (3 * len(po) if mode else 0)
     assert np.abs(got - po).max() <= 1e-4 + 1e-6      # results file prints "%f"
