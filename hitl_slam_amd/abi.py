@@ -89,7 +89,8 @@ class Options(C.Structure):
         ("rccl_unique_id", C.c_void_p),
         ("stf_moments", C.c_int64),
         ("timing_level", C.c_int64),
-        ("reserved", C.c_int64 * 2),
+        ("kd_tree_search", C.c_int64),
+        ("reserved", C.c_int64 * 1),
     ]
 
 

@@ -45,6 +45,9 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
   const int n = s->n;
   if (window <= 0 || window > n) window = n;
   const int slots = (int)std::min<int64_t>(2 * window, std::max(n - 1, 1));
+  const bool kd = s->opt.kd_tree_search != 0;
+  if (kd && (match_kd_lds_bytes(s->max_scan) > (size_t)150 * 1024 || kd_build_lds_bytes(s->max_scan) > (size_t)150 * 1024))
+    return fail(HITL_ERR_UNSUPPORTED, "find_correspondences (kd_tree_search): a scan of " + std::to_string(s->max_scan) + " points exceeds the LDS budget of the tree kernels (limit ~4000 points)");
   if (match_lds_bytes(s->max_scan) > (size_t)160 * 1024)
     return fail(HITL_ERR_UNSUPPORTED, "find_correspondences: a scan of " + std::to_string(s->max_scan) +
                 " points does not fit the 160 KB of LDS the matcher stages a target scan in (limit ~7900 points)");
@@ -102,7 +105,18 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
   mp.cap = s->opt.max_correspondences_per_point;
   mp.skip = std::max(s->opt.num_skip_readings, 1);
   const MapView mv = s->map_view();
-  launch_match(st, mv, s->max_scan, slots, d_tgt.p, d_tf.p, mp, d_table.p, d_counts.p);
+  if (kd) {
+    if (!s->kd_built) {      // BuildKDTrees: once per map (JointOptimization.cpp:1307, kdtrees_.size() == 0)
+      TRYC(s->kd_pts.resize((size_t)std::max<int64_t>(s->n_obs, 1)));
+      TRYC(s->kd_meta.resize((size_t)std::max<int64_t>(s->n_obs, 1)));
+      launch_kd_build(st, mv, s->max_scan, s->kd_pts.p, s->kd_meta.p);
+      s->kd_built = true;
+      mark("k_kd_build");
+    }
+    launch_match_kd(st, mv, s->max_scan, slots, d_tgt.p, d_tf.p, mp, s->kd_pts.p, s->kd_meta.p, d_table.p, d_counts.p);
+  } else {
+    launch_match(st, mv, s->max_scan, slots, d_tgt.p, d_tf.p, mp, d_table.p, d_counts.p);
+  }
   if (hipGetLastError() != hipSuccess) { cleanup(); return fail(HITL_ERR_HIP, "find_correspondences: the match kernel could not be launched"); }
   std::vector<int> counts((size_t)n * slots);
   if (hipMemcpyAsync(counts.data(), d_counts.p, counts.size() * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||

@@ -106,6 +106,270 @@ __global__ __launch_bounds__(kMatchBlock) void k_match(MapView map, int chunk, i
   }
 }
 
+// ===========================================================================================
+// kd_tree_search (hitl_options): the reference's OWN search.  BuildKDTrees (JointOptimization.cpp:514-537) builds one
+// median-split tree per scan (KDTree::BuildKDTree, kdtree.cpp:106-139: split plane of larger variance, kdtree.cpp:37-69;
+// std::sort by that coordinate -- ties taken in their incoming order, i.e. the stable outcome; node = element n/2) and
+// FindNearestPointNormal (kdtree.cpp:141-197) walks it, pruning sub-trees with the PLANE distance.  On flat walls many
+// target points score almost equally, so which one the pruned walk returns depends on the tree: its index sets differ
+// from the brute-force definition on a large share of the matches.  Both pieces are reproduced here bit for
+// bit (fp32, no FMA contraction, the same order of every sum), so that with this option the index sets are the
+// reference's own.
+//
+// Tree layout: the scan's points in the order the recursive sorts leave them ("in-order"): the node of segment [lo, lo+n)
+// sits at lo + n/2, its children are the nodes of [lo, lo + n/2) and [lo + n/2 + 1, lo + n).  No pointers.
+// ===========================================================================================
+constexpr int kKdBlock = 256;
+
+// one workgroup per scan; level by level: split plane per live segment (one thread walks the segment: the fp32 sums of
+// kdtree.cpp:40-58 are order-dependent), stable rank sort inside every segment, the median becomes a node.
+__global__ __launch_bounds__(kKdBlock) void k_kd_build(MapView map, int max_scan, float4* __restrict__ kd_pts, uint32_t* __restrict__ kd_meta) {
+  extern __shared__ float s_raw[];
+  float* ax = s_raw;                       // current order
+  float* ay = ax + max_scan;
+  int* aid = (int*)(ay + max_scan);
+  float* bx = (float*)(aid + max_scan);    // next order
+  float* by = bx + max_scan;
+  int* bid = (int*)(by + max_scan);
+  int* seg_lo = bid + max_scan;            // segment of the element at this position (n == 0: already a node)
+  int* seg_n = seg_lo + max_scan;
+  int* s_plane = seg_n + max_scan;         // split plane of the live segment that starts at this position
+  int* s_split = s_plane + max_scan;       // split plane of the node sitting at this position
+  __shared__ int s_live;
+  const int i = blockIdx.x;
+  const int64_t o = map.obs_off[i];
+  const int m = (int)(map.obs_off[i + 1] - o);
+  if (m <= 0) return;
+  for (int p = threadIdx.x; p < m; p += kKdBlock) {
+    const float4 v = map.obs[o + p];
+    ax[p] = v.x; ay[p] = v.y; aid[p] = p; seg_lo[p] = 0; seg_n[p] = m; s_plane[p] = 0; s_split[p] = 0;
+  }
+  __syncthreads();
+  for (;;) {
+    if (threadIdx.x == 0) s_live = 0;
+    __syncthreads();
+    // 1. split plane of every live segment (its first position does the sequential sums)
+    for (int p = threadIdx.x; p < m; p += kKdBlock) {
+      const int n = seg_n[p];
+      if (n > 0 && seg_lo[p] == p) {
+        float mx = 0.0f, my = 0.0f;
+        for (int q = p; q < p + n; ++q) { mx = mx + ax[q]; my = my + ay[q]; }
+        mx = mx / (float)n; my = my / (float)n;
+        float sx = 0.0f, sy = 0.0f;
+        for (int q = p; q < p + n; ++q) {
+          sx = sx + (ax[q] - mx) * (ax[q] - mx);
+          sy = sy + (ay[q] - my) * (ay[q] - my);
+        }
+        int plane = 0;
+        float best = 0.0f;
+        if (sx > best) { plane = 0; best = sx; }
+        if (sy > best) { plane = 1; best = sy; }
+        s_plane[p] = plane;
+        s_live = 1;
+      }
+    }
+    __syncthreads();
+    if (!s_live) break;
+    // 2. stable sort of every live segment by its split coordinate: new position = lo + #{smaller, or equal and earlier}
+    for (int p = threadIdx.x; p < m; p += kKdBlock) {
+      const int n = seg_n[p];
+      int dst = p;
+      if (n > 0) {
+        const int lo = seg_lo[p];
+        const int plane = s_plane[lo];
+        const float key = plane ? ay[p] : ax[p];
+        int rank = 0;
+        for (int q = lo; q < lo + n; ++q) {
+          const float kq = plane ? ay[q] : ax[q];
+          rank += (kq < key || (kq == key && q < p)) ? 1 : 0;
+        }
+        dst = lo + rank;
+      }
+      bx[dst] = ax[p]; by[dst] = ay[p]; bid[dst] = aid[p];
+    }
+    __syncthreads();
+    // 3. the median of a segment becomes its node; the two halves are the next level's segments
+    for (int p = threadIdx.x; p < m; p += kKdBlock) {
+      const int n = seg_n[p];
+      ax[p] = bx[p]; ay[p] = by[p]; aid[p] = bid[p];
+      if (n > 0) {
+        const int lo = seg_lo[p], ind = n / 2;
+        if (p == lo + ind) { s_split[p] = s_plane[lo]; seg_n[p] = 0; }
+        else if (p < lo + ind) { seg_n[p] = ind; }
+        else { seg_lo[p] = lo + ind + 1; seg_n[p] = n - ind - 1; }
+      }
+    }
+    __syncthreads();
+  }
+  for (int p = threadIdx.x; p < m; p += kKdBlock) {
+    kd_pts[o + p] = map.obs[o + aid[p]];
+    kd_meta[o + p] = (uint32_t)aid[p] | ((uint32_t)s_split[p] << 16);
+  }
+}
+
+size_t kd_build_lds_bytes(int max_scan) { return (size_t)max_scan * 10 * sizeof(float); }
+
+void launch_kd_build(hipStream_t st, const MapView& map, int max_scan, float4* kd_pts, uint32_t* kd_meta) {
+  const size_t lds = kd_build_lds_bytes(max_scan);
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kd_build), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k_kd_build, dim3(map.n_poses), dim3(kKdBlock), lds, st, map, max_scan, kd_pts, kd_meta);
+}
+
+// KDTree::FindNearestPointNormal (kdtree.cpp:141-197) on the in-order layout, recursion unrolled onto an explicit stack
+// in LDS (frame = segment, stage, running best, position of the running winner, plane distance).  Returns the point-to-
+// plane distance of the winner (FLT_MAX when nothing inside the gate was visited) and its tree position.
+__device__ __forceinline__ float kd_find_nearest_point_normal(const float4* __restrict__ pts, const uint32_t* __restrict__ meta, int m,
+                                                              float qx, float qy, float thr, uint32_t* st_seg, float* st_best,
+                                                              uint32_t* st_out, float* st_pd, int stride, int* out_pos) {
+  constexpr float kFltMax = 3.402823466e+38f, kFltMin = 1.175494351e-38f;
+  int sp = 1;
+  st_seg[0] = (uint32_t)m << 16;            // lo = 0, n = m
+  st_out[0] = 0;                            // stage 0
+  float ret_d = kFltMax;
+  int ret_c = -1;
+  while (sp > 0) {
+    const int f = (sp - 1) * stride;
+    const uint32_t seg = st_seg[f];
+    const int lo = (int)(seg & 0xffffu), n = (int)(seg >> 16), ind = n / 2, pos = lo + ind;
+    const uint32_t os = st_out[f];
+    int stage = (int)(os >> 28);
+    int out = (int)(os & 0x0fffffffu) - 1;  // -1 = none
+    float best = st_best[f], pd = st_pd[f];
+    bool went_left = false, other_left = false, have_other = false;
+    if (stage == 0) {
+      const float4 g = pts[pos];
+      const float dx = g.x - qx, dy = g.y - qy;
+      best = kFltMax; out = -1;
+      if (dx * dx + dy * dy < thr * thr) {
+        out = pos;
+        best = fabsf(g.z * (qx - g.x) + g.w * (qy - g.y));
+        if (best < kFltMin) { ret_d = 0.0f; ret_c = pos; --sp; continue; }
+      }
+      const int split = (int)(meta[pos] >> 16);
+      pd = (split ? qy : qx) - (split ? g.y : g.x);
+      if (pd <= 0.0f && ind > 0) {            // search the left sub-tree first
+        st_best[f] = best; st_pd[f] = pd; st_out[f] = (1u << 28) | (uint32_t)(out + 1);
+        const int c = sp * stride;
+        st_seg[c] = (uint32_t)lo | ((uint32_t)ind << 16); st_out[c] = 0;
+        ++sp;
+        continue;
+      }
+      stage = 2;
+    } else if (stage == 1) {                  // back from the left sub-tree
+      if (ret_d < best) { best = ret_d; out = ret_c; }
+      went_left = true;
+      stage = 2;
+    }
+    if (stage == 2) {
+      if (pd >= 0.0f && ind < n - 1) {        // the right sub-tree
+        st_best[f] = best; st_pd[f] = pd; st_out[f] = (3u << 28) | (uint32_t)(out + 1);
+        const int c = sp * stride;
+        st_seg[c] = (uint32_t)(lo + ind + 1) | ((uint32_t)(n - ind - 1) << 16); st_out[c] = 0;
+        ++sp;
+        continue;
+      }
+      have_other = went_left && (ind < n - 1);   // `other = nd->right` was set in the left branch (NULL without a right child)
+      other_left = false;
+      stage = 4;
+    } else if (stage == 3) {                  // back from the right sub-tree
+      if (ret_d < best) { best = ret_d; out = ret_c; }
+      have_other = ind > 0;                   // `other = nd->left`
+      other_left = true;
+      stage = 4;
+    }
+    if (stage == 4) {
+      if (have_other && pd != 0.0f && fabsf(pd) < ((best < thr) ? best : thr)) {   // the other side of the split plane may hold a closer point
+        st_best[f] = best; st_pd[f] = pd; st_out[f] = (5u << 28) | (uint32_t)(out + 1);
+        const int c = sp * stride;
+        st_seg[c] = other_left ? ((uint32_t)lo | ((uint32_t)ind << 16)) : ((uint32_t)(lo + ind + 1) | ((uint32_t)(n - ind - 1) << 16));
+        st_out[c] = 0;
+        ++sp;
+        continue;
+      }
+    } else if (stage == 5) {                  // back from the other side
+      if (ret_d < best) { best = ret_d; out = ret_c; }
+    }
+    ret_d = best; ret_c = out;
+    --sp;
+  }
+  *out_pos = ret_c;
+  return ret_d;
+}
+
+__global__ __launch_bounds__(kMatchBlock) void k_match_kd(MapView map, int chunk, int max_scan, int slots, int depth,
+                                                           const int* __restrict__ cand_tgt, const float* __restrict__ cand_tf, MatchParams mp,
+                                                           const float4* __restrict__ kd_pts, const uint32_t* __restrict__ kd_meta,
+                                                           uint16_t* __restrict__ table, int* __restrict__ counts) {
+  extern __shared__ float4 s_tgt[];                 // [max_scan] target tree points (in-order layout)
+  uint32_t* s_meta = (uint32_t*)(s_tgt + max_scan); // [max_scan] original index | split << 16
+  int* s_cnt = (int*)(s_meta + max_scan);           // [max_scan] accepted matches per source point
+  uint32_t* st_seg = (uint32_t*)(s_cnt + max_scan); // [depth][kMatchBlock] each
+  float* st_best = (float*)(st_seg + (size_t)depth * kMatchBlock);
+  uint32_t* st_out = (uint32_t*)(st_best + (size_t)depth * kMatchBlock);
+  float* st_pd = (float*)(st_out + (size_t)depth * kMatchBlock);
+  __shared__ int s_pair_count;
+  const int b = blockIdx.x;
+  const int idx = b >> 3;
+  const int i = (b & 7) * chunk + idx;
+  if (idx >= chunk || i >= map.n_poses) return;
+  const int64_t oi = map.obs_off[i];
+  const int mi = (int)(map.obs_off[i + 1] - oi);
+  for (int k = threadIdx.x; k < mi; k += kMatchBlock) s_cnt[k] = 0;
+  const float thr = mp.thr;
+  for (int slot = 0; slot < slots; ++slot) {
+    const int j = cand_tgt[(size_t)i * slots + slot];
+    if (j < 0) continue;                            // block-uniform
+    const int64_t oj = map.obs_off[j];
+    const int mj = (int)(map.obs_off[j + 1] - oj);
+    __syncthreads();
+    if (threadIdx.x == 0) s_pair_count = 0;
+    for (int t = threadIdx.x; t < mj; t += kMatchBlock) { s_tgt[t] = kd_pts[oj + t]; s_meta[t] = kd_meta[oj + t]; }
+    __syncthreads();
+    const float* tf = cand_tf + ((size_t)i * slots + slot) * 8;
+    const float m00 = tf[0], m01 = tf[1], m10 = tf[2], m11 = tf[3], tx = tf[4], ty = tf[5], cr = tf[6], sr = tf[7];
+    uint16_t* row = table + ((size_t)i * slots + slot) * max_scan;
+    int local = 0;
+    for (int k = threadIdx.x; k < mi; k += kMatchBlock) {
+      uint16_t res = 0xFFFFu;
+      if ((k % mp.skip) == 0 && s_cnt[k] < mp.cap && mj > 0) {
+        const float4 a = map.obs[oi + k];
+        const float ax = a.x, ay = a.y;
+        const float qx = (m00 * ax + m01 * ay) + tx;
+        const float qy = (m10 * ax + m11 * ay) + ty;
+        int pos = -1;
+        const float dist = kd_find_nearest_point_normal(s_tgt, s_meta, mj, qx, qy, thr, st_seg + threadIdx.x, st_best + threadIdx.x,
+                                                        st_out + threadIdx.x, st_pd + threadIdx.x, kMatchBlock, &pos);
+        if (pos >= 0 && dist < thr) {
+          const float anx = a.z, any = a.w;
+          const float nqx = cr * anx - sr * any, nqy = sr * anx + cr * any;
+          const float4 g = s_tgt[pos];
+          const float cosang = g.z * nqx + g.w * nqy;
+          if (cosang > mp.min_cos) { res = (uint16_t)(s_meta[pos] & 0xffffu); s_cnt[k] += 1; ++local; }
+        }
+      }
+      row[k] = res;
+    }
+    if (local) atomicAdd(&s_pair_count, local);
+    __syncthreads();
+    if (threadIdx.x == 0) counts[(size_t)i * slots + slot] = s_pair_count;
+  }
+}
+
+static int kd_depth(int max_scan) { int d = 1; while ((1 << d) <= max_scan) ++d; return d + 1; }
+
+size_t match_kd_lds_bytes(int max_scan) {
+  return (size_t)max_scan * (sizeof(float4) + 2 * sizeof(int)) + (size_t)kd_depth(max_scan) * kMatchBlock * 16;
+}
+
+void launch_match_kd(hipStream_t st, const MapView& map, int max_scan, int slots, const int* cand_tgt, const float* cand_tf, MatchParams mp,
+                     const float4* kd_pts, const uint32_t* kd_meta, uint16_t* table, int* counts) {
+  const int chunk = (map.n_poses + 7) / 8;
+  const size_t lds = match_kd_lds_bytes(max_scan);
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_match_kd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k_match_kd, dim3(8 * chunk), dim3(kMatchBlock), lds, st, map, chunk, max_scan, slots, kd_depth(max_scan), cand_tgt, cand_tf,
+                     mp, kd_pts, kd_meta, table, counts);
+}
+
 size_t match_lds_bytes(int max_scan) {
   return (size_t)max_scan * sizeof(float4) + (size_t)((max_scan + 3) & ~3) * sizeof(int) +
          (size_t)((max_scan + kMatchGroup - 1) / kMatchGroup) * sizeof(float4);

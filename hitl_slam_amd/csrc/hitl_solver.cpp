@@ -447,7 +447,7 @@ void hitl_solver_destroy(hitl_solver* s) {
                            &s->ob_hi, &s->ob_fwd, &s->ob_rev, &s->obadj_off, &s->obadj_ent, &s->hc_off})
     v->release();
   s->d_cand_tgt.release(); s->d_cand_counts.release(); s->d_cand_kept.release(); s->d_cand_tf.release(); s->d_cand_table.release();
-  s->pairM.release();
+  s->pairM.release(); s->kd_pts.release(); s->kd_meta.release();
   s->matches.release(); s->odom_A.release(); s->hc_tgt.release(); s->odom_rr.release(); s->hc_type.release();
   if (s->nccl) (void)ncclCommDestroy(s->nccl);
   s->comm_send.release(); s->comm_recv.release(); s->fixed.release(); s->if_cols.release(); s->halo_idx.release();
@@ -556,7 +556,8 @@ int hitl_solver_set_map(hitl_solver* s, int64_t n_poses, const int64_t* obs_offs
   }
   if (cov9) TRY(s->cov9.upload(cov9, (size_t)n_poses * 9, st));   // carried like covariances_; no live factor reads it
   HIP_TRY(hipStreamSynchronize(st));
-  // a new map invalidates correspondences and human rows
+  // a new map invalidates correspondences, human rows and the KD-trees
+  s->kd_built = false;
   s->n_pairs = 0; s->n_matches = 0; s->pose_pair_off.n = 0;
   s->h_hc.clear();
   return ensure_empty_pair_tables(s);

@@ -72,6 +72,9 @@ struct hitl_solver {
   DevArray<int> d_cand_tgt, d_cand_counts, d_cand_kept;
   DevArray<float> d_cand_tf;
   DevArray<uint16_t> d_cand_table;
+  DevArray<float4> kd_pts;                     // opt-in (kd_tree_search): every scan in KD in-order layout
+  DevArray<uint32_t> kd_meta;                  //   original index | split plane << 16
+  bool kd_built = false;                       //   trees belong to the resident map
   DevArray<double> pairM;                      // opt-in (stf_moments): 2 x 15 moments per pair
   int64_t moments_of = -1;                     // correspondence-set generation the moments belong to
   int64_t corr_generation = 0;                 // bumped whenever the pair tables change

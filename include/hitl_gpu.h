@@ -117,7 +117,14 @@ typedef struct hitl_options {
    * 1 (default) = every 4th k_linearize_stf launch is bracketed (linearize_ms over linearize_timed_calls launches),
    * no linear-solver timing; 2 = every launch bracketed and linear_solver_ms filled. */
   int64_t timing_level;
-  int64_t reserved[2];
+  /* hitl_solver_find_correspondences: 0 (default) = the brute-force definition of FindNearestPointNormal (among the
+   * target points inside the Euclidean gate, the smallest point-to-plane distance, first index on ties); 1 = the
+   * reference's own per-scan KD-trees and pruned walk (BuildKDTrees, JointOptimization.cpp:514-537;
+   * perception_tools/kdtree.cpp:37-197) reproduced bit for bit -- std::sort's tie order taken as the stable one.  The
+   * walk prunes with the plane distance and therefore returns a different, tree-dependent winner wherever several
+   * target points score almost equally (flat walls): use 1 when the index sets must be the reference's. */
+  int64_t kd_tree_search;
+  int64_t reserved[1];
 } hitl_options;
 
 /* Per-solve report (what Ceres' Solver::Summary gives the caller at

@@ -95,6 +95,45 @@ def test_fullsize_solve_matches_oracle(big):
     assert dxy <= 1e-4 and dth <= 1e-4
 
 
+def test_fullsize_kd_tree_search_matches_the_reference_walk(big):
+    """The reference's own correspondence search (per-scan KD-trees + pruned walk, kdtree.cpp:37-197) at full size:
+    50 000 trees of 400 points, 120 M queries; index sets bit for bit against the oracle's restatement (method 1).  Also
+    records how far the converged poses move between the two definitions of a correspondence."""
+    import os
+    import time
+    import hitl_slam_amd as H
+    from oracle import hitl_oracle as O
+    opt = H.default_options()
+    opt.kd_tree_search = 1
+    g = H.Solver(opt)
+    g.set_map(*big["map"])
+    g.set_human_constraints(big["rows"])
+    t0 = time.time()
+    g.find_correspondences(big["init"], 3)
+    t_first = time.time() - t0
+    t0 = time.time()
+    g.find_correspondences(big["init"], 3)          # trees are kept: BuildKDTrees runs once per map
+    t_again = time.time() - t0
+    got = g.get_correspondences()
+    o = O.OracleSolver()
+    o.set_map(*big["map"])
+    O.set_num_threads(min(len(os.sched_getaffinity(0)), 16))
+    o.find_correspondences(big["init"], 3, 1)
+    want = o.get_correspondences()
+    o.close()
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+    bf = big["s"].get_correspondences()
+    pk, sk = g.solve(H.MODE_JOINT, big["init"])
+    pb, sb = big["s"].solve(H.MODE_JOINT, big["init"])
+    dxy, dth = _pose_diff(pk, pb)
+    same = int(np.array_equal(got[4], bf[4])) if len(got[4]) == len(bf[4]) else 0
+    print("\nkd_tree_search at C4: %d pairs, %d matches (brute force %d); search %.1f ms incl. tree build, %.1f ms with trees resident; "
+          "mode C on the KD set: %d iterations, cost %.9g (brute-force set: %d, %.9g); converged poses differ by %.3g m / %.3g rad; identical sets: %d"
+          % (len(got[0]), len(got[3]), len(bf[3]), t_first * 1e3, t_again * 1e3, sk.iterations, sk.final_cost, sb.iterations, sb.final_cost, dxy, dth, same))
+    g.close()
+
+
 def test_fullsize_correction_cycle_matches_oracle(big):
     """One whole user correction on the 20 M-observation map: every pre-solve stage against the oracle (index sets and
     fp32 poses bit for bit), then the longest possible back-propagation (both ends of the 50 000-pose trajectory:

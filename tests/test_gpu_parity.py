@@ -332,3 +332,46 @@ def test_evaluate_jacobian_is_the_crs_form_of_the_pair_jacobians(small_problem):
     grad[:3] = 0.0                                                                 # pose 0 is constant
     assert np.abs(grad - go).max() <= 1e-9 * np.abs(go).max()
     g.close(); o.close()
+
+
+@pytest.mark.parametrize("shape", [(60, 90, 30, 3), (24, 64, 24, 0), (120, 128, 120, 3), (16, 700, 16, 5)])
+def test_kd_tree_search_reproduces_the_reference_walk(shape):
+    """hitl_options.kd_tree_search = 1: per-scan KD-trees (kdtree.cpp:37-139) and the pruned FindNearestPointNormal walk
+    (kdtree.cpp:141-197) on the GPU, bit for bit: the index sets equal the oracle's restatement of the walk (method 1) and
+    differ from the brute-force definition (method 0) where the walk prunes a better-scoring point away."""
+    import hitl_slam_amd as H
+    n, m, ppf, window = shape
+    prob = Problem(n, m, ppf=ppf)
+    opt = H.default_options()
+    opt.kd_tree_search = 1
+    g = prob.load(H.Solver(opt))
+    g.find_correspondences(prob.init, window)
+    got = g.get_correspondences()
+    kd = oracle_corr(prob, window=window, method=1)
+    for a, b in zip(got, kd):
+        assert np.array_equal(a, b)
+    g.close()
+
+
+def test_kd_tree_search_on_ragged_and_empty_scans():
+    """Scans of different lengths (one empty, one with a single point) through the tree kernels."""
+    import hitl_slam_amd as H
+    from oracle import hitl_oracle as O
+    prob = Problem(30, 80, ppf=30)
+    rng = np.random.default_rng(11)
+    keep = [rng.permutation(80)[:int(k)] for k in rng.integers(0, 81, size=30)]
+    keep[7] = np.zeros(0, int); keep[11] = np.array([5])
+    keep = [np.sort(k) for k in keep]
+    off = np.concatenate([[0], np.cumsum([len(k) for k in keep])]).astype(np.int64)
+    sel = np.concatenate([prob.off[i] + k for i, k in enumerate(keep)]).astype(np.int64)
+    arrs = [np.ascontiguousarray(a[sel]) for a in (prob.px, prob.py, prob.nx, prob.ny)]
+    opt = H.default_options()
+    opt.kd_tree_search = 1
+    g, o = H.Solver(opt), O.OracleSolver()
+    for s in (g, o):
+        s.set_map(off, *arrs, prob.cov)
+    g.find_correspondences(prob.init, 4)
+    o.find_correspondences(prob.init, 4, 1)
+    for a, b in zip(g.get_correspondences(), o.get_correspondences()):
+        assert np.array_equal(a, b)
+    g.close(); o.close()
