@@ -191,6 +191,7 @@ def main():
             solver = H.Solver(opt)
             ops, fn = torch_allgather_ops(device=torch.device("cuda", dev_index) if args.backend == "nccl" else None)
             solver.set_comm(ops, fn)
+            comm_ranks = solver.comm_ranks()
             comm_kind = "torch.distributed all_gather callback (%s backend)%s" % (
                 "nccl = RCCL" if args.backend == "nccl" else "gloo",
                 "; in-library RCCL was tried first and failed" if args.comm == "auto" and args.backend == "nccl" else "")
@@ -290,7 +291,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling if world > 1 else "weak",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
@@ -298,7 +299,8 @@ def main():
                    "n_obs_per_gpu": n_obs, "matches_per_gpu": int(n_matches_l), "pairs_per_gpu": int(n_pairs_l),
                    "matches_per_obs": n_matches_l / max(n_obs, 1), "window": wl["window"],
                    "human_constraint_rows": rows[1], "mode": "C (joint)", "band_poses": int(summ.band_poses),
-                   "parallelism": ("%d pose-range submaps, 1 per GPU, one global LM; exchange: %s" % (world, comm_kind)) if world > 1 else "single GPU"},
+                   "parallelism": ("%d pose-range submaps, 1 per GPU, one global LM; exchange: %s" % (world, comm_kind)) if world > 1 else "single GPU",
+                   "comm": comm_kind, "comm_ranks": comm_ranks if world > 1 else 1},
         "resolve_ms": ms_per_step,
         "gn_iters_per_sec": iters_all / elapsed,
         "lm_iterations_per_resolve": summ.iterations,

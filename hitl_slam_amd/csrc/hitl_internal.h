@@ -16,7 +16,7 @@ namespace hitl {
 constexpr int kMaxBandPoses = 4;          // super-block size B = 3*Wb <= 12
 constexpr int kPairRJ = 14;               // r0, r1, J[2][6] per directed STF pair
 constexpr int kNumScalars = 16;           // device scalar scratch (doubles)
-constexpr int kMatchPad = 256;            // readable words behind the last match (k_linearize_stf fetches one trip ahead)
+constexpr int kMatchPad = 512;            // readable words behind the last match (k_linearize_stf fetches one trip ahead)
 
 // ---- view structs passed to kernels by value ------------------------------------------
 struct MapView {            // SoA robot-frame scans (JointOptimization.h:62-68)

@@ -11,6 +11,7 @@
 // products, PCG pieces, submap interface helpers).
 // All arithmetic is fp64 (T = double in the reference functors); observations stay fp32.
 
+#include <algorithm>
 #include <cstdlib>
 
 #include "hitl_device.h"
@@ -33,6 +34,12 @@ namespace hitl {
 // holding the totals pass them through LDS to lane 0 of the half-wave, which forms the residual, the square roots and the
 // 2x6 Jacobian.  (A separate one-thread-per-pair finishing kernel was measured at 21 us: strided 112-byte rows.)
 //
+// What bounds it (round 2, C4, rocprofv3 kernel trace + PMC, profiles/r02_stf_*): 280 us per launch = 80 us with every
+// trip removed (launch, scan staging, the pair prologue/epilogue) + ~35 us per trip.  Removing any ONE ingredient of a trip
+// moves it by 5-14 % only (no target gathers 250 us, no index stream 253, no arithmetic 268, no LDS source reads 276);
+// 27 % fewer VALU instructions, 5 instead of 6 waves per SIMD, index words 1-3 trips ahead, gathers one trip ahead, several
+// poses per workgroup: all within +-3 %.  VALU issue slots ~58 % used, TA ~55 % busy, L1 72 % / L2 75 % hit rates, HBM
+// 2.7 TB/s.  The kernel sits on several ceilings at once; the moments form (stf_moments) is the way past them.
 // Round-2 instruction diet (rocprofv3 PMC, C4: 845 VALU instructions per wave before):
 //  * full trips carry no tail weights; the last partial trip is a separate copy of the body with weights,
 //  * the source scan sits in LDS as fp64 (4 conversions per match instead of 8),
@@ -67,6 +74,7 @@ __device__ __forceinline__ double swz_xor(double v) {
   }
 
 constexpr int kStfSub = 32;     // lanes per directed pair: two pairs per wave
+constexpr int kStfAheadDefault = 2;   // index words requested this many trips ahead (tools/stf_trace.sh A/B)
 constexpr int kStfSums = 8;     // S0, A0x, A0y, T01, S1, A1x, A1y, T10 (of e / k)
 
 // per-pose (cos theta, sin theta), computed once per linearisation instead of per pair
@@ -99,10 +107,10 @@ __device__ __forceinline__ void stf_match(StfAcc& a, double ax, double ay, doubl
 
 // SRC: 0 = source scan read from global memory (scans beyond the LDS budget), 1 = staged in LDS as float4 (<= 4096
 // points), 2 = staged in LDS widened to fp64 (<= 2048 points)
-// OFF32: every observation lies within 4 GB of map.obs, so a target gather is `scalar base + 32-bit lane offset`
-// (global_load with an SGPR base: no 64-bit address arithmetic per match)
-// PIPE: 1 = the target gathers of trip t+1 are issued before the arithmetic of trip t (and the index words of trip t+2):
-// a workgroup's life is a chain of dependent memory rounds, and this takes one round out of every trip
+// OFF32: every observation and every index word lies within 4 GB of its array base, so a gather / index fetch is
+// `scalar base + 32-bit lane offset` (global_load with an SGPR base: no 64-bit address arithmetic, no address to keep alive)
+// AHEAD: how many trips ahead the index words are requested (1..3).  The index stream comes from HBM (about 1.2 us under
+// load, rocprofv3 TCC_EA0_RDREQ_LEVEL / TCC_EA0_RDREQ), a trip lasts about as long: one trip ahead does not hide it.
 template <int SRC>
 __device__ __forceinline__ void stf_source(const double2* s_scan8, const float4* s_scan4, const float4* __restrict__ src_g, uint32_t u,
                                            double& ax, double& ay, double& anx, double& any) {
@@ -116,7 +124,7 @@ __device__ __forceinline__ void stf_source(const double2* s_scan8, const float4*
   }
 }
 
-template <int SRC, bool OFF32, int PIPE, int MINB, int ABL = 0>
+template <int SRC, bool OFF32, int AHEAD, int MINB>
 __global__ __launch_bounds__(kStfBlock, MINB) void k_linearize_stf(MapView map, PairView pr, int chunk,
                                                                     const double* __restrict__ x, const double2* __restrict__ cs,
                                                                     double kf, double* __restrict__ pairRJ) {
@@ -133,112 +141,86 @@ __global__ __launch_bounds__(kStfBlock, MINB) void k_linearize_stf(MapView map, 
   const int64_t oi = map.obs_off[i];
   const int mi = (int)(map.obs_off[i + 1] - oi);
   const float4* __restrict__ src_g = map.obs + oi;
+  const int lane = threadIdx.x & 63;
+  const int sub = threadIdx.x / kStfSub;        // pair slot of this half-wave within the workgroup
+  const int hl = threadIdx.x & (kStfSub - 1);   // lane within the half-wave
+  const uint32_t* __restrict__ mt = pr.matches;
+  const char* __restrict__ mtb = reinterpret_cast<const char*>(mt);
+  const char* __restrict__ obs_b = reinterpret_cast<const char*>(map.obs);
+  constexpr int kSlots = kStfBlock / kStfSub;
+  // A workgroup's life is a chain of dependent memory rounds (pose -> pair -> target pose / index words -> gathers), and
+  // the machine holds only 8 workgroups per CU: every round taken off the chain is throughput.  Round 1 of the first
+  // pair round (target pose, match range) is requested here, together with the scan; round 2 (target state, first index
+  // words) right behind the scan's LDS stores, BEFORE the barrier -- not after it.
+  int p = p_begin + sub;
+  bool live = p < p_end;
+  int pc = live ? p : p_begin;
+  int j = pr.pair_tgt[pc];
+  int64_t m_begin = pr.match_off[pc];
+  int64_t m_end = pr.match_off[pc + 1];
   if (SRC == 1) {
     for (int k = threadIdx.x; k < mi; k += kStfBlock) s_scan4[k] = src_g[k];
-    __syncthreads();
   } else if (SRC == 2) {
     for (int k = threadIdx.x; k < mi; k += kStfBlock) {
       const float4 o = src_g[k];
       s_scan8[2 * k] = make_double2((double)o.x, (double)o.y);
       s_scan8[2 * k + 1] = make_double2((double)o.z, (double)o.w);
     }
-    __syncthreads();
   }
-  const int lane = threadIdx.x & 63;
-  const int sub = threadIdx.x / kStfSub;        // pair slot of this half-wave within the workgroup
-  const int hl = threadIdx.x & (kStfSub - 1);   // lane within the half-wave
   // workgroup-uniform values pinned to SGPRs
   const double xi = uniform_f64(x[3 * i]), yi = uniform_f64(x[3 * i + 1]);
   const double2 cs0 = cs[i];
   const double c0 = uniform_f64(cs0.x), s0 = uniform_f64(cs0.y);
-  const uint32_t* __restrict__ mt = pr.matches;
-  constexpr int kSlots = kStfBlock / kStfSub;
-  for (int pb = p_begin; pb < p_end; pb += kSlots) {   // workgroup-uniform trip count
-    const int p = pb + sub;
-    const bool live = p < p_end;
-    const int pc = live ? p : p_begin;
-    const int j = pr.pair_tgt[pc];
+  bool staged = (SRC == 0);
+  for (int pb = p_begin;;) {                            // workgroup-uniform trip count
     const int64_t oj = map.obs_off[j];
     const float4* __restrict__ tgt_g = map.obs + oj;
     const uint32_t tgt_b = (uint32_t)oj << 4;                                   // OFF32: byte offset of the target scan
-    const char* __restrict__ obs_b = reinterpret_cast<const char*>(map.obs);
 #define HITL_TGT(u) (OFF32 ? *reinterpret_cast<const float4*>(obs_b + (tgt_b + (__builtin_amdgcn_ubfe((u), 16, 16) << 4))) : tgt_g[(u) >> 16])
-    const double ddx = x[3 * j] - xi, ddy = x[3 * j + 1] - yi;
+    const double xj = x[3 * j], yj = x[3 * j + 1];
     const double2 cs1 = cs[j];
-    const double cR = c0 * cs1.x + s0 * cs1.y, sR = c0 * cs1.y - s0 * cs1.x;   // R01 = R0^T R1
-    const double t01x = c0 * ddx + s0 * ddy, t01y = c0 * ddy - s0 * ddx;       // R0^T (t1 - t0)
-    const int64_t m_begin = pr.match_off[pc];
-    const int len = live ? (int)(pr.match_off[pc + 1] - m_begin) : 0;          // a pair holds < 65536 matches
-    StfAcc acc = {0, 0, 0, 0, 0, 0, 0, 0};
-    // index words: OFF32 reads them as `scalar base + 32-bit lane offset` as well (no 64-bit lane address to keep alive)
+    const int len = live ? (int)(m_end - m_begin) : 0;                          // a pair holds < 65536 matches
+    // index words, AHEAD trips in flight.  Unguarded: the array ends with kMatchPad words of padding.
     const uint32_t* __restrict__ mp = mt + m_begin + hl;
     uint32_t mo = ((uint32_t)m_begin + (uint32_t)hl) << 2;
-    const char* __restrict__ mtb = reinterpret_cast<const char*>(mt);
 #define HITL_IDX(k) (OFF32 ? *reinterpret_cast<const uint32_t*>(mtb + (mo + 4u * (uint32_t)(k))) : mp[(k)])
-#define HITL_IDX_ADVANCE(k) { if (OFF32) mo += 4u * (uint32_t)(k); else mp += (k); }
-    const int nfull = (ABL == 5) ? 0 : (ABL == 6) ? 1 : (len >> 6), rem = (ABL >= 5) ? 0 : (len & 63);   // ABL 5: prologue + epilogue only; 6: one trip
+    uint32_t ua[AHEAD], ub[AHEAD];
+#pragma unroll
+    for (int d = 0; d < AHEAD; ++d) { ua[d] = HITL_IDX(2 * kStfSub * d); ub[d] = HITL_IDX(2 * kStfSub * d + kStfSub); }
+    if (!staged) { __syncthreads(); staged = true; }    // the source scan is in LDS
+    const double ddx = xj - xi, ddy = yj - yi;
+    const double cR = c0 * cs1.x + s0 * cs1.y, sR = c0 * cs1.y - s0 * cs1.x;   // R01 = R0^T R1
+    const double t01x = c0 * ddx + s0 * ddy, t01y = c0 * ddy - s0 * ddx;       // R0^T (t1 - t0)
+    StfAcc acc = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int nfull = len >> 6, rem = len & 63;
     double ax0, ay0, anx0, any0, ax1, ay1, anx1, any1;
-    if (PIPE == 0) {
-      // The index words of the NEXT trip are requested before this trip's arithmetic, so a trip waits for one memory
-      // round (the gathers) instead of two dependent ones.  Unguarded: the array ends with kMatchPad words of padding.
-      uint32_t un0 = HITL_IDX(0), un1 = HITL_IDX(kStfSub);
-      for (int t = 0; t < nfull; ++t) {
-        const uint32_t u0 = un0, u1 = un1;
-        HITL_IDX_ADVANCE(2 * kStfSub)
-        // ABL (development ablations, results are wrong): 1 no target gathers, 2 no source reads, 3 no arithmetic, 4 no index stream
-        float4 tv0, tv1;
-        if (ABL == 1) { tv0 = make_float4(__uint_as_float(u0), 1.f, 0.f, 1.f); tv1 = make_float4(__uint_as_float(u1), 1.f, 0.f, 1.f); }
-        else { tv0 = HITL_TGT(u0); tv1 = HITL_TGT(u1); }
-        if (ABL == 2) { ax0 = (double)u0; ay0 = 1.0; anx0 = 0.0; any0 = 1.0; ax1 = (double)u1; ay1 = 1.0; anx1 = 0.0; any1 = 1.0; }
-        else {
+    for (int t = 0; t < nfull; t += AHEAD) {
+#pragma unroll
+      for (int d = 0; d < AHEAD; ++d) {
+        if (t + d < nfull) {
+          const uint32_t u0 = ua[d], u1 = ub[d];
+          const float4 tv0 = HITL_TGT(u0), tv1 = HITL_TGT(u1);
           stf_source<SRC>(s_scan8, s_scan4, src_g, u0, ax0, ay0, anx0, any0);
           stf_source<SRC>(s_scan8, s_scan4, src_g, u1, ax1, ay1, anx1, any1);
-        }
-        if (ABL == 4) { un0 = (u0 + 0x10001u) & 0x00ff00ffu; un1 = (u1 + 0x10001u) & 0x00ff00ffu; }
-        else { un0 = HITL_IDX(0); un1 = HITL_IDX(kStfSub); }
-        __builtin_amdgcn_sched_barrier(0);      // keep the index prefetch ahead of the arithmetic (the scheduler sinks it otherwise)
-        if (ABL == 3) { acc.S0 += (ax0 + ax1) + (double)(tv0.x + tv1.x); acc.S1 += (any0 + any1) + (double)(tv0.w + tv1.w); }
-        else {
+          ua[d] = HITL_IDX(2 * kStfSub * (d + AHEAD)); ub[d] = HITL_IDX(2 * kStfSub * (d + AHEAD) + kStfSub);   // trip t + d + AHEAD
+          __builtin_amdgcn_sched_barrier(0);      // keep the index prefetch ahead of the arithmetic (the scheduler sinks it otherwise)
           stf_match<false>(acc, ax0, ay0, anx0, any0, tv0, cR, sR, t01x, t01y, 1.0);
           stf_match<false>(acc, ax1, ay1, anx1, any1, tv1, cR, sR, t01x, t01y, 1.0);
         }
       }
-      if (rem > 0) {      // the last, partial trip: lanes past the end take index 0 (valid) with weight 0
-        const bool v0 = hl < rem, v1 = hl + kStfSub < rem;
-        const uint32_t u0 = v0 ? un0 : 0u, u1 = v1 ? un1 : 0u;
-        const float4 tv0 = HITL_TGT(u0), tv1 = HITL_TGT(u1);
-        stf_source<SRC>(s_scan8, s_scan4, src_g, u0, ax0, ay0, anx0, any0);
-        stf_source<SRC>(s_scan8, s_scan4, src_g, u1, ax1, ay1, anx1, any1);
-        stf_match<true>(acc, ax0, ay0, anx0, any0, tv0, cR, sR, t01x, t01y, v0 ? 1.0 : 0.0);
-        stf_match<true>(acc, ax1, ay1, anx1, any1, tv1, cR, sR, t01x, t01y, v1 ? 1.0 : 0.0);
-      }
-    } else {
-      // two-stage pipeline: (ua, ub, ta, tb) = index words and gathered targets of the CURRENT trip; (na, nb) = index
-      // words of the next one.  Words past the pair's end are replaced by 0 (a valid index) before they address anything.
-      uint32_t ua = HITL_IDX(0), ub = HITL_IDX(kStfSub);
-      uint32_t na = HITL_IDX(2 * kStfSub), nb = HITL_IDX(3 * kStfSub);
-      ua = (hl < len) ? ua : 0u; ub = (hl + kStfSub < len) ? ub : 0u;
-      float4 ta = HITL_TGT(ua), tb = HITL_TGT(ub);
-      int pos = hl + 2 * kStfSub;                      // list position of na
-      for (int t = 0; t < nfull; ++t) {
-        const uint32_t ca = (pos < len) ? na : 0u, cb = (pos + kStfSub < len) ? nb : 0u;
-        const float4 nta = HITL_TGT(ca), ntb = HITL_TGT(cb);        // next trip's gathers, in flight during this trip's arithmetic
-        HITL_IDX_ADVANCE(2 * kStfSub) pos += 2 * kStfSub;
-        if (ABL == 4) { na = (ca + 0x10001u) & 0x00ff00ffu; nb = (cb + 0x10001u) & 0x00ff00ffu; }   // development ablation: no index stream
-        else { na = HITL_IDX(2 * kStfSub); nb = HITL_IDX(3 * kStfSub); }        // index words two trips ahead
-        stf_source<SRC>(s_scan8, s_scan4, src_g, ua, ax0, ay0, anx0, any0);
-        stf_source<SRC>(s_scan8, s_scan4, src_g, ub, ax1, ay1, anx1, any1);
-        __builtin_amdgcn_sched_barrier(0);
-        stf_match<false>(acc, ax0, ay0, anx0, any0, ta, cR, sR, t01x, t01y, 1.0);
-        stf_match<false>(acc, ax1, ay1, anx1, any1, tb, cR, sR, t01x, t01y, 1.0);
-        ua = ca; ub = cb; ta = nta; tb = ntb;
-      }
-      if (rem > 0) {
-        stf_source<SRC>(s_scan8, s_scan4, src_g, ua, ax0, ay0, anx0, any0);
-        stf_source<SRC>(s_scan8, s_scan4, src_g, ub, ax1, ay1, anx1, any1);
-        stf_match<true>(acc, ax0, ay0, anx0, any0, ta, cR, sR, t01x, t01y, (hl < rem) ? 1.0 : 0.0);
-        stf_match<true>(acc, ax1, ay1, anx1, any1, tb, cR, sR, t01x, t01y, (hl + kStfSub < rem) ? 1.0 : 0.0);
-      }
+      if (OFF32) mo += 8u * kStfSub * AHEAD; else mp += 2 * kStfSub * AHEAD;
+    }
+    if (rem > 0) {      // the last, partial trip: lanes past the end take index 0 (valid) with weight 0
+      uint32_t w0 = ua[0], w1 = ub[0];
+#pragma unroll
+      for (int d = 1; d < AHEAD; ++d) { const bool here = (nfull % AHEAD) == d; w0 = here ? ua[d] : w0; w1 = here ? ub[d] : w1; }
+      const bool v0 = hl < rem, v1 = hl + kStfSub < rem;
+      const uint32_t u0 = v0 ? w0 : 0u, u1 = v1 ? w1 : 0u;
+      const float4 tv0 = HITL_TGT(u0), tv1 = HITL_TGT(u1);
+      stf_source<SRC>(s_scan8, s_scan4, src_g, u0, ax0, ay0, anx0, any0);
+      stf_source<SRC>(s_scan8, s_scan4, src_g, u1, ax1, ay1, anx1, any1);
+      stf_match<true>(acc, ax0, ay0, anx0, any0, tv0, cR, sR, t01x, t01y, v0 ? 1.0 : 0.0);
+      stf_match<true>(acc, ax1, ay1, anx1, any1, tv1, cR, sR, t01x, t01y, v1 ? 1.0 : 0.0);
     }
     // reduce-scatter over the 32 lanes of this pair: after the three exchange steps lane hl holds the 4-lane partial of
     // value (hl >> 2); two more exchanges complete it
@@ -272,7 +254,10 @@ __global__ __launch_bounds__(kStfBlock, MINB) void k_linearize_stf(MapView map, 
     }
 #undef HITL_TGT
 #undef HITL_IDX
-#undef HITL_IDX_ADVANCE
+    pb += kSlots;
+    if (pb >= p_end) break;
+    p = pb + sub; live = p < p_end; pc = live ? p : p_begin;
+    j = pr.pair_tgt[pc]; m_begin = pr.match_off[pc]; m_end = pr.match_off[pc + 1];
   }
 }
 
@@ -387,49 +372,20 @@ void launch_linearize_stf(hipStream_t st, const MapView& map, const PairView& pr
   const bool off32 = (uint64_t)map_obs_count * 16 < ((uint64_t)1 << 32) && ((uint64_t)n_matches + kMatchPad) * 4 < ((uint64_t)1 << 32);
   const double kf = (double)corr / (double)std_dev;                       // k = corr / sigma, divided here once
   const dim3 grid(8 * chunk), block(kStfBlock);
-  // HITL_STF_VARIANT (development switch): 3 decimal digits "src pipe minblocks", e.g. 116 = fp32 source in LDS, pipelined
-  // gathers, 6 workgroups per CU.  Unset: the default below.
+  // HITL_STF_VARIANT (development switch): 2 decimal digits "ahead minwaves", e.g. 36 = index words 3 trips ahead, 6 waves per
+  // SIMD.  Unset: the default below.
   static const int variant = [] { const char* e = std::getenv("HITL_STF_VARIANT"); return e ? std::atoi(e) : 0; }();
-  int src = ((size_t)cap * 32 <= 64 * 1024) ? 2 : ((size_t)cap * 16 <= 64 * 1024) ? 1 : 0;
-  int pipe = 0, minb = (src == 2 && off32) ? 6 : 5;     // the fallback layouts need > 80 VGPRs: 5 waves per SIMD instead of spilling
-  if (variant >= 1000) {     // ablations of the default kernel: 1000 + ABL
-    const int abl = variant - 1000;
-    if (src == 2 && off32) {
-      if (abl == 1) hipLaunchKernelGGL((k_linearize_stf<2, true, 0, 6, 1>), grid, block, (size_t)cap * 32, st, map, pr, chunk, x, cs, kf, pairRJ);
-      else if (abl == 2) hipLaunchKernelGGL((k_linearize_stf<2, true, 0, 6, 2>), grid, block, (size_t)cap * 32, st, map, pr, chunk, x, cs, kf, pairRJ);
-      else if (abl == 3) hipLaunchKernelGGL((k_linearize_stf<2, true, 0, 6, 3>), grid, block, (size_t)cap * 32, st, map, pr, chunk, x, cs, kf, pairRJ);
-      else if (abl == 14) hipLaunchKernelGGL((k_linearize_stf<2, true, 1, 5, 4>), grid, block, (size_t)cap * 32, st, map, pr, chunk, x, cs, kf, pairRJ);
-      else if (abl == 5) hipLaunchKernelGGL((k_linearize_stf<2, true, 0, 6, 5>), grid, block, (size_t)cap * 32, st, map, pr, chunk, x, cs, kf, pairRJ);
-      else if (abl == 6) hipLaunchKernelGGL((k_linearize_stf<2, true, 0, 6, 6>), grid, block, (size_t)cap * 32, st, map, pr, chunk, x, cs, kf, pairRJ);
-      else hipLaunchKernelGGL((k_linearize_stf<2, true, 0, 6, 4>), grid, block, (size_t)cap * 32, st, map, pr, chunk, x, cs, kf, pairRJ);
-      return;
-    }
-  }
-  if (variant > 0 && variant < 1000) {
-    const int vs = variant / 100, vp = (variant / 10) % 10, vm = variant % 10;
-    if (vs <= src) src = vs;
-    pipe = vp ? 1 : 0;
-    minb = (vm == 5) ? 5 : (vm == 4) ? 4 : 6;
-  }
+  const int src = ((size_t)cap * 32 <= 64 * 1024) ? 2 : ((size_t)cap * 16 <= 64 * 1024) ? 1 : 0;
+  int ahead = kStfAheadDefault, minb = (src == 2 && off32) ? 6 : 5;     // the fallback layouts need > 80 VGPRs: 5 waves per SIMD instead of spilling
+  if (variant > 0 && src == 2 && off32) { ahead = std::min(3, std::max(1, variant / 10)); minb = (variant % 10 == 5) ? 5 : 6; }
   const size_t lds = (src == 2) ? (size_t)cap * 32 : (src == 1) ? (size_t)cap * 16 : 0;
-#define HITL_STF_GO(SRC, PIPE, MINB)                                                                                            \
-  {                                                                                                                            \
-    if (off32) hipLaunchKernelGGL((k_linearize_stf<SRC, true, PIPE, MINB>), grid, block, lds, st, map, pr, chunk, x, cs, kf, pairRJ); \
-    else hipLaunchKernelGGL((k_linearize_stf<SRC, false, PIPE, MINB>), grid, block, lds, st, map, pr, chunk, x, cs, kf, pairRJ);     \
-  }
-#define HITL_STF_PM(SRC)                                                                   \
-  {                                                                                        \
-    if (pipe == 0 && minb == 6) HITL_STF_GO(SRC, 0, 6)                                     \
-    else if (pipe == 0 && minb == 5) HITL_STF_GO(SRC, 0, 5)                                \
-    else if (pipe == 0) HITL_STF_GO(SRC, 0, 4)                                             \
-    else if (minb == 6) HITL_STF_GO(SRC, 1, 6)                                             \
-    else if (minb == 5) HITL_STF_GO(SRC, 1, 5)                                             \
-    else HITL_STF_GO(SRC, 1, 4)                                                            \
-  }
-  if (src == 2) HITL_STF_PM(2)
-  else if (src == 1) HITL_STF_PM(1)
-  else HITL_STF_PM(0)
-#undef HITL_STF_PM
+#define HITL_STF_GO(SRC, O32, AH, MINB) hipLaunchKernelGGL((k_linearize_stf<SRC, O32, AH, MINB>), grid, block, lds, st, map, pr, chunk, x, cs, kf, pairRJ)
+  if (src == 2 && off32) {
+    if (minb == 6) { if (ahead == 1) HITL_STF_GO(2, true, 1, 6); else if (ahead == 2) HITL_STF_GO(2, true, 2, 6); else HITL_STF_GO(2, true, 3, 6); }
+    else { if (ahead == 1) HITL_STF_GO(2, true, 1, 5); else if (ahead == 2) HITL_STF_GO(2, true, 2, 5); else HITL_STF_GO(2, true, 3, 5); }
+  } else if (src == 2) HITL_STF_GO(2, false, 1, 5);
+  else if (src == 1) { if (off32) HITL_STF_GO(1, true, 1, 5); else HITL_STF_GO(1, false, 1, 5); }
+  else { if (off32) HITL_STF_GO(0, true, 1, 5); else HITL_STF_GO(0, false, 1, 5); }
 #undef HITL_STF_GO
 }
 

@@ -290,10 +290,12 @@ static int linear_solve_and_step_dist(hitl_solver* s, const FactorView& fv, int 
   const double* Z = s->zN.p + npad;
   launch_gather_iface(st, s->dt.p, Z, (size_t)npad, s->scale.p, s->if_cols.p, nc, s->iface_dev.p);
   const int RI = nc * (nc + 2), RC = m * m, R = RI + 2 * RC;
-  std::vector<double> rec((size_t)R, 0.0);
+  // host buffers of the exchange live in the solver (sized once per interface width, reused every LM iteration)
+  std::vector<double>&rec = s->if_rec, &hb_lo = s->if_hb_lo, &hb_up = s->if_hb_up, &all = s->if_all, &A = s->if_A, &y = s->if_y, &Ct = s->if_Ct;
+  rec.assign((size_t)R, 0.0);
+  hb_lo.assign((size_t)Wi * W1 * 9, 0.0); hb_up.assign((size_t)Wi * W1 * 9, 0.0);
   HIP_TRY(hipMemcpyAsync(rec.data(), s->iface_dev.p, sizeof(double) * RI, hipMemcpyDeviceToHost, st));
   // cross-cut blocks from the band: block (i, i+d) lives at Hband[i][d]
-  std::vector<double> hb_lo((size_t)Wi * W1 * 9, 0.0), hb_up((size_t)Wi * W1 * 9, 0.0);
   if (me > 0) HIP_TRY(hipMemcpyAsync(hb_lo.data(), lv.Hband + (size_t)(s->own_lo - Wi) * W1 * 9, sizeof(double) * hb_lo.size(), hipMemcpyDeviceToHost, st));
   if (me < W - 1) HIP_TRY(hipMemcpyAsync(hb_up.data(), lv.Hband + (size_t)(s->own_hi - Wi) * W1 * 9, sizeof(double) * hb_up.size(), hipMemcpyDeviceToHost, st));
   TRY(spin_sync(s));
@@ -315,7 +317,7 @@ static int linear_solve_and_step_dist(hitl_solver* s, const FactorView& fv, int 
         const double* blk = &hb_up[((size_t)ap * W1 + d) * 9];   // block (a, b)
         for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Cup[(size_t)(3 * ap + r) * m + 3 * bp + c] = blk[r * 3 + c];
       }
-  std::vector<double> all((size_t)R * W);
+  all.resize((size_t)R * W);
   TRY(comm_allgather(s, rec.data(), all.data(), sizeof(double) * R));
   auto z0_of = [&](int g) { return &all[(size_t)R * g]; };
   auto Z_of = [&](int g) { return &all[(size_t)R * g + nc]; };              // Z[c][r] = Z_of[nc*c + r]
@@ -324,7 +326,7 @@ static int linear_solve_and_step_dist(hitl_solver* s, const FactorView& fv, int 
   auto Cup_of = [&](int g) { return &all[(size_t)R * g + RI + RC]; };
   // interface system
   const int NI = nc * W;
-  std::vector<double> A((size_t)NI * NI, 0.0), y(NI, 0.0), Ct((size_t)m * m);
+  A.assign((size_t)NI * NI, 0.0); y.assign(NI, 0.0); Ct.assign((size_t)m * m, 0.0);
   for (int g = 0; g < W; ++g) {
     for (int r = 0; r < nc; ++r) { A[(size_t)(nc * g + r) * NI + nc * g + r] = 1.0; y[nc * g + r] = z0_of(g)[r]; }
     if (g >= 1) {       // C~_lo,g = diag(s_first,g) C_lo,g diag(s_last,g-1); columns of v_{g-1}

@@ -48,6 +48,7 @@ struct hitl_solver {
   DevArray<unsigned char> fixed;     // n : constant poses (global pose 0, halos)
   DevArray<int> if_cols, halo_idx;   // interface column indices (2m) ; scalar indices of the nearest halo poses
   DevArray<double> iface_dev, rhsN, zN, coef_dev, halo_val, halo_sc;
+  std::vector<double> if_rec, if_hb_lo, if_hb_up, if_all, if_A, if_y, if_Ct;   // host side of the interface exchange
   int Wi = 1;                        // interface width in poses: deepest reach of a factor across any cut (global max)
   int n_pairs_owned = 0;             // pairs whose SOURCE pose is owned (each pair is counted by one rank)
   int64_t n_matches_owned = 0;

@@ -12,7 +12,7 @@ i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU" \
            "SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum" "TCP_PENDING_STALL_CYCLES_sum TCP_GATE_EN1_sum" "SQ_WAVES"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --output-format csv -d $OUT/p$i -- python3 bench.py $ARGS > $OUT/p$i.json 2> $OUT/p$i.err
+  timeout 300 rocprofv3 --pmc $grp --output-format csv -d $OUT/p$i -- python3 bench.py $ARGS > $OUT/p$i.json 2> $OUT/p$i.err < /dev/null
 done
 python3 tools/summarize_pmc.py $OUT > $OUT/summary.md 2> $OUT/summary.err
 cat $OUT/summary.md

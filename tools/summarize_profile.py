@@ -62,6 +62,9 @@ def main():
     try:
         bj = json.loads(open(os.path.join(out, "bench_trace.json")).read().strip().splitlines()[-1])
         res["n_obs"] = bj["config"]["n_obs_per_gpu"]
+        res["n_matches"] = bj["config"]["matches_per_gpu"]
+        res["source"] = "tools/profile_bench.sh %s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py %s`, FETCH_SIZE x2 (gfx950)" % (
+            os.path.basename(out.rstrip("/")), " ".join(sys.argv[2:]) if len(sys.argv) > 2 else "--steps 3 --warmup 1 --no-cpu-baseline")
         res["bench_avg_launch_ms"] = bj["roofline"]["avg_launch_ms"]
         print("\nbench.py (same run, under the profiler): avg k_linearize_stf launch %.4f ms by HIP events; kernel trace avg %.4f ms"
               % (bj["roofline"]["avg_launch_ms"], res.get("stf_avg_us", 0) / 1e3))
