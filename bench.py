@@ -321,7 +321,8 @@ def main():
                      "algorithmic_frac": alg_achieved / HBM_PEAK_GBS,
                      "compulsory_bytes_this_layout": compulsory,
                      "avg_launch_ms": avg_stf_ms, "launches": stf_launches, "launches_bracketed_by_hip_events": stf_calls,
-                     "limiter": "VALU issue (fp64 + address arithmetic), not HBM: see utilisation_counters",
+                     "limiter": "no single unit: fp64 issue slots ~74 %, L1 gather path (TA) ~55 %, HBM ~36 % of peak; ablations in "
+                                "profiles/r02_stf_ablation_kernel_trace.txt (no ingredient of a trip is worth more than 14 % of the launch)",
                      "utilisation_counters": pmc},
         "synth_gen_s": gen_s,
     }

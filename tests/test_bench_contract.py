@@ -1,5 +1,6 @@
-"""The bench line contract (one JSON object: metric/value/unit/..., a `roofline` object from ALGORITHMIC bytes, a
-`cpu_baseline` object), checked on the committed lines of the last profiled run (profiles/r01_final_bench_*.json) and on
+"""The bench line contract (one JSON object: metric/value/unit/..., a `roofline` object -- `achieved` from the HBM bytes the
+kernel really moves, the SURVEY 8(d) algorithmic-byte figure beside it -- and a `cpu_baseline` object), checked on the
+committed lines of the last profiled run (profiles/r02_mid_bench_*.json) and on
 bench.py's own source: the product path may not fall back to the oracle, the oracle is only the cpu_baseline leg."""
 import json
 import os
@@ -8,7 +9,7 @@ import re
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LINES = [os.path.join(ROOT, "profiles", f) for f in ("r01_final_bench_c4.json", "r01_final_bench_c2.json")]
+LINES = [os.path.join(ROOT, "profiles", f) for f in ("r02_mid_bench_c4.json", "r02_mid_bench_c2.json")]
 
 
 @pytest.mark.parametrize("path", LINES, ids=[os.path.basename(p) for p in LINES])
@@ -24,13 +25,18 @@ def test_committed_bench_line_has_the_contract_fields(path):
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in rf, k
     assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s") and rf["peak"] == 8000.0
-    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
-    # achieved = algorithmic bytes per launch / measured launch time
-    assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * rf["achieved"]
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0 < rf["frac"] < 1      # a fraction of a physical peak
+    # achieved = bytes really moved per launch (PMC-measured, else the layout's compulsory bytes) / measured launch time
+    assert abs(rf["achieved"] - rf["bytes_per_launch_used_for_achieved"] / (rf["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * rf["achieved"]
+    assert rf["bytes_per_launch_used_for_achieved"] in (rf["traffic"], rf["compulsory_bytes_this_layout"])
+    assert (rf["traffic"] is None) == (rf["traffic_source"] is None)
+    assert abs(rf["algorithmic_achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * rf["algorithmic_achieved"]
     cb = r["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
     assert cb["kind"] in ("port", "reference") and cb["unit"] == r["unit"] and cb["cores"] >= 1
+    assert "extrapolated" not in json.dumps(cb) and cb["lm_iterations"] == cb["lm_iterations_gpu"] == r["lm_iterations_per_resolve"]
+    assert cb["cores"] == cb["host"]["threads_used"] <= cb["host"]["affinity"]
 
 
 def test_bench_source_keeps_the_oracle_in_its_lane():
