@@ -63,7 +63,9 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
   if (cs.size() != (size_t)2 * n) cs.resize((size_t)2 * n);
   {
     // candidate transforms: fp32 host libm (bit-identical to the CPU restatement), spread over a few threads
-    const int nt = (int)std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    // a handful of threads: spawning 32 cost more than the trigonometry (hardware_concurrency() also counts CPUs a container's
+    // quota does not grant)
+    const int nt = (int)std::max(1u, std::min(12u, std::thread::hardware_concurrency()));
     auto run = [&](auto&& body) {
       std::vector<std::thread> th;
       for (int t = 1; t < nt; ++t) th.emplace_back([&, t]() { body((int64_t)n * t / nt, (int64_t)n * (t + 1) / nt); });
