@@ -637,7 +637,6 @@ struct CrStage {
   int prev_par, next_par;
   int np;         // slots per contribution array
   int nsl;        // LDS slots (local nodes 0 .. nsl-1 are addressable)
-  int abl;        // development ablations (HITL_CR_ABL): 1 skip Gauss-Jordan, 2 skip the products, 4 skip the survivor updates
 };
 
 // workgroup barrier that orders LDS traffic only: the Dinv / Gl / Gr stores of a level are read by LATER launches, never by
@@ -722,7 +721,7 @@ __global__ __launch_bounds__(B >= 12 ? 512 : 1024) void k_cr_chunk(CrView cr, Cr
         else if (grp == 3 && has_b) v = Lb[c * B + r];      // column c of L_b^T
         col[r] = v;
       }
-      if (!(sg.abl & 1)) gauss_jordan_cols<B>(col);
+      gauss_jordan_cols<B>(col);
       const size_t gn = (size_t)((base + u) * S) * BB;
       if (grp >= 1 && grp <= 3) {
         double* dst = (grp == 1) ? cr.Dinv + gn : (grp == 2) ? cr.Gl + gn : cr.Gr + gn;
@@ -752,7 +751,7 @@ __global__ __launch_bounds__(B >= 12 ? 512 : 1024) void k_cr_chunk(CrView cr, Cr
       double acc[B];
 #pragma unroll
       for (int r = 0; r < B; ++r) acc[r] = 0.0;
-      if (grp < 3 && !(sg.abl & 2)) {
+      if (grp < 3) {
         const double* G = Gs + ((grp == 1) ? BB : 0);                              // Gr for P_b, Gl otherwise
         const bool on = (grp == 0) || has_b;
         // one instruction stream for the three groups: A(r, q) = Abase[r * sr + q * sq] is L_u^T for g = 0, L_b otherwise
@@ -773,7 +772,7 @@ __global__ __launch_bounds__(B >= 12 ? 512 : 1024) void k_cr_chunk(CrView cr, Cr
     }
     lds_barrier();
     // ---- survivors j = 0, 2s, 4s .. subtract what their eliminated neighbours left (left one first) ----
-    const int nsv = (sg.abl & 4) ? 0 : M / (2 * s) + 1;
+    const int nsv = M / (2 * s) + 1;
     for (int e = tid; e < nsv * BB; e += nthr) {
       const int j = 2 * s * (e / BB), q = e % BB;
       if (j > u_last) continue;
@@ -910,7 +909,8 @@ static int cr_chunk_threads(int M, int B) { return (M <= 2) ? 64 : (M <= 4) ? 12
 
 // stages of the fused factorisation for nsb super-blocks (host): chunks of 16 at stride 1, chunks of 32 above, then the top.
 // (Chunks of M = 2 -- one wave per eliminated node, no barrier -- were measured for the wide first levels and are not
-// faster: a node costs a whole wave's instruction stream either way.)  HITL_CR_PLAN="2,2,16,32" (development) overrides
+// faster: a node costs a whole wave's instruction stream either way; chunks of 4 or 8 at 2 waves per workgroup: 56 / 68 us for
+// the first stage against 54 us for chunks of 16.)  HITL_CR_PLAN="2,2,16,32" (development) overrides
 // the chunk sizes of the first stages.
 static CrPlan cr_plan(int nsb, int B, int np) {
   CrPlan pl;
@@ -923,7 +923,6 @@ static CrPlan cr_plan(int nsb, int B, int np) {
     }
     return v;
   }();
-  static const int abl = [] { const char* e = std::getenv("HITL_CR_ABL"); return e ? std::atoi(e) : 0; }();
   int S = 1, par = 0;
   bool prev = false;
   for (;;) {
@@ -932,7 +931,6 @@ static CrPlan cr_plan(int nsb, int B, int np) {
     while (Mtop < alive) Mtop *= 2;                        // interior u = 1 .. alive-1 < Mtop
     const bool fits_top = alive <= 40 && cr_chunk_lds_bytes((int)alive, B, cr_chunk_threads(64, B)) <= lds_cap;
     CrStage& g = pl.st[pl.n++];
-    g.abl = abl;
     g.S = S; g.has_prev = prev ? 1 : 0; g.prev_par = par; g.next_par = par ^ 1; g.np = np;
     if (fits_top || pl.n == 8) { g.M = Mtop; g.top = 1; g.nsl = (int)alive + 1; break; }
     int M = (pl.n == 1) ? 16 : 32;       // measured on C4 (tools/cr_plans.sh): 16,32,top = 111 us; 2,2,16,.. = 117; 2,2,2,32,.. = 125
