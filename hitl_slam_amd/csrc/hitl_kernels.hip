@@ -369,7 +369,9 @@ void launch_linearize_stf(hipStream_t st, const MapView& map, const PairView& pr
   if (pr.n_pairs == 0) return;
   const int chunk = (map.n_poses + 7) / 8;
   const int cap = (max_scan + 63) & ~63;
-  const bool off32 = (uint64_t)map_obs_count * 16 < ((uint64_t)1 << 32) && ((uint64_t)n_matches + kMatchPad) * 4 < ((uint64_t)1 << 32);
+  // HITL_STF_ADDR64=1 (tests): take the 64-bit addressing instantiations although the arrays are smaller than 4 GB
+  const bool off32 = (uint64_t)map_obs_count * 16 < ((uint64_t)1 << 32) && ((uint64_t)n_matches + kMatchPad) * 4 < ((uint64_t)1 << 32) &&
+                     std::getenv("HITL_STF_ADDR64") == nullptr;
   const double kf = (double)corr / (double)std_dev;                       // k = corr / sigma, divided here once
   const dim3 grid(8 * chunk), block(kStfBlock);
   // HITL_STF_VARIANT (development switch): 2 decimal digits "ahead minwaves", e.g. 36 = index words 3 trips ahead, 6 waves per

@@ -151,3 +151,25 @@ def test_long_scans():
     assert "LDS" in str(e.value)
     g.solve(H.MODE_ODOM_HC, prob.init)        # the solver is still usable
     g.close()
+
+
+@pytest.mark.parametrize("obs, addr64", [(3000, False), (700, True), (3000, True), (5000, True)])
+def test_linearisation_layout_variants(obs, addr64, monkeypatch):
+    """The instantiations of k_linearize_stf the default-size tests never reach: the fp32 source scan in LDS (2049-4096 points
+    per scan), and the 64-bit addressing path (arrays beyond 4 GB; forced here through HITL_STF_ADDR64) in all three source
+    layouts.  One linearisation against the oracle plus the whole solve."""
+    import hitl_slam_amd as H
+    from oracle import hitl_oracle as O
+    if addr64:
+        monkeypatch.setenv("HITL_STF_ADDR64", "1")
+    prob = Problem(10, obs, ppf=10, groups=1, kind=4, window=2)
+    corr = oracle_corr(prob, window=2)
+    g, o = prob.load(H.Solver(), corr=corr), prob.load(O.OracleSolver(), corr=corr)
+    rng = np.random.default_rng(obs)
+    x = prob.init.astype(np.float64) + 0.004 * rng.standard_normal(prob.init.shape)
+    cg, gg, rg, jg = g.linearize(H.MODE_JOINT, prob.init, x)
+    co, go, ro, jo = o.linearize(H.MODE_JOINT, prob.init, x)
+    assert abs(cg - co) <= 1e-10 * co and np.abs(gg - go).max() <= 1e-9 * np.abs(go).max()
+    assert np.abs(rg - ro).max() <= 1e-11 * np.abs(ro).max() and np.abs(jg - jo).max() <= 1e-9 * np.abs(jo).max()
+    _check(g, o, H.MODE_JOINT, prob.init)
+    g.close(); o.close()
