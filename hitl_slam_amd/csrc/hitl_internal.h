@@ -123,7 +123,7 @@ void launch_spmv_residual(hipStream_t st, int n_poses, int npad, const FactorVie
 // q = (S H S) dt ; xc = x + s*dt ; partials[blk*8 + 2..6] = (dt.rhs, dt.q, |s dt|^2, |x|^2, #non-finite)
 void launch_spmv_residual_step(hipStream_t st, int n_poses, int npad, const FactorView& fv, const LinView& lin, const double* scale, double mu,
                                double min_diag, double max_diag, const double* v, const double* rhs, const double* x, double* q, double* xc,
-                               double* partials);
+                               double* partials, double2* cs = nullptr);   // cs: also (cos, sin) of the candidate's angles
 void launch_spmv_step(hipStream_t st, int n_poses, int npad, const FactorView& fv, const LinView& lin,
                       const double* scale, const double* dt, const double* rhs, const double* x, double* q, double* xc,
                       double* partials);

@@ -19,14 +19,14 @@ namespace hitl {
 // one pass over every factor at state xdev: residuals, Jacobians, J^T J blocks, gradient, cost.
 // enqueue_linearize only queues the kernels and the copy of the per-workgroup partials (behind the step partials in
 // the pinned buffer); finish_linearize adds them up once the stream has been synchronised.
-static int enqueue_linearize(hitl_solver* s, const FactorView& fv, const double* xdev, int buf, bool direct = false) {
+static int enqueue_linearize(hitl_solver* s, const FactorView& fv, const double* xdev, int buf, bool direct = false, bool have_trig = false) {
   hipStream_t st = s->stream;
   const MapView mv = s->map_view();
   const PairView pv = s->pair_view();
   LinView lv = s->lin_view(buf);
   double* host = s->h_partials + (size_t)spmv_blocks(s->npad) * 8;
   if (direct) lv.partials = host;      // pinned host memory is device-visible: the partials land there without a copy
-  if (fv.with_stf) launch_pose_trig(st, s->n, xdev, s->pose_cs.p);
+  if (fv.with_stf && !have_trig) launch_pose_trig(st, s->n, xdev, s->pose_cs.p);   // have_trig: the band pass that produced xdev wrote them
   // ev0..ev1 brackets exactly the k_linearize_stf launch.  An event record drains the queue (~6 us each), so at the
   // default timing level only every 4th linearisation is bracketed; level 2 brackets all, level 0 none.
   const int64_t tl = s->opt.timing_level;
@@ -257,7 +257,8 @@ static int enqueue_linear_solve_banded(hitl_solver* s, const FactorView& fv, int
   launch_build_system(st, s->n, fv.band_poses, lv, s->scale.p, s->fixed.p, mu, mind, maxd, cr, s->rhs.p, s->wv.p);
   launch_cr_factor_solve(st, cr, s->wv.p, s->dt.p);
   // residual check of the factorisation and the trust-region bookkeeping in one pass over the band
-  launch_spmv_residual_step(st, s->n, npad, fv, lv, s->scale.p, mu, mind, maxd, s->dt.p, s->rhs.p, xcur, s->qv.p, xcand, s->h_partials);   // straight into pinned host memory
+  launch_spmv_residual_step(st, s->n, npad, fv, lv, s->scale.p, mu, mind, maxd, s->dt.p, s->rhs.p, xcur, s->qv.p, xcand, s->h_partials,   // straight into pinned host memory
+                            fv.with_stf ? s->pose_cs.p : nullptr);
   HIP_TRY(hipGetLastError());
   return HITL_OK;
 }
@@ -461,7 +462,7 @@ int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float* poses
     if (fused) {
       TRY(enqueue_linear_solve_banded(s, fv, cur, radius, xcur, xcand));
       if (time_solver) HIP_TRY(hipEventRecord(s->ev3, st));
-      TRY(enqueue_linearize(s, fv, xcand, cur ^ 1, /*direct=*/true));   // partial sums are written to pinned host memory by the kernels
+      TRY(enqueue_linearize(s, fv, xcand, cur ^ 1, /*direct=*/true, /*have_trig=*/true));   // partial sums are written to pinned host memory by the kernels
       TRY(spin_sync(s));
       double rr, bb;
       TRY(finish_step_partials(s, &rr, &bb, &ss));

@@ -22,6 +22,7 @@ struct SpmvAux {
   const double* x;     // MODE 2
   double* xc;          // MODE 2
   double* partials;    // MODE 1, 2 : [gridDim.x][8]
+  double2* cs;         // MODE 3 (may be null): (cos, sin) of the candidate's theta, saves the k_pose_trig launch in front of k_linearize_stf
 };
 
 template <int MODE>
@@ -41,7 +42,13 @@ __global__ __launch_bounds__(128) void k_spmv(int n_poses, int npad, FactorView 
         if (t < npad) {
           if (MODE == 0) y[t] = v[t];
           if (kRes) { const double r = aux.rhs[t] - v[t]; if (MODE == 1) aux.r_out[t] = r; part[0] += r * r; part[1] += aux.rhs[t] * aux.rhs[t]; }
-          if (kStep) { y[t] = v[t]; if (i < n_poses) aux.xc[t] = aux.x[t]; }
+          if (kStep) {
+            y[t] = v[t];
+            if (i < n_poses) {
+              aux.xc[t] = aux.x[t];
+              if (MODE == 3 && c == 2 && aux.cs != nullptr) { double sn, cn; sincos(aux.x[t], &sn, &cn); aux.cs[i] = make_double2(cn, sn); }
+            }
+          }
         }
       }
     } else {
@@ -107,6 +114,7 @@ __global__ __launch_bounds__(128) void k_spmv(int n_poses, int npad, FactorView 
           part[o + 1] += vt * rq;
           part[o + 2] += dl * dl; part[o + 3] += xt * xt;
           aux.xc[t] = xt + dl;
+          if (MODE == 3 && a == 2 && aux.cs != nullptr) { double sn, cn; sincos(xt + dl, &sn, &cn); aux.cs[i] = make_double2(cn, sn); }
           if (!isfinite(vt)) part[o + 4] += 1.0;
         }
       }
@@ -130,7 +138,7 @@ int spmv_blocks(int npad) { return ((npad + 2) / 3 + 127) / 128; }
 
 void launch_spmv(hipStream_t st, int n_poses, int npad, const FactorView& fv, const LinView& lin, const double* scale,
                  double mu, double min_diag, double max_diag, const double* v, double* y) {
-  SpmvAux aux = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  SpmvAux aux = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipLaunchKernelGGL(k_spmv<0>, dim3(spmv_blocks(npad)), dim3(128), 0, st, n_poses, npad, fv, lin, scale, mu, min_diag,
                      max_diag, v, y, aux);
 }
@@ -138,22 +146,22 @@ void launch_spmv(hipStream_t st, int n_poses, int npad, const FactorView& fv, co
 void launch_spmv_residual(hipStream_t st, int n_poses, int npad, const FactorView& fv, const LinView& lin,
                           const double* scale, double mu, double min_diag, double max_diag, const double* v,
                           const double* rhs, double* r_out, double* partials) {
-  SpmvAux aux = {rhs, r_out, nullptr, nullptr, partials};
+  SpmvAux aux = {rhs, r_out, nullptr, nullptr, partials, nullptr};
   hipLaunchKernelGGL(k_spmv<1>, dim3(spmv_blocks(npad)), dim3(128), 0, st, n_poses, npad, fv, lin, scale, mu, min_diag,
                      max_diag, v, (double*)nullptr, aux);
 }
 
 void launch_spmv_residual_step(hipStream_t st, int n_poses, int npad, const FactorView& fv, const LinView& lin, const double* scale, double mu,
                                double min_diag, double max_diag, const double* v, const double* rhs, const double* x, double* q, double* xc,
-                               double* partials) {
-  SpmvAux aux = {rhs, nullptr, x, xc, partials};
+                               double* partials, double2* cs) {
+  SpmvAux aux = {rhs, nullptr, x, xc, partials, cs};
   hipLaunchKernelGGL(k_spmv<3>, dim3(spmv_blocks(npad)), dim3(128), 0, st, n_poses, npad, fv, lin, scale, mu, min_diag, max_diag, v, q, aux);
 }
 
 void launch_spmv_step(hipStream_t st, int n_poses, int npad, const FactorView& fv, const LinView& lin,
                       const double* scale, const double* dt, const double* rhs, const double* x, double* q, double* xc,
                       double* partials) {
-  SpmvAux aux = {rhs, nullptr, x, xc, partials};
+  SpmvAux aux = {rhs, nullptr, x, xc, partials, nullptr};
   hipLaunchKernelGGL(k_spmv<2>, dim3(spmv_blocks(npad)), dim3(128), 0, st, n_poses, npad, fv, lin, scale, 0.0, 0.0, 0.0, dt,
                      q, aux);
 }
