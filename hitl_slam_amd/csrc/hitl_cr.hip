@@ -637,6 +637,8 @@ struct CrStage {
   int prev_par, next_par;
   int np;         // slots per contribution array
   int nsl;        // LDS slots (local nodes 0 .. nsl-1 are addressable)
+  int nrhs;       // right-hand sides riding through the factorisation (0: factorise only)
+  size_t wstride; // doubles between consecutive right-hand sides in w / x
 };
 
 // workgroup barrier that orders LDS traffic only: the Dinv / Gl / Gr stores of a level are read by LATER launches, never by
@@ -657,20 +659,22 @@ __global__ __launch_bounds__(B >= 12 ? 512 : 1024) void k_cr_chunk(CrView cr, Cr
   double* sL = sD + (size_t)nsl * BB;                     // nsl tiles: L_u (coupling u <-> u - s)
   double* sPb = sL + (size_t)nsl * BB;                    // nsl tiles: P_b of an eliminated u
   double* sG = sPb + (size_t)nsl * BB;                    // per wave: Gl, Gr of the node it is eliminating (2 tiles)
-  double* sW = sG + (size_t)(blockDim.x >> 6) * 2 * BB;   // nsl vectors: right-hand side
-  double* sCa = sW + (size_t)nsl * B;                     // nsl vectors: Gl_u^T w_u (for a)
-  double* sCb = sCa + (size_t)nsl * B;                    // nsl vectors: Gr_u^T w_u (for b)
-  double* accR = sCb + (size_t)nsl * B;                   // tile: contributions to local node 0
+  const int NR = sg.nrhs;                                 // right-hand sides; vector v of local node u lives at [(v * nsl + u) * B]
+  double* sW = sG + (size_t)(blockDim.x >> 6) * 2 * BB;   // NR x nsl vectors: right-hand sides
+  double* sCa = sW + (size_t)NR * nsl * B;                // NR x nsl vectors: Gl_u^T w_u (for a)
+  double* sCb = sCa + (size_t)NR * nsl * B;               // NR x nsl vectors: Gr_u^T w_u (for b)
+  double* accR = sCb + (size_t)NR * nsl * B;              // tile: contributions to local node 0
   double* accL = accR + BB;                               // tile: contributions to local node M
-  double* accWR = accL + BB;                              // vectors
-  double* accWL = accWR + B;
+  double* accWR = accL + BB;                              // NR vectors
+  double* accWL = accWR + (size_t)NR * B;                 // NR vectors
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int wave = tid >> 6, lane = tid & 63, NW = nthr >> 6;
   const int64_t base = (int64_t)blockIdx.x * M;            // in stage nodes
   const int64_t nst = ((int64_t)cr.nsb + S - 1) / S;       // stage nodes alive: 0 .. nst-1
   // local slots that exist: u with base + u < nst
   const int u_last = (int)((nst - 1 - base < M) ? (nst - 1 - base) : M);     // >= 0
-  const bool has_w = (w != nullptr);
+  const bool has_w = (w != nullptr) && NR > 0;
+  const size_t pws = (size_t)4 * sg.np * B;               // doubles of one right-hand side's contribution arrays
   const double* PLp = cr.P + (size_t)(sg.prev_par * 2 + 0) * sg.np * BB;
   const double* PRp = cr.P + (size_t)(sg.prev_par * 2 + 1) * sg.np * BB;
   const double* WLp = cr.Pw + (size_t)(sg.prev_par * 2 + 0) * sg.np * B;
@@ -687,17 +691,18 @@ __global__ __launch_bounds__(B >= 12 ? 512 : 1024) void k_cr_chunk(CrView cr, Cr
     if (u == 0 && sg.has_prev && !sg.top) cr.D[g] = d;     // the left boundary stays alive: keep its folded value
   }
   if (has_w)
-    for (int e = tid; e < (u_last + 1) * B; e += nthr) {
-      const int u = e / B, q = e % B;
+    for (int e = tid; e < NR * (u_last + 1) * B; e += nthr) {
+      const int rv = e / ((u_last + 1) * B), e2 = e % ((u_last + 1) * B);
+      const int u = e2 / B, q = e2 % B;
       const int64_t sn = base + u;
-      const size_t g = (size_t)(sn * S) * B + q;
+      const size_t g = sg.wstride * rv + (size_t)(sn * S) * B + q;
       double v = w[g];
-      if (sg.has_prev) v = (v - WLp[(size_t)sn * B + q]) - WRp[(size_t)sn * B + q];
-      sW[e] = v;
+      if (sg.has_prev) v = (v - WLp[pws * rv + (size_t)sn * B + q]) - WRp[pws * rv + (size_t)sn * B + q];
+      sW[((size_t)rv * nsl + u) * B + q] = v;
       if (sg.has_prev && (u == 0 || u == M) == false) w[g] = v;          // interior: the back-substitution reads the folded w
       if (u == 0 && sg.has_prev && !sg.top) w[g] = v;
     }
-  for (int e = tid; e < 2 * BB + 2 * B; e += nthr) accR[e] = 0.0;   // accR, accL, accWR, accWL are contiguous
+  for (int e = tid; e < 2 * BB + 2 * NR * B; e += nthr) accR[e] = 0.0;   // accR, accL, accWR, accWL are contiguous
   lds_barrier();
   const int u_hi = sg.top ? u_last : ((u_last < M) ? u_last : M - 1);    // largest local node that may be eliminated
   for (int s = 1; s < M; s *= 2) {
@@ -734,12 +739,14 @@ __global__ __launch_bounds__(B >= 12 ? 512 : 1024) void k_cr_chunk(CrView cr, Cr
       //                                  g = 2: -L_b Gl        -> L_b in place (new coupling b <-> a)
       // The left operands are wave-uniform LDS reads per group.  In-place safety: every q-step reads column / row data of
       // L_u and L_b, all writes happen after the last q-step (program order within the wave).
-      double cw = 0.0;
       if (has_w && (grp == 2 || grp == 3)) {
-        const double* wu = sW + (size_t)u * B;
+        for (int rv = 0; rv < NR; ++rv) {
+          const double* wu = sW + ((size_t)rv * nsl + u) * B;
+          double cw = 0.0;
 #pragma unroll
-        for (int r = 0; r < B; ++r) cw += col[r] * wu[r];                          // (G^T w_u)[c]
-        if (grp == 2) sCa[(size_t)u * B + c] = cw; else sCb[(size_t)u * B + c] = cw;
+          for (int r = 0; r < B; ++r) cw += col[r] * wu[r];                        // (G^T w_u)[c]
+          if (grp == 2) sCa[((size_t)rv * nsl + u) * B + c] = cw; else sCb[((size_t)rv * nsl + u) * B + c] = cw;
+        }
       }
       double* Gs = sG + (size_t)wave * 2 * BB;
       if (grp == 2 || grp == 3) {
@@ -784,22 +791,25 @@ __global__ __launch_bounds__(B >= 12 ? 512 : 1024) void k_cr_chunk(CrView cr, Cr
       else sD[(size_t)j * BB + q] = (sD[(size_t)j * BB + q] - pl) - pr;
     }
     if (has_w)
-      for (int e = tid; e < nsv * B; e += nthr) {
-        const int j = 2 * s * (e / B), q = e % B;
+      for (int e = tid; e < NR * nsv * B; e += nthr) {
+        const int rv = e / (nsv * B), e2 = e % (nsv * B);
+        const int j = 2 * s * (e2 / B), q = e2 % B;
         if (j > u_last) continue;
         const bool hl_ = (j - s >= 1), hr_ = (j + s <= u_hi) && (j + s < M || sg.top);
-        const double pl = hl_ ? sCb[(size_t)(j - s) * B + q] : 0.0;
-        const double pr = hr_ ? sCa[(size_t)(j + s) * B + q] : 0.0;
-        if (j == 0) accWR[q] += pr;
-        else if (j == M) accWL[q] += pl;
-        else sW[(size_t)j * B + q] = (sW[(size_t)j * B + q] - pl) - pr;
+        const size_t vb = (size_t)rv * nsl;
+        const double pl = hl_ ? sCb[(vb + (j - s)) * B + q] : 0.0;
+        const double pr = hr_ ? sCa[(vb + (j + s)) * B + q] : 0.0;
+        if (j == 0) accWR[(size_t)rv * B + q] += pr;
+        else if (j == M) accWL[(size_t)rv * B + q] += pl;
+        else sW[(vb + j) * B + q] = (sW[(vb + j) * B + q] - pl) - pr;
       }
     lds_barrier();
     // the right-hand side of a node is final once it is eliminated: the back-substitution reads it from global memory
     if (has_w)
-      for (int e = tid; e < (M / (2 * s)) * B; e += nthr) {
-        const int u2 = 2 * s * (2 * (e / B) + 1), q = e % B;                       // nodes eliminated at the NEXT level
-        if (u2 <= u_hi && 2 * s < M) w[(size_t)((base + u2) * S) * B + q] = sW[(size_t)u2 * B + q];
+      for (int e = tid; e < NR * (M / (2 * s)) * B; e += nthr) {
+        const int rv = e / ((M / (2 * s)) * B), e2 = e % ((M / (2 * s)) * B);
+        const int u2 = 2 * s * (2 * (e2 / B) + 1), q = e2 % B;                     // nodes eliminated at the NEXT level
+        if (u2 <= u_hi && 2 * s < M) w[sg.wstride * rv + (size_t)((base + u2) * S) * B + q] = sW[((size_t)rv * nsl + u2) * B + q];
       }
   }
   if (!sg.top) {
@@ -816,11 +826,13 @@ __global__ __launch_bounds__(B >= 12 ? 512 : 1024) void k_cr_chunk(CrView cr, Cr
       if (u_last == M && base + M == nst - 1) PRn[c1 * BB + e] = 0.0;              // the last node has no chunk on its right
     }
     if (has_w)
-      for (int e = tid; e < B; e += nthr) {
-        WRn[c0 * B + e] = accWR[e];
-        if (blockIdx.x == 0) WLn[e] = 0.0;
-        if (u_last == M) WLn[c1 * B + e] = accWL[e];
-        if (u_last == M && base + M == nst - 1) WRn[c1 * B + e] = 0.0;
+      for (int e2 = tid; e2 < NR * B; e2 += nthr) {
+        const int rv = e2 / B, e = e2 % B;
+        const size_t vo = pws * rv;
+        WRn[vo + c0 * B + e] = accWR[e2];
+        if (blockIdx.x == 0) WLn[vo + e] = 0.0;
+        if (u_last == M) WLn[vo + c1 * B + e] = accWL[e2];
+        if (u_last == M && base + M == nst - 1) WRn[vo + c1 * B + e] = 0.0;
       }
     return;
   }
@@ -837,27 +849,33 @@ __global__ __launch_bounds__(B >= 12 ? 512 : 1024) void k_cr_chunk(CrView cr, Cr
     }
   }
   lds_barrier();
-  if (has_w && tid < B) {
-    const double wr = sW[tid] - accWR[tid];
-    w[tid] = wr;                                                                  // folded root right-hand side (cr_back reads Dinv_0 w_0)
-    sW[tid] = wr;
-  }
+  if (has_w)
+    for (int e = tid; e < NR * B; e += nthr) {
+      const int rv = e / B, q = e % B;
+      const double wr = sW[(size_t)rv * nsl * B + q] - accWR[e];
+      w[sg.wstride * rv + q] = wr;                                                // folded root right-hand side (cr_back reads Dinv_0 w_0)
+      sW[(size_t)rv * nsl * B + q] = wr;
+    }
   lds_barrier();
-  if (has_w && x != nullptr && tid < B) {
-    double v = 0.0;
+  if (has_w && x != nullptr)
+    for (int e = tid; e < NR * B; e += nthr) {
+      const int rv = e / B, q = e % B;
+      double v = 0.0;
 #pragma unroll
-    for (int c = 0; c < B; ++c) v += sL[tid * B + c] * sW[c];
-    x[tid] = v;
-  }
+      for (int c = 0; c < B; ++c) v += sL[q * B + c] * sW[(size_t)rv * nsl * B + c];
+      x[sg.wstride * rv + q] = v;
+    }
 }
 
 // Back-substitution of one stage: x is known at the chunk's two boundary nodes; thread (u, r) owns row r of interior
 // node u, fetches its three coefficient rows ONCE (all loads of the launch are in flight together), forms
 // v = (Dinv_u w_u)[r] and then only touches LDS: x_u[r] = v - Gl_u[r,:] x_{u-s} - Gr_u[r,:] x_{u+s}, level by level.
 template <int B>
-__global__ __launch_bounds__(1024) void k_cr_chunk_back(CrView cr, int S, int M, int top, const double* __restrict__ w, double* __restrict__ x) {
+__global__ __launch_bounds__(1024) void k_cr_chunk_back(CrView cr, int S, int M, int top, const double* __restrict__ w, double* __restrict__ x, size_t wstride) {
   extern __shared__ double sx[];                         // (M + 1) * B
   const int tid = threadIdx.x;
+  w += wstride * blockIdx.y;                             // one right-hand side per workgroup row
+  x += wstride * blockIdx.y;
   const int64_t base = (int64_t)blockIdx.x * M;
   const int64_t nst = ((int64_t)cr.nsb + S - 1) / S;
   const int u_last = (int)((nst - 1 - base < M) ? (nst - 1 - base) : M);
@@ -902,8 +920,9 @@ __global__ __launch_bounds__(1024) void k_cr_chunk_back(CrView cr, int S, int M,
 
 struct CrPlan { CrStage st[8]; int n; };
 
-static size_t cr_chunk_lds_bytes(int M, int B, int threads) {
-  return sizeof(double) * ((size_t)(M + 1) * (3 * B * B + 3 * B) + (size_t)(threads / 64) * 2 * B * B + 2 * B * B + 2 * B);
+static size_t cr_chunk_lds_bytes(int M, int B, int threads, int nrhs) {
+  const int nr = nrhs > 0 ? nrhs : 1;
+  return sizeof(double) * ((size_t)(M + 1) * (3 * B * B + 3 * B * nr) + (size_t)(threads / 64) * 2 * B * B + 2 * B * B + 2 * B * nr);
 }
 static int cr_chunk_threads(int M, int B) { return (M <= 2) ? 64 : (M <= 4) ? 128 : (M <= 8) ? 256 : (M >= 32 && B < 12) ? 1024 : 512; }
 
@@ -912,7 +931,7 @@ static int cr_chunk_threads(int M, int B) { return (M <= 2) ? 64 : (M <= 4) ? 12
 // faster: a node costs a whole wave's instruction stream either way; chunks of 4 or 8 at 2 waves per workgroup: 56 / 68 us for
 // the first stage against 54 us for chunks of 16.)  HITL_CR_PLAN="2,2,16,32" (development) overrides
 // the chunk sizes of the first stages.
-static CrPlan cr_plan(int nsb, int B, int np) {
+static CrPlan cr_plan(int nsb, int B, int np, int nrhs, size_t wstride) {
   CrPlan pl;
   pl.n = 0;
   const size_t lds_cap = 128 * 1024;
@@ -929,11 +948,13 @@ static CrPlan cr_plan(int nsb, int B, int np) {
     const int64_t alive = ((int64_t)nsb + S - 1) / S;
     int Mtop = 2;
     while (Mtop < alive) Mtop *= 2;                        // interior u = 1 .. alive-1 < Mtop
-    const bool fits_top = alive <= 40 && cr_chunk_lds_bytes((int)alive, B, cr_chunk_threads(64, B)) <= lds_cap;
+    const bool fits_top = alive <= 40 && cr_chunk_lds_bytes((int)alive, B, cr_chunk_threads(64, B), nrhs) <= lds_cap;
     CrStage& g = pl.st[pl.n++];
-    g.S = S; g.has_prev = prev ? 1 : 0; g.prev_par = par; g.next_par = par ^ 1; g.np = np;
+    g.S = S; g.has_prev = prev ? 1 : 0; g.prev_par = par; g.next_par = par ^ 1; g.np = np; g.nrhs = nrhs; g.wstride = wstride;
     if (fits_top || pl.n == 8) { g.M = Mtop; g.top = 1; g.nsl = (int)alive + 1; break; }
     int M = (pl.n == 1) ? 16 : 32;       // measured on C4 (tools/cr_plans.sh): 16,32,top = 111 us; 2,2,16,.. = 117; 2,2,2,32,.. = 125
+    if (cr_chunk_lds_bytes(M, B, cr_chunk_threads(M, B), nrhs) > lds_cap) M = 16;      // many right-hand sides (submap solve): smaller chunks
+    if (cr_chunk_lds_bytes(M, B, cr_chunk_threads(M, B), nrhs) > lds_cap) M = 8;
     if ((size_t)pl.n <= forced.size() && forced[pl.n - 1] >= 2) M = forced[pl.n - 1];
     g.M = M; g.top = 0; g.nsl = g.M + 1;
     S *= g.M; par ^= 1; prev = true;
@@ -944,20 +965,24 @@ static CrPlan cr_plan(int nsb, int B, int np) {
 int cr_contrib_slots(int nsb) { return nsb / 2 + 3; }     // boundary nodes of the finest chunk stage (M = 2)
 
 template <int B>
-static bool cr_factor_fused(hipStream_t st, const CrView& cr, double* w, double* x) {
+static bool cr_factor_fused(hipStream_t st, const CrView& cr, double* w, double* x, int nrhs, size_t wstride) {
   if (cr.P == nullptr || cr.Pw == nullptr) return false;
+  if (w == nullptr) nrhs = 0;
+  if (nrhs > cr.pw_rhs) return false;                     // contribution arrays are sized for cr.pw_rhs right-hand sides
   static bool raised = false;
   if (!raised) {
     raised = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cr_chunk<B>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess;
     if (!raised) { (void)hipGetLastError(); return false; }
   }
-  const CrPlan pl = cr_plan(cr.nsb, B, cr.np);
+  const CrPlan pl = cr_plan(cr.nsb, B, cr.np, nrhs, wstride);
+  for (int t = 0; t < pl.n; ++t)                          // every stage must fit its LDS budget, else the level-per-launch path
+    if (cr_chunk_lds_bytes(pl.st[t].nsl - 1, B, cr_chunk_threads(pl.st[t].M, B), nrhs) > 128 * 1024) return false;
   for (int t = 0; t < pl.n; ++t) {
     const CrStage& g = pl.st[t];
     const int64_t alive = ((int64_t)cr.nsb + g.S - 1) / g.S;
     const int chunks = g.top ? 1 : (int)((alive - 1 + g.M - 1) / g.M);       // chunks with at least one interior or boundary-M node
     const int thr = cr_chunk_threads(g.M, B);
-    const size_t lds = cr_chunk_lds_bytes(g.nsl - 1, B, thr);
+    const size_t lds = cr_chunk_lds_bytes(g.nsl - 1, B, thr, nrhs);
     hipLaunchKernelGGL(k_cr_chunk<B>, dim3(chunks > 0 ? chunks : 1), dim3(thr), lds, st, cr, g, w, x);
   }
   if (w != nullptr && x != nullptr) {
@@ -969,7 +994,7 @@ static bool cr_factor_fused(hipStream_t st, const CrView& cr, double* w, double*
       int thr = (g.M - (g.top ? 0 : 1)) * B;
       thr = (thr + 63) & ~63;
       if (thr > 1024) return false;                                          // never with the stage sizes above (M <= 64, B <= 12)
-      hipLaunchKernelGGL(k_cr_chunk_back<B>, dim3(chunks), dim3(thr), sizeof(double) * (g.M + 1) * B, st, cr, g.S, g.M, g.top, w, x);
+      hipLaunchKernelGGL(k_cr_chunk_back<B>, dim3(chunks, nrhs), dim3(thr), sizeof(double) * (g.M + 1) * B, st, cr, g.S, g.M, g.top, w, x, wstride);
     }
   }
   return true;
@@ -980,7 +1005,7 @@ template <int B>
 static void cr_factor_t(hipStream_t st, const CrView& cr, double* w, double* x, int nrhs, size_t stride) {
   const int nr = (w != nullptr) ? nrhs : 0;
   static const bool legacy = std::getenv("HITL_CR_LEGACY") != nullptr;       // development switch: the level-per-launch path
-  if (!legacy && nr <= 1 && cr_factor_fused<B>(st, cr, nr ? w : nullptr, nr ? x : nullptr)) return;
+  if (!legacy && cr_factor_fused<B>(st, cr, nr ? w : nullptr, nr ? x : nullptr, nr, stride)) return;
   const int s_top = cr_top_start(cr.nsb, B, nr);
   if (s_top > 1) {
     const int n_elim = (cr.nsb - 1 + 1) / 2;

@@ -73,8 +73,9 @@ struct CrView {             // block-tridiagonal system + cyclic-reduction facto
   double* Gr;                 // nsb*B*B  Dinv_k * L_{k+s}^T
   // fused factorisation: what a chunk's interior contributes to its two boundary nodes, handed from stage to stage
   double* P = nullptr;        // [parity 2][left/right 2][np][B*B]
-  double* Pw = nullptr;       // [parity 2][left/right 2][np][B]
+  double* Pw = nullptr;       // [rhs pw_rhs][parity 2][left/right 2][np][B]
   int np = 0;                 // cr_contrib_slots(nsb)
+  int pw_rhs = 1;             // right-hand sides Pw is sized for
 };
 int cr_contrib_slots(int nsb);
 

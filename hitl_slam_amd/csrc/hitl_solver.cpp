@@ -157,7 +157,8 @@ int ensure_work(hitl_solver* s, int Wb) {
   TRY(s->crD.resize(bb)); TRY(s->crL.resize(bb)); TRY(s->crDinv.resize(bb)); TRY(s->crGl.resize(bb)); TRY(s->crGr.resize(bb));
   {
     const size_t np = (size_t)cr_contrib_slots(s->nsb);
-    TRY(s->crP.resize(4 * np * s->B * s->B)); TRY(s->crPw.resize(4 * np * s->B));
+    s->cr_pw_rhs = (s->world > 1) ? 1 + 6 * Wb : 1;       // the submap solve pushes its interface columns through the factorisation
+    TRY(s->crP.resize(4 * np * s->B * s->B)); TRY(s->crPw.resize((size_t)s->cr_pw_rhs * 4 * np * s->B));
   }
   s->wb_Wb = Wb; s->wb_n = n; s->wb_pairs = s->n_pairs; s->wb_offband = s->n_offband;
   return HITL_OK;

@@ -96,6 +96,7 @@ struct hitl_solver {
   DevArray<double> pairRJ[2], Hband[2], gvec[2], obblk[2], lin_partials[2];
   DevArray<double2> pose_cs;        // (cos, sin) of every pose at the state being linearised
   DevArray<double> crD, crL, crDinv, crGl, crGr, crP, crPw;
+  int cr_pw_rhs = 1;                // right-hand sides crPw is sized for (1 + 6 * band on a submap rank)
 
   MapView map_view() const {
     MapView m;
@@ -116,7 +117,7 @@ struct hitl_solver {
   CrView cr_view() {
     CrView c;
     c.nsb = nsb; c.B = B; c.D = crD.p; c.L = crL.p; c.Dinv = crDinv.p; c.Gl = crGl.p; c.Gr = crGr.p;
-    c.P = crP.p; c.Pw = crPw.p; c.np = cr_contrib_slots(nsb);
+    c.P = crP.p; c.Pw = crPw.p; c.np = cr_contrib_slots(nsb); c.pw_rhs = cr_pw_rhs;
     return c;
   }
 };
