@@ -213,7 +213,7 @@ class SolverBase(object):
         pin = _as(poses_xyt, np.float32).reshape(-1)
         seg = _as(seg_xy8, np.float32).reshape(-1)
         assert seg.size == 8
-        counts = np.zeros((self.n_poses, 2), np.int32)
+        counts = np.zeros((len(self.obs_offset) - 1, 2), np.int32)      # resident poses (== n_poses on a single GPU)
         n_obs = int(self.obs_offset[-1])
         mask = np.zeros(max(n_obs, 1), np.uint8) if want_mask else None
         f = self._scan_fn("obs_sets")

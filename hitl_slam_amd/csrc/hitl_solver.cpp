@@ -806,8 +806,9 @@ namespace {
 int obs_scan_prepare(hitl_solver* s, const float* poses, DevArray<float>* T4) {
   if (!s || !poses) return fail(HITL_ERR_INVALID_ARGUMENT, "observation scan: null argument");
   if (s->n <= 0) return fail(HITL_ERR_NOT_READY, "observation scan before set_map");
-  if (s->world > 1) return fail(HITL_ERR_UNSUPPORTED, "observation scans are single-GPU entry points");
   HIP_TRY(hipSetDevice(s->device));
+  // submap rank: poses is the GLOBAL array; the rank's resident scans (halos included) start at global pose g_begin - hl
+  poses += 3 * (size_t)(s->g_begin - s->hl);
   std::vector<float> t((size_t)4 * s->n);
   for (int i = 0; i < s->n; ++i) {      // Rotation2Df(angle), Translation2f: fp32 trig on the host
     t[4 * i] = cosf(poses[3 * i + 2]); t[4 * i + 1] = sinf(poses[3 * i + 2]); t[4 * i + 2] = poses[3 * i]; t[4 * i + 3] = poses[3 * i + 1];

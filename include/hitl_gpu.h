@@ -231,7 +231,10 @@ int hitl_solver_evaluate_jacobian(hitl_solver*, const float* poses_xyt, double* 
  * hitl_solver_observation_sets == EMInput::EstablishObservationSets (EMinput.cpp:281-323) with
  *     distToLineSeg (:268-279): seg_xy8 = selected_points_[0..3]; counts[2*i + s] = number of
  *     observations of pose i within `threshold` (0.03 in the reference) of selection s; mask (may be
- *     NULL) gets bit s set per observation.  The caller keeps poses with counts > 5 (:309-316). */
+ *     NULL) gets bit s set per observation.  The caller keeps poses with counts > 5 (:309-316).
+ * Submap ranks (world_size > 1): poses_xyt is the GLOBAL pose array; the three calls run over the rank's RESIDENT scans --
+ * global poses [begin - hl, end + hh), halos included, in that order -- so world_x / world_y / mask hold one value per
+ * resident observation and counts two per resident pose; `seen` flags are per rank (the caller ORs them). */
 int hitl_solver_transform_scans(hitl_solver*, const float* poses_xyt, float* world_x, float* world_y);
 int hitl_solver_verify_points(hitl_solver*, const float* poses_xyt, int32_t n_points, const float* points_xy,
                               float threshold, int32_t* seen);

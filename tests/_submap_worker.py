@@ -43,8 +43,16 @@ def main():
     own = (corr[0] >= b) & (corr[0] < e)             # every pair is reported by the rank owning its source pose
     lens = corr[2][1:] - corr[2][:-1]
     poses, summ = s.solve(mode, prob.init)
+    # observation scans on a submap rank: over its resident scans (global poses [lo, hi)), global pose array in
+    wx, wy = s.transform_scans(prob.init)
+    probe = np.array([[wx[5], wy[5]], [wx[-7], wy[-7]], [1e6, 1e6]], np.float32)
+    seen = s.verify_points(prob.init, probe, 0.05)
+    seg = np.array([wx[3], wy[3], wx[40], wy[40], wx[60], wy[60], wx[90], wy[90]], np.float32)
+    counts, mask = s.observation_sets(prob.init, seg, 0.03)
     res = dict(rank=rank, begin=b, end=e, poses=poses.tolist(), summary=summ.as_dict(),
-               pairs=[corr[0][own].tolist(), corr[1][own].tolist()], n_matches=int(lens[own].sum()))
+               pairs=[corr[0][own].tolist(), corr[1][own].tolist()], n_matches=int(lens[own].sum()),
+               scans=dict(lo=lo, hi=hi, wx=wx.tolist(), wy=wy.tolist(), probe=probe.tolist(), seen=seen.tolist(), seg=seg.tolist(),
+                          counts=counts.tolist(), mask_sum=int(mask.sum())))
     json.dump(res, open("%s.%d" % (out_path, rank), "w"))
     s.close()
     dist.destroy_process_group()

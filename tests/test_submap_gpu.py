@@ -52,6 +52,18 @@ def test_submaps_equal_the_global_solve(tmp_path, mode, ppf, world, moments):
     if world == 3:
         assert res[1]["begin"] == 40 and res[1]["end"] == 80   # the middle rank has halos on both sides
     assert sum(x["n_matches"] for x in res) == len(ops[3])
+    # observation scans on the submap ranks == the same calls of the oracle on the whole map, restricted to the rank's
+    # resident poses [lo, hi) (bit for bit: fp32, host trigonometry)
+    M = 48
+    owx, owy = o.transform_scans(prob.init)
+    for x in res:
+        sc = x["scans"]
+        sl = slice(sc["lo"] * M, sc["hi"] * M)
+        assert np.array_equal(np.array(sc["wx"], np.float32), owx[sl]) and np.array_equal(np.array(sc["wy"], np.float32), owy[sl])
+        seen = o.verify_points(prob.init, np.array(sc["probe"], np.float32), 0.05)
+        assert sc["seen"][0] == 1 and sc["seen"][1] == 1 and sc["seen"][2] == 0 and seen[0] == 1 and seen[2] == 0
+        oc, om = o.observation_sets(prob.init, np.array(sc["seg"], np.float32), 0.03)
+        assert np.array_equal(np.array(sc["counts"], np.int32), oc[sc["lo"]:sc["hi"]]) and sc["mask_sum"] == int(om[sl].sum())
     po, so = o.solve(mode, prob.init)
     for x in res:
         sm = x["summary"]
