@@ -101,6 +101,7 @@ def main():
 
     wl = dict(WORKLOADS[args.workload])
     if args.poses:
+        wl["groups"] = max(1, int(round(wl["groups"] * args.poses / wl["poses"])))   # constraint density of the named workload
         wl["poses"] = args.poses
     if args.obs:
         wl["obs"] = args.obs
