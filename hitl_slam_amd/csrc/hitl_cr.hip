@@ -918,6 +918,101 @@ __global__ __launch_bounds__(1024) void k_cr_chunk_back(CrView cr, int S, int M,
   }
 }
 
+// Forward sweep of one stage on STORED factors (a new right-hand side against an existing factorisation: the PCG
+// preconditioner): the chunk's Gl / Gr tiles and right-hand side come into LDS in one round of loads, then every local
+// level is   c_a = Gl_u^T w_u -> node a,   c_b = Gr_u^T w_u -> node b   for the eliminated u, a barrier, and the survivors'
+// subtraction (left neighbour first) -- the same order of operations as the factorising kernel, so a solve through
+// k_cr_chunk and one through this kernel agree bit for bit.  Boundary contributions travel through Pw like there.
+template <int B>
+__global__ __launch_bounds__(512) void k_cr_chunk_fwd(CrView cr, CrStage sg, double* w, double* x) {
+  extern __shared__ double lds[];
+  constexpr int BB = B * B;
+  const int M = sg.M, S = sg.S, nsl = sg.nsl;
+  double* sGl = lds;                                      // nsl tiles
+  double* sGr = sGl + (size_t)nsl * BB;                   // nsl tiles
+  double* sW = sGr + (size_t)nsl * BB;                    // nsl vectors
+  double* sCa = sW + (size_t)nsl * B;
+  double* sCb = sCa + (size_t)nsl * B;
+  double* accWR = sCb + (size_t)nsl * B;
+  double* accWL = accWR + B;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int64_t base = (int64_t)blockIdx.x * M;
+  const int64_t nst = ((int64_t)cr.nsb + S - 1) / S;
+  const int u_last = (int)((nst - 1 - base < M) ? (nst - 1 - base) : M);
+  const int u_hi = sg.top ? u_last : ((u_last < M) ? u_last : M - 1);
+  const double* WLp = cr.Pw + (size_t)(sg.prev_par * 2 + 0) * sg.np * B;
+  const double* WRp = cr.Pw + (size_t)(sg.prev_par * 2 + 1) * sg.np * B;
+  for (int e = tid; e < u_hi * BB; e += nthr) {            // interior nodes 1 .. u_hi
+    const int u = 1 + e / BB, q = e % BB;
+    const size_t g = (size_t)((base + u) * S) * BB + q;
+    sGl[(size_t)u * BB + q] = cr.Gl[g];
+    sGr[(size_t)u * BB + q] = cr.Gr[g];
+  }
+  for (int e = tid; e < (u_last + 1) * B; e += nthr) {
+    const int u = e / B, q = e % B;
+    const int64_t sn = base + u;
+    const size_t g = (size_t)(sn * S) * B + q;
+    double v = w[g];
+    if (sg.has_prev) v = (v - WLp[(size_t)sn * B + q]) - WRp[(size_t)sn * B + q];
+    sW[e] = v;
+    if (sg.has_prev && (u == 0 || u == M) == false) w[g] = v;
+    if (u == 0 && sg.has_prev && !sg.top) w[g] = v;
+  }
+  for (int e = tid; e < 2 * B; e += nthr) accWR[e] = 0.0;
+  lds_barrier();
+  for (int s = 1; s < M; s *= 2) {
+    const int nel = M / (2 * s);                           // eliminated nodes u = s (2 k + 1)
+    for (int e = tid; e < nel * 2 * B; e += nthr) {
+      const int u = s * (2 * (e / (2 * B)) + 1), c = e % B, which = (e / B) & 1;
+      if (u > u_hi) continue;
+      const double* G = (which ? sGr : sGl) + (size_t)u * BB;
+      const double* wu = sW + (size_t)u * B;
+      double cw = 0.0;
+#pragma unroll
+      for (int r = 0; r < B; ++r) cw += G[r * B + c] * wu[r];
+      (which ? sCb : sCa)[(size_t)u * B + c] = cw;
+    }
+    lds_barrier();
+    const int nsv = M / (2 * s) + 1;
+    for (int e = tid; e < nsv * B; e += nthr) {
+      const int j = 2 * s * (e / B), q = e % B;
+      if (j > u_last) continue;
+      const bool hl_ = (j - s >= 1), hr_ = (j + s <= u_hi) && (j + s < M || sg.top);
+      const double pl = hl_ ? sCb[(size_t)(j - s) * B + q] : 0.0;
+      const double pr = hr_ ? sCa[(size_t)(j + s) * B + q] : 0.0;
+      if (j == 0) accWR[q] += pr;
+      else if (j == M) accWL[q] += pl;
+      else sW[(size_t)j * B + q] = (sW[(size_t)j * B + q] - pl) - pr;
+    }
+    lds_barrier();
+    for (int e = tid; e < (M / (2 * s)) * B; e += nthr) {
+      const int u2 = 2 * s * (2 * (e / B) + 1), q = e % B;
+      if (u2 <= u_hi && 2 * s < M) w[(size_t)((base + u2) * S) * B + q] = sW[(size_t)u2 * B + q];
+    }
+  }
+  if (!sg.top) {
+    double* WLn = cr.Pw + (size_t)(sg.next_par * 2 + 0) * sg.np * B;
+    double* WRn = cr.Pw + (size_t)(sg.next_par * 2 + 1) * sg.np * B;
+    const size_t c0 = (size_t)blockIdx.x, c1 = c0 + 1;
+    for (int e = tid; e < B; e += nthr) {
+      WRn[c0 * B + e] = accWR[e];
+      if (blockIdx.x == 0) WLn[e] = 0.0;
+      if (u_last == M) WLn[c1 * B + e] = accWL[e];
+      if (u_last == M && base + M == nst - 1) WRn[c1 * B + e] = 0.0;
+    }
+    return;
+  }
+  for (int e = tid; e < B; e += nthr) { const double wr = sW[e] - accWR[e]; w[e] = wr; sW[e] = wr; }
+  lds_barrier();
+  if (x != nullptr)
+    for (int e = tid; e < B; e += nthr) {
+      double v = 0.0;
+#pragma unroll
+      for (int c = 0; c < B; ++c) v += cr.Dinv[e * B + c] * sW[c];
+      x[e] = v;
+    }
+}
+
 struct CrPlan { CrStage st[8]; int n; };
 
 static size_t cr_chunk_lds_bytes(int M, int B, int threads, int nrhs) {
@@ -996,6 +1091,37 @@ static bool cr_factor_fused(hipStream_t st, const CrView& cr, double* w, double*
       if (thr > 1024) return false;                                          // never with the stage sizes above (M <= 64, B <= 12)
       hipLaunchKernelGGL(k_cr_chunk_back<B>, dim3(chunks, nrhs), dim3(thr), sizeof(double) * (g.M + 1) * B, st, cr, g.S, g.M, g.top, w, x, wstride);
     }
+  }
+  return true;
+}
+
+// x = M^-1 w through the stored factors, one right-hand side, fused stages (3 + 3 launches instead of ~30)
+template <int B>
+static bool cr_solve_fused(hipStream_t st, const CrView& cr, double* w, double* x) {
+  if (cr.P == nullptr || cr.Pw == nullptr) return false;
+  static bool raised = false;
+  if (!raised) {
+    raised = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cr_chunk_fwd<B>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess;
+    if (!raised) { (void)hipGetLastError(); return false; }
+  }
+  const CrPlan pl = cr_plan(cr.nsb, B, cr.np, 1, 0);
+  for (int t = 0; t < pl.n; ++t) {
+    const CrStage& g = pl.st[t];
+    const int64_t alive = ((int64_t)cr.nsb + g.S - 1) / g.S;
+    const int chunks = g.top ? 1 : (int)((alive - 1 + g.M - 1) / g.M);
+    const size_t lds = sizeof(double) * ((size_t)g.nsl * (2 * B * B + 3 * B) + 2 * B);
+    if (lds > 128 * 1024) return false;
+    hipLaunchKernelGGL(k_cr_chunk_fwd<B>, dim3(chunks > 0 ? chunks : 1), dim3(256), lds, st, cr, g, w, x);
+  }
+  for (int t = pl.n - 1; t >= 0; --t) {
+    const CrStage& g = pl.st[t];
+    const int64_t alive = ((int64_t)cr.nsb + g.S - 1) / g.S;
+    if (alive <= 1) continue;
+    const int chunks = g.top ? 1 : (int)((alive - 1 + g.M - 1) / g.M);
+    int thr = (g.M - (g.top ? 0 : 1)) * B;
+    thr = (thr + 63) & ~63;
+    if (thr > 1024) return false;
+    hipLaunchKernelGGL(k_cr_chunk_back<B>, dim3(chunks, 1), dim3(thr), sizeof(double) * (g.M + 1) * B, st, cr, g.S, g.M, g.top, w, x, (size_t)0);
   }
   return true;
 }
@@ -1085,7 +1211,17 @@ void launch_cr_solve_multi(hipStream_t st, const CrView& cr, double* w, double* 
 }
 
 void launch_cr_solve(hipStream_t st, const CrView& cr, double* w, double* x) {
-  launch_cr_solve_multi(st, cr, w, x, 1, 0);
+  static const bool legacy = std::getenv("HITL_CR_LEGACY") != nullptr;
+  bool done = false;
+  if (!legacy) {
+    switch (cr.B) {
+      case 3: done = cr_solve_fused<3>(st, cr, w, x); break;
+      case 6: done = cr_solve_fused<6>(st, cr, w, x); break;
+      case 9: done = cr_solve_fused<9>(st, cr, w, x); break;
+      default: done = cr_solve_fused<12>(st, cr, w, x); break;
+    }
+  }
+  if (!done) launch_cr_solve_multi(st, cr, w, x, 1, 0);
 }
 
 // ===========================================================================================

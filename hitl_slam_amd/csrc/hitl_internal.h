@@ -130,6 +130,9 @@ void launch_spmv_step(hipStream_t st, int n_poses, int npad, const FactorView& f
                       double* partials);
 // out[k] = a_k . b_k for k < ndots (<= 4)
 void launch_dots(hipStream_t st, int n, int ndots, const double* const* a, const double* const* b, double* out);
+// PCG updates with device-resident scalars s[] = (r.z, previous r.z, p.q, r.r, breakdown flag)
+void launch_pcg_update_p(hipStream_t st, int n, const double* z, double* p, const double* s, bool first);
+void launch_pcg_update_xr(hipStream_t st, int n, const double* p, const double* q, double* x, double* r, double* s);
 // y = alpha*x + beta*y
 void launch_axpby(hipStream_t st, int n, double alpha, const double* x, double beta, double* y);
 void launch_copy(hipStream_t st, int n, const double* src, double* dst);

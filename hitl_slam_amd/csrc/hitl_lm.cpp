@@ -202,42 +202,39 @@ static int linear_solve_and_step(hitl_solver* s, const FactorView& fv, int buf, 
     if (!(rr == rr) || rr > guard * guard * bb) *ok = false;   // the factorisation broke down
     return HITL_OK;
   }
-  // off-band pose pairs present: PCG on the full matrix from x0, preconditioned by the band factorisation
+  // off-band pose pairs present: PCG on the full matrix from x0, preconditioned by the band factorisation.  The
+  // iteration runs on the device: its scalars (r.z, p.q, r.r) never leave d_scalars, a CG iteration is 13 queued
+  // launches (copy, 3 + 3 fused preconditioner stages, 3 dots, 2 updates, one band product), and the host looks at r.r
+  // only once per kPcgBatch iterations (up to kPcgBatch - 1 iterations past the tolerance: harmless).
   double rr, bb;
   TRY(read_step_partials(s, &rr, &bb, nullptr));
   const double target = tol * tol * bb;
   if (!(rr == rr)) { *ok = false; return HITL_OK; }
-  double rz_old = 0.0;
-  for (int it = 0; it < s->opt.max_linear_iterations && rr > target; ++it) {
-    launch_copy(st, npad, s->rv.p, s->wv.p);
-    launch_cr_solve(st, cr, s->wv.p, s->zv.p);
-    const double* a1[4] = {s->rv.p, s->rv.p, s->rv.p, s->rv.p};
-    const double* b1[4] = {s->zv.p, s->zv.p, s->zv.p, s->zv.p};
-    launch_dots(st, npad, 1, a1, b1, s->d_scalars.p + 8);
-    HIP_TRY(hipMemcpyAsync(s->h_scalars + 8, s->d_scalars.p + 8, sizeof(double), hipMemcpyDeviceToHost, st));
+  constexpr int kPcgBatch = 4;
+  double* sc = s->d_scalars.p + 8;           // (r.z, previous r.z, p.q, r.r, breakdown)
+  HIP_TRY(hipMemsetAsync(sc, 0, sizeof(double) * 5, st));
+  for (int it = 0; it < s->opt.max_linear_iterations && rr > target;) {
+    const int nb = std::min(kPcgBatch, s->opt.max_linear_iterations - it);
+    for (int k = 0; k < nb; ++k, ++it) {
+      launch_copy(st, npad, s->rv.p, s->wv.p);
+      launch_cr_solve(st, cr, s->wv.p, s->zv.p);                                   // z = M^-1 r
+      const double* a1[4] = {s->rv.p, s->rv.p, s->rv.p, s->rv.p};
+      const double* b1[4] = {s->zv.p, s->zv.p, s->zv.p, s->zv.p};
+      launch_dots(st, npad, 1, a1, b1, sc + 0);                                    // r.z
+      launch_pcg_update_p(st, npad, s->zv.p, s->pv.p, sc, it == 0);                // p = z + beta p
+      launch_spmv(st, s->n, npad, fv, lv, s->scale.p, mu, mind, maxd, s->pv.p, s->qv.p);   // q = A p
+      const double* a2[4] = {s->pv.p, s->pv.p, s->pv.p, s->pv.p};
+      const double* b2[4] = {s->qv.p, s->qv.p, s->qv.p, s->qv.p};
+      launch_dots(st, npad, 1, a2, b2, sc + 2);                                    // p.q
+      launch_pcg_update_xr(st, npad, s->pv.p, s->qv.p, s->dt.p, s->rv.p, sc);      // x += alpha p, r -= alpha q
+      const double* a3[4] = {s->rv.p, s->rv.p, s->rv.p, s->rv.p};
+      launch_dots(st, npad, 1, a3, a3, sc + 3);                                    // r.r
+    }
+    *iters += nb;
+    HIP_TRY(hipMemcpyAsync(s->h_scalars + 8, sc, sizeof(double) * 5, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    const double rz = s->h_scalars[8];
-    if (it == 0) launch_copy(st, npad, s->zv.p, s->pv.p);
-    else launch_axpby(st, npad, 1.0, s->zv.p, rz / rz_old, s->pv.p);
-    rz_old = rz;
-    launch_spmv(st, s->n, npad, fv, lv, s->scale.p, mu, mind, maxd, s->pv.p, s->qv.p);
-    const double* a2[4] = {s->pv.p, s->rv.p, s->pv.p, s->pv.p};
-    const double* b2[4] = {s->qv.p, s->rv.p, s->qv.p, s->qv.p};
-    launch_dots(st, npad, 1, a2, b2, s->d_scalars.p + 8);
-    HIP_TRY(hipMemcpyAsync(s->h_scalars + 8, s->d_scalars.p + 8, sizeof(double), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    const double pq = s->h_scalars[8];
-    if (!(pq > 0.0)) { *ok = false; return HITL_OK; }
-    const double alpha = rz / pq;
-    launch_axpby(st, npad, alpha, s->pv.p, 1.0, s->dt.p);
-    launch_axpby(st, npad, -alpha, s->qv.p, 1.0, s->rv.p);
-    const double* a3[4] = {s->rv.p, s->rv.p, s->rv.p, s->rv.p};
-    launch_dots(st, npad, 1, a3, a3, s->d_scalars.p + 8);
-    HIP_TRY(hipMemcpyAsync(s->h_scalars + 8, s->d_scalars.p + 8, sizeof(double), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    rr = s->h_scalars[8];
-    ++*iters;
-    if (!(rr == rr)) { *ok = false; return HITL_OK; }
+    rr = s->h_scalars[8 + 3];
+    if (!(rr == rr) || s->h_scalars[8 + 4] != 0.0) { *ok = false; return HITL_OK; }
   }
   launch_spmv_step(st, s->n, npad, fv, lv, s->scale.p, s->dt.p, s->rhs.p, xcur, s->qv.p, xcand, s->step_partials.p);
   HIP_TRY(hipGetLastError());

@@ -265,6 +265,37 @@ void launch_dots(hipStream_t st, int n, int ndots, const double* const* a, const
   hipLaunchKernelGGL(k_dots, dim3(1), dim3(kRedBlock), 0, st, n, ndots, args, out);
 }
 
+// ---- PCG updates whose scalars stay on the device (no host round trip inside a CG iteration) ----
+// slots of the scalar block s[]: 0 = r.z, 1 = previous r.z, 2 = p.q, 3 = r.r, 4 = breakdown flag
+// p = z + (rz / rz_old) p      (first: p = z)
+__global__ void k_pcg_update_p(int n, const double* __restrict__ z, double* __restrict__ p, const double* __restrict__ s, int first) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const double beta = (first || s[1] == 0.0) ? 0.0 : s[0] / s[1];
+  p[t] = z[t] + (first ? 0.0 : beta * p[t]);
+}
+
+// alpha = rz / pq;  x += alpha p;  r -= alpha q;  rz_old <- rz   (pq <= 0 or NaN: breakdown flag, no update)
+__global__ void k_pcg_update_xr(int n, const double* __restrict__ p, const double* __restrict__ q, double* __restrict__ x, double* __restrict__ r,
+                                double* __restrict__ s) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const double rz = s[0], pq = s[2];
+  const bool ok = pq > 0.0;
+  const double alpha = ok ? rz / pq : 0.0;
+  if (t < n) { x[t] += alpha * p[t]; r[t] -= alpha * q[t]; }
+  // s[1] is read by the NEXT k_pcg_update_p only.  p.q <= 0 with r.z != 0 is a breakdown (the matrix is SPD); with
+  // r.z == 0 the residual is exactly zero (an iteration past convergence inside a batch) and nothing is left to do.
+  if (t == 0) { s[1] = rz; if (!ok && rz != 0.0) s[4] = 1.0; }
+}
+
+void launch_pcg_update_p(hipStream_t st, int n, const double* z, double* p, const double* s, bool first) {
+  hipLaunchKernelGGL(k_pcg_update_p, dim3((n + 255) / 256), dim3(256), 0, st, n, z, p, s, first ? 1 : 0);
+}
+
+void launch_pcg_update_xr(hipStream_t st, int n, const double* p, const double* q, double* x, double* r, double* s) {
+  hipLaunchKernelGGL(k_pcg_update_xr, dim3((n + 255) / 256), dim3(256), 0, st, n, p, q, x, r, s);
+}
+
 __global__ void k_axpby(int n, double alpha, const double* __restrict__ x, double beta, double* __restrict__ y) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
