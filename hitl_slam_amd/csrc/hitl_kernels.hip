@@ -74,7 +74,8 @@ __device__ __forceinline__ double swz_xor(double v) {
   }
 
 constexpr int kStfSub = 32;     // lanes per directed pair: two pairs per wave
-constexpr int kStfAheadDefault = 2;   // index words requested this many trips ahead (tools/stf_trace.sh A/B)
+constexpr int kStfAheadDefault = 1;   // index words requested this many trips ahead: one trip costs 72 VGPRs = 7 waves per SIMD, and the
+                                      // ninth workgroup per CU is worth more than the second trip (bench.py A/B: 254 vs 270 us)
 constexpr int kStfSums = 8;     // S0, A0x, A0y, T01, S1, A1x, A1y, T10 (of e / k)
 
 // per-pose (cos theta, sin theta), computed once per linearisation instead of per pair
@@ -112,11 +113,11 @@ __device__ __forceinline__ void stf_match(StfAcc& a, double ax, double ay, doubl
 // AHEAD: how many trips ahead the index words are requested (1..3).  The index stream comes from HBM (about 1.2 us under
 // load, rocprofv3 TCC_EA0_RDREQ_LEVEL / TCC_EA0_RDREQ), a trip lasts about as long: one trip ahead does not hide it.
 template <int SRC>
-__device__ __forceinline__ void stf_source(const double2* s_scan8, const float4* s_scan4, const float4* __restrict__ src_g, uint32_t u,
+__device__ __forceinline__ void stf_source(const double2* s_scan8, const double2* s_scanN, const float4* s_scan4, const float4* __restrict__ src_g, uint32_t u,
                                            double& ax, double& ay, double& anx, double& any) {
   const int k0 = (int)__builtin_amdgcn_ubfe(u, 0, 16);
   if (SRC == 2) {
-    const double2 a = s_scan8[2 * k0], b = s_scan8[2 * k0 + 1];
+    const double2 a = s_scan8[k0], b = s_scanN[k0];   // two planes: a 16-byte lane stride keeps the b128 reads off each other's banks
     ax = a.x; ay = a.y; anx = b.x; any = b.y;
   } else {
     const float4 a = (SRC == 1) ? s_scan4[k0] : src_g[k0];
@@ -140,6 +141,7 @@ __global__ __launch_bounds__(kStfBlock, MINB) void k_linearize_stf(MapView map, 
   if (p_begin == p_end) return;
   const int64_t oi = map.obs_off[i];
   const int mi = (int)(map.obs_off[i + 1] - oi);
+  double2* s_scanN = s_scan8 + mi;                                    // SRC == 2: the (nx, ny) plane behind the (px, py) plane
   const float4* __restrict__ src_g = map.obs + oi;
   const int lane = threadIdx.x & 63;
   const int sub = threadIdx.x / kStfSub;        // pair slot of this half-wave within the workgroup
@@ -163,8 +165,8 @@ __global__ __launch_bounds__(kStfBlock, MINB) void k_linearize_stf(MapView map, 
   } else if (SRC == 2) {
     for (int k = threadIdx.x; k < mi; k += kStfBlock) {
       const float4 o = src_g[k];
-      s_scan8[2 * k] = make_double2((double)o.x, (double)o.y);
-      s_scan8[2 * k + 1] = make_double2((double)o.z, (double)o.w);
+      s_scan8[k] = make_double2((double)o.x, (double)o.y);
+      s_scanN[k] = make_double2((double)o.z, (double)o.w);
     }
   }
   // workgroup-uniform values pinned to SGPRs
@@ -200,12 +202,18 @@ __global__ __launch_bounds__(kStfBlock, MINB) void k_linearize_stf(MapView map, 
         if (t + d < nfull) {
           const uint32_t u0 = ua[d], u1 = ub[d];
           const float4 tv0 = HITL_TGT(u0), tv1 = HITL_TGT(u1);
-          stf_source<SRC>(s_scan8, s_scan4, src_g, u0, ax0, ay0, anx0, any0);
-          stf_source<SRC>(s_scan8, s_scan4, src_g, u1, ax1, ay1, anx1, any1);
+          stf_source<SRC>(s_scan8, s_scanN, s_scan4, src_g, u0, ax0, ay0, anx0, any0);
+          if (MINB < 8) stf_source<SRC>(s_scan8, s_scanN, s_scan4, src_g, u1, ax1, ay1, anx1, any1);
           ua[d] = HITL_IDX(2 * kStfSub * (d + AHEAD)); ub[d] = HITL_IDX(2 * kStfSub * (d + AHEAD) + kStfSub);   // trip t + d + AHEAD
           __builtin_amdgcn_sched_barrier(0);      // keep the index prefetch ahead of the arithmetic (the scheduler sinks it otherwise)
           stf_match<false>(acc, ax0, ay0, anx0, any0, tv0, cR, sR, t01x, t01y, 1.0);
-          stf_match<false>(acc, ax1, ay1, anx1, any1, tv1, cR, sR, t01x, t01y, 1.0);
+          if (MINB >= 8) {                        // 64 VGPRs: the second source point takes the first one's registers
+            __builtin_amdgcn_sched_barrier(0);
+            stf_source<SRC>(s_scan8, s_scanN, s_scan4, src_g, u1, ax0, ay0, anx0, any0);
+            stf_match<false>(acc, ax0, ay0, anx0, any0, tv1, cR, sR, t01x, t01y, 1.0);
+          } else {
+            stf_match<false>(acc, ax1, ay1, anx1, any1, tv1, cR, sR, t01x, t01y, 1.0);
+          }
         }
       }
       if (OFF32) mo += 8u * kStfSub * AHEAD; else mp += 2 * kStfSub * AHEAD;
@@ -217,10 +225,16 @@ __global__ __launch_bounds__(kStfBlock, MINB) void k_linearize_stf(MapView map, 
       const bool v0 = hl < rem, v1 = hl + kStfSub < rem;
       const uint32_t u0 = v0 ? w0 : 0u, u1 = v1 ? w1 : 0u;
       const float4 tv0 = HITL_TGT(u0), tv1 = HITL_TGT(u1);
-      stf_source<SRC>(s_scan8, s_scan4, src_g, u0, ax0, ay0, anx0, any0);
-      stf_source<SRC>(s_scan8, s_scan4, src_g, u1, ax1, ay1, anx1, any1);
+      stf_source<SRC>(s_scan8, s_scanN, s_scan4, src_g, u0, ax0, ay0, anx0, any0);
+      if (MINB < 8) stf_source<SRC>(s_scan8, s_scanN, s_scan4, src_g, u1, ax1, ay1, anx1, any1);
       stf_match<true>(acc, ax0, ay0, anx0, any0, tv0, cR, sR, t01x, t01y, v0 ? 1.0 : 0.0);
-      stf_match<true>(acc, ax1, ay1, anx1, any1, tv1, cR, sR, t01x, t01y, v1 ? 1.0 : 0.0);
+      if (MINB >= 8) {
+        __builtin_amdgcn_sched_barrier(0);
+        stf_source<SRC>(s_scan8, s_scanN, s_scan4, src_g, u1, ax0, ay0, anx0, any0);
+        stf_match<true>(acc, ax0, ay0, anx0, any0, tv1, cR, sR, t01x, t01y, v1 ? 1.0 : 0.0);
+      } else {
+        stf_match<true>(acc, ax1, ay1, anx1, any1, tv1, cR, sR, t01x, t01y, v1 ? 1.0 : 0.0);
+      }
     }
     // reduce-scatter over the 32 lanes of this pair: after the three exchange steps lane hl holds the 4-lane partial of
     // value (hl >> 2); two more exchanges complete it
@@ -374,15 +388,19 @@ void launch_linearize_stf(hipStream_t st, const MapView& map, const PairView& pr
                      std::getenv("HITL_STF_ADDR64") == nullptr;
   const double kf = (double)corr / (double)std_dev;                       // k = corr / sigma, divided here once
   const dim3 grid(8 * chunk), block(kStfBlock);
-  // HITL_STF_VARIANT (development switch): 2 decimal digits "ahead minwaves", e.g. 36 = index words 3 trips ahead, 6 waves per
-  // SIMD.  Unset: the default below.
+  // HITL_STF_VARIANT (development switch): 2 decimal digits "ahead minwaves", e.g. 26 = index words 2 trips ahead, 6 waves per
+  // SIMD (5, 6, 7 exist; 7 only with 1 or 2 trips ahead).  Unset: the default below.
   static const int variant = [] { const char* e = std::getenv("HITL_STF_VARIANT"); return e ? std::atoi(e) : 0; }();
   const int src = ((size_t)cap * 32 <= 64 * 1024) ? 2 : ((size_t)cap * 16 <= 64 * 1024) ? 1 : 0;
-  int ahead = kStfAheadDefault, minb = (src == 2 && off32) ? 6 : 5;     // the fallback layouts need > 80 VGPRs: 5 waves per SIMD instead of spilling
-  if (variant > 0 && src == 2 && off32) { ahead = std::min(3, std::max(1, variant / 10)); minb = (variant % 10 == 5) ? 5 : 6; }
+  int ahead = kStfAheadDefault, minb = (src == 2 && off32) ? 7 : 5;     // the fallback layouts need > 80 VGPRs: 5 waves per SIMD instead of spilling
+  if (variant > 0 && src == 2 && off32) { ahead = std::min(3, std::max(1, variant / 10)); minb = (variant % 10 == 5) ? 5 : (variant % 10 == 7) ? 7 : (variant % 10 == 8) ? 8 : 6; }
   const size_t lds = (src == 2) ? (size_t)cap * 32 : (src == 1) ? (size_t)cap * 16 : 0;
 #define HITL_STF_GO(SRC, O32, AH, MINB) hipLaunchKernelGGL((k_linearize_stf<SRC, O32, AH, MINB>), grid, block, lds, st, map, pr, chunk, x, cs, kf, pairRJ)
-  if (src == 2 && off32) {
+  if (src == 2 && off32 && minb == 8) {
+    HITL_STF_GO(2, true, 1, 8);
+  } else if (src == 2 && off32 && minb == 7) {
+    if (ahead == 1) HITL_STF_GO(2, true, 1, 7); else HITL_STF_GO(2, true, 2, 7);
+  } else if (src == 2 && off32) {
     if (minb == 6) { if (ahead == 1) HITL_STF_GO(2, true, 1, 6); else if (ahead == 2) HITL_STF_GO(2, true, 2, 6); else HITL_STF_GO(2, true, 3, 6); }
     else { if (ahead == 1) HITL_STF_GO(2, true, 1, 5); else if (ahead == 2) HITL_STF_GO(2, true, 2, 5); else HITL_STF_GO(2, true, 3, 5); }
   } else if (src == 2) HITL_STF_GO(2, false, 1, 5);
