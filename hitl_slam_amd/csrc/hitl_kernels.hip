@@ -75,7 +75,8 @@ __device__ __forceinline__ double swz_xor(double v) {
 
 constexpr int kStfSub = 32;     // lanes per directed pair: two pairs per wave
 constexpr int kStfAheadDefault = 1;   // index words requested this many trips ahead: one trip costs 72 VGPRs = 7 waves per SIMD, and the
-                                      // ninth workgroup per CU is worth more than the second trip (bench.py A/B: 254 vs 270 us)
+                                      // ninth workgroup per CU is worth more than the second trip (bench.py A/B: 254 vs 270 us; a 64-VGPR build with
+                                      // the two source points read one after the other, 8 waves per SIMD, measured the same as 7)
 constexpr int kStfSums = 8;     // S0, A0x, A0y, T01, S1, A1x, A1y, T10 (of e / k)
 
 // per-pose (cos theta, sin theta), computed once per linearisation instead of per pair
@@ -203,17 +204,11 @@ __global__ __launch_bounds__(kStfBlock, MINB) void k_linearize_stf(MapView map, 
           const uint32_t u0 = ua[d], u1 = ub[d];
           const float4 tv0 = HITL_TGT(u0), tv1 = HITL_TGT(u1);
           stf_source<SRC>(s_scan8, s_scanN, s_scan4, src_g, u0, ax0, ay0, anx0, any0);
-          if (MINB < 8) stf_source<SRC>(s_scan8, s_scanN, s_scan4, src_g, u1, ax1, ay1, anx1, any1);
+          stf_source<SRC>(s_scan8, s_scanN, s_scan4, src_g, u1, ax1, ay1, anx1, any1);
           ua[d] = HITL_IDX(2 * kStfSub * (d + AHEAD)); ub[d] = HITL_IDX(2 * kStfSub * (d + AHEAD) + kStfSub);   // trip t + d + AHEAD
           __builtin_amdgcn_sched_barrier(0);      // keep the index prefetch ahead of the arithmetic (the scheduler sinks it otherwise)
           stf_match<false>(acc, ax0, ay0, anx0, any0, tv0, cR, sR, t01x, t01y, 1.0);
-          if (MINB >= 8) {                        // 64 VGPRs: the second source point takes the first one's registers
-            __builtin_amdgcn_sched_barrier(0);
-            stf_source<SRC>(s_scan8, s_scanN, s_scan4, src_g, u1, ax0, ay0, anx0, any0);
-            stf_match<false>(acc, ax0, ay0, anx0, any0, tv1, cR, sR, t01x, t01y, 1.0);
-          } else {
-            stf_match<false>(acc, ax1, ay1, anx1, any1, tv1, cR, sR, t01x, t01y, 1.0);
-          }
+          stf_match<false>(acc, ax1, ay1, anx1, any1, tv1, cR, sR, t01x, t01y, 1.0);
         }
       }
       if (OFF32) mo += 8u * kStfSub * AHEAD; else mp += 2 * kStfSub * AHEAD;
@@ -226,15 +221,9 @@ __global__ __launch_bounds__(kStfBlock, MINB) void k_linearize_stf(MapView map, 
       const uint32_t u0 = v0 ? w0 : 0u, u1 = v1 ? w1 : 0u;
       const float4 tv0 = HITL_TGT(u0), tv1 = HITL_TGT(u1);
       stf_source<SRC>(s_scan8, s_scanN, s_scan4, src_g, u0, ax0, ay0, anx0, any0);
-      if (MINB < 8) stf_source<SRC>(s_scan8, s_scanN, s_scan4, src_g, u1, ax1, ay1, anx1, any1);
+      stf_source<SRC>(s_scan8, s_scanN, s_scan4, src_g, u1, ax1, ay1, anx1, any1);
       stf_match<true>(acc, ax0, ay0, anx0, any0, tv0, cR, sR, t01x, t01y, v0 ? 1.0 : 0.0);
-      if (MINB >= 8) {
-        __builtin_amdgcn_sched_barrier(0);
-        stf_source<SRC>(s_scan8, s_scanN, s_scan4, src_g, u1, ax0, ay0, anx0, any0);
-        stf_match<true>(acc, ax0, ay0, anx0, any0, tv1, cR, sR, t01x, t01y, v1 ? 1.0 : 0.0);
-      } else {
-        stf_match<true>(acc, ax1, ay1, anx1, any1, tv1, cR, sR, t01x, t01y, v1 ? 1.0 : 0.0);
-      }
+      stf_match<true>(acc, ax1, ay1, anx1, any1, tv1, cR, sR, t01x, t01y, v1 ? 1.0 : 0.0);
     }
     // reduce-scatter over the 32 lanes of this pair: after the three exchange steps lane hl holds the 4-lane partial of
     // value (hl >> 2); two more exchanges complete it
@@ -393,12 +382,10 @@ void launch_linearize_stf(hipStream_t st, const MapView& map, const PairView& pr
   static const int variant = [] { const char* e = std::getenv("HITL_STF_VARIANT"); return e ? std::atoi(e) : 0; }();
   const int src = ((size_t)cap * 32 <= 64 * 1024) ? 2 : ((size_t)cap * 16 <= 64 * 1024) ? 1 : 0;
   int ahead = kStfAheadDefault, minb = (src == 2 && off32) ? 7 : 5;     // the fallback layouts need > 80 VGPRs: 5 waves per SIMD instead of spilling
-  if (variant > 0 && src == 2 && off32) { ahead = std::min(3, std::max(1, variant / 10)); minb = (variant % 10 == 5) ? 5 : (variant % 10 == 7) ? 7 : (variant % 10 == 8) ? 8 : 6; }
+  if (variant > 0 && src == 2 && off32) { ahead = std::min(3, std::max(1, variant / 10)); minb = (variant % 10 == 5) ? 5 : (variant % 10 == 7) ? 7 : 6; }
   const size_t lds = (src == 2) ? (size_t)cap * 32 : (src == 1) ? (size_t)cap * 16 : 0;
 #define HITL_STF_GO(SRC, O32, AH, MINB) hipLaunchKernelGGL((k_linearize_stf<SRC, O32, AH, MINB>), grid, block, lds, st, map, pr, chunk, x, cs, kf, pairRJ)
-  if (src == 2 && off32 && minb == 8) {
-    HITL_STF_GO(2, true, 1, 8);
-  } else if (src == 2 && off32 && minb == 7) {
+  if (src == 2 && off32 && minb == 7) {
     if (ahead == 1) HITL_STF_GO(2, true, 1, 7); else HITL_STF_GO(2, true, 2, 7);
   } else if (src == 2 && off32) {
     if (minb == 6) { if (ahead == 1) HITL_STF_GO(2, true, 1, 6); else if (ahead == 2) HITL_STF_GO(2, true, 2, 6); else HITL_STF_GO(2, true, 3, 6); }
