@@ -120,6 +120,52 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
     launch_match(st, mv, s->max_scan, slots, d_tgt.p, d_tf.p, mp, d_table.p, d_counts.p);
   }
   if (hipGetLastError() != hipSuccess) { cleanup(); return fail(HITL_ERR_HIP, "find_correspondences: the match kernel could not be launched"); }
+  // A window inside the pose band cannot produce an off-band pair: the pair tables are then built on the device, next to
+  // the counts, and only five totals come back.  Wider windows (all-pairs search) take the general host path below.
+  const int band_cap = std::min(std::max((int)s->opt.max_band_poses, 1), kMaxBandPoses);
+  if (window <= band_cap) {
+    DevArray<int>& d_maxd = s->d_pose_maxd;
+    DevArray<int64_t>&d_pmo = s->d_pose_match_off, &d_tot = s->d_pair_totals;
+    TRYC(s->pose_pair_off.resize((size_t)n + 1)); TRYC(s->inc_off.resize((size_t)n + 1));
+    TRYC(d_pmo.resize((size_t)n + 1)); TRYC(d_maxd.resize((size_t)n)); TRYC(d_tot.resize(5));
+    const int min_count = (int)s->opt.min_inter_pose_correspondence;
+    launch_pair_count_scan(st, n, slots, (int)window, min_count, s->own_lo, s->own_hi, d_counts.p, s->pose_pair_off.p, d_pmo.p,
+                           s->inc_off.p, d_maxd.p, d_tot.p);
+    int64_t tot[5] = {0, 0, 0, 0, 0};
+    if (hipMemcpyAsync(tot, d_tot.p, sizeof(tot), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+      return fail(HITL_ERR_HIP, std::string("match kernel: ") + hipGetErrorString(hipGetLastError()));
+    mark("k_match + pair counts");
+    const int P = (int)tot[0];
+    const int Wb = std::min(std::max((int)tot[2], 1), band_cap);
+    s->n_pairs = P; s->n_matches = tot[1];
+    s->n_pairs_owned = (int)tot[3]; s->n_matches_owned = tot[4];
+    s->band_pairs_Wb = Wb;
+    s->n_offband = 0;
+    ++s->corr_generation;
+    s->h_pair_src.clear(); s->h_pair_tgt.clear(); s->h_perm.clear(); s->h_match_off.clear();
+    s->host_pairs_stale = true;                 // ensure_host_pairs() fetches the lists for the entry points that want them
+    TRYC(d_kept.resize((size_t)P)); TRYC(s->pair_src.resize((size_t)P)); TRYC(s->pair_tgt.resize((size_t)P));
+    TRYC(s->match_off.resize((size_t)P + 1)); TRYC(s->inc_ent.resize((size_t)std::max(2 * P, 1)));
+    TRYC(s->band_pair.resize((size_t)n * Wb * 2));
+    TRYC(s->matches.resize((size_t)s->n_matches + kMatchPad));      // k_linearize_stf prefetches index words unguarded
+    if (hipMemsetAsync(s->band_pair.p, 0xFF, sizeof(int) * (size_t)n * Wb * 2, st) != hipSuccess ||
+        hipMemsetAsync(s->matches.p + s->n_matches, 0, sizeof(uint32_t) * kMatchPad, st) != hipSuccess)
+      return fail(HITL_ERR_HIP, "find_correspondences: clearing the pair tables failed");
+    launch_pair_fill(st, n, slots, (int)window, min_count, s->own_lo, s->own_hi, d_counts.p, Wb, s->pose_pair_off.p, d_pmo.p,
+                     s->inc_off.p, d_kept.p, s->pair_src.p, s->pair_tgt.p, s->match_off.p, s->inc_ent.p, s->band_pair.p);
+    launch_compact(st, mv, s->max_scan, slots, P, d_kept.p, s->match_off.p, d_table.p, s->matches.p);
+    if (s->ob_lo.n != 1 || s->obadj_off.n != (size_t)n + 1 || s->obadj_nonzero) {     // no off-band pairs: the empty tables
+      const std::vector<int> zero1(1, 0), minus1(1, -1);
+      TRYC(s->ob_lo.upload(zero1, st)); TRYC(s->ob_hi.upload(zero1, st));
+      TRYC(s->ob_fwd.upload(minus1, st)); TRYC(s->ob_rev.upload(minus1, st));
+      TRYC(s->obadj_off.resize((size_t)n + 1)); TRYC(s->obadj_off.zero(st));
+      TRYC(s->obadj_ent.resize(1));
+      s->obadj_nonzero = false;
+    }
+    if (hipStreamSynchronize(st) != hipSuccess) return fail(HITL_ERR_HIP, "find_correspondences: the pair-table kernels failed");
+    mark("pair tables + k_compact");
+    return HITL_OK;
+  }
   std::vector<int> counts((size_t)n * slots);
   if (hipMemcpyAsync(counts.data(), d_counts.p, counts.size() * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
       hipStreamSynchronize(st) != hipSuccess) {

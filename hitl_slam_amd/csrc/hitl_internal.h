@@ -153,6 +153,14 @@ void launch_compact(hipStream_t st, const MapView& map, int max_scan, int slots,
                     const int* kept_cand /* index into n*slots */, const int64_t* match_off, const uint16_t* table,
                     uint32_t* matches);
 
+// pair tables of a windowed search on the device (the layout of build_pair_structures, hitl_solver.cpp):
+// count + scan leave exclusive offsets (n + 1 entries) and totals[5] = pairs, matches, max |i - j|, owned pairs, owned matches
+void launch_pair_count_scan(hipStream_t st, int n, int slots, int window, int min_count, int own_lo, int own_hi, const int* counts,
+                            int* pose_pair_off, int64_t* pose_match_off, int* inc_off, int* pose_maxd, int64_t* totals);
+void launch_pair_fill(hipStream_t st, int n, int slots, int window, int min_count, int own_lo, int own_hi, const int* counts, int Wb,
+                      const int* pose_pair_off, const int64_t* pose_match_off, const int* inc_off, int* kept_cand, int* pair_src,
+                      int* pair_tgt, int64_t* match_off, int* inc_ent, int* band_pair /* n*Wb*2, preset to -1 */);
+
 // observation scans (hitl_obs.hip); T4 = n x (cos, sin, tx, ty) fp32 computed on the host
 void launch_transform(hipStream_t st, const MapView& map, const float* T4, float* world_x, float* world_y);
 void launch_verify(hipStream_t st, const MapView& map, const float* T4, int n, const float* pts_xy, float thr, int* seen);

@@ -414,4 +414,137 @@ void launch_compact(hipStream_t st, const MapView& map, int max_scan, int slots,
   hipLaunchKernelGGL(k_compact, dim3(n_kept), dim3(64), 0, st, map, max_scan, slots, kept_cand, match_off, table, matches);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Pair tables of a windowed search, built where the counts are (JointOptimization.cpp:632-641: keep a candidate with more
+// than kMinInterPoseCorrespondence matches, pose order).  The candidate list of a windowed search is regular -- pose i's
+// slots are j = max(0, i - w) .. min(n - 1, i + w) without i -- so a pose can find the candidates that point AT it without
+// any list.  Three launches: per-pose counts, one-workgroup scan, per-pose fill.  The layout written is the one
+// build_pair_structures (hitl_solver.cpp) derives on the host from arbitrary pair lists, entry for entry.
+// ---------------------------------------------------------------------------------------------------------------------
+struct WinCand {
+  int n, slots, window, min_count, own_lo, own_hi;
+  const int* __restrict__ counts;
+  __device__ int j0(int i) const { return max(0, i - window); }
+  __device__ int j1(int i) const { return min(n - 1, i + window); }
+  __device__ int slot_of(int i, int j) const { return (j - j0(i)) - (j > i ? 1 : 0); }       // j != i, inside i's window
+  __device__ int target_of(int i, int sl) const { const int j = j0(i) + sl; return j >= i ? j + 1 : j; }
+  __device__ int n_slots(int i) const { return j1(i) - j0(i); }
+  __device__ bool kept(int i, int sl, int j) const {        // halo-halo pairs belong to other ranks
+    const bool relevant = (i >= own_lo && i < own_hi) || (j >= own_lo && j < own_hi);
+    return relevant && counts[(size_t)i * slots + sl] > min_count;
+  }
+};
+
+__global__ void k_pair_count(WinCand w, int* __restrict__ pose_pairs, int64_t* __restrict__ pose_matches, int* __restrict__ pose_inc,
+                             int* __restrict__ pose_maxd) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= w.n) return;
+  int np = 0, ninc = 0, maxd = 0;
+  int64_t nm = 0;
+  const int ns = w.n_slots(i);
+  for (int sl = 0; sl < ns; ++sl) {
+    const int j = w.target_of(i, sl);
+    if (w.kept(i, sl, j)) { ++np; nm += w.counts[(size_t)i * w.slots + sl]; maxd = max(maxd, abs(i - j)); }
+    if (w.kept(j, w.slot_of(j, i), i)) ++ninc;       // the candidate j -> i (i lies in j's window exactly when j lies in i's)
+  }
+  pose_pairs[i] = np; pose_matches[i] = nm; pose_inc[i] = np + ninc; pose_maxd[i] = maxd;
+}
+
+// exclusive scans over the poses, in place (n + 1 entries each), by one workgroup; totals to `out`:
+// out[0] = pairs, out[1] = matches, out[2] = max |i - j|, out[3] = pairs with an owned source, out[4] = their matches
+constexpr int kScanThreads = 1024;
+__global__ __launch_bounds__(kScanThreads) void k_pair_scan(int n, int own_lo, int own_hi, int* __restrict__ pose_pairs,
+                                                             int64_t* __restrict__ pose_matches, int* __restrict__ pose_inc,
+                                                             const int* __restrict__ pose_maxd, int64_t* __restrict__ out) {
+  __shared__ int64_t s_a[kScanThreads], s_b[kScanThreads], s_c[kScanThreads];
+  __shared__ int s_d[kScanThreads];
+  __shared__ int64_t s_oa[kScanThreads], s_ob[kScanThreads];
+  const int t = threadIdx.x;
+  const int per = (n + kScanThreads - 1) / kScanThreads;
+  const int lo = min(n, t * per), hi = min(n, lo + per);
+  int64_t a = 0, b = 0, c = 0, oa = 0, ob = 0;
+  int d = 0;
+  for (int i = lo; i < hi; ++i) {
+    a += pose_pairs[i]; b += pose_matches[i]; c += pose_inc[i]; d = max(d, pose_maxd[i]);
+    if (i >= own_lo && i < own_hi) { oa += pose_pairs[i]; ob += pose_matches[i]; }
+  }
+  s_a[t] = a; s_b[t] = b; s_c[t] = c; s_d[t] = d; s_oa[t] = oa; s_ob[t] = ob;
+  __syncthreads();
+  for (int off = 1; off < kScanThreads; off <<= 1) {        // inclusive scan of the per-thread sums
+    const int64_t va = (t >= off) ? s_a[t - off] : 0, vb = (t >= off) ? s_b[t - off] : 0, vc = (t >= off) ? s_c[t - off] : 0;
+    const int64_t voa = (t >= off) ? s_oa[t - off] : 0, vob = (t >= off) ? s_ob[t - off] : 0;
+    const int vd = (t >= off) ? s_d[t - off] : 0;
+    __syncthreads();
+    s_a[t] += va; s_b[t] += vb; s_c[t] += vc; s_oa[t] += voa; s_ob[t] += vob; s_d[t] = max(s_d[t], vd);
+    __syncthreads();
+  }
+  int64_t ra = s_a[t] - a, rb = s_b[t] - b, rc = s_c[t] - c;
+  for (int i = lo; i < hi; ++i) {
+    const int pa = pose_pairs[i], pc = pose_inc[i];
+    const int64_t pb = pose_matches[i];
+    pose_pairs[i] = (int)ra; pose_matches[i] = rb; pose_inc[i] = (int)rc;
+    ra += pa; rb += pb; rc += pc;
+  }
+  if (t == kScanThreads - 1) {
+    pose_pairs[n] = (int)s_a[t]; pose_matches[n] = s_b[t]; pose_inc[n] = (int)s_c[t];
+    out[0] = s_a[t]; out[1] = s_b[t]; out[2] = s_d[t]; out[3] = s_oa[t]; out[4] = s_ob[t];
+  }
+}
+
+__global__ void k_pair_fill(WinCand w, int Wb, const int* __restrict__ pose_pair_off, const int64_t* __restrict__ pose_match_off,
+                            const int* __restrict__ inc_off, int* __restrict__ kept_cand, int* __restrict__ pair_src,
+                            int* __restrict__ pair_tgt, int64_t* __restrict__ match_off, int* __restrict__ inc_ent,
+                            int* __restrict__ band_pair) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= w.n) return;
+  int f = inc_off[i];
+  // index of the kept pair j -> i: j's first pair + the kept candidates of j in the slots before i's
+  auto pair_into = [&](int j) -> int {
+    const int sl = w.slot_of(j, i);
+    if (!w.kept(j, sl, i)) return -1;
+    int q = pose_pair_off[j];
+    for (int k = 0; k < sl; ++k) q += w.kept(j, k, w.target_of(j, k)) ? 1 : 0;
+    return q;
+  };
+  // incidence list in ascending pair index: pairs into i from earlier poses, i's own pairs, pairs into i from later poses
+  for (int j = w.j0(i); j < i; ++j) { const int q = pair_into(j); if (q >= 0) inc_ent[f++] = 2 * q + 1; }
+  int q = pose_pair_off[i];
+  int64_t mo = pose_match_off[i];
+  const int ns = w.n_slots(i);
+  for (int sl = 0; sl < ns; ++sl) {
+    const int j = w.target_of(i, sl);
+    if (!w.kept(i, sl, j)) continue;
+    kept_cand[q] = i * w.slots + sl; pair_src[q] = i; pair_tgt[q] = j; match_off[q] = mo;
+    mo += w.counts[(size_t)i * w.slots + sl];
+    const int lo = min(i, j), d = abs(i - j);
+    band_pair[((size_t)lo * Wb + (d - 1)) * 2 + (i < j ? 0 : 1)] = q;       // d <= window <= Wb's cap: never off the band
+    inc_ent[f++] = 2 * q;
+    ++q;
+  }
+  for (int j = i + 1; j <= w.j1(i); ++j) { const int qq = pair_into(j); if (qq >= 0) inc_ent[f++] = 2 * qq + 1; }
+  if (i == w.n - 1) match_off[q] = mo;      // the last pose closes the offsets: q == n_pairs, mo == n_matches
+}
+
+static WinCand win_cand(int n, int slots, int window, int min_count, int own_lo, int own_hi, const int* counts) {
+  WinCand w;
+  w.n = n; w.slots = slots; w.window = window; w.min_count = min_count; w.own_lo = own_lo; w.own_hi = own_hi; w.counts = counts;
+  return w;
+}
+
+void launch_pair_count_scan(hipStream_t st, int n, int slots, int window, int min_count, int own_lo, int own_hi, const int* counts,
+                            int* pose_pair_off, int64_t* pose_match_off, int* inc_off, int* pose_maxd, int64_t* totals) {
+  const WinCand w = win_cand(n, slots, window, min_count, own_lo, own_hi, counts);
+  hipLaunchKernelGGL(k_pair_count, dim3((n + 255) / 256), dim3(256), 0, st, w, pose_pair_off, pose_match_off, inc_off, pose_maxd);
+  hipLaunchKernelGGL(k_pair_scan, dim3(1), dim3(kScanThreads), 0, st, n, own_lo, own_hi, pose_pair_off, pose_match_off, inc_off, pose_maxd, totals);
+}
+
+void launch_pair_fill(hipStream_t st, int n, int slots, int window, int min_count, int own_lo, int own_hi, const int* counts, int Wb,
+                      const int* pose_pair_off, const int64_t* pose_match_off, const int* inc_off, int* kept_cand, int* pair_src,
+                      int* pair_tgt, int64_t* match_off, int* inc_ent, int* band_pair) {
+  const WinCand w = win_cand(n, slots, window, min_count, own_lo, own_hi, counts);
+  hipLaunchKernelGGL(k_pair_fill, dim3((n + 255) / 256), dim3(256), 0, st, w, Wb, pose_pair_off, pose_match_off, inc_off, kept_cand,
+                     pair_src, pair_tgt, match_off, inc_ent, band_pair);
+}
+
+
 }  // namespace hitl

@@ -44,8 +44,27 @@ int solver_ctx(hitl_solver* s, SolverCtx* out) {
 // ---------------------------------------------------------------------------------------
 // derived pair structures (host, O(P)); called whenever the correspondence set changes
 // ---------------------------------------------------------------------------------------
+int ensure_host_pairs(hitl_solver* s) {
+  if (!s->host_pairs_stale) return HITL_OK;
+  const size_t P = (size_t)s->n_pairs;
+  s->h_pair_src.resize(P); s->h_pair_tgt.resize(P); s->h_match_off.resize(P + 1);
+  hipStream_t st = s->stream;
+  if (P) {
+    HIP_TRY(hipMemcpyAsync(s->h_pair_src.data(), s->pair_src.p, P * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(s->h_pair_tgt.data(), s->pair_tgt.p, P * sizeof(int), hipMemcpyDeviceToHost, st));
+  }
+  HIP_TRY(hipMemcpyAsync(s->h_match_off.data(), s->match_off.p, (P + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  s->h_perm.resize(P);
+  std::iota(s->h_perm.begin(), s->h_perm.end(), 0);
+  s->host_pairs_stale = false;
+  return HITL_OK;
+}
+
 int build_pair_structures(hitl_solver* s) {
   ++s->corr_generation;
+  s->host_pairs_stale = false;      // the caller has just written the host lists
+  s->obadj_nonzero = true;
   const int n = s->n, P = s->n_pairs;
   int maxd = 1;
   for (int p = 0; p < P; ++p) maxd = std::max(maxd, std::abs(s->h_pair_src[p] - s->h_pair_tgt[p]));
@@ -280,7 +299,7 @@ int prepare(hitl_solver* s, int mode, const float* poses_ref, const float* poses
     // interface width = how deep (in poses) any factor reaches across a cut, maximised over all
     // ranks: 1 when only the odometry edges straddle the cuts, up to the pose band otherwise
     int wi_local = 1;
-    if (mode != HITL_MODE_ODOM_HC && local_rc == HITL_OK)
+    if (mode != HITL_MODE_ODOM_HC && local_rc == HITL_OK && ensure_host_pairs(s) == HITL_OK)
       for (int p = 0; p < s->n_pairs; ++p) {
         const int a = std::min(s->h_pair_src[p], s->h_pair_tgt[p]), b = std::max(s->h_pair_src[p], s->h_pair_tgt[p]);
         if (a < s->own_lo && b >= s->own_lo) wi_local = std::max(wi_local, std::max(s->own_lo - a, b - s->own_lo + 1));
@@ -638,6 +657,7 @@ int hitl_solver_get_correspondences(hitl_solver* s, int32_t* pair_src, int32_t* 
   if (!s || !match_offset) return fail(HITL_ERR_INVALID_ARGUMENT, "get_correspondences: null argument");
   HIP_TRY(hipSetDevice(s->device));
   const int P = s->n_pairs;
+  TRY(ensure_host_pairs(s));
   std::vector<uint32_t> packed((size_t)s->n_matches);
   if (s->n_matches) {
     HIP_TRY(hipMemcpyAsync(packed.data(), s->matches.p, packed.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
@@ -703,6 +723,7 @@ int hitl_solver_linearize(hitl_solver* s, int32_t mode, const float* poses_ref_x
   if (cost) *cost = lr.cost;
   if (gradient) HIP_TRY(hipMemcpyAsync(gradient, s->gvec[0].p, sizeof(double) * n3, hipMemcpyDeviceToHost, st));
   if (fv.with_stf && (pair_residuals || pair_jacobians)) {
+    TRY(ensure_host_pairs(s));
     std::vector<double> rj((size_t)s->n_pairs * kPairRJ);
     HIP_TRY(hipMemcpyAsync(rj.data(), s->pairRJ[0].p, rj.size() * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -737,6 +758,7 @@ int hitl_solver_evaluate_jacobian(hitl_solver* s, const float* poses_xyt, double
   if (cost) *cost = c;
   if (residuals) std::memcpy(residuals, pr.data(), sizeof(double) * 2 * (size_t)P);
   // caller order: pair p of the caller is internal pair q with h_perm[q] == p
+  TRY(ensure_host_pairs(s));
   std::vector<int> inv((size_t)P);
   for (int q = 0; q < P; ++q) inv[s->h_perm[q]] = q;
   for (int p = 0; p < P; ++p) {

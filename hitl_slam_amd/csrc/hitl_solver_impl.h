@@ -71,6 +71,10 @@ struct hitl_solver {
   std::vector<int> h_cand_tgt;
   std::vector<float> h_cand_tf, h_cand_cs;
   DevArray<int> d_cand_tgt, d_cand_counts, d_cand_kept;
+  DevArray<int> d_pose_maxd;                   // device-built pair tables (windowed search inside the band): per-pose scratch
+  DevArray<int64_t> d_pose_match_off, d_pair_totals;
+  bool host_pairs_stale = false;               // h_pair_src / h_pair_tgt / h_perm / h_match_off not yet fetched from the device
+  bool obadj_nonzero = true;                   // the off-band adjacency on the device is not known to be the empty one
   DevArray<float> d_cand_tf;
   DevArray<uint16_t> d_cand_table;
   DevArray<float4> kd_pts;                     // opt-in (kd_tree_search): every scan in KD in-order layout
@@ -132,6 +136,7 @@ static inline double angle_mod(double a) {  // shared/math/util.h:433-439
 
 // hitl_solver.cpp
 int build_pair_structures(hitl_solver* s);
+int ensure_host_pairs(hitl_solver* s);      // host mirrors of the pair lists, fetched on first use after a device-side build
 int ensure_empty_pair_tables(hitl_solver* s);
 int ensure_work(hitl_solver* s, int Wb);
 int setup_factors(hitl_solver* s, const float* poses, const float* poses_global, bool with_odom_hc);

@@ -375,3 +375,29 @@ def test_kd_tree_search_on_ragged_and_empty_scans():
     for a, b in zip(g.get_correspondences(), o.get_correspondences()):
         assert np.array_equal(a, b)
     g.close(); o.close()
+
+
+@pytest.mark.parametrize("shape", [(60, 90, 30, 3, 1), (120, 128, 120, 3, 2), (9, 64, 9, 3, 0), (40, 64, 20, 1, 0), (3, 64, 3, 4, 0)])
+def test_device_built_pair_tables_equal_the_host_built_ones(shape):
+    """A windowed search inside the band builds the pair tables (kept pairs, match offsets, per-pose incidence lists, band
+    slots) on the device; `set_correspondences` builds them on the host from the caller's lists.  Same set -> the same
+    tables -> the same sums in the same order: cost, gradient and the whole solve agree bit for bit, and the pair lists
+    read back are the oracle's (JointOptimization.cpp:632-641: pose order, more than kMinInterPoseCorrespondence matches)."""
+    n, m, ppf, window, groups = shape
+    prob = Problem(n, m, ppf=ppf, groups=groups)
+    g, o = prob.load(_gpu()), prob.load(_oracle())
+    g.find_correspondences(prob.init, window)            # device-built tables
+    o.find_correspondences(prob.init, window, 0)
+    rng = np.random.default_rng(11)
+    x = (prob.init + 0.01 * rng.standard_normal(prob.init.shape)).astype(np.float32)
+    c_dev, g_dev = g.evaluate(2, x)                      # before any host mirror of the lists exists
+    p_dev, s_dev = g.solve(2, prob.init)
+    lists = g.get_correspondences()
+    for a, b in zip(lists, o.get_correspondences()):
+        assert np.array_equal(a, b)
+    h = prob.load(_gpu(), corr=lists)                    # host-built tables from the same lists
+    c_host, g_host = h.evaluate(2, x)
+    p_host, s_host = h.solve(2, prob.init)
+    assert c_dev == c_host and np.array_equal(g_dev, g_host)
+    assert s_dev.iterations == s_host.iterations and s_dev.final_cost == s_host.final_cost
+    assert np.array_equal(p_dev, p_host)
