@@ -159,7 +159,7 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
       TRYC(s->ob_lo.upload(zero1, st)); TRYC(s->ob_hi.upload(zero1, st));
       TRYC(s->ob_fwd.upload(minus1, st)); TRYC(s->ob_rev.upload(minus1, st));
       TRYC(s->obadj_off.resize((size_t)n + 1)); TRYC(s->obadj_off.zero(st));
-      TRYC(s->obadj_ent.resize(1));
+      TRYC(s->obadj_ent.resize(1)); TRYC(s->obadj_col.resize(1));
       s->obadj_nonzero = false;
     }
     if (hipStreamSynchronize(st) != hipSuccess) return fail(HITL_ERR_HIP, "find_correspondences: the pair-table kernels failed");

@@ -924,7 +924,7 @@ __global__ __launch_bounds__(1024) void k_cr_chunk_back(CrView cr, int S, int M,
 // subtraction (left neighbour first) -- the same order of operations as the factorising kernel, so a solve through
 // k_cr_chunk and one through this kernel agree bit for bit.  Boundary contributions travel through Pw like there.
 template <int B>
-__global__ __launch_bounds__(512) void k_cr_chunk_fwd(CrView cr, CrStage sg, double* w, double* x) {
+__global__ __launch_bounds__(512) void k_cr_chunk_fwd(CrView cr, CrStage sg, const double* w_in, double* w, double* x) {
   extern __shared__ double lds[];
   constexpr int BB = B * B;
   const int M = sg.M, S = sg.S, nsl = sg.nsl;
@@ -952,8 +952,9 @@ __global__ __launch_bounds__(512) void k_cr_chunk_fwd(CrView cr, CrStage sg, dou
     const int u = e / B, q = e % B;
     const int64_t sn = base + u;
     const size_t g = (size_t)(sn * S) * B + q;
-    double v = w[g];
+    double v = sg.has_prev ? w[g] : w_in[g];     // the first stage may read the right-hand side from another vector (no copy in front)
     if (sg.has_prev) v = (v - WLp[(size_t)sn * B + q]) - WRp[(size_t)sn * B + q];
+    else if (w_in != w) w[g] = v;                // ... and then leaves every node's value where the backward stages read it
     sW[e] = v;
     if (sg.has_prev && (u == 0 || u == M) == false) w[g] = v;
     if (u == 0 && sg.has_prev && !sg.top) w[g] = v;
@@ -1097,7 +1098,7 @@ static bool cr_factor_fused(hipStream_t st, const CrView& cr, double* w, double*
 
 // x = M^-1 w through the stored factors, one right-hand side, fused stages (3 + 3 launches instead of ~30)
 template <int B>
-static bool cr_solve_fused(hipStream_t st, const CrView& cr, double* w, double* x) {
+static bool cr_solve_fused(hipStream_t st, const CrView& cr, const double* w_in, double* w, double* x) {
   if (cr.P == nullptr || cr.Pw == nullptr) return false;
   static bool raised = false;
   if (!raised) {
@@ -1111,7 +1112,7 @@ static bool cr_solve_fused(hipStream_t st, const CrView& cr, double* w, double* 
     const int chunks = g.top ? 1 : (int)((alive - 1 + g.M - 1) / g.M);
     const size_t lds = sizeof(double) * ((size_t)g.nsl * (2 * B * B + 3 * B) + 2 * B);
     if (lds > 128 * 1024) return false;
-    hipLaunchKernelGGL(k_cr_chunk_fwd<B>, dim3(chunks > 0 ? chunks : 1), dim3(256), lds, st, cr, g, w, x);
+    hipLaunchKernelGGL(k_cr_chunk_fwd<B>, dim3(chunks > 0 ? chunks : 1), dim3(256), lds, st, cr, g, w_in, w, x);
   }
   for (int t = pl.n - 1; t >= 0; --t) {
     const CrStage& g = pl.st[t];
@@ -1210,18 +1211,21 @@ void launch_cr_solve_multi(hipStream_t st, const CrView& cr, double* w, double* 
   }
 }
 
-void launch_cr_solve(hipStream_t st, const CrView& cr, double* w, double* x) {
+void launch_cr_solve(hipStream_t st, const CrView& cr, const double* rhs, double* w, double* x) {
   static const bool legacy = std::getenv("HITL_CR_LEGACY") != nullptr;
   bool done = false;
   if (!legacy) {
     switch (cr.B) {
-      case 3: done = cr_solve_fused<3>(st, cr, w, x); break;
-      case 6: done = cr_solve_fused<6>(st, cr, w, x); break;
-      case 9: done = cr_solve_fused<9>(st, cr, w, x); break;
-      default: done = cr_solve_fused<12>(st, cr, w, x); break;
+      case 3: done = cr_solve_fused<3>(st, cr, rhs, w, x); break;
+      case 6: done = cr_solve_fused<6>(st, cr, rhs, w, x); break;
+      case 9: done = cr_solve_fused<9>(st, cr, rhs, w, x); break;
+      default: done = cr_solve_fused<12>(st, cr, rhs, w, x); break;
     }
   }
-  if (!done) launch_cr_solve_multi(st, cr, w, x, 1, 0);
+  if (!done) {
+    if (rhs != w) (void)hipMemcpyAsync(w, rhs, sizeof(double) * (size_t)cr.nsb * cr.B, hipMemcpyDeviceToDevice, st);
+    launch_cr_solve_multi(st, cr, w, x, 1, 0);
+  }
 }
 
 // ===========================================================================================

@@ -50,6 +50,9 @@ struct FactorView {         // everything assemble needs besides the per-pair r/
   const int* ob_lo; const int* ob_hi; const int* ob_fwd; const int* ob_rev;   // E each
   const int* obadj_off;       // n+1
   const int* obadj_ent;       // entry*2 + transposed
+  const int* obadj_col;       // the other pose of the entry (ob_hi or ob_lo), resolved once on the host
+  double* ob_acc;             // npad scratch, or null: dense off-band adjacency -> k_spmv_offband sums a pose's off-band
+                              // blocks with one wave per pose in front of k_spmv; sparse -> k_spmv walks the few entries itself
   // constant poses (global pose 0, submap halos) and the owned range of a submap
   const unsigned char* fixed; // n : 1 = constant
   int own_lo, own_hi;         // cost / |g|max / step scalars are taken over local poses [own_lo, own_hi)
@@ -112,7 +115,7 @@ void launch_halo_candidate(hipStream_t st, int cnt, const int* idx, const double
 // factorise and solve M x = w in one pass (w is destroyed)
 void launch_cr_factor_solve(hipStream_t st, const CrView& cr, double* w, double* x, int nrhs = 1, size_t stride = 0);
 // x = M^{-1} w   (w is destroyed)
-void launch_cr_solve(hipStream_t st, const CrView& cr, double* w, double* x);
+void launch_cr_solve(hipStream_t st, const CrView& cr, const double* rhs, double* w, double* x);   // x = M^-1 rhs; w = work vector (may be rhs itself: overwritten)
 // y = (S H S [+ D^2]) v ; damping added when mu > 0
 void launch_spmv(hipStream_t st, int n_poses, int npad, const FactorView& fv, const LinView& lin,
                  const double* scale, double mu, double min_diag, double max_diag, const double* v, double* y);
@@ -133,6 +136,10 @@ void launch_dots(hipStream_t st, int n, int ndots, const double* const* a, const
 // PCG updates with device-resident scalars s[] = (r.z, previous r.z, p.q, r.r, breakdown flag)
 void launch_pcg_update_p(hipStream_t st, int n, const double* z, double* p, const double* s, bool first);
 void launch_pcg_update_xr(hipStream_t st, int n, const double* p, const double* q, double* x, double* r, double* s);
+// the same steps for systems one workgroup can sweep (n <= kPcgFusedMax): dot + update in one launch each, bit-identical sums
+constexpr int kPcgFusedMax = 32768;
+void launch_pcg_dir(hipStream_t st, int n, const double* r, const double* z, double* p, double* s, bool first);          // r.z, p = z + beta p
+void launch_pcg_step(hipStream_t st, int n, const double* p, const double* q, double* x, double* r, double* s);          // p.q, x, r, r.r
 // y = alpha*x + beta*y
 void launch_axpby(hipStream_t st, int n, double alpha, const double* x, double beta, double* y);
 void launch_copy(hipStream_t st, int n, const double* src, double* dst);

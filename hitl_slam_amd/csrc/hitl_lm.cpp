@@ -203,8 +203,9 @@ static int linear_solve_and_step(hitl_solver* s, const FactorView& fv, int buf, 
     return HITL_OK;
   }
   // off-band pose pairs present: PCG on the full matrix from x0, preconditioned by the band factorisation.  The
-  // iteration runs on the device: its scalars (r.z, p.q, r.r) never leave d_scalars, a CG iteration is 13 queued
-  // launches (copy, 3 + 3 fused preconditioner stages, 3 dots, 2 updates, one band product), and the host looks at r.r
+  // iteration runs on the device: its scalars (r.z, p.q, r.r) never leave d_scalars, a CG iteration is the fused
+  // preconditioner stages (forward + backward), the product (off-band sums + band) and two single-workgroup kernels that
+  // pair each dot with the update that needs it (larger systems: 3 dots + 2 updates), and the host looks at r.r
   // only once per kPcgBatch iterations (up to kPcgBatch - 1 iterations past the tolerance: harmless).
   double rr, bb;
   TRY(read_step_partials(s, &rr, &bb, nullptr));
@@ -216,8 +217,13 @@ static int linear_solve_and_step(hitl_solver* s, const FactorView& fv, int buf, 
   for (int it = 0; it < s->opt.max_linear_iterations && rr > target;) {
     const int nb = std::min(kPcgBatch, s->opt.max_linear_iterations - it);
     for (int k = 0; k < nb; ++k, ++it) {
-      launch_copy(st, npad, s->rv.p, s->wv.p);
-      launch_cr_solve(st, cr, s->wv.p, s->zv.p);                                   // z = M^-1 r
+      launch_cr_solve(st, cr, s->rv.p, s->wv.p, s->zv.p);                          // z = M^-1 r
+      if (npad <= kPcgFusedMax) {          // one workgroup sweeps the vectors: each dot shares a launch with the update that needs it
+        launch_pcg_dir(st, npad, s->rv.p, s->zv.p, s->pv.p, sc, it == 0);          // r.z, p = z + beta p
+        launch_spmv(st, s->n, npad, fv, lv, s->scale.p, mu, mind, maxd, s->pv.p, s->qv.p);   // q = A p
+        launch_pcg_step(st, npad, s->pv.p, s->qv.p, s->dt.p, s->rv.p, sc);         // p.q, x += alpha p, r -= alpha q, r.r
+        continue;
+      }
       const double* a1[4] = {s->rv.p, s->rv.p, s->rv.p, s->rv.p};
       const double* b1[4] = {s->zv.p, s->zv.p, s->zv.p, s->zv.p};
       launch_dots(st, npad, 1, a1, b1, sc + 0);                                    // r.z

@@ -110,8 +110,11 @@ int build_pair_structures(hitl_solver* s) {
   std::vector<int> obadj_off(n + 1, 0);
   for (int e = 0; e < E; ++e) { obadj_off[ob_lo[e] + 1]++; obadj_off[ob_hi[e] + 1]++; }
   for (int i = 0; i < n; ++i) obadj_off[i + 1] += obadj_off[i];
-  std::vector<int> obadj_ent(std::max(2 * E, 1)), fill2(obadj_off.begin(), obadj_off.end() - 1);
-  for (int e = 0; e < E; ++e) { obadj_ent[fill2[ob_lo[e]]++] = 2 * e; obadj_ent[fill2[ob_hi[e]]++] = 2 * e + 1; }
+  std::vector<int> obadj_ent(std::max(2 * E, 1)), obadj_col(std::max(2 * E, 1)), fill2(obadj_off.begin(), obadj_off.end() - 1);
+  for (int e = 0; e < E; ++e) {
+    obadj_col[fill2[ob_lo[e]]] = ob_hi[e]; obadj_ent[fill2[ob_lo[e]]++] = 2 * e;
+    obadj_col[fill2[ob_hi[e]]] = ob_lo[e]; obadj_ent[fill2[ob_hi[e]]++] = 2 * e + 1;
+  }
   s->n_offband = E;
   hipStream_t st = s->stream;
   TRY(s->pose_pair_off.upload(ppo, st));
@@ -121,7 +124,7 @@ int build_pair_structures(hitl_solver* s) {
   if (ob_lo.empty()) { ob_lo.push_back(0); ob_hi.push_back(0); ob_fwd.push_back(-1); ob_rev.push_back(-1); }
   TRY(s->ob_lo.upload(ob_lo, st)); TRY(s->ob_hi.upload(ob_hi, st));
   TRY(s->ob_fwd.upload(ob_fwd, st)); TRY(s->ob_rev.upload(ob_rev, st));
-  TRY(s->obadj_off.upload(obadj_off, st)); TRY(s->obadj_ent.upload(obadj_ent, st));
+  TRY(s->obadj_off.upload(obadj_off, st)); TRY(s->obadj_ent.upload(obadj_ent, st)); TRY(s->obadj_col.upload(obadj_col, st));
   HIP_TRY(hipStreamSynchronize(st));
   return HITL_OK;
 }
@@ -161,6 +164,7 @@ int ensure_work(hitl_solver* s, int Wb) {
     TRY(s->lin_partials[k].resize((size_t)assemble_blocks(n) * 2));
   }
   TRY(s->step_partials.resize((size_t)spmv_blocks(s->npad) * 8));
+  TRY(s->ob_acc.resize(npad));
   TRY(s->pose_cs.resize((size_t)n));
   {
     // step partials at offset 0, linearisation partials behind them: one iteration reads both with one sync
@@ -262,7 +266,9 @@ FactorView factor_view(hitl_solver* s, int mode, int Wb) {
   f.hc_off = s->hc_off.p; f.hc_type = s->hc_type.p; f.hc_tgt = s->hc_tgt.p;
   f.n_offband = f.with_stf ? s->n_offband : 0;
   f.ob_lo = s->ob_lo.p; f.ob_hi = s->ob_hi.p; f.ob_fwd = s->ob_fwd.p; f.ob_rev = s->ob_rev.p;
-  f.obadj_off = s->obadj_off.p; f.obadj_ent = s->obadj_ent.p;
+  f.obadj_off = s->obadj_off.p; f.obadj_ent = s->obadj_ent.p; f.obadj_col = s->obadj_col.p;
+  // 8 or more off-band neighbours per pose on average: a serial walk per pose is what the product then waits for
+  f.ob_acc = (f.n_offband > 0 && (int64_t)2 * f.n_offband >= (int64_t)8 * s->n) ? s->ob_acc.p : nullptr;
   f.fixed = s->fixed.p; f.own_lo = s->own_lo; f.own_hi = s->own_hi;
   return f;
 }

@@ -84,7 +84,8 @@ struct hitl_solver {
   int64_t moments_of = -1;                     // correspondence-set generation the moments belong to
   int64_t corr_generation = 0;                 // bumped whenever the pair tables change
   int n_offband = 0;
-  DevArray<int> inc_off, inc_ent, band_pair, ob_lo, ob_hi, ob_fwd, ob_rev, obadj_off, obadj_ent;
+  DevArray<int> inc_off, inc_ent, band_pair, ob_lo, ob_hi, ob_fwd, ob_rev, obadj_off, obadj_ent, obadj_col;
+  DevArray<double> ob_acc;                     // per-pose sums of the off-band products (k_spmv_offband)
 
   // ---- per-solve factor tables ----
   DevArray<float4> odom_A, hc_tgt;

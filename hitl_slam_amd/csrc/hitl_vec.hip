@@ -74,7 +74,10 @@ __global__ __launch_bounds__(128) void k_spmv(int n_poses, int npad, FactorView 
 #pragma unroll
         for (int a = 0; a < 3; ++a) acc[a] += blk[a] * v0 + blk[3 + a] * v1 + blk[6 + a] * v2;
       }
-      if (fv.with_stf && fv.n_offband > 0) {
+      if (fv.with_stf && fv.n_offband > 0 && fv.ob_acc != nullptr) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) acc[a] += fv.ob_acc[3 * i + a];        // summed by k_spmv_offband in front of this launch
+      } else if (fv.with_stf && fv.n_offband > 0) {
         for (int e = fv.obadj_off[i]; e < fv.obadj_off[i + 1]; ++e) {
           const int ent = fv.obadj_ent[e];
           const int en = ent >> 1, tr = ent & 1;
@@ -134,11 +137,50 @@ __global__ __launch_bounds__(128) void k_spmv(int n_poses, int npad, FactorView 
   }
 }
 
+// Off-band part of the product for maps whose poses see many far-away poses (all-pairs search on a corridor: ~90 blocks
+// per pose): one wave per pose, lanes stride over the pose's adjacency entries, fixed-order butterfly sum.  ALLCOLS: columns
+// of constant poses take part (the step bookkeeping of MODE 2/3).
+template <bool ALLCOLS>
+__global__ __launch_bounds__(256) void k_spmv_offband(int n_poses, FactorView fv, LinView lin, const double* __restrict__ scale,
+                                                       const double* __restrict__ v, double* __restrict__ ob) {
+  const int i = (blockIdx.x * 256 + (int)threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (i >= n_poses || fv.fixed[i]) return;        // wave-uniform
+  double acc[3] = {0, 0, 0};
+  for (int e = fv.obadj_off[i] + lane; e < fv.obadj_off[i + 1]; e += WAVE) {
+    const int ent = fv.obadj_ent[e], j = fv.obadj_col[e];
+    if (!ALLCOLS && fv.fixed[j]) continue;
+    const double* blk = lin.obblk + (size_t)(ent >> 1) * 9;
+    const double v0 = scale[3 * j] * v[3 * j], v1 = scale[3 * j + 1] * v[3 * j + 1], v2 = scale[3 * j + 2] * v[3 * j + 2];
+    if (!(ent & 1)) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) acc[a] += blk[a * 3] * v0 + blk[a * 3 + 1] * v1 + blk[a * 3 + 2] * v2;
+    } else {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) acc[a] += blk[a] * v0 + blk[3 + a] * v1 + blk[6 + a] * v2;
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const double t = wave_sum(acc[a]);
+    if (lane == 0) ob[3 * i + a] = t;
+  }
+}
+
+static void spmv_offband(hipStream_t st, int n_poses, const FactorView& fv, const LinView& lin, const double* scale, const double* v,
+                         bool allcols) {
+  if (!(fv.with_stf && fv.n_offband > 0 && fv.ob_acc != nullptr)) return;
+  const dim3 grid((n_poses + 3) / 4), block(256);
+  if (allcols) hipLaunchKernelGGL(k_spmv_offband<true>, grid, block, 0, st, n_poses, fv, lin, scale, v, fv.ob_acc);
+  else hipLaunchKernelGGL(k_spmv_offband<false>, grid, block, 0, st, n_poses, fv, lin, scale, v, fv.ob_acc);
+}
+
 int spmv_blocks(int npad) { return ((npad + 2) / 3 + 127) / 128; }
 
 void launch_spmv(hipStream_t st, int n_poses, int npad, const FactorView& fv, const LinView& lin, const double* scale,
                  double mu, double min_diag, double max_diag, const double* v, double* y) {
   SpmvAux aux = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  spmv_offband(st, n_poses, fv, lin, scale, v, false);
   hipLaunchKernelGGL(k_spmv<0>, dim3(spmv_blocks(npad)), dim3(128), 0, st, n_poses, npad, fv, lin, scale, mu, min_diag,
                      max_diag, v, y, aux);
 }
@@ -147,6 +189,7 @@ void launch_spmv_residual(hipStream_t st, int n_poses, int npad, const FactorVie
                           const double* scale, double mu, double min_diag, double max_diag, const double* v,
                           const double* rhs, double* r_out, double* partials) {
   SpmvAux aux = {rhs, r_out, nullptr, nullptr, partials, nullptr};
+  spmv_offband(st, n_poses, fv, lin, scale, v, false);
   hipLaunchKernelGGL(k_spmv<1>, dim3(spmv_blocks(npad)), dim3(128), 0, st, n_poses, npad, fv, lin, scale, mu, min_diag,
                      max_diag, v, (double*)nullptr, aux);
 }
@@ -155,6 +198,7 @@ void launch_spmv_residual_step(hipStream_t st, int n_poses, int npad, const Fact
                                double min_diag, double max_diag, const double* v, const double* rhs, const double* x, double* q, double* xc,
                                double* partials, double2* cs) {
   SpmvAux aux = {rhs, nullptr, x, xc, partials, cs};
+  spmv_offband(st, n_poses, fv, lin, scale, v, true);
   hipLaunchKernelGGL(k_spmv<3>, dim3(spmv_blocks(npad)), dim3(128), 0, st, n_poses, npad, fv, lin, scale, mu, min_diag, max_diag, v, q, aux);
 }
 
@@ -162,6 +206,7 @@ void launch_spmv_step(hipStream_t st, int n_poses, int npad, const FactorView& f
                       const double* scale, const double* dt, const double* rhs, const double* x, double* q, double* xc,
                       double* partials) {
   SpmvAux aux = {rhs, nullptr, x, xc, partials, nullptr};
+  spmv_offband(st, n_poses, fv, lin, scale, dt, true);
   hipLaunchKernelGGL(k_spmv<2>, dim3(spmv_blocks(npad)), dim3(128), 0, st, n_poses, npad, fv, lin, scale, 0.0, 0.0, 0.0, dt,
                      q, aux);
 }
@@ -294,6 +339,48 @@ void launch_pcg_update_p(hipStream_t st, int n, const double* z, double* p, cons
 
 void launch_pcg_update_xr(hipStream_t st, int n, const double* p, const double* q, double* x, double* r, double* s) {
   hipLaunchKernelGGL(k_pcg_update_xr, dim3((n + 255) / 256), dim3(256), 0, st, n, p, q, x, r, s);
+}
+
+// one workgroup: s[0] = r.z, then p = z + (r.z / previous r.z) p          (k_dots + k_pcg_update_p in one launch)
+__global__ __launch_bounds__(kRedBlock) void k_pcg_dir(int n, const double* __restrict__ r, const double* __restrict__ z, double* __restrict__ p,
+                                                        double* __restrict__ s, int first) {
+  __shared__ double sm[kRedBlock / WAVE];
+  double acc = 0.0;
+  for (int t = threadIdx.x; t < n; t += kRedBlock) acc += r[t] * z[t];
+  const double rz = block_sum(acc, sm);
+  const double rz_old = s[1];
+  const double beta = (first || rz_old == 0.0) ? 0.0 : rz / rz_old;
+  for (int t = threadIdx.x; t < n; t += kRedBlock) p[t] = z[t] + (first ? 0.0 : beta * p[t]);
+  if (threadIdx.x == 0) s[0] = rz;
+}
+
+// one workgroup: s[2] = p.q, alpha = r.z / p.q, x += alpha p, r -= alpha q, s[3] = r.r, s[1] <- r.z   (k_dots, k_pcg_update_xr, k_dots)
+__global__ __launch_bounds__(kRedBlock) void k_pcg_step(int n, const double* __restrict__ p, const double* __restrict__ q, double* __restrict__ x,
+                                                         double* __restrict__ r, double* __restrict__ s) {
+  __shared__ double sm[kRedBlock / WAVE];
+  double acc = 0.0;
+  for (int t = threadIdx.x; t < n; t += kRedBlock) acc += p[t] * q[t];
+  const double pq = block_sum(acc, sm);
+  const double rz = s[0];
+  const bool ok = pq > 0.0;
+  const double alpha = ok ? rz / pq : 0.0;
+  acc = 0.0;
+  for (int t = threadIdx.x; t < n; t += kRedBlock) {
+    x[t] += alpha * p[t];
+    const double rt = r[t] - alpha * q[t];
+    r[t] = rt;
+    acc += rt * rt;
+  }
+  const double rr = block_sum(acc, sm);
+  if (threadIdx.x == 0) { s[1] = rz; s[2] = pq; s[3] = rr; if (!ok && rz != 0.0) s[4] = 1.0; }
+}
+
+void launch_pcg_dir(hipStream_t st, int n, const double* r, const double* z, double* p, double* s, bool first) {
+  hipLaunchKernelGGL(k_pcg_dir, dim3(1), dim3(kRedBlock), 0, st, n, r, z, p, s, first ? 1 : 0);
+}
+
+void launch_pcg_step(hipStream_t st, int n, const double* p, const double* q, double* x, double* r, double* s) {
+  hipLaunchKernelGGL(k_pcg_step, dim3(1), dim3(kRedBlock), 0, st, n, p, q, x, r, s);
 }
 
 __global__ void k_axpby(int n, double alpha, const double* __restrict__ x, double beta, double* __restrict__ y) {
