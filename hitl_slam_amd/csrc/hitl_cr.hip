@@ -35,42 +35,80 @@ void launch_jacobi_scale(hipStream_t st, int n_poses, int npad, int Wb, const do
 // (Wb consecutive poses each) in the Jacobi-scaled space with the LM diagonal
 //   D^2 = clamp(diag(S H S), min, max) / mu     
 // ===========================================================================================
-// one thread per (super-block k, row a, column b): coalesced stores of D and L
-__global__ void k_build_system(int n_poses, int Wb, const double* __restrict__ Hband, const double* __restrict__ g,
-                               const double* __restrict__ scale, const unsigned char* __restrict__ fixed, double mu,
-                               double min_diag, double max_diag, CrView cr, double* __restrict__ rhs, double* __restrict__ rhs_work) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int B = cr.B, BB = B * B;
-  if (t >= cr.nsb * BB) return;
-  const int k = t / BB, e = t % BB, a = e / B, b = e % B;
-  const int i = k * Wb + a / 3, ca = a % 3;
-  if (i >= n_poses || fixed[i]) {     // padding rows and constant poses: identity
-    cr.D[t] = (b == a) ? 1.0 : 0.0;
-    cr.L[t] = 0.0;
-    if (b == 0) { rhs[k * B + a] = 0.0; if (rhs_work) rhs_work[k * B + a] = 0.0; }
-    return;
-  }
+// entry e = a * B + b of super-block k: D (with the LM diagonal) and L (coupling to super-block k - 1)
+__device__ __forceinline__ void cr_source_tile(const CrSource& sc, int B, int k, int e, double& dv, double& lv) {
+  const int a = e / B, b = e % B;
+  const int Wb = sc.Wb, i = k * Wb + a / 3, ca = a % 3;
+  if (i >= sc.n_poses || sc.fixed[i]) { dv = (b == a) ? 1.0 : 0.0; lv = 0.0; return; }     // padding rows and constant poses: identity
   const int W1 = Wb + 1;
-  const double sa = scale[3 * i + ca];
+  const double sa = sc.scale[3 * i + ca];
   const int i2 = k * Wb + b / 3, cb = b % 3;
   double v = 0.0;
-  if (i2 < n_poses && !fixed[i2]) {
-    v = (i2 >= i) ? Hband[((size_t)i * W1 + (i2 - i)) * 9 + ca * 3 + cb]
-                  : Hband[((size_t)i2 * W1 + (i - i2)) * 9 + cb * 3 + ca];
-    v *= sa * scale[3 * i2 + cb];
+  if (i2 < sc.n_poses && !sc.fixed[i2]) {
+    v = (i2 >= i) ? sc.Hband[((size_t)i * W1 + (i2 - i)) * 9 + ca * 3 + cb]
+                  : sc.Hband[((size_t)i2 * W1 + (i - i2)) * 9 + cb * 3 + ca];
+    v *= sa * sc.scale[3 * i2 + cb];
   }
-  if (b == a) v += fmin(fmax(v, min_diag), max_diag) / mu;
-  cr.D[t] = v;
+  if (b == a) v += fmin(fmax(v, sc.min_diag), sc.max_diag) / sc.mu;
+  dv = v;
   double l = 0.0;
   if (k > 0) {
     const int i3 = (k - 1) * Wb + b / 3;
     const int d = i - i3;
-    if (d <= Wb && !fixed[i3]) l = Hband[((size_t)i3 * W1 + d) * 9 + cb * 3 + ca] * sa * scale[3 * i3 + cb];
+    if (d <= Wb && !sc.fixed[i3]) l = sc.Hband[((size_t)i3 * W1 + d) * 9 + cb * 3 + ca] * sa * sc.scale[3 * i3 + cb];
   }
-  cr.L[t] = l;
-  if (b == 0) {
-    const double v = -sa * g[3 * i + ca];
-    rhs[k * B + a] = v;
+  lv = l;
+}
+
+// The same entry from a staged copy of the band rows: pose i's record (rl = (Wb + 1) * 9 + 4 doubles: band blocks, 3 scales,
+// constant flag) sits at rec + (i - p0) * rl.  Same operations in the same order as cr_source_tile.
+__device__ __forceinline__ void cr_source_tile_rec(const double* rec, int rl, int p0, int n_poses, int Wb, double mu, double min_diag,
+                                                   double max_diag, int B, int k, int e, double& dv, double& lv) {
+  const int a = e / B, b = e % B;
+  const int i = k * Wb + a / 3, ca = a % 3;
+  const int so = (Wb + 1) * 9;
+  const double* ri = rec + (size_t)(i - p0) * rl;
+  if (i >= n_poses || ri[so + 3] != 0.0) { dv = (b == a) ? 1.0 : 0.0; lv = 0.0; return; }
+  const double sa = ri[so + ca];
+  const int i2 = k * Wb + b / 3, cb = b % 3;
+  const double* r2 = rec + (size_t)(i2 - p0) * rl;
+  double v = 0.0;
+  if (i2 < n_poses && r2[so + 3] == 0.0) {
+    v = (i2 >= i) ? ri[(i2 - i) * 9 + ca * 3 + cb] : r2[(i - i2) * 9 + cb * 3 + ca];
+    v *= sa * r2[so + cb];
+  }
+  if (b == a) v += fmin(fmax(v, min_diag), max_diag) / mu;
+  dv = v;
+  double l = 0.0;
+  if (k > 0) {
+    const int i3 = (k - 1) * Wb + b / 3;
+    const int d = i - i3;
+    const double* r3 = rec + (size_t)(i3 - p0) * rl;
+    if (d <= Wb && r3[so + 3] == 0.0) l = r3[d * 9 + cb * 3 + ca] * sa * r3[so + cb];
+  }
+  lv = l;
+}
+
+__device__ __forceinline__ double cr_source_rhs(const CrSource& sc, int k, int a) {
+  const int i = k * sc.Wb + a / 3, ca = a % 3;
+  if (i >= sc.n_poses || sc.fixed[i]) return 0.0;
+  return -sc.scale[3 * i + ca] * sc.g[3 * i + ca];
+}
+
+// one thread per (super-block k, row a, column b): coalesced stores of D and L
+__global__ void k_build_system(CrSource sc, CrView cr, double* __restrict__ rhs_work) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int B = cr.B, BB = B * B;
+  if (t >= cr.nsb * BB) return;
+  const int k = t / BB, e = t % BB;
+  double dv, lv;
+  cr_source_tile(sc, B, k, e, dv, lv);
+  cr.D[t] = dv;
+  cr.L[t] = lv;
+  if (e % B == 0) {
+    const int a = e / B;
+    const double v = cr_source_rhs(sc, k, a);
+    sc.rhs[k * B + a] = v;
     if (rhs_work) rhs_work[k * B + a] = v;      // the copy the factor-solve consumes in place
   }
 }
@@ -79,8 +117,8 @@ void launch_build_system(hipStream_t st, int n_poses, int Wb, const LinView& lin
                          const unsigned char* fixed, double mu, double min_diag, double max_diag, const CrView& cr,
                          double* rhs, double* rhs_work) {
   const int tot = cr.nsb * cr.B * cr.B;
-  hipLaunchKernelGGL(k_build_system, dim3((tot + 255) / 256), dim3(256), 0, st, n_poses, Wb, lin.Hband, lin.g, scale, fixed,
-                     mu, min_diag, max_diag, cr, rhs, rhs_work);
+  const CrSource sc = {lin.Hband, lin.g, scale, fixed, mu, min_diag, max_diag, n_poses, Wb, rhs};
+  hipLaunchKernelGGL(k_build_system, dim3((tot + 255) / 256), dim3(256), 0, st, sc, cr, rhs_work);
 }
 
 // ===========================================================================================
@@ -650,7 +688,7 @@ __device__ __forceinline__ void lds_barrier() {
 }
 
 template <int B>
-__global__ __launch_bounds__(B >= 12 ? 512 : 1024) void k_cr_chunk(CrView cr, CrStage sg, double* w, double* x) {
+__global__ __launch_bounds__(B >= 12 ? 512 : 1024) void k_cr_chunk(CrView cr, CrStage sg, CrSource src, double* w, double* x) {
   extern __shared__ double lds[];
   constexpr int BB = B * B;
   const int M = sg.M, S = sg.S;
@@ -674,20 +712,50 @@ __global__ __launch_bounds__(B >= 12 ? 512 : 1024) void k_cr_chunk(CrView cr, Cr
   // local slots that exist: u with base + u < nst
   const int u_last = (int)((nst - 1 - base < M) ? (nst - 1 - base) : M);     // >= 0
   const bool has_w = (w != nullptr) && NR > 0;
+  const bool from_src = src.Hband != nullptr;             // host: only with S == 1, no previous stage, one right-hand side
   const size_t pws = (size_t)4 * sg.np * B;               // doubles of one right-hand side's contribution arrays
   const double* PLp = cr.P + (size_t)(sg.prev_par * 2 + 0) * sg.np * BB;
   const double* PRp = cr.P + (size_t)(sg.prev_par * 2 + 1) * sg.np * BB;
   const double* WLp = cr.Pw + (size_t)(sg.prev_par * 2 + 0) * sg.np * B;
   const double* WRp = cr.Pw + (size_t)(sg.prev_par * 2 + 1) * sg.np * B;
+  // ---- first stage straight from the band blocks: stage the band rows of this chunk's poses (and of the super-block on its
+  //      left, for L of local 0) with coalesced loads; the tiles are then cut from LDS.  The staging area lies over sPb / sG
+  //      (idle until the first elimination) when it fits there, behind everything else otherwise (cr_chunk_src_extra) ----
+  const int src_rl = (src.Wb + 1) * 9 + 4;
+  const int src_p0 = from_src ? (int)((base > 0 ? base - 1 : 0) * src.Wb) : 0;
+  double* sRec = nullptr;
+  if (from_src) {
+    const int p1 = min(src.n_poses, (int)(base + u_last + 1) * src.Wb);
+    const int np_st = max(p1 - src_p0, 0);
+    const size_t need = (size_t)(nsl + 1) * src.Wb * src_rl, avail = (size_t)nsl * BB + (size_t)NW * 2 * BB;
+    sRec = (need <= avail) ? sPb : accWL + (size_t)NR * B;
+    const int hl = (src.Wb + 1) * 9;
+    const double* Hg = src.Hband + (size_t)src_p0 * hl;
+    for (int e = tid; e < np_st * hl; e += nthr) sRec[(size_t)(e / hl) * src_rl + e % hl] = Hg[e];
+    for (int e = tid; e < np_st * 4; e += nthr) {
+      const int pp = e >> 2, c = e & 3;
+      sRec[(size_t)pp * src_rl + hl + c] = (c < 3) ? src.scale[3 * (src_p0 + pp) + c] : (src.fixed[src_p0 + pp] ? 1.0 : 0.0);
+    }
+    lds_barrier();
+  }
   // ---- load: D (folded with the previous stage's contributions), L, w of local 0 .. u_last ----
   for (int e = tid; e < (u_last + 1) * BB; e += nthr) {
     const int u = e / BB, q = e % BB;
     const int64_t sn = base + u;                           // stage node index == slot of the previous stage's arrays
     const size_t g = (size_t)(sn * S) * BB + q;
-    double d = cr.D[g];
+    double d, l;
+    if (from_src) {
+      // first stage straight from the band blocks (k_build_system's arithmetic): only the nodes that outlive this stage
+      // -- the chunk boundaries -- need their D in memory, where the next stage folds the contributions into it
+      cr_source_tile_rec(sRec, src_rl, src_p0, src.n_poses, src.Wb, src.mu, src.min_diag, src.max_diag, B, (int)sn, q, d, l);
+      if (u == 0 || (u == M && sn == nst - 1)) cr.D[g] = d;
+    } else {
+      d = cr.D[g];
+      l = cr.L[g];
+    }
     if (sg.has_prev) d = (d - PLp[(size_t)sn * BB + q]) - PRp[(size_t)sn * BB + q];
     sD[e] = d;
-    sL[e] = cr.L[g];
+    sL[e] = l;
     if (u == 0 && sg.has_prev && !sg.top) cr.D[g] = d;     // the left boundary stays alive: keep its folded value
   }
   if (has_w)
@@ -696,7 +764,9 @@ __global__ __launch_bounds__(B >= 12 ? 512 : 1024) void k_cr_chunk(CrView cr, Cr
       const int u = e2 / B, q = e2 % B;
       const int64_t sn = base + u;
       const size_t g = sg.wstride * rv + (size_t)(sn * S) * B + q;
-      double v = w[g];
+      double v;
+      if (from_src) { v = cr_source_rhs(src, (int)sn, q); w[g] = v; src.rhs[g] = v; }    // one right-hand side: -S g, kept for the back-substitution and the caller
+      else v = w[g];
       if (sg.has_prev) v = (v - WLp[pws * rv + (size_t)sn * B + q]) - WRp[pws * rv + (size_t)sn * B + q];
       sW[((size_t)rv * nsl + u) * B + q] = v;
       if (sg.has_prev && (u == 0 || u == M) == false) w[g] = v;          // interior: the back-substitution reads the folded w
@@ -1020,6 +1090,11 @@ static size_t cr_chunk_lds_bytes(int M, int B, int threads, int nrhs) {
   const int nr = nrhs > 0 ? nrhs : 1;
   return sizeof(double) * ((size_t)(M + 1) * (3 * B * B + 3 * B * nr) + (size_t)(threads / 64) * 2 * B * B + 2 * B * B + 2 * B * nr);
 }
+// extra dynamic LDS of a first stage that stages its band rows (k_cr_chunk, from_src) when they do not fit over sPb / sG
+static size_t cr_chunk_src_extra(int nsl, int B, int threads, int Wb) {
+  const size_t need = (size_t)(nsl + 1) * Wb * ((Wb + 1) * 9 + 4), avail = (size_t)nsl * B * B + (size_t)(threads / 64) * 2 * B * B;
+  return (need <= avail) ? 0 : need * sizeof(double);
+}
 static int cr_chunk_threads(int M, int B) { return (M <= 2) ? 64 : (M <= 4) ? 128 : (M <= 8) ? 256 : (M >= 32 && B < 12) ? 1024 : 512; }
 
 // stages of the fused factorisation for nsb super-blocks (host): chunks of 16 at stride 1, chunks of 32 above, then the top.
@@ -1061,9 +1136,10 @@ static CrPlan cr_plan(int nsb, int B, int np, int nrhs, size_t wstride) {
 int cr_contrib_slots(int nsb) { return nsb / 2 + 3; }     // boundary nodes of the finest chunk stage (M = 2)
 
 template <int B>
-static bool cr_factor_fused(hipStream_t st, const CrView& cr, double* w, double* x, int nrhs, size_t wstride) {
+static bool cr_factor_fused(hipStream_t st, const CrView& cr, double* w, double* x, int nrhs, size_t wstride, const CrSource* src = nullptr) {
   if (cr.P == nullptr || cr.Pw == nullptr) return false;
   if (w == nullptr) nrhs = 0;
+  if (src != nullptr && (nrhs != 1 || x == nullptr)) return false;
   if (nrhs > cr.pw_rhs) return false;                     // contribution arrays are sized for cr.pw_rhs right-hand sides
   static bool raised = false;
   if (!raised) {
@@ -1078,8 +1154,11 @@ static bool cr_factor_fused(hipStream_t st, const CrView& cr, double* w, double*
     const int64_t alive = ((int64_t)cr.nsb + g.S - 1) / g.S;
     const int chunks = g.top ? 1 : (int)((alive - 1 + g.M - 1) / g.M);       // chunks with at least one interior or boundary-M node
     const int thr = cr_chunk_threads(g.M, B);
-    const size_t lds = cr_chunk_lds_bytes(g.nsl - 1, B, thr, nrhs);
-    hipLaunchKernelGGL(k_cr_chunk<B>, dim3(chunks > 0 ? chunks : 1), dim3(thr), lds, st, cr, g, w, x);
+    const bool use_src = (src != nullptr && t == 0);
+    const size_t lds = cr_chunk_lds_bytes(g.nsl - 1, B, thr, nrhs) + (use_src ? cr_chunk_src_extra(g.nsl, B, thr, src->Wb) : 0);
+    if (lds > 128 * 1024) return false;
+    CrSource none = {};
+    hipLaunchKernelGGL(k_cr_chunk<B>, dim3(chunks > 0 ? chunks : 1), dim3(thr), lds, st, cr, g, (src != nullptr && t == 0) ? *src : none, w, x);
   }
   if (w != nullptr && x != nullptr) {
     for (int t = pl.n - 1; t >= 0; --t) {
@@ -1200,6 +1279,23 @@ void launch_cr_factor_solve(hipStream_t st, const CrView& cr, double* w, double*
     case 9: cr_factor_t<9>(st, cr, w, x, nrhs, stride); break;
     default: cr_factor_t<12>(st, cr, w, x, nrhs, stride); break;
   }
+}
+
+void launch_cr_build_factor_solve(hipStream_t st, const CrView& cr, const CrSource& src, double* w, double* x) {
+  static const bool legacy = std::getenv("HITL_CR_LEGACY") != nullptr || std::getenv("HITL_CR_UNFUSED_BUILD") != nullptr;
+  bool done = false;
+  if (!legacy) {
+    switch (cr.B) {
+      case 3: done = cr_factor_fused<3>(st, cr, w, x, 1, 0, &src); break;
+      case 6: done = cr_factor_fused<6>(st, cr, w, x, 1, 0, &src); break;
+      case 9: done = cr_factor_fused<9>(st, cr, w, x, 1, 0, &src); break;
+      default: done = cr_factor_fused<12>(st, cr, w, x, 1, 0, &src); break;
+    }
+  }
+  if (done) return;
+  const int tot = cr.nsb * cr.B * cr.B;
+  hipLaunchKernelGGL(k_build_system, dim3((tot + 255) / 256), dim3(256), 0, st, src, cr, w);
+  launch_cr_factor_solve(st, cr, w, x, 1, 0);
 }
 
 void launch_cr_solve_multi(hipStream_t st, const CrView& cr, double* w, double* x, int nrhs, size_t stride) {

@@ -66,6 +66,13 @@ struct LinView {            // one linearisation (double buffered by the driver)
   double* partials;           // assemble workgroups x 2 : (cost, max |g|) per workgroup
 };
 
+struct CrSource {           // where the first cyclic-reduction stage can take its tiles from instead of cr.D / cr.L (Hband == null: unused)
+  const double* Hband; const double* g; const double* scale; const unsigned char* fixed;
+  double mu, min_diag, max_diag;
+  int n_poses, Wb;
+  double* rhs;                // receives the scaled right-hand side -S g (the copy the residual check and the step bookkeeping read)
+};
+
 struct CrView {             // block-tridiagonal system + cyclic-reduction factors
   int nsb;                    // super-blocks
   int B;                      // 3*Wb
@@ -115,6 +122,9 @@ void launch_halo_candidate(hipStream_t st, int cnt, const int* idx, const double
 // factorise and solve M x = w in one pass (w is destroyed)
 void launch_cr_factor_solve(hipStream_t st, const CrView& cr, double* w, double* x, int nrhs = 1, size_t stride = 0);
 // x = M^{-1} w   (w is destroyed)
+// build_system + factor + solve with the first stage reading the band blocks itself (no D / L round trip through memory);
+// falls back to launch_build_system + launch_cr_factor_solve where the fused stages do not apply
+void launch_cr_build_factor_solve(hipStream_t st, const CrView& cr, const CrSource& src, double* w, double* x);
 void launch_cr_solve(hipStream_t st, const CrView& cr, const double* rhs, double* w, double* x);   // x = M^-1 rhs; w = work vector (may be rhs itself: overwritten)
 // y = (S H S [+ D^2]) v ; damping added when mu > 0
 void launch_spmv(hipStream_t st, int n_poses, int npad, const FactorView& fv, const LinView& lin,

@@ -257,8 +257,8 @@ static int enqueue_linear_solve_banded(hitl_solver* s, const FactorView& fv, int
   const CrView cr = s->cr_view();
   const double mind = s->opt.min_lm_diagonal, maxd = s->opt.max_lm_diagonal;
   const int npad = s->npad;
-  launch_build_system(st, s->n, fv.band_poses, lv, s->scale.p, s->fixed.p, mu, mind, maxd, cr, s->rhs.p, s->wv.p);
-  launch_cr_factor_solve(st, cr, s->wv.p, s->dt.p);
+  const CrSource src = {lv.Hband, lv.g, s->scale.p, s->fixed.p, mu, mind, maxd, s->n, fv.band_poses, s->rhs.p};
+  launch_cr_build_factor_solve(st, cr, src, s->wv.p, s->dt.p);
   // residual check of the factorisation and the trust-region bookkeeping in one pass over the band
   launch_spmv_residual_step(st, s->n, npad, fv, lv, s->scale.p, mu, mind, maxd, s->dt.p, s->rhs.p, xcur, s->qv.p, xcand, s->h_partials,   // straight into pinned host memory
                             fv.with_stf ? s->pose_cs.p : nullptr);
