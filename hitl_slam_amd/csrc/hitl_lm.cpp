@@ -101,6 +101,24 @@ int comm_allgather(hitl_solver* s, const void* send, void* recv, int64_t bytes) 
   return HITL_OK;
 }
 
+// the same exchange with the send record already in device memory: RCCL takes it where it is and one copy brings the
+// gathered records to the host; a caller callback (host buffers) gets a host copy of the record first
+int comm_allgather_dev(hitl_solver* s, const void* send_dev, void* recv_host, int64_t bytes, std::vector<double>& stage) {
+  hipStream_t st = s->stream;
+  if (s->nccl && !s->comm.allgather) {
+    TRY(s->comm_recv.resize((size_t)bytes * s->world));
+    const ncclResult_t r = ncclAllGather(send_dev, s->comm_recv.p, (size_t)bytes, ncclChar, s->nccl, st);
+    if (r != ncclSuccess) return fail(HITL_ERR_COMM, std::string("ncclAllGather: ") + ncclGetErrorString(r));
+    HIP_TRY(hipMemcpyAsync(recv_host, s->comm_recv.p, (size_t)bytes * s->world, hipMemcpyDeviceToHost, st));
+    TRY(spin_sync(s));
+    return HITL_OK;
+  }
+  stage.resize((size_t)(bytes + 7) / 8);
+  HIP_TRY(hipMemcpyAsync(stage.data(), send_dev, (size_t)bytes, hipMemcpyDeviceToHost, st));
+  TRY(spin_sync(s));
+  return comm_allgather(s, stage.data(), recv_host, bytes);
+}
+
 static inline double nan_max(double a, double b) { return (b > a || b != b) ? b : a; }
 
 // local linearisation (every rank evaluates all factors touching its owned poses, so its rows are
@@ -283,7 +301,7 @@ static int linear_solve_and_step_dist(hitl_solver* s, const FactorView& fv, int 
   const CrView cr = s->cr_view();
   const double mind = s->opt.min_lm_diagonal, maxd = s->opt.max_lm_diagonal;
   const int npad = s->npad, n = s->n, W = s->world, me = s->rank;
-  const int Wb = fv.band_poses, Wi = s->Wi, m = 3 * Wi, nc = 2 * m, W1 = Wb + 1;
+  const int Wb = fv.band_poses, Wi = s->Wi, m = 3 * Wi, nc = 2 * m;
   *iters = 1;
   *ok = true;
   launch_build_system(st, n, Wb, lv, s->scale.p, s->fixed.p, mu, mind, maxd, cr, s->rhs.p);
@@ -292,37 +310,14 @@ static int linear_solve_and_step_dist(hitl_solver* s, const FactorView& fv, int 
   launch_cr_factor_solve(st, cr, s->rhsN.p, s->zN.p, 1 + nc, (size_t)npad);   // z0 and Z = M^{-1} [E_F, E_L]
   launch_copy(st, npad, s->zN.p, s->dt.p);
   const double* Z = s->zN.p + npad;
-  launch_gather_iface(st, s->dt.p, Z, (size_t)npad, s->scale.p, s->if_cols.p, nc, s->iface_dev.p);
   const int RI = nc * (nc + 2), RC = m * m, R = RI + 2 * RC;
+  // the exchange record (interface rows of z0 / Z / scale, then the two cross-cut blocks) is put together on the device
+  launch_gather_iface(st, s->dt.p, Z, (size_t)npad, s->scale.p, s->if_cols.p, nc, s->iface_dev.p);
+  launch_iface_blocks(st, lv.Hband, Wb, Wi, s->own_lo, s->own_hi, me > 0, me < W - 1, s->iface_dev.p + RI, s->iface_dev.p + RI + RC);
   // host buffers of the exchange live in the solver (sized once per interface width, reused every LM iteration)
-  std::vector<double>&rec = s->if_rec, &hb_lo = s->if_hb_lo, &hb_up = s->if_hb_up, &all = s->if_all, &A = s->if_A, &y = s->if_y, &Ct = s->if_Ct;
-  rec.assign((size_t)R, 0.0);
-  hb_lo.assign((size_t)Wi * W1 * 9, 0.0); hb_up.assign((size_t)Wi * W1 * 9, 0.0);
-  HIP_TRY(hipMemcpyAsync(rec.data(), s->iface_dev.p, sizeof(double) * RI, hipMemcpyDeviceToHost, st));
-  // cross-cut blocks from the band: block (i, i+d) lives at Hband[i][d]
-  if (me > 0) HIP_TRY(hipMemcpyAsync(hb_lo.data(), lv.Hband + (size_t)(s->own_lo - Wi) * W1 * 9, sizeof(double) * hb_lo.size(), hipMemcpyDeviceToHost, st));
-  if (me < W - 1) HIP_TRY(hipMemcpyAsync(hb_up.data(), lv.Hband + (size_t)(s->own_hi - Wi) * W1 * 9, sizeof(double) * hb_up.size(), hipMemcpyDeviceToHost, st));
-  TRY(spin_sync(s));
-  double* Clo = rec.data() + RI;        // rows: first Wi owned poses, cols: the Wi halo poses below
-  double* Cup = Clo + RC;               // rows: last Wi owned poses,  cols: the Wi halo poses above
-  if (me > 0)
-    for (int ap = 0; ap < Wi; ++ap)
-      for (int bp = 0; bp < Wi; ++bp) {
-        const int d = (Wi + ap) - bp;   // a = own_lo + ap, b = own_lo - Wi + bp
-        if (d > Wb) continue;
-        const double* blk = &hb_lo[((size_t)bp * W1 + d) * 9];   // block (b, a): transpose it
-        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Clo[(size_t)(3 * ap + r) * m + 3 * bp + c] = blk[c * 3 + r];
-      }
-  if (me < W - 1)
-    for (int ap = 0; ap < Wi; ++ap)
-      for (int bp = 0; bp < Wi; ++bp) {
-        const int d = (Wi + bp) - ap;   // a = own_hi - Wi + ap, b = own_hi + bp
-        if (d > Wb) continue;
-        const double* blk = &hb_up[((size_t)ap * W1 + d) * 9];   // block (a, b)
-        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Cup[(size_t)(3 * ap + r) * m + 3 * bp + c] = blk[r * 3 + c];
-      }
+  std::vector<double>&rec = s->if_rec, &all = s->if_all, &A = s->if_A, &y = s->if_y, &Ct = s->if_Ct;
   all.resize((size_t)R * W);
-  TRY(comm_allgather(s, rec.data(), all.data(), sizeof(double) * R));
+  TRY(comm_allgather_dev(s, s->iface_dev.p, all.data(), (int64_t)sizeof(double) * R, rec));
   auto z0_of = [&](int g) { return &all[(size_t)R * g]; };
   auto Z_of = [&](int g) { return &all[(size_t)R * g + nc]; };              // Z[c][r] = Z_of[nc*c + r]
   auto sc_of = [&](int g) { return &all[(size_t)R * g + nc + nc * nc]; };   // [0,m): first Wi poses, [m,2m): last Wi

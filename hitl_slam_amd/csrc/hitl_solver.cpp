@@ -341,7 +341,7 @@ int prepare(hitl_solver* s, int mode, const float* poses_ref, const float* poses
     TRY(s->if_cols.upload(cols, s->stream));
     if (hidx.empty()) hidx.push_back(0);
     TRY(s->halo_idx.upload(hidx, s->stream));
-    TRY(s->iface_dev.resize((size_t)nc * (nc + 2)));
+    TRY(s->iface_dev.resize((size_t)nc * (nc + 2) + 2 * (size_t)(nc / 2) * (nc / 2)));   // interface rows + the two cross-cut blocks
     TRY(s->rhsN.resize((size_t)(1 + nc) * s->npad)); TRY(s->zN.resize((size_t)(1 + nc) * s->npad));
     TRY(s->coef_dev.resize(nc)); TRY(s->halo_val.resize(nc)); TRY(s->halo_sc.resize(nc));
     HIP_TRY(hipStreamSynchronize(s->stream));
@@ -500,6 +500,15 @@ int hitl_solver_comm_selftest(hitl_solver* s) {
   for (int r = 0; r < s->world; ++r)
     for (int k = 0; k < 8; ++k)
       if (recv[(size_t)8 * r + k] != 0x4849544c00000000ull + (uint64_t)r * 8 + k) return fail(HITL_ERR_COMM, "all-gather self-test: wrong payload");
+  // the same payload from a device buffer: the path the interface records of a submap solve take
+  DevArray<uint64_t> dsend;
+  TRY(dsend.upload(send, 8, s->stream));
+  std::fill(recv.begin(), recv.end(), 0);
+  std::vector<double> stage;
+  TRY(comm_allgather_dev(s, dsend.p, recv.data(), sizeof(send), stage));
+  for (int r = 0; r < s->world; ++r)
+    for (int k = 0; k < 8; ++k)
+      if (recv[(size_t)8 * r + k] != 0x4849544c00000000ull + (uint64_t)r * 8 + k) return fail(HITL_ERR_COMM, "all-gather self-test (device record): wrong payload");
   return HITL_OK;
 }
 

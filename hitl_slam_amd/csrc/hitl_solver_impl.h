@@ -48,7 +48,7 @@ struct hitl_solver {
   DevArray<unsigned char> fixed;     // n : constant poses (global pose 0, halos)
   DevArray<int> if_cols, halo_idx;   // interface column indices (2m) ; scalar indices of the nearest halo poses
   DevArray<double> iface_dev, rhsN, zN, coef_dev, halo_val, halo_sc;
-  std::vector<double> if_rec, if_hb_lo, if_hb_up, if_all, if_A, if_y, if_Ct;   // host side of the interface exchange
+  std::vector<double> if_rec, if_all, if_A, if_y, if_Ct;   // host side of the interface exchange
   int Wi = 1;                        // interface width in poses: deepest reach of a factor across any cut (global max)
   int n_pairs_owned = 0;             // pairs whose SOURCE pose is owned (each pair is counted by one rank)
   int64_t n_matches_owned = 0;
@@ -147,6 +147,7 @@ int prepare(hitl_solver* s, int mode, const float* poses_ref, const float* poses
 // hitl_lm.cpp
 int run_linearize(hitl_solver* s, const FactorView& fv, const double* xdev, int buf, LinResult* out);
 int comm_allgather(hitl_solver* s, const void* send, void* recv, int64_t bytes);
+int comm_allgather_dev(hitl_solver* s, const void* send_dev, void* recv_host, int64_t bytes, std::vector<double>& stage);   // send record in device memory
 int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float* poses_global, float* poses_out, hitl_summary* summary);
 // hitl_corr.cpp
 int find_correspondences(hitl_solver* s, const float* poses, int64_t window);

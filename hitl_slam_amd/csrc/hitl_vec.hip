@@ -244,6 +244,32 @@ void launch_gather_iface(hipStream_t st, const double* z0, const double* Z, size
   hipLaunchKernelGGL(k_gather_iface, dim3(1), dim3(256), 0, st, z0, Z, stride, scale, cols_dev, ncols, out);
 }
 
+// cross-cut Hessian blocks of a submap rank, cut from the band where they were assembled (block (i, i+d) lives at
+// Hband[i][d]), into the exchange record:  Clo[3ap+r][3bp+c] = block(own_lo + ap, own_lo - Wi + bp)  (transposed band
+// block),  Cup[3ap+r][3bp+c] = block(own_hi - Wi + ap, own_hi + bp);  zero beyond the band or at the ends of the map
+__global__ void k_iface_blocks(const double* __restrict__ Hband, int Wb, int Wi, int own_lo, int own_hi, int has_lo, int has_up,
+                               double* __restrict__ Clo, double* __restrict__ Cup) {
+  const int m = 3 * Wi, W1 = Wb + 1;
+  for (int t = threadIdx.x; t < 2 * m * m; t += blockDim.x) {
+    const int up = t / (m * m), e = t % (m * m);
+    const int row = e / m, col = e % m, ap = row / 3, r = row % 3, bp = col / 3, c = col % 3;
+    double v = 0.0;
+    if (!up && has_lo) {
+      const int d = (Wi + ap) - bp;                       // a = own_lo + ap, b = own_lo - Wi + bp
+      if (d <= Wb) v = Hband[((size_t)(own_lo - Wi + bp) * W1 + d) * 9 + c * 3 + r];
+    } else if (up && has_up) {
+      const int d = (Wi + bp) - ap;                       // a = own_hi - Wi + ap, b = own_hi + bp
+      if (d <= Wb) v = Hband[((size_t)(own_hi - Wi + ap) * W1 + d) * 9 + r * 3 + c];
+    }
+    (up ? Cup : Clo)[e] = v;
+  }
+}
+
+void launch_iface_blocks(hipStream_t st, const double* Hband, int Wb, int Wi, int own_lo, int own_hi, bool has_lo, bool has_up,
+                         double* Clo, double* Cup) {
+  hipLaunchKernelGGL(k_iface_blocks, dim3(1), dim3(256), 0, st, Hband, Wb, Wi, own_lo, own_hi, has_lo ? 1 : 0, has_up ? 1 : 0, Clo, Cup);
+}
+
 // dt = z0 - sum_k coef[k] * Z[k]   (Z: ncols columns, `stride` apart; coef in device memory)
 __global__ void k_combine(int npad, const double* __restrict__ z0, const double* __restrict__ Z, size_t stride,
                           const double* __restrict__ coef, int ncols, double* __restrict__ dt) {
