@@ -130,7 +130,9 @@ void launch_cr_build_factor_solve(hipStream_t st, const CrView& cr, const CrSour
 void launch_cr_solve(hipStream_t st, const CrView& cr, const double* rhs, double* w, double* x);   // x = M^-1 rhs; w = work vector (may be rhs itself: overwritten)
 // y = (S H S [+ D^2]) v ; damping added when mu > 0
 void launch_spmv(hipStream_t st, int n_poses, int npad, const FactorView& fv, const LinView& lin,
-                 const double* scale, double mu, double min_diag, double max_diag, const double* v, double* y);
+                 const double* scale, double mu, double min_diag, double max_diag, const double* v, double* y, bool all_cols = false);
+void launch_pack_owned(hipStream_t st, int nhead, const double* head, const double* vec, int off, int cnt, int maxcnt, double* rec);
+void launch_scatter_idx(hipStream_t st, int cnt, const int* idx, const double* val, double* vec);
 int spmv_blocks(int npad);
 // r = rhs - (S H S + D^2) v ; partials[blk*8 + 0,1] = (r.r, rhs.rhs) per workgroup
 void launch_spmv_residual(hipStream_t st, int n_poses, int npad, const FactorView& fv, const LinView& lin,

@@ -284,6 +284,90 @@ static int enqueue_linear_solve_banded(hitl_solver* s, const FactorView& fv, int
   return HITL_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// distributed PCG pieces (submap ranks holding pose pairs outside the band)
+// ---------------------------------------------------------------------------------------
+// One exchange: every rank contributes `nhead` scalars (device memory) and the owned part of `vec`; afterwards the halo
+// rows of `vec` hold their owners' values and heads[r * nhead + k] the scalars of rank r.
+static int dist_gather_owned(hitl_solver* s, int nhead, const double* head_dev, double* vec, std::vector<double>* heads) {
+  hipStream_t st = s->stream;
+  const int W = s->world, cnt = 3 * (s->own_hi - s->own_lo), maxcnt = 3 * s->maxown, R = nhead + maxcnt;
+  launch_pack_owned(st, nhead, head_dev, vec, 3 * s->own_lo, cnt, maxcnt, s->pcg_rec.p);
+  s->pcg_all.resize((size_t)R * W);
+  TRY(comm_allgather_dev(s, s->pcg_rec.p, s->pcg_all.data(), (int64_t)sizeof(double) * R, s->pcg_stage));
+  if (heads) {
+    heads->resize((size_t)nhead * W);
+    for (int r = 0; r < W; ++r) for (int k = 0; k < nhead; ++k) (*heads)[(size_t)nhead * r + k] = s->pcg_all[(size_t)R * r + k];
+  }
+  if (s->n_halo > 0) {
+    s->pcg_hval.resize((size_t)s->n_halo);
+    for (int k = 0; k < s->n_halo; ++k) {
+      const int slot = s->halo_owner_slot[k], r = slot / maxcnt, o = slot % maxcnt;
+      s->pcg_hval[k] = s->pcg_all[(size_t)R * r + nhead + o];
+    }
+    HIP_TRY(hipMemcpyAsync(s->halo_val.p, s->pcg_hval.data(), sizeof(double) * s->n_halo, hipMemcpyHostToDevice, st));
+    launch_scatter_idx(st, s->n_halo, s->halo_idx.p, s->halo_val.p, vec);
+  }
+  return HITL_OK;
+}
+
+// (S H S + D^2) dt = rhs over ALL ranks by preconditioned CG; the preconditioner is block-Jacobi: every rank's own banded
+// block (halo poses constant), factorised by cyclic reduction as in the single-GPU solve.  Products use the halo entries of
+// p (filled from the owners by the exchange that also carries r.z, r.r); p.q takes a second, scalar exchange.  Sums run
+// over the ranks in rank order on every rank: all ranks take identical decisions.  dt returns with its halo rows filled.
+static int dist_pcg_solve(hitl_solver* s, const FactorView& fv, const LinView& lv, const CrView& cr, double mu, int* iters, bool* ok) {
+  hipStream_t st = s->stream;
+  const double mind = s->opt.min_lm_diagonal, maxd = s->opt.max_lm_diagonal;
+  const int npad = s->npad, n = s->n, W = s->world;
+  const int off = 3 * s->own_lo, cnt = 3 * (s->own_hi - s->own_lo);
+  const double tol = std::max(s->opt.linear_solver_tolerance, 1e-15);
+  double* x = s->dt.p;
+  double* head = s->pcg_head.p;
+  HIP_TRY(hipMemsetAsync(x, 0, sizeof(double) * npad, st));
+  HIP_TRY(hipMemsetAsync(s->pv.p, 0, sizeof(double) * npad, st));
+  launch_copy(st, npad, s->rhs.p, s->rv.p);
+  std::vector<double> heads;
+  double rz_old = 0.0, target = 0.0;
+  *iters = 0;
+  for (int it = 0;; ++it) {
+    if (it == 0) { launch_copy(st, npad, s->rv.p, s->wv.p); launch_cr_factor_solve(st, cr, s->wv.p, s->zv.p); }   // factorise + z = M^-1 r
+    else launch_cr_solve(st, cr, s->rv.p, s->wv.p, s->zv.p);
+    {
+      const double* a[4] = {s->rv.p + off, s->rv.p + off, s->rhs.p + off, s->rv.p + off};
+      const double* b[4] = {s->zv.p + off, s->rv.p + off, s->rhs.p + off, s->rv.p + off};
+      launch_dots(st, cnt, 3, a, b, head);                       // r.z, r.r, b.b over the owned rows
+    }
+    TRY(dist_gather_owned(s, 3, head, s->zv.p, &heads));
+    double rz = 0.0, rr = 0.0, bb = 0.0;
+    for (int r = 0; r < W; ++r) { rz += heads[(size_t)3 * r]; rr += heads[(size_t)3 * r + 1]; bb += heads[(size_t)3 * r + 2]; }
+    if (it == 0) target = tol * tol * bb;
+    if (!(rr == rr) || !(rz == rz)) { *ok = false; break; }
+    if (rr <= target || it >= s->opt.max_linear_iterations) break;
+    const double beta = (it == 0 || rz_old == 0.0) ? 0.0 : rz / rz_old;
+    launch_axpby(st, npad, 1.0, s->zv.p, beta, s->pv.p);         // p = z + beta p  (halo rows: the owners' z, this rank's copy of their p)
+    launch_spmv(st, n, npad, fv, lv, s->scale.p, mu, mind, maxd, s->pv.p, s->qv.p, /*all_cols=*/true);
+    {
+      const double* a[4] = {s->pv.p + off, s->pv.p + off, s->pv.p + off, s->pv.p + off};
+      const double* b[4] = {s->qv.p + off, s->qv.p + off, s->qv.p + off, s->qv.p + off};
+      launch_dots(st, cnt, 1, a, b, head);
+    }
+    double mine = 0.0;
+    HIP_TRY(hipMemcpyAsync(&mine, head, sizeof(double), hipMemcpyDeviceToHost, st));
+    TRY(spin_sync(s));
+    std::vector<double> pqs((size_t)W);
+    TRY(comm_allgather(s, &mine, pqs.data(), sizeof(double)));
+    double pq = 0.0;
+    for (int r = 0; r < W; ++r) pq += pqs[r];
+    if (!(pq > 0.0)) { if (rz != 0.0) *ok = false; break; }
+    const double alpha = rz / pq;
+    launch_axpby(st, npad, alpha, s->pv.p, 1.0, x);              // halo rows of x follow their owners' x: same alpha, same p
+    launch_axpby(st, npad, -alpha, s->qv.p, 1.0, s->rv.p);
+    rz_old = rz;
+    ++*iters;
+  }
+  return HITL_OK;
+}
+
 // Submap version.  Rank g's unknowns x_g (owned poses) satisfy
 //     M_g x_g + E_F C_lo,g v_{g-1} + E_L C_up,g u_{g+1} = b_g
 // with M_g its own banded block (halo poses are constant locally), v_{g-1} / u_{g+1} the steps of
@@ -305,6 +389,12 @@ static int linear_solve_and_step_dist(hitl_solver* s, const FactorView& fv, int 
   *iters = 1;
   *ok = true;
   launch_build_system(st, n, Wb, lv, s->scale.p, s->fixed.p, mu, mind, maxd, cr, s->rhs.p);
+  int nh = 0;
+  std::vector<double> coef, hval, hsc;   // uploaded asynchronously below: alive until the synchronisation at the end
+  if (s->dist_pcg) {
+    TRY(dist_pcg_solve(s, fv, lv, cr, mu, iters, ok));
+    nh = s->n_halo;                      // dt and scale already hold the owners' values on every halo row
+  } else {
   launch_copy(st, npad, s->rhs.p, s->rhsN.p);
   launch_unit_rhs(st, npad, s->rhsN.p + npad, (size_t)npad, s->if_cols.p, nc);
   launch_cr_factor_solve(st, cr, s->rhsN.p, s->zN.p, 1 + nc, (size_t)npad);   // z0 and Z = M^{-1} [E_F, E_L]
@@ -349,7 +439,7 @@ static int linear_solve_and_step_dist(hitl_solver* s, const FactorView& fv, int 
   }
   if (!solve_dense(NI, A, y)) *ok = false;
   // this rank's correction coefficients, and the neighbours' steps / scales for its halo poses
-  std::vector<double> coef(nc, 0.0), hval, hsc;
+  coef.assign(nc, 0.0);
   if (me >= 1) {
     const double* vprev = &y[nc * (me - 1) + m];
     for (int a = 0; a < m; ++a)
@@ -362,7 +452,7 @@ static int linear_solve_and_step_dist(hitl_solver* s, const FactorView& fv, int 
       for (int k = 0; k < m; ++k) coef[m + a] += sc_of(me)[m + a] * Cup_of(me)[(size_t)a * m + k] * sc_of(me + 1)[k] * unext[k];
     for (int k = 0; k < m; ++k) { hval.push_back(unext[k]); hsc.push_back(sc_of(me + 1)[k]); }
   }
-  const int nh = (int)hval.size();
+  nh = (int)hval.size();
   HIP_TRY(hipMemcpyAsync(s->coef_dev.p, coef.data(), sizeof(double) * nc, hipMemcpyHostToDevice, st));
   if (nh) {
     HIP_TRY(hipMemcpyAsync(s->halo_val.p, hval.data(), sizeof(double) * nh, hipMemcpyHostToDevice, st));
@@ -370,6 +460,7 @@ static int linear_solve_and_step_dist(hitl_solver* s, const FactorView& fv, int 
   }
   launch_combine(st, npad, s->dt.p, Z, (size_t)npad, s->coef_dev.p, nc, s->dt.p);
   launch_scatter_halo(st, nh, s->halo_idx.p, s->halo_val.p, s->halo_sc.p, s->dt.p, s->scale.p);
+  }
   // model-cost pieces over the owned rows (halo columns carry the neighbours' steps), candidate state
   launch_spmv_step(st, n, npad, fv, lv, s->scale.p, s->dt.p, s->rhs.p, xcur, s->qv.p, xcand, s->step_partials.p);
   launch_halo_candidate(st, nh, s->halo_idx.p, xcur, s->scale.p, s->dt.p, xcand);
@@ -440,6 +531,7 @@ int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float* poses
   const int n_edges = (s->own_hi - s->own_lo) - ((s->g_begin == 0) ? 1 : 0);
   S.num_residuals = (fv.with_stf ? 2 * s->n_pairs_owned : 0) + (fv.with_odom ? 3 * n_edges : 0) + (fv.with_hc ? s->num_hc_residuals : 0);
   launch_jacobi_scale(st, n, s->npad, fv.band_poses, s->Hband[cur].p, o.jacobi_scaling, s->fixed.p, s->scale.p);
+  if (s->world > 1 && s->dist_pcg) TRY(dist_gather_owned(s, 0, nullptr, s->scale.p, nullptr));   // halo rows: the owners' scales (complete diagonal blocks)
   double radius = o.initial_trust_region_radius, decrease_factor = 2.0;
   int iter = 0, invalid_run = 0;
   int term = HITL_NO_CONVERGENCE;

@@ -328,9 +328,47 @@ int prepare(hitl_solver* s, int mode, const float* poses_ref, const float* poses
       }
       if (local_rc != HITL_OK) return local_rc;
       if (worst != HITL_OK) return fail(worst, "another rank failed while preparing the solve");
-      if (any_offband) return fail(HITL_ERR_UNSUPPORTED, "submap solves need every pose pair inside the band (on every rank)");
+      s->dist_pcg = any_offband;
     }
     s->Wi = wi_local;
+    if (s->dist_pcg) {
+      // Pose pairs outside the band somewhere: the ranks iterate together (distributed PCG, hitl_lm.cpp).  A factor that
+      // straddles a cut must be seen by both ranks it touches, i.e. reach no deeper than the halos on either side.
+      if (s->Wi > s->halo_req)
+        return fail(HITL_ERR_UNSUPPORTED, "a pose pair reaches " + std::to_string(s->Wi) + " poses across a cut but the halos hold " +
+                                          std::to_string(s->halo_req) + ": raise halo_poses of hitl_solver_set_partition");
+      double mine2[2] = {(double)s->g_begin, (double)(s->own_hi - s->own_lo)};
+      std::vector<double> all2((size_t)2 * s->world);
+      TRY(comm_allgather(s, mine2, all2.data(), sizeof(mine2)));
+      s->part_begin.assign(s->world, 0); s->part_count.assign(s->world, 0);
+      s->maxown = 1;
+      for (int r = 0; r < s->world; ++r) {
+        s->part_begin[r] = (int64_t)all2[(size_t)2 * r]; s->part_count[r] = (int64_t)all2[(size_t)2 * r + 1];
+        s->maxown = std::max(s->maxown, (int)s->part_count[r]);
+      }
+      const int rec_len = 3 * s->maxown;         // head excluded
+      std::vector<int> hidx;
+      s->halo_owner_slot.clear();
+      for (int li = 0; li < s->n; ++li) {
+        if (li >= s->own_lo && li < s->own_hi) continue;
+        const int64_t gi = s->g_begin - s->hl + li;
+        int owner = -1;
+        for (int r = 0; r < s->world; ++r) if (gi >= s->part_begin[r] && gi < s->part_begin[r] + s->part_count[r]) owner = r;
+        if (owner < 0) return fail(HITL_ERR_INVALID_ARGUMENT, "the ranks' owned ranges do not tile the map");
+        for (int c = 0; c < 3; ++c) {
+          hidx.push_back(3 * li + c);
+          s->halo_owner_slot.push_back(owner * rec_len + 3 * (int)(gi - s->part_begin[owner]) + c);
+        }
+      }
+      s->n_halo = (int)hidx.size();
+      if (hidx.empty()) hidx.push_back(0);
+      TRY(s->halo_idx.upload(hidx, s->stream));
+      TRY(s->halo_val.resize((size_t)std::max(s->n_halo, 1)));
+      TRY(s->pcg_rec.resize((size_t)rec_len + 4)); TRY(s->pcg_head.resize(4));
+      HIP_TRY(hipStreamSynchronize(s->stream));
+      *fv = factor_view(s, mode, Wb);
+      return HITL_OK;
+    }
     const int Wi = s->Wi, nc = 6 * Wi;
     if (Wi > Wb) return fail(HITL_ERR_UNSUPPORTED, "a factor reaches further across a cut than the pose band");
     std::vector<int> cols(nc), hidx;

@@ -49,6 +49,15 @@ struct hitl_solver {
   DevArray<int> if_cols, halo_idx;   // interface column indices (2m) ; scalar indices of the nearest halo poses
   DevArray<double> iface_dev, rhsN, zN, coef_dev, halo_val, halo_sc;
   std::vector<double> if_rec, if_all, if_A, if_y, if_Ct;   // host side of the interface exchange
+  // off-band pose pairs on a submap rank: distributed PCG (block-Jacobi = the ranks' own band factorisations) instead of the
+  // exact interface system.  Every CG iteration all-gathers the owned part of one vector; halo rows are filled from it.
+  bool dist_pcg = false;
+  std::vector<int64_t> part_begin, part_count;   // owned global range of every rank
+  int maxown = 0;                                // widest owned range, in poses
+  int n_halo = 0;                                // halo scalars (3 per halo pose, all of them)
+  std::vector<int> halo_owner_slot;              // per halo scalar: index into the gathered records (rank * record + 3 * pose + c), head excluded
+  DevArray<double> pcg_rec, pcg_head;
+  std::vector<double> pcg_all, pcg_stage, pcg_hval;
   int Wi = 1;                        // interface width in poses: deepest reach of a factor across any cut (global max)
   int n_pairs_owned = 0;             // pairs whose SOURCE pose is owned (each pair is counted by one rank)
   int64_t n_matches_owned = 0;

@@ -2,6 +2,8 @@
 // check, trust-region bookkeeping), the submap interface helpers (unit right-hand sides, interface gather, combine,
 // halo scatter), dots / axpby / copy for the PCG.  fp64.
 
+#include <algorithm>
+
 #include "hitl_device.h"
 
 namespace hitl {
@@ -23,6 +25,8 @@ struct SpmvAux {
   double* xc;          // MODE 2
   double* partials;    // MODE 1, 2 : [gridDim.x][8]
   double2* cs;         // MODE 3 (may be null): (cos, sin) of the candidate's theta, saves the k_pose_trig launch in front of k_linearize_stf
+  int all_cols;        // MODE 0: columns of constant poses take part too (distributed PCG: the halo entries of v carry the
+                       // neighbouring submaps' values; global pose 0 carries an exact 0)
 };
 
 template <int MODE>
@@ -60,7 +64,7 @@ __global__ __launch_bounds__(128) void k_spmv(int n_poses, int npad, FactorView 
       const double* Hi = lin.Hband + (size_t)i * W1 * 9;
       for (int d = 0; d <= Wb && i + d < n_poses; ++d) {
         const int j = i + d;
-        if (!kStep && fv.fixed[j]) continue;
+        if (!kStep && !aux.all_cols && fv.fixed[j]) continue;
         const double* blk = Hi + d * 9;
         const double v0 = scale[3 * j] * v[3 * j], v1 = scale[3 * j + 1] * v[3 * j + 1], v2 = scale[3 * j + 2] * v[3 * j + 2];
 #pragma unroll
@@ -68,7 +72,7 @@ __global__ __launch_bounds__(128) void k_spmv(int n_poses, int npad, FactorView 
       }
       for (int d = 1; d <= Wb && i - d >= 0; ++d) {
         const int j = i - d;
-        if (!kStep && fv.fixed[j]) continue;
+        if (!kStep && !aux.all_cols && fv.fixed[j]) continue;
         const double* blk = lin.Hband + ((size_t)j * W1 + d) * 9;  // block (j, i), used transposed
         const double v0 = scale[3 * j] * v[3 * j], v1 = scale[3 * j + 1] * v[3 * j + 1], v2 = scale[3 * j + 2] * v[3 * j + 2];
 #pragma unroll
@@ -83,7 +87,7 @@ __global__ __launch_bounds__(128) void k_spmv(int n_poses, int npad, FactorView 
           const int en = ent >> 1, tr = ent & 1;
           const double* blk = lin.obblk + (size_t)en * 9;
           const int j = tr ? fv.ob_lo[en] : fv.ob_hi[en];
-          if (!kStep && fv.fixed[j]) continue;
+          if (!kStep && !aux.all_cols && fv.fixed[j]) continue;
           const double v0 = scale[3 * j] * v[3 * j], v1 = scale[3 * j + 1] * v[3 * j + 1], v2 = scale[3 * j + 2] * v[3 * j + 2];
           if (!tr) {
             for (int a = 0; a < 3; ++a) acc[a] += blk[a * 3] * v0 + blk[a * 3 + 1] * v1 + blk[a * 3 + 2] * v2;
@@ -178,9 +182,9 @@ static void spmv_offband(hipStream_t st, int n_poses, const FactorView& fv, cons
 int spmv_blocks(int npad) { return ((npad + 2) / 3 + 127) / 128; }
 
 void launch_spmv(hipStream_t st, int n_poses, int npad, const FactorView& fv, const LinView& lin, const double* scale,
-                 double mu, double min_diag, double max_diag, const double* v, double* y) {
-  SpmvAux aux = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  spmv_offband(st, n_poses, fv, lin, scale, v, false);
+                 double mu, double min_diag, double max_diag, const double* v, double* y, bool all_cols) {
+  SpmvAux aux = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, all_cols ? 1 : 0};
+  spmv_offband(st, n_poses, fv, lin, scale, v, all_cols);
   hipLaunchKernelGGL(k_spmv<0>, dim3(spmv_blocks(npad)), dim3(128), 0, st, n_poses, npad, fv, lin, scale, mu, min_diag,
                      max_diag, v, y, aux);
 }
@@ -188,7 +192,7 @@ void launch_spmv(hipStream_t st, int n_poses, int npad, const FactorView& fv, co
 void launch_spmv_residual(hipStream_t st, int n_poses, int npad, const FactorView& fv, const LinView& lin,
                           const double* scale, double mu, double min_diag, double max_diag, const double* v,
                           const double* rhs, double* r_out, double* partials) {
-  SpmvAux aux = {rhs, r_out, nullptr, nullptr, partials, nullptr};
+  SpmvAux aux = {rhs, r_out, nullptr, nullptr, partials, nullptr, 0};
   spmv_offband(st, n_poses, fv, lin, scale, v, false);
   hipLaunchKernelGGL(k_spmv<1>, dim3(spmv_blocks(npad)), dim3(128), 0, st, n_poses, npad, fv, lin, scale, mu, min_diag,
                      max_diag, v, (double*)nullptr, aux);
@@ -197,7 +201,7 @@ void launch_spmv_residual(hipStream_t st, int n_poses, int npad, const FactorVie
 void launch_spmv_residual_step(hipStream_t st, int n_poses, int npad, const FactorView& fv, const LinView& lin, const double* scale, double mu,
                                double min_diag, double max_diag, const double* v, const double* rhs, const double* x, double* q, double* xc,
                                double* partials, double2* cs) {
-  SpmvAux aux = {rhs, nullptr, x, xc, partials, cs};
+  SpmvAux aux = {rhs, nullptr, x, xc, partials, cs, 0};
   spmv_offband(st, n_poses, fv, lin, scale, v, true);
   hipLaunchKernelGGL(k_spmv<3>, dim3(spmv_blocks(npad)), dim3(128), 0, st, n_poses, npad, fv, lin, scale, mu, min_diag, max_diag, v, q, aux);
 }
@@ -205,7 +209,7 @@ void launch_spmv_residual_step(hipStream_t st, int n_poses, int npad, const Fact
 void launch_spmv_step(hipStream_t st, int n_poses, int npad, const FactorView& fv, const LinView& lin,
                       const double* scale, const double* dt, const double* rhs, const double* x, double* q, double* xc,
                       double* partials) {
-  SpmvAux aux = {rhs, nullptr, x, xc, partials, nullptr};
+  SpmvAux aux = {rhs, nullptr, x, xc, partials, nullptr, 0};
   spmv_offband(st, n_poses, fv, lin, scale, dt, true);
   hipLaunchKernelGGL(k_spmv<2>, dim3(spmv_blocks(npad)), dim3(128), 0, st, n_poses, npad, fv, lin, scale, 0.0, 0.0, 0.0, dt,
                      q, aux);
@@ -299,6 +303,30 @@ void launch_scatter_halo(hipStream_t st, int cnt, const int* idx, const double* 
                          double* scale) {
   if (cnt <= 0) return;
   hipLaunchKernelGGL(k_scatter_halo, dim3((cnt + 63) / 64), dim3(64), 0, st, cnt, idx, val, sc, dt, scale);
+}
+
+// distributed PCG: one exchange record = `nhead` scalars followed by the owned part of a vector, zero-padded to the widest rank
+__global__ void k_pack_owned(int nhead, const double* __restrict__ head, const double* __restrict__ vec, int off, int cnt, int maxcnt,
+                             double* __restrict__ rec) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < nhead) rec[t] = head[t];
+  if (t < maxcnt) rec[nhead + t] = (t < cnt) ? vec[off + t] : 0.0;
+}
+
+void launch_pack_owned(hipStream_t st, int nhead, const double* head, const double* vec, int off, int cnt, int maxcnt, double* rec) {
+  const int tot = std::max(maxcnt, nhead);
+  hipLaunchKernelGGL(k_pack_owned, dim3((tot + 255) / 256), dim3(256), 0, st, nhead, head, vec, off, cnt, maxcnt, rec);
+}
+
+// vec[idx[k]] = val[k]
+__global__ void k_scatter_idx(int cnt, const int* __restrict__ idx, const double* __restrict__ val, double* __restrict__ vec) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < cnt) vec[idx[k]] = val[k];
+}
+
+void launch_scatter_idx(hipStream_t st, int cnt, const int* idx, const double* val, double* vec) {
+  if (cnt <= 0) return;
+  hipLaunchKernelGGL(k_scatter_idx, dim3((cnt + 255) / 256), dim3(256), 0, st, cnt, idx, val, vec);
 }
 
 // candidate state of the halo poses: xc = x + scale * dt  (k_spmv<2> leaves xc = x on constant poses)

@@ -313,6 +313,12 @@ int hitl_solver_linearize(hitl_solver*, int32_t mode, const float* poses_ref_xyt
  * every rank); then 7 doubles per rank: the step scalars together with (cost, |g|max) of the
  * candidate, whose linearisation is queued speculatively behind the step.  (cost, |g|max) of the
  * initial linearisation travel once, before the loop.
+ * Pose pairs farther apart than the band (window > max_band_poses, the reference's all-pairs search
+ * JointOptimization.cpp:575-635, revisits) on ANY rank switch all ranks to a distributed PCG: block-Jacobi
+ * preconditioner = each rank's own band factorisation, two all-gathers per CG iteration -- (r.z, r.r, b.b) + the
+ * owned part of one vector (halo rows are filled from it), then p.q.  A pair that straddles a cut must reach no
+ * deeper than halo_poses on either side (both ranks it touches must see it), else HITL_ERR_UNSUPPORTED on every
+ * rank; halos may span several ranks (two ranks whose halos cover the whole map = all-pairs search over the map).
  * The all-gather is either the built-in RCCL one (opt.rccl_unique_id != NULL) or a caller
  * supplied callback on HOST buffers (tests use torch.distributed/gloo). */
 typedef int (*hitl_allgather_fn)(void* ctx, const void* send, void* recv, int64_t bytes_per_rank);

@@ -23,6 +23,10 @@ def main():
     from conftest import Problem
 
     n_per, halo = (60 if world == 2 else 40), 6     # halo = 2 x matching window
+    # variants of tests/test_submap_offband_gpu.py: poses per rank, halo depth, search window (0 = all pairs), band cap
+    n_per = int(os.environ.get("HITL_TEST_NPER", n_per))
+    halo = int(os.environ.get("HITL_TEST_HALO", halo))
+    window = int(os.environ.get("HITL_TEST_WINDOW", 3))
     prob = Problem(n_per * world, 48, ppf=ppf, groups=2, kind=0)
     b, e = rank * n_per, (rank + 1) * n_per
     lo, hi = b - (halo if rank > 0 else 0), e + (halo if rank < world - 1 else 0)
@@ -31,6 +35,8 @@ def main():
     opt.rank, opt.world_size = rank, world
     opt.device = rank % max(torch.cuda.device_count(), 1)
     opt.stf_moments = int(os.environ.get("HITL_TEST_STF_MOMENTS", "0"))
+    if "HITL_TEST_BAND" in os.environ:
+        opt.max_band_poses = int(os.environ["HITL_TEST_BAND"])
     s = H.Solver(opt)
     ops, keep = torch_allgather_ops()
     s.set_comm(ops, keep)
@@ -38,7 +44,7 @@ def main():
     sl = slice(lo * M, hi * M)
     s.set_map(np.arange(hi - lo + 1, dtype=np.int64) * M, prob.px[sl], prob.py[sl], prob.nx[sl], prob.ny[sl], prob.cov[lo:hi])
     s.set_human_constraints(prob.rows)
-    s.find_correspondences(prob.init, 3)
+    s.find_correspondences(prob.init, window)
     corr = s.get_correspondences()
     own = (corr[0] >= b) & (corr[0] < e)             # every pair is reported by the rank owning its source pose
     lens = corr[2][1:] - corr[2][:-1]
