@@ -687,6 +687,8 @@ __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
 template <int B>
 __global__ __launch_bounds__(B >= 12 ? 512 : 1024) void k_cr_chunk(CrView cr, CrStage sg, CrSource src, double* w, double* x) {
   extern __shared__ double lds[];
@@ -825,25 +827,33 @@ __global__ __launch_bounds__(B >= 12 ? 512 : 1024) void k_cr_chunk(CrView cr, Cr
         for (int r = 0; r < B; ++r) dstg[r * B + c] = col[r];
       }
       // (same wave: LDS operations complete in order, no barrier needed)
-      double acc[B];
+      // The three B x B products on the matrix pipe: v_mfma_f64_16x16x4_f64 holds a whole (zero-padded) 16 x 16 result per wave,
+      // lane l feeds A[l & 15][4 step + (l >> 4)] and B[4 step + (l >> 4)][l & 15] and receives rows (l >> 4) + 4 reg of column
+      // l & 15: ceil(B / 4) steps per product instead of B^2 broadcast reads and FMAs on a third of the lanes.
+      {
+        const int mr = lane & 15, mk = lane >> 4;
+        v4f64 c1 = {0.0, 0.0, 0.0, 0.0}, c2 = c1, c3 = c1;
 #pragma unroll
-      for (int r = 0; r < B; ++r) acc[r] = 0.0;
-      if (grp < 3) {
-        const double* G = Gs + ((grp == 1) ? BB : 0);                              // Gr for P_b, Gl otherwise
-        const bool on = (grp == 0) || has_b;
-        // one instruction stream for the three groups: A(r, q) = Abase[r * sr + q * sq] is L_u^T for g = 0, L_b otherwise
-        const double* Abase = (grp == 0) ? Lu : Lb;
-        const int sr = (grp == 0) ? 1 : B, sq = (grp == 0) ? B : 1;
-#pragma unroll 3
-        for (int qq = 0; qq < B; ++qq) {
-          const double g = on ? G[qq * B + c] : 0.0;
-#pragma unroll
-          for (int r = 0; r < B; ++r) acc[r] += Abase[r * sr + qq * sq] * g;
+        for (int ks = 0; ks < (B + 3) / 4; ++ks) {
+          const int k = 4 * ks + mk;
+          const bool in = (k < B) && (mr < B);
+          const double a_lut = in ? Lu[k * B + mr] : 0.0;                  // L_u^T[mr][k]
+          const double a_lb = (in && has_b) ? Lb[mr * B + k] : 0.0;        // L_b[mr][k]
+          const double b_gl = in ? Gs[k * B + mr] : 0.0;                   // Gl[k][mr]
+          const double b_gr = in ? Gs[BB + k * B + mr] : 0.0;              // Gr[k][mr]
+          c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a_lut, b_gl, c1, 0, 0, 0);    // P_a = L_u^T Gl
+          c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a_lb, b_gr, c2, 0, 0, 0);     // P_b = L_b Gr
+          c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a_lb, b_gl, c3, 0, 0, 0);     // L_b Gl
         }
-        double* dst = (grp == 0) ? Du : (grp == 1) ? (sPb + (size_t)u * BB) : Lb;
-        if (grp != 2 || has_b) {
+        double* Pb = sPb + (size_t)u * BB;
 #pragma unroll
-          for (int r = 0; r < B; ++r) dst[r * B + c] = (grp == 2) ? -acc[r] : acc[r];
+        for (int rg = 0; rg < 4; ++rg) {
+          const int row = mk + 4 * rg;
+          if (row < B && mr < B) {
+            Du[row * B + mr] = c1[rg];                                     // slot of D_u (dead since the load above)
+            Pb[row * B + mr] = c2[rg];
+            if (has_b) Lb[row * B + mr] = -c3[rg];                         // new coupling b <-> a, in place (all reads are behind us)
+          }
         }
       }
     }
