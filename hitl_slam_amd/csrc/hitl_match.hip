@@ -453,41 +453,49 @@ __global__ void k_pair_count(WinCand w, int* __restrict__ pose_pairs, int64_t* _
 // exclusive scans over the poses, in place (n + 1 entries each), by one workgroup; totals to `out`:
 // out[0] = pairs, out[1] = matches, out[2] = max |i - j|, out[3] = pairs with an owned source, out[4] = their matches
 constexpr int kScanThreads = 1024;
+__device__ __forceinline__ int64_t wave_incl_scan(int64_t v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int64_t o = __shfl_up(v, d, 64); if (lane >= d) v += o; }
+  return v;
+}
 __global__ __launch_bounds__(kScanThreads) void k_pair_scan(int n, int own_lo, int own_hi, int* __restrict__ pose_pairs,
                                                              int64_t* __restrict__ pose_matches, int* __restrict__ pose_inc,
                                                              const int* __restrict__ pose_maxd, int64_t* __restrict__ out) {
-  __shared__ int64_t s_a[kScanThreads], s_b[kScanThreads], s_c[kScanThreads];
-  __shared__ int s_d[kScanThreads];
-  __shared__ int64_t s_oa[kScanThreads], s_ob[kScanThreads];
-  const int t = threadIdx.x;
-  const int per = (n + kScanThreads - 1) / kScanThreads;
-  const int lo = min(n, t * per), hi = min(n, lo + per);
-  int64_t a = 0, b = 0, c = 0, oa = 0, ob = 0;
+  // tiles of 1024 consecutive poses (coalesced), a wave-level scan per tile, running carries across tiles
+  constexpr int NW = kScanThreads / 64;
+  __shared__ int64_t s_w[3][NW];
+  __shared__ int64_t s_red[3][NW];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  int64_t carry_a = 0, carry_b = 0, carry_c = 0, oa = 0, ob = 0;
   int d = 0;
-  for (int i = lo; i < hi; ++i) {
-    a += pose_pairs[i]; b += pose_matches[i]; c += pose_inc[i]; d = max(d, pose_maxd[i]);
-    if (i >= own_lo && i < own_hi) { oa += pose_pairs[i]; ob += pose_matches[i]; }
+  for (int base = 0; base < n; base += kScanThreads) {
+    const int i = base + t;
+    const bool in = i < n;
+    const int64_t a = in ? pose_pairs[i] : 0, b = in ? pose_matches[i] : 0, c = in ? pose_inc[i] : 0;
+    if (in) { d = max(d, pose_maxd[i]); if (i >= own_lo && i < own_hi) { oa += a; ob += b; } }
+    const int64_t ia = wave_incl_scan(a, lane), ib = wave_incl_scan(b, lane), ic = wave_incl_scan(c, lane);
+    __syncthreads();                                         // the previous tile's readers are done with s_w
+    if (lane == 63) { s_w[0][wave] = ia; s_w[1][wave] = ib; s_w[2][wave] = ic; }
+    __syncthreads();
+    int64_t pa = 0, pb = 0, pc = 0, ta = 0, tb = 0, tc = 0;
+    for (int w = 0; w < NW; ++w) {
+      if (w < wave) { pa += s_w[0][w]; pb += s_w[1][w]; pc += s_w[2][w]; }
+      ta += s_w[0][w]; tb += s_w[1][w]; tc += s_w[2][w];
+    }
+    if (in) { pose_pairs[i] = (int)(carry_a + pa + ia - a); pose_matches[i] = carry_b + pb + ib - b; pose_inc[i] = (int)(carry_c + pc + ic - c); }
+    carry_a += ta; carry_b += tb; carry_c += tc;
   }
-  s_a[t] = a; s_b[t] = b; s_c[t] = c; s_d[t] = d; s_oa[t] = oa; s_ob[t] = ob;
+  // totals: carries are the same in every thread; the maximum and the owned sums need one block reduction
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) { d = max(d, __shfl_xor(d, m, 64)); oa += __shfl_xor(oa, m, 64); ob += __shfl_xor(ob, m, 64); }
   __syncthreads();
-  for (int off = 1; off < kScanThreads; off <<= 1) {        // inclusive scan of the per-thread sums
-    const int64_t va = (t >= off) ? s_a[t - off] : 0, vb = (t >= off) ? s_b[t - off] : 0, vc = (t >= off) ? s_c[t - off] : 0;
-    const int64_t voa = (t >= off) ? s_oa[t - off] : 0, vob = (t >= off) ? s_ob[t - off] : 0;
-    const int vd = (t >= off) ? s_d[t - off] : 0;
-    __syncthreads();
-    s_a[t] += va; s_b[t] += vb; s_c[t] += vc; s_oa[t] += voa; s_ob[t] += vob; s_d[t] = max(s_d[t], vd);
-    __syncthreads();
-  }
-  int64_t ra = s_a[t] - a, rb = s_b[t] - b, rc = s_c[t] - c;
-  for (int i = lo; i < hi; ++i) {
-    const int pa = pose_pairs[i], pc = pose_inc[i];
-    const int64_t pb = pose_matches[i];
-    pose_pairs[i] = (int)ra; pose_matches[i] = rb; pose_inc[i] = (int)rc;
-    ra += pa; rb += pb; rc += pc;
-  }
-  if (t == kScanThreads - 1) {
-    pose_pairs[n] = (int)s_a[t]; pose_matches[n] = s_b[t]; pose_inc[n] = (int)s_c[t];
-    out[0] = s_a[t]; out[1] = s_b[t]; out[2] = s_d[t]; out[3] = s_oa[t]; out[4] = s_ob[t];
+  if (lane == 0) { s_red[0][wave] = d; s_red[1][wave] = oa; s_red[2][wave] = ob; }
+  __syncthreads();
+  if (t == 0) {
+    int64_t dd = 0, soa = 0, sob = 0;
+    for (int w = 0; w < NW; ++w) { dd = max(dd, s_red[0][w]); soa += s_red[1][w]; sob += s_red[2][w]; }
+    pose_pairs[n] = (int)carry_a; pose_matches[n] = carry_b; pose_inc[n] = (int)carry_c;
+    out[0] = carry_a; out[1] = carry_b; out[2] = dd; out[3] = soa; out[4] = sob;
   }
 }
 
