@@ -48,6 +48,17 @@ def main():
     corr = s.get_correspondences()
     own = (corr[0] >= b) & (corr[0] < e)             # every pair is reported by the rank owning its source pose
     lens = corr[2][1:] - corr[2][:-1]
+    if os.environ.get("HITL_TEST_EXPECT_FAIL"):
+        # a solve every rank must refuse together (no rank may be left waiting in a collective)
+        try:
+            s.solve(mode, prob.init)
+            err = ""
+        except H.HitlError as ex:
+            err = str(ex)
+        json.dump(dict(rank=rank, error=err), open("%s.%d" % (out_path, rank), "w"))
+        s.close()
+        dist.destroy_process_group()
+        return
     poses, summ = s.solve(mode, prob.init)
     # observation scans on a submap rank: over its resident scans (global poses [lo, hi)), global pose array in
     wx, wy = s.transform_scans(prob.init)

@@ -65,3 +65,20 @@ def test_offband_submaps_equal_the_global_solve(tmp_path, case):
     print("%s: oracle %d LM iterations, cost %.9g | ranks: %s" % (case, so.iterations, so.final_cost, [(x["summary"]["iterations"],
           x["summary"]["linear_iterations"], x["summary"]["num_offband_pairs"], "%.9g" % x["summary"]["final_cost"]) for x in res]))
     assert len({(x["summary"]["iterations"], x["summary"]["termination"], x["summary"]["final_cost"]) for x in res}) == 1   # identical on all ranks
+
+
+def test_a_pair_reaching_past_the_halos_is_refused_on_every_rank(tmp_path):
+    """Window 3 with halos of 2 poses: the pair (57, 60) straddles the cut at 60 and reaches 3 poses into rank 0, where rank 1
+    cannot see it.  Both ranks must come back with HITL_ERR_UNSUPPORTED (agreed in prepare's exchange) instead of one of them
+    waiting in the first collective of the LM loop."""
+    out = str(tmp_path / "res")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", HITL_TEST_NPER="60", HITL_TEST_HALO="2",
+               HITL_TEST_WINDOW="3", HITL_TEST_BAND="1", HITL_TEST_EXPECT_FAIL="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_submap_worker.py"), out, "2", "120"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = [json.load(open("%s.%d" % (out, k))) for k in range(2)]
+    for x in res:
+        assert "status 6" in x["error"] or "UNSUPPORTED" in x["error"].upper(), x["error"]
+    assert any("halo" in x["error"] for x in res)
