@@ -19,6 +19,7 @@ using namespace hitl;
 namespace {
 
 int upload_pose_rt(const SolverCtx& cx, const float* poses, DevArray<float>* T4) {
+  poses += 3 * (size_t)cx.pose_base;     // submap rank: the caller's array is the GLOBAL one
   std::vector<float> t((size_t)4 * cx.n);
   for (int i = 0; i < cx.n; ++i) {      // Rotation2Df(angle), Translation2f: fp32 trig on the host
     t[4 * i] = cosf(poses[3 * i + 2]); t[4 * i + 1] = sinf(poses[3 * i + 2]); t[4 * i + 2] = poses[3 * i]; t[4 * i + 3] = poses[3 * i + 1];
@@ -134,17 +135,25 @@ int hitl_solver_fit_segments(hitl_solver* s, const float* poses_xyt, int32_t n_s
   TRY(solver_ctx(s, &cx));
   if (!poses_xyt || !seg_xy4 || n_segments < 0) return fail(HITL_ERR_INVALID_ARGUMENT, "fit_segments: null argument");
   if (cx.n <= 0) return fail(HITL_ERR_NOT_READY, "fit_segments before set_map");
-  if (cx.world > 1) return fail(HITL_ERR_UNSUPPORTED, "fit_segments is a single-GPU entry point");
+  // Submap ranks: every rank scans the observations of its OWNED poses, the inlier points travel in one all-gather (a few
+  // hundred points; rank order = pose order = the reading order of the single-GPU list) and every rank then runs the same
+  // M step on the same list: identical endpoints everywhere, equal to the single-GPU ones.
   HIP_TRY(hipSetDevice(cx.device));
+  const int n_own = cx.own_hi - cx.own_lo;
+  MapView own = cx.map;
+  own.n_poses = n_own; own.obs_off = cx.map.obs_off + cx.own_lo;
+  std::vector<float2> h_pts, h_all;
+  std::vector<int64_t> h_m;
   DevArray<float> T4;
   DevArray<int> d_cnt;
   DevArray<int64_t> d_off;
   DevArray<float2> d_pts;
   DevArray<double> d_partial;
   int rc = upload_pose_rt(cx, poses_xyt, &T4);
-  if (rc == HITL_OK) rc = d_cnt.resize((size_t)cx.n);
-  std::vector<int> h_cnt((size_t)cx.n);
-  std::vector<int64_t> h_off((size_t)cx.n + 1);
+  if (rc == HITL_OK) rc = d_cnt.resize((size_t)n_own);
+  std::vector<int> h_cnt((size_t)n_own);
+  std::vector<int64_t> h_off((size_t)n_own + 1);
+  const float* T4own = T4.p + (size_t)4 * cx.own_lo;
   for (int k = 0; k < n_segments && rc == HITL_OK; ++k) {
     float* sp = seg_xy4 + 4 * k;
     const double thresh = 0.05;
@@ -155,16 +164,34 @@ int hitl_solver_fit_segments(hitl_solver* s, const float* poses_xyt, int32_t n_s
       if (sp[0] == sp[2] && sp[1] == sp[3]) { rc = fail(HITL_ERR_INVALID_ARGUMENT, "fit_segments: zero-length segment"); break; }
       if (++pass > 64) { rc = fail(HITL_ERR_SOLVER_FAILURE, "fit_segments: endpoints did not settle in 64 passes"); break; }
       // E step: observations within 3 cm of the current segment (pass 1 counts, pass 2 gathers in reading order)
-      launch_fit_inliers(cx.stream, cx.map, T4.p, sp, d_cnt.p, nullptr, nullptr);
+      launch_fit_inliers(cx.stream, own, T4own, sp, d_cnt.p, nullptr, nullptr);
       if (hipMemcpyAsync(h_cnt.data(), d_cnt.p, sizeof(int) * h_cnt.size(), hipMemcpyDeviceToHost, cx.stream) != hipSuccess ||
           hipStreamSynchronize(cx.stream) != hipSuccess) { rc = fail(HITL_ERR_HIP, "fit_segments: inlier scan failed"); break; }
       h_off[0] = 0;
-      for (int i = 0; i < cx.n; ++i) h_off[i + 1] = h_off[i] + h_cnt[i];
-      m = h_off[cx.n];
+      for (int i = 0; i < n_own; ++i) h_off[i + 1] = h_off[i] + h_cnt[i];
+      m = h_off[n_own];
       if (m > 0) {
         if ((rc = d_off.upload(h_off, cx.stream)) != HITL_OK) break;
         if ((rc = d_pts.resize((size_t)m)) != HITL_OK) break;
-        launch_fit_inliers(cx.stream, cx.map, T4.p, sp, nullptr, d_off.p, d_pts.p);
+        launch_fit_inliers(cx.stream, own, T4own, sp, nullptr, d_off.p, d_pts.p);
+      }
+      if (cx.world > 1) {
+        h_m.assign((size_t)cx.world, 0);
+        const int64_t mine = m;
+        if ((rc = solver_allgather(s, &mine, h_m.data(), sizeof(int64_t))) != HITL_OK) break;
+        int64_t mmax = 1, mtot = 0;
+        for (int r = 0; r < cx.world; ++r) { mmax = std::max(mmax, h_m[r]); mtot += h_m[r]; }
+        h_pts.assign((size_t)mmax, make_float2(0.f, 0.f));
+        if (m > 0 && (hipMemcpyAsync(h_pts.data(), d_pts.p, sizeof(float2) * (size_t)m, hipMemcpyDeviceToHost, cx.stream) != hipSuccess ||
+                      hipStreamSynchronize(cx.stream) != hipSuccess)) { rc = fail(HITL_ERR_HIP, "fit_segments: inlier download failed"); break; }
+        h_all.resize((size_t)mmax * cx.world);
+        if ((rc = solver_allgather(s, h_pts.data(), h_all.data(), (int64_t)sizeof(float2) * mmax)) != HITL_OK) break;
+        std::vector<float2> full((size_t)std::max<int64_t>(mtot, 1));
+        int64_t w = 0;
+        for (int r = 0; r < cx.world; ++r) for (int64_t q = 0; q < h_m[r]; ++q) full[(size_t)w++] = h_all[(size_t)mmax * r + q];
+        m = mtot;
+        if ((rc = d_pts.upload(full.data(), (size_t)std::max<int64_t>(mtot, 1), cx.stream)) != HITL_OK) break;
+        if (hipStreamSynchronize(cx.stream) != hipSuccess) { rc = fail(HITL_ERR_HIP, "fit_segments: inlier upload failed"); break; }
       }
       // M step
       float ep[4];

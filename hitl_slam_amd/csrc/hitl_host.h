@@ -72,7 +72,10 @@ struct SolverCtx {
   int64_t n_obs;
   int world;
   MapView map;
+  int own_lo, own_hi;        // owned local pose range (the whole map on a single GPU)
+  int64_t pose_base;         // GLOBAL index of local pose 0 (submap ranks take global pose arrays)
 };
 int solver_ctx(hitl_solver* s, SolverCtx* out);
+int solver_allgather(hitl_solver* s, const void* send, void* recv, int64_t bytes_per_rank);   // the submap transport, host buffers
 
 }  // namespace hitl

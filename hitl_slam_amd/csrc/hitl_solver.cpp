@@ -38,8 +38,11 @@ int solver_ctx(hitl_solver* s, SolverCtx* out) {
   if (!s) return fail(HITL_ERR_INVALID_ARGUMENT, "null solver");
   out->device = s->device; out->stream = s->stream; out->n = s->n; out->n_obs = s->n_obs; out->world = s->world;
   out->map = s->map_view();
+  out->own_lo = s->own_lo; out->own_hi = s->own_hi; out->pose_base = s->g_begin - s->hl;
   return HITL_OK;
 }
+
+int solver_allgather(hitl_solver* s, const void* send, void* recv, int64_t bytes_per_rank) { return comm_allgather(s, send, recv, bytes_per_rank); }
 
 // ---------------------------------------------------------------------------------------
 // derived pair structures (host, O(P)); called whenever the correspondence set changes

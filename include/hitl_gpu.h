@@ -244,7 +244,10 @@ int hitl_solver_observation_sets(hitl_solver*, const float* poses_xyt, const flo
 /* ---- the correction cycle around the solve (HitLSLAM::Run, HitLSLAM.cpp:380-480) -----
  * One user correction is: verify_points -> fit_segments -> observation_sets -> order_user_input ->
  * apply_explicit_correction -> backprop -> normalize_angles -> set_human_constraints + solve -> transform_scans.
- * fp32 like the reference; float transcendental scalars are the C library's.  Single-GPU entry points.
+ * fp32 like the reference; float transcendental scalars are the C library's.  On submap ranks: fit_segments takes the
+ * GLOBAL pose array and the SAME segments on every rank, scans the owned poses, all-gathers the inlier points in pose order
+ * and runs the same M step everywhere (identical results on all ranks, equal to the single-GPU ones); the pose-array steps
+ * (order_user_input, apply_explicit_correction, backprop, normalize_angles) need no map and run on any rank.
  *
  * hitl_solver_fit_segments == EMInput::AutomaticEndpointAdjustment + SegFitEM (EMinput.cpp:153-250): each of the
  *     n_segments rows of seg_xy4 (x0,y0,x1,y1; in/out) is re-fitted to the world-frame observations within 3 cm of it

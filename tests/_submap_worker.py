@@ -66,10 +66,18 @@ def main():
     seen = s.verify_points(prob.init, probe, 0.05)
     seg = np.array([wx[3], wy[3], wx[40], wy[40], wx[60], wy[60], wx[90], wy[90]], np.float32)
     counts, mask = s.observation_sets(prob.init, seg, 0.03)
+    # endpoint fit across the ranks: every rank passes the SAME two clicks (rank 1's, broadcast: two points of its first
+    # owned scan, i.e. of the pose right above the first cut -- a wall piece seen from poses on both sides of the cut where
+    # the corridor continues) and must come back with the same fitted segment
+    fb = (b - lo) * M                                   # first owned scan of this rank
+    clicks = torch.tensor([wx[fb + 3], wy[fb + 3], wx[fb + 40], wy[fb + 40]], dtype=torch.float32)
+    dist.broadcast(clicks, 1)
+    fseg, finl, fpas, fits = s.fit_segments(prob.init, clicks.numpy().reshape(1, 4))
     res = dict(rank=rank, begin=b, end=e, poses=poses.tolist(), summary=summ.as_dict(),
                pairs=[corr[0][own].tolist(), corr[1][own].tolist()], n_matches=int(lens[own].sum()),
                scans=dict(lo=lo, hi=hi, wx=wx.tolist(), wy=wy.tolist(), probe=probe.tolist(), seen=seen.tolist(), seg=seg.tolist(),
-                          counts=counts.tolist(), mask_sum=int(mask.sum())))
+                          counts=counts.tolist(), mask_sum=int(mask.sum())),
+               fit=dict(clicks=clicks.numpy().tolist(), seg=fseg.tolist(), inliers=finl.tolist(), passes=fpas.tolist(), its=fits.tolist()))
     json.dump(res, open("%s.%d" % (out_path, rank), "w"))
     s.close()
     dist.destroy_process_group()

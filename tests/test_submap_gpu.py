@@ -64,6 +64,21 @@ def test_submaps_equal_the_global_solve(tmp_path, mode, ppf, world, moments):
         assert sc["seen"][0] == 1 and sc["seen"][1] == 1 and sc["seen"][2] == 0 and seen[0] == 1 and seen[2] == 0
         oc, om = o.observation_sets(prob.init, np.array(sc["seg"], np.float32), 0.03)
         assert np.array_equal(np.array(sc["counts"], np.int32), oc[sc["lo"]:sc["hi"]]) and sc["mask_sum"] == int(om[sl].sum())
+    # endpoint fit (EMInput::AutomaticEndpointAdjustment) over the ranks == the oracle's fit on the whole map: same inlier
+    # set (gathered from the owners in pose order), same passes and LM path; identical on every rank
+    fo = o.fit_segments(prob.init, np.array(res[0]["fit"]["clicks"], np.float32).reshape(1, 4))
+    for x in res:
+        f = x["fit"]
+        assert f["clicks"] == res[0]["fit"]["clicks"]
+        assert f["inliers"] == fo[1].tolist() and f["passes"] == fo[2].tolist() and f["its"] == fo[3].tolist()
+        assert np.abs(np.array(f["seg"], np.float32) - fo[0]).max() <= 2e-6
+        assert f["seg"] == res[0]["fit"]["seg"]
+    assert fo[1][0] > 0
+    if ppf == 120:      # one corridor: the wall piece is seen from both sides of the first cut, so the inliers come from two ranks
+        cnt, _ = o.observation_sets(prob.init, np.r_[fo[0][0], fo[0][0]].astype(np.float32), 0.03)
+        seen_by = np.nonzero(cnt.reshape(-1, 2)[:, 0] > 0)[0]
+        cut = res[1]["begin"]
+        assert seen_by.min() < cut <= seen_by.max()
     po, so = o.solve(mode, prob.init)
     for x in res:
         sm = x["summary"]
