@@ -127,10 +127,10 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
     DevArray<int>& d_maxd = s->d_pose_maxd;
     DevArray<int64_t>&d_pmo = s->d_pose_match_off, &d_tot = s->d_pair_totals;
     TRYC(s->pose_pair_off.resize((size_t)n + 1)); TRYC(s->inc_off.resize((size_t)n + 1));
-    TRYC(d_pmo.resize((size_t)n + 1)); TRYC(d_maxd.resize((size_t)n)); TRYC(d_tot.resize(5));
+    TRYC(d_pmo.resize((size_t)n + 1)); TRYC(d_maxd.resize((size_t)n)); TRYC(d_tot.resize(5 + 6 * (size_t)pair_scan_blocks(n)));
     const int min_count = (int)s->opt.min_inter_pose_correspondence;
     launch_pair_count_scan(st, n, slots, (int)window, min_count, s->own_lo, s->own_hi, d_counts.p, s->pose_pair_off.p, d_pmo.p,
-                           s->inc_off.p, d_maxd.p, d_tot.p);
+                           s->inc_off.p, d_maxd.p, d_tot.p + 5, d_tot.p);
     int64_t tot[5] = {0, 0, 0, 0, 0};
     if (hipMemcpyAsync(tot, d_tot.p, sizeof(tot), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
       return fail(HITL_ERR_HIP, std::string("match kernel: ") + hipGetErrorString(hipGetLastError()));

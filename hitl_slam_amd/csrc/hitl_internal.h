@@ -177,7 +177,9 @@ void launch_compact(hipStream_t st, const MapView& map, int max_scan, int slots,
 // pair tables of a windowed search on the device (the layout of build_pair_structures, hitl_solver.cpp):
 // count + scan leave exclusive offsets (n + 1 entries) and totals[5] = pairs, matches, max |i - j|, owned pairs, owned matches
 void launch_pair_count_scan(hipStream_t st, int n, int slots, int window, int min_count, int own_lo, int own_hi, const int* counts,
-                            int* pose_pair_off, int64_t* pose_match_off, int* inc_off, int* pose_maxd, int64_t* totals);
+                            int* pose_pair_off, int64_t* pose_match_off, int* inc_off, int* pose_maxd,
+                            int64_t* blk /* 6 * pair_scan_blocks(n) scratch */, int64_t* totals);
+int pair_scan_blocks(int n);
 void launch_pair_fill(hipStream_t st, int n, int slots, int window, int min_count, int own_lo, int own_hi, const int* counts, int Wb,
                       const int* pose_pair_off, const int64_t* pose_match_off, const int* inc_off, int* kept_cand, int* pair_src,
                       int* pair_tgt, int64_t* match_off, int* inc_ent, int* band_pair /* n*Wb*2, preset to -1 */);

@@ -388,21 +388,20 @@ static int linear_solve_and_step_dist(hitl_solver* s, const FactorView& fv, int 
   const int Wb = fv.band_poses, Wi = s->Wi, m = 3 * Wi, nc = 2 * m;
   *iters = 1;
   *ok = true;
-  launch_build_system(st, n, Wb, lv, s->scale.p, s->fixed.p, mu, mind, maxd, cr, s->rhs.p);
+  launch_build_system(st, n, Wb, lv, s->scale.p, s->fixed.p, mu, mind, maxd, cr, s->rhs.p, s->dist_pcg ? nullptr : s->rhsN.p);   // rhsN[0]: the copy the factorisation consumes
   int nh = 0;
   std::vector<double> coef, hval, hsc;   // uploaded asynchronously below: alive until the synchronisation at the end
   if (s->dist_pcg) {
     TRY(dist_pcg_solve(s, fv, lv, cr, mu, iters, ok));
     nh = s->n_halo;                      // dt and scale already hold the owners' values on every halo row
   } else {
-  launch_copy(st, npad, s->rhs.p, s->rhsN.p);
   launch_unit_rhs(st, npad, s->rhsN.p + npad, (size_t)npad, s->if_cols.p, nc);
   launch_cr_factor_solve(st, cr, s->rhsN.p, s->zN.p, 1 + nc, (size_t)npad);   // z0 and Z = M^{-1} [E_F, E_L]
-  launch_copy(st, npad, s->zN.p, s->dt.p);
+  const double* z0 = s->zN.p;
   const double* Z = s->zN.p + npad;
   const int RI = nc * (nc + 2), RC = m * m, R = RI + 2 * RC;
   // the exchange record (interface rows of z0 / Z / scale, then the two cross-cut blocks) is put together on the device
-  launch_gather_iface(st, s->dt.p, Z, (size_t)npad, s->scale.p, s->if_cols.p, nc, s->iface_dev.p);
+  launch_gather_iface(st, z0, Z, (size_t)npad, s->scale.p, s->if_cols.p, nc, s->iface_dev.p);
   launch_iface_blocks(st, lv.Hband, Wb, Wi, s->own_lo, s->own_hi, me > 0, me < W - 1, s->iface_dev.p + RI, s->iface_dev.p + RI + RC);
   // host buffers of the exchange live in the solver (sized once per interface width, reused every LM iteration)
   std::vector<double>&rec = s->if_rec, &all = s->if_all, &A = s->if_A, &y = s->if_y, &Ct = s->if_Ct;
@@ -458,7 +457,7 @@ static int linear_solve_and_step_dist(hitl_solver* s, const FactorView& fv, int 
     HIP_TRY(hipMemcpyAsync(s->halo_val.p, hval.data(), sizeof(double) * nh, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(s->halo_sc.p, hsc.data(), sizeof(double) * nh, hipMemcpyHostToDevice, st));
   }
-  launch_combine(st, npad, s->dt.p, Z, (size_t)npad, s->coef_dev.p, nc, s->dt.p);
+  launch_combine(st, npad, z0, Z, (size_t)npad, s->coef_dev.p, nc, s->dt.p);
   launch_scatter_halo(st, nh, s->halo_idx.p, s->halo_val.p, s->halo_sc.p, s->dt.p, s->scale.p);
   }
   // model-cost pieces over the owned rows (halo columns carry the neighbours' steps), candidate state
@@ -531,7 +530,7 @@ int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float* poses
   const int n_edges = (s->own_hi - s->own_lo) - ((s->g_begin == 0) ? 1 : 0);
   S.num_residuals = (fv.with_stf ? 2 * s->n_pairs_owned : 0) + (fv.with_odom ? 3 * n_edges : 0) + (fv.with_hc ? s->num_hc_residuals : 0);
   launch_jacobi_scale(st, n, s->npad, fv.band_poses, s->Hband[cur].p, o.jacobi_scaling, s->fixed.p, s->scale.p);
-  if (s->world > 1 && s->dist_pcg) TRY(dist_gather_owned(s, 0, nullptr, s->scale.p, nullptr));   // halo rows: the owners' scales (complete diagonal blocks)
+  if (s->dist_mode() && s->dist_pcg) TRY(dist_gather_owned(s, 0, nullptr, s->scale.p, nullptr));   // halo rows: the owners' scales (complete diagonal blocks)
   double radius = o.initial_trust_region_radius, decrease_factor = 2.0;
   int iter = 0, invalid_run = 0;
   int term = HITL_NO_CONVERGENCE;
@@ -546,7 +545,7 @@ int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float* poses
     const bool time_solver = o.timing_level >= 2;
     if (time_solver) HIP_TRY(hipEventRecord(s->ev2, st));
     StepScalars ss;
-    const bool fused = (s->world == 1 && fv.n_offband == 0);   // one host synchronisation per LM iteration
+    const bool fused = (!s->dist_mode() && fv.n_offband == 0);   // one host synchronisation per LM iteration
     LinResult lr_spec = {0.0, 0.0, 0.f, 0};
     bool have_spec = false;
     if (fused) {
@@ -560,7 +559,7 @@ int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float* poses
       if (!(rr == rr) || rr > guard * guard * bb) ok = false;   // the factorisation broke down
       lin_iters = 1;
     } else {
-      if (s->world > 1) { TRY(linear_solve_and_step_dist(s, fv, cur, radius, xcur, xcand, &lin_iters, &ok, &ss, &lr_spec)); have_spec = true; }
+      if (s->dist_mode()) { TRY(linear_solve_and_step_dist(s, fv, cur, radius, xcur, xcand, &lin_iters, &ok, &ss, &lr_spec)); have_spec = true; }
       else TRY(linear_solve_and_step(s, fv, cur, radius, xcur, xcand, &lin_iters, &ok, &ss));
       if (time_solver) { HIP_TRY(hipEventRecord(s->ev3, st)); HIP_TRY(hipEventSynchronize(s->ev3)); }
     }

@@ -450,53 +450,100 @@ __global__ void k_pair_count(WinCand w, int* __restrict__ pose_pairs, int64_t* _
   pose_pairs[i] = np; pose_matches[i] = nm; pose_inc[i] = np + ninc; pose_maxd[i] = maxd;
 }
 
-// exclusive scans over the poses, in place (n + 1 entries each), by one workgroup; totals to `out`:
-// out[0] = pairs, out[1] = matches, out[2] = max |i - j|, out[3] = pairs with an owned source, out[4] = their matches
-constexpr int kScanThreads = 1024;
+// Exclusive scans over the poses in three steps (a single workgroup streaming 50 000 x 20 bytes took 236 us): per-block
+// totals, one small scan over the blocks (+ the five totals of launch_pair_count_scan), then every block scans its own
+// poses and adds its offset.  Blocks of kPairBlock poses.
+constexpr int kPairBlock = 256;
 __device__ __forceinline__ int64_t wave_incl_scan(int64_t v, int lane) {
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) { const int64_t o = __shfl_up(v, d, 64); if (lane >= d) v += o; }
   return v;
 }
-__global__ __launch_bounds__(kScanThreads) void k_pair_scan(int n, int own_lo, int own_hi, int* __restrict__ pose_pairs,
-                                                             int64_t* __restrict__ pose_matches, int* __restrict__ pose_inc,
-                                                             const int* __restrict__ pose_maxd, int64_t* __restrict__ out) {
-  // tiles of 1024 consecutive poses (coalesced), a wave-level scan per tile, running carries across tiles
-  constexpr int NW = kScanThreads / 64;
+
+// in-block exclusive prefix of three per-thread values; returns the block totals through tot[3] (valid in every thread)
+__device__ __forceinline__ void block_excl_scan3(int64_t a, int64_t b, int64_t c, int64_t* ea, int64_t* eb, int64_t* ec, int64_t tot[3]) {
+  constexpr int NW = kPairBlock / 64;
   __shared__ int64_t s_w[3][NW];
-  __shared__ int64_t s_red[3][NW];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  int64_t carry_a = 0, carry_b = 0, carry_c = 0, oa = 0, ob = 0;
-  int d = 0;
-  for (int base = 0; base < n; base += kScanThreads) {
-    const int i = base + t;
-    const bool in = i < n;
-    const int64_t a = in ? pose_pairs[i] : 0, b = in ? pose_matches[i] : 0, c = in ? pose_inc[i] : 0;
-    if (in) { d = max(d, pose_maxd[i]); if (i >= own_lo && i < own_hi) { oa += a; ob += b; } }
-    const int64_t ia = wave_incl_scan(a, lane), ib = wave_incl_scan(b, lane), ic = wave_incl_scan(c, lane);
-    __syncthreads();                                         // the previous tile's readers are done with s_w
-    if (lane == 63) { s_w[0][wave] = ia; s_w[1][wave] = ib; s_w[2][wave] = ic; }
-    __syncthreads();
-    int64_t pa = 0, pb = 0, pc = 0, ta = 0, tb = 0, tc = 0;
-    for (int w = 0; w < NW; ++w) {
-      if (w < wave) { pa += s_w[0][w]; pb += s_w[1][w]; pc += s_w[2][w]; }
-      ta += s_w[0][w]; tb += s_w[1][w]; tc += s_w[2][w];
-    }
-    if (in) { pose_pairs[i] = (int)(carry_a + pa + ia - a); pose_matches[i] = carry_b + pb + ib - b; pose_inc[i] = (int)(carry_c + pc + ic - c); }
-    carry_a += ta; carry_b += tb; carry_c += tc;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t ia = wave_incl_scan(a, lane), ib = wave_incl_scan(b, lane), ic = wave_incl_scan(c, lane);
+  if (lane == 63) { s_w[0][wave] = ia; s_w[1][wave] = ib; s_w[2][wave] = ic; }
+  __syncthreads();
+  int64_t pa = 0, pb = 0, pc = 0;
+  tot[0] = tot[1] = tot[2] = 0;
+  for (int w = 0; w < NW; ++w) {
+    if (w < wave) { pa += s_w[0][w]; pb += s_w[1][w]; pc += s_w[2][w]; }
+    tot[0] += s_w[0][w]; tot[1] += s_w[1][w]; tot[2] += s_w[2][w];
   }
-  // totals: carries are the same in every thread; the maximum and the owned sums need one block reduction
+  *ea = pa + ia - a; *eb = pb + ib - b; *ec = pc + ic - c;
+}
+
+// block b: totals of (pairs, matches, incidences), max |i - j|, owned (pairs, matches) -> blk[6 * b ..]
+__global__ __launch_bounds__(kPairBlock) void k_pair_block_sums(int n, int own_lo, int own_hi, const int* __restrict__ pose_pairs,
+                                                                 const int64_t* __restrict__ pose_matches, const int* __restrict__ pose_inc,
+                                                                 const int* __restrict__ pose_maxd, int64_t* __restrict__ blk) {
+  __shared__ int64_t s_red[3][kPairBlock / 64];
+  const int i = blockIdx.x * kPairBlock + threadIdx.x;
+  const bool in = i < n;
+  const int64_t a = in ? pose_pairs[i] : 0, b = in ? pose_matches[i] : 0, c = in ? pose_inc[i] : 0;
+  int64_t ea, eb, ec, tot[3];
+  block_excl_scan3(a, b, c, &ea, &eb, &ec, tot);
+  const bool own = in && i >= own_lo && i < own_hi;
+  int64_t d = in ? pose_maxd[i] : 0, oa = own ? a : 0, ob = own ? b : 0;
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) { d = max(d, __shfl_xor(d, m, 64)); oa += __shfl_xor(oa, m, 64); ob += __shfl_xor(ob, m, 64); }
-  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0) { s_red[0][wave] = d; s_red[1][wave] = oa; s_red[2][wave] = ob; }
   __syncthreads();
-  if (t == 0) {
+  if (threadIdx.x == 0) {
     int64_t dd = 0, soa = 0, sob = 0;
-    for (int w = 0; w < NW; ++w) { dd = max(dd, s_red[0][w]); soa += s_red[1][w]; sob += s_red[2][w]; }
-    pose_pairs[n] = (int)carry_a; pose_matches[n] = carry_b; pose_inc[n] = (int)carry_c;
-    out[0] = carry_a; out[1] = carry_b; out[2] = dd; out[3] = soa; out[4] = sob;
+    for (int w = 0; w < kPairBlock / 64; ++w) { dd = max(dd, s_red[0][w]); soa += s_red[1][w]; sob += s_red[2][w]; }
+    int64_t* o = blk + 6 * (size_t)blockIdx.x;
+    o[0] = tot[0]; o[1] = tot[1]; o[2] = tot[2]; o[3] = dd; o[4] = soa; o[5] = sob;
   }
+}
+
+// one workgroup: exclusive scan of the block totals in place (slots 0..2), totals to out[5]
+__global__ __launch_bounds__(kPairBlock) void k_pair_block_scan(int nblk, int64_t* __restrict__ blk, int64_t* __restrict__ out) {
+  int64_t ca = 0, cb = 0, cc = 0, dd = 0, oa = 0, ob = 0;
+  for (int base = 0; base < nblk; base += kPairBlock) {
+    const int k = base + threadIdx.x;
+    const bool in = k < nblk;
+    int64_t* e = blk + 6 * (size_t)(in ? k : 0);
+    const int64_t a = in ? e[0] : 0, b = in ? e[1] : 0, c = in ? e[2] : 0;
+    if (in) { dd = max(dd, e[3]); oa += e[4]; ob += e[5]; }
+    int64_t ea, eb, ec, tot[3];
+    __syncthreads();
+    block_excl_scan3(a, b, c, &ea, &eb, &ec, tot);
+    if (in) { e[0] = ca + ea; e[1] = cb + eb; e[2] = cc + ec; }
+    ca += tot[0]; cb += tot[1]; cc += tot[2];
+  }
+  __shared__ int64_t s_red[3][kPairBlock / 64];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) { dd = max(dd, __shfl_xor(dd, m, 64)); oa += __shfl_xor(oa, m, 64); ob += __shfl_xor(ob, m, 64); }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) { s_red[0][wave] = dd; s_red[1][wave] = oa; s_red[2][wave] = ob; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int64_t d2 = 0, soa = 0, sob = 0;
+    for (int w = 0; w < kPairBlock / 64; ++w) { d2 = max(d2, s_red[0][w]); soa += s_red[1][w]; sob += s_red[2][w]; }
+    out[0] = ca; out[1] = cb; out[2] = d2; out[3] = soa; out[4] = sob;
+  }
+}
+
+// every block: exclusive offsets of its poses = block offset + in-block prefix, in place; the last entries (index n) = totals
+__global__ __launch_bounds__(kPairBlock) void k_pair_offsets(int n, const int64_t* __restrict__ blk, const int64_t* __restrict__ totals,
+                                                              int* __restrict__ pose_pairs, int64_t* __restrict__ pose_matches,
+                                                              int* __restrict__ pose_inc) {
+  const int i = blockIdx.x * kPairBlock + threadIdx.x;
+  const bool in = i < n;
+  const int64_t a = in ? pose_pairs[i] : 0, b = in ? pose_matches[i] : 0, c = in ? pose_inc[i] : 0;
+  int64_t ea, eb, ec, tot[3];
+  block_excl_scan3(a, b, c, &ea, &eb, &ec, tot);
+  const int64_t* o = blk + 6 * (size_t)blockIdx.x;
+  if (in) { pose_pairs[i] = (int)(o[0] + ea); pose_matches[i] = o[1] + eb; pose_inc[i] = (int)(o[2] + ec); }
+  if (i == n - 1) { pose_pairs[n] = (int)(o[0] + ea + a); pose_matches[n] = o[1] + eb + b; pose_inc[n] = (int)(o[2] + ec + c); }
+  (void)totals;
 }
 
 __global__ void k_pair_fill(WinCand w, int Wb, const int* __restrict__ pose_pair_off, const int64_t* __restrict__ pose_match_off,
@@ -540,11 +587,16 @@ static WinCand win_cand(int n, int slots, int window, int min_count, int own_lo,
 }
 
 void launch_pair_count_scan(hipStream_t st, int n, int slots, int window, int min_count, int own_lo, int own_hi, const int* counts,
-                            int* pose_pair_off, int64_t* pose_match_off, int* inc_off, int* pose_maxd, int64_t* totals) {
+                            int* pose_pair_off, int64_t* pose_match_off, int* inc_off, int* pose_maxd, int64_t* blk, int64_t* totals) {
   const WinCand w = win_cand(n, slots, window, min_count, own_lo, own_hi, counts);
   hipLaunchKernelGGL(k_pair_count, dim3((n + 255) / 256), dim3(256), 0, st, w, pose_pair_off, pose_match_off, inc_off, pose_maxd);
-  hipLaunchKernelGGL(k_pair_scan, dim3(1), dim3(kScanThreads), 0, st, n, own_lo, own_hi, pose_pair_off, pose_match_off, inc_off, pose_maxd, totals);
+  const int nblk = (n + kPairBlock - 1) / kPairBlock;
+  hipLaunchKernelGGL(k_pair_block_sums, dim3(nblk), dim3(kPairBlock), 0, st, n, own_lo, own_hi, pose_pair_off, pose_match_off, inc_off, pose_maxd, blk);
+  hipLaunchKernelGGL(k_pair_block_scan, dim3(1), dim3(kPairBlock), 0, st, nblk, blk, totals);
+  hipLaunchKernelGGL(k_pair_offsets, dim3(nblk), dim3(kPairBlock), 0, st, n, blk, totals, pose_pair_off, pose_match_off, inc_off);
 }
+
+int pair_scan_blocks(int n) { return (n + kPairBlock - 1) / kPairBlock; }
 
 void launch_pair_fill(hipStream_t st, int n, int slots, int window, int min_count, int own_lo, int own_hi, const int* counts, int Wb,
                       const int* pose_pair_off, const int64_t* pose_match_off, const int* inc_off, int* kept_cand, int* pair_src,

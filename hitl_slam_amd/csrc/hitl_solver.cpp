@@ -183,7 +183,7 @@ int ensure_work(hitl_solver* s, int Wb) {
   TRY(s->crD.resize(bb)); TRY(s->crL.resize(bb)); TRY(s->crDinv.resize(bb)); TRY(s->crGl.resize(bb)); TRY(s->crGr.resize(bb));
   {
     const size_t np = (size_t)cr_contrib_slots(s->nsb);
-    s->cr_pw_rhs = (s->world > 1) ? 1 + 6 * Wb : 1;       // the submap solve pushes its interface columns through the factorisation
+    s->cr_pw_rhs = s->dist_mode() ? 1 + 6 * Wb : 1;       // the submap solve pushes its interface columns through the factorisation
     TRY(s->crP.resize(4 * np * s->B * s->B)); TRY(s->crPw.resize((size_t)s->cr_pw_rhs * 4 * np * s->B));
   }
   s->wb_Wb = Wb; s->wb_n = n; s->wb_pairs = s->n_pairs; s->wb_offband = s->n_offband;
@@ -303,8 +303,8 @@ int prepare(hitl_solver* s, int mode, const float* poses_ref, const float* poses
   // mode A reads no pair table: a 1-pose band; the pair-derived band_pair table is unused
   const int Wb = (mode == HITL_MODE_ODOM_HC) ? 1 : s->band_pairs_Wb;
   const int local_rc = prepare_local(s, mode, poses_ref, poses_global, Wb);
-  if (s->world == 1 && local_rc != HITL_OK) return local_rc;
-  if (s->world > 1) {
+  if (!s->dist_mode() && local_rc != HITL_OK) return local_rc;
+  if (s->dist_mode()) {
     // interface width = how deep (in poses) any factor reaches across a cut, maximised over all
     // ranks: 1 when only the odometry edges straddle the cuts, up to the pose band otherwise
     int wi_local = 1;
@@ -487,6 +487,7 @@ int hitl_solver_create(const hitl_options* opt, hitl_solver** out) {
   if (s->d_scalars.resize(kNumScalars) != HITL_OK) return bail(HITL_ERR_OUT_OF_MEMORY, "hipMalloc failed");
   s->rank = o.rank;
   s->world = o.world_size;
+  s->force_dist = std::getenv("HITL_FORCE_DIST") != nullptr;
   if ((o.world_size > 1 || std::getenv("HITL_FORCE_RCCL")) && o.rccl_unique_id != nullptr) {
     ncclUniqueId id;
     static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");

@@ -51,6 +51,8 @@ struct hitl_solver {
   std::vector<double> if_rec, if_all, if_A, if_y, if_Ct;   // host side of the interface exchange
   // off-band pose pairs on a submap rank: distributed PCG (block-Jacobi = the ranks' own band factorisations) instead of the
   // exact interface system.  Every CG iteration all-gathers the owned part of one vector; halo rows are filled from it.
+  bool force_dist = false;            // HITL_FORCE_DIST (development): a single rank takes the submap code path (profiling its kernels)
+  bool dist_mode() const { return world > 1 || force_dist; }
   bool dist_pcg = false;
   std::vector<int64_t> part_begin, part_count;   // owned global range of every rank
   int maxown = 0;                                // widest owned range, in poses
