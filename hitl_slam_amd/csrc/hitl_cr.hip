@@ -758,7 +758,9 @@ __global__ __launch_bounds__(B >= 12 ? 512 : 1024) void k_cr_chunk(CrView cr, Cr
     if (sg.has_prev) d = (d - PLp[(size_t)sn * BB + q]) - PRp[(size_t)sn * BB + q];
     sD[e] = d;
     sL[e] = l;
-    if (u == 0 && sg.has_prev && !sg.top) cr.D[g] = d;     // the left boundary stays alive: keep its folded value
+    // A boundary node stays alive: keep its folded value where the next stage reads it.  Every boundary is local node 0 of
+    // one chunk -- except the very last node when it is local node M of the last chunk (no chunk on its right).
+    if ((u == 0 || (u == M && sn == nst - 1)) && sg.has_prev && !sg.top) cr.D[g] = d;
   }
   if (has_w)
     for (int e = tid; e < NR * (u_last + 1) * B; e += nthr) {
@@ -772,7 +774,7 @@ __global__ __launch_bounds__(B >= 12 ? 512 : 1024) void k_cr_chunk(CrView cr, Cr
       if (sg.has_prev) v = (v - WLp[pws * rv + (size_t)sn * B + q]) - WRp[pws * rv + (size_t)sn * B + q];
       sW[((size_t)rv * nsl + u) * B + q] = v;
       if (sg.has_prev && (u == 0 || u == M) == false) w[g] = v;          // interior: the back-substitution reads the folded w
-      if (u == 0 && sg.has_prev && !sg.top) w[g] = v;
+      if ((u == 0 || (u == M && sn == nst - 1)) && sg.has_prev && !sg.top) w[g] = v;
     }
   for (int e = tid; e < 2 * BB + 2 * NR * B; e += nthr) accR[e] = 0.0;   // accR, accL, accWR, accWL are contiguous
   lds_barrier();
@@ -1037,7 +1039,7 @@ __global__ __launch_bounds__(512) void k_cr_chunk_fwd(CrView cr, CrStage sg, con
     else if (w_in != w) w[g] = v;                // ... and then leaves every node's value where the backward stages read it
     sW[e] = v;
     if (sg.has_prev && (u == 0 || u == M) == false) w[g] = v;
-    if (u == 0 && sg.has_prev && !sg.top) w[g] = v;
+    if ((u == 0 || (u == M && sn == nst - 1)) && sg.has_prev && !sg.top) w[g] = v;     // see k_cr_chunk: the last node may be nobody's local 0
   }
   for (int e = tid; e < 2 * B; e += nthr) accWR[e] = 0.0;
   lds_barrier();
