@@ -175,13 +175,14 @@ def test_linearisation_layout_variants(obs, addr64, monkeypatch):
     g.close(); o.close()
 
 
-@pytest.mark.parametrize("mode, n", [(0, 1030), (0, 1040), (0, 1041), (0, 1537), (0, 1553), (0, 17410), (2, 3100), (2, 3120), (2, 1540)])
+@pytest.mark.parametrize("mode, n", [(0, 1030), (0, 1040), (0, 1041), (0, 1537), (0, 1553), (0, 17410), (0, 33000), (2, 3100), (2, 3120), (2, 1540)])
 def test_cyclic_reduction_stage_boundaries(mode, n):
     """Sizes that put the LAST super-block on a chunk boundary of the fused cyclic reduction.  The nodes alive after the first
     stage (chunks of 16) number ceil(nsb / 16); when that count is 1 (mod 32) the last node is local node M of the last
     second-stage chunk and local node 0 of none -- the one boundary whose folded diagonal block and right-hand side no
     neighbouring chunk keeps for the next stage (a 20 000-pose map, nsb = 6667, lost them and the factorisation broke down).
-    Mode A: band of one pose (nsb = n); mode C with window 3: nsb = ceil(n / 3).  Neighbouring sizes ride along."""
+    Mode A: band of one pose (nsb = n); mode C with window 3: nsb = ceil(n / 3).  33 000 poses: the same on the THIRD stage
+    (ceil(nsb / 512) = 65).  Neighbouring sizes ride along."""
     prob = Problem(n, 16, ppf=200, groups=max(1, n // 1000), kind=0)
     g, o = _both()
     prob.load(g); prob.load(o)
