@@ -102,7 +102,7 @@ typedef struct hitl_options {
   /* linear solver: PCG preconditioned by the exact block-cyclic-reduction factorisation
    * of the in-band part of the Hessian.                                                 */
   double linear_solver_tolerance;         /* relative residual, 1e-12                  */
-  int32_t max_linear_iterations;          /* 50                                        */
+  int32_t max_linear_iterations;          /* 500 (Ceres max_linear_solver_iterations); PCG only */
   int32_t max_band_poses;                 /* widest pose distance kept in the band, 1..4 (default 4) */
   /* multi-GPU (pose-range submaps).  world_size 1 = single device, no RCCL.             */
   int32_t rank;

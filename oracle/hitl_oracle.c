@@ -60,7 +60,7 @@ static void orc_options_default(hitl_options* o) {
   o->min_lm_diagonal = 1e-6;
   o->max_lm_diagonal = 1e32;
   o->linear_solver_tolerance = 1e-12;
-  o->max_linear_iterations = 50;
+  o->max_linear_iterations = 500;
   o->max_band_poses = 4;
   o->rank = 0;
   o->world_size = 1;
