@@ -40,7 +40,7 @@ def test_joint_mode_matches_dense_inverse(n, obs, ppf, window):
     g.close(); o.close()
 
 
-@pytest.mark.parametrize("n", [2, 3, 7, 64, 65, 300])
+@pytest.mark.parametrize("n", [2, 3, 7, 64, 65, 300, 1030])      # 1030: the last super-block on a chunk boundary of the fused factorisation
 def test_odometry_and_constraints_mode(n):
     prob = Problem(n, 24, ppf=max(n, 8), groups=1 if n > 8 else 0)
     g, o = _pair(prob)
