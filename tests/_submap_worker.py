@@ -29,6 +29,10 @@ def main():
     window = int(os.environ.get("HITL_TEST_WINDOW", 3))
     prob = Problem(n_per * world, 48, ppf=ppf, groups=2, kind=0)
     b, e = rank * n_per, (rank + 1) * n_per
+    if "HITL_TEST_CUTS" in os.environ:            # uneven submaps: "0,50,120" = rank 0 owns [0, 50), rank 1 [50, 120)
+        cuts = [int(x) for x in os.environ["HITL_TEST_CUTS"].split(",")]
+        assert len(cuts) == world + 1 and cuts[-1] == n_per * world
+        b, e = cuts[rank], cuts[rank + 1]
     lo, hi = b - (halo if rank > 0 else 0), e + (halo if rank < world - 1 else 0)
     M = 48
     opt = H.default_options()

@@ -27,7 +27,9 @@ CASES = {
     "band1_3ranks": (3, 40, 6, 3, 1, 120),
     "band1_floor_cut": (2, 60, 6, 3, 1, 30),
     "allpairs_replicated": (2, 12, 12, 0, 4, 24),
+    "band1_uneven_3ranks": (3, 40, 6, 3, 1, 120),      # ranks own 23, 60 and 37 poses (HITL_TEST_CUTS below)
 }
+CUTS = {"band1_uneven_3ranks": "0,23,83,120"}
 
 
 @pytest.mark.parametrize("case", sorted(CASES))
@@ -37,6 +39,8 @@ def test_offband_submaps_equal_the_global_solve(tmp_path, case):
     out = str(tmp_path / "res")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", HITL_TEST_NPER=str(n_per), HITL_TEST_HALO=str(halo),
                HITL_TEST_WINDOW=str(window), HITL_TEST_BAND=str(band))
+    if case in CUTS:
+        env["HITL_TEST_CUTS"] = CUTS[case]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_submap_worker.py"), out, "2", str(ppf)]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
