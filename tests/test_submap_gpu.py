@@ -26,12 +26,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("mode,ppf,world,moments", [(0, 30, 2, 0), (2, 30, 2, 0), (2, 120, 2, 0), (0, 120, 2, 0), (2, 120, 3, 0), (2, 40, 3, 0),
-                                                    (2, 120, 2, 1)])
-def test_submaps_equal_the_global_solve(tmp_path, mode, ppf, world, moments):
+@pytest.mark.parametrize("mode,ppf,world,moments,cuts", [(0, 30, 2, 0, None), (2, 30, 2, 0, None), (2, 120, 2, 0, None), (0, 120, 2, 0, None),
+                                                         (2, 120, 3, 0, None), (2, 40, 3, 0, None), (2, 120, 2, 1, None),
+                                                         (2, 120, 3, 0, "0,23,83,120")])      # uneven submaps: 23, 60 and 37 poses
+def test_submaps_equal_the_global_solve(tmp_path, mode, ppf, world, moments, cuts):
     from oracle import hitl_oracle as O
     out = str(tmp_path / "res")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", HITL_TEST_STF_MOMENTS=str(moments))
+    if cuts:
+        env["HITL_TEST_CUTS"] = cuts
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_submap_worker.py"), out, str(mode), str(ppf)]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
@@ -47,10 +50,12 @@ def test_submaps_equal_the_global_solve(tmp_path, mode, ppf, world, moments):
     tgt = np.concatenate([np.array(x["pairs"][1], np.int32) for x in res])
     assert np.array_equal(src, ops[0]) and np.array_equal(tgt, ops[1])
     if ppf == 120:
-        cut = 120 // world
+        cut = res[1]["begin"]
         assert np.any((ops[0] < cut) != (ops[1] < cut))        # pairs really straddle the cut
-    if world == 3:
+    if world == 3 and not cuts:
         assert res[1]["begin"] == 40 and res[1]["end"] == 80   # the middle rank has halos on both sides
+    if cuts:
+        assert [x["begin"] for x in res] + [res[-1]["end"]] == [int(c) for c in cuts.split(",")]
     assert sum(x["n_matches"] for x in res) == len(ops[3])
     # observation scans on the submap ranks == the same calls of the oracle on the whole map, restricted to the rank's
     # resident poses [lo, hi) (bit for bit: fp32, host trigonometry)
