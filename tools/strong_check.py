@@ -6,7 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import hitl_slam_amd as H
 from hitl_slam_amd import abi
 from tools import hitl_synth as S
-n, m, world = int(sys.argv[1]) if len(sys.argv) > 1 else 50000, 400, 2
+n, m = int(sys.argv[1]) if len(sys.argv) > 1 else 50000, 400
+world = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 ppf, window = 200, 3
 groups = max(1, int(round(50 * n / 50000)))          # bench.py --poses keeps the constraint density of the named workload
 p = S.params(n, m, seed=20260102 + 4000, poses_per_floor=ppf)
@@ -24,4 +25,4 @@ off, px, py, nx, ny = S.scans(p)
 s = H.Solver(); s.set_map(off, px, py, nx, ny, cov); s.set_human_constraints((rows, tot))
 s.find_correspondences(init, window)
 out, summ = s.solve(H.MODE_JOINT, init, allow_failure=True)
-print("single GPU on the strong-2 problem: iterations %d, termination %d, cost %.9g -> %.9g, rows %d" % (summ.iterations, summ.termination, summ.initial_cost, summ.final_cost, tot))
+print("single GPU on the strong-%d problem:" % world + " iterations %d, termination %d, cost %.9g -> %.9g, rows %d" % (summ.iterations, summ.termination, summ.initial_cost, summ.final_cost, tot))
