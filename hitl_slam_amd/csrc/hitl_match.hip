@@ -17,6 +17,7 @@
 
 namespace hitl {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int kMatchBlock = 256;
 constexpr int kMatchGroup = 16;    // target points per bounding box
 
@@ -25,7 +26,7 @@ __global__ __launch_bounds__(kMatchBlock) void k_match(MapView map, int chunk, i
                                                         const float* __restrict__ cand_tf, MatchParams mp,
                                                         uint16_t* __restrict__ table, int* __restrict__ counts) {
   extern __shared__ float4 s_tgt[];                 // [max_scan]
-  int* s_cnt = (int*)(s_tgt + max_scan);            // [max_scan] accepted matches per source point
+  int* s_cnt = (int*)(s_tgt + ((max_scan + 1) & ~1));   // [max_scan] accepted matches per source point
   float4* s_box = (float4*)(s_cnt + ((max_scan + 3) & ~3));   // [ceil(max_scan / kMatchGroup)] (min x, min y, max x, max y), 16-byte aligned
   __shared__ int s_pair_count;
   const int b = blockIdx.x;
@@ -43,7 +44,16 @@ __global__ __launch_bounds__(kMatchBlock) void k_match(MapView map, int chunk, i
     const int mj = (int)(map.obs_off[j + 1] - oj);
     __syncthreads();
     if (threadIdx.x == 0) s_pair_count = 0;
-    for (int t = threadIdx.x; t < mj; t += kMatchBlock) s_tgt[t] = map.obs[oj + t];
+    // Two consecutive target points per LDS record pair -- s_tgt[2h] = (x, x', y, y'), s_tgt[2h + 1] = (nx, nx', ny, ny') of
+    // points 2h and 2h + 1 -- so that the gate and the point-to-plane score of both come out of packed fp32 instructions
+    // (v_pk_add_f32 / v_pk_mul_f32: two IEEE results per instruction, each identical to the scalar one; no contraction).
+    // An odd scan ends with a copy of its last point (never selected: its index is past the end).
+    for (int h = threadIdx.x; 2 * h < mj; h += kMatchBlock) {
+      const float4 a = map.obs[oj + 2 * h];
+      const float4 b = (2 * h + 1 < mj) ? map.obs[oj + 2 * h + 1] : a;
+      s_tgt[2 * h] = make_float4(a.x, b.x, a.y, b.y);
+      s_tgt[2 * h + 1] = make_float4(a.z, b.z, a.w, b.w);
+    }
     __syncthreads();
     // Bounding box of every run of kMatchGroup consecutive target points (a scan is ordered by bearing, so a run is a
     // short piece of wall).  A source point farther than the gate from a box cannot pass the gate for any point in
@@ -54,8 +64,9 @@ __global__ __launch_bounds__(kMatchBlock) void k_match(MapView map, int chunk, i
       float4 bx = make_float4(3.402823466e+38f, 3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f);
       const int t1 = min(mj, (g + 1) * kMatchGroup);
       for (int t = g * kMatchGroup; t < t1; ++t) {
-        const float4 v = s_tgt[t];
-        bx.x = fminf(bx.x, v.x); bx.y = fminf(bx.y, v.y); bx.z = fmaxf(bx.z, v.x); bx.w = fmaxf(bx.w, v.y);
+        const float4 v = s_tgt[t & ~1];
+        const float vx = (t & 1) ? v.y : v.x, vy = (t & 1) ? v.w : v.z;
+        bx.x = fminf(bx.x, vx); bx.y = fminf(bx.y, vy); bx.z = fmaxf(bx.z, vx); bx.w = fmaxf(bx.w, vy);
       }
       s_box[g] = bx;
     }
@@ -73,6 +84,7 @@ __global__ __launch_bounds__(kMatchBlock) void k_match(MapView map, int chunk, i
         const float qy = (m10 * ax + m11 * ay) + ty;
         float best = 3.402823466e+38f;
         int bi = -1;
+        const f32x2 q2x = {qx, qx}, q2y = {qy, qy};
         for (int gi = 0; gi < ngrp; ++gi) {
           const float4 bx = s_box[gi];
           // distance from q to the box, with the same subtractions the point test uses (q - coordinate)
@@ -80,21 +92,22 @@ __global__ __launch_bounds__(kMatchBlock) void k_match(MapView map, int chunk, i
           const float ey = fmaxf(fmaxf(qy - bx.w, -(qy - bx.y)), 0.0f);
           if (!(ex * ex + ey * ey < thr2)) continue;
           const int t1 = min(mj, (gi + 1) * kMatchGroup);
-          for (int t = gi * kMatchGroup; t < t1; ++t) {
-            const float4 g = s_tgt[t];
-            const float dx = qx - g.x, dy = qy - g.y;
-            const float dsq = dx * dx + dy * dy;
-            if (dsq < thr2) {
-              const float sc = fabsf(g.z * dx + g.w * dy);
-              if (sc < best) { best = sc; bi = t; }
-            }
+          for (int t = gi * kMatchGroup; t < t1; t += 2) {            // kMatchGroup is even: t is even
+            const float4 P = s_tgt[t], N = s_tgt[t + 1];
+            const f32x2 dx = q2x - f32x2{P.x, P.y}, dy = q2y - f32x2{P.z, P.w};
+            const f32x2 dsq = dx * dx + dy * dy;
+            const f32x2 sc = f32x2{N.x, N.y} * dx + f32x2{N.z, N.w} * dy;
+            const float s0 = fabsf(sc.x), s1 = fabsf(sc.y);
+            if (dsq.x < thr2 && s0 < best) { best = s0; bi = t; }
+            if (t + 1 < t1 && dsq.y < thr2 && s1 < best) { best = s1; bi = t + 1; }
           }
         }
         if (bi >= 0 && best < thr) {
           const float anx = a.z, any = a.w;
           const float nqx = cr * anx - sr * any, nqy = sr * anx + cr * any;
-          const float4 g = s_tgt[bi];
-          const float cosang = g.z * nqx + g.w * nqy;
+          const float4 gn = s_tgt[(bi & ~1) + 1];
+          const float gnx = (bi & 1) ? gn.y : gn.x, gny = (bi & 1) ? gn.w : gn.z;
+          const float cosang = gnx * nqx + gny * nqy;
           if (cosang > mp.min_cos) { res = (uint16_t)bi; s_cnt[k] += 1; ++local; }
         }
       }
@@ -371,7 +384,7 @@ void launch_match_kd(hipStream_t st, const MapView& map, int max_scan, int slots
 }
 
 size_t match_lds_bytes(int max_scan) {
-  return (size_t)max_scan * sizeof(float4) + (size_t)((max_scan + 3) & ~3) * sizeof(int) +
+  return (size_t)((max_scan + 1) & ~1) * sizeof(float4) + (size_t)((max_scan + 3) & ~3) * sizeof(int) +
          (size_t)((max_scan + kMatchGroup - 1) / kMatchGroup) * sizeof(float4);
 }
 
