@@ -12,7 +12,7 @@ for kd in (0, 1):
     opt = H.default_options(); opt.kd_tree_search = kd
     s = H.Solver(opt)
     s.set_map(off, px, py, nx, ny, cov)
-    for rep in range(3):
+    for rep in range(8):
         t0 = time.perf_counter()
         s.find_correspondences(init, 3)
         print("kd=%d rep %d: %.2f ms" % (kd, rep, (time.perf_counter() - t0) * 1e3), file=sys.stderr)
