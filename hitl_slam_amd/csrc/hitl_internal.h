@@ -131,6 +131,7 @@ void launch_cr_solve(hipStream_t st, const CrView& cr, const double* rhs, double
 // y = (S H S [+ D^2]) v ; damping added when mu > 0
 void launch_spmv(hipStream_t st, int n_poses, int npad, const FactorView& fv, const LinView& lin,
                  const double* scale, double mu, double min_diag, double max_diag, const double* v, double* y, bool all_cols = false);
+void launch_host_flag(hipStream_t st, double* flag_pinned, double seq);
 void launch_pack_owned(hipStream_t st, int nhead, const double* head, const double* vec, int off, int cnt, int maxcnt, double* rec);
 void launch_scatter_idx(hipStream_t st, int cnt, const int* idx, const double* val, double* vec);
 int spmv_blocks(int npad);

@@ -20,6 +20,7 @@ struct hitl_solver {
   int64_t lin_launches = 0;     // linearisations queued so far (every 4th is bracketed by events at timing_level 1)
   bool lin_timed = false;       // the linearisation in flight is bracketed
   double* h_scalars = nullptr;  // pinned, kNumScalars
+  int64_t sync_seq = 0;
   double* h_partials = nullptr; // pinned, h_partials_cap doubles
   size_t h_partials_cap = 0;
   DevArray<double> step_partials;   // spmv workgroups x 8

@@ -447,6 +447,13 @@ void launch_axpby(hipStream_t st, int n, double alpha, const double* x, double b
   hipLaunchKernelGGL(k_axpby, dim3((n + 255) / 256), dim3(256), 0, st, n, alpha, x, beta, y);
 }
 
+// one store of a sequence number into pinned host memory, behind everything queued before it: the host polls the word
+// instead of an event (hipEventRecord + hipEventQuery cost the LM loop several microseconds per turn)
+__global__ void k_host_flag(volatile double* flag, double seq) { *flag = seq; }
+void launch_host_flag(hipStream_t st, double* flag_pinned, double seq) {
+  hipLaunchKernelGGL(k_host_flag, dim3(1), dim3(1), 0, st, flag_pinned, seq);
+}
+
 void launch_copy(hipStream_t st, int n, const double* src, double* dst) {
   (void)hipMemcpyAsync(dst, src, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st);
 }

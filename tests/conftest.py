@@ -9,6 +9,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# The oracle is an OpenMP program.  A GPU box shows 256 CPUs but grants 16 cores (cgroup quota): 256 threads on them make
+# every small oracle solve take seconds (7.5 s for 104 poses).  Use what can really run at once -- before the library loads.
+if "OMP_NUM_THREADS" not in os.environ:
+    from tools.probe_host import usable_cores
+    os.environ["OMP_NUM_THREADS"] = str(max(1, min(usable_cores(), 16)))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
