@@ -136,8 +136,7 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
   DevArray<float>& d_tf = s->d_cand_tf;
   DevArray<uint16_t>& d_table = s->d_cand_table;
   int rc = HITL_OK;
-  auto cleanup = [&]() {};
-#define TRYC(expr) do { rc = (expr); if (rc != HITL_OK) { cleanup(); return rc; } } while (0)
+#define TRYC(expr) do { rc = (expr); if (rc != HITL_OK) return rc; } while (0)
   TRYC(d_tgt.upload(cand_tgt, st));
   TRYC(d_tf.upload(cand_tf, st));
   TRYC(d_counts.resize((size_t)n * slots));
@@ -162,7 +161,7 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
   } else {
     launch_match(st, mv, s->max_scan, slots, d_tgt.p, d_tf.p, mp, d_table.p, d_counts.p);
   }
-  if (hipGetLastError() != hipSuccess) { cleanup(); return fail(HITL_ERR_HIP, "find_correspondences: the match kernel could not be launched"); }
+  if (hipGetLastError() != hipSuccess) { return fail(HITL_ERR_HIP, "find_correspondences: the match kernel could not be launched"); }
   // A window inside the pose band cannot produce an off-band pair: the pair tables are then built on the device, next to
   // the counts, and only five totals come back.  Wider windows (all-pairs search) take the general host path below.
   const int band_cap = std::min(std::max((int)s->opt.max_band_poses, 1), kMaxBandPoses);
@@ -212,7 +211,6 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
   std::vector<int> counts((size_t)n * slots);
   if (hipMemcpyAsync(counts.data(), d_counts.p, counts.size() * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
       hipStreamSynchronize(st) != hipSuccess) {
-    cleanup();
     return fail(HITL_ERR_HIP, std::string("match kernel: ") + hipGetErrorString(hipGetLastError()));
   }
   mark("k_match + counts");
@@ -242,11 +240,10 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
   TRYC(s->pair_tgt.upload(s->h_pair_tgt, st));
   TRYC(s->match_off.upload(s->h_match_off, st));
   TRYC(s->matches.resize((size_t)s->n_matches + kMatchPad));      // k_linearize_stf prefetches index words unguarded
-  if (hipMemsetAsync(s->matches.p + s->n_matches, 0, sizeof(uint32_t) * kMatchPad, st) != hipSuccess) { cleanup(); return fail(HITL_ERR_HIP, "find_correspondences: padding the match array failed"); }
+  if (hipMemsetAsync(s->matches.p + s->n_matches, 0, sizeof(uint32_t) * kMatchPad, st) != hipSuccess) { return fail(HITL_ERR_HIP, "find_correspondences: padding the match array failed"); }
   launch_compact(st, mv, s->max_scan, slots, s->n_pairs, d_kept.p, s->match_off.p, d_table.p, s->matches.p);
-  if (hipStreamSynchronize(st) != hipSuccess) { cleanup(); return fail(HITL_ERR_HIP, "compact kernel failed"); }
+  if (hipStreamSynchronize(st) != hipSuccess) { return fail(HITL_ERR_HIP, "compact kernel failed"); }
   mark("uploads + k_compact");
-  cleanup();
   mark("free");
 #undef TRYC
   rc = build_pair_structures(s);

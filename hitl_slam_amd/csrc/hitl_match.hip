@@ -545,8 +545,7 @@ __global__ __launch_bounds__(kPairBlock) void k_pair_block_scan(int nblk, int64_
 }
 
 // every block: exclusive offsets of its poses = block offset + in-block prefix, in place; the last entries (index n) = totals
-__global__ __launch_bounds__(kPairBlock) void k_pair_offsets(int n, const int64_t* __restrict__ blk, const int64_t* __restrict__ totals,
-                                                              int* __restrict__ pose_pairs, int64_t* __restrict__ pose_matches,
+__global__ __launch_bounds__(kPairBlock) void k_pair_offsets(int n, const int64_t* __restrict__ blk, int* __restrict__ pose_pairs, int64_t* __restrict__ pose_matches,
                                                               int* __restrict__ pose_inc) {
   const int i = blockIdx.x * kPairBlock + threadIdx.x;
   const bool in = i < n;
@@ -556,7 +555,6 @@ __global__ __launch_bounds__(kPairBlock) void k_pair_offsets(int n, const int64_
   const int64_t* o = blk + 6 * (size_t)blockIdx.x;
   if (in) { pose_pairs[i] = (int)(o[0] + ea); pose_matches[i] = o[1] + eb; pose_inc[i] = (int)(o[2] + ec); }
   if (i == n - 1) { pose_pairs[n] = (int)(o[0] + ea + a); pose_matches[n] = o[1] + eb + b; pose_inc[n] = (int)(o[2] + ec + c); }
-  (void)totals;
 }
 
 __global__ void k_pair_fill(WinCand w, int Wb, const int* __restrict__ pose_pair_off, const int64_t* __restrict__ pose_match_off,
@@ -606,7 +604,7 @@ void launch_pair_count_scan(hipStream_t st, int n, int slots, int window, int mi
   const int nblk = (n + kPairBlock - 1) / kPairBlock;
   hipLaunchKernelGGL(k_pair_block_sums, dim3(nblk), dim3(kPairBlock), 0, st, n, own_lo, own_hi, pose_pair_off, pose_match_off, inc_off, pose_maxd, blk);
   hipLaunchKernelGGL(k_pair_block_scan, dim3(1), dim3(kPairBlock), 0, st, nblk, blk, totals);
-  hipLaunchKernelGGL(k_pair_offsets, dim3(nblk), dim3(kPairBlock), 0, st, n, blk, totals, pose_pair_off, pose_match_off, inc_off);
+  hipLaunchKernelGGL(k_pair_offsets, dim3(nblk), dim3(kPairBlock), 0, st, n, blk, pose_pair_off, pose_match_off, inc_off);
 }
 
 int pair_scan_blocks(int n) { return (n + kPairBlock - 1) / kPairBlock; }
