@@ -76,42 +76,51 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
   if (match_lds_bytes(s->max_scan) > (size_t)160 * 1024)
     return fail(HITL_ERR_UNSUPPORTED, "find_correspondences: a scan of " + std::to_string(s->max_scan) +
                 " points does not fit the 160 KB of LDS the matcher stages a target scan in (limit ~7900 points)");
-  const size_t table_entries = (size_t)n * slots * s->max_scan;
-  if (table_entries * sizeof(uint16_t) > (size_t)64 << 30)
-    return fail(HITL_ERR_OUT_OF_MEMORY, "candidate table would exceed 64 GiB; use a smaller window");
+  // The candidate table (u16 per candidate and source point) of a window inside the band is small (<= 8 slots per pose);
+  // wider windows -- the reference's all-pairs search above all -- are cut into tiles of source poses so that the table
+  // stays below a budget whatever the map (all slots of a source pose share a tile: the per-point cap counts across them).
+  const int band_cap = std::min(std::max((int)s->opt.max_band_poses, 1), kMaxBandPoses);
+  const bool device_tables = window <= band_cap;
+  size_t tile_budget = (size_t)4 << 30;
+  if (const char* e = std::getenv("HITL_CAND_TILE_BYTES")) tile_budget = (size_t)std::max(1ll, std::atoll(e));     // tests: force several tiles
+  const size_t per_pose = (size_t)slots * s->max_scan * sizeof(uint16_t);
+  const int tile = device_tables ? n : (int)std::min<size_t>((size_t)n, std::max<size_t>(1, tile_budget / std::max<size_t>(per_pose, 1)));
   // scratch kept in the solver between calls (no 10 MB allocate-and-clear per search)
   std::vector<int>& cand_tgt = s->h_cand_tgt;
   std::vector<float>& cand_tf = s->h_cand_tf;
   std::vector<float>& cs = s->h_cand_cs;
-  if (cand_tgt.size() != (size_t)n * slots) cand_tgt.resize((size_t)n * slots);
-  if (cand_tf.size() != (size_t)n * slots * 8) cand_tf.resize((size_t)n * slots * 8);
+  if (cand_tgt.size() != (size_t)tile * slots) cand_tgt.resize((size_t)tile * slots);
+  if (cand_tf.size() != (size_t)tile * slots * 8) cand_tf.resize((size_t)tile * slots * 8);
   if (cs.size() != (size_t)2 * n) cs.resize((size_t)2 * n);
-  {
-    // candidate transforms: fp32 host libm (bit-identical to the CPU restatement), spread over a few threads
-    // a handful of threads: spawning 32 cost more than the trigonometry (hardware_concurrency() also counts CPUs a container's
-    // quota does not grant)
-    const int nt = (int)std::max(1u, std::min(12u, std::thread::hardware_concurrency()));
-    auto run = [&](auto&& body) {
-      std::vector<std::thread> th;
-      for (int t = 1; t < nt; ++t) th.emplace_back([&, t]() { body((int64_t)n * t / nt, (int64_t)n * (t + 1) / nt); });
-      body(0, (int64_t)n / nt);
-      for (auto& x : th) x.join();
-    };
-    const bool paired = libm_sincos_exact();
-    run([&](int64_t a, int64_t b) {
-      for (int64_t i = a; i < b; ++i) {
-        if (paired) sincosf(poses[3 * i + 2], &cs[2 * i + 1], &cs[2 * i]);
-        else { cs[2 * i] = cosf(poses[3 * i + 2]); cs[2 * i + 1] = sinf(poses[3 * i + 2]); }
-      }
-    });
-    run([&](int64_t a, int64_t b) {
+  // candidate transforms: fp32 host libm (bit-identical to the CPU restatement), spread over a few threads
+  // a handful of threads: spawning 32 cost more than the trigonometry (hardware_concurrency() also counts CPUs a container's
+  // quota does not grant)
+  const int nt = (int)std::max(1u, std::min(12u, std::thread::hardware_concurrency()));
+  auto run = [&](int64_t lo, int64_t hi, auto&& body) {
+    std::vector<std::thread> th;
+    const int64_t len = hi - lo;
+    for (int t = 1; t < nt; ++t) th.emplace_back([&, t]() { body(lo + len * t / nt, lo + len * (t + 1) / nt); });
+    body(lo, lo + len / nt);
+    for (auto& x : th) x.join();
+  };
+  const bool libm_ok = libm_sincos_exact();
+  run(0, n, [&](int64_t a, int64_t b) {
+    for (int64_t i = a; i < b; ++i) {
+      if (libm_ok) sincosf(poses[3 * i + 2], &cs[2 * i + 1], &cs[2 * i]);
+      else { cs[2 * i] = cosf(poses[3 * i + 2]); cs[2 * i + 1] = sinf(poses[3 * i + 2]); }
+    }
+  });
+  // candidates of the source poses [i0, i1) into cand_tgt / cand_tf (indexed from i0)
+  auto fill_candidates = [&](int64_t i0, int64_t i1) {
+    const bool paired = libm_ok && i0 == 0 && i1 == n;        // the mirror of a candidate lies in the same tile only when there is one tile
+    run(i0, i1, [&](int64_t a, int64_t b) {
       for (int64_t i = a; i < b; ++i) {
         int slot = 0;
         const int64_t j0 = std::max<int64_t>(0, i - window), j1 = std::min<int64_t>(n - 1, i + window);
         for (int64_t j = j0; j <= j1; ++j) {
           if (j == i) continue;
-          cand_tgt[(size_t)i * slots + slot] = (int)j;
-          float* t = &cand_tf[((size_t)i * slots + slot) * 8];
+          cand_tgt[(size_t)(i - i0) * slots + slot] = (int)j;
+          float* t = &cand_tf[((size_t)(i - i0) * slots + slot) * 8];
           make_rel_tf(poses + 3 * i, poses + 3 * j, &cs[2 * i], &cs[2 * j], t, !paired);
           if (paired && j > i) {
             // one sincosf serves the candidate (i -> j) and its mirror (j -> i): the angle of the mirror is the exact
@@ -121,15 +130,16 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
             sincosf(dth, &sn, &cn);
             t[6] = cn; t[7] = sn;
             const int64_t jj0 = std::max<int64_t>(0, j - window);
-            float* tm = &cand_tf[((size_t)j * slots + (size_t)((i - jj0) - (i > j ? 1 : 0))) * 8];   // slot of i in j's list (i < j)
+            float* tm = &cand_tf[((size_t)j * slots + (size_t)(i - jj0)) * 8];   // slot of i in j's list (i < j)
             tm[6] = cn; tm[7] = -sn;
           }
           ++slot;
         }
-        for (; slot < slots; ++slot) cand_tgt[(size_t)i * slots + slot] = -1;     // unused slots of poses near the ends
+        for (; slot < slots; ++slot) cand_tgt[(size_t)(i - i0) * slots + slot] = -1;     // unused slots of poses near the ends
       }
     });
-  }
+  };
+  if (device_tables) fill_candidates(0, n);
   mark("candidate transforms");
   hipStream_t st = s->stream;
   DevArray<int>&d_tgt = s->d_cand_tgt, &d_counts = s->d_cand_counts, &d_kept = s->d_cand_kept;   // device scratch, kept too
@@ -137,35 +147,35 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
   DevArray<uint16_t>& d_table = s->d_cand_table;
   int rc = HITL_OK;
 #define TRYC(expr) do { rc = (expr); if (rc != HITL_OK) return rc; } while (0)
-  TRYC(d_tgt.upload(cand_tgt, st));
-  TRYC(d_tf.upload(cand_tf, st));
-  TRYC(d_counts.resize((size_t)n * slots));
-  TRYC(d_counts.zero(st));
-  TRYC(d_table.resize(table_entries));
-  mark("uploads + table alloc");
   MatchParams mp;
   mp.thr = s->opt.point_match_threshold;
   mp.min_cos = cosf(s->opt.max_stf_angle_error);   // JointOptimization.cpp:564
   mp.cap = s->opt.max_correspondences_per_point;
   mp.skip = std::max(s->opt.num_skip_readings, 1);
   const MapView mv = s->map_view();
-  if (kd) {
-    if (!s->kd_built) {      // BuildKDTrees: once per map (JointOptimization.cpp:1307, kdtrees_.size() == 0)
-      TRYC(s->kd_pts.resize((size_t)std::max<int64_t>(s->n_obs, 1)));
-      TRYC(s->kd_meta.resize((size_t)std::max<int64_t>(s->n_obs, 1)));
-      launch_kd_build(st, mv, s->max_scan, s->kd_pts.p, s->kd_meta.p);
-      s->kd_built = true;
-      mark("k_kd_build");
-    }
-    launch_match_kd(st, mv, s->max_scan, slots, d_tgt.p, d_tf.p, mp, s->kd_pts.p, s->kd_meta.p, d_table.p, d_counts.p);
-  } else {
-    launch_match(st, mv, s->max_scan, slots, d_tgt.p, d_tf.p, mp, d_table.p, d_counts.p);
+  if (kd && !s->kd_built) {      // BuildKDTrees: once per map (JointOptimization.cpp:1307, kdtrees_.size() == 0)
+    TRYC(s->kd_pts.resize((size_t)std::max<int64_t>(s->n_obs, 1)));
+    TRYC(s->kd_meta.resize((size_t)std::max<int64_t>(s->n_obs, 1)));
+    launch_kd_build(st, mv, s->max_scan, s->kd_pts.p, s->kd_meta.p);
+    s->kd_built = true;
+    mark("k_kd_build");
   }
-  if (hipGetLastError() != hipSuccess) { return fail(HITL_ERR_HIP, "find_correspondences: the match kernel could not be launched"); }
+  // one tile of source poses [i0, i0 + cnt): upload its candidates, match
+  auto match_tile = [&](int i0, int cnt) -> int {
+    TRYC(d_tgt.upload(cand_tgt.data(), (size_t)cnt * slots, st));
+    TRYC(d_tf.upload(cand_tf.data(), (size_t)cnt * slots * 8, st));
+    TRYC(d_counts.resize((size_t)cnt * slots));
+    TRYC(d_counts.zero(st));
+    TRYC(d_table.resize((size_t)cnt * slots * s->max_scan));
+    if (kd) launch_match_kd(st, mv, s->max_scan, slots, d_tgt.p, d_tf.p, mp, s->kd_pts.p, s->kd_meta.p, d_table.p, d_counts.p, i0, cnt);
+    else launch_match(st, mv, s->max_scan, slots, d_tgt.p, d_tf.p, mp, d_table.p, d_counts.p, i0, cnt);
+    if (hipGetLastError() != hipSuccess) return fail(HITL_ERR_HIP, "find_correspondences: the match kernel could not be launched");
+    return HITL_OK;
+  };
+  if (device_tables) TRYC(match_tile(0, n));
   // A window inside the pose band cannot produce an off-band pair: the pair tables are then built on the device, next to
   // the counts, and only five totals come back.  Wider windows (all-pairs search) take the general host path below.
-  const int band_cap = std::min(std::max((int)s->opt.max_band_poses, 1), kMaxBandPoses);
-  if (window <= band_cap) {
+  if (device_tables) {
     DevArray<int>& d_maxd = s->d_pose_maxd;
     DevArray<int64_t>&d_pmo = s->d_pose_match_off, &d_tot = s->d_pair_totals;
     TRYC(s->pose_pair_off.resize((size_t)n + 1)); TRYC(s->inc_off.resize((size_t)n + 1));
@@ -208,43 +218,63 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
     mark("pair tables + k_compact");
     return HITL_OK;
   }
-  std::vector<int> counts((size_t)n * slots);
-  if (hipMemcpyAsync(counts.data(), d_counts.p, counts.size() * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
-      hipStreamSynchronize(st) != hipSuccess) {
-    return fail(HITL_ERR_HIP, std::string("match kernel: ") + hipGetErrorString(hipGetLastError()));
-  }
-  mark("k_match + counts");
-  // keep pairs with more than kMinInterPoseCorrespondence matches (:632-634), pose order (:636-641)
-  std::vector<int> kept;
-  kept.reserve(cand_tgt.size());
+  // general path (windows wider than the band): tile by tile -- match, fetch the counts, keep pairs with more than
+  // kMinInterPoseCorrespondence matches (:632-634) in pose order (:636-641), compact the tile's rows behind what is there
+  std::vector<int> counts, kept;
+  std::vector<int64_t> tile_off;
   s->h_pair_src.clear(); s->h_pair_tgt.clear(); s->h_match_off.assign(1, 0);
-  s->h_pair_src.reserve(cand_tgt.size()); s->h_pair_tgt.reserve(cand_tgt.size()); s->h_match_off.reserve(cand_tgt.size() + 1);
-  for (int i = 0; i < n; ++i)
-    for (int sl = 0; sl < slots; ++sl) {
-      const size_t c = (size_t)i * slots + sl;
-      const int jt = cand_tgt[c];
-      const bool relevant = (i >= s->own_lo && i < s->own_hi) || (jt >= s->own_lo && jt < s->own_hi);   // halo-halo pairs belong to other ranks
-      if (jt >= 0 && relevant && counts[c] > s->opt.min_inter_pose_correspondence) {
-        kept.push_back((int)c);
-        s->h_pair_src.push_back(i); s->h_pair_tgt.push_back(cand_tgt[c]);
-        s->h_match_off.push_back(s->h_match_off.back() + counts[c]);
+  int64_t written = 0;                                   // matches compacted so far
+  for (int i0 = 0; i0 < n; i0 += tile) {
+    const int cnt = std::min(tile, n - i0);
+    fill_candidates(i0, i0 + cnt);
+    TRYC(match_tile(i0, cnt));
+    counts.resize((size_t)cnt * slots);
+    if (hipMemcpyAsync(counts.data(), d_counts.p, counts.size() * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+      return fail(HITL_ERR_HIP, std::string("match kernel: ") + hipGetErrorString(hipGetLastError()));
+    kept.clear(); tile_off.clear();
+    for (int il = 0; il < cnt; ++il)
+      for (int sl = 0; sl < slots; ++sl) {
+        const size_t c = (size_t)il * slots + sl;
+        const int i = i0 + il, jt = cand_tgt[c];
+        const bool relevant = (i >= s->own_lo && i < s->own_hi) || (jt >= s->own_lo && jt < s->own_hi);   // halo-halo pairs belong to other ranks
+        if (jt >= 0 && relevant && counts[c] > s->opt.min_inter_pose_correspondence) {
+          kept.push_back((int)c);
+          tile_off.push_back(s->h_match_off.back());
+          s->h_pair_src.push_back(i); s->h_pair_tgt.push_back(jt);
+          s->h_match_off.push_back(s->h_match_off.back() + counts[c]);
+        }
       }
+    const int64_t need = s->h_match_off.back() + kMatchPad;
+    if ((size_t)need > s->matches.cap) {                 // grow, keeping what the earlier tiles wrote
+      DevArray<uint32_t> bigger;
+      TRYC(bigger.resize((size_t)std::max<int64_t>(need, 2 * (int64_t)s->matches.cap)));
+      if (written > 0 && hipMemcpyAsync(bigger.p, s->matches.p, sizeof(uint32_t) * (size_t)written, hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return fail(HITL_ERR_HIP, "find_correspondences: growing the match array failed");
+      HIP_TRY(hipStreamSynchronize(st));
+      std::swap(bigger.p, s->matches.p); std::swap(bigger.cap, s->matches.cap); std::swap(bigger.n, s->matches.n);
     }
-  mark("pair filter");
-  s->n_pairs = (int)kept.size();
+    s->matches.n = (size_t)need;
+    if (!kept.empty()) {
+      TRYC(d_kept.upload(kept, st));
+      TRYC(s->match_off.upload(tile_off, st));           // this tile's write offsets (the full list goes up after the loop)
+      launch_compact(st, mv, s->max_scan, slots, (int)kept.size(), d_kept.p, s->match_off.p, d_table.p, s->matches.p, i0);
+      if (hipStreamSynchronize(st) != hipSuccess) return fail(HITL_ERR_HIP, "compact kernel failed");
+    }
+    written = s->h_match_off.back();
+  }
+  mark("match + filter + compact (tiles)");
+  s->n_pairs = (int)s->h_pair_src.size();
   s->n_matches = s->h_match_off.back();
   s->h_perm.resize(s->n_pairs);
   std::iota(s->h_perm.begin(), s->h_perm.end(), 0);
-  TRYC(d_kept.upload(kept, st));
   TRYC(s->pair_src.upload(s->h_pair_src, st));
   TRYC(s->pair_tgt.upload(s->h_pair_tgt, st));
   TRYC(s->match_off.upload(s->h_match_off, st));
-  TRYC(s->matches.resize((size_t)s->n_matches + kMatchPad));      // k_linearize_stf prefetches index words unguarded
+  TRYC(s->matches.resize((size_t)s->n_matches + kMatchPad));      // k_linearize_stf prefetches index words unguarded (capacity is there already)
   if (hipMemsetAsync(s->matches.p + s->n_matches, 0, sizeof(uint32_t) * kMatchPad, st) != hipSuccess) { return fail(HITL_ERR_HIP, "find_correspondences: padding the match array failed"); }
-  launch_compact(st, mv, s->max_scan, slots, s->n_pairs, d_kept.p, s->match_off.p, d_table.p, s->matches.p);
-  if (hipStreamSynchronize(st) != hipSuccess) { return fail(HITL_ERR_HIP, "compact kernel failed"); }
-  mark("uploads + k_compact");
-  mark("free");
+  if (hipStreamSynchronize(st) != hipSuccess) { return fail(HITL_ERR_HIP, "find_correspondences: uploads failed"); }
+  mark("uploads");
 #undef TRYC
   rc = build_pair_structures(s);
   mark("pair structures");

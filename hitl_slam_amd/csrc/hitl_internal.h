@@ -164,16 +164,16 @@ struct MatchParams { float thr, min_cos; int cap, skip; };
 size_t match_lds_bytes(int max_scan);     // dynamic LDS of k_match: the target scan, per-point counters, bounding boxes
 void launch_match(hipStream_t st, const MapView& map, int max_scan, int slots, const int* cand_tgt /* n*slots, -1 = none */,
                   const float* cand_tf /* n*slots*8 */, MatchParams mp, uint16_t* table /* n*slots*max_scan */,
-                  int* counts /* n*slots */);
+                  int* counts /* n*slots */, int i0 = 0, int n_tile = -1 /* source poses [i0, i0 + n_tile): the arrays hold the tile only */);
 // kd_tree_search: the reference's own trees and pruned walk (kdtree.cpp:37-197), bit for bit
 size_t kd_build_lds_bytes(int max_scan);
 size_t match_kd_lds_bytes(int max_scan);
 void launch_kd_build(hipStream_t st, const MapView& map, int max_scan, float4* kd_pts, uint32_t* kd_meta);
 void launch_match_kd(hipStream_t st, const MapView& map, int max_scan, int slots, const int* cand_tgt, const float* cand_tf, MatchParams mp,
-                     const float4* kd_pts, const uint32_t* kd_meta, uint16_t* table, int* counts);
+                     const float4* kd_pts, const uint32_t* kd_meta, uint16_t* table, int* counts, int i0 = 0, int n_tile = -1);
 void launch_compact(hipStream_t st, const MapView& map, int max_scan, int slots, int n_kept,
                     const int* kept_cand /* index into n*slots */, const int64_t* match_off, const uint16_t* table,
-                    uint32_t* matches);
+                    uint32_t* matches, int i0 = 0);
 
 // pair tables of a windowed search on the device (the layout of build_pair_structures, hitl_solver.cpp):
 // count + scan leave exclusive offsets (n + 1 entries) and totals[5] = pairs, matches, max |i - j|, owned pairs, owned matches

@@ -24,21 +24,22 @@ constexpr int kMatchGroup = 16;    // target points per bounding box
 __global__ __launch_bounds__(kMatchBlock) void k_match(MapView map, int chunk, int max_scan, int slots,
                                                         const int* __restrict__ cand_tgt,
                                                         const float* __restrict__ cand_tf, MatchParams mp,
-                                                        uint16_t* __restrict__ table, int* __restrict__ counts) {
+                                                        uint16_t* __restrict__ table, int* __restrict__ counts, int i0, int n_tile) {
   extern __shared__ float4 s_tgt[];                 // [max_scan]
   int* s_cnt = (int*)(s_tgt + ((max_scan + 1) & ~1));   // [max_scan] accepted matches per source point
   float4* s_box = (float4*)(s_cnt + ((max_scan + 3) & ~3));   // [ceil(max_scan / kMatchGroup)] (min x, min y, max x, max y), 16-byte aligned
   __shared__ int s_pair_count;
   const int b = blockIdx.x;
   const int idx = b >> 3;
-  const int i = (b & 7) * chunk + idx;              // consecutive poses share an XCD (L2 reuse of neighbours)
-  if (idx >= chunk || i >= map.n_poses) return;
+  const int il = (b & 7) * chunk + idx;             // consecutive poses share an XCD (L2 reuse of neighbours)
+  if (idx >= chunk || il >= n_tile) return;
+  const int i = i0 + il;                            // candidate arrays, table and counts hold the tile [i0, i0 + n_tile) only
   const int64_t oi = map.obs_off[i];
   const int mi = (int)(map.obs_off[i + 1] - oi);
   for (int k = threadIdx.x; k < mi; k += kMatchBlock) s_cnt[k] = 0;
   const float thr = mp.thr, thr2 = mp.thr * mp.thr;
   for (int slot = 0; slot < slots; ++slot) {
-    const int j = cand_tgt[(size_t)i * slots + slot];
+    const int j = cand_tgt[(size_t)il * slots + slot];
     if (j < 0) continue;                            // block-uniform
     const int64_t oj = map.obs_off[j];
     const int mj = (int)(map.obs_off[j + 1] - oj);
@@ -71,9 +72,9 @@ __global__ __launch_bounds__(kMatchBlock) void k_match(MapView map, int chunk, i
       s_box[g] = bx;
     }
     __syncthreads();
-    const float* tf = cand_tf + ((size_t)i * slots + slot) * 8;
+    const float* tf = cand_tf + ((size_t)il * slots + slot) * 8;
     const float m00 = tf[0], m01 = tf[1], m10 = tf[2], m11 = tf[3], tx = tf[4], ty = tf[5], cr = tf[6], sr = tf[7];
-    uint16_t* row = table + ((size_t)i * slots + slot) * max_scan;
+    uint16_t* row = table + ((size_t)il * slots + slot) * max_scan;
     int local = 0;
     for (int k = threadIdx.x; k < mi; k += kMatchBlock) {
       uint16_t res = 0xFFFFu;
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(kMatchBlock) void k_match(MapView map, int chunk, i
     }
     if (local) atomicAdd(&s_pair_count, local);
     __syncthreads();
-    if (threadIdx.x == 0) counts[(size_t)i * slots + slot] = s_pair_count;
+    if (threadIdx.x == 0) counts[(size_t)il * slots + slot] = s_pair_count;
   }
 }
 
@@ -312,7 +313,7 @@ __device__ __forceinline__ float kd_find_nearest_point_normal(const float4* __re
 __global__ __launch_bounds__(kMatchBlock) void k_match_kd(MapView map, int chunk, int max_scan, int slots, int depth,
                                                            const int* __restrict__ cand_tgt, const float* __restrict__ cand_tf, MatchParams mp,
                                                            const float4* __restrict__ kd_pts, const uint32_t* __restrict__ kd_meta,
-                                                           uint16_t* __restrict__ table, int* __restrict__ counts) {
+                                                           uint16_t* __restrict__ table, int* __restrict__ counts, int i0, int n_tile) {
   extern __shared__ float4 s_tgt[];                 // [max_scan] target tree points (in-order layout)
   uint32_t* s_meta = (uint32_t*)(s_tgt + max_scan); // [max_scan] original index | split << 16
   int* s_cnt = (int*)(s_meta + max_scan);           // [max_scan] accepted matches per source point
@@ -323,14 +324,15 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_kd(MapView map, int chunk
   __shared__ int s_pair_count;
   const int b = blockIdx.x;
   const int idx = b >> 3;
-  const int i = (b & 7) * chunk + idx;
-  if (idx >= chunk || i >= map.n_poses) return;
+  const int il = (b & 7) * chunk + idx;
+  if (idx >= chunk || il >= n_tile) return;
+  const int i = i0 + il;                            // tile [i0, i0 + n_tile): see k_match
   const int64_t oi = map.obs_off[i];
   const int mi = (int)(map.obs_off[i + 1] - oi);
   for (int k = threadIdx.x; k < mi; k += kMatchBlock) s_cnt[k] = 0;
   const float thr = mp.thr;
   for (int slot = 0; slot < slots; ++slot) {
-    const int j = cand_tgt[(size_t)i * slots + slot];
+    const int j = cand_tgt[(size_t)il * slots + slot];
     if (j < 0) continue;                            // block-uniform
     const int64_t oj = map.obs_off[j];
     const int mj = (int)(map.obs_off[j + 1] - oj);
@@ -338,9 +340,9 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_kd(MapView map, int chunk
     if (threadIdx.x == 0) s_pair_count = 0;
     for (int t = threadIdx.x; t < mj; t += kMatchBlock) { s_tgt[t] = kd_pts[oj + t]; s_meta[t] = kd_meta[oj + t]; }
     __syncthreads();
-    const float* tf = cand_tf + ((size_t)i * slots + slot) * 8;
+    const float* tf = cand_tf + ((size_t)il * slots + slot) * 8;
     const float m00 = tf[0], m01 = tf[1], m10 = tf[2], m11 = tf[3], tx = tf[4], ty = tf[5], cr = tf[6], sr = tf[7];
-    uint16_t* row = table + ((size_t)i * slots + slot) * max_scan;
+    uint16_t* row = table + ((size_t)il * slots + slot) * max_scan;
     int local = 0;
     for (int k = threadIdx.x; k < mi; k += kMatchBlock) {
       uint16_t res = 0xFFFFu;
@@ -364,7 +366,7 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_kd(MapView map, int chunk
     }
     if (local) atomicAdd(&s_pair_count, local);
     __syncthreads();
-    if (threadIdx.x == 0) counts[(size_t)i * slots + slot] = s_pair_count;
+    if (threadIdx.x == 0) counts[(size_t)il * slots + slot] = s_pair_count;
   }
 }
 
@@ -375,12 +377,13 @@ size_t match_kd_lds_bytes(int max_scan) {
 }
 
 void launch_match_kd(hipStream_t st, const MapView& map, int max_scan, int slots, const int* cand_tgt, const float* cand_tf, MatchParams mp,
-                     const float4* kd_pts, const uint32_t* kd_meta, uint16_t* table, int* counts) {
-  const int chunk = (map.n_poses + 7) / 8;
+                     const float4* kd_pts, const uint32_t* kd_meta, uint16_t* table, int* counts, int i0, int n_tile) {
+  if (n_tile < 0) n_tile = map.n_poses - i0;
+  const int chunk = (n_tile + 7) / 8;
   const size_t lds = match_kd_lds_bytes(max_scan);
   if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_match_kd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k_match_kd, dim3(8 * chunk), dim3(kMatchBlock), lds, st, map, chunk, max_scan, slots, kd_depth(max_scan), cand_tgt, cand_tf,
-                     mp, kd_pts, kd_meta, table, counts);
+                     mp, kd_pts, kd_meta, table, counts, i0, n_tile);
 }
 
 size_t match_lds_bytes(int max_scan) {
@@ -389,21 +392,22 @@ size_t match_lds_bytes(int max_scan) {
 }
 
 void launch_match(hipStream_t st, const MapView& map, int max_scan, int slots, const int* cand_tgt, const float* cand_tf,
-                  MatchParams mp, uint16_t* table, int* counts) {
-  const int chunk = (map.n_poses + 7) / 8;
+                  MatchParams mp, uint16_t* table, int* counts, int i0, int n_tile) {
+  if (n_tile < 0) n_tile = map.n_poses - i0;
+  const int chunk = (n_tile + 7) / 8;
   const size_t lds = match_lds_bytes(max_scan);
   if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_match), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k_match, dim3(8 * chunk), dim3(kMatchBlock), lds, st, map, chunk, max_scan, slots, cand_tgt, cand_tf,
-                     mp, table, counts);
+                     mp, table, counts, i0, n_tile);
 }
 
 // ordered stream compaction of one kept pair's table row into packed (src | tgt << 16) matches
 __global__ __launch_bounds__(64) void k_compact(MapView map, int max_scan, int slots, const int* __restrict__ kept_cand,
                                                  const int64_t* __restrict__ match_off,
-                                                 const uint16_t* __restrict__ table, uint32_t* __restrict__ matches) {
+                                                 const uint16_t* __restrict__ table, uint32_t* __restrict__ matches, int i0) {
   const int p = blockIdx.x;
-  const int cand = kept_cand[p];
-  const int i = cand / slots;
+  const int cand = kept_cand[p];                    // index into the tile's candidate arrays; its source pose is i0 + cand / slots
+  const int i = i0 + cand / slots;
   const int mi = (int)(map.obs_off[i + 1] - map.obs_off[i]);
   const uint16_t* row = table + (size_t)cand * max_scan;
   int64_t w = match_off[p];
@@ -422,9 +426,9 @@ __global__ __launch_bounds__(64) void k_compact(MapView map, int max_scan, int s
 }
 
 void launch_compact(hipStream_t st, const MapView& map, int max_scan, int slots, int n_kept, const int* kept_cand,
-                    const int64_t* match_off, const uint16_t* table, uint32_t* matches) {
+                    const int64_t* match_off, const uint16_t* table, uint32_t* matches, int i0) {
   if (n_kept == 0) return;
-  hipLaunchKernelGGL(k_compact, dim3(n_kept), dim3(64), 0, st, map, max_scan, slots, kept_cand, match_off, table, matches);
+  hipLaunchKernelGGL(k_compact, dim3(n_kept), dim3(64), 0, st, map, max_scan, slots, kept_cand, match_off, table, matches, i0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

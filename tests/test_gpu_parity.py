@@ -401,3 +401,36 @@ def test_device_built_pair_tables_equal_the_host_built_ones(shape):
     assert c_dev == c_host and np.array_equal(g_dev, g_host)
     assert s_dev.iterations == s_host.iterations and s_dev.final_cost == s_host.final_cost
     assert np.array_equal(p_dev, p_host)
+
+
+@pytest.mark.parametrize("kd", [0, 1])
+def test_tiled_candidate_table_gives_the_same_sets(monkeypatch, kd):
+    """Windows wider than the band (the reference's all-pairs search above all) are matched tile by tile over the source
+    poses so that the candidate table stays inside a budget whatever the map.  With the budget forced down to a handful of
+    poses per tile the index sets, and the solve on them, are those of the single-tile run and of the oracle."""
+    import hitl_slam_amd as H
+    prob = Problem(60, 90, ppf=60, groups=1)
+    opt = H.default_options()
+    opt.kd_tree_search = kd
+    sets = {}
+    for budget in (None, 7 * 59 * 90 * 2, 1):            # one tile / 7 poses per tile / one pose per tile
+        if budget is None:
+            monkeypatch.delenv("HITL_CAND_TILE_BYTES", raising=False)
+        else:
+            monkeypatch.setenv("HITL_CAND_TILE_BYTES", str(budget))
+        g = prob.load(H.Solver(opt))
+        for window in (0, 6):
+            g.find_correspondences(prob.init, window)
+            sets[(budget, window)] = g.get_correspondences()
+        pg, sg = g.solve(2, prob.init)
+        sets[(budget, "solve")] = (pg, sg.iterations, sg.final_cost)
+        g.close()
+    o = prob.load(_oracle(opt))
+    for window in (0, 6):
+        o.find_correspondences(prob.init, window, kd)
+        for budget in (None, 7 * 59 * 90 * 2, 1):
+            for a, b in zip(sets[(budget, window)], o.get_correspondences()):
+                assert np.array_equal(a, b)
+    for budget in (7 * 59 * 90 * 2, 1):
+        assert sets[(budget, "solve")][1] == sets[(None, "solve")][1] and sets[(budget, "solve")][2] == sets[(None, "solve")][2]
+        assert np.array_equal(sets[(budget, "solve")][0], sets[(None, "solve")][0])
