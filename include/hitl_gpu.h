@@ -222,7 +222,7 @@ int hitl_solver_evaluate_jacobian(hitl_solver*, const float* poses_xyt, double* 
 /* ---- the O(N*M) observation scans either side of the solve ----------
  * They run over the resident scans with the robot->world transform fused in, so the
  * WORLD_FRAME_point_clouds_ copies of the reference never have to exist.  fp32 like the
- * reference; results are bit-identical to the CPU restatement.  Single-GPU entry points.
+ * reference; results are bit-identical to the CPU restatement.  (Submap ranks: see the end of this comment.)
  * hitl_solver_transform_scans  == HitLSLAM::transformPointCloudsToWorldFrame (HitLSLAM.cpp:245-254):
  *     world_x/world_y receive n_obs values each (pose_transform * point).
  * hitl_solver_verify_points    == the scan of HitLSLAM::verifyUserInput (HitLSLAM.cpp:218-243):
