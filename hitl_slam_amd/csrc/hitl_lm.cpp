@@ -144,7 +144,7 @@ static inline double nan_max(double a, double b) { return (b > a || b != b) ? b 
 
 // local linearisation (every rank evaluates all factors touching its owned poses, so its rows are
 // complete) + the global cost and gradient max-norm
-static int run_linearize_dist(hitl_solver* s, const FactorView& fv, const double* xdev, int buf, LinResult* out) {
+int run_linearize_dist(hitl_solver* s, const FactorView& fv, const double* xdev, int buf, LinResult* out) {
   TRY(run_linearize(s, fv, xdev, buf, out));
   if (s->world == 1) return HITL_OK;
   const int W = s->world;

@@ -797,6 +797,29 @@ int hitl_solver_linearize(hitl_solver* s, int32_t mode, const float* poses_ref_x
 int hitl_solver_evaluate(hitl_solver* s, int32_t mode, const float* poses_xyt, double* cost, double* gradient) {
   TRY(check_ready(s, mode));
   if (!poses_xyt) return fail(HITL_ERR_INVALID_ARGUMENT, "evaluate: null pose array");
+  if (s->world > 1) {
+    // submap rank (collective: every rank calls it): poses_xyt is the GLOBAL array; cost is the global cost (every factor is
+    // counted by the rank owning it); gradient (3 * n_global doubles) receives this rank's OWNED rows, zeros elsewhere
+    if (mode == HITL_MODE_STF_ONLY) return fail(HITL_ERR_UNSUPPORTED, "submap ranks need the odometry chain (mode A or C)");
+    HIP_TRY(hipSetDevice(s->device));
+    const size_t n = (size_t)s->n, first = (size_t)(s->g_begin - s->hl);
+    std::vector<float> in(poses_xyt + 3 * first, poses_xyt + 3 * (first + n));
+    std::vector<double> xl(3 * n);
+    for (size_t t = 0; t < xl.size(); ++t) xl[t] = (double)in[t];
+    FactorView fv;
+    TRY(prepare(s, mode, in.data(), poses_xyt, &fv));
+    HIP_TRY(hipMemcpyAsync(s->x.p, xl.data(), sizeof(double) * xl.size(), hipMemcpyHostToDevice, s->stream));
+    LinResult lr;
+    TRY(run_linearize_dist(s, fv, s->x.p, 0, &lr));
+    if (cost) *cost = lr.cost;
+    if (gradient) {
+      std::memset(gradient, 0, sizeof(double) * 3 * (size_t)s->g_n);
+      const size_t own = (size_t)(s->own_hi - s->own_lo);
+      HIP_TRY(hipMemcpyAsync(gradient + 3 * (size_t)s->g_begin, s->gvec[0].p + 3 * (size_t)s->own_lo, sizeof(double) * 3 * own, hipMemcpyDeviceToHost, s->stream));
+      HIP_TRY(hipStreamSynchronize(s->stream));
+    }
+    return HITL_OK;
+  }
   std::vector<double> x((size_t)3 * s->n);
   for (size_t t = 0; t < x.size(); ++t) x[t] = (double)poses_xyt[t];
   return hitl_solver_linearize(s, mode, poses_xyt, x.data(), cost, gradient, nullptr, nullptr);

@@ -204,7 +204,9 @@ int hitl_solver_solve(hitl_solver*, int32_t mode, const float* poses_in_xyt,
 
 /* Replaces: problem.Evaluate(..., &residuals, &gradients_, ...) (JointOptimization.cpp:1247-1252).
  * cost = 1/2 |r|^2; gradient (3*n_poses, pose 0 entries are 0) may be NULL.  The odometry
- * measurements and human targets are re-derived from poses_xyt exactly as a solve would. */
+ * measurements and human targets are re-derived from poses_xyt exactly as a solve would.
+ * Submap ranks (collective: every rank calls it; mode A or C): poses_xyt is the GLOBAL array, cost the global cost (every
+ * factor is counted by the rank owning it), gradient (3 * n_global) receives the rank's OWNED rows and zeros elsewhere. */
 int hitl_solver_evaluate(hitl_solver*, int32_t mode, const float* poses_xyt,
                          double* cost, double* gradient);
 

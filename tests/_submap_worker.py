@@ -63,6 +63,7 @@ def main():
         s.close()
         dist.destroy_process_group()
         return
+    ecost, egrad = s.evaluate(mode, prob.init)        # collective: global cost, this rank's owned gradient rows
     poses, summ = s.solve(mode, prob.init)
     # observation scans on a submap rank: over its resident scans (global poses [lo, hi)), global pose array in
     wx, wy = s.transform_scans(prob.init)
@@ -81,6 +82,7 @@ def main():
                pairs=[corr[0][own].tolist(), corr[1][own].tolist()], n_matches=int(lens[own].sum()),
                scans=dict(lo=lo, hi=hi, wx=wx.tolist(), wy=wy.tolist(), probe=probe.tolist(), seen=seen.tolist(), seg=seg.tolist(),
                           counts=counts.tolist(), mask_sum=int(mask.sum())),
+               evaluate=dict(cost=ecost, grad=egrad.tolist()),
                fit=dict(clicks=clicks.numpy().tolist(), seg=fseg.tolist(), inliers=finl.tolist(), passes=fpas.tolist(), its=fits.tolist()))
     json.dump(res, open("%s.%d" % (out_path, rank), "w"))
     s.close()

@@ -84,6 +84,15 @@ def test_submaps_equal_the_global_solve(tmp_path, mode, ppf, world, moments, cut
         seen_by = np.nonzero(cnt.reshape(-1, 2)[:, 0] > 0)[0]
         cut = res[1]["begin"]
         assert seen_by.min() < cut <= seen_by.max()
+    # evaluate on the ranks (cost + gradient at the initial poses): the global cost on every rank, each rank's owned rows
+    oc, og, _, _ = o.linearize(mode, prob.init, prob.init.astype(np.float64))
+    for x in res:
+        ev = x["evaluate"]
+        assert abs(ev["cost"] - oc) <= 1e-11 * oc
+        gr = np.array(ev["grad"])
+        lo3, hi3 = 3 * x["begin"], 3 * x["end"]
+        assert np.abs(gr[lo3:hi3] - og[lo3:hi3]).max() <= 1e-9 * np.abs(og).max()
+        assert not gr[:lo3].any() and not gr[hi3:].any()
     po, so = o.solve(mode, prob.init)
     for x in res:
         sm = x["summary"]
