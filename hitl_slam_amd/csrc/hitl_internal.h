@@ -113,6 +113,8 @@ void launch_cr_solve_multi(hipStream_t st, const CrView& cr, double* w, double* 
 void launch_unit_rhs(hipStream_t st, int npad, double* w, size_t stride, const int* cols_dev, int ncols);
 void launch_iface_blocks(hipStream_t st, const double* Hband, int Wb, int Wi, int own_lo, int own_hi, bool has_lo, bool has_up,
                          double* Clo, double* Cup);
+void launch_cov_iface_correction(hipStream_t st, int own_lo, int own_hi, int Wb, int B, const double* Z, size_t stride, const double* T_dev,
+                                 int nc, double* Sd);
 void launch_gather_iface(hipStream_t st, const double* z0, const double* Z, size_t stride, const double* scale,
                          const int* cols_dev, int ncols, double* out /* ncols * (ncols + 2) */);
 void launch_combine(hipStream_t st, int npad, const double* z0, const double* Z, size_t stride, const double* coef_dev,

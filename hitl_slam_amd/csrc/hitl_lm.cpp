@@ -509,6 +509,88 @@ static int linear_solve_and_step_dist(hitl_solver* s, const FactorView& fv, int 
   return HITL_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// Pose covariances on submap ranks (collective).  With only rank g's right-hand side non-zero, the interface solve of
+// linear_solve_and_step_dist gives  x_g = M_g^-1 e - Z_g (B_g A^-1 P_g) Z_g^T e  (A: the interface matrix, P_g: rank g's
+// slot, B_g: the map from the interface unknowns to g's correction coefficients), i.e. the diagonal block of the global
+// inverse over g's poses is  M_g^-1 - Z_g T_g Z_g^T  with the nc x nc matrix T_g = B_g A^-1 P_g.  The caller has linearised
+// into buffer `buf` and Jacobi-scaled; this factorises (with the interface columns riding along), runs the local selected
+// inversion into Sd / So and subtracts the correction from the diagonal tiles.
+// ---------------------------------------------------------------------------------------
+int dist_cov_correction(hitl_solver* s, const FactorView& fv, int buf, double* Sd, double* So) {
+  hipStream_t st = s->stream;
+  const LinView lv = s->lin_view(buf);
+  const CrView cr = s->cr_view();
+  const int npad = s->npad, n = s->n, W = s->world, me = s->rank;
+  const int Wb = fv.band_poses, Wi = s->Wi, m = 3 * Wi, nc = 2 * m;
+  if (s->dist_pcg) return fail(HITL_ERR_UNSUPPORTED, "pose_covariances: pose pairs outside the band (raise max_band_poses)");
+  // J^T J itself (no trust-region diagonal); right-hand side 0 in slot 0, the interface unit vectors behind it
+  launch_build_system(st, n, Wb, lv, s->scale.p, s->fixed.p, INFINITY, s->opt.min_lm_diagonal, s->opt.max_lm_diagonal, cr, s->rhs.p, nullptr);
+  HIP_TRY(hipMemsetAsync(s->rhsN.p, 0, sizeof(double) * npad, st));
+  launch_unit_rhs(st, npad, s->rhsN.p + npad, (size_t)npad, s->if_cols.p, nc);
+  launch_cr_factor_solve(st, cr, s->rhsN.p, s->zN.p, 1 + nc, (size_t)npad);
+  launch_cr_selinv(st, cr, Sd, So);
+  const double* z0 = s->zN.p;
+  const double* Z = s->zN.p + npad;
+  const int RI = nc * (nc + 2), RC = m * m, R = RI + 2 * RC;
+  launch_gather_iface(st, z0, Z, (size_t)npad, s->scale.p, s->if_cols.p, nc, s->iface_dev.p);
+  launch_iface_blocks(st, lv.Hband, Wb, Wi, s->own_lo, s->own_hi, me > 0, me < W - 1, s->iface_dev.p + RI, s->iface_dev.p + RI + RC);
+  std::vector<double>&rec = s->if_rec, &all = s->if_all;
+  all.resize((size_t)R * W);
+  TRY(comm_allgather_dev(s, s->iface_dev.p, all.data(), (int64_t)sizeof(double) * R, rec));
+  auto Z_of = [&](int g) { return &all[(size_t)R * g + nc]; };
+  auto sc_of = [&](int g) { return &all[(size_t)R * g + nc + nc * nc]; };
+  auto Clo_of = [&](int g) { return &all[(size_t)R * g + RI]; };
+  auto Cup_of = [&](int g) { return &all[(size_t)R * g + RI + RC]; };
+  const int NI = nc * W;
+  std::vector<double> A((size_t)NI * NI, 0.0), Ct((size_t)m * m), X((size_t)NI * nc, 0.0);
+  for (int g = 0; g < W; ++g) {                       // the interface matrix of linear_solve_and_step_dist
+    for (int r = 0; r < nc; ++r) A[(size_t)(nc * g + r) * NI + nc * g + r] = 1.0;
+    if (g >= 1) {
+      for (int a = 0; a < m; ++a) for (int k = 0; k < m; ++k) Ct[(size_t)a * m + k] = sc_of(g)[a] * Clo_of(g)[(size_t)a * m + k] * sc_of(g - 1)[m + k];
+      for (int r = 0; r < nc; ++r)
+        for (int k = 0; k < m; ++k) {
+          double v = 0.0;
+          for (int c = 0; c < m; ++c) v += Z_of(g)[(size_t)nc * c + r] * Ct[(size_t)c * m + k];
+          A[(size_t)(nc * g + r) * NI + nc * (g - 1) + m + k] += v;
+        }
+    }
+    if (g + 1 < W) {
+      for (int a = 0; a < m; ++a) for (int k = 0; k < m; ++k) Ct[(size_t)a * m + k] = sc_of(g)[m + a] * Cup_of(g)[(size_t)a * m + k] * sc_of(g + 1)[k];
+      for (int r = 0; r < nc; ++r)
+        for (int k = 0; k < m; ++k) {
+          double v = 0.0;
+          for (int c = 0; c < m; ++c) v += Z_of(g)[(size_t)nc * (m + c) + r] * Ct[(size_t)c * m + k];
+          A[(size_t)(nc * g + r) * NI + nc * (g + 1) + k] += v;
+        }
+    }
+  }
+  // X = A^-1 P_me (NI x nc), one column at a time on a copy of A (NI is a few dozen)
+  std::vector<double> T((size_t)nc * nc, 0.0), Acopy, y;
+  for (int c = 0; c < nc; ++c) {
+    Acopy = A;
+    y.assign(NI, 0.0);
+    y[nc * me + c] = 1.0;
+    if (!solve_dense(NI, Acopy, y)) return fail(HITL_ERR_SOLVER_FAILURE, "pose_covariances: the interface system is singular");
+    // this rank's correction coefficients for that right-hand side = column c of T
+    if (me >= 1) {
+      const double* vprev = &y[nc * (me - 1) + m];
+      for (int a = 0; a < m; ++a)
+        for (int k = 0; k < m; ++k) T[(size_t)a * nc + c] += sc_of(me)[a] * Clo_of(me)[(size_t)a * m + k] * sc_of(me - 1)[m + k] * vprev[k];
+    }
+    if (me + 1 < W) {
+      const double* unext = &y[nc * (me + 1)];
+      for (int a = 0; a < m; ++a)
+        for (int k = 0; k < m; ++k) T[(size_t)(m + a) * nc + c] += sc_of(me)[m + a] * Cup_of(me)[(size_t)a * m + k] * sc_of(me + 1)[k] * unext[k];
+    }
+  }
+  DevArray<double> d_T;
+  TRY(d_T.upload(T, st));
+  launch_cov_iface_correction(st, s->own_lo, s->own_hi, Wb, cr.B, Z, (size_t)npad, d_T.p, nc, Sd);
+  HIP_TRY(hipStreamSynchronize(st));
+  return HITL_OK;
+}
+
 static double now_ms() {
   using namespace std::chrono;
   return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();

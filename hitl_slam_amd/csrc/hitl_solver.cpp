@@ -865,7 +865,40 @@ int hitl_solver_evaluate_jacobian(hitl_solver* s, const float* poses_xyt, double
 int hitl_solver_pose_covariances(hitl_solver* s, int32_t mode, const float* poses_xyt, double* cov9) {
   TRY(check_ready(s, mode));
   if (!poses_xyt || !cov9) return fail(HITL_ERR_INVALID_ARGUMENT, "pose_covariances: null argument");
-  if (s->world > 1) return fail(HITL_ERR_UNSUPPORTED, "pose_covariances is a single-GPU entry point");
+  if (s->world > 1) {
+    // submap rank (collective; mode A or C): poses_xyt is the GLOBAL array, cov9 (9 * n_global) receives the blocks of the
+    // rank's OWNED poses (zeros elsewhere): the blocks of the GLOBAL inverse, hitl_lm.cpp dist_cov_correction
+    if (mode == HITL_MODE_STF_ONLY) return fail(HITL_ERR_UNSUPPORTED, "submap ranks need the odometry chain (mode A or C)");
+    HIP_TRY(hipSetDevice(s->device));
+    const size_t nl = (size_t)s->n, first = (size_t)(s->g_begin - s->hl);
+    std::vector<float> in(poses_xyt + 3 * first, poses_xyt + 3 * (first + nl));
+    FactorView fvd;
+    TRY(prepare(s, mode, in.data(), poses_xyt, &fvd));
+    hipStream_t sd = s->stream;
+    std::vector<double> hx((size_t)s->npad, 0.0);
+    for (size_t t = 0; t < 3 * nl; ++t) hx[t] = (double)in[t];
+    HIP_TRY(hipMemcpyAsync(s->x.p, hx.data(), sizeof(double) * s->npad, hipMemcpyHostToDevice, sd));
+    LinResult lrd;
+    TRY(run_linearize(s, fvd, s->x.p, 0, &lrd));
+    launch_jacobi_scale(sd, s->n, s->npad, fvd.band_poses, s->Hband[0].p, s->opt.jacobi_scaling, s->fixed.p, s->scale.p);
+    const CrView crd = s->cr_view();
+    DevArray<double> Sd, So, d_out;
+    DevArray<float2> d_rot;
+    std::vector<float2> rot(nl);
+    for (size_t i = 0; i < nl; ++i) { const float a = -in[3 * i + 2]; rot[i] = make_float2(cosf(a), sinf(a)); }
+    TRY(Sd.resize((size_t)crd.nsb * crd.B * crd.B)); TRY(So.resize((size_t)crd.nsb * crd.B * crd.B)); TRY(d_out.resize(9 * nl));
+    TRY(d_rot.upload(rot, sd));
+    TRY(dist_cov_correction(s, fvd, 0, Sd.p, So.p));
+    // halo poses are constant locally: the extraction treats them like pose 0 (zero block); only the owned range goes out
+    launch_cov_extract(sd, s->n, fvd.band_poses, crd.B, Sd.p, s->scale.p, s->fixed.p, d_rot.p, d_out.p);
+    std::memset(cov9, 0, sizeof(double) * 9 * (size_t)s->g_n);
+    const size_t own = (size_t)(s->own_hi - s->own_lo);
+    HIP_TRY(hipMemcpyAsync(cov9 + 9 * (size_t)s->g_begin, d_out.p + 9 * (size_t)s->own_lo, sizeof(double) * 9 * own, hipMemcpyDeviceToHost, sd));
+    HIP_TRY(hipStreamSynchronize(sd));
+    for (size_t t = 9 * (size_t)s->g_begin; t < 9 * ((size_t)s->g_begin + own); ++t)
+      if (!(cov9[t] == cov9[t])) return fail(HITL_ERR_SOLVER_FAILURE, "pose_covariances: J^T J is singular at these poses");
+    return HITL_OK;
+  }
   FactorView fv;
   TRY(prepare(s, mode, poses_xyt, poses_xyt, &fv));
   if (fv.n_offband > 0) return fail(HITL_ERR_UNSUPPORTED, "pose_covariances: pose pairs outside the band (raise max_band_poses)");

@@ -158,6 +158,7 @@ int check_ready(hitl_solver* s, int mode);
 int prepare(hitl_solver* s, int mode, const float* poses_ref, const float* poses_global, FactorView* fv);
 // hitl_lm.cpp
 int run_linearize(hitl_solver* s, const FactorView& fv, const double* xdev, int buf, LinResult* out);
+int dist_cov_correction(hitl_solver* s, const FactorView& fv, int buf, double* Sd, double* So);   // submap ranks: global-inverse correction of the selected inversion
 int run_linearize_dist(hitl_solver* s, const FactorView& fv, const double* xdev, int buf, LinResult* out);   // cost / |g|max summed over the ranks
 int comm_allgather(hitl_solver* s, const void* send, void* recv, int64_t bytes);
 int comm_allgather_dev(hitl_solver* s, const void* send_dev, void* recv_host, int64_t bytes, std::vector<double>& stage);   // send record in device memory

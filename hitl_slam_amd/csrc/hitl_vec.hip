@@ -274,6 +274,37 @@ void launch_iface_blocks(hipStream_t st, const double* Hband, int Wb, int Wi, in
   hipLaunchKernelGGL(k_iface_blocks, dim3(1), dim3(256), 0, st, Hband, Wb, Wi, own_lo, own_hi, has_lo ? 1 : 0, has_up ? 1 : 0, Clo, Cup);
 }
 
+// Pose covariances on a submap rank: the diagonal blocks of the GLOBAL inverse are those of the rank's own inverse minus
+// a rank-2m correction through its interface columns,  Sigma_ii = (M^-1)_ii - Z_i T Z_i^T  (Z_i: the three rows of pose i of
+// Z = M^-1 [E_F, E_L], T: nc x nc from the interface system, hitl_lm.cpp).  One thread per owned pose; Sd holds the B x B
+// tiles of the selected inversion, pose i sits at rows / columns 3 (i mod Wb) of tile i / Wb.
+__global__ void k_cov_iface_correction(int own_lo, int own_hi, int Wb, int B, const double* __restrict__ Z, size_t stride,
+                                       const double* __restrict__ T, int nc, double* __restrict__ Sd) {
+  const int i = own_lo + blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= own_hi) return;
+  double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int c = 0; c < nc; ++c) {
+    double t[3] = {0, 0, 0};                                  // (Z_i T)[:, c]
+    for (int a = 0; a < nc; ++a) {
+      const double tac = T[(size_t)a * nc + c];
+      for (int r = 0; r < 3; ++r) t[r] += Z[stride * a + 3 * i + r] * tac;
+    }
+    for (int r = 0; r < 3; ++r)
+      for (int q = 0; q < 3; ++q) acc[r * 3 + q] += t[r] * Z[stride * c + 3 * i + q];
+  }
+  double* tile = Sd + (size_t)(i / Wb) * B * B;
+  const int o = 3 * (i % Wb);
+  for (int r = 0; r < 3; ++r)
+    for (int q = 0; q < 3; ++q) tile[(o + r) * B + o + q] -= acc[r * 3 + q];
+}
+
+void launch_cov_iface_correction(hipStream_t st, int own_lo, int own_hi, int Wb, int B, const double* Z, size_t stride, const double* T_dev,
+                                 int nc, double* Sd) {
+  const int cnt = own_hi - own_lo;
+  if (cnt <= 0) return;
+  hipLaunchKernelGGL(k_cov_iface_correction, dim3((cnt + 127) / 128), dim3(128), 0, st, own_lo, own_hi, Wb, B, Z, stride, T_dev, nc, Sd);
+}
+
 // dt = z0 - sum_k coef[k] * Z[k]   (Z: ncols columns, `stride` apart; coef in device memory)
 __global__ void k_combine(int npad, const double* __restrict__ z0, const double* __restrict__ Z, size_t stride,
                           const double* __restrict__ coef, int ncols, double* __restrict__ dt) {

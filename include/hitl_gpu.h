@@ -281,7 +281,10 @@ int hitl_normalize_angles(int64_t n_poses, float* poses_xyt);
  * poses_xyt (constant poses removed, no trust-region diagonal), rotated into the robot frame with
  * transform = blockdiag(Rotation2Df(-angle), 1).  cov9 = n_poses*9 doubles, row-major; zeros for constant poses
  * (the reference never writes pose min_poses).  Computed from the cyclic-reduction factors by selected inversion --
- * no dense inverse, no SVD.  Needs every pose pair inside the band.  Single-GPU entry point. */
+ * no dense inverse, no SVD.  Needs every pose pair inside the band.
+ * Submap ranks (collective; mode A or C): poses_xyt is the GLOBAL array, cov9 (9 * n_global) receives the blocks of the rank's
+ * OWNED poses (zeros elsewhere) -- blocks of the GLOBAL inverse: the rank's own selected inversion minus a low-rank correction
+ * through its interface columns, with one all-gather of the interface record. */
 int hitl_solver_pose_covariances(hitl_solver*, int32_t mode, const float* poses_xyt, double* cov9);
 
 /* Debug / parity: linearise at double-precision poses x (3*n_poses) with the odometry

@@ -64,6 +64,7 @@ def main():
         dist.destroy_process_group()
         return
     ecost, egrad = s.evaluate(mode, prob.init)        # collective: global cost, this rank's owned gradient rows
+    cov = s.pose_covariances(mode, prob.init) if window <= 4 and "HITL_TEST_BAND" not in os.environ else None   # collective; needs every pair inside the band
     poses, summ = s.solve(mode, prob.init)
     # observation scans on a submap rank: over its resident scans (global poses [lo, hi)), global pose array in
     wx, wy = s.transform_scans(prob.init)
@@ -82,7 +83,7 @@ def main():
                pairs=[corr[0][own].tolist(), corr[1][own].tolist()], n_matches=int(lens[own].sum()),
                scans=dict(lo=lo, hi=hi, wx=wx.tolist(), wy=wy.tolist(), probe=probe.tolist(), seen=seen.tolist(), seg=seg.tolist(),
                           counts=counts.tolist(), mask_sum=int(mask.sum())),
-               evaluate=dict(cost=ecost, grad=egrad.tolist()),
+               evaluate=dict(cost=ecost, grad=egrad.tolist()), cov=(cov.tolist() if cov is not None else None),
                fit=dict(clicks=clicks.numpy().tolist(), seg=fseg.tolist(), inliers=finl.tolist(), passes=fpas.tolist(), its=fits.tolist()))
     json.dump(res, open("%s.%d" % (out_path, rank), "w"))
     s.close()

@@ -93,6 +93,15 @@ def test_submaps_equal_the_global_solve(tmp_path, mode, ppf, world, moments, cut
         lo3, hi3 = 3 * x["begin"], 3 * x["end"]
         assert np.abs(gr[lo3:hi3] - og[lo3:hi3]).max() <= 1e-9 * np.abs(og).max()
         assert not gr[:lo3].any() and not gr[hi3:].any()
+    # pose covariances on the ranks: the 3x3 blocks of the GLOBAL inverse over each rank's owned poses (the rank's own
+    # selected inversion minus the rank-2m correction through its interface columns) == the oracle's dense inverse
+    So = o.pose_covariances(mode, prob.init)
+    for x in res:
+        Sg = np.array(x["cov"])
+        b, e = x["begin"], x["end"]
+        scale = np.abs(So[b:e]).max(axis=(1, 2))[:, None, None] + 1e-300
+        assert (np.abs(Sg[b:e] - So[b:e]) / scale).max() < 1e-6, (np.abs(Sg[b:e] - So[b:e]) / scale).max()
+        assert not Sg[:b].any() and not Sg[e:].any()
     po, so = o.solve(mode, prob.init)
     for x in res:
         sm = x["summary"]
