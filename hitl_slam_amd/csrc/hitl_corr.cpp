@@ -282,3 +282,5 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
 }
 
 }  // namespace hitl
+
+extern "C" int hitl_libm_sincos_exact(void) { return hitl::libm_sincos_exact() ? 1 : 0; }

@@ -399,6 +399,10 @@ int hitl_device_memory(int32_t device, int64_t* free_bytes, int64_t* total_bytes
 const char* hitl_status_string(int status);
 const char* hitl_last_error(void);       /* thread-local detail of the last failure      */
 int hitl_abi_version(void);
+/* Host check behind the correspondence search's trigonometry: 1 if sincosf(x) == (sinf(x), cosf(x)) and sinf(-x) == -sinf(x),
+ * cosf(-x) == cosf(x) hold bit for bit on a 200 000-value sample of this C library (glibc: exhaustively true); 0 makes the
+ * search fall back to one cosf and one sinf per candidate.  No GPU involved. */
+int hitl_libm_sincos_exact(void);
 
 #ifdef __cplusplus
 }

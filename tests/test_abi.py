@@ -103,3 +103,26 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "hitl_oracle" not in txt and "orc_" not in txt, "%s references the oracle" % f
+
+
+def test_libm_pairing_assumption_holds_on_this_host(lib):
+    """The correspondence search computes one sincosf per candidate PAIR (hitl_corr.cpp): that is exact only if sincosf agrees
+    with sinf / cosf and the odd / even symmetry holds bit for bit in the C library at hand.  The library checks a sample at
+    first use (and falls back otherwise); this asserts the fast path is the one in use here, and repeats the check in numpy
+    terms through ctypes' libm on a different sample."""
+    import ctypes.util
+    assert lib.hitl_libm_sincos_exact() == 1
+    m = C.CDLL(ctypes.util.find_library("m"))
+    for f in (m.sinf, m.cosf):
+        f.restype = C.c_float
+        f.argtypes = [C.c_float]
+    m.sincosf.restype = None
+    m.sincosf.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    rng = np.random.default_rng(3)
+    xs = np.concatenate([rng.uniform(-7.0, 7.0, 4000), rng.uniform(-1e-3, 1e-3, 500), [0.0, -0.0, np.pi, -np.pi, 1e9]]).astype(np.float32)
+    for x in xs:
+        s, c = C.c_float(), C.c_float()
+        m.sincosf(float(x), C.byref(s), C.byref(c))
+        s1, c1, s2, c2 = m.sinf(float(x)), m.cosf(float(x)), m.sinf(float(-x)), m.cosf(float(-x))
+        assert np.float32(s.value).tobytes() == np.float32(s1).tobytes() and np.float32(c.value).tobytes() == np.float32(c1).tobytes()
+        assert np.float32(s2).tobytes() == np.float32(-np.float32(s1)).tobytes() and np.float32(c2).tobytes() == np.float32(c1).tobytes()
