@@ -122,7 +122,7 @@ void launch_combine(hipStream_t st, int npad, const double* z0, const double* Z,
 void launch_scatter_halo(hipStream_t st, int cnt, const int* idx, const double* val, const double* sc, double* dt,
                          double* scale);
 void launch_halo_candidate(hipStream_t st, int cnt, const int* idx, const double* x, const double* scale, const double* dt,
-                           double* xc);
+                           double* xc, double2* cs = nullptr /* (cos, sin) of the halo poses' candidate theta */);
 // factorise and solve M x = w in one pass (w is destroyed)
 void launch_cr_factor_solve(hipStream_t st, const CrView& cr, double* w, double* x, int nrhs = 1, size_t stride = 0);
 // x = M^{-1} w   (w is destroyed)
@@ -147,7 +147,7 @@ void launch_spmv_residual_step(hipStream_t st, int n_poses, int npad, const Fact
                                double* partials, double2* cs = nullptr);   // cs: also (cos, sin) of the candidate's angles
 void launch_spmv_step(hipStream_t st, int n_poses, int npad, const FactorView& fv, const LinView& lin,
                       const double* scale, const double* dt, const double* rhs, const double* x, double* q, double* xc,
-                      double* partials);
+                      double* partials, double2* cs = nullptr /* (cos, sin) of the candidate's theta per pose: saves k_pose_trig */);
 // out[k] = a_k . b_k for k < ndots (<= 4)
 void launch_dots(hipStream_t st, int n, int ndots, const double* const* a, const double* const* b, double* out);
 // PCG updates with device-resident scalars s[] = (r.z, previous r.z, p.q, r.r, breakdown flag)

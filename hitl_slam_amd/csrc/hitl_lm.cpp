@@ -473,21 +473,21 @@ static int linear_solve_and_step_dist(hitl_solver* s, const FactorView& fv, int 
     for (int k = 0; k < m; ++k) { hval.push_back(unext[k]); hsc.push_back(sc_of(me + 1)[k]); }
   }
   nh = (int)hval.size();
-  HIP_TRY(hipMemcpyAsync(s->coef_dev.p, coef.data(), sizeof(double) * nc, hipMemcpyHostToDevice, st));
-  if (nh) {
-    HIP_TRY(hipMemcpyAsync(s->halo_val.p, hval.data(), sizeof(double) * nh, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(s->halo_sc.p, hsc.data(), sizeof(double) * nh, hipMemcpyHostToDevice, st));
-  }
+  coef.resize((size_t)3 * nc, 0.0);                      // one upload: coefficients | halo steps | halo scales
+  std::copy(hval.begin(), hval.end(), coef.begin() + nc);
+  std::copy(hsc.begin(), hsc.end(), coef.begin() + 2 * nc);
+  HIP_TRY(hipMemcpyAsync(s->coef_dev.p, coef.data(), sizeof(double) * 3 * nc, hipMemcpyHostToDevice, st));
   launch_combine(st, npad, z0, Z, (size_t)npad, s->coef_dev.p, nc, s->dt.p);
-  launch_scatter_halo(st, nh, s->halo_idx.p, s->halo_val.p, s->halo_sc.p, s->dt.p, s->scale.p);
+  launch_scatter_halo(st, nh, s->halo_idx.p, s->coef_dev.p + nc, s->coef_dev.p + 2 * nc, s->dt.p, s->scale.p);
   }
   // model-cost pieces over the owned rows (halo columns carry the neighbours' steps), candidate state
-  launch_spmv_step(st, n, npad, fv, lv, s->scale.p, s->dt.p, s->rhs.p, xcur, s->qv.p, xcand, s->step_partials.p);
-  launch_halo_candidate(st, nh, s->halo_idx.p, xcur, s->scale.p, s->dt.p, xcand);
+  double2* cs_out = fv.with_stf ? s->pose_cs.p : nullptr;      // the trig table of the candidate, written by the two kernels that form it
+  launch_spmv_step(st, n, npad, fv, lv, s->scale.p, s->dt.p, s->rhs.p, xcur, s->qv.p, xcand, s->step_partials.p, cs_out);
+  launch_halo_candidate(st, nh, s->halo_idx.p, xcur, s->scale.p, s->dt.p, xcand, cs_out);
   HIP_TRY(hipGetLastError());
   // The candidate does not depend on any host decision, so its linearisation is queued right here and its two scalars
   // ride in the same all-gather as the step scalars (exchanges 3 and 1 merged: 7 doubles per rank).
-  if (spec) TRY(enqueue_linearize(s, fv, xcand, buf ^ 1));
+  if (spec) TRY(enqueue_linearize(s, fv, xcand, buf ^ 1, /*direct=*/false, /*have_trig=*/true));
   TRY(enqueue_step_partials(s));
   TRY(spin_sync(s));                     // host vectors above stay alive until here
   StepScalars loc;

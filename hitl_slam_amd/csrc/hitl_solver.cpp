@@ -384,7 +384,7 @@ int prepare(hitl_solver* s, int mode, const float* poses_ref, const float* poses
     TRY(s->halo_idx.upload(hidx, s->stream));
     TRY(s->iface_dev.resize((size_t)nc * (nc + 2) + 2 * (size_t)(nc / 2) * (nc / 2)));   // interface rows + the two cross-cut blocks
     TRY(s->rhsN.resize((size_t)(1 + nc) * s->npad)); TRY(s->zN.resize((size_t)(1 + nc) * s->npad));
-    TRY(s->coef_dev.resize(nc)); TRY(s->halo_val.resize(nc)); TRY(s->halo_sc.resize(nc));
+    TRY(s->coef_dev.resize((size_t)3 * nc));      // coefficients | halo steps | halo scales: one upload per LM iteration
     HIP_TRY(hipStreamSynchronize(s->stream));
   }
   *fv = factor_view(s, mode, Wb);

@@ -24,7 +24,7 @@ struct SpmvAux {
   const double* x;     // MODE 2
   double* xc;          // MODE 2
   double* partials;    // MODE 1, 2 : [gridDim.x][8]
-  double2* cs;         // MODE 3 (may be null): (cos, sin) of the candidate's theta, saves the k_pose_trig launch in front of k_linearize_stf
+  double2* cs;         // MODE 2, 3 (may be null): (cos, sin) of the candidate's theta, saves the k_pose_trig launch in front of k_linearize_stf
   int all_cols;        // MODE 0: columns of constant poses take part too (distributed PCG: the halo entries of v carry the
                        // neighbouring submaps' values; global pose 0 carries an exact 0)
 };
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(128) void k_spmv(int n_poses, int npad, FactorView 
             y[t] = v[t];
             if (i < n_poses) {
               aux.xc[t] = aux.x[t];
-              if (MODE == 3 && c == 2 && aux.cs != nullptr) { double sn, cn; sincos(aux.x[t], &sn, &cn); aux.cs[i] = make_double2(cn, sn); }
+              if (kStep && c == 2 && aux.cs != nullptr) { double sn, cn; sincos(aux.x[t], &sn, &cn); aux.cs[i] = make_double2(cn, sn); }
             }
           }
         }
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(128) void k_spmv(int n_poses, int npad, FactorView 
           part[o + 1] += vt * rq;
           part[o + 2] += dl * dl; part[o + 3] += xt * xt;
           aux.xc[t] = xt + dl;
-          if (MODE == 3 && a == 2 && aux.cs != nullptr) { double sn, cn; sincos(xt + dl, &sn, &cn); aux.cs[i] = make_double2(cn, sn); }
+          if (kStep && a == 2 && aux.cs != nullptr) { double sn, cn; sincos(xt + dl, &sn, &cn); aux.cs[i] = make_double2(cn, sn); }
           if (!isfinite(vt)) part[o + 4] += 1.0;
         }
       }
@@ -208,8 +208,8 @@ void launch_spmv_residual_step(hipStream_t st, int n_poses, int npad, const Fact
 
 void launch_spmv_step(hipStream_t st, int n_poses, int npad, const FactorView& fv, const LinView& lin,
                       const double* scale, const double* dt, const double* rhs, const double* x, double* q, double* xc,
-                      double* partials) {
-  SpmvAux aux = {rhs, nullptr, x, xc, partials, nullptr, 0};
+                      double* partials, double2* cs) {
+  SpmvAux aux = {rhs, nullptr, x, xc, partials, cs, 0};
   spmv_offband(st, n_poses, fv, lin, scale, dt, true);
   hipLaunchKernelGGL(k_spmv<2>, dim3(spmv_blocks(npad)), dim3(128), 0, st, n_poses, npad, fv, lin, scale, 0.0, 0.0, 0.0, dt,
                      q, aux);
@@ -362,17 +362,19 @@ void launch_scatter_idx(hipStream_t st, int cnt, const int* idx, const double* v
 
 // candidate state of the halo poses: xc = x + scale * dt  (k_spmv<2> leaves xc = x on constant poses)
 __global__ void k_halo_candidate(int cnt, const int* __restrict__ idx, const double* __restrict__ x,
-                                 const double* __restrict__ scale, const double* __restrict__ dt, double* __restrict__ xc) {
+                                 const double* __restrict__ scale, const double* __restrict__ dt, double* __restrict__ xc, double2* __restrict__ cs) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= cnt) return;
   const int t = idx[k];
-  xc[t] = x[t] + scale[t] * dt[t];
+  const double v = x[t] + scale[t] * dt[t];
+  xc[t] = v;
+  if (cs != nullptr && t % 3 == 2) { double sn, cn; sincos(v, &sn, &cn); cs[t / 3] = make_double2(cn, sn); }   // the pose's theta: trig table of the candidate
 }
 
 void launch_halo_candidate(hipStream_t st, int cnt, const int* idx, const double* x, const double* scale, const double* dt,
-                           double* xc) {
+                           double* xc, double2* cs) {
   if (cnt <= 0) return;
-  hipLaunchKernelGGL(k_halo_candidate, dim3((cnt + 63) / 64), dim3(64), 0, st, cnt, idx, x, scale, dt, xc);
+  hipLaunchKernelGGL(k_halo_candidate, dim3((cnt + 63) / 64), dim3(64), 0, st, cnt, idx, x, scale, dt, xc, cs);
 }
 
 struct DotArgs { const double* a[4]; const double* b[4]; };
