@@ -482,13 +482,12 @@ static int linear_solve_and_step_dist(hitl_solver* s, const FactorView& fv, int 
   }
   // model-cost pieces over the owned rows (halo columns carry the neighbours' steps), candidate state
   double2* cs_out = fv.with_stf ? s->pose_cs.p : nullptr;      // the trig table of the candidate, written by the two kernels that form it
-  launch_spmv_step(st, n, npad, fv, lv, s->scale.p, s->dt.p, s->rhs.p, xcur, s->qv.p, xcand, s->step_partials.p, cs_out);
+  launch_spmv_step(st, n, npad, fv, lv, s->scale.p, s->dt.p, s->rhs.p, xcur, s->qv.p, xcand, s->h_partials, cs_out);   // partials straight into pinned host memory
   launch_halo_candidate(st, nh, s->halo_idx.p, xcur, s->scale.p, s->dt.p, xcand, cs_out);
   HIP_TRY(hipGetLastError());
   // The candidate does not depend on any host decision, so its linearisation is queued right here and its two scalars
   // ride in the same all-gather as the step scalars (exchanges 3 and 1 merged: 7 doubles per rank).
-  if (spec) TRY(enqueue_linearize(s, fv, xcand, buf ^ 1, /*direct=*/false, /*have_trig=*/true));
-  TRY(enqueue_step_partials(s));
+  if (spec) TRY(enqueue_linearize(s, fv, xcand, buf ^ 1, /*direct=*/true, /*have_trig=*/true));
   TRY(spin_sync(s));                     // host vectors above stay alive until here
   StepScalars loc;
   TRY(finish_step_partials(s, nullptr, nullptr, &loc));
