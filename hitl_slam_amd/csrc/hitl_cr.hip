@@ -117,7 +117,7 @@ void launch_build_system(hipStream_t st, int n_poses, int Wb, const LinView& lin
                          const unsigned char* fixed, double mu, double min_diag, double max_diag, const CrView& cr,
                          double* rhs, double* rhs_work) {
   const int tot = cr.nsb * cr.B * cr.B;
-  const CrSource sc = {lin.Hband, lin.g, scale, fixed, mu, min_diag, max_diag, n_poses, Wb, rhs};
+  const CrSource sc = {lin.Hband, lin.g, scale, fixed, mu, min_diag, max_diag, n_poses, Wb, rhs, nullptr, 0};
   hipLaunchKernelGGL(k_build_system, dim3((tot + 255) / 256), dim3(256), 0, st, sc, cr, rhs_work);
 }
 
@@ -769,8 +769,12 @@ __global__ __launch_bounds__(B >= 12 ? 512 : 1024) void k_cr_chunk(CrView cr, Cr
       const int64_t sn = base + u;
       const size_t g = sg.wstride * rv + (size_t)(sn * S) * B + q;
       double v;
-      if (from_src) { v = cr_source_rhs(src, (int)sn, q); w[g] = v; src.rhs[g] = v; }    // one right-hand side: -S g, kept for the back-substitution and the caller
-      else v = w[g];
+      if (from_src) {
+        // right-hand side 0: -S g, kept for the back-substitution and the caller; the others: unit vectors (submap interface columns)
+        if (rv == 0) { v = cr_source_rhs(src, (int)sn, q); src.rhs[(size_t)(sn * S) * B + q] = v; }
+        else v = ((int)(sn * S) * B + q == src.unit_cols[rv - 1]) ? 1.0 : 0.0;
+        w[g] = v;
+      } else v = w[g];
       if (sg.has_prev) v = (v - WLp[pws * rv + (size_t)sn * B + q]) - WRp[pws * rv + (size_t)sn * B + q];
       sW[((size_t)rv * nsl + u) * B + q] = v;
       if (sg.has_prev && (u == 0 || u == M) == false) w[g] = v;          // interior: the back-substitution reads the folded w
@@ -1151,7 +1155,7 @@ template <int B>
 static bool cr_factor_fused(hipStream_t st, const CrView& cr, double* w, double* x, int nrhs, size_t wstride, const CrSource* src = nullptr) {
   if (cr.P == nullptr || cr.Pw == nullptr) return false;
   if (w == nullptr) nrhs = 0;
-  if (src != nullptr && (nrhs != 1 || x == nullptr)) return false;
+  if (src != nullptr && (x == nullptr || nrhs != 1 + src->n_unit)) return false;
   if (nrhs > cr.pw_rhs) return false;                     // contribution arrays are sized for cr.pw_rhs right-hand sides
   static bool raised = false;
   if (!raised) {
@@ -1291,6 +1295,25 @@ void launch_cr_factor_solve(hipStream_t st, const CrView& cr, double* w, double*
     case 9: cr_factor_t<9>(st, cr, w, x, nrhs, stride); break;
     default: cr_factor_t<12>(st, cr, w, x, nrhs, stride); break;
   }
+}
+
+void launch_cr_build_factor_solve_multi(hipStream_t st, const CrView& cr, const CrSource& src, double* w, double* x, size_t stride) {
+  static const bool legacy = std::getenv("HITL_CR_LEGACY") != nullptr || std::getenv("HITL_CR_UNFUSED_BUILD") != nullptr;
+  const int nrhs = 1 + src.n_unit;
+  bool done = false;
+  if (!legacy) {
+    switch (cr.B) {
+      case 3: done = cr_factor_fused<3>(st, cr, w, x, nrhs, stride, &src); break;
+      case 6: done = cr_factor_fused<6>(st, cr, w, x, nrhs, stride, &src); break;
+      case 9: done = cr_factor_fused<9>(st, cr, w, x, nrhs, stride, &src); break;
+      default: done = cr_factor_fused<12>(st, cr, w, x, nrhs, stride, &src); break;
+    }
+  }
+  if (done) return;
+  const int tot = cr.nsb * cr.B * cr.B;
+  hipLaunchKernelGGL(k_build_system, dim3((tot + 255) / 256), dim3(256), 0, st, src, cr, w);
+  launch_unit_rhs(st, cr.nsb * cr.B, w + stride, stride, src.unit_cols, src.n_unit);
+  launch_cr_factor_solve(st, cr, w, x, nrhs, stride);
 }
 
 void launch_cr_build_factor_solve(hipStream_t st, const CrView& cr, const CrSource& src, double* w, double* x) {

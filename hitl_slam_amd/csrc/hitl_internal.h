@@ -71,6 +71,8 @@ struct CrSource {           // where the first cyclic-reduction stage can take i
   double mu, min_diag, max_diag;
   int n_poses, Wb;
   double* rhs;                // receives the scaled right-hand side -S g (the copy the residual check and the step bookkeeping read)
+  const int* unit_cols;       // right-hand sides 1 .. n_unit are unit vectors e_{unit_cols[k]} (the interface columns of a submap rank)
+  int n_unit;
 };
 
 struct CrView {             // block-tridiagonal system + cyclic-reduction factors
@@ -129,6 +131,8 @@ void launch_cr_factor_solve(hipStream_t st, const CrView& cr, double* w, double*
 // build_system + factor + solve with the first stage reading the band blocks itself (no D / L round trip through memory);
 // falls back to launch_build_system + launch_cr_factor_solve where the fused stages do not apply
 void launch_cr_build_factor_solve(hipStream_t st, const CrView& cr, const CrSource& src, double* w, double* x);
+// the same with src.n_unit unit right-hand sides behind the first one (w, x: 1 + n_unit vectors `stride` apart)
+void launch_cr_build_factor_solve_multi(hipStream_t st, const CrView& cr, const CrSource& src, double* w, double* x, size_t stride);
 void launch_cr_solve(hipStream_t st, const CrView& cr, const double* rhs, double* w, double* x);   // x = M^-1 rhs; w = work vector (may be rhs itself: overwritten)
 // y = (S H S [+ D^2]) v ; damping added when mu > 0
 void launch_spmv(hipStream_t st, int n_poses, int npad, const FactorView& fv, const LinView& lin,

@@ -296,7 +296,7 @@ static int enqueue_linear_solve_banded(hitl_solver* s, const FactorView& fv, int
   const CrView cr = s->cr_view();
   const double mind = s->opt.min_lm_diagonal, maxd = s->opt.max_lm_diagonal;
   const int npad = s->npad;
-  const CrSource src = {lv.Hband, lv.g, s->scale.p, s->fixed.p, mu, mind, maxd, s->n, fv.band_poses, s->rhs.p};
+  const CrSource src = {lv.Hband, lv.g, s->scale.p, s->fixed.p, mu, mind, maxd, s->n, fv.band_poses, s->rhs.p, nullptr, 0};
   launch_cr_build_factor_solve(st, cr, src, s->wv.p, s->dt.p);
   // residual check of the factorisation and the trust-region bookkeeping in one pass over the band
   launch_spmv_residual_step(st, s->n, npad, fv, lv, s->scale.p, mu, mind, maxd, s->dt.p, s->rhs.p, xcur, s->qv.p, xcand, s->h_partials,   // straight into pinned host memory
@@ -409,15 +409,19 @@ static int linear_solve_and_step_dist(hitl_solver* s, const FactorView& fv, int 
   const int Wb = fv.band_poses, Wi = s->Wi, m = 3 * Wi, nc = 2 * m;
   *iters = 1;
   *ok = true;
-  launch_build_system(st, n, Wb, lv, s->scale.p, s->fixed.p, mu, mind, maxd, cr, s->rhs.p, s->dist_pcg ? nullptr : s->rhsN.p);   // rhsN[0]: the copy the factorisation consumes
+  if (s->dist_pcg) launch_build_system(st, n, Wb, lv, s->scale.p, s->fixed.p, mu, mind, maxd, cr, s->rhs.p, nullptr);
   int nh = 0;
   std::vector<double> coef, hval, hsc;   // uploaded asynchronously below: alive until the synchronisation at the end
   if (s->dist_pcg) {
     TRY(dist_pcg_solve(s, fv, lv, cr, mu, iters, ok));
     nh = s->n_halo;                      // dt and scale already hold the owners' values on every halo row
   } else {
-  launch_unit_rhs(st, npad, s->rhsN.p + npad, (size_t)npad, s->if_cols.p, nc);
-  launch_cr_factor_solve(st, cr, s->rhsN.p, s->zN.p, 1 + nc, (size_t)npad);   // z0 and Z = M^{-1} [E_F, E_L]
+  {
+    // build + factorise + solve for b and the interface unit vectors in one pass: z0 and Z = M^{-1} [E_F, E_L]; the first
+    // stage cuts its tiles and all 1 + nc right-hand sides itself (no k_build_system, no unit-vector fill)
+    const CrSource src = {lv.Hband, lv.g, s->scale.p, s->fixed.p, mu, mind, maxd, n, Wb, s->rhs.p, s->if_cols.p, nc};
+    launch_cr_build_factor_solve_multi(st, cr, src, s->rhsN.p, s->zN.p, (size_t)npad);
+  }
   const double* z0 = s->zN.p;
   const double* Z = s->zN.p + npad;
   const int RI = nc * (nc + 2), RC = m * m, R = RI + 2 * RC;
