@@ -84,6 +84,7 @@ def main():
             for r in range(6):
                 for k in range(3):
                     S[6 * gk + r, 6 * (gk + 1) + k] += sum(Zg[3 + c][r] * Ct[c][k] for c in range(3))
+    S_iface = S.copy()                                     # the interface matrix (np.linalg.solve below leaves it alone, the copy is for the covariance check)
     y = np.linalg.solve(S, y)
     coef = np.zeros(6)
     if rank >= 1:
@@ -92,12 +93,33 @@ def main():
         coef[3:] = allr[rank + 1][42:].reshape(3, 3) @ y[6 * (rank + 1):6 * (rank + 1) + 3]
     dt = z0 - Z @ coef
     err = float(np.abs(dt - ref[lo:hi]).max() / np.abs(ref).max())
+    # ---- pose covariances on the ranks (hitl_lm.cpp: dist_cov_correction): with only this rank's right-hand side non-zero the
+    # interface solve gives x_g = M^-1 e - Z (B A^-1 P) Z^T e, i.e. the diagonal block of the GLOBAL inverse over this rank's
+    # rows is M^-1 - Z T Z^T with T = B A^-1 P (6 x 6); compare its 3x3 pose blocks with the dense global inverse
+    T = np.zeros((6, 6))
+    for c in range(6):
+        rhs_i = np.zeros(NI)
+        rhs_i[6 * rank + c] = 1.0
+        yy = np.linalg.solve(S_iface, rhs_i)
+        if rank >= 1:
+            T[:3, c] = allr[rank][42:].reshape(3, 3).T @ yy[6 * (rank - 1) + 3:6 * (rank - 1) + 6]
+        if rank + 1 < world:
+            T[3:, c] = allr[rank + 1][42:].reshape(3, 3) @ yy[6 * (rank + 1):6 * (rank + 1) + 3]
+    Minv = np.linalg.inv(M)
+    Sig_local = Minv - Z @ T @ Z.T
+    Sig_global = np.linalg.inv(A)[lo:hi, lo:hi]
+    cov_err = 0.0
+    for k in range(nloc // 3):
+        blk = slice(3 * k, 3 * k + 3)
+        if lo + 3 * k == 0:
+            continue                                       # global pose 0: identity rows
+        cov_err = max(cov_err, float(np.abs(Sig_local[blk, blk] - Sig_global[blk, blk]).max() / np.abs(Sig_global[blk, blk]).max()))
     # rank-ordered scalar sums (cost, dt.rhs, ...) are identical on every rank
     part = torch.tensor([float(dt @ br), float(np.sum((scale[lo:hi] * dt) ** 2))], dtype=torch.float64)
     parts = [torch.zeros_like(part) for _ in range(world)]
     dist.all_gather(parts, part)
     tot = sum(p.numpy() for p in parts)
-    json.dump(dict(rank=rank, err=err, tot=tot.tolist(), ref=[float(ref @ rhs), float(np.sum((scale * ref)[3:] ** 2))]),
+    json.dump(dict(rank=rank, err=err, cov_err=cov_err, tot=tot.tolist(), ref=[float(ref @ rhs), float(np.sum((scale * ref)[3:] ** 2))]),
               open("%s.%d" % (out_path, rank), "w"))
     dist.destroy_process_group()
 

@@ -29,6 +29,7 @@ def test_interface_solve_reproduces_the_global_step(tmp_path):
     res = [json.load(open("%s.%d" % (out, k))) for k in range(2)]
     for x in res:
         assert x["err"] < 1e-9                      # local step == rows of the global solve
+        assert x["cov_err"] < 1e-8                  # local selected inverse - interface correction == blocks of the global inverse
         assert abs(x["tot"][0] - x["ref"][0]) <= 1e-9 * abs(x["ref"][0])
         assert abs(x["tot"][1] - x["ref"][1]) <= 1e-9 * abs(x["ref"][1])
     assert res[0]["tot"] == res[1]["tot"]           # bit-identical decisions on every rank
