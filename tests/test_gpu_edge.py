@@ -218,3 +218,22 @@ def test_pcg_runs_to_tolerance_behind_a_weak_preconditioner():
     assert abs(sg.final_cost - so.final_cost) <= 1e-8 * so.final_cost
     assert np.abs(pg[:, :2] - po[:, :2]).max() <= 2e-3 and np.abs(pg[:, 2] - po[:, 2]).max() <= 1e-4
     g.close(); o.close()
+
+
+@pytest.mark.parametrize("n, band", [(3100, 3), (1030, 1), (2060, 2)])
+def test_pcg_preconditioner_at_stage_boundaries(n, band):
+    """The same chunk-boundary sizes (see test_cyclic_reduction_stage_boundaries) through the OTHER user of the fused stages:
+    the PCG preconditioner solve on stored factors (k_cr_chunk_fwd + backward stages), reached with a window two poses wider
+    than the band.  The LM must walk the oracle's exact path."""
+    import hitl_slam_amd as H
+    from oracle import hitl_oracle as O
+    prob = Problem(n, 48, ppf=200, groups=3, kind=0)
+    opt = H.default_options()
+    opt.max_band_poses = band
+    g, o = H.Solver(opt), O.OracleSolver(opt)
+    prob.load(g); prob.load(o)
+    o.find_correspondences(prob.init, band + 2, 0)
+    g.set_correspondences(*o.get_correspondences())
+    pg, sg = _check(g, o, 2, prob.init)
+    assert sg.num_offband_pairs > 0 and sg.linear_iterations > sg.iterations
+    g.close(); o.close()
