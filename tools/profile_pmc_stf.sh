@@ -18,7 +18,7 @@ for grp in "TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum" "TA_ADDR_STALLED_BY_TC_C
            "SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_VMEM" "SQ_INSTS_VMEM_RD SQ_INST_LEVEL_LDS" \
            "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_DRAM_sum"; do
   i=$((i+1))
-  timeout 90 rocprofv3 --pmc $grp --output-format csv -d $OUT/p$i -- python3 tools/stf_ablate.py > $OUT/p$i.out 2> $OUT/p$i.err
+  timeout 90 rocprofv3 --pmc $grp --output-format csv -d $OUT/p$i -- python3 tools/stf_time.py > $OUT/p$i.out 2> $OUT/p$i.err < /dev/null
 done
 python3 - <<PY
 import csv, glob, os
