@@ -325,7 +325,7 @@ def main():
                      "algorithmic_frac": alg_achieved / HBM_PEAK_GBS,
                      "compulsory_bytes_this_layout": compulsory,
                      "avg_launch_ms": avg_stf_ms, "launches": stf_launches, "launches_bracketed_by_hip_events": stf_calls,
-                     "limiter": "no single unit: fp64 issue slots ~82 %, L1 gather path (TA) ~58 %, HBM ~39 % of peak; ablations in "
+                     "limiter": "no single unit: fp64 issue slots 73-82 %, L1 gather path (TA) ~73 %, HBM ~39 % of peak (profiles/r02_stf_memory_path_pmc.txt, profiles/r02_final_pmc.md); ablations in "
                                 "profiles/r02_stf_ablation_kernel_trace.txt (no ingredient of a trip is worth more than 14 % of the launch)",
                      "utilisation_counters": pmc},
         "synth_gen_s": gen_s,
