@@ -160,6 +160,7 @@ def default_options():
     o.rank = 0
     o.world_size = 1
     o.timing_level = 1
+    o.kd_tree_search = 1
     o.rccl_unique_id = None
     return o
 

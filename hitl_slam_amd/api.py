@@ -453,6 +453,16 @@ def load_library(path=None):
 class Solver(SolverBase):
     """The MI355X backend (libhitlgpu.so)."""
 
+    def get_kd_trees(self):
+        """(pts float32 [n_obs, 4], meta uint32 [n_obs]) of hitl_solver_get_kd_trees: every scan's KD-tree in the in-order layout."""
+        n_obs = int(self.obs_offset[-1] - self.obs_offset[0])
+        pts = np.zeros((max(n_obs, 1), 4), np.float32)
+        meta = np.zeros(max(n_obs, 1), np.uint32)
+        f = self._lib.hitl_solver_get_kd_trees
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        self._check(f(self._h, pts.ctypes.data_as(C.c_void_p), meta.ctypes.data_as(C.c_void_p)), "get_kd_trees")
+        return pts[:n_obs], meta[:n_obs]
+
     _names = dict(create="hitl_solver_create", destroy="hitl_solver_destroy", set_map="hitl_solver_set_map",
                   set_hc="hitl_solver_set_human_constraints", set_corr="hitl_solver_set_correspondences",
                   get_corr_counts="hitl_solver_get_correspondence_counts",

@@ -57,9 +57,23 @@ static void make_rel_tf(const float* pi, const float* pj, const float* csi, cons
   t[6] = cosf(dth); t[7] = sinf(dth);
 }
 
+int ensure_kd_trees(hitl_solver* s) {      // BuildKDTrees: once per map (JointOptimization.cpp:1307, kdtrees_.size() == 0)
+  if (s->kd_built) return HITL_OK;
+  if (kd_build_lds_bytes(s->max_scan) > (size_t)150 * 1024)
+    return fail(HITL_ERR_UNSUPPORTED, "kd_tree_search: a scan of " + std::to_string(s->max_scan) + " points exceeds the LDS budget of the tree build (limit ~3800 points)");
+  int rc = s->kd_pts.resize((size_t)std::max<int64_t>(s->n_obs, 1));
+  if (rc != HITL_OK) return rc;
+  rc = s->kd_meta.resize((size_t)std::max<int64_t>(s->n_obs, 1));
+  if (rc != HITL_OK) return rc;
+  launch_kd_build(s->stream, s->map_view(), s->max_scan, s->kd_pts.p, s->kd_meta.p);
+  if (hipGetLastError() != hipSuccess) return fail(HITL_ERR_HIP, "the tree-build kernel could not be launched");
+  s->kd_built = true;
+  return HITL_OK;
+}
+
 int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
   HIP_TRY(hipSetDevice(s->device));
-  const bool timing = std::getenv("HITL_TIMING") != nullptr;
+  const bool timing = dev_switches().timing;
   auto t_prev = std::chrono::steady_clock::now();
   auto mark = [&](const char* what) {
     if (!timing) return;
@@ -81,8 +95,7 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
   // stays below a budget whatever the map (all slots of a source pose share a tile: the per-point cap counts across them).
   const int band_cap = std::min(std::max((int)s->opt.max_band_poses, 1), kMaxBandPoses);
   const bool device_tables = window <= band_cap;
-  size_t tile_budget = (size_t)4 << 30;
-  if (const char* e = std::getenv("HITL_CAND_TILE_BYTES")) tile_budget = (size_t)std::max(1ll, std::atoll(e));     // tests: force several tiles
+  const size_t tile_budget = dev_switches().cand_tile_bytes;     // tests force several tiles
   const size_t per_pose = (size_t)slots * s->max_scan * sizeof(uint16_t);
   const int tile = device_tables ? n : (int)std::min<size_t>((size_t)n, std::max<size_t>(1, tile_budget / std::max<size_t>(per_pose, 1)));
   // scratch kept in the solver between calls (no 10 MB allocate-and-clear per search)
@@ -153,11 +166,8 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
   mp.cap = s->opt.max_correspondences_per_point;
   mp.skip = std::max(s->opt.num_skip_readings, 1);
   const MapView mv = s->map_view();
-  if (kd && !s->kd_built) {      // BuildKDTrees: once per map (JointOptimization.cpp:1307, kdtrees_.size() == 0)
-    TRYC(s->kd_pts.resize((size_t)std::max<int64_t>(s->n_obs, 1)));
-    TRYC(s->kd_meta.resize((size_t)std::max<int64_t>(s->n_obs, 1)));
-    launch_kd_build(st, mv, s->max_scan, s->kd_pts.p, s->kd_meta.p);
-    s->kd_built = true;
+  if (kd && !s->kd_built) {
+    TRYC(ensure_kd_trees(s));
     mark("k_kd_build");
   }
   // one tile of source poses [i0, i0 + cnt): upload its candidates, match
@@ -167,7 +177,13 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
     TRYC(d_counts.resize((size_t)cnt * slots));
     TRYC(d_counts.zero(st));
     TRYC(d_table.resize((size_t)cnt * slots * s->max_scan));
-    if (kd) launch_match_kd(st, mv, s->max_scan, slots, d_tgt.p, d_tf.p, mp, s->kd_pts.p, s->kd_meta.p, d_table.p, d_counts.p, i0, cnt);
+    if (kd && device_tables && match_kd_tgt_applies(slots, (int)window, mp)) {
+      // the per-point cap cannot bind (slots <= cap): every (source, target) pair is independent, one workgroup per target tree
+      const int kd_block = dev_switches().kd_block, kd_refill = dev_switches().kd_refill;
+      if (mp.skip > 1 && hipMemsetAsync(d_table.p, 0xFF, sizeof(uint16_t) * (size_t)cnt * slots * s->max_scan, st) != hipSuccess)
+        return fail(HITL_ERR_HIP, "find_correspondences: clearing the candidate table failed");
+      launch_match_kd_tgt(st, mv, s->max_scan, slots, (int)window, d_tf.p, mp, s->kd_pts.p, s->kd_meta.p, d_table.p, d_counts.p, kd_block, kd_refill);
+    } else if (kd) launch_match_kd(st, mv, s->max_scan, slots, d_tgt.p, d_tf.p, mp, s->kd_pts.p, s->kd_meta.p, d_table.p, d_counts.p, i0, cnt);
     else launch_match(st, mv, s->max_scan, slots, d_tgt.p, d_tf.p, mp, d_table.p, d_counts.p, i0, cnt);
     if (hipGetLastError() != hipSuccess) return fail(HITL_ERR_HIP, "find_correspondences: the match kernel could not be launched");
     return HITL_OK;

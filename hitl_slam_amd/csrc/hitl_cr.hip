@@ -1122,13 +1122,7 @@ static CrPlan cr_plan(int nsb, int B, int np, int nrhs, size_t wstride) {
   CrPlan pl;
   pl.n = 0;
   const size_t lds_cap = 128 * 1024;
-  static const std::vector<int> forced = [] {
-    std::vector<int> v;
-    if (const char* e = std::getenv("HITL_CR_PLAN")) {
-      for (const char* q = e; *q;) { v.push_back(std::atoi(q)); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
-    }
-    return v;
-  }();
+  const std::vector<int> forced(dev_switches().cr_plan, dev_switches().cr_plan + dev_switches().cr_plan_n);
   int S = 1, par = 0;
   bool prev = false;
   for (;;) {
@@ -1226,7 +1220,7 @@ static bool cr_solve_fused(hipStream_t st, const CrView& cr, const double* w_in,
 template <int B>
 static void cr_factor_t(hipStream_t st, const CrView& cr, double* w, double* x, int nrhs, size_t stride) {
   const int nr = (w != nullptr) ? nrhs : 0;
-  static const bool legacy = std::getenv("HITL_CR_LEGACY") != nullptr;       // development switch: the level-per-launch path
+  const bool legacy = dev_switches().cr_legacy;       // development switch: the level-per-launch path
   if (!legacy && cr_factor_fused<B>(st, cr, nr ? w : nullptr, nr ? x : nullptr, nr, stride)) return;
   const int s_top = cr_top_start(cr.nsb, B, nr);
   if (s_top > 1) {
@@ -1298,7 +1292,7 @@ void launch_cr_factor_solve(hipStream_t st, const CrView& cr, double* w, double*
 }
 
 void launch_cr_build_factor_solve_multi(hipStream_t st, const CrView& cr, const CrSource& src, double* w, double* x, size_t stride) {
-  static const bool legacy = std::getenv("HITL_CR_LEGACY") != nullptr || std::getenv("HITL_CR_UNFUSED_BUILD") != nullptr;
+  const bool legacy = dev_switches().cr_legacy || dev_switches().cr_unfused_build;
   const int nrhs = 1 + src.n_unit;
   bool done = false;
   if (!legacy) {
@@ -1317,7 +1311,7 @@ void launch_cr_build_factor_solve_multi(hipStream_t st, const CrView& cr, const 
 }
 
 void launch_cr_build_factor_solve(hipStream_t st, const CrView& cr, const CrSource& src, double* w, double* x) {
-  static const bool legacy = std::getenv("HITL_CR_LEGACY") != nullptr || std::getenv("HITL_CR_UNFUSED_BUILD") != nullptr;
+  const bool legacy = dev_switches().cr_legacy || dev_switches().cr_unfused_build;
   bool done = false;
   if (!legacy) {
     switch (cr.B) {
@@ -1343,7 +1337,7 @@ void launch_cr_solve_multi(hipStream_t st, const CrView& cr, double* w, double* 
 }
 
 void launch_cr_solve(hipStream_t st, const CrView& cr, const double* rhs, double* w, double* x) {
-  static const bool legacy = std::getenv("HITL_CR_LEGACY") != nullptr;
+  const bool legacy = dev_switches().cr_legacy;
   bool done = false;
   if (!legacy) {
     switch (cr.B) {

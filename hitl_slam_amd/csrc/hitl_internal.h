@@ -18,6 +18,27 @@ constexpr int kPairRJ = 14;               // r0, r1, J[2][6] per directed STF pa
 constexpr int kNumScalars = 16;           // device scalar scratch (doubles)
 constexpr int kMatchPad = 512;            // readable words behind the last match (k_linearize_stf fetches one trip ahead)
 
+// Development switches (environment variables; DESIGN.md section 5 lists them).  Read in ONE place, hitl_solver_create --
+// nothing on a launch or solve path calls getenv -- and kept per process: the values the last hitl_solver_create saw.
+struct DevSwitches {
+  bool timing = false;             // HITL_TIMING: phase times of find_correspondences / prepare on stderr
+  bool event_sync = false;         // HITL_EVENT_SYNC: event instead of the pinned-memory flag in the LM loop
+  bool cr_legacy = false;          // HITL_CR_LEGACY: level-per-launch cyclic reduction
+  bool cr_unfused_build = false;   // HITL_CR_UNFUSED_BUILD: k_build_system as its own launch
+  bool stf_addr64 = false;         // HITL_STF_ADDR64: 64-bit addressing instantiations of k_linearize_stf
+  bool force_dist = false;         // HITL_FORCE_DIST: one rank takes the submap code path
+  bool force_rccl = false;         // HITL_FORCE_RCCL: in-library RCCL communicator with one rank
+  bool host_lm = false;            // HITL_HOST_LM: accept/reject decisions of the LM loop on the host (round-2 loop)
+  int stf_variant = 0;             // HITL_STF_VARIANT: instantiation of k_linearize_stf
+  int kd_block = 256;              // HITL_KD_BLOCK: workgroup size of k_match_kd_tgt (64 / 128 / 256)
+  int kd_refill = 16;              // HITL_KD_REFILL: idle lanes per wave that trigger a refill from the query queue
+  size_t cand_tile_bytes = (size_t)4 << 30;   // HITL_CAND_TILE_BYTES: candidate-table budget of the tiled search
+  int cr_plan[16] = {0};           // HITL_CR_PLAN: chunk sizes of the fused stages
+  int cr_plan_n = 0;
+};
+const DevSwitches& dev_switches();
+void read_dev_switches();          // hitl_solver_create only
+
 // ---- view structs passed to kernels by value ------------------------------------------
 struct MapView {            // SoA robot-frame scans (JointOptimization.h:62-68)
   int n_poses;
@@ -177,6 +198,12 @@ size_t match_kd_lds_bytes(int max_scan);
 void launch_kd_build(hipStream_t st, const MapView& map, int max_scan, float4* kd_pts, uint32_t* kd_meta);
 void launch_match_kd(hipStream_t st, const MapView& map, int max_scan, int slots, const int* cand_tgt, const float* cand_tf, MatchParams mp,
                      const float4* kd_pts, const uint32_t* kd_meta, uint16_t* table, int* counts, int i0 = 0, int n_tile = -1);
+// target-major form of the same search (one workgroup per target tree, one queue of all its queries): whole map, windowed
+// candidates, slots <= cap (the per-point cap cannot bind); block = 64 / 128 / 256 threads, refill_min = idle lanes per wave
+// that trigger a refill from the queue
+bool match_kd_tgt_applies(int slots, int window, const MatchParams& mp);
+void launch_match_kd_tgt(hipStream_t st, const MapView& map, int max_scan, int slots, int window, const float* cand_tf, MatchParams mp,
+                         const float4* kd_pts, const uint32_t* kd_meta, uint16_t* table, int* counts, int block, int refill_min);
 void launch_compact(hipStream_t st, const MapView& map, int max_scan, int slots, int n_kept,
                     const int* kept_cand /* index into n*slots */, const int64_t* match_off, const uint16_t* table,
                     uint32_t* matches, int i0 = 0);

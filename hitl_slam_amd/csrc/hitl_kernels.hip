@@ -374,12 +374,12 @@ void launch_linearize_stf(hipStream_t st, const MapView& map, const PairView& pr
   const int cap = (max_scan + 63) & ~63;
   // HITL_STF_ADDR64=1 (tests): take the 64-bit addressing instantiations although the arrays are smaller than 4 GB
   const bool off32 = (uint64_t)map_obs_count * 16 < ((uint64_t)1 << 32) && ((uint64_t)n_matches + kMatchPad) * 4 < ((uint64_t)1 << 32) &&
-                     std::getenv("HITL_STF_ADDR64") == nullptr;
+                     !dev_switches().stf_addr64;
   const double kf = (double)corr / (double)std_dev;                       // k = corr / sigma, divided here once
   const dim3 grid(8 * chunk), block(kStfBlock);
   // HITL_STF_VARIANT (development switch): 2 decimal digits "ahead minwaves", e.g. 26 = index words 2 trips ahead, 6 waves per
   // SIMD (5, 6, 7 exist; 7 only with 1 or 2 trips ahead).  Unset: the default below.
-  static const int variant = [] { const char* e = std::getenv("HITL_STF_VARIANT"); return e ? std::atoi(e) : 0; }();
+  const int variant = dev_switches().stf_variant;
   const int src = ((size_t)cap * 32 <= 64 * 1024) ? 2 : ((size_t)cap * 16 <= 64 * 1024) ? 1 : 0;
   int ahead = kStfAheadDefault, minb = (src == 2 && off32) ? 7 : 5;     // the fallback layouts need > 80 VGPRs: 5 waves per SIMD instead of spilling
   if (variant > 0 && src == 2 && off32) { ahead = std::min(3, std::max(1, variant / 10)); minb = (variant % 10 == 5) ? 5 : (variant % 10 == 7) ? 7 : 6; }

@@ -70,8 +70,7 @@ static int finish_linearize(hitl_solver* s, const FactorView& fv, LinResult* out
 // re-solve cheaper than hipEventRecord + hipEventQuery (HITL_EVENT_SYNC=1 brings those back).  The kernels in front of it
 // have completed -- and their own stores to pinned memory (the partial sums) are visible -- before it starts.
 static int spin_sync(hitl_solver* s) {
-  static const bool event_sync = std::getenv("HITL_EVENT_SYNC") != nullptr;
-  if (!event_sync) {
+  if (!dev_switches().event_sync) {
     volatile double* flag = s->h_scalars + 15;
     const double seq = (double)(++s->sync_seq);
     launch_host_flag(s->stream, s->h_scalars + 15, seq);
@@ -608,7 +607,7 @@ int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float* poses
   const hitl_options& o = s->opt;
   FactorView fv;
   TRY(prepare(s, mode, poses_in, poses_global, &fv));
-  if (std::getenv("HITL_TIMING")) std::fprintf(stderr, "lm_solve: prepare (factor tables)   %.3f ms\n", now_ms() - t_start);
+  if (dev_switches().timing) std::fprintf(stderr, "lm_solve: prepare (factor tables)   %.3f ms\n", now_ms() - t_start);
   hipStream_t st = s->stream;
   const int n = s->n, n3 = 3 * n;
   hitl_summary S;

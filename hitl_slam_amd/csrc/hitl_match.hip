@@ -14,6 +14,7 @@
 // points k = tid, tid+256, ... and walks the staged scan with broadcast ds_read_b128.
 
 #include "hitl_internal.h"
+#include "hitl_kdwalk.h"
 
 namespace hitl {
 
@@ -229,87 +230,118 @@ void launch_kd_build(hipStream_t st, const MapView& map, int max_scan, float4* k
   hipLaunchKernelGGL(k_kd_build, dim3(map.n_poses), dim3(kKdBlock), lds, st, map, max_scan, kd_pts, kd_meta);
 }
 
-// KDTree::FindNearestPointNormal (kdtree.cpp:141-197) on the in-order layout, recursion unrolled onto an explicit stack
-// in LDS (frame = segment, stage, running best, position of the running winner, plane distance).  Returns the point-to-
-// plane distance of the winner (FLT_MAX when nothing inside the gate was visited) and its tree position.
-__device__ __forceinline__ float kd_find_nearest_point_normal(const float4* __restrict__ pts, const uint32_t* __restrict__ meta, int m,
-                                                              float qx, float qy, float thr, uint32_t* st_seg, float* st_best,
-                                                              uint32_t* st_out, float* st_pd, int stride, int* out_pos) {
-  constexpr float kFltMax = 3.402823466e+38f, kFltMin = 1.175494351e-38f;
-  int sp = 1;
-  st_seg[0] = (uint32_t)m << 16;            // lo = 0, n = m
-  st_out[0] = 0;                            // stage 0
-  float ret_d = kFltMax;
-  int ret_c = -1;
-  while (sp > 0) {
-    const int f = (sp - 1) * stride;
-    const uint32_t seg = st_seg[f];
-    const int lo = (int)(seg & 0xffffu), n = (int)(seg >> 16), ind = n / 2, pos = lo + ind;
-    const uint32_t os = st_out[f];
-    int stage = (int)(os >> 28);
-    int out = (int)(os & 0x0fffffffu) - 1;  // -1 = none
-    float best = st_best[f], pd = st_pd[f];
-    bool went_left = false, other_left = false, have_other = false;
-    if (stage == 0) {
-      const float4 g = pts[pos];
-      const float dx = g.x - qx, dy = g.y - qy;
-      best = kFltMax; out = -1;
-      if (dx * dx + dy * dy < thr * thr) {
-        out = pos;
-        best = fabsf(g.z * (qx - g.x) + g.w * (qy - g.y));
-        if (best < kFltMin) { ret_d = 0.0f; ret_c = pos; --sp; continue; }
-      }
-      const int split = (int)(meta[pos] >> 16);
-      pd = (split ? qy : qx) - (split ? g.y : g.x);
-      if (pd <= 0.0f && ind > 0) {            // search the left sub-tree first
-        st_best[f] = best; st_pd[f] = pd; st_out[f] = (1u << 28) | (uint32_t)(out + 1);
-        const int c = sp * stride;
-        st_seg[c] = (uint32_t)lo | ((uint32_t)ind << 16); st_out[c] = 0;
-        ++sp;
-        continue;
-      }
-      stage = 2;
-    } else if (stage == 1) {                  // back from the left sub-tree
-      if (ret_d < best) { best = ret_d; out = ret_c; }
-      went_left = true;
-      stage = 2;
+// ---------------------------------------------------------------------------------------------------------------------
+// The walk itself: hitl_kdwalk.h (`kd_step`, one node evaluation of one query per call; the same source is held to the
+// literal unrolling of the recursion on the CPU in tests/test_kdwalk_cpu.py).
+//
+// k_match_kd_tgt -- one workgroup per TARGET pose.  Its tree is staged in LDS once and serves the queries of every source
+// scan that has this pose in its window: one queue of (source, point) items per workgroup (2W x M ~ 2400 queries), handed
+// out in order; a lane that finishes its query takes the next item, so the 64 walks of a wave -- each at its own node, at
+// its own depth -- keep the lanes busy (lock-step simulation in tests/test_kdwalk_cpu.py: 95 % with refills when >= 8 lanes
+// are idle) instead of waiting for the longest walk of a static round.  Legal only when the per-point cap cannot bind:
+// FindSTFCorrespondences counts a source point's accepted matches across its targets in ascending order
+// (JointOptimization.cpp:596-599), which couples the targets of one source pose -- but a point that has seen s targets has
+// at most s matches, so with (number of slots) <= cap the test is vacuous and every (source, target) pair is independent.
+// k_match_kd (source-major, targets in order, counters in LDS) serves every other case with the same `kd_step`.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kKdMaxSrc = 2 * kMaxBandPoses;      // slots of a windowed search inside the band
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_match_kd_tgt(MapView map, int chunk, int max_scan, int slots, int window, int depth, int refill_min,
+                                                         const float* __restrict__ cand_tf, MatchParams mp,
+                                                         const float4* __restrict__ kd_pts, const uint32_t* __restrict__ kd_meta,
+                                                         uint16_t* __restrict__ table, int* __restrict__ counts) {
+  extern __shared__ float4 s_tgt[];                 // [max_scan] target tree points (in-order layout)
+  uint32_t* s_meta = (uint32_t*)(s_tgt + max_scan); // [max_scan] original index | split << 16
+  float* sv_best = (float*)(s_meta + max_scan);     // [depth + 1][BLOCK] stored-best stack of kd_step (+ its dump entry)
+  int* sv_out = (int*)(sv_best + (size_t)(depth + 1) * BLOCK);
+  __shared__ int s_next, s_total, s_nsrc;
+  __shared__ int s_count[kKdMaxSrc], s_cand[kKdMaxSrc], s_start[kKdMaxSrc + 1];
+  __shared__ long long s_obs[kKdMaxSrc];
+  __shared__ float s_tf[kKdMaxSrc][8];
+  const int b = blockIdx.x;
+  const int idx = b >> 3;
+  const int j = (b & 7) * chunk + idx;              // consecutive poses share an XCD (L2 reuse of the neighbouring scans)
+  if (idx >= chunk || j >= map.n_poses) return;
+  const int64_t oj = map.obs_off[j];
+  const int mj = (int)(map.obs_off[j + 1] - oj);
+  if (threadIdx.x == 0) {
+    // the sources that have j in their window, ascending; slot of j in source i's candidate list as fill_candidates lays it out
+    int ns = 0, start = 0;
+    const int i0 = max(0, j - window), i1 = min(map.n_poses - 1, j + window);
+    for (int i = i0; i <= i1; ++i) {
+      if (i == j) continue;
+      const int sl = (j - max(0, i - window)) - (j > i ? 1 : 0);
+      const int64_t oi = map.obs_off[i];
+      const int mi = (int)(map.obs_off[i + 1] - oi);
+      s_cand[ns] = i * slots + sl; s_obs[ns] = oi; s_start[ns] = start; s_count[ns] = 0;
+      start += (mi + mp.skip - 1) / mp.skip;        // items = source points k with k % skip == 0
+      ++ns;
     }
-    if (stage == 2) {
-      if (pd >= 0.0f && ind < n - 1) {        // the right sub-tree
-        st_best[f] = best; st_pd[f] = pd; st_out[f] = (3u << 28) | (uint32_t)(out + 1);
-        const int c = sp * stride;
-        st_seg[c] = (uint32_t)(lo + ind + 1) | ((uint32_t)(n - ind - 1) << 16); st_out[c] = 0;
-        ++sp;
-        continue;
-      }
-      have_other = went_left && (ind < n - 1);   // `other = nd->right` was set in the left branch (NULL without a right child)
-      other_left = false;
-      stage = 4;
-    } else if (stage == 3) {                  // back from the right sub-tree
-      if (ret_d < best) { best = ret_d; out = ret_c; }
-      have_other = ind > 0;                   // `other = nd->left`
-      other_left = true;
-      stage = 4;
-    }
-    if (stage == 4) {
-      if (have_other && pd != 0.0f && fabsf(pd) < ((best < thr) ? best : thr)) {   // the other side of the split plane may hold a closer point
-        st_best[f] = best; st_pd[f] = pd; st_out[f] = (5u << 28) | (uint32_t)(out + 1);
-        const int c = sp * stride;
-        st_seg[c] = other_left ? ((uint32_t)lo | ((uint32_t)ind << 16)) : ((uint32_t)(lo + ind + 1) | ((uint32_t)(n - ind - 1) << 16));
-        st_out[c] = 0;
-        ++sp;
-        continue;
-      }
-    } else if (stage == 5) {                  // back from the other side
-      if (ret_d < best) { best = ret_d; out = ret_c; }
-    }
-    ret_d = best; ret_c = out;
-    --sp;
+    s_start[ns] = start; s_nsrc = ns; s_total = start; s_next = 0;
   }
-  *out_pos = ret_c;
-  return ret_d;
+  for (int t = threadIdx.x; t < mj; t += BLOCK) { s_tgt[t] = kd_pts[oj + t]; s_meta[t] = kd_meta[oj + t]; }
+  __syncthreads();
+  const int ns = s_nsrc, total = s_total;
+  for (int t = threadIdx.x; t < ns * 8; t += BLOCK) s_tf[t >> 3][t & 7] = cand_tf[(size_t)s_cand[t >> 3] * 8 + (t & 7)];
+  __syncthreads();
+  const float thr = mp.thr, thr2 = mp.thr * mp.thr;
+  float* my_best = sv_best + threadIdx.x;
+  int* my_out = sv_out + threadIdx.x;
+  KdWalk w;
+  w.mode = 2; w.qx = w.qy = 0.0f; w.lo = w.n = 0; w.ret_d = 0.0f; w.ret_c = -1; w.stk = 1ull; w.ssp = 0; w.ovf = 0;
+  bool have = false;                                // this lane holds a query (running or finished, not yet written)
+  int src = 0, k = 0;
+  float nqx = 0.0f, nqy = 0.0f;
+  bool more = total > 0;                            // wave-uniform: the queue may still hold items
+  for (;;) {
+    const bool idle = (w.mode == 2);
+    const int nidle = __popcll(__ballot(idle));
+    if (nidle >= (more ? refill_min : 64) || nidle == 64) {
+      bool got = false;
+      if (idle) {
+        if (have) {                                 // finish: JointOptimization.cpp:606-621 on the walk's winner
+          uint16_t res = 0xFFFFu;
+          if (w.ret_c >= 0 && w.ret_d < thr) {
+            const float4 g = s_tgt[w.ret_c];
+            const float cosang = g.z * nqx + g.w * nqy;
+            if (cosang > mp.min_cos) { res = (uint16_t)(s_meta[w.ret_c] & 0xffffu); atomicAdd(&s_count[src], 1); }
+          }
+          table[(size_t)s_cand[src] * max_scan + k] = res;
+          have = false;
+        }
+        if (more) {
+          const int t = atomicAdd(&s_next, 1);
+          if (t < total) {
+            int sidx = 0;
+#pragma unroll
+            for (int q = 1; q < kKdMaxSrc; ++q) sidx += (q < ns && t >= s_start[q]) ? 1 : 0;
+            src = sidx;
+            k = (t - s_start[sidx]) * mp.skip;
+            const float4 a = map.obs[s_obs[sidx] + k];
+            const float* tf = s_tf[sidx];
+            const float qx = (tf[0] * a.x + tf[1] * a.y) + tf[4];
+            const float qy = (tf[2] * a.x + tf[3] * a.y) + tf[5];
+            nqx = tf[6] * a.z - tf[7] * a.w; nqy = tf[7] * a.z + tf[6] * a.w;
+            kd_begin(w, qx, qy, mj);
+            have = true; got = true;
+          }
+        }
+      }
+      if (more && !__any(got)) more = false;        // the queue ran dry (t >= total on every asking lane)
+      if (!more && __all(w.mode == 2)) {
+        if (__any(have)) continue;                  // walks of empty trees finish at once: one more round writes them
+        break;
+      }
+    }
+    kd_step(w, s_tgt, s_meta, thr, thr2, my_best, my_out, BLOCK, depth);
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < ns) counts[s_cand[threadIdx.x]] = s_count[threadIdx.x];
 }
 
+// source-major form (any number of slots, tiles of source poses): targets in ascending order, the per-point counters of
+// JointOptimization.cpp:596-599 in LDS, one query per thread and round.
 __global__ __launch_bounds__(kMatchBlock) void k_match_kd(MapView map, int chunk, int max_scan, int slots, int depth,
                                                            const int* __restrict__ cand_tgt, const float* __restrict__ cand_tf, MatchParams mp,
                                                            const float4* __restrict__ kd_pts, const uint32_t* __restrict__ kd_meta,
@@ -317,10 +349,8 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_kd(MapView map, int chunk
   extern __shared__ float4 s_tgt[];                 // [max_scan] target tree points (in-order layout)
   uint32_t* s_meta = (uint32_t*)(s_tgt + max_scan); // [max_scan] original index | split << 16
   int* s_cnt = (int*)(s_meta + max_scan);           // [max_scan] accepted matches per source point
-  uint32_t* st_seg = (uint32_t*)(s_cnt + max_scan); // [depth][kMatchBlock] each
-  float* st_best = (float*)(st_seg + (size_t)depth * kMatchBlock);
-  uint32_t* st_out = (uint32_t*)(st_best + (size_t)depth * kMatchBlock);
-  float* st_pd = (float*)(st_out + (size_t)depth * kMatchBlock);
+  float* sv_best = (float*)(s_cnt + max_scan);      // [depth + 1][kMatchBlock] stored-best stack of kd_step (+ its dump entry)
+  int* sv_out = (int*)(sv_best + (size_t)(depth + 1) * kMatchBlock);
   __shared__ int s_pair_count;
   const int b = blockIdx.x;
   const int idx = b >> 3;
@@ -330,7 +360,7 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_kd(MapView map, int chunk
   const int64_t oi = map.obs_off[i];
   const int mi = (int)(map.obs_off[i + 1] - oi);
   for (int k = threadIdx.x; k < mi; k += kMatchBlock) s_cnt[k] = 0;
-  const float thr = mp.thr;
+  const float thr = mp.thr, thr2 = mp.thr * mp.thr;
   for (int slot = 0; slot < slots; ++slot) {
     const int j = cand_tgt[(size_t)il * slots + slot];
     if (j < 0) continue;                            // block-uniform
@@ -351,15 +381,16 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_kd(MapView map, int chunk
         const float ax = a.x, ay = a.y;
         const float qx = (m00 * ax + m01 * ay) + tx;
         const float qy = (m10 * ax + m11 * ay) + ty;
-        int pos = -1;
-        const float dist = kd_find_nearest_point_normal(s_tgt, s_meta, mj, qx, qy, thr, st_seg + threadIdx.x, st_best + threadIdx.x,
-                                                        st_out + threadIdx.x, st_pd + threadIdx.x, kMatchBlock, &pos);
-        if (pos >= 0 && dist < thr) {
+        KdWalk w;
+        w.ovf = 0;
+        kd_begin(w, qx, qy, mj);
+        while (w.mode != 2) kd_step(w, s_tgt, s_meta, thr, thr2, sv_best + threadIdx.x, sv_out + threadIdx.x, kMatchBlock, depth);
+        if (w.ret_c >= 0 && w.ret_d < thr) {
           const float anx = a.z, any = a.w;
           const float nqx = cr * anx - sr * any, nqy = sr * anx + cr * any;
-          const float4 g = s_tgt[pos];
+          const float4 g = s_tgt[w.ret_c];
           const float cosang = g.z * nqx + g.w * nqy;
-          if (cosang > mp.min_cos) { res = (uint16_t)(s_meta[pos] & 0xffffu); s_cnt[k] += 1; ++local; }
+          if (cosang > mp.min_cos) { res = (uint16_t)(s_meta[w.ret_c] & 0xffffu); s_cnt[k] += 1; ++local; }
         }
       }
       row[k] = res;
@@ -373,7 +404,7 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_kd(MapView map, int chunk
 static int kd_depth(int max_scan) { int d = 1; while ((1 << d) <= max_scan) ++d; return d + 1; }
 
 size_t match_kd_lds_bytes(int max_scan) {
-  return (size_t)max_scan * (sizeof(float4) + 2 * sizeof(int)) + (size_t)kd_depth(max_scan) * kMatchBlock * 16;
+  return (size_t)std::max(max_scan, 1) * (sizeof(float4) + 2 * sizeof(int)) + (size_t)(kd_depth(max_scan) + 1) * kMatchBlock * 8;
 }
 
 void launch_match_kd(hipStream_t st, const MapView& map, int max_scan, int slots, const int* cand_tgt, const float* cand_tf, MatchParams mp,
@@ -384,6 +415,29 @@ void launch_match_kd(hipStream_t st, const MapView& map, int max_scan, int slots
   if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_match_kd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k_match_kd, dim3(8 * chunk), dim3(kMatchBlock), lds, st, map, chunk, max_scan, slots, kd_depth(max_scan), cand_tgt, cand_tf,
                      mp, kd_pts, kd_meta, table, counts, i0, n_tile);
+}
+
+// target-major search over the whole map (a windowed search inside the band whose slots cannot reach the per-point cap)
+bool match_kd_tgt_applies(int slots, int window, const MatchParams& mp) {
+  return window >= 1 && 2 * window <= kKdMaxSrc && slots <= 2 * window && slots <= mp.cap && mp.skip >= 1;
+}
+
+template <int BLOCK>
+static void launch_match_kd_tgt_t(hipStream_t st, const MapView& map, int max_scan, int slots, int window, int refill_min, const float* cand_tf,
+                                  MatchParams mp, const float4* kd_pts, const uint32_t* kd_meta, uint16_t* table, int* counts) {
+  const int chunk = (map.n_poses + 7) / 8;
+  const int depth = kd_depth(max_scan);
+  const size_t lds = (size_t)max_scan * (sizeof(float4) + sizeof(uint32_t)) + (size_t)(depth + 1) * BLOCK * 8;
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_match_kd_tgt<BLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k_match_kd_tgt<BLOCK>, dim3(8 * chunk), dim3(BLOCK), lds, st, map, chunk, max_scan, slots, window, depth, refill_min, cand_tf, mp,
+                     kd_pts, kd_meta, table, counts);
+}
+
+void launch_match_kd_tgt(hipStream_t st, const MapView& map, int max_scan, int slots, int window, const float* cand_tf, MatchParams mp,
+                         const float4* kd_pts, const uint32_t* kd_meta, uint16_t* table, int* counts, int block, int refill_min) {
+  if (block == 64) launch_match_kd_tgt_t<64>(st, map, max_scan, slots, window, refill_min, cand_tf, mp, kd_pts, kd_meta, table, counts);
+  else if (block == 256) launch_match_kd_tgt_t<256>(st, map, max_scan, slots, window, refill_min, cand_tf, mp, kd_pts, kd_meta, table, counts);
+  else launch_match_kd_tgt_t<128>(st, map, max_scan, slots, window, refill_min, cand_tf, mp, kd_pts, kd_meta, table, counts);
 }
 
 size_t match_lds_bytes(int max_scan) {

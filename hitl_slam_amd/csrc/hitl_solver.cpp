@@ -393,6 +393,26 @@ int prepare(hitl_solver* s, int mode, const float* poses_ref, const float* poses
 
 }  // namespace hitl
 
+namespace hitl {
+static DevSwitches g_dev;
+const DevSwitches& dev_switches() { return g_dev; }
+void read_dev_switches() {
+  DevSwitches d;
+  auto on = [](const char* name) { return std::getenv(name) != nullptr; };
+  auto num = [](const char* name, long long dflt) { const char* e = std::getenv(name); return e ? std::atoll(e) : dflt; };
+  d.timing = on("HITL_TIMING"); d.event_sync = on("HITL_EVENT_SYNC"); d.cr_legacy = on("HITL_CR_LEGACY");
+  d.cr_unfused_build = on("HITL_CR_UNFUSED_BUILD"); d.stf_addr64 = on("HITL_STF_ADDR64"); d.force_dist = on("HITL_FORCE_DIST");
+  d.force_rccl = on("HITL_FORCE_RCCL"); d.host_lm = on("HITL_HOST_LM");
+  d.stf_variant = (int)num("HITL_STF_VARIANT", 0);
+  d.kd_block = (int)num("HITL_KD_BLOCK", d.kd_block);
+  d.kd_refill = (int)std::max(1ll, std::min(64ll, num("HITL_KD_REFILL", d.kd_refill)));
+  d.cand_tile_bytes = (size_t)std::max(1ll, num("HITL_CAND_TILE_BYTES", (long long)d.cand_tile_bytes));
+  if (const char* e = std::getenv("HITL_CR_PLAN"))
+    for (const char* q = e; *q && d.cr_plan_n < 16;) { d.cr_plan[d.cr_plan_n++] = std::atoi(q); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
+  g_dev = d;
+}
+}  // namespace hitl
+
 // =========================================================================================
 // C ABI
 // =========================================================================================
@@ -430,6 +450,7 @@ void hitl_options_default(hitl_options* o) {
   o->rank = 0;
   o->world_size = 1;
   o->timing_level = 1;
+  o->kd_tree_search = 1;          // the reference's own search (BuildKDTrees + FindNearestPointNormal); 0 = the brute-force definition
   o->rccl_unique_id = nullptr;
 }
 
@@ -469,6 +490,7 @@ int hitl_solver_create(const hitl_options* opt, hitl_solver** out) {
   hitl_options o;
   if (opt) o = *opt; else hitl_options_default(&o);
   if (o.abi_version != HITL_ABI_VERSION) return fail(HITL_ERR_INVALID_ARGUMENT, "hitl_options.abi_version mismatch");
+  read_dev_switches();
   if (o.world_size < 1 || o.rank < 0 || o.rank >= o.world_size) return fail(HITL_ERR_INVALID_ARGUMENT, "bad rank/world_size");
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
@@ -484,11 +506,12 @@ int hitl_solver_create(const hitl_options* opt, hitl_solver** out) {
   for (hipEvent_t* e : {&s->ev0, &s->ev1, &s->ev2, &s->ev3, &s->ev_sync})
     if (hipEventCreate(e) != hipSuccess) return bail(HITL_ERR_HIP, "hipEventCreate failed");
   if (hipHostMalloc((void**)&s->h_scalars, sizeof(double) * kNumScalars) != hipSuccess) return bail(HITL_ERR_HIP, "hipHostMalloc failed");
+  std::memset(s->h_scalars, 0, sizeof(double) * kNumScalars);     // a recycled pinned block may hold an old sequence word (spin_sync polls it)
   if (s->d_scalars.resize(kNumScalars) != HITL_OK) return bail(HITL_ERR_OUT_OF_MEMORY, "hipMalloc failed");
   s->rank = o.rank;
   s->world = o.world_size;
-  s->force_dist = std::getenv("HITL_FORCE_DIST") != nullptr;
-  if ((o.world_size > 1 || std::getenv("HITL_FORCE_RCCL")) && o.rccl_unique_id != nullptr) {
+  s->force_dist = dev_switches().force_dist;
+  if ((o.world_size > 1 || dev_switches().force_rccl) && o.rccl_unique_id != nullptr) {
     ncclUniqueId id;
     static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
     std::memcpy(&id, o.rccl_unique_id, sizeof(id));
@@ -700,6 +723,17 @@ int hitl_solver_set_correspondences(hitl_solver* s, int64_t n_pairs, const int32
   TRY(s->match_off.upload(s->h_match_off, st)); TRY(s->matches.upload(packed, st));
   HIP_TRY(hipStreamSynchronize(st));
   return build_pair_structures(s);
+}
+
+int hitl_solver_get_kd_trees(hitl_solver* s, float* pts4, uint32_t* meta) {
+  if (!s) return fail(HITL_ERR_INVALID_ARGUMENT, "null solver");
+  if (s->n <= 0) return fail(HITL_ERR_INVALID_ARGUMENT, "get_kd_trees: no map set");
+  HIP_TRY(hipSetDevice(s->device));
+  TRY(ensure_kd_trees(s));
+  if (pts4 && s->n_obs > 0) HIP_TRY(hipMemcpyAsync(pts4, s->kd_pts.p, sizeof(float4) * (size_t)s->n_obs, hipMemcpyDeviceToHost, s->stream));
+  if (meta && s->n_obs > 0) HIP_TRY(hipMemcpyAsync(meta, s->kd_meta.p, sizeof(uint32_t) * (size_t)s->n_obs, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return HITL_OK;
 }
 
 int hitl_solver_get_correspondence_counts(hitl_solver* s, int64_t* n_pairs, int64_t* n_matches) {

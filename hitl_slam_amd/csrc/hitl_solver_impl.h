@@ -165,5 +165,6 @@ int comm_allgather_dev(hitl_solver* s, const void* send_dev, void* recv_host, in
 int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float* poses_global, float* poses_out, hitl_summary* summary);
 // hitl_corr.cpp
 int find_correspondences(hitl_solver* s, const float* poses, int64_t window);
+int ensure_kd_trees(hitl_solver* s);     // BuildKDTrees: once per resident map
 
 }  // namespace hitl

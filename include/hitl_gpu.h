@@ -117,12 +117,13 @@ typedef struct hitl_options {
    * 1 (default) = every 4th k_linearize_stf launch is bracketed (linearize_ms over linearize_timed_calls launches),
    * no linear-solver timing; 2 = every launch bracketed and linear_solver_ms filled. */
   int64_t timing_level;
-  /* hitl_solver_find_correspondences: 0 (default) = the brute-force definition of FindNearestPointNormal (among the
-   * target points inside the Euclidean gate, the smallest point-to-plane distance, first index on ties); 1 = the
-   * reference's own per-scan KD-trees and pruned walk (BuildKDTrees, JointOptimization.cpp:514-537;
-   * perception_tools/kdtree.cpp:37-197) reproduced bit for bit -- std::sort's tie order taken as the stable one.  The
-   * walk prunes with the plane distance and therefore returns a different, tree-dependent winner wherever several
-   * target points score almost equally (flat walls): use 1 when the index sets must be the reference's. */
+  /* hitl_solver_find_correspondences: 1 (default) = the reference's own per-scan KD-trees and pruned walk (BuildKDTrees,
+   * JointOptimization.cpp:514-537; perception_tools/kdtree.cpp:37-197) reproduced bit for bit -- std::sort's tie order
+   * taken as the stable one.  The walk prunes with the plane distance and therefore returns a tree-dependent winner
+   * wherever several target points score almost equally (flat walls); these are the index sets JointOpt::Run computes.
+   * 0 = the brute-force definition of FindNearestPointNormal (among the target points inside the Euclidean gate, the
+   * smallest point-to-plane distance, first index on ties): tree-independent, a different set on ~40 % of the matches of
+   * a corridor map, converged poses up to 3e-3 m away from the reference's. */
   int64_t kd_tree_search;
   int64_t reserved[1];
 } hitl_options;
@@ -182,6 +183,14 @@ int hitl_solver_set_human_constraints(hitl_solver*, int64_t n, const hitl_human_
  * is matched against target poses j in [i-window, i+window], j != i, ascending; window <= 0
  * or >= n_poses reproduces the reference's all-pairs search. */
 int hitl_solver_find_correspondences(hitl_solver*, const float* poses_xyt, int64_t window);
+
+/* Replaces: BuildKDTrees (JointOptimization.cpp:514-537) + KDTree::BuildKDTree (perception_tools/kdtree.cpp:37-139), read
+ * back.  Builds the per-scan trees of the resident map if they do not exist yet (they are built once per map, like
+ * `kdtrees_.size() == 0` at :1307) and copies them out in the library's pointer-free layout: the tree of scan i occupies
+ * the scan's own range [obs_offset[i], obs_offset[i+1]); the node of a sub-range [lo, lo + n) sits at lo + n / 2, its
+ * children are the nodes of [lo, lo + n / 2) and [lo + n / 2 + 1, lo + n).  pts4[4*p ..] = (x, y, nx, ny) of the node's
+ * KDNodeValue, meta[p] = KDNodeValue::index | splitting_dimension_ << 16.  Either output may be NULL. */
+int hitl_solver_get_kd_trees(hitl_solver*, float* pts4 /* n_obs * 4 */, uint32_t* meta /* n_obs */);
 
 /* Install a correspondence set directly (parity tests; == point_point_glob_correspondences_,
  * vector_mapping.h:102-119 as index pairs).  Directed pairs p: source pose pair_src[p],

@@ -56,7 +56,12 @@ def small_problem():
     return Problem(60, 90, ppf=30)
 
 
-def oracle_corr(prob, window=None, method=0):
+# the oracle's search method that matches the product's default (hitl_options.kd_tree_search = 1): the reference's own
+# KD-tree walk (method 1); method 0 is the brute-force definition (kd_tree_search = 0)
+REF_SEARCH = 1
+
+
+def oracle_corr(prob, window=None, method=REF_SEARCH):
     from oracle import hitl_oracle as O
     o = O.OracleSolver()
     prob.load(o)

@@ -58,7 +58,7 @@ def test_config3_figure8_with_loop_and_colinear_constraints(fig8, mode):
         s.set_human_constraints(rows)
     if mode == abi.MODE_JOINT:
         gpu.find_correspondences(g["poses"], 0)            # all pairs, like the reference
-        orc.find_correspondences(g["poses"], 0, 0)
+        orc.find_correspondences(g["poses"], 0, 1)
         cg, co = gpu.get_correspondences(), orc.get_correspondences()
         for a, b in zip(cg, co):
             assert np.array_equal(a, b)
@@ -95,7 +95,7 @@ def test_config2_corridor_1k_x_360_two_colinear_constraints():
         s.set_map(off, px, py, nx, ny, cov)
         s.set_human_constraints(rows)
     gpu.find_correspondences(init, 3)
-    orc.find_correspondences(init, 3, 0)
+    orc.find_correspondences(init, 3, 1)
     for a, b in zip(gpu.get_correspondences(), orc.get_correspondences()):
         assert np.array_equal(a, b)
     pg, sg = gpu.solve(H.MODE_JOINT, init)

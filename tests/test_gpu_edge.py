@@ -82,7 +82,7 @@ def test_option_variants(variant):
     for s in (g, o):
         prob.load(s)
     g.find_correspondences(prob.init, 3)
-    o.find_correspondences(prob.init, 3, 0)
+    o.find_correspondences(prob.init, 3, 1)
     for a, b in zip(g.get_correspondences(), o.get_correspondences()):
         assert np.array_equal(a, b)
     _check(g, o, H.MODE_JOINT, prob.init)
@@ -136,7 +136,7 @@ def test_long_scans():
     g, o = H.Solver(), O.OracleSolver()
     prob.load(g); prob.load(o)
     g.find_correspondences(prob.init, 2)
-    o.find_correspondences(prob.init, 2, 0)
+    o.find_correspondences(prob.init, 2, 1)
     for a, b in zip(g.get_correspondences(), o.get_correspondences()):
         assert np.array_equal(a, b)
     pg, sg = g.solve(H.MODE_JOINT, prob.init)
@@ -187,7 +187,7 @@ def test_cyclic_reduction_stage_boundaries(mode, n):
     g, o = _both()
     prob.load(g); prob.load(o)
     if mode == 2:
-        o.find_correspondences(prob.init, 3, 0)
+        o.find_correspondences(prob.init, 3, 1)
         g.set_correspondences(*o.get_correspondences())
     pg, sg = _check(g, o, mode, prob.init)
     assert sg.termination != 2
@@ -209,7 +209,7 @@ def test_pcg_runs_to_tolerance_behind_a_weak_preconditioner():
     assert opt.max_linear_iterations == 500
     g, o = H.Solver(opt), O.OracleSolver(opt)
     prob.load(g); prob.load(o)
-    o.find_correspondences(prob.init, 3, 0)
+    o.find_correspondences(prob.init, 3, 1)
     g.set_correspondences(*o.get_correspondences())
     pg, sg = g.solve(2, prob.init)
     po, so = o.solve(2, prob.init)
@@ -232,7 +232,7 @@ def test_pcg_preconditioner_at_stage_boundaries(n, band):
     opt.max_band_poses = band
     g, o = H.Solver(opt), O.OracleSolver(opt)
     prob.load(g); prob.load(o)
-    o.find_correspondences(prob.init, band + 2, 0)
+    o.find_correspondences(prob.init, band + 2, 1)
     g.set_correspondences(*o.get_correspondences())
     pg, sg = _check(g, o, 2, prob.init)
     assert sg.num_offband_pairs > 0 and sg.linear_iterations > sg.iterations

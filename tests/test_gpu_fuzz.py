@@ -30,7 +30,7 @@ def test_seeded_problem(n, obs, ppf, window, kind, groups, seed):
     prob.load(g)
     prob.load(o)
     g.find_correspondences(prob.init, window)
-    o.find_correspondences(prob.init, window, 0)
+    o.find_correspondences(prob.init, window, 1)
     cg, co = g.get_correspondences(), o.get_correspondences()
     for a, b in zip(cg, co):
         assert np.array_equal(a, b)

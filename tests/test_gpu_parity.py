@@ -51,12 +51,20 @@ def test_linearize_matches_oracle(small_problem, mode):
         assert _relerr(jg, jo) <= 1e-10
 
 
-def test_matcher_bit_exact_vs_bruteforce_definition(small_problem):
+@pytest.mark.parametrize("kd", [1, 0])
+def test_matcher_bit_exact(small_problem, kd):
+    """kd_tree_search = 1 (default): the reference's trees + pruned walk; 0: the brute-force definition.  Index sets bit for
+    bit against the oracle's method of the same name, windowed (target-major kernel for the walk: 2 x window <= cap) and all
+    pairs (source-major kernels, per-point counters across the targets)."""
+    import hitl_slam_amd as H
     prob = small_problem
-    g, o = prob.load(_gpu()), prob.load(_oracle())
-    for window in (1, 3, 0):                              # 0 = all pairs (the reference's search)
+    opt = H.default_options()
+    assert opt.kd_tree_search == 1
+    opt.kd_tree_search = kd
+    g, o = prob.load(_gpu(opt)), prob.load(_oracle())
+    for window in (1, 3, 4, 0):                           # 0 = all pairs (the reference's search); 4: 8 slots > cap 6
         g.find_correspondences(prob.init, window)
-        o.find_correspondences(prob.init, window, 0)
+        o.find_correspondences(prob.init, window, kd)
         for a, b in zip(g.get_correspondences(), o.get_correspondences()):
             assert np.array_equal(a, b)
 
@@ -223,7 +231,7 @@ def test_ragged_and_empty_scans():
     prob.px, prob.py, prob.nx, prob.ny = (a[keep] for a in (prob.px, prob.py, prob.nx, prob.ny))
     g, o = prob.load(_gpu()), prob.load(_oracle())
     g.find_correspondences(prob.init, 3)
-    o.find_correspondences(prob.init, 3, 0)
+    o.find_correspondences(prob.init, 3, 1)
     cg, co = g.get_correspondences(), o.get_correspondences()
     for a, b in zip(cg, co):
         assert np.array_equal(a, b)
@@ -387,7 +395,7 @@ def test_device_built_pair_tables_equal_the_host_built_ones(shape):
     prob = Problem(n, m, ppf=ppf, groups=groups)
     g, o = prob.load(_gpu()), prob.load(_oracle())
     g.find_correspondences(prob.init, window)            # device-built tables
-    o.find_correspondences(prob.init, window, 0)
+    o.find_correspondences(prob.init, window, 1)
     rng = np.random.default_rng(11)
     x = (prob.init + 0.01 * rng.standard_normal(prob.init.shape)).astype(np.float32)
     c_dev, g_dev = g.evaluate(2, x)                      # before any host mirror of the lists exists

@@ -60,7 +60,7 @@ def test_shim_reproduces_the_oracle(driver, case, mode):
     o.set_map(g["obs_offset"], g["px"], g["py"], g["nx"], g["ny"], g["cov9"])
     o.set_human_constraints(hc_rows(rows))
     if mode:
-        o.find_correspondences(g["poses"], 3, 0)
+        o.find_correspondences(g["poses"], 3, 1)
     po, so = o.solve(mode, g["poses"])
     fields = r.stdout.split()
     assert int(fields[1]) == so.iterations and int(fields[3]) == so.num_hc_residuals and int(fields[7]) == 3 * len(po)

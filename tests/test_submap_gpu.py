@@ -43,7 +43,7 @@ def test_submaps_equal_the_global_solve(tmp_path, mode, ppf, world, moments, cut
 
     prob = Problem(120, 48, ppf=ppf, groups=2, kind=0)
     o = prob.load(O.OracleSolver())
-    o.find_correspondences(prob.init, 3, 0)
+    o.find_correspondences(prob.init, 3, 1)
     ops = o.get_correspondences()
     # the pairs reported by the ranks owning their source pose tile the global set exactly
     src = np.concatenate([np.array(x["pairs"][0], np.int32) for x in res])

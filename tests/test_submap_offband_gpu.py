@@ -49,7 +49,7 @@ def test_offband_submaps_equal_the_global_solve(tmp_path, case):
 
     prob = Problem(n_per * world, 48, ppf=ppf, groups=2, kind=0)
     o = prob.load(O.OracleSolver())
-    o.find_correspondences(prob.init, window, 0)
+    o.find_correspondences(prob.init, window, 1)
     ops = o.get_correspondences()
     src = np.concatenate([np.array(x["pairs"][0], np.int32) for x in res])
     tgt = np.concatenate([np.array(x["pairs"][1], np.int32) for x in res])
