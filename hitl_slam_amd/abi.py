@@ -90,7 +90,7 @@ class Options(C.Structure):
         ("stf_moments", C.c_int64),
         ("timing_level", C.c_int64),
         ("kd_tree_search", C.c_int64),
-        ("reserved", C.c_int64 * 1),
+        ("tolerances_after_accept", C.c_int64),
     ]
 
 

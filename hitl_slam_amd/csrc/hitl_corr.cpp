@@ -44,14 +44,22 @@ static bool libm_sincos_exact() {
 
 // with_trig == false: t[6], t[7] are written by the mirrored candidate (j -> i), see find_correspondences
 static void make_rel_tf(const float* pi, const float* pj, const float* csi, const float* csj, float* t, bool with_trig = true) {
-  // RelativePoseTransform (JointOptimization.cpp:296-305) and the normal rotation at :603-605
-  // in fp32; R_j^T stands in for Eigen's general 2x2 inverse (fp32-rounding-level deviation).
+  // RelativePoseTransform (JointOptimization.cpp:296-305) and the normal rotation at :603-605 in fp32, in the operation
+  // order of the Eigen expression `target_tf.inverse(Eigen::Affine) * source_tf`: tf = Translation2Df * Rotation2Df (linear
+  // [[c, -s], [s, c]]); inverse(Affine) = 2x2 cofactor inverse with invdet = 1 / (m00 m11 - m10 m01) and translation
+  // -linear^-1 t; Transform * Transform: linear = L1 L2, translation = L1 t2 + t1; 2-term dot products a*b + c*d (this file
+  // is compiled with -ffp-contract=off).  Rounds 1-2 composed R_j^T (t_i - t_j) instead: the same map, different last bits.
   // cs = (cosf, sinf) of each pose angle, computed once per pose by the caller.
   const float ci = csi[0], si = csi[1], cj = csj[0], sj = csj[1];
-  t[0] = cj * ci + sj * si; t[1] = sj * ci - cj * si;
-  t[2] = cj * si - sj * ci; t[3] = sj * si + cj * ci;
-  const float dx = pi[0] - pj[0], dy = pi[1] - pj[1];
-  t[4] = cj * dx + sj * dy; t[5] = cj * dy - sj * dx;
+  const float nsj = -sj, nsi = -si;
+  const float det = cj * cj - sj * nsj;
+  const float invdet = 1.0f / det;
+  const float a00 = cj * invdet, a01 = (-nsj) * invdet, a10 = (-sj) * invdet, a11 = cj * invdet;
+  t[0] = a00 * ci + a01 * si; t[1] = a00 * nsi + a01 * ci;
+  t[2] = a10 * ci + a11 * si; t[3] = a10 * nsi + a11 * ci;
+  const float ix = (-a00) * pj[0] + (-a01) * pj[1], iy = (-a10) * pj[0] + (-a11) * pj[1];
+  t[4] = (a00 * pi[0] + a01 * pi[1]) + ix;
+  t[5] = (a10 * pi[0] + a11 * pi[1]) + iy;
   if (!with_trig) return;
   const float dth = (float)((double)pj[2] - (double)pi[2]);
   t[6] = cosf(dth); t[7] = sinf(dth);
@@ -60,7 +68,7 @@ static void make_rel_tf(const float* pi, const float* pj, const float* csi, cons
 int ensure_kd_trees(hitl_solver* s) {      // BuildKDTrees: once per map (JointOptimization.cpp:1307, kdtrees_.size() == 0)
   if (s->kd_built) return HITL_OK;
   if (kd_build_lds_bytes(s->max_scan) > (size_t)150 * 1024)
-    return fail(HITL_ERR_UNSUPPORTED, "kd_tree_search: a scan of " + std::to_string(s->max_scan) + " points exceeds the LDS budget of the tree build (limit ~3800 points)");
+    return fail(HITL_ERR_UNSUPPORTED, "kd_tree_search: a scan of " + std::to_string(s->max_scan) + " points exceeds the LDS budget of the tree build (limit ~8500 points)");
   int rc = s->kd_pts.resize((size_t)std::max<int64_t>(s->n_obs, 1));
   if (rc != HITL_OK) return rc;
   rc = s->kd_meta.resize((size_t)std::max<int64_t>(s->n_obs, 1));
@@ -85,16 +93,26 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
   if (window <= 0 || window > n) window = n;
   const int slots = (int)std::min<int64_t>(2 * window, std::max(n - 1, 1));
   const bool kd = s->opt.kd_tree_search != 0;
-  if (kd && (match_kd_lds_bytes(s->max_scan) > (size_t)150 * 1024 || kd_build_lds_bytes(s->max_scan) > (size_t)150 * 1024))
-    return fail(HITL_ERR_UNSUPPORTED, "find_correspondences (kd_tree_search): a scan of " + std::to_string(s->max_scan) + " points exceeds the LDS budget of the tree kernels (limit ~4000 points)");
+  MatchParams mp;
+  mp.thr = s->opt.point_match_threshold;
+  mp.min_cos = cosf(s->opt.max_stf_angle_error);   // JointOptimization.cpp:564
+  mp.cap = s->opt.max_correspondences_per_point;
+  mp.skip = std::max(s->opt.num_skip_readings, 1);
+  const int band_cap = std::min(std::max((int)s->opt.max_band_poses, 1), kMaxBandPoses);
+  const bool device_tables = window <= band_cap;
+  const bool kd_tgt = kd && device_tables && match_kd_tgt_applies(slots, (int)window, mp);
+  if (kd) {
+    const size_t need = kd_tgt ? match_kd_tgt_lds_bytes(s->max_scan, 64) : match_kd_lds_bytes(s->max_scan);
+    if (need > (size_t)150 * 1024 || kd_build_lds_bytes(s->max_scan) > (size_t)150 * 1024)
+      return fail(HITL_ERR_UNSUPPORTED, "find_correspondences (kd_tree_search): a scan of " + std::to_string(s->max_scan) +
+                  " points exceeds the LDS budget of the tree kernels (limit ~7300 points for windowed searches, ~5000 for wider ones)");
+  }
   if (match_lds_bytes(s->max_scan) > (size_t)160 * 1024)
     return fail(HITL_ERR_UNSUPPORTED, "find_correspondences: a scan of " + std::to_string(s->max_scan) +
                 " points does not fit the 160 KB of LDS the matcher stages a target scan in (limit ~7900 points)");
   // The candidate table (u16 per candidate and source point) of a window inside the band is small (<= 8 slots per pose);
   // wider windows -- the reference's all-pairs search above all -- are cut into tiles of source poses so that the table
   // stays below a budget whatever the map (all slots of a source pose share a tile: the per-point cap counts across them).
-  const int band_cap = std::min(std::max((int)s->opt.max_band_poses, 1), kMaxBandPoses);
-  const bool device_tables = window <= band_cap;
   const size_t tile_budget = dev_switches().cand_tile_bytes;     // tests force several tiles
   const size_t per_pose = (size_t)slots * s->max_scan * sizeof(uint16_t);
   const int tile = device_tables ? n : (int)std::min<size_t>((size_t)n, std::max<size_t>(1, tile_budget / std::max<size_t>(per_pose, 1)));
@@ -160,11 +178,6 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
   DevArray<uint16_t>& d_table = s->d_cand_table;
   int rc = HITL_OK;
 #define TRYC(expr) do { rc = (expr); if (rc != HITL_OK) return rc; } while (0)
-  MatchParams mp;
-  mp.thr = s->opt.point_match_threshold;
-  mp.min_cos = cosf(s->opt.max_stf_angle_error);   // JointOptimization.cpp:564
-  mp.cap = s->opt.max_correspondences_per_point;
-  mp.skip = std::max(s->opt.num_skip_readings, 1);
   const MapView mv = s->map_view();
   if (kd && !s->kd_built) {
     TRYC(ensure_kd_trees(s));
@@ -177,7 +190,7 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
     TRYC(d_counts.resize((size_t)cnt * slots));
     TRYC(d_counts.zero(st));
     TRYC(d_table.resize((size_t)cnt * slots * s->max_scan));
-    if (kd && device_tables && match_kd_tgt_applies(slots, (int)window, mp)) {
+    if (kd_tgt) {
       // the per-point cap cannot bind (slots <= cap): every (source, target) pair is independent, one workgroup per target tree
       const int kd_block = dev_switches().kd_block, kd_refill = dev_switches().kd_refill;
       if (mp.skip > 1 && hipMemsetAsync(d_table.p, 0xFF, sizeof(uint16_t) * (size_t)cnt * slots * s->max_scan, st) != hipSuccess)

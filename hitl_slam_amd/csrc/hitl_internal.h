@@ -195,6 +195,7 @@ void launch_match(hipStream_t st, const MapView& map, int max_scan, int slots, c
 // kd_tree_search: the reference's own trees and pruned walk (kdtree.cpp:37-197), bit for bit
 size_t kd_build_lds_bytes(int max_scan);
 size_t match_kd_lds_bytes(int max_scan);
+size_t match_kd_tgt_lds_bytes(int max_scan, int block);
 void launch_kd_build(hipStream_t st, const MapView& map, int max_scan, float4* kd_pts, uint32_t* kd_meta);
 void launch_match_kd(hipStream_t st, const MapView& map, int max_scan, int slots, const int* cand_tgt, const float* cand_tf, MatchParams mp,
                      const float4* kd_pts, const uint32_t* kd_meta, uint16_t* table, int* counts, int i0 = 0, int n_tile = -1);

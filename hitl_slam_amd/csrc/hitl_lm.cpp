@@ -688,9 +688,12 @@ int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float* poses
     else if (have_spec) lr = lr_spec;
     else TRY(run_linearize_dist(s, fv, xcand, cur ^ 1, &lr));
     S.linearize_ms += lr.stf_ms; S.linearize_calls++; S.linearize_timed_calls += lr.timed;
-    if (std::sqrt(step2) <= o.parameter_tolerance * (std::sqrt(xn2) + o.parameter_tolerance)) { term = HITL_CONVERGENCE; break; }
+    const bool late = o.tolerances_after_accept != 0;      // hitl_options: where the two step tolerances are tested
+    const bool par_tol = std::sqrt(step2) <= o.parameter_tolerance * (std::sqrt(xn2) + o.parameter_tolerance);
+    if (!late && par_tol) { term = HITL_CONVERGENCE; break; }
     const double cost_change = cost - lr.cost;
-    if (std::fabs(cost_change) <= o.function_tolerance * cost) { term = HITL_CONVERGENCE; break; }
+    const bool fun_tol = std::fabs(cost_change) <= o.function_tolerance * cost;
+    if (!late && fun_tol) { term = HITL_CONVERGENCE; break; }
     const double rho = cost_change / mcc;
     if (rho > o.min_relative_decrease) {
       ++S.successful_steps;
@@ -698,6 +701,7 @@ int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float* poses
       cur ^= 1;
       cost = lr.cost; gmax = lr.gmax;
       if (gmax <= o.gradient_tolerance) { term = HITL_CONVERGENCE; break; }
+      if (late && (par_tol || fun_tol)) { term = HITL_CONVERGENCE; break; }
       const double q = 2.0 * rho - 1.0;
       radius = std::min(o.max_trust_region_radius, radius / std::max(1.0 / 3.0, 1.0 - q * q * q));
       decrease_factor = 2.0;

@@ -138,18 +138,17 @@ constexpr int kKdBlock = 256;
 
 // one workgroup per scan; level by level: split plane per live segment (one thread walks the segment: the fp32 sums of
 // kdtree.cpp:40-58 are order-dependent), stable rank sort inside every segment, the median becomes a node.
+// LDS: the scan's coordinates stay where they are (ox, oy); what is sorted is a 16-bit permutation (cur -> nxt), so a scan
+// costs 18 bytes per point and scans of ~8000 points fit (the limit of the brute-force matcher's staging is 7900).
 __global__ __launch_bounds__(kKdBlock) void k_kd_build(MapView map, int max_scan, float4* __restrict__ kd_pts, uint32_t* __restrict__ kd_meta) {
   extern __shared__ float s_raw[];
-  float* ax = s_raw;                       // current order
-  float* ay = ax + max_scan;
-  int* aid = (int*)(ay + max_scan);
-  float* bx = (float*)(aid + max_scan);    // next order
-  float* by = bx + max_scan;
-  int* bid = (int*)(by + max_scan);
-  int* seg_lo = bid + max_scan;            // segment of the element at this position (n == 0: already a node)
-  int* seg_n = seg_lo + max_scan;
-  int* s_plane = seg_n + max_scan;         // split plane of the live segment that starts at this position
-  int* s_split = s_plane + max_scan;       // split plane of the node sitting at this position
+  float* ox = s_raw;                                    // coordinates by original index
+  float* oy = ox + max_scan;
+  uint32_t* seg = (uint32_t*)(oy + max_scan);           // lo | n << 16 of the segment the element at this position is in (n == 0: already a node)
+  uint16_t* cur = (uint16_t*)(seg + max_scan);          // original index of the element at this position
+  uint16_t* nxt = cur + max_scan;
+  unsigned char* s_plane = (unsigned char*)(nxt + max_scan);   // split plane of the live segment that starts at this position
+  unsigned char* s_split = s_plane + max_scan;                 // split plane of the node sitting at this position
   __shared__ int s_live;
   const int i = blockIdx.x;
   const int64_t o = map.obs_off[i];
@@ -157,7 +156,7 @@ __global__ __launch_bounds__(kKdBlock) void k_kd_build(MapView map, int max_scan
   if (m <= 0) return;
   for (int p = threadIdx.x; p < m; p += kKdBlock) {
     const float4 v = map.obs[o + p];
-    ax[p] = v.x; ay[p] = v.y; aid[p] = p; seg_lo[p] = 0; seg_n[p] = m; s_plane[p] = 0; s_split[p] = 0;
+    ox[p] = v.x; oy[p] = v.y; cur[p] = (uint16_t)p; seg[p] = (uint32_t)m << 16; s_plane[p] = 0; s_split[p] = 0;
   }
   __syncthreads();
   for (;;) {
@@ -165,21 +164,23 @@ __global__ __launch_bounds__(kKdBlock) void k_kd_build(MapView map, int max_scan
     __syncthreads();
     // 1. split plane of every live segment (its first position does the sequential sums)
     for (int p = threadIdx.x; p < m; p += kKdBlock) {
-      const int n = seg_n[p];
-      if (n > 0 && seg_lo[p] == p) {
+      const uint32_t sg = seg[p];
+      const int n = (int)(sg >> 16);
+      if (n > 0 && (int)(sg & 0xffffu) == p) {
         float mx = 0.0f, my = 0.0f;
-        for (int q = p; q < p + n; ++q) { mx = mx + ax[q]; my = my + ay[q]; }
+        for (int q = p; q < p + n; ++q) { const int e = cur[q]; mx = mx + ox[e]; my = my + oy[e]; }
         mx = mx / (float)n; my = my / (float)n;
         float sx = 0.0f, sy = 0.0f;
         for (int q = p; q < p + n; ++q) {
-          sx = sx + (ax[q] - mx) * (ax[q] - mx);
-          sy = sy + (ay[q] - my) * (ay[q] - my);
+          const int e = cur[q];
+          sx = sx + (ox[e] - mx) * (ox[e] - mx);
+          sy = sy + (oy[e] - my) * (oy[e] - my);
         }
         int plane = 0;
         float best = 0.0f;
         if (sx > best) { plane = 0; best = sx; }
         if (sy > best) { plane = 1; best = sy; }
-        s_plane[p] = plane;
+        s_plane[p] = (unsigned char)plane;
         s_live = 1;
       }
     }
@@ -187,44 +188,48 @@ __global__ __launch_bounds__(kKdBlock) void k_kd_build(MapView map, int max_scan
     if (!s_live) break;
     // 2. stable sort of every live segment by its split coordinate: new position = lo + #{smaller, or equal and earlier}
     for (int p = threadIdx.x; p < m; p += kKdBlock) {
-      const int n = seg_n[p];
+      const uint32_t sg = seg[p];
+      const int n = (int)(sg >> 16);
       int dst = p;
       if (n > 0) {
-        const int lo = seg_lo[p];
-        const int plane = s_plane[lo];
-        const float key = plane ? ay[p] : ax[p];
+        const int lo = (int)(sg & 0xffffu);
+        const float* co = s_plane[lo] ? oy : ox;
+        const float key = co[cur[p]];
         int rank = 0;
         for (int q = lo; q < lo + n; ++q) {
-          const float kq = plane ? ay[q] : ax[q];
+          const float kq = co[cur[q]];
           rank += (kq < key || (kq == key && q < p)) ? 1 : 0;
         }
         dst = lo + rank;
       }
-      bx[dst] = ax[p]; by[dst] = ay[p]; bid[dst] = aid[p];
+      nxt[dst] = cur[p];
     }
     __syncthreads();
     // 3. the median of a segment becomes its node; the two halves are the next level's segments
     for (int p = threadIdx.x; p < m; p += kKdBlock) {
-      const int n = seg_n[p];
-      ax[p] = bx[p]; ay[p] = by[p]; aid[p] = bid[p];
+      const uint32_t sg = seg[p];
+      const int n = (int)(sg >> 16);
+      cur[p] = nxt[p];
       if (n > 0) {
-        const int lo = seg_lo[p], ind = n / 2;
-        if (p == lo + ind) { s_split[p] = s_plane[lo]; seg_n[p] = 0; }
-        else if (p < lo + ind) { seg_n[p] = ind; }
-        else { seg_lo[p] = lo + ind + 1; seg_n[p] = n - ind - 1; }
+        const int lo = (int)(sg & 0xffffu), ind = n / 2;
+        if (p == lo + ind) { s_split[p] = s_plane[lo]; seg[p] = (uint32_t)lo; }
+        else if (p < lo + ind) { seg[p] = (uint32_t)lo | ((uint32_t)ind << 16); }
+        else { seg[p] = (uint32_t)(lo + ind + 1) | ((uint32_t)(n - ind - 1) << 16); }
       }
     }
     __syncthreads();
   }
   for (int p = threadIdx.x; p < m; p += kKdBlock) {
-    kd_pts[o + p] = map.obs[o + aid[p]];
-    kd_meta[o + p] = (uint32_t)aid[p] | ((uint32_t)s_split[p] << 16);
+    const int e = cur[p];
+    kd_pts[o + p] = map.obs[o + e];
+    kd_meta[o + p] = (uint32_t)e | ((uint32_t)s_split[p] << 16);
   }
 }
 
-size_t kd_build_lds_bytes(int max_scan) { return (size_t)max_scan * 10 * sizeof(float); }
+size_t kd_build_lds_bytes(int max_scan) { return (size_t)((max_scan + 3) & ~3) * 18; }
 
 void launch_kd_build(hipStream_t st, const MapView& map, int max_scan, float4* kd_pts, uint32_t* kd_meta) {
+  max_scan = (max_scan + 3) & ~3;            // keeps the 4-, 2- and 1-byte arrays aligned behind one another
   const size_t lds = kd_build_lds_bytes(max_scan);
   if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kd_build), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k_kd_build, dim3(map.n_poses), dim3(kKdBlock), lds, st, map, max_scan, kd_pts, kd_meta);
@@ -427,14 +432,19 @@ static void launch_match_kd_tgt_t(hipStream_t st, const MapView& map, int max_sc
                                   MatchParams mp, const float4* kd_pts, const uint32_t* kd_meta, uint16_t* table, int* counts) {
   const int chunk = (map.n_poses + 7) / 8;
   const int depth = kd_depth(max_scan);
-  const size_t lds = (size_t)max_scan * (sizeof(float4) + sizeof(uint32_t)) + (size_t)(depth + 1) * BLOCK * 8;
+  const size_t lds = match_kd_tgt_lds_bytes(max_scan, BLOCK);
   if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_match_kd_tgt<BLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k_match_kd_tgt<BLOCK>, dim3(8 * chunk), dim3(BLOCK), lds, st, map, chunk, max_scan, slots, window, depth, refill_min, cand_tf, mp,
                      kd_pts, kd_meta, table, counts);
 }
 
+size_t match_kd_tgt_lds_bytes(int max_scan, int block) {
+  return (size_t)max_scan * (sizeof(float4) + sizeof(uint32_t)) + (size_t)(kd_depth(max_scan) + 1) * block * 8;
+}
+
 void launch_match_kd_tgt(hipStream_t st, const MapView& map, int max_scan, int slots, int window, const float* cand_tf, MatchParams mp,
                          const float4* kd_pts, const uint32_t* kd_meta, uint16_t* table, int* counts, int block, int refill_min) {
+  while (block > 64 && match_kd_tgt_lds_bytes(max_scan, block) > (size_t)150 * 1024) block /= 2;     // long scans: fewer lanes share the tree
   if (block == 64) launch_match_kd_tgt_t<64>(st, map, max_scan, slots, window, refill_min, cand_tf, mp, kd_pts, kd_meta, table, counts);
   else if (block == 256) launch_match_kd_tgt_t<256>(st, map, max_scan, slots, window, refill_min, cand_tf, mp, kd_pts, kd_meta, table, counts);
   else launch_match_kd_tgt_t<128>(st, map, max_scan, slots, window, refill_min, cand_tf, mp, kd_pts, kd_meta, table, counts);

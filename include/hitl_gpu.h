@@ -125,7 +125,12 @@ typedef struct hitl_options {
    * smallest point-to-plane distance, first index on ties): tree-independent, a different set on ~40 % of the matches of
    * a corridor map, converged poses up to 3e-3 m away from the reference's. */
   int64_t kd_tree_search;
-  int64_t reserved[1];
+  /* Where the Levenberg-Marquardt loop tests parameter_tolerance and function_tolerance.  0 (default): on the candidate,
+   * BEFORE the accept test; reaching one ends the solve at the PRE-step state (the order of Ceres'
+   * TrustRegionMinimizer: ...ParameterToleranceReached / FunctionToleranceReached, then IsStepSuccessful).  1: after an
+   * accepted step, on the updated state.  The reference's Ceres version is not pinned (CMakeLists.txt:83); the two orders
+   * differ in the last step of a solve only.  tests/golden/ holds fixtures for both. */
+  int64_t tolerances_after_accept;
 } hitl_options;
 
 /* Per-solve report (what Ceres' Solver::Summary gives the caller at

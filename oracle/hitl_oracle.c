@@ -438,18 +438,26 @@ int orc_get_correspondences(orc_solver* s, int32_t* ps, int32_t* pt, int64_t* mo
 /* ===================================================================================== */
 /* correspondence search                                                                  */
 /* ===================================================================================== */
-/* Relative transform source i -> target j (JointOptimization.cpp:296-305, :601-605) in fp32.
- * Documented deviation: Eigen's Affine2f inverse uses the general 2x2 inverse of the
- * rotation; here R_j^T is used (differs at fp32 rounding level only). */
+/* Relative transform source i -> target j (JointOptimization.cpp:296-305, :601-605) in fp32, in the operation order of
+ * the Eigen expression `target_tf.inverse(Eigen::Affine) * source_tf` (round 3; rounds 1-2 used R_j^T (t_i - t_j), which
+ * is the same map but differs in the last bits -- up to ~1e-5 m at coordinates of 100 m, enough to flip near-ties):
+ *   tf = Translation2Df(x, y) * Rotation2Df(theta): linear [[c, -s], [s, c]], translation (x, y);
+ *   inverse(Affine): linear^-1 by the 2x2 cofactor formula with invdet = 1 / (m00 m11 - m10 m01), translation -linear^-1 t;
+ *   Transform * Transform: linear = L1 L2, translation = L1 t2 + t1; every 2-term dot product is a*b + c*d. */
 typedef struct { float m00, m01, m10, m11, tx, ty, cr, sr; } rel_tf;
 
 static rel_tf make_rel_tf(const float* pi, const float* pj) {
   rel_tf t;
   const float ci = cosf(pi[2]), si = sinf(pi[2]), cj = cosf(pj[2]), sj = sinf(pj[2]);
-  t.m00 = cj * ci + sj * si;  t.m01 = sj * ci - cj * si;
-  t.m10 = cj * si - sj * ci;  t.m11 = sj * si + cj * ci;
-  const float dx = pi[0] - pj[0], dy = pi[1] - pj[1];
-  t.tx = cj * dx + sj * dy;   t.ty = cj * dy - sj * dx;
+  const float nsj = -sj, nsi = -si;
+  const float det = cj * cj - sj * nsj;
+  const float invdet = 1.0f / det;
+  const float a00 = cj * invdet, a01 = (-nsj) * invdet, a10 = (-sj) * invdet, a11 = cj * invdet;     /* target linear^-1 */
+  t.m00 = a00 * ci + a01 * si;   t.m01 = a00 * nsi + a01 * ci;
+  t.m10 = a10 * ci + a11 * si;   t.m11 = a10 * nsi + a11 * ci;
+  const float ix = (-a00) * pj[0] + (-a01) * pj[1], iy = (-a10) * pj[0] + (-a11) * pj[1];            /* -linear^-1 * t_j */
+  t.tx = (a00 * pi[0] + a01 * pi[1]) + ix;
+  t.ty = (a10 * pi[0] + a11 * pi[1]) + iy;
   const float dth = (float)((double)pj[2] - (double)pi[2]);
   t.cr = cosf(dth); t.sr = sinf(dth);
   return t;
@@ -1078,9 +1086,12 @@ int orc_solve_f64(orc_solver* s, int32_t mode, const float* poses_in, double* x_
     tl = now_ms();
     linearize(s, mode, om, tgt, xc, cand);
     S.linearize_ms += now_ms() - tl; S.linearize_calls++;
-    if (sqrt(step2) <= o->parameter_tolerance * (sqrt(xn2) + o->parameter_tolerance)) { term = HITL_CONVERGENCE; break; }
+    const int late = o->tolerances_after_accept != 0;   /* hitl_options: test the two step tolerances after an accepted step instead */
+    const int par_tol = sqrt(step2) <= o->parameter_tolerance * (sqrt(xn2) + o->parameter_tolerance);
+    if (!late && par_tol) { term = HITL_CONVERGENCE; break; }
     const double cost_change = cur->cost - cand->cost;
-    if (fabs(cost_change) <= o->function_tolerance * cur->cost) { term = HITL_CONVERGENCE; break; }
+    const int fun_tol = fabs(cost_change) <= o->function_tolerance * cur->cost;
+    if (!late && fun_tol) { term = HITL_CONVERGENCE; break; }
     const double rho = cost_change / mcc;
     if (rho > o->min_relative_decrease) {
       ++S.successful_steps;
@@ -1088,6 +1099,7 @@ int orc_solve_f64(orc_solver* s, int32_t mode, const float* poses_in, double* x_
       lin_sys* tl2 = cur; cur = cand; cand = tl2;
       gmax = 0; for (int64_t i = 3; i < d; ++i) if (fabs(cur->g[i]) > gmax) gmax = fabs(cur->g[i]);
       if (gmax <= o->gradient_tolerance) { term = HITL_CONVERGENCE; break; }
+      if (late && (par_tol || fun_tol)) { term = HITL_CONVERGENCE; break; }
       const double q = 2.0 * rho - 1.0;
       double f = 1.0 - q * q * q; if (f < 1.0 / 3.0) f = 1.0 / 3.0;
       radius = radius / f; if (radius > o->max_trust_region_radius) radius = o->max_trust_region_radius;

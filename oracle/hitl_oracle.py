@@ -138,7 +138,8 @@ class OracleSolver(SolverBase):
         L.orc_assemble_dense.argtypes = [C.c_void_p, C.c_int32, _f32p, _f64p, _f64p, _f64p, _f64p]
         L.orc_set_use_jets.argtypes = [C.c_void_p, C.c_int]
 
-    def find_correspondences(self, poses_xyt, window, method=0):
+    def find_correspondences(self, poses_xyt, window, method=1):
+        """method 1 (default, like hitl_options.kd_tree_search = 1): the reference's KD-tree walk; 0: the brute-force definition."""
         pin = _as(poses_xyt, np.float32).reshape(-1)
         st = self._lib.orc_find_correspondences(self._h, _ptr(pin, _f32p), int(window), int(method))
         self._check(st, "create")

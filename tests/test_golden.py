@@ -1,7 +1,9 @@
-"""Committed golden fixtures (tests/golden/*.npz, made by tests/golden/make_golden.py from
-the oracle; the reference itself has none -- parity unpinned).  CPU: the oracle still
-reproduces them bit-for-bit in its index work and to 1e-12 in fp64.  GPU: the HIP path
-through the C ABI lands on them within the north-star tolerance."""
+"""Committed golden fixtures (tests/golden/*.npz).  Since round 3 they are emitted by tests/golden/mirror.py, an independent
+numpy restatement of the reference's path (literal autodiff functors, dense normal equations, the recursion of kdtree.cpp as
+written) that shares no code with the C oracle or the product; the reference itself has no vectors (parity unpinned).
+CPU: the C oracle reproduces them -- index sets bit for bit, fp64 to 1e-11, the whole Levenberg-Marquardt path iteration for
+iteration, under both orders of the tolerance tests (hitl_options.tolerances_after_accept).  GPU: the HIP path through the C
+ABI does the same within the north-star tolerance."""
 import glob
 import os
 
@@ -42,8 +44,13 @@ def _stf_components(z):
     return len({find(i) for i in range(n)})
 
 
-def _check(solver, z, lin_rtol, matcher):
-    if matcher is not None:
+def _check(solver, z, lin_rtol, matcher, prefix="solve", bf_matcher=None):
+    if bf_matcher is not None:                             # the brute-force definition of the query (kd_tree_search = 0)
+        bf_matcher(solver, z)
+        got = solver.get_correspondences()
+        for a, key in zip(got, ("pair_src", "pair_tgt", "match_offset", "src_idx", "tgt_idx")):
+            assert np.array_equal(a, z["bf_" + key].astype(a.dtype)), "bf_" + key
+    if matcher is not None:                                # the reference's KD-tree walk (the default)
         matcher(solver, z)
         got = solver.get_correspondences()
         for a, key in zip(got, ("pair_src", "pair_tgt", "match_offset", "src_idx", "tgt_idx")):
@@ -56,50 +63,66 @@ def _check(solver, z, lin_rtol, matcher):
             assert np.abs(pr - z["lin_pair_r_%d" % mode]).max() <= lin_rtol * np.abs(z["lin_pair_r_%d" % mode]).max()
             assert np.abs(pj - z["lin_pair_J_%d" % mode]).max() <= lin_rtol * np.abs(z["lin_pair_J_%d" % mode]).max()
         poses, summ = solver.solve(mode, z["init"])
-        exp = z["solve_summary_%d" % mode]
-        ec = z["solve_cost_%d" % mode]
+        exp = z["%s_summary_%d" % (prefix, mode)]
+        ec = z["%s_cost_%d" % (prefix, mode)]
         assert abs(summ.initial_cost - ec[0]) <= 1e-9 * ec[0]
         assert [summ.num_residuals, summ.num_hc_residuals] == exp.tolist()[3:]
         offband = int(np.abs(z["pair_src"].astype(np.int64) - z["pair_tgt"]).max()) > 4   # linear solve = PCG (1e-12), not the exact factorisation
-        if mode == abi.MODE_STF_ONLY and (offband or _stf_components(z) > 1):
+        if mode == abi.MODE_STF_ONLY and (offband or _stf_components(z) > 1 or exp[0] == abi.NO_CONVERGENCE):
             # The one case that is NOT held to the step-for-step bar.  Mode B is the dormant STF-only solve
-            # (JointOptimization.cpp:1156-1256: no odometry, only pose 0 held).  When the scan-overlap graph of the fixture has
-            # more than one connected component (two floors that share no overlap), every component that does not hold pose 0
-            # is a free rigid body: J^T J has a 3-dimensional null space per such component (shown on the oracle's dense
-            # Hessian in tests/test_gpu_parity.py).  The LM diagonal makes the linear systems solvable but leaves the step
-            # along those directions to rounding, so two exact solvers (banded Cholesky there, cyclic reduction / PCG here)
-            # drift apart over ~100 accept/reject decisions; the same holds when pose pairs outside the band send the linear
-            # solve through the PCG (relative residual 1e-12 instead of an exact factorisation) on this slowly converging
-            # problem.  Asserted: the cost level and a 1e-2 pose bar.  On connected maps with every pair inside the band mode B
-            # reproduces the oracle's whole run, iteration for iteration (tests/test_gpu_parity.py).
+            # (JointOptimization.cpp:1156-1256: no odometry, only pose 0 held); on these corridor maps it is so ill-conditioned
+            # that it never converges (100 iterations, NO_CONVERGENCE) and its accept/reject sequence depends on the ROUNDING of the
+            # linear solver: the mirror itself takes 86 / 87 / 88 / 89 accepted steps of 100 with an eigen-decomposition / refined
+            # Cholesky / LU / plain Cholesky solve of the same normal equations (final costs equal to 4 digits, poses 3e-4 m apart).
+            # With more than one connected component of the scan-overlap graph J^T J is singular outright (a free rigid body per
+            # component without pose 0: shown on the oracle's dense Hessian in tests/test_gpu_parity.py).  No implementation
+            # can be held to another's path here; asserted: the cost level and a 1e-2 pose bar.  (Oracle and product do walk the
+            # same path on connected maps with every pair inside the band -- banded Cholesky and cyclic reduction round alike --
+            # see tests/test_gpu_parity.py.)
             assert abs(summ.final_cost - ec[1]) <= 2e-3 * ec[1]
-            assert np.abs(poses - z["solve_poses_%d" % mode]).max() <= 1e-2
+            assert np.abs(poses - z["%s_poses_%d" % (prefix, mode)]).max() <= 1e-2
             continue
         assert [summ.termination, summ.iterations, summ.successful_steps] == exp.tolist()[:3]
         assert abs(summ.final_cost - ec[1]) <= 1e-7 * ec[1]
-        assert np.abs(poses[:, :2] - z["solve_poses_%d" % mode][:, :2]).max() <= POSE_TOL_M
-        assert np.abs(poses[:, 2] - z["solve_poses_%d" % mode][:, 2]).max() <= POSE_TOL_RAD
+        assert np.abs(poses[:, :2] - z["%s_poses_%d" % (prefix, mode)][:, :2]).max() <= POSE_TOL_M
+        assert np.abs(poses[:, 2] - z["%s_poses_%d" % (prefix, mode)][:, 2]).max() <= POSE_TOL_RAD
 
 
 def test_fixtures_exist():
     assert len(GOLDEN) >= 3
 
 
+def _options(late):
+    opt = abi.default_options()
+    opt.tolerances_after_accept = int(late)
+    return opt
+
+
+@pytest.mark.parametrize("late", [0, 1], ids=["tolerances_before_accept", "tolerances_after_accept"])
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
-def test_oracle_reproduces_golden(path):
+def test_oracle_reproduces_golden(path, late):
     from oracle import hitl_oracle as O
     z = np.load(path)
-    s = _load(O.OracleSolver(), z, with_corr=False)
-    _check(s, z, 1e-12, lambda sv, zz: sv.find_correspondences(zz["init"], int(zz["window"]), 0))
+    s = _load(O.OracleSolver(_options(late)), z, with_corr=False)
+    _check(s, z, 1e-11, lambda sv, zz: sv.find_correspondences(zz["init"], int(zz["window"]), 1), "late_solve" if late else "solve",
+           bf_matcher=lambda sv, zz: sv.find_correspondences(zz["init"], int(zz["window"]), 0))
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("late", [0, 1], ids=["tolerances_before_accept", "tolerances_after_accept"])
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
-def test_hip_path_reproduces_golden(path):
+def test_hip_path_reproduces_golden(path, late):
     import hitl_slam_amd as H
     z = np.load(path)
-    s = _load(H.Solver(), z, with_corr=False)
-    _check(s, z, 1e-10, lambda sv, zz: sv.find_correspondences(zz["init"], int(zz["window"])))
+    opt = _options(late)
+    opt.kd_tree_search = 0
+    s = _load(H.Solver(opt), z, with_corr=False)
+    s.find_correspondences(z["init"], int(z["window"]))
+    for a, key in zip(s.get_correspondences(), ("pair_src", "pair_tgt", "match_offset", "src_idx", "tgt_idx")):
+        assert np.array_equal(a, z["bf_" + key].astype(a.dtype)), "bf_" + key
+    s.close()
+    s = _load(H.Solver(_options(late)), z, with_corr=False)
+    _check(s, z, 1e-10, lambda sv, zz: sv.find_correspondences(zz["init"], int(zz["window"])), "late_solve" if late else "solve")
     s.close()
 
 
