@@ -217,7 +217,7 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
       return fail(HITL_ERR_HIP, std::string("match kernel: ") + hipGetErrorString(hipGetLastError()));
     mark("k_match + pair counts");
     const int P = (int)tot[0];
-    const int Wb = std::min(std::max((int)tot[2], 1), band_cap);
+    const int Wb = std::min(std::max((int)tot[2], std::max(s->min_band_poses, 1)), band_cap);
     s->n_pairs = P; s->n_matches = tot[1];
     s->n_pairs_owned = (int)tot[3]; s->n_matches_owned = tot[4];
     s->band_pairs_Wb = Wb;

@@ -72,7 +72,7 @@ int build_pair_structures(hitl_solver* s) {
   int maxd = 1;
   for (int p = 0; p < P; ++p) maxd = std::max(maxd, std::abs(s->h_pair_src[p] - s->h_pair_tgt[p]));
   const int cap = std::min(std::max(s->opt.max_band_poses, 1), kMaxBandPoses);
-  const int Wb = std::min(maxd, cap);
+  const int Wb = std::min(std::max(maxd, s->min_band_poses), cap);      // min_band_poses: a submap rank's band is at least as wide as the interface (prepare)
   s->band_pairs_Wb = Wb;
   std::vector<int> ppo(n + 1, 0), inc_off(n + 1, 0);
   for (int p = 0; p < P; ++p) { ppo[s->h_pair_src[p] + 1]++; inc_off[s->h_pair_src[p] + 1]++; inc_off[s->h_pair_tgt[p] + 1]++; }
@@ -301,7 +301,7 @@ static int prepare_local(hitl_solver* s, int mode, const float* poses_ref, const
 
 int prepare(hitl_solver* s, int mode, const float* poses_ref, const float* poses_global, FactorView* fv) {
   // mode A reads no pair table: a 1-pose band; the pair-derived band_pair table is unused
-  const int Wb = (mode == HITL_MODE_ODOM_HC) ? 1 : s->band_pairs_Wb;
+  int Wb = (mode == HITL_MODE_ODOM_HC) ? 1 : s->band_pairs_Wb;
   const int local_rc = prepare_local(s, mode, poses_ref, poses_global, Wb);
   if (!s->dist_mode() && local_rc != HITL_OK) return local_rc;
   if (s->dist_mode()) {
@@ -334,6 +334,22 @@ int prepare(hitl_solver* s, int mode, const float* poses_ref, const float* poses
       s->dist_pcg = any_offband;
     }
     s->Wi = wi_local;
+    if (!s->dist_pcg && mode != HITL_MODE_ODOM_HC) {
+      // The interface width is a maximum over ALL ranks; the band of this rank comes from its own kept pairs.  A rank that
+      // holds only short pairs while a cut elsewhere is crossed by longer ones widens its band to the interface (the exact
+      // interface system needs Wi <= Wb, and the multi-right-hand-side work buffers are sized by Wb).  The verdict must be the
+      // same on every rank -- Wi and the cap are -- or the others would walk into the collectives of the LM loop alone.
+      const int cap = std::min(std::max((int)s->opt.max_band_poses, 1), kMaxBandPoses);
+      if (s->Wi > cap)
+        return fail(HITL_ERR_UNSUPPORTED, "a factor reaches " + std::to_string(s->Wi) + " poses across a cut, further than the pose band may be wide (max_band_poses)");
+      if (s->Wi > Wb) {
+        s->min_band_poses = s->Wi;
+        TRY(ensure_host_pairs(s));
+        TRY(build_pair_structures(s));
+        Wb = s->band_pairs_Wb;
+        TRY(prepare_local(s, mode, poses_ref, poses_global, Wb));
+      }
+    }
     if (s->dist_pcg) {
       // Pose pairs outside the band somewhere: the ranks iterate together (distributed PCG, hitl_lm.cpp).  A factor that
       // straddles a cut must be seen by both ranks it touches, i.e. reach no deeper than the halos on either side.

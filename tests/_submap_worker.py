@@ -27,6 +27,8 @@ def main():
     n_per = int(os.environ.get("HITL_TEST_NPER", n_per))
     halo = int(os.environ.get("HITL_TEST_HALO", halo))
     window = int(os.environ.get("HITL_TEST_WINDOW", 3))
+    if "HITL_TEST_WINDOWS" in os.environ:          # a search window per rank ("1,3,3"): a rank whose own pairs are all short
+        window = int(os.environ["HITL_TEST_WINDOWS"].split(",")[rank])
     prob = Problem(n_per * world, 48, ppf=ppf, groups=2, kind=0)
     b, e = rank * n_per, (rank + 1) * n_per
     if "HITL_TEST_CUTS" in os.environ:            # uneven submaps: "0,50,120" = rank 0 owns [0, 50), rank 1 [50, 120)

@@ -66,71 +66,110 @@ def _pose_diff(a, b):
     return float(np.abs(d[:, :2]).max()), float(np.abs(d[:, 2]).max())
 
 
-def test_fullsize_solve_matches_oracle(big):
-    """The whole mode-C re-solve (JointOptimization.cpp:1064-1138 + :1156-1256 as one problem) at the size the north
-    star quotes: 50 000 poses x 400 obs, the GPU's own correspondence set handed to the oracle.  Same termination, same
-    LM iteration and accepted-step counts, final cost to 1e-8 relative, poses to 1e-4 m / 1e-4 rad."""
+def _oracle_solve(big):
+    """The oracle's mode-C solve on the oracle's OWN search result (method 1 = the reference's KD-tree walk), once per module."""
+    if "oracle_solve" not in big:
+        import os
+        import time
+        import hitl_slam_amd as H
+        from oracle import hitl_oracle as O
+        o = O.OracleSolver()
+        o.set_map(*big["map"])
+        o.set_human_constraints(big["rows"])
+        O.set_num_threads(min(len(os.sched_getaffinity(0)), 16))
+        t0 = time.time()
+        o.find_correspondences(big["init"], 3, 1)
+        t1 = time.time()
+        big["oracle_corr"] = o.get_correspondences()
+        po, so = o.solve(H.MODE_JOINT, big["init"])
+        big["oracle_solve"] = (po, so, time.time() - t1, t1 - t0)
+        o.close()
+    return big["oracle_solve"]
+
+
+def test_fullsize_search_and_solve_match_oracle(big):
+    """Search AND solve at the size the north star quotes (50 000 poses x 400 obs), both sides on their own: the GPU's default
+    correspondence search (the reference's KD-trees + pruned walk, JointOptimization.cpp:561-642 + kdtree.cpp:141-197) gives
+    the oracle's index sets bit for bit (297 000 pairs, ~106 M matches), and the whole mode-C re-solve on them
+    (JointOptimization.cpp:1064-1138 + :1156-1256 as one problem) ends like the oracle's: same termination, same LM
+    iteration and accepted-step counts, final cost to 1e-8 relative, poses to 1e-4 m / 1e-4 rad."""
     import os
-    import time
-    import hitl_slam_amd as H
-    from oracle import hitl_oracle as O
     s = big["s"]
+    po, so, dt, dts = _oracle_solve(big)
+    for a, b in zip(s.get_correspondences(), big["oracle_corr"]):
+        assert np.array_equal(a, b)
+    import hitl_slam_amd as H
     pg, sg = s.solve(H.MODE_JOINT, big["init"])
-    o = O.OracleSolver()
-    o.set_map(*big["map"])
-    o.set_human_constraints(big["rows"])
-    o.set_correspondences(*s.get_correspondences())
-    O.set_num_threads(len(os.sched_getaffinity(0)))
-    t0 = time.time()
-    po, so = o.solve(H.MODE_JOINT, big["init"])
-    dt = time.time() - t0
-    o.close()
     dxy, dth = _pose_diff(pg, po)
-    print("\nC4 full-size solve: gpu iters=%d ok=%d cost=%.12g | oracle iters=%d ok=%d cost=%.12g (%.1f s on %d threads) | "
-          "max|dxy|=%.3g m max|dth|=%.3g rad" % (sg.iterations, sg.successful_steps, sg.final_cost, so.iterations,
-                                                  so.successful_steps, so.final_cost, dt, len(os.sched_getaffinity(0)), dxy, dth))
+    print("\nC4 full-size search + solve: %d matches identical | gpu iters=%d ok=%d cost=%.12g | oracle iters=%d ok=%d cost=%.12g "
+          "(search %.1f s, solve %.1f s on <= 16 of %d threads) | max|dxy|=%.3g m max|dth|=%.3g rad"
+          % (len(big["oracle_corr"][3]), sg.iterations, sg.successful_steps, sg.final_cost, so.iterations, so.successful_steps, so.final_cost,
+             dts, dt, len(os.sched_getaffinity(0)), dxy, dth))
     assert sg.termination == so.termination
     assert sg.iterations == so.iterations and sg.successful_steps == so.successful_steps
     assert abs(sg.final_cost - so.final_cost) <= 1e-8 * so.final_cost
     assert dxy <= 1e-4 and dth <= 1e-4
 
 
-def test_fullsize_kd_tree_search_matches_the_reference_walk(big):
-    """The reference's own correspondence search (per-scan KD-trees + pruned walk, kdtree.cpp:37-197) at full size:
-    50 000 trees of 400 points, 120 M queries; index sets bit for bit against the oracle's restatement (method 1).  Also
-    records how far the converged poses move between the two definitions of a correspondence."""
+def test_fullsize_moments_form_matches_oracle(big):
+    """hitl_options.stf_moments at the quoted size, against the ORACLE (not only against the streaming kernels): the factors
+    come from 2 x 15 moments per pose pair summed once per correspondence set; same LM path, cost to 1e-8, poses to 1e-4."""
+    import hitl_slam_amd as H
+    po, so, _, _ = _oracle_solve(big)
+    opt = H.default_options()
+    opt.stf_moments = 1
+    g = H.Solver(opt)
+    g.set_map(*big["map"])
+    g.set_human_constraints(big["rows"])
+    g.find_correspondences(big["init"], 3)
+    for a, b in zip(g.get_correspondences(), big["oracle_corr"]):
+        assert np.array_equal(a, b)
+    pg, sg = g.solve(H.MODE_JOINT, big["init"])
+    g.close()
+    dxy, dth = _pose_diff(pg, po)
+    print("\nC4 moments form: gpu iters=%d ok=%d cost=%.12g | oracle iters=%d ok=%d cost=%.12g | max|dxy|=%.3g m max|dth|=%.3g rad"
+          % (sg.iterations, sg.successful_steps, sg.final_cost, so.iterations, so.successful_steps, so.final_cost, dxy, dth))
+    assert (sg.termination, sg.iterations, sg.successful_steps) == (so.termination, so.iterations, so.successful_steps)
+    assert abs(sg.final_cost - so.final_cost) <= 1e-8 * so.final_cost
+    assert dxy <= 1e-4 and dth <= 1e-4
+
+
+def test_fullsize_brute_force_definition_matches_oracle(big):
+    """kd_tree_search = 0, the tree-independent definition of the query, at full size: index sets bit for bit against the
+    oracle's method 0.  Also records how far the converged poses move between the two definitions of a correspondence
+    (why the reference's walk is the default)."""
     import os
     import time
     import hitl_slam_amd as H
     from oracle import hitl_oracle as O
     opt = H.default_options()
-    opt.kd_tree_search = 1
+    opt.kd_tree_search = 0
     g = H.Solver(opt)
     g.set_map(*big["map"])
     g.set_human_constraints(big["rows"])
+    g.find_correspondences(big["init"], 3)
     t0 = time.time()
     g.find_correspondences(big["init"], 3)
-    t_first = time.time() - t0
+    t_bf = time.time() - t0
     t0 = time.time()
-    g.find_correspondences(big["init"], 3)          # trees are kept: BuildKDTrees runs once per map
-    t_again = time.time() - t0
+    big["s"].find_correspondences(big["init"], 3)
+    t_kd = time.time() - t0
     got = g.get_correspondences()
     o = O.OracleSolver()
     o.set_map(*big["map"])
     O.set_num_threads(min(len(os.sched_getaffinity(0)), 16))
-    o.find_correspondences(big["init"], 3, 1)
-    want = o.get_correspondences()
-    o.close()
-    for a, b in zip(got, want):
+    o.find_correspondences(big["init"], 3, 0)
+    for a, b in zip(got, o.get_correspondences()):
         assert np.array_equal(a, b)
-    bf = big["s"].get_correspondences()
-    pk, sk = g.solve(H.MODE_JOINT, big["init"])
-    pb, sb = big["s"].solve(H.MODE_JOINT, big["init"])
+    o.close()
+    kd = big["s"].get_correspondences()
+    pb, sb = g.solve(H.MODE_JOINT, big["init"])
+    pk, sk = big["s"].solve(H.MODE_JOINT, big["init"])
     dxy, dth = _pose_diff(pk, pb)
-    same = int(np.array_equal(got[4], bf[4])) if len(got[4]) == len(bf[4]) else 0
-    print("\nkd_tree_search at C4: %d pairs, %d matches (brute force %d); search %.1f ms incl. tree build, %.1f ms with trees resident; "
-          "mode C on the KD set: %d iterations, cost %.9g (brute-force set: %d, %.9g); converged poses differ by %.3g m / %.3g rad; identical sets: %d"
-          % (len(got[0]), len(got[3]), len(bf[3]), t_first * 1e3, t_again * 1e3, sk.iterations, sk.final_cost, sb.iterations, sb.final_cost, dxy, dth, same))
+    same = int(np.array_equal(got[4], kd[4])) if len(got[4]) == len(kd[4]) else 0
+    print("\ncorrespondence search at C4: KD walk %d matches in %.1f ms, brute force %d matches in %.1f ms (trees resident); mode C: %d iterations, "
+          "cost %.9g on the KD set, %d iterations, cost %.9g on the brute-force set; converged poses differ by %.3g m / %.3g rad; identical sets: %d"
+          % (len(kd[3]), t_kd * 1e3, len(got[3]), t_bf * 1e3, sk.iterations, sk.final_cost, sb.iterations, sb.final_cost, dxy, dth, same))
     g.close()
 
 

@@ -26,15 +26,22 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("mode,ppf,world,moments,cuts", [(0, 30, 2, 0, None), (2, 30, 2, 0, None), (2, 120, 2, 0, None), (0, 120, 2, 0, None),
-                                                         (2, 120, 3, 0, None), (2, 40, 3, 0, None), (2, 120, 2, 1, None),
-                                                         (2, 120, 3, 0, "0,23,83,120")])      # uneven submaps: 23, 60 and 37 poses
-def test_submaps_equal_the_global_solve(tmp_path, mode, ppf, world, moments, cuts):
+@pytest.mark.parametrize("mode,ppf,world,moments,cuts,windows",
+                         [(0, 30, 2, 0, None, None), (2, 30, 2, 0, None, None), (2, 120, 2, 0, None, None), (0, 120, 2, 0, None, None),
+                          (2, 120, 3, 0, None, None), (2, 40, 3, 0, None, None), (2, 120, 2, 1, None, None),
+                          (2, 120, 3, 0, "0,23,83,120", None),      # uneven submaps: 23, 60 and 37 poses
+                          # rank 0 = the first floor, matched within +-1 pose only: its own band is one pose wide while the cut
+                          # between ranks 1 and 2 (inside the second floor) is crossed by pairs three poses long.  Every rank must
+                          # widen its band to the interface of the whole partition (round 2: rank 0 alone refused and the others hung)
+                          (2, 40, 3, 0, "0,40,70,120", "1,3,3")])
+def test_submaps_equal_the_global_solve(tmp_path, mode, ppf, world, moments, cuts, windows):
     from oracle import hitl_oracle as O
     out = str(tmp_path / "res")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", HITL_TEST_STF_MOMENTS=str(moments))
     if cuts:
         env["HITL_TEST_CUTS"] = cuts
+    if windows:
+        env["HITL_TEST_WINDOWS"] = windows
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_submap_worker.py"), out, str(mode), str(ppf)]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
@@ -45,6 +52,15 @@ def test_submaps_equal_the_global_solve(tmp_path, mode, ppf, world, moments, cut
     o = prob.load(O.OracleSolver())
     o.find_correspondences(prob.init, 3, 1)
     ops = o.get_correspondences()
+    if windows:      # the global problem of the per-rank windows: inside rank r's range only pairs within its window (6 slots <= cap 6: the cap never binds)
+        cl, wl = [int(c) for c in cuts.split(",")], [int(w) for w in windows.split(",")]
+        rank_of = np.searchsorted(np.array(cl[1:]), np.arange(prob.n), side="right")
+        keep = np.array([not (rank_of[a] == rank_of[b] and abs(int(a) - int(b)) > wl[rank_of[a]]) for a, b in zip(ops[0], ops[1])])
+        assert 0 < keep.sum() < len(keep)
+        lens = (ops[2][1:] - ops[2][:-1])[keep]
+        sel = np.concatenate([np.arange(ops[2][p], ops[2][p + 1]) for p in np.nonzero(keep)[0]])
+        ops = (ops[0][keep], ops[1][keep], np.concatenate([[0], np.cumsum(lens)]).astype(np.int64), ops[3][sel], ops[4][sel])
+        o.set_correspondences(*ops)
     # the pairs reported by the ranks owning their source pose tile the global set exactly
     src = np.concatenate([np.array(x["pairs"][0], np.int32) for x in res])
     tgt = np.concatenate([np.array(x["pairs"][1], np.int32) for x in res])
