@@ -217,6 +217,7 @@ def main():
 
     # ---- warm-up, then exactly K timed re-solves -----------------------------------------------------
     for _ in range(args.warmup):
+        solver.set_human_constraints(rows)
         out, summ = solver.solve(H.MODE_JOINT, pose_arg)
     if use_dist:
         dist.barrier()
@@ -228,6 +229,7 @@ def main():
     stf_launches = 0
     lin_solver_ms = 0.0
     for _ in range(args.steps):
+        solver.set_human_constraints(rows)                       # constraints + poses are handed over inside the timed region
         out, summ = solver.solve(H.MODE_JOINT, pose_arg)
         iters += summ.iterations
         stf_ms += summ.linearize_ms
@@ -311,6 +313,8 @@ def main():
         "termination": int(summ.termination),
         "final_cost": summ.final_cost,
         "correspondence_search_ms": match_ms, "correspondence_search_first_call_ms": match_first_ms,
+        "correspondence_search": "kd_tree_search = 1 (default): the reference's per-scan KD-trees + pruned walk (JointOptimization.cpp:561-642, "
+                                 "kdtree.cpp:141-197); first call includes BuildKDTrees (once per map)",
         "residual_drift_vs_ground_truth_m": err_gt,
         "residual_drift_note": "max |xy - ground truth| after the re-solve; the synthetic odometry drift is only removed where "
                                "human constraints and scan overlap observe it, so this is a property of the input, not an error",
@@ -325,9 +329,10 @@ def main():
                      "algorithmic_frac": alg_achieved / HBM_PEAK_GBS,
                      "compulsory_bytes_this_layout": compulsory,
                      "avg_launch_ms": avg_stf_ms, "launches": stf_launches, "launches_bracketed_by_hip_events": stf_calls,
-                     "limiter": "no single unit: fp64 issue slots 73-82 %, L1 gather path (TA) ~73 %, HBM ~39 % of peak (profiles/r02_stf_memory_path_pmc.txt, profiles/r02_final_pmc.md); ablations in "
-                                "profiles/r02_stf_ablation_kernel_trace.txt (no ingredient of a trip is worth more than 14 % of the launch)",
-                     "utilisation_counters": pmc},
+                     # counter digests describe ONE profiled workload: reported only when this run is that workload
+                     "limiter": (pmc or {}).get("limiter") if traffic_source else None,
+                     "utilisation_counters": pmc if traffic_source else None,
+                     "profiled": bool(traffic_source)},
         "synth_gen_s": gen_s,
     }
 
@@ -366,7 +371,17 @@ def main():
             # the worst case of the O(span^2) stage: bounds at the two ends of the whole trajectory
             _, cyc["backprop_full_span_ms"] = timed(solver.backprop, poses0, cov, 1, n_local - 2, corr_v)
             _, cyc["transform_scans_ms"] = timed(solver.transform_scans, poses0)
+            (_, _, pinned), _ = timed(solver.transform_scans_pinned, poses0)                       # allocates the pinned buffers
+            _, cyc["transform_scans_pinned_host_ms"] = timed(solver.transform_scans_pinned, poses0, pinned)
+            solver.host_free(pinned)
+            _, cyc["transform_scans_device_resident_ms"] = timed(solver.transform_scans_device, poses0)
             _, cyc["pose_covariances_ms"] = timed(solver.pose_covariances, H.MODE_JOINT, out)
+            pre = sum(cyc[k] for k in ("verify_points_ms", "fit_segments_ms", "observation_sets_ms", "order_user_input_ms",
+                                       "explicit_correction_ms", "backprop_ms"))
+            cyc["pre_solve_stages_ms"] = pre
+            # what ONE interactive correction costs end to end on this map: pre-solve stages + new correspondences + the re-solve
+            # + the world-frame re-projection for the display (HitLSLAM::Run, HitLSLAM.cpp:380-480)
+            result["interactive_correction_ms"] = pre + match_ms + ms_per_step + cyc["transform_scans_ms"]
             cyc.update(all_points_verified=bool(int(seen.sum()) == 4), fit_passes=[int(v) for v in pas], fit_inliers=[int(v) for v in inl],
                        anchors=int(od["anchor"].size), corrected=int(od["corrected"].size), new_rows=int(new_rows.size),
                        backprop_bounds=[int(od["bounds"][0]), int(od["bounds"][1])],
@@ -384,18 +399,27 @@ def main():
             s2 = H.Solver(opt2)
             s2.set_map(off, px, py, nx, ny, cov)
             s2.set_human_constraints(rows)
-            s2.set_correspondences(*solver.get_correspondences())
+            s2.find_correspondences(init_l, wl["window"])
             out2, summ2 = s2.solve(H.MODE_JOINT, init_l)                 # includes summing the moments once
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(args.steps):
-                out2, summ2 = s2.solve(H.MODE_JOINT, init_l)
+                out2, summ2 = s2.solve(H.MODE_JOINT, init_l)             # moments of the resident correspondence set reused
             torch.cuda.synchronize()
             ms2 = (time.perf_counter() - t0) * 1e3 / args.steps
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                # the reference rebuilds its correspondences on every solve (JointOptimization.cpp:1189-1191): search, the
+                # moment sums of the new set (k_stf_moments) and the solve, all inside the timed region
+                s2.find_correspondences(init_l, wl["window"])
+                out2, summ2 = s2.solve(H.MODE_JOINT, init_l)
+            torch.cuda.synchronize()
+            ms2_full = (time.perf_counter() - t0) * 1e3 / args.steps
             d = out2.astype(np.float64) - out
             d[:, 2] = np.angle(np.exp(1j * d[:, 2]))
             result["stf_moments_mode"] = {
-                "resolve_ms": ms2, "lm_iterations_per_resolve": int(summ2.iterations), "final_cost": summ2.final_cost,
+                "resolve_ms": ms2, "search_plus_moments_plus_resolve_ms": ms2_full,
+                "lm_iterations_per_resolve": int(summ2.iterations), "final_cost": summ2.final_cost,
                 "max_pose_difference_vs_streaming": float(np.abs(d).max()),
                 "linearize_stf_ms_per_launch": summ2.linearize_ms / max(summ2.linearize_timed_calls, 1),
                 "note": "hitl_options.stf_moments=1: scan-to-scan factors from 2x15 moments per pose pair summed once per "
@@ -403,6 +427,24 @@ def main():
             s2.close()
         except Exception as e:
             result["stf_moments_mode"] = {"failed": repr(e)}
+
+    # ---- the opt-in brute-force definition of the correspondence query on the same map (kd_tree_search = 0) ----
+    if world == 1:
+        try:
+            opt3 = H.default_options()
+            opt3.device = dev_index
+            opt3.kd_tree_search = 0
+            s3 = H.Solver(opt3)
+            s3.set_map(off, px, py, nx, ny, cov)
+            s3.find_correspondences(init_l, wl["window"])
+            t0 = time.perf_counter()
+            s3.find_correspondences(init_l, wl["window"])
+            result["correspondence_search_brute_force_ms"] = (time.perf_counter() - t0) * 1e3
+            result["correspondence_search_brute_force_matches"] = int(s3.correspondence_counts()[1])
+            s3.close()
+        except Exception as e:
+            result["correspondence_search_brute_force_ms"] = None
+            result["correspondence_search_brute_force_error"] = repr(e)
 
     # ---- CPU baseline: the oracle (a port, not the reference binary) on the WHOLE bench workload ----------------
     # Same map, same correspondences, same human rows, same mode; threads = the cores this process may really use

@@ -453,6 +453,39 @@ def load_library(path=None):
 class Solver(SolverBase):
     """The MI355X backend (libhitlgpu.so)."""
 
+    def transform_scans_device(self, poses_xyt):
+        """hitl_solver_transform_scans_device: (device pointer of world x, of world y) as ints; the clouds stay in HBM."""
+        pin = _as(poses_xyt, np.float32).reshape(-1)
+        dx, dy = C.c_void_p(), C.c_void_p()
+        f = self._lib.hitl_solver_transform_scans_device
+        f.argtypes = [C.c_void_p, _f32p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+        self._check(f(self._h, _ptr(pin, _f32p), C.byref(dx), C.byref(dy)), "solve")
+        return dx.value, dy.value
+
+    def transform_scans_pinned(self, poses_xyt, buffers=None):
+        """hitl_solver_transform_scans into page-locked host memory from hitl_host_alloc (allocated once and returned for
+        reuse): (world_x, world_y, buffers)."""
+        pin = _as(poses_xyt, np.float32).reshape(-1)
+        n_obs = int(self.obs_offset[-1])
+        lib = self._lib
+        lib.hitl_host_alloc.restype = C.c_void_p
+        lib.hitl_host_alloc.argtypes = [C.c_size_t]
+        if buffers is None:
+            buffers = (lib.hitl_host_alloc(4 * max(n_obs, 1)), lib.hitl_host_alloc(4 * max(n_obs, 1)))
+            if not buffers[0] or not buffers[1]:
+                raise MemoryError("hitl_host_alloc failed")
+        f = lib.hitl_solver_transform_scans
+        f.argtypes = [C.c_void_p, _f32p, C.c_void_p, C.c_void_p]
+        self._check(f(self._h, _ptr(pin, _f32p), buffers[0], buffers[1]), "solve")
+        wx = np.ctypeslib.as_array(C.cast(buffers[0], C.POINTER(C.c_float)), shape=(max(n_obs, 1),))[:n_obs]
+        wy = np.ctypeslib.as_array(C.cast(buffers[1], C.POINTER(C.c_float)), shape=(max(n_obs, 1),))[:n_obs]
+        return wx, wy, buffers
+
+    def host_free(self, buffers):
+        self._lib.hitl_host_free.argtypes = [C.c_void_p]
+        for b in buffers:
+            self._lib.hitl_host_free(b)
+
     def get_kd_trees(self):
         """(pts float32 [n_obs, 4], meta uint32 [n_obs]) of hitl_solver_get_kd_trees: every scan's KD-tree in the in-order layout."""
         n_obs = int(self.obs_offset[-1] - self.obs_offset[0])

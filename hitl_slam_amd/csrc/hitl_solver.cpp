@@ -554,7 +554,7 @@ void hitl_solver_destroy(hitl_solver* s) {
                            &s->ob_hi, &s->ob_fwd, &s->ob_rev, &s->obadj_off, &s->obadj_ent, &s->hc_off})
     v->release();
   s->d_cand_tgt.release(); s->d_cand_counts.release(); s->d_cand_kept.release(); s->d_cand_tf.release(); s->d_cand_table.release();
-  s->pairM.release(); s->kd_pts.release(); s->kd_meta.release();
+  s->pairM.release(); s->kd_pts.release(); s->kd_meta.release(); s->world_xy.release();
   s->matches.release(); s->odom_A.release(); s->hc_tgt.release(); s->odom_rr.release(); s->hc_type.release();
   if (s->nccl) (void)ncclCommDestroy(s->nccl);
   s->comm_send.release(); s->comm_recv.release(); s->fixed.release(); s->if_cols.release(); s->halo_idx.release();
@@ -1004,21 +1004,44 @@ int obs_scan_prepare(hitl_solver* s, const float* poses, DevArray<float>* T4) {
 }
 }  // namespace
 
-int hitl_solver_transform_scans(hitl_solver* s, const float* poses_xyt, float* world_x, float* world_y) {
+// world x of every observation, then world y, in a buffer the solver keeps (no 160 MB allocation per call)
+static int transform_scans_resident(hitl_solver* s, const float* poses_xyt) {
   DevArray<float> T4;
-  DevArray<float> w;           // world x of every observation, then world y: copied straight into the caller's two arrays
   int rc = obs_scan_prepare(s, poses_xyt, &T4);
-  if (rc == HITL_OK && (!world_x || !world_y)) rc = fail(HITL_ERR_INVALID_ARGUMENT, "transform_scans: null output");
-  if (rc == HITL_OK) rc = w.resize((size_t)2 * s->n_obs);
+  if (rc == HITL_OK) rc = s->world_xy.resize((size_t)2 * std::max<int64_t>(s->n_obs, 1));
   if (rc == HITL_OK) {
-    launch_transform(s->stream, s->map_view(), T4.p, w.p, w.p + s->n_obs);
-    if (hipMemcpyAsync(world_x, w.p, sizeof(float) * (size_t)s->n_obs, hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
-        hipMemcpyAsync(world_y, w.p + s->n_obs, sizeof(float) * (size_t)s->n_obs, hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
-        hipStreamSynchronize(s->stream) != hipSuccess) rc = fail(HITL_ERR_HIP, "transform_scans failed");
+    launch_transform(s->stream, s->map_view(), T4.p, s->world_xy.p, s->world_xy.p + s->n_obs);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s->stream) != hipSuccess) rc = fail(HITL_ERR_HIP, "transform_scans failed");
   }
-  T4.release(); w.release();
+  T4.release();
   return rc;
 }
+
+int hitl_solver_transform_scans(hitl_solver* s, const float* poses_xyt, float* world_x, float* world_y) {
+  if (!world_x || !world_y) return fail(HITL_ERR_INVALID_ARGUMENT, "transform_scans: null output");
+  int rc = transform_scans_resident(s, poses_xyt);
+  if (rc == HITL_OK && s->n_obs > 0 &&
+      (hipMemcpyAsync(world_x, s->world_xy.p, sizeof(float) * (size_t)s->n_obs, hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
+       hipMemcpyAsync(world_y, s->world_xy.p + s->n_obs, sizeof(float) * (size_t)s->n_obs, hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
+       hipStreamSynchronize(s->stream) != hipSuccess)) rc = fail(HITL_ERR_HIP, "transform_scans: the copy to the host failed");
+  return rc;
+}
+
+int hitl_solver_transform_scans_device(hitl_solver* s, const float* poses_xyt, const float** d_world_x, const float** d_world_y) {
+  if (!d_world_x || !d_world_y) return fail(HITL_ERR_INVALID_ARGUMENT, "transform_scans_device: null output");
+  *d_world_x = *d_world_y = nullptr;
+  const int rc = transform_scans_resident(s, poses_xyt);
+  if (rc == HITL_OK) { *d_world_x = s->world_xy.p; *d_world_y = s->world_xy.p + s->n_obs; }
+  return rc;
+}
+
+void* hitl_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (bytes == 0 || hipHostMalloc(&p, bytes) != hipSuccess) return nullptr;
+  return p;
+}
+
+void hitl_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
 int hitl_solver_verify_points(hitl_solver* s, const float* poses_xyt, int32_t n_points, const float* points_xy,
                               float threshold, int32_t* seen) {

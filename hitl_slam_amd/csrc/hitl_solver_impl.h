@@ -92,6 +92,7 @@ struct hitl_solver {
   DevArray<float4> kd_pts;                     // opt-in (kd_tree_search): every scan in KD in-order layout
   DevArray<uint32_t> kd_meta;                  //   original index | split plane << 16
   bool kd_built = false;                       //   trees belong to the resident map
+  DevArray<float> world_xy;                    // hitl_solver_transform_scans*: world x of every observation, then world y
   int min_band_poses = 1;                      // lower bound of the pose band (a submap rank: the interface width of the whole partition)
   DevArray<double> pairM;                      // opt-in (stf_moments): 2 x 15 moments per pair
   int64_t moments_of = -1;                     // correspondence-set generation the moments belong to

@@ -252,6 +252,15 @@ int hitl_solver_evaluate_jacobian(hitl_solver*, const float* poses_xyt, double* 
  * global poses [begin - hl, end + hh), halos included, in that order -- so world_x / world_y / mask hold one value per
  * resident observation and counts two per resident pose; `seen` flags are per rank (the caller ORs them). */
 int hitl_solver_transform_scans(hitl_solver*, const float* poses_xyt, float* world_x, float* world_y);
+/* The same re-projection, left where a renderer or a later kernel wants it: *d_world_x / *d_world_y receive DEVICE pointers
+ * to n_obs floats each, owned by the solver and valid until the next transform_scans* call, set_map or destroy.  The 160 MB
+ * of world-frame clouds of a 20 M-observation map never cross PCIe (0.1 ms instead of ~11 ms into pageable host memory).
+ * hitl_solver_transform_scans itself copies at pinned-memory speed when world_x / world_y come from hitl_host_alloc. */
+int hitl_solver_transform_scans_device(hitl_solver*, const float* poses_xyt, const float** d_world_x, const float** d_world_y);
+/* Page-locked host memory for the large outputs of the library (transform_scans, get_correspondences ...): copies into it
+ * run at the full PCIe rate and need no staging.  NULL on failure. */
+void* hitl_host_alloc(size_t bytes);
+void hitl_host_free(void* p);
 int hitl_solver_verify_points(hitl_solver*, const float* poses_xyt, int32_t n_points, const float* points_xy,
                               float threshold, int32_t* seen);
 int hitl_solver_observation_sets(hitl_solver*, const float* poses_xyt, const float* seg_xy8, double threshold,

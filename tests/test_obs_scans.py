@@ -48,6 +48,17 @@ def test_gpu_scans_bit_exact_vs_oracle():
     poses = prob.init
     wg, wo = g.transform_scans(poses), o.transform_scans(poses)
     assert np.array_equal(wg[0], wo[0]) and np.array_equal(wg[1], wo[1])
+    # the same clouds into page-locked memory of the library's allocator, and left on the device (read back through torch)
+    px_, py_, pinned = g.transform_scans_pinned(poses)
+    assert np.array_equal(px_, wo[0]) and np.array_equal(py_, wo[1])
+    g.host_free(pinned)
+    dx, dy = g.transform_scans_device(poses)
+    assert dx and dy and dy - dx == 4 * len(wo[0])
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    back = np.zeros(len(wo[0]), np.float32)
+    assert hip.hipMemcpy(back.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(dy), ctypes.c_size_t(back.nbytes), 2) == 0     # 2 = device to host
+    assert np.array_equal(back, wo[1])
     wx, wy = wo
     rng = np.random.default_rng(0)
     pick = rng.integers(0, len(wx), 6)
