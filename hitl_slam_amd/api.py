@@ -486,6 +486,16 @@ class Solver(SolverBase):
         for b in buffers:
             self._lib.hitl_host_free(b)
 
+    def get_info_mat(self, mode):
+        """hitl_solver_get_info_mat: (rows, cols) int32 -- the reference's info_mat_ adjacency as a sorted upper-triangle COO list."""
+        f = self._lib.hitl_solver_get_info_mat
+        f.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.c_void_p, C.c_void_p]
+        ne = C.c_int64(0)
+        self._check(f(self._h, int(mode), C.byref(ne), None, None), "solve")
+        r, c = np.zeros(max(ne.value, 1), np.int32), np.zeros(max(ne.value, 1), np.int32)
+        self._check(f(self._h, int(mode), C.byref(ne), r.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p)), "solve")
+        return r[:ne.value], c[:ne.value]
+
     def get_kd_trees(self):
         """(pts float32 [n_obs, 4], meta uint32 [n_obs]) of hitl_solver_get_kd_trees: every scan's KD-tree in the in-order layout."""
         n_obs = int(self.obs_offset[-1] - self.obs_offset[0])

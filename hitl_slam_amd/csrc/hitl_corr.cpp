@@ -221,6 +221,7 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
     s->n_pairs = P; s->n_matches = tot[1];
     s->n_pairs_owned = (int)tot[3]; s->n_matches_owned = tot[4];
     s->band_pairs_Wb = Wb;
+    s->adj_window = (int)window; s->adj_slots = slots; s->h_adj.clear();       // info_mat: from the candidate counts, on demand
     s->n_offband = 0;
     ++s->corr_generation;
     s->h_pair_src.clear(); s->h_pair_tgt.clear(); s->h_perm.clear(); s->h_match_off.clear();
@@ -251,6 +252,7 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
   // kMinInterPoseCorrespondence matches (:632-634) in pose order (:636-641), compact the tile's rows behind what is there
   std::vector<int> counts, kept;
   std::vector<int64_t> tile_off;
+  s->adj_window = 0; s->adj_slots = 0; s->h_adj.clear();
   s->h_pair_src.clear(); s->h_pair_tgt.clear(); s->h_match_off.assign(1, 0);
   int64_t written = 0;                                   // matches compacted so far
   for (int i0 = 0; i0 < n; i0 += tile) {
@@ -266,6 +268,7 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
       for (int sl = 0; sl < slots; ++sl) {
         const size_t c = (size_t)il * slots + sl;
         const int i = i0 + il, jt = cand_tgt[c];
+        if (jt >= 0 && counts[c] > 0) s->h_adj.emplace_back(std::min(i, jt), std::max(i, jt));        // info_mat_ marks per accepted match (:624-625)
         const bool relevant = (i >= s->own_lo && i < s->own_hi) || (jt >= s->own_lo && jt < s->own_hi);   // halo-halo pairs belong to other ranks
         if (jt >= 0 && relevant && counts[c] > s->opt.min_inter_pose_correspondence) {
           kept.push_back((int)c);

@@ -734,6 +734,7 @@ int hitl_solver_set_correspondences(hitl_solver* s, int64_t n_pairs, const int32
     s->h_match_off[q + 1] = w;
   }
   s->n_pairs = P; s->n_matches = C;
+  s->adj_window = 0; s->adj_slots = 0; s->h_adj.clear();          // info_mat: the installed pairs
   hipStream_t st = s->stream;
   TRY(s->pair_src.upload(s->h_pair_src, st)); TRY(s->pair_tgt.upload(s->h_pair_tgt, st));
   TRY(s->match_off.upload(s->h_match_off, st)); TRY(s->matches.upload(packed, st));
@@ -749,6 +750,54 @@ int hitl_solver_get_kd_trees(hitl_solver* s, float* pts4, uint32_t* meta) {
   if (pts4 && s->n_obs > 0) HIP_TRY(hipMemcpyAsync(pts4, s->kd_pts.p, sizeof(float4) * (size_t)s->n_obs, hipMemcpyDeviceToHost, s->stream));
   if (meta && s->n_obs > 0) HIP_TRY(hipMemcpyAsync(meta, s->kd_meta.p, sizeof(uint32_t) * (size_t)s->n_obs, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
+  return HITL_OK;
+}
+
+int hitl_solver_get_info_mat(hitl_solver* s, int32_t mode, int64_t* n_entries, int32_t* rows, int32_t* cols) {
+  int rc = check_ready(s, mode);
+  if (rc != HITL_OK) return rc;
+  if (!n_entries || ((rows == nullptr) != (cols == nullptr))) return fail(HITL_ERR_INVALID_ARGUMENT, "get_info_mat: n_entries and both or neither of rows / cols");
+  if (s->dist_mode()) return fail(HITL_ERR_UNSUPPORTED, "get_info_mat is a single-GPU entry point");
+  HIP_TRY(hipSetDevice(s->device));
+  std::vector<std::pair<int, int>> e;
+  const int n = s->n;
+  if (mode != HITL_MODE_STF_ONLY) {
+    for (int i = 1; i < n; ++i) e.emplace_back(i - 1, i);                                   // AddOdometryConstraints :744-745
+    for (const hitl_human_constraint_t& r : s->h_hc) {                                       // AddHumanConstraints :978-979 (every row, whatever its type)
+      const int a = r.anchor_pose_id, c = r.constrained_pose_id;
+      if (a >= 0 && a < n && c >= 0 && c < n) e.emplace_back(std::min(a, c), std::max(a, c));
+    }
+  }
+  if (mode != HITL_MODE_ODOM_HC) {
+    if (s->adj_window > 0) {          // windowed search: the candidate counts are still on the device
+      std::vector<int> counts((size_t)n * s->adj_slots);
+      if (!counts.empty()) {
+        HIP_TRY(hipMemcpyAsync(counts.data(), s->d_cand_counts.p, sizeof(int) * counts.size(), hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+      }
+      for (int i = 0; i < n; ++i) {
+        const int j0 = std::max(0, i - s->adj_window), j1 = std::min(n - 1, i + s->adj_window);
+        int slot = 0;
+        for (int j = j0; j <= j1; ++j) {
+          if (j == i) continue;
+          if (counts[(size_t)i * s->adj_slots + slot] > 0) e.emplace_back(std::min(i, j), std::max(i, j));
+          ++slot;
+        }
+      }
+    } else if (!s->h_adj.empty()) {
+      e.insert(e.end(), s->h_adj.begin(), s->h_adj.end());
+    } else {                          // an installed set (hitl_solver_set_correspondences): its pairs
+      TRY(ensure_host_pairs(s));
+      for (int p = 0; p < s->n_pairs; ++p) e.emplace_back(std::min(s->h_pair_src[p], s->h_pair_tgt[p]), std::max(s->h_pair_src[p], s->h_pair_tgt[p]));
+    }
+  }
+  std::sort(e.begin(), e.end());
+  e.erase(std::unique(e.begin(), e.end()), e.end());
+  if (rows) {
+    if (*n_entries < (int64_t)e.size()) return fail(HITL_ERR_INVALID_ARGUMENT, "get_info_mat: arrays too small (call with NULL arrays for the count)");
+    for (size_t k = 0; k < e.size(); ++k) { rows[k] = e[k].first; cols[k] = e[k].second; }
+  }
+  *n_entries = (int64_t)e.size();
   return HITL_OK;
 }
 

@@ -93,6 +93,10 @@ struct hitl_solver {
   DevArray<uint32_t> kd_meta;                  //   original index | split plane << 16
   bool kd_built = false;                       //   trees belong to the resident map
   DevArray<float> world_xy;                    // hitl_solver_transform_scans*: world x of every observation, then world y
+  // pose pairs with >= 1 accepted match in the last search (info_mat_, JointOptimization.cpp:624-625): either derivable from
+  // the candidate counts still on the device (windowed search: adj_window > 0), or collected on the host (tiled search)
+  int adj_window = 0, adj_slots = 0;
+  std::vector<std::pair<int, int>> h_adj;
   int min_band_poses = 1;                      // lower bound of the pose band (a submap rank: the interface width of the whole partition)
   DevArray<double> pairM;                      // opt-in (stf_moments): 2 x 15 moments per pair
   int64_t moments_of = -1;                     // correspondence-set generation the moments belong to

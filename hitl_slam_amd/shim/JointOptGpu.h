@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 #include "hitl_gpu.h"
@@ -35,7 +36,7 @@ struct CRSMatrix {
 template <class Pose2Df, class Vec2f, class Mat3f, class HumanConstraint>
 class JointOptGpuT {
  public:
-  JointOptGpuT() : num_hc_residuals_(0), mode_(HITL_MODE_ODOM_HC), stf_window_(3), solver_(NULL), map_poses_(0), map_print_(0), stf_moments_(false) {
+  JointOptGpuT() : num_hc_residuals_(0), mode_(HITL_MODE_ODOM_HC), stf_window_(3), solver_(NULL), map_poses_(0), map_print_(0), stf_moments_(false), brute_force_search_(false) {
     std::memset(&summary_, 0, sizeof(summary_));
   }
   virtual ~JointOptGpuT() { if (solver_) hitl_solver_destroy(solver_); }
@@ -48,6 +49,9 @@ class JointOptGpuT {
   std::vector<std::vector<HumanConstraint> > human_constraints_;
   std::vector<double> gradients_;
   CRSMatrix ceres_jacobian_;          // filled with gradients_ when want_gradients and the mode has scan-to-scan factors
+  // info_mat_ (JointOptimization.h:256; an N x N float image saved as info_mat.png, :1313-1324, :1381-1382) as what it
+  // encodes: the pose pairs connected by a factor or a matched point, upper triangle, sorted, filled when want_info_mat
+  std::vector<std::pair<int, int> > info_mat_;
   int num_hc_residuals_;
   // JointOptimization.cpp:342-344 returns ceres_cost_, which nothing ever fills (its code at :836-838 is commented out):
   // an empty vector, as in the reference
@@ -71,8 +75,14 @@ class JointOptGpuT {
   // legacy kMaxHistory = 80, or 0 = all pairs like FindSTFCorrespondences) is allowed but takes the off-band PCG path
   // (3 host synchronisations per CG iteration) and a candidate table of n * 2*window * max_scan * 2 bytes.
   void SetMode(int mode, int64_t stf_window = 3) { mode_ = mode; stf_window_ = stf_window; }
+  // The correspondence search is the reference's own (per-scan KD-trees + pruned FindNearestPointNormal walk) unless this is
+  // called with true before the first Run(): then the brute-force definition of the same query (hitl_options.kd_tree_search = 0)
+  void SetBruteForceSearch(bool on) { brute_force_search_ = on; }
+  // forget the resident map: the next Run() uploads the scans again whatever their fingerprint says
+  void InvalidateMap() { map_poses_ = 0; map_print_ = 0; }
   const hitl_summary& Summary() const { return summary_; }
   bool want_gradients = false;     // fill gradients_ like problem.Evaluate at :1247-1252
+  bool want_info_mat = false;      // fill info_mat_
 
   // The session's solver (created on first use): the correction-cycle entry points (hitl_solver_fit_segments,
   // hitl_solver_apply_explicit_correction, hitl_solver_backprop ...) run on the same resident map.
@@ -81,6 +91,7 @@ class JointOptGpuT {
       hitl_options opt;
       hitl_options_default(&opt);
       opt.stf_moments = stf_moments_ ? 1 : 0;
+      opt.kd_tree_search = brute_force_search_ ? 0 : 1;
       create_status_ = hitl_solver_create(&opt, &solver_);
       if (create_status_ != HITL_OK) solver_ = NULL;
     }
@@ -93,20 +104,23 @@ class JointOptGpuT {
     if (!Solver()) return create_status_;
     const size_t n = poses_.size();
     if (n == 0 || robot_frame_point_clouds_.size() != n || robot_frame_normal_clouds_.size() != n) return HITL_ERR_INVALID_ARGUMENT;
-    // == BuildKDTrees on the first call (:1307).  The scans normally never change afterwards; a different map (other
-    // pose count, other scan sizes, or other coordinates in a sample of every scan) is uploaded again.
-    unsigned long long print = 1469598103934665603ull;
+    // == BuildKDTrees on the first call (:1307).  The scans normally never change afterwards; a different map -- any bit of
+    // any point or normal, any scan size -- is uploaded again.  The fingerprint reads every coordinate once (O(n_obs), the
+    // cost of the repack below; 4 lanes of FNV-1a over the 32-bit patterns) -- a sample would miss an edited point.
+    unsigned long long lane[4] = {1469598103934665603ull, 1099511628211ull * 31, 0x9e3779b97f4a7c15ull, 0xc2b2ae3d27d4eb4full};
     for (size_t i = 0; i < n; ++i) {
       const size_t m = robot_frame_point_clouds_[i].size();
-      print = (print ^ (unsigned long long)m) * 1099511628211ull;
-      if (m) {
-        const float probe[4] = {robot_frame_point_clouds_[i][0].x(), robot_frame_point_clouds_[i][0].y(),
-                                robot_frame_point_clouds_[i][m - 1].x(), robot_frame_point_clouds_[i][m / 2].y()};
+      if (robot_frame_normal_clouds_[i].size() != m) return HITL_ERR_INVALID_ARGUMENT;
+      lane[0] = (lane[0] ^ (unsigned long long)m) * 1099511628211ull;
+      for (size_t k = 0; k < m; ++k) {
+        const float v[4] = {robot_frame_point_clouds_[i][k].x(), robot_frame_point_clouds_[i][k].y(),
+                            robot_frame_normal_clouds_[i][k].x(), robot_frame_normal_clouds_[i][k].y()};
         unsigned int bits[4];
-        std::memcpy(bits, probe, sizeof(bits));
-        for (int k = 0; k < 4; ++k) print = (print ^ bits[k]) * 1099511628211ull;
+        std::memcpy(bits, v, sizeof(bits));
+        for (int q = 0; q < 4; ++q) lane[q] = (lane[q] ^ bits[q]) * 1099511628211ull;
       }
     }
+    const unsigned long long print = lane[0] ^ (lane[1] * 3) ^ (lane[2] * 5) ^ (lane[3] * 7);
     if (map_poses_ != n || map_print_ != print) {
       std::vector<int64_t> off(n + 1, 0);
       for (size_t i = 0; i < n; ++i) off[i + 1] = off[i] + (int64_t)robot_frame_point_clouds_[i].size();
@@ -147,6 +161,16 @@ class JointOptGpuT {
     for (size_t i = 0; i < n; ++i) {   // == CopyParams (:380-390)
       poses_[i].translation.x() = xyt[3 * i]; poses_[i].translation.y() = xyt[3 * i + 1]; poses_[i].angle = xyt[3 * i + 2];
     }
+    if (want_info_mat) {
+      int64_t ne = 0;
+      st = hitl_solver_get_info_mat(solver_, mode_, &ne, NULL, NULL);
+      if (st != HITL_OK) return st;
+      std::vector<int32_t> r(ne > 0 ? ne : 1), c(ne > 0 ? ne : 1);
+      st = hitl_solver_get_info_mat(solver_, mode_, &ne, r.data(), c.data());
+      if (st != HITL_OK) return st;
+      info_mat_.resize((size_t)ne);
+      for (int64_t k = 0; k < ne; ++k) info_mat_[(size_t)k] = std::make_pair((int)r[k], (int)c[k]);
+    }
     if (want_gradients) {
       gradients_.assign(3 * n, 0.0);
       double cost = 0.0;
@@ -174,7 +198,7 @@ class JointOptGpuT {
   hitl_solver* solver_;
   size_t map_poses_;
   unsigned long long map_print_;
-  bool stf_moments_;
+  bool stf_moments_, brute_force_search_;
   std::vector<float> ceres_cost_;
   int create_status_ = HITL_OK;
   hitl_summary summary_;

@@ -210,6 +210,18 @@ int hitl_solver_get_correspondence_counts(hitl_solver*, int64_t* n_pairs, int64_
 int hitl_solver_get_correspondences(hitl_solver*, int32_t* pair_src, int32_t* pair_tgt,
                                     int64_t* match_offset, int32_t* src_idx, int32_t* tgt_idx);
 
+/* Replaces: the `info_mat_` side effect of JointOpt::Run -- an N x N float image (JointOptimization.cpp:1313-1324, written
+ * to info_mat.png at :1381-1382; 10 GB at 50 000 poses) in which every pose pair that a factor or a matched point connects
+ * is set to 255 -- as the sparse list it is: the symmetric adjacency in coordinate form, upper triangle (row <= col),
+ * sorted by (row, col), no duplicates.  Entries (mode selects the factor sets, as for hitl_solver_solve):
+ *   odometry edges (i - 1, i)                                  (:744-745; modes A and C)
+ *   human rows (anchor_pose_id, constrained_pose_id), any type (:978-979; modes A and C)
+ *   pose pairs (i, j) with at least one accepted point match in the last correspondence search -- whether or not the
+ *   pair passed the more-than-kMinInterPoseCorrespondence filter (:624-625 marks per match; modes B and C); after
+ *   hitl_solver_set_correspondences: the installed pairs.
+ * Call with rows == cols == NULL for the count, then with arrays of that size.  Single-GPU entry point. */
+int hitl_solver_get_info_mat(hitl_solver*, int32_t mode, int64_t* n_entries, int32_t* rows, int32_t* cols);
+
 /* Replaces: SetParams + SolveHumanConstraints / PostHumanOptimization + CopyParams, i.e. the
  * ceres::Solve call sites (JointOptimization.cpp:392-402, :1064-1138, :1156-1256, :380-390).
  * poses_in_xyt / poses_out_xyt are n_poses*3 fp32 (x,y,theta); they may alias.  Synchronous. */

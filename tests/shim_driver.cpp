@@ -42,14 +42,31 @@ int main(int argc, char** argv) {
   if (!group.empty()) jo.human_constraints_.push_back(group);
   jo.SetMode(std::atoi(argv[3]), 3);
   jo.want_gradients = true;
+  jo.want_info_mat = true;
   const int st = jo.RunStatus();
   if (st != HITL_OK) { std::fprintf(stderr, "shim: %s (%s)\n", hitl_status_string(st), hitl_last_error()); return st == HITL_ERR_NO_DEVICE ? 3 : 70; }
   std::vector<float> xyt(3 * n);
   for (int64_t i = 0; i < n; ++i) { xyt[3 * i] = jo.poses_[i].translation.x(); xyt[3 * i + 1] = jo.poses_[i].translation.y(); xyt[3 * i + 2] = jo.poses_[i].angle; }
   if (hitl_io_save_results(argv[4], n, xyt.data()) != HITL_OK) return 67;
-  std::printf("iterations %d num_hc_residuals %d final_cost %.17g gradients %zu jacobian_rows %d jacobian_cols %d nnz %zu ceres_cost %zu\n",
+  // a second Run() on the same object after one coordinate of one scan changed (same sizes): the map must be uploaded again
+  // (round 2's sampled fingerprint missed it); the run itself is only checked to succeed
+  long long changed = 0;
+  if (n > 2 && jo.robot_frame_point_clouds_[1].size() > 3) {
+    JointOpt edited;
+    edited.poses_ = jo.poses_; edited.robot_frame_point_clouds_ = jo.robot_frame_point_clouds_; edited.robot_frame_normal_clouds_ = jo.robot_frame_normal_clouds_;
+    edited.covariances_ = jo.covariances_; edited.human_constraints_ = jo.human_constraints_;
+    edited.SetMode(HITL_MODE_STF_ONLY, 3);
+    if (edited.RunStatus() != HITL_OK) return 71;
+    const double c0 = edited.Summary().initial_cost;
+    edited.poses_ = jo.poses_;
+    edited.robot_frame_point_clouds_[1][2].x() += 0.02f;          // not one of the three points the old fingerprint sampled
+    if (edited.RunStatus() != HITL_OK) return 72;
+    changed = (edited.Summary().initial_cost != c0) ? 1 : 0;
+  }
+  std::printf("iterations %d num_hc_residuals %d final_cost %.17g gradients %zu jacobian_rows %d jacobian_cols %d nnz %zu ceres_cost %zu info_mat %zu edited_map_seen %lld\n",
               jo.Summary().iterations, jo.num_hc_residuals_, jo.Summary().final_cost, jo.gradients_.size(), jo.ceres_jacobian_.num_rows,
-              jo.ceres_jacobian_.num_cols, jo.ceres_jacobian_.values.size(), jo.GetCeresCost().size());
+              jo.ceres_jacobian_.num_cols, jo.ceres_jacobian_.values.size(), jo.GetCeresCost().size(), jo.info_mat_.size(), changed);
+  for (size_t k = 0; k < jo.info_mat_.size(); ++k) std::printf("info %d %d\n", jo.info_mat_[k].first, jo.info_mat_[k].second);
   hitl_posegraph_free(g);
   return 0;
 }

@@ -69,3 +69,19 @@ def test_shim_reproduces_the_oracle(driver, case, mode):
     assert int(fields[9]) == 2 * n_pairs and int(fields[13]) == 12 * n_pairs and int(fields[15]) == 0
     assert int(fields[11]) == (3 * len(po) if mode else 0)
     assert np.abs(got - po).max() <= 1e-4 + 1e-6      # results file prints "%f"
+    # info_mat_ as a sorted upper-triangle list: odometry edges, (anchor, constrained) of every human row, and -- in mode C --
+    # every pose pair with at least ONE accepted match (JointOptimization.cpp:624-625 marks per match, before the
+    # more-than-10 filter), held to the independent mirror's search with the filter switched off
+    info = [tuple(int(v) for v in ln.split()[1:]) for ln in r.stdout.splitlines() if ln.startswith("info ")]
+    assert int(fields[17]) == len(info) and info == sorted(set(info)) and all(a <= b for a, b in info)
+    want = {(i - 1, i) for i in range(1, len(po))} | {(min(int(rw[2]), int(rw[1])), max(int(rw[2]), int(rw[1]))) for rw in rows}
+    if mode:
+        import sys
+        sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+        import mirror as M
+        ps, pt = M.find_stf_correspondences(g["poses"], g["obs_offset"], g["px"], g["py"], g["nx"], g["ny"], 3, 1, min_pair=0)[:2]
+        want |= {(min(int(a), int(b)), max(int(a), int(b))) for a, b in zip(ps, pt)}
+        kept = o.get_correspondences()
+        assert {(min(int(a), int(b)), max(int(a), int(b))) for a, b in zip(kept[0], kept[1])} <= want
+    assert set(info) == want
+    assert int(fields[19]) == 1                       # an edited scan point (same sizes) was noticed: the map went up again
