@@ -692,6 +692,13 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 template <int B>
 __global__ __launch_bounds__(B >= 12 ? 512 : 1024) void k_cr_chunk(CrView cr, CrStage sg, CrSource src, double* w, double* x) {
   extern __shared__ double lds[];
+  if (cr.lm != nullptr) {                                  // device-driven LM loop (uniform branch)
+    if (cr.lm->done) return;
+    if (src.Hband != nullptr && src.lm != nullptr) {       // the first stage: the CURRENT buffers, today's trust region
+      if (src.lm->cur) { src.Hband = src.Hband_alt; src.g = src.g_alt; }
+      src.mu = src.lm->radius;
+    }
+  }
   constexpr int BB = B * B;
   const int M = sg.M, S = sg.S;
   const int nsl = sg.nsl;                                 // local slots: 0 .. M (a chunk) / 0 .. alive-1 (the top)
@@ -958,6 +965,7 @@ __global__ __launch_bounds__(B >= 12 ? 512 : 1024) void k_cr_chunk(CrView cr, Cr
 // v = (Dinv_u w_u)[r] and then only touches LDS: x_u[r] = v - Gl_u[r,:] x_{u-s} - Gr_u[r,:] x_{u+s}, level by level.
 template <int B>
 __global__ __launch_bounds__(1024) void k_cr_chunk_back(CrView cr, int S, int M, int top, const double* __restrict__ w, double* __restrict__ x, size_t wstride) {
+  if (cr.lm != nullptr && cr.lm->done) return;
   extern __shared__ double sx[];                         // (M + 1) * B
   const int tid = threadIdx.x;
   w += wstride * blockIdx.y;                             // one right-hand side per workgroup row
@@ -1145,8 +1153,11 @@ static CrPlan cr_plan(int nsb, int B, int np, int nrhs, size_t wstride) {
 
 int cr_contrib_slots(int nsb) { return nsb / 2 + 3; }     // boundary nodes of the finest chunk stage (M = 2)
 
+// validate == true: nothing is launched, the return value says whether the fused stages apply.  Every check runs BEFORE the
+// first launch, so a `false` never leaves half a factorisation behind for the level-per-launch fallback.
 template <int B>
-static bool cr_factor_fused(hipStream_t st, const CrView& cr, double* w, double* x, int nrhs, size_t wstride, const CrSource* src = nullptr) {
+static bool cr_factor_fused(hipStream_t st, const CrView& cr, double* w, double* x, int nrhs, size_t wstride, const CrSource* src = nullptr,
+                            bool validate = false) {
   if (cr.P == nullptr || cr.Pw == nullptr) return false;
   if (w == nullptr) nrhs = 0;
   if (src != nullptr && (x == nullptr || nrhs != 1 + src->n_unit)) return false;
@@ -1157,8 +1168,17 @@ static bool cr_factor_fused(hipStream_t st, const CrView& cr, double* w, double*
     if (!raised) { (void)hipGetLastError(); return false; }
   }
   const CrPlan pl = cr_plan(cr.nsb, B, cr.np, nrhs, wstride);
-  for (int t = 0; t < pl.n; ++t)                          // every stage must fit its LDS budget, else the level-per-launch path
-    if (cr_chunk_lds_bytes(pl.st[t].nsl - 1, B, cr_chunk_threads(pl.st[t].M, B), nrhs) > 128 * 1024) return false;
+  for (int t = 0; t < pl.n; ++t) {                        // every stage must fit its LDS budget, else the level-per-launch path
+    const CrStage& g = pl.st[t];
+    if (g.M < 2 || g.M > 64 || (g.M & (g.M - 1)) != 0) return false;         // a forced plan (HITL_CR_PLAN) with an unusable chunk size
+    const int thr = cr_chunk_threads(g.M, B);
+    const bool use_src = (src != nullptr && t == 0);
+    if (cr_chunk_lds_bytes(g.nsl - 1, B, thr, nrhs) + (use_src ? cr_chunk_src_extra(g.nsl, B, thr, src->Wb) : 0) > 128 * 1024) return false;
+    int bthr = (g.M - (g.top ? 0 : 1)) * B;
+    bthr = (bthr + 63) & ~63;
+    if (bthr > 1024) return false;                                           // never with M <= 64, B <= 12
+  }
+  if (validate) return true;
   for (int t = 0; t < pl.n; ++t) {
     const CrStage& g = pl.st[t];
     const int64_t alive = ((int64_t)cr.nsb + g.S - 1) / g.S;
@@ -1166,9 +1186,8 @@ static bool cr_factor_fused(hipStream_t st, const CrView& cr, double* w, double*
     const int thr = cr_chunk_threads(g.M, B);
     const bool use_src = (src != nullptr && t == 0);
     const size_t lds = cr_chunk_lds_bytes(g.nsl - 1, B, thr, nrhs) + (use_src ? cr_chunk_src_extra(g.nsl, B, thr, src->Wb) : 0);
-    if (lds > 128 * 1024) return false;
     CrSource none = {};
-    hipLaunchKernelGGL(k_cr_chunk<B>, dim3(chunks > 0 ? chunks : 1), dim3(thr), lds, st, cr, g, (src != nullptr && t == 0) ? *src : none, w, x);
+    hipLaunchKernelGGL(k_cr_chunk<B>, dim3(chunks > 0 ? chunks : 1), dim3(thr), lds, st, cr, g, use_src ? *src : none, w, x);
   }
   if (w != nullptr && x != nullptr) {
     for (int t = pl.n - 1; t >= 0; --t) {
@@ -1178,7 +1197,6 @@ static bool cr_factor_fused(hipStream_t st, const CrView& cr, double* w, double*
       const int chunks = g.top ? 1 : (int)((alive - 1 + g.M - 1) / g.M);
       int thr = (g.M - (g.top ? 0 : 1)) * B;
       thr = (thr + 63) & ~63;
-      if (thr > 1024) return false;                                          // never with the stage sizes above (M <= 64, B <= 12)
       hipLaunchKernelGGL(k_cr_chunk_back<B>, dim3(chunks, nrhs), dim3(thr), sizeof(double) * (g.M + 1) * B, st, cr, g.S, g.M, g.top, w, x, wstride);
     }
   }
@@ -1308,6 +1326,18 @@ void launch_cr_build_factor_solve_multi(hipStream_t st, const CrView& cr, const 
   hipLaunchKernelGGL(k_build_system, dim3((tot + 255) / 256), dim3(256), 0, st, src, cr, w);
   launch_unit_rhs(st, cr.nsb * cr.B, w + stride, stride, src.unit_cols, src.n_unit);
   launch_cr_factor_solve(st, cr, w, x, nrhs, stride);
+}
+
+// whether launch_cr_build_factor_solve would run as fused stages only (the device-driven LM loop needs that: the level-per-
+// launch fallback takes its buffers and the trust region from the host)
+bool cr_build_factor_solve_is_fused(const CrView& cr, const CrSource& src, double* w, double* x) {
+  if (dev_switches().cr_legacy || dev_switches().cr_unfused_build) return false;
+  switch (cr.B) {
+    case 3: return cr_factor_fused<3>(nullptr, cr, w, x, 1, 0, &src, true);
+    case 6: return cr_factor_fused<6>(nullptr, cr, w, x, 1, 0, &src, true);
+    case 9: return cr_factor_fused<9>(nullptr, cr, w, x, 1, 0, &src, true);
+    default: return cr_factor_fused<12>(nullptr, cr, w, x, 1, 0, &src, true);
+  }
 }
 
 void launch_cr_build_factor_solve(hipStream_t st, const CrView& cr, const CrSource& src, double* w, double* x) {

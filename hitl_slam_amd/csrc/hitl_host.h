@@ -76,6 +76,18 @@ struct SolverCtx {
   int64_t pose_base;         // GLOBAL index of local pose 0 (submap ranks take global pose arrays)
 };
 int solver_ctx(hitl_solver* s, SolverCtx* out);
+
+// The fixed summation order of the per-workgroup partial sums, shared by the host-driven LM loop and k_lm_decide (so that
+// both take bit-identical decisions): 32 accumulators take the terms b = lane, lane + 32, ... in ascending order, then the
+// 32 accumulators are added from lane 0 up.  v[b * stride] is term b.
+static inline double ordered_sum32(const double* v, int n, int stride) {
+  double p[32];
+  for (int q = 0; q < 32; ++q) p[q] = 0.0;
+  for (int b = 0; b < n; ++b) p[b & 31] += v[(size_t)b * stride];
+  double t = 0.0;
+  for (int q = 0; q < 32; ++q) t += p[q];
+  return t;
+}
 int solver_allgather(hitl_solver* s, const void* send, void* recv, int64_t bytes_per_rank);   // the submap transport, host buffers
 
 }  // namespace hitl

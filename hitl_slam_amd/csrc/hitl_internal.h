@@ -28,9 +28,12 @@ struct DevSwitches {
   bool stf_addr64 = false;         // HITL_STF_ADDR64: 64-bit addressing instantiations of k_linearize_stf
   bool force_dist = false;         // HITL_FORCE_DIST: one rank takes the submap code path
   bool force_rccl = false;         // HITL_FORCE_RCCL: in-library RCCL communicator with one rank
-  bool host_lm = false;            // HITL_HOST_LM: accept/reject decisions of the LM loop on the host (round-2 loop)
+  bool device_lm = false;          // HITL_DEVICE_LM: accept / reject / terminate decided on the device (k_lm_decide), iterations queued ahead.
+                                   // Measured (round 3): gap-free kernel timeline, but the decision kernel costs what the host turn-around
+                                   // cost -- 4-8 us per iteration SLOWER on every workload -- so the host-driven loop stays the default
   int stf_variant = 0;             // HITL_STF_VARIANT: instantiation of k_linearize_stf
   int kd_block = 256;              // HITL_KD_BLOCK: workgroup size of k_match_kd_tgt (64 / 128 / 256)
+  int lm_ahead = 3;                // HITL_LM_AHEAD: LM iterations the host queues ahead of the device-driven loop
   int kd_refill = 16;              // HITL_KD_REFILL: idle lanes per wave that trigger a refill from the query queue
   size_t cand_tile_bytes = (size_t)4 << 30;   // HITL_CAND_TILE_BYTES: candidate-table budget of the tiled search
   int cr_plan[16] = {0};           // HITL_CR_PLAN: chunk sizes of the fused stages
@@ -87,6 +90,22 @@ struct LinView {            // one linearisation (double buffered by the driver)
   double* partials;           // assemble workgroups x 2 : (cost, max |g|) per workgroup
 };
 
+// Device-resident state of the Levenberg-Marquardt loop (round 3: accept / reject / terminate are decided by k_lm_decide on
+// the device; the host only queues iterations ahead and polls a pinned progress word).  Kernels of the chain take a pointer
+// to it: `done` makes the launches queued behind the terminating iteration return at once, `cur` selects which of the two
+// linearisation / state buffers is the current one, `radius` is the trust region the next step is solved with.
+struct LmDev {
+  int cur;                    // linearisation buffer (and state buffer) of the CURRENT state: 0 / 1; the candidate lives in cur ^ 1
+  int done;                   // the loop has terminated
+  int term;                   // HITL_CONVERGENCE / HITL_NO_CONVERGENCE / HITL_FAILURE
+  int iter, successful, unsuccessful, invalid_run, lin_calls;
+  double radius, decrease_factor, cost, gmax;
+};
+struct LmOpts {               // the constants of the decision, by value
+  double function_tolerance, gradient_tolerance, parameter_tolerance, max_radius, min_radius, min_relative_decrease, guard2;
+  int max_iter, late;
+};
+
 struct CrSource {           // where the first cyclic-reduction stage can take its tiles from instead of cr.D / cr.L (Hband == null: unused)
   const double* Hband; const double* g; const double* scale; const unsigned char* fixed;
   double mu, min_diag, max_diag;
@@ -94,6 +113,9 @@ struct CrSource {           // where the first cyclic-reduction stage can take i
   double* rhs;                // receives the scaled right-hand side -S g (the copy the residual check and the step bookkeeping read)
   const int* unit_cols;       // right-hand sides 1 .. n_unit are unit vectors e_{unit_cols[k]} (the interface columns of a submap rank)
   int n_unit;
+  // device-driven LM loop (lm != null): Hband / g are buffer 0, the *_alt pointers buffer 1, lm->cur picks; mu = lm->radius
+  const LmDev* lm;
+  const double* Hband_alt; const double* g_alt;
 };
 
 struct CrView {             // block-tridiagonal system + cyclic-reduction factors
@@ -109,6 +131,7 @@ struct CrView {             // block-tridiagonal system + cyclic-reduction facto
   double* Pw = nullptr;       // [rhs pw_rhs][parity 2][left/right 2][np][B]
   int np = 0;                 // cr_contrib_slots(nsb)
   int pw_rhs = 1;             // right-hand sides Pw is sized for
+  const LmDev* lm = nullptr;  // device-driven LM loop: the fused stage kernels return at once when lm->done
 };
 int cr_contrib_slots(int nsb);
 
@@ -118,13 +141,16 @@ void launch_pose_trig(hipStream_t st, int n_poses, const double* x, double2* cs)
 constexpr int kPairMomStride = 32;
 void launch_stf_moments(hipStream_t st, const MapView& map, const PairView& pr, double* pairM);
 void launch_linearize_stf_moments(hipStream_t st, const PairView& pr, const double* pairM, const double* x, const double2* cs, double corr,
-                                  double sd, double* pairRJ);
+                                  double sd, double* pairRJ, const LmDev* lm = nullptr, const double* x_alt = nullptr, double* pairRJ_alt = nullptr);
+// lm != null (device-driven LM loop): x / pairRJ are buffer 0, x_alt / pairRJ_alt buffer 1; the kernel works on the
+// CANDIDATE's buffers (lm->cur ^ 1) and returns at once when lm->done
 void launch_linearize_stf(hipStream_t st, const MapView& map, const PairView& pr, int max_scan, int64_t map_obs_count, int64_t n_matches,
-                          const double* x, const double2* cs, float corr, float std_dev, double* pairRJ);
+                          const double* x, const double2* cs, float corr, float std_dev, double* pairRJ,
+                          const LmDev* lm = nullptr, const double* x_alt = nullptr, double* pairRJ_alt = nullptr);
 void launch_pack_obs(hipStream_t st, int64_t n, const float* px, const float* py, const float* nx, const float* ny,
                      float4* obs);
 void launch_assemble(hipStream_t st, const MapView& map, const PairView& pr, const FactorView& fv,
-                     const double* x, const LinView& lin);
+                     const double* x, const LinView& lin, const LmDev* lm = nullptr, const double* x_alt = nullptr, const LinView* lin_alt = nullptr);
 inline int assemble_blocks(int n_poses) { return (n_poses + 63) / 64; }   // k_assemble: 4 lanes per pose, 256 threads
 void launch_jacobi_scale(hipStream_t st, int n_poses, int npad, int Wb, const double* Hband, int enable,
                          const unsigned char* fixed, double* scale);
@@ -152,6 +178,7 @@ void launch_cr_factor_solve(hipStream_t st, const CrView& cr, double* w, double*
 // build_system + factor + solve with the first stage reading the band blocks itself (no D / L round trip through memory);
 // falls back to launch_build_system + launch_cr_factor_solve where the fused stages do not apply
 void launch_cr_build_factor_solve(hipStream_t st, const CrView& cr, const CrSource& src, double* w, double* x);
+bool cr_build_factor_solve_is_fused(const CrView& cr, const CrSource& src, double* w, double* x);   // no launch: would it run as fused stages only?
 // the same with src.n_unit unit right-hand sides behind the first one (w, x: 1 + n_unit vectors `stride` apart)
 void launch_cr_build_factor_solve_multi(hipStream_t st, const CrView& cr, const CrSource& src, double* w, double* x, size_t stride);
 void launch_cr_solve(hipStream_t st, const CrView& cr, const double* rhs, double* w, double* x);   // x = M^-1 rhs; w = work vector (may be rhs itself: overwritten)
@@ -159,6 +186,15 @@ void launch_cr_solve(hipStream_t st, const CrView& cr, const double* rhs, double
 void launch_spmv(hipStream_t st, int n_poses, int npad, const FactorView& fv, const LinView& lin,
                  const double* scale, double mu, double min_diag, double max_diag, const double* v, double* y, bool all_cols = false);
 void launch_host_flag(hipStream_t st, double* flag_pinned, double seq);
+// device-driven LM loop: the band pass on the CURRENT buffers (lin0 / lin1, x0 / x1 picked by lm->cur; mu = lm->radius),
+// candidate state into the other x buffer, partials into device memory
+void launch_spmv_residual_step_lm(hipStream_t st, int n_poses, int npad, const FactorView& fv, const LinView& lin0, const LinView& lin1,
+                                  const double* scale, double min_diag, double max_diag, const double* v, const double* rhs, double* x0,
+                                  double* x1, double* q, double* partials, double2* cs, const LmDev* lm);
+// the decision of one LM iteration (Ceres' trust-region rules) from the partial sums of the band pass and of
+// the candidate's linearisation; progress[0..7] (pinned host memory) = iterations completed, done, termination, cost, ...
+void launch_lm_decide(hipStream_t st, LmDev* lm, LmOpts o, const double* step_partials, int nblk_step, const double* lin_partials0,
+                      const double* lin_partials1, int nblk_lin, double* progress_pinned);
 void launch_pack_owned(hipStream_t st, int nhead, const double* head, const double* vec, int off, int cnt, int maxcnt, double* rec);
 void launch_scatter_idx(hipStream_t st, int cnt, const int* idx, const double* val, double* vec);
 int spmv_blocks(int npad);

@@ -89,6 +89,7 @@ __global__ void k_pose_trig(int n, const double* __restrict__ x, double2* __rest
 }
 
 struct StfAcc { double S0, A0x, A0y, T01, S1, A1x, A1y, T10; };
+struct StfLm { const LmDev* lm; const double* x_alt; double* pairRJ_alt; };
 
 // one match: source point (ax, ay) + normal (anx, any) already fp64, target observation tv fp32
 template <bool WEIGHTED>
@@ -129,7 +130,11 @@ __device__ __forceinline__ void stf_source(const double2* s_scan8, const double2
 template <int SRC, bool OFF32, int AHEAD, int MINB>
 __global__ __launch_bounds__(kStfBlock, MINB) void k_linearize_stf(MapView map, PairView pr, int chunk,
                                                                     const double* __restrict__ x, const double2* __restrict__ cs,
-                                                                    double kf, double* __restrict__ pairRJ) {
+                                                                    double kf, double* __restrict__ pairRJ, StfLm lmsel) {
+  if (lmsel.lm != nullptr) {                    // device-driven LM loop: the candidate's buffers (uniform branch, scalar loads)
+    if (lmsel.lm->done) return;
+    if ((lmsel.lm->cur ^ 1) != 0) { x = lmsel.x_alt; pairRJ = lmsel.pairRJ_alt; }
+  }
   __shared__ double s_tot[kStfBlock / kStfSub][kStfSums];           // the 8 totals of each half-wave's pair
   extern __shared__ double s_scan_raw[];
   float4* s_scan4 = reinterpret_cast<float4*>(s_scan_raw);            // SRC == 1
@@ -316,7 +321,11 @@ __device__ __forceinline__ void sym5_mul(const double* __restrict__ M, const dou
 
 __global__ __launch_bounds__(128) void k_linearize_stf_moments(PairView pr, const double* __restrict__ pairM, const double* __restrict__ x,
                                                                const double2* __restrict__ cs, double corr, double sd,
-                                                               double* __restrict__ pairRJ) {
+                                                               double* __restrict__ pairRJ, StfLm lmsel) {
+  if (lmsel.lm != nullptr) {                    // device-driven LM loop: the candidate's buffers
+    if (lmsel.lm->done) return;
+    if ((lmsel.lm->cur ^ 1) != 0) { x = lmsel.x_alt; pairRJ = lmsel.pairRJ_alt; }
+  }
   const int p = blockIdx.x * 128 + threadIdx.x;
   if (p >= pr.n_pairs) return;
   const int i = pr.pair_src[p], j = pr.pair_tgt[p];
@@ -358,9 +367,10 @@ void launch_stf_moments(hipStream_t st, const MapView& map, const PairView& pr, 
 }
 
 void launch_linearize_stf_moments(hipStream_t st, const PairView& pr, const double* pairM, const double* x, const double2* cs, double corr,
-                                  double sd, double* pairRJ) {
+                                  double sd, double* pairRJ, const LmDev* lm, const double* x_alt, double* pairRJ_alt) {
   if (pr.n_pairs == 0) return;
-  hipLaunchKernelGGL(k_linearize_stf_moments, dim3((pr.n_pairs + 127) / 128), dim3(128), 0, st, pr, pairM, x, cs, corr, sd, pairRJ);
+  const StfLm lmsel = {lm, x_alt, pairRJ_alt};
+  hipLaunchKernelGGL(k_linearize_stf_moments, dim3((pr.n_pairs + 127) / 128), dim3(128), 0, st, pr, pairM, x, cs, corr, sd, pairRJ, lmsel);
 }
 
 void launch_pose_trig(hipStream_t st, int n_poses, const double* x, double2* cs) {
@@ -368,7 +378,8 @@ void launch_pose_trig(hipStream_t st, int n_poses, const double* x, double2* cs)
 }
 
 void launch_linearize_stf(hipStream_t st, const MapView& map, const PairView& pr, int max_scan, int64_t map_obs_count, int64_t n_matches, const double* x,
-                          const double2* cs, float corr, float std_dev, double* pairRJ) {
+                          const double2* cs, float corr, float std_dev, double* pairRJ, const LmDev* lm, const double* x_alt, double* pairRJ_alt) {
+  const StfLm lmsel = {lm, x_alt, pairRJ_alt};
   if (pr.n_pairs == 0) return;
   const int chunk = (map.n_poses + 7) / 8;
   const int cap = (max_scan + 63) & ~63;
@@ -384,7 +395,7 @@ void launch_linearize_stf(hipStream_t st, const MapView& map, const PairView& pr
   int ahead = kStfAheadDefault, minb = (src == 2 && off32) ? 7 : 5;     // the fallback layouts need > 80 VGPRs: 5 waves per SIMD instead of spilling
   if (variant > 0 && src == 2 && off32) { ahead = std::min(3, std::max(1, variant / 10)); minb = (variant % 10 == 5) ? 5 : (variant % 10 == 7) ? 7 : 6; }
   const size_t lds = (src == 2) ? (size_t)cap * 32 : (src == 1) ? (size_t)cap * 16 : 0;
-#define HITL_STF_GO(SRC, O32, AH, MINB) hipLaunchKernelGGL((k_linearize_stf<SRC, O32, AH, MINB>), grid, block, lds, st, map, pr, chunk, x, cs, kf, pairRJ)
+#define HITL_STF_GO(SRC, O32, AH, MINB) hipLaunchKernelGGL((k_linearize_stf<SRC, O32, AH, MINB>), grid, block, lds, st, map, pr, chunk, x, cs, kf, pairRJ, lmsel)
   if (src == 2 && off32 && minb == 7) {
     if (ahead == 1) HITL_STF_GO(2, true, 1, 7); else HITL_STF_GO(2, true, 2, 7);
   } else if (src == 2 && off32) {
@@ -450,8 +461,13 @@ __device__ __forceinline__ double quad_sum(double v) {     // fixed order: (l0 +
 // the odometry edge (i-1, i), lane 1 the edge (i, i+1), lane 2 the human rows, lane d-1 the band block (i, i+d); the
 // diagonal block, gradient and cost are then summed across the quad in a fixed order.  No atomics: bit-reproducible.
 constexpr int kAsmBlock = 256;     // 64 poses per workgroup
+struct AsmLm { const LmDev* lm; const double* x_alt; LinView lin_alt; };
 __global__ __launch_bounds__(kAsmBlock) void k_assemble(MapView map, PairView pr, FactorView fv, const double* __restrict__ x,
-                                                         LinView lin) {
+                                                         LinView lin, AsmLm lmsel) {
+  if (lmsel.lm != nullptr) {                    // device-driven LM loop: the candidate's buffers
+    if (lmsel.lm->done) return;
+    if ((lmsel.lm->cur ^ 1) != 0) { x = lmsel.x_alt; lin = lmsel.lin_alt; }
+  }
   const int i = (blockIdx.x * kAsmBlock + (int)threadIdx.x) >> 2;
   const int r = threadIdx.x & 3;
   const int n = map.n_poses;
@@ -626,9 +642,10 @@ __global__ __launch_bounds__(128) void k_assemble_offband(FactorView fv, LinView
 }
 
 void launch_assemble(hipStream_t st, const MapView& map, const PairView& pr, const FactorView& fv, const double* x,
-                     const LinView& lin) {
+                     const LinView& lin, const LmDev* lm, const double* x_alt, const LinView* lin_alt) {
   const int n = map.n_poses;
-  hipLaunchKernelGGL(k_assemble, dim3(assemble_blocks(n)), dim3(kAsmBlock), 0, st, map, pr, fv, x, lin);
+  AsmLm lmsel = {lm, x_alt, lin_alt ? *lin_alt : lin};
+  hipLaunchKernelGGL(k_assemble, dim3(assemble_blocks(n)), dim3(kAsmBlock), 0, st, map, pr, fv, x, lin, lmsel);
   if (fv.with_stf && fv.n_offband > 0)
     hipLaunchKernelGGL(k_assemble_offband, dim3((fv.n_offband + 127) / 128), dim3(128), 0, st, fv, lin);
 }

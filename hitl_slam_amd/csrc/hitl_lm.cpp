@@ -51,9 +51,9 @@ static int enqueue_linearize(hitl_solver* s, const FactorView& fv, const double*
 static int finish_linearize(hitl_solver* s, const FactorView& fv, LinResult* out) {
   const int nblk = assemble_blocks(s->n);
   const double* host = s->h_partials + (size_t)spmv_blocks(s->npad) * 8;
-  double cost = 0.0, gmax = 0.0;
-  for (int b = 0; b < nblk; ++b) {   // fixed order: bit-reproducible
-    cost += host[2 * b];
+  const double cost = ordered_sum32(host, nblk, 2);   // fixed order: bit-reproducible, and the order k_lm_decide uses
+  double gmax = 0.0;
+  for (int b = 0; b < nblk; ++b) {
     const double g = host[2 * b + 1];
     if (g > gmax || g != g) gmax = g;
   }
@@ -205,9 +205,8 @@ static int read_step_partials(hitl_solver* s, double* rr, double* bb, StepScalar
 
 static int finish_step_partials(hitl_solver* s, double* rr, double* bb, StepScalars* ss) {
   const int nblk = spmv_blocks(s->npad);
-  double acc[7] = {0, 0, 0, 0, 0, 0, 0};
-  for (int b = 0; b < nblk; ++b)
-    for (int k = 0; k < 7; ++k) acc[k] += s->h_partials[8 * b + k];
+  double acc[7];
+  for (int k = 0; k < 7; ++k) acc[k] = ordered_sum32(s->h_partials + k, nblk, 8);     // the order k_lm_decide uses
   if (rr) *rr = acc[0];
   if (bb) *bb = acc[1];
   if (ss) { ss->dt_rhs = acc[2]; ss->dt_q = acc[3]; ss->step2 = acc[4]; ss->xn2 = acc[5]; ss->bad = acc[6]; }
@@ -601,6 +600,122 @@ static double now_ms() {
 // ---------------------------------------------------------------------------------------
 // Levenberg-Marquardt with Ceres trust-region semantics (DESIGN.md "LM")
 // ---------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------
+// The Levenberg-Marquardt loop with the decisions on the device (single GPU, every pose pair inside the band -- the path
+// the headline numbers run).  The host queues whole iterations -- banded solve on the CURRENT buffers with the CURRENT
+// trust region, band pass + candidate state, the candidate's linearisation, k_lm_decide -- up to DevSwitches::lm_ahead (3) iterations ahead
+// of the one the device has finished, and polls one pinned word.  No kernel argument depends on a decision: which buffers
+// are current, the radius, and whether the loop is over are read from LmDev on the device.  Launches queued behind the
+// terminating iteration return at once.  Same statements, same sums in the same order as the host loop below: identical
+// iteration sequences and bit-identical poses (tests/test_gpu_parity.py A/B).
+// OPT-IN (HITL_DEVICE_LM=1).  Measured on MI355X (tools/dev/lm_ab.py, lm_ab2.py): the kernel trace of this loop has no gaps
+// between launches (the host-driven loop: ~40 us per iteration in the round-2 trace), yet its wall clock is 4-8 us per
+// iteration LONGER on every workload tried (C4 18.65 vs 18.15 ms, C2 1.20 vs 1.16 ms, moments mode 7.39 vs 7.15 ms,
+// mode A 5.13 vs 5.01 ms; queue depth 1..6 makes no difference): k_lm_decide (sums of ~4700 partials, a system-scope fence
+// for the progress word, one more launch boundary: 12 us) costs what the host's turn-around really cost -- most of those
+// 40 us were already hidden behind the first cyclic-reduction stage the host queues first.
+// ---------------------------------------------------------------------------------------
+constexpr int kLmEventPairs = 32;
+
+static bool lm_device_loop_applies(hitl_solver* s, const FactorView& fv) {
+  if (!dev_switches().device_lm || s->dist_mode() || fv.n_offband != 0 || s->opt.timing_level >= 2) return false;
+  const LinView lv0 = s->lin_view(0), lv1 = s->lin_view(1);
+  CrView cr = s->cr_view();
+  cr.lm = s->lm_dev.p;
+  const CrSource src = {lv0.Hband, lv0.g, s->scale.p, s->fixed.p, 1.0, s->opt.min_lm_diagonal, s->opt.max_lm_diagonal, s->n, fv.band_poses, s->rhs.p,
+                        nullptr, 0, s->lm_dev.p, lv1.Hband, lv1.g};
+  return cr_build_factor_solve_is_fused(cr, src, s->wv.p, s->dt.p);
+}
+
+// cur: the buffer holding the initial linearisation; on return *xfinal points at the state the loop ended in
+static int lm_device_loop(hitl_solver* s, const FactorView& fv, int cur, double cost, double gmax, hitl_summary* S, double** xfinal,
+                          double* radius_out, int* term_out) {
+  hipStream_t st = s->stream;
+  const hitl_options& o = s->opt;
+  const MapView mv = s->map_view();
+  const PairView pv = s->pair_view();
+  const LinView lv0 = s->lin_view(0), lv1 = s->lin_view(1);
+  LmDev init;
+  std::memset(&init, 0, sizeof(init));
+  init.cur = cur; init.radius = o.initial_trust_region_radius; init.decrease_factor = 2.0; init.cost = cost; init.gmax = gmax;
+  init.term = HITL_NO_CONVERGENCE; init.lin_calls = 0;
+  HIP_TRY(hipMemcpyAsync(s->lm_dev.p, &init, sizeof(init), hipMemcpyHostToDevice, st));
+  volatile double* prog = s->h_scalars + kNumScalars;
+  for (int k = 0; k < 8; ++k) prog[k] = 0.0;
+  const double guard = std::max(std::max(o.linear_solver_tolerance, 1e-15), 1e-9);
+  const LmOpts lo = {o.function_tolerance, o.gradient_tolerance, o.parameter_tolerance, o.max_trust_region_radius, o.min_trust_region_radius,
+                     o.min_relative_decrease, guard * guard, (int)o.max_num_iterations, o.tolerances_after_accept != 0 ? 1 : 0};
+  CrView cr = s->cr_view();
+  cr.lm = s->lm_dev.p;
+  const CrSource src = {lv0.Hband, lv0.g, s->scale.p, s->fixed.p, 1.0, o.min_lm_diagonal, o.max_lm_diagonal, s->n, fv.band_poses, s->rhs.p,
+                        nullptr, 0, s->lm_dev.p, lv1.Hband, lv1.g};
+  const int nblk_step = spmv_blocks(s->npad), nblk_lin = assemble_blocks(s->n);
+  if (s->lm_events.empty() && o.timing_level >= 1) {
+    s->lm_events.assign(2 * kLmEventPairs, nullptr);
+    for (hipEvent_t& e : s->lm_events) if (hipEventCreate(&e) != hipSuccess) return fail(HITL_ERR_HIP, "hipEventCreate failed");
+  }
+  const double t_loop0 = now_ms();
+  int queued = 0, completed = 0, pairs_used = 0;
+  int pair_iter[kLmEventPairs];                          // the (1-based) iteration each event pair brackets
+  bool done = false;
+  const int max_it = (int)o.max_num_iterations;
+  // the state buffers: s->x holds the current state when cur == 0 ... the initial linearisation was taken at s->x with buffer
+  // `cur`; buffer index and state index move together, so x of buffer b is (b == cur0 ? s->x : s->xc)
+  double* xb[2];
+  xb[cur] = s->x.p; xb[cur ^ 1] = s->xc.p;
+  while (!done) {
+    while (queued < max_it && queued - completed < dev_switches().lm_ahead) {
+      launch_cr_build_factor_solve(st, cr, src, s->wv.p, s->dt.p);
+      launch_spmv_residual_step_lm(st, s->n, s->npad, fv, lv0, lv1, s->scale.p, o.min_lm_diagonal, o.max_lm_diagonal, s->dt.p, s->rhs.p, xb[0], xb[1],
+                                   s->qv.p, s->step_partials.p, fv.with_stf ? s->pose_cs.p : nullptr, s->lm_dev.p);
+      const bool timed = fv.with_stf && o.timing_level >= 1 && (s->lin_launches & 3) == 0 && pairs_used < kLmEventPairs;
+      ++s->lin_launches;
+      if (timed) HIP_TRY(hipEventRecord(s->lm_events[2 * pairs_used], st));
+      if (fv.with_stf) {
+        if (o.stf_moments)
+          launch_linearize_stf_moments(st, pv, s->pairM.p, xb[0], s->pose_cs.p, o.point_correlation_factor, o.laser_std_dev, lv0.pairRJ, s->lm_dev.p, xb[1], lv1.pairRJ);
+        else
+          launch_linearize_stf(st, mv, pv, s->max_scan, s->n_obs, s->n_matches, xb[0], s->pose_cs.p, o.point_correlation_factor, o.laser_std_dev, lv0.pairRJ,
+                               s->lm_dev.p, xb[1], lv1.pairRJ);
+      }
+      if (timed) { HIP_TRY(hipEventRecord(s->lm_events[2 * pairs_used + 1], st)); pair_iter[pairs_used] = queued + 1; ++pairs_used; }
+      launch_assemble(st, mv, pv, fv, xb[0], lv0, s->lm_dev.p, xb[1], &lv1);
+      launch_lm_decide(st, s->lm_dev.p, lo, s->step_partials.p, nblk_step, lv0.partials, lv1.partials, nblk_lin, s->h_scalars + kNumScalars);
+      HIP_TRY(hipGetLastError());
+      ++queued;
+    }
+    // wait until the device has finished another iteration (or the loop)
+    for (uint32_t spins = 1;; ++spins) {
+      const int c = (int)prog[0];
+      if (c > completed) { completed = c; std::atomic_thread_fence(std::memory_order_acquire); break; }
+      if ((spins & 0xfffffu) == 0) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e == hipSuccess) { if ((int)prog[0] > completed) continue; return fail(HITL_ERR_HIP, "the stream drained without progress of the LM loop"); }
+        if (e != hipErrorNotReady) return fail(HITL_ERR_HIP, std::string("while waiting for the LM loop: ") + hipGetErrorString(e));
+      }
+    }
+    if (prog[1] != 0.0 || completed >= max_it) done = true;
+  }
+  const double t_done = now_ms();
+  LmDev fin;
+  HIP_TRY(hipMemcpyAsync(&fin, s->lm_dev.p, sizeof(fin), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (dev_switches().timing) std::fprintf(stderr, "lm_device_loop: loop %.3f ms, drain %.3f ms, queued %d completed %d\n", t_done - t_loop0, now_ms() - t_done, queued, completed);
+  //                    // also drains the launches queued behind the end (they return at once)
+  for (int k = 0; k < pairs_used; ++k) {
+    if (pair_iter[k] > fin.iter) continue;                 // queued behind the end of the loop: that launch returned at once, not a sample
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, s->lm_events[2 * k], s->lm_events[2 * k + 1]) == hipSuccess) { S->linearize_ms += ms; S->linearize_timed_calls++; }
+    else (void)hipGetLastError();
+  }
+  S->iterations = fin.iter; S->successful_steps += fin.successful; S->unsuccessful_steps += fin.unsuccessful;
+  S->linear_iterations += fin.iter; S->linearize_calls += fin.lin_calls;
+  S->final_cost = fin.cost; S->final_gradient_max_norm = fin.gmax;
+  *radius_out = fin.radius; *term_out = fin.term;
+  *xfinal = xb[fin.cur];
+  return HITL_OK;
+}
+
 int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float* poses_global, float* poses_out,
                     hitl_summary* summary) {
   const double t_start = now_ms();
@@ -642,6 +757,15 @@ int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float* poses
   bool done = false;
   if (!(cost == cost) || !(gmax == gmax)) { term = HITL_FAILURE; done = true; }
   else if (gmax <= o.gradient_tolerance) { term = HITL_CONVERGENCE; done = true; }
+  bool dev_loop = false;
+  if (!done && o.max_num_iterations > 0 && lm_device_loop_applies(s, fv)) {
+    // decisions on the device, iterations queued ahead (single GPU, banded): see lm_device_loop
+    double* xf = nullptr;
+    TRY(lm_device_loop(s, fv, cur, cost, gmax, &S, &xf, &radius, &term));
+    xcur = xf;
+    cost = S.final_cost; gmax = S.final_gradient_max_norm; iter = S.iterations;
+    done = true; dev_loop = true;
+  }
   while (!done) {
     if (iter >= o.max_num_iterations) { term = HITL_NO_CONVERGENCE; break; }
     ++iter;
@@ -711,6 +835,7 @@ int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float* poses
       if (radius < o.min_trust_region_radius) { term = HITL_CONVERGENCE; break; }
     }
   }
+  (void)dev_loop;
   S.termination = term; S.iterations = iter;
   S.final_cost = cost; S.final_gradient_max_norm = gmax; S.final_trust_region_radius = radius;
   {  // CopyParams (JointOptimization.cpp:380-390): fp64 -> fp32, theta through angle_mod

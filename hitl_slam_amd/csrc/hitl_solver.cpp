@@ -418,9 +418,10 @@ void read_dev_switches() {
   auto num = [](const char* name, long long dflt) { const char* e = std::getenv(name); return e ? std::atoll(e) : dflt; };
   d.timing = on("HITL_TIMING"); d.event_sync = on("HITL_EVENT_SYNC"); d.cr_legacy = on("HITL_CR_LEGACY");
   d.cr_unfused_build = on("HITL_CR_UNFUSED_BUILD"); d.stf_addr64 = on("HITL_STF_ADDR64"); d.force_dist = on("HITL_FORCE_DIST");
-  d.force_rccl = on("HITL_FORCE_RCCL"); d.host_lm = on("HITL_HOST_LM");
+  d.force_rccl = on("HITL_FORCE_RCCL"); d.device_lm = on("HITL_DEVICE_LM");
   d.stf_variant = (int)num("HITL_STF_VARIANT", 0);
   d.kd_block = (int)num("HITL_KD_BLOCK", d.kd_block);
+  d.lm_ahead = (int)std::max(1ll, std::min(16ll, num("HITL_LM_AHEAD", d.lm_ahead)));
   d.kd_refill = (int)std::max(1ll, std::min(64ll, num("HITL_KD_REFILL", d.kd_refill)));
   d.cand_tile_bytes = (size_t)std::max(1ll, num("HITL_CAND_TILE_BYTES", (long long)d.cand_tile_bytes));
   if (const char* e = std::getenv("HITL_CR_PLAN"))
@@ -521,8 +522,9 @@ int hitl_solver_create(const hitl_options* opt, hitl_solver** out) {
   if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) return bail(HITL_ERR_HIP, "hipStreamCreate failed");
   for (hipEvent_t* e : {&s->ev0, &s->ev1, &s->ev2, &s->ev3, &s->ev_sync})
     if (hipEventCreate(e) != hipSuccess) return bail(HITL_ERR_HIP, "hipEventCreate failed");
-  if (hipHostMalloc((void**)&s->h_scalars, sizeof(double) * kNumScalars) != hipSuccess) return bail(HITL_ERR_HIP, "hipHostMalloc failed");
-  std::memset(s->h_scalars, 0, sizeof(double) * kNumScalars);     // a recycled pinned block may hold an old sequence word (spin_sync polls it)
+  if (hipHostMalloc((void**)&s->h_scalars, sizeof(double) * (kNumScalars + 8)) != hipSuccess) return bail(HITL_ERR_HIP, "hipHostMalloc failed");
+  std::memset(s->h_scalars, 0, sizeof(double) * (kNumScalars + 8));
+  if (s->lm_dev.resize(1) != HITL_OK) return bail(HITL_ERR_OUT_OF_MEMORY, "hipMalloc failed");     // a recycled pinned block may hold an old sequence word (spin_sync polls it)
   if (s->d_scalars.resize(kNumScalars) != HITL_OK) return bail(HITL_ERR_OUT_OF_MEMORY, "hipMalloc failed");
   s->rank = o.rank;
   s->world = o.world_size;
@@ -561,6 +563,8 @@ void hitl_solver_destroy(hitl_solver* s) {
   s->iface_dev.release(); s->rhsN.release(); s->zN.release(); s->coef_dev.release(); s->halo_val.release(); s->halo_sc.release();
   if (s->h_scalars) (void)hipHostFree(s->h_scalars);
   for (hipEvent_t e : {s->ev0, s->ev1, s->ev2, s->ev3, s->ev_sync}) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : s->lm_events) if (e) (void)hipEventDestroy(e);
+  s->lm_dev.release();
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
 }

@@ -19,7 +19,9 @@ struct hitl_solver {
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr, ev_sync = nullptr;
   int64_t lin_launches = 0;     // linearisations queued so far (every 4th is bracketed by events at timing_level 1)
   bool lin_timed = false;       // the linearisation in flight is bracketed
-  double* h_scalars = nullptr;  // pinned, kNumScalars
+  double* h_scalars = nullptr;  // pinned, kNumScalars + 8: [15] = sequence word of spin_sync, [kNumScalars ..] = progress record of the device-driven LM loop
+  DevArray<LmDev> lm_dev;       // device-resident state of the LM loop (k_lm_decide)
+  std::vector<hipEvent_t> lm_events;   // pairs bracketing k_linearize_stf launches queued ahead (device-driven loop)
   int64_t sync_seq = 0;
   double* h_partials = nullptr; // pinned, h_partials_cap doubles
   size_t h_partials_cap = 0;

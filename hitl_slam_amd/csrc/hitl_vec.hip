@@ -27,6 +27,11 @@ struct SpmvAux {
   double2* cs;         // MODE 2, 3 (may be null): (cos, sin) of the candidate's theta, saves the k_pose_trig launch in front of k_linearize_stf
   int all_cols;        // MODE 0: columns of constant poses take part too (distributed PCG: the halo entries of v carry the
                        // neighbouring submaps' values; global pose 0 carries an exact 0)
+  // device-driven LM loop (MODE 3, lm != null): lin / x are buffer 0, lin_alt / x_alt buffer 1; lm->cur picks the current
+  // one, the candidate state goes to the other x buffer; mu = lm->radius
+  const LmDev* lm;
+  LinView lin_alt;
+  double* x_alt;
 };
 
 template <int MODE>
@@ -34,6 +39,13 @@ __global__ __launch_bounds__(128) void k_spmv(int n_poses, int npad, FactorView 
                                                const double* __restrict__ scale, double mu, double min_diag,
                                                double max_diag, const double* __restrict__ v, double* __restrict__ y,
                                                SpmvAux aux) {
+  if (MODE == 3 && aux.lm != nullptr) {          // uniform branch, scalar loads
+    if (aux.lm->done) return;
+    double* xb1 = aux.x_alt;
+    double* xb0 = const_cast<double*>(aux.x);
+    if (aux.lm->cur) { lin = aux.lin_alt; aux.x = xb1; aux.xc = xb0; } else { aux.xc = xb1; }
+    mu = aux.lm->radius;
+  }
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   // MODE 3 = MODE 1 and MODE 2 in one pass (banded single-GPU solve: v is exactly 0 on constant poses, so including
   // their columns changes nothing): residual partials in slots 0,1 and the step bookkeeping in slots 2..6
@@ -204,6 +216,111 @@ void launch_spmv_residual_step(hipStream_t st, int n_poses, int npad, const Fact
   SpmvAux aux = {rhs, nullptr, x, xc, partials, cs, 0};
   spmv_offband(st, n_poses, fv, lin, scale, v, true);
   hipLaunchKernelGGL(k_spmv<3>, dim3(spmv_blocks(npad)), dim3(128), 0, st, n_poses, npad, fv, lin, scale, mu, min_diag, max_diag, v, q, aux);
+}
+
+void launch_spmv_residual_step_lm(hipStream_t st, int n_poses, int npad, const FactorView& fv, const LinView& lin0, const LinView& lin1,
+                                  const double* scale, double min_diag, double max_diag, const double* v, const double* rhs, double* x0,
+                                  double* x1, double* q, double* partials, double2* cs, const LmDev* lm) {
+  SpmvAux aux = {rhs, nullptr, x0, nullptr, partials, cs, 0, lm, lin1, x1};
+  hipLaunchKernelGGL(k_spmv<3>, dim3(spmv_blocks(npad)), dim3(128), 0, st, n_poses, npad, fv, lin0, scale, 1.0, min_diag, max_diag, v, q, aux);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The decision of one Levenberg-Marquardt iteration on the device (round 3; until round 2 the host took it after a
+// synchronisation, which left the GPU idle for ~40 us per iteration).  Ceres' trust-region rules as restated in SURVEY.md
+// A.4 / DESIGN.md section 2, the same statements in the same order as the host loop of lm_solve (which remains for the
+// submap and off-band paths and as the A/B reference: HITL_HOST_LM=1).  The per-workgroup partial sums are added in index
+// order, one sequence per lane -- the same order the host used, so both loops take bit-identical decisions.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(320) void k_lm_decide(LmDev* lm, LmOpts o, const double* __restrict__ sp, int nblk_step, const double* __restrict__ lp0,
+                                                   const double* __restrict__ lp1, int nblk_lin, volatile double* progress) {
+#pragma clang fp contract(off)      // the host loop is compiled without contraction: 1 - q*q*q must round like there
+  if (lm->done) return;
+  // Nine sums over the per-workgroup partials (7 of the band pass, cost and max |g| of the candidate's linearisation), each
+  // in the fixed order of ordered_sum32 (hitl_host.h; the host-driven loop adds them the same way): 32 lanes take the terms
+  // b = lane, lane + 32, ... in ascending order, then the 32 lane sums are added from lane 0 up.  The partials are staged
+  // through LDS by the whole workgroup (a dependent chain of global loads would cost ~0.5 us per term).
+  __shared__ double buf[4096];
+  __shared__ double part[9][32];
+  __shared__ double tot[9];
+  const int tid = threadIdx.x, grp = tid >> 5, j = tid & 31;
+  const double* lp = (lm->cur ^ 1) ? lp1 : lp0;        // the candidate's linearisation
+  double acc = 0.0;
+  for (int base = 0; base < nblk_step; base += 512) {                         // 512 = 16 x 32: lane j keeps the terms b = j (mod 32)
+    const int cnt = min(512, nblk_step - base);
+    for (int e = tid; e < cnt * 8; e += 320) buf[e] = sp[(size_t)base * 8 + e];
+    __syncthreads();
+    if (grp < 7)
+      for (int b = j; b < cnt; b += 32) acc += buf[8 * b + grp];
+    __syncthreads();
+  }
+  for (int base = 0; base < nblk_lin; base += 2048) {
+    const int cnt = min(2048, nblk_lin - base);
+    for (int e = tid; e < cnt * 2; e += 320) buf[e] = lp[(size_t)base * 2 + e];
+    __syncthreads();
+    if (grp == 7) {
+      for (int b = j; b < cnt; b += 32) acc += buf[2 * b];
+    } else if (grp == 8) {
+      for (int b = j; b < cnt; b += 32) { const double g = buf[2 * b + 1]; if (g > acc || g != g) acc = g; }
+    }
+    __syncthreads();
+  }
+  if (grp < 9) part[grp][j] = acc;
+  __syncthreads();
+  if (tid < 9) {
+    double t = 0.0;
+    if (tid != 8) { for (int q = 0; q < 32; ++q) t += part[tid][q]; }
+    else { for (int q = 0; q < 32; ++q) { const double g = part[8][q]; if (g > t || g != g) t = g; } }
+    tot[tid] = t;
+  }
+  __syncthreads();
+  if (tid != 0) return;
+  const double rr = tot[0], bb = tot[1], dt_rhs = tot[2], dt_q = tot[3], step2 = tot[4], xn2 = tot[5], bad = tot[6], cand_cost = tot[7], cand_gmax = tot[8];
+  LmDev s = *lm;
+  ++s.iter;
+  const bool ok = (rr == rr) && !(rr > o.guard2 * bb);          // the factorisation did not break down
+  const double mcc = dt_rhs - 0.5 * dt_q;                        // model_cost_change; rhs = -S g
+  if (!ok || bad > 0.0 || !(mcc == mcc) || mcc < 0.0) {         // invalid step
+    ++s.unsuccessful;
+    if (++s.invalid_run >= 5) { s.term = HITL_FAILURE; s.done = 1; }
+    else s.radius *= 0.5;                                        // LevenbergMarquardtStrategy::StepIsInvalid
+  } else {
+    s.invalid_run = 0;
+    ++s.lin_calls;
+    const bool par_tol = sqrt(step2) <= o.parameter_tolerance * (sqrt(xn2) + o.parameter_tolerance);
+    const double cost_change = s.cost - cand_cost;
+    const bool fun_tol = fabs(cost_change) <= o.function_tolerance * s.cost;
+    if (!o.late && (par_tol || fun_tol)) { s.term = HITL_CONVERGENCE; s.done = 1; }
+    else {
+      const double rho = cost_change / mcc;
+      if (rho > o.min_relative_decrease) {
+        ++s.successful;
+        s.cur ^= 1;
+        s.cost = cand_cost; s.gmax = cand_gmax;
+        if (s.gmax <= o.gradient_tolerance) { s.term = HITL_CONVERGENCE; s.done = 1; }
+        else if (o.late && (par_tol || fun_tol)) { s.term = HITL_CONVERGENCE; s.done = 1; }
+        else {
+          const double q = 2.0 * rho - 1.0;
+          s.radius = fmin(o.max_radius, s.radius / fmax(1.0 / 3.0, 1.0 - q * q * q));
+          s.decrease_factor = 2.0;
+        }
+      } else {
+        ++s.unsuccessful;
+        s.radius /= s.decrease_factor; s.decrease_factor *= 2.0;
+        if (s.radius < o.min_radius) { s.term = HITL_CONVERGENCE; s.done = 1; }
+      }
+    }
+  }
+  if (!s.done && s.iter >= o.max_iter) { s.term = HITL_NO_CONVERGENCE; s.done = 1; }
+  *lm = s;
+  progress[1] = (double)s.done; progress[2] = (double)s.term; progress[3] = s.cost; progress[4] = s.radius;
+  __threadfence_system();
+  progress[0] = (double)s.iter;                                  // last: the host polls this word
+}
+
+void launch_lm_decide(hipStream_t st, LmDev* lm, LmOpts o, const double* step_partials, int nblk_step, const double* lin_partials0,
+                      const double* lin_partials1, int nblk_lin, double* progress_pinned) {
+  hipLaunchKernelGGL(k_lm_decide, dim3(1), dim3(320), 0, st, lm, o, step_partials, nblk_step, lin_partials0, lin_partials1, nblk_lin, progress_pinned);
 }
 
 void launch_spmv_step(hipStream_t st, int n_poses, int npad, const FactorView& fv, const LinView& lin,
