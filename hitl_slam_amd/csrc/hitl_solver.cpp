@@ -847,7 +847,10 @@ int hitl_solver_solve(hitl_solver* s, int32_t mode, const float* poses_in_xyt, f
     return lm_solve(s, mode, poses_in_xyt, poses_in_xyt, poses_out_xyt, summary);
   }
   // submap rank: poses are GLOBAL arrays; this rank solves [halo pose +] its owned range
-  if (mode == HITL_MODE_STF_ONLY) return fail(HITL_ERR_UNSUPPORTED, "submap solves need the odometry chain (mode A or C)");
+  // Mode B (the dormant STF-only solve) runs on submap ranks since round 3.  Without the odometry chain the ranks are coupled
+  // through the scan-to-scan pairs across the cuts only, the problem is ill-conditioned or singular, and -- as on one GPU -- its
+  // accept / reject path depends on the rounding of the linear solver: the ranks reach the cost level of
+  // the single-GPU solve, not its iteration sequence.
   const size_t n = (size_t)s->n, first = (size_t)(s->g_begin - s->hl);
   std::vector<float> in(poses_in_xyt + 3 * first, poses_in_xyt + 3 * (first + n)), out(3 * n);
   hitl_summary S = {};
@@ -903,7 +906,6 @@ int hitl_solver_evaluate(hitl_solver* s, int32_t mode, const float* poses_xyt, d
   if (s->world > 1) {
     // submap rank (collective: every rank calls it): poses_xyt is the GLOBAL array; cost is the global cost (every factor is
     // counted by the rank owning it); gradient (3 * n_global doubles) receives this rank's OWNED rows, zeros elsewhere
-    if (mode == HITL_MODE_STF_ONLY) return fail(HITL_ERR_UNSUPPORTED, "submap ranks need the odometry chain (mode A or C)");
     HIP_TRY(hipSetDevice(s->device));
     const size_t n = (size_t)s->n, first = (size_t)(s->g_begin - s->hl);
     std::vector<float> in(poses_xyt + 3 * first, poses_xyt + 3 * (first + n));

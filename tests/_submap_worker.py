@@ -66,7 +66,7 @@ def main():
         dist.destroy_process_group()
         return
     ecost, egrad = s.evaluate(mode, prob.init)        # collective: global cost, this rank's owned gradient rows
-    cov = s.pose_covariances(mode, prob.init) if window <= 4 and "HITL_TEST_BAND" not in os.environ else None   # collective; needs every pair inside the band
+    cov = s.pose_covariances(mode, prob.init) if window <= 4 and "HITL_TEST_BAND" not in os.environ and mode != 1 else None   # collective; needs every pair inside the band (mode B: J^T J may be singular)
     poses, summ = s.solve(mode, prob.init)
     # observation scans on a submap rank: over its resident scans (global poses [lo, hi)), global pose array in
     wx, wy = s.transform_scans(prob.init)

@@ -129,3 +129,39 @@ def test_submaps_equal_the_global_solve(tmp_path, mode, ppf, world, moments, cut
         got = np.array(x["poses"], np.float32)[x["begin"]:x["end"]]
         assert np.abs(got[:, :2] - po[x["begin"]:x["end"], :2]).max() <= 1e-4
         assert np.abs(got[:, 2] - po[x["begin"]:x["end"], 2]).max() <= 1e-4
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_mode_b_on_submap_ranks_reaches_the_global_cost_level(tmp_path, world):
+    """Mode B (PostHumanOptimization as written: scan-to-scan factors only, pose 0 held) on submap ranks, one corridor cut inside
+    (pairs straddle the cuts).  The STF-only problem is ill-conditioned and does not converge in 100 iterations; its
+    accept / reject path depends on the rounding of the linear solver even between two dense solvers of the same normal
+    equations (tests/test_golden.py), so ranks and the single-GPU oracle are held to what CAN agree: the
+    cost and gradient at the start exactly, the final cost level (2 %; measured 5e-4), poses to 3e-2 -- not the iteration count (75 on one GPU,
+    100 / 64 on 2 / 3 ranks when this was first tried in round 2) and hence not the termination flag."""
+    from oracle import hitl_oracle as O
+    out = str(tmp_path / "res")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_submap_worker.py"), out, "1", "120"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = [json.load(open("%s.%d" % (out, k))) for k in range(world)]
+    prob = Problem(120, 48, ppf=120, groups=2, kind=0)
+    o = prob.load(O.OracleSolver())
+    o.find_correspondences(prob.init, 3, 1)
+    oc, og, _, _ = o.linearize(1, prob.init, prob.init.astype(np.float64))
+    po, so = o.solve(1, prob.init)
+    for x in res:
+        assert abs(x["evaluate"]["cost"] - oc) <= 1e-11 * oc
+        gr = np.array(x["evaluate"]["grad"])
+        assert np.abs(gr[3 * x["begin"]:3 * x["end"]] - og[3 * x["begin"]:3 * x["end"]]).max() <= 1e-9 * np.abs(og).max()
+        sm = x["summary"]
+        assert abs(sm["initial_cost"] - so.initial_cost) <= 1e-10 * so.initial_cost
+        got = np.array(x["poses"], np.float32)[x["begin"]:x["end"]]
+        print("\nmode B on %d ranks, rank %d: term %d iters %d cost %.6g | one GPU (oracle): term %d iters %d cost %.6g | max pose difference %.3g"
+              % (world, x["rank"], sm["termination"], sm["iterations"], sm["final_cost"], so.termination, so.iterations, so.final_cost,
+                 np.abs(got - po[x["begin"]:x["end"]]).max()))
+        assert sm["termination"] in (0, 1) and sm["final_cost"] < sm["initial_cost"]
+        assert abs(sm["final_cost"] - so.final_cost) <= 2e-2 * so.final_cost
+        assert np.abs(got - po[x["begin"]:x["end"]]).max() <= 3e-2      # along the weakly observed corridor direction (1.5e-2 on 2 ranks, 9e-4 on 3)
