@@ -196,6 +196,7 @@ void launch_spmv_residual_step_lm(hipStream_t st, int n_poses, int npad, const F
 void launch_lm_decide(hipStream_t st, LmDev* lm, LmOpts o, const double* step_partials, int nblk_step, const double* lin_partials0,
                       const double* lin_partials1, int nblk_lin, double* progress_pinned);
 void launch_pack_owned(hipStream_t st, int nhead, const double* head, const double* vec, int off, int cnt, int maxcnt, double* rec);
+void launch_pack_edges(hipStream_t st, int nhead, const double* head, const double* vec, int off, int cnt, int edge, int maxcnt, double* rec);
 void launch_scatter_idx(hipStream_t st, int cnt, const int* idx, const double* val, double* vec);
 int spmv_blocks(int npad);
 // r = rhs - (S H S + D^2) v ; partials[blk*8 + 0,1] = (r.r, rhs.rhs) per workgroup

@@ -310,8 +310,11 @@ static int enqueue_linear_solve_banded(hitl_solver* s, const FactorView& fv, int
 // rows of `vec` hold their owners' values and heads[r * nhead + k] the scalars of rank r.
 static int dist_gather_owned(hitl_solver* s, int nhead, const double* head_dev, double* vec, std::vector<double>* heads) {
   hipStream_t st = s->stream;
-  const int W = s->world, cnt = 3 * (s->own_hi - s->own_lo), maxcnt = 3 * s->maxown, R = nhead + maxcnt;
-  launch_pack_owned(st, nhead, head_dev, vec, 3 * s->own_lo, cnt, maxcnt, s->pcg_rec.p);
+  // the record: `nhead` scalars + the owned entries a halo can need (the first and the last pcg_edge owned poses; everything
+  // when the range is no longer than two edges)
+  const int W = s->world, own = s->own_hi - s->own_lo, rec_poses = std::min(s->maxown, 2 * s->pcg_edge);
+  const int maxcnt = 3 * rec_poses, R = nhead + maxcnt;
+  launch_pack_edges(st, nhead, head_dev, vec, 3 * s->own_lo, 3 * own, 3 * s->pcg_edge, maxcnt, s->pcg_rec.p);
   s->pcg_all.resize((size_t)R * W);
   TRY(comm_allgather_dev(s, s->pcg_rec.p, s->pcg_all.data(), (int64_t)sizeof(double) * R, s->pcg_stage));
   if (heads) {

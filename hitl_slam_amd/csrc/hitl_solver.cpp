@@ -356,16 +356,25 @@ int prepare(hitl_solver* s, int mode, const float* poses_ref, const float* poses
       if (s->Wi > s->halo_req)
         return fail(HITL_ERR_UNSUPPORTED, "a pose pair reaches " + std::to_string(s->Wi) + " poses across a cut but the halos hold " +
                                           std::to_string(s->halo_req) + ": raise halo_poses of hitl_solver_set_partition");
-      double mine2[2] = {(double)s->g_begin, (double)(s->own_hi - s->own_lo)};
-      std::vector<double> all2((size_t)2 * s->world);
+      double mine2[3] = {(double)s->g_begin, (double)(s->own_hi - s->own_lo), (double)s->halo_req};
+      std::vector<double> all2((size_t)3 * s->world);
       TRY(comm_allgather(s, mine2, all2.data(), sizeof(mine2)));
       s->part_begin.assign(s->world, 0); s->part_count.assign(s->world, 0);
       s->maxown = 1;
+      int hmax = 1;
       for (int r = 0; r < s->world; ++r) {
-        s->part_begin[r] = (int64_t)all2[(size_t)2 * r]; s->part_count[r] = (int64_t)all2[(size_t)2 * r + 1];
+        s->part_begin[r] = (int64_t)all2[(size_t)3 * r]; s->part_count[r] = (int64_t)all2[(size_t)3 * r + 1];
         s->maxown = std::max(s->maxown, (int)s->part_count[r]);
+        hmax = std::max(hmax, (int)all2[(size_t)3 * r + 2]);
       }
-      const int rec_len = 3 * s->maxown;         // head excluded
+      // The exchange record of the distributed PCG carries only what somebody's halo can need (round 3; the whole owned vector
+      // until round 2: 1.2 MB per CG iteration at 50 000 poses): a halo pose lies within `halo` poses of one of its owner's
+      // two boundaries, so the first and the last pcg_edge owned poses of every rank are enough (a rank no longer than two
+      // edges sends everything).  Slot of owned offset o of a rank with c poses: o if c <= 2 edge or o < edge, else
+      // edge + (o - (c - edge)).
+      s->pcg_edge = std::min(hmax, s->maxown);
+      const int rec_poses = std::min(s->maxown, 2 * s->pcg_edge);
+      const int rec_len = 3 * rec_poses;         // head excluded
       std::vector<int> hidx;
       s->halo_owner_slot.clear();
       for (int li = 0; li < s->n; ++li) {
@@ -376,7 +385,12 @@ int prepare(hitl_solver* s, int mode, const float* poses_ref, const float* poses
         if (owner < 0) return fail(HITL_ERR_INVALID_ARGUMENT, "the ranks' owned ranges do not tile the map");
         for (int c = 0; c < 3; ++c) {
           hidx.push_back(3 * li + c);
-          s->halo_owner_slot.push_back(owner * rec_len + 3 * (int)(gi - s->part_begin[owner]) + c);
+          const int oo = (int)(gi - s->part_begin[owner]), cc = (int)s->part_count[owner];
+          int slot_pose;
+          if (cc <= rec_poses || oo < s->pcg_edge) slot_pose = oo;
+          else if (oo >= cc - s->pcg_edge) slot_pose = s->pcg_edge + (oo - (cc - s->pcg_edge));
+          else return fail(HITL_ERR_INVALID_ARGUMENT, "a halo pose lies deeper inside its owner's range than any rank's halo: inconsistent partition");
+          s->halo_owner_slot.push_back(owner * rec_len + 3 * slot_pose + c);
         }
       }
       s->n_halo = (int)hidx.size();

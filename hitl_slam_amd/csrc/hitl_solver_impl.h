@@ -59,6 +59,7 @@ struct hitl_solver {
   bool dist_pcg = false;
   std::vector<int64_t> part_begin, part_count;   // owned global range of every rank
   int maxown = 0;                                // widest owned range, in poses
+  int pcg_edge = 0;                              // owned poses at either end of a rank's range that travel in the PCG exchange record
   int n_halo = 0;                                // halo scalars (3 per halo pose, all of them)
   std::vector<int> halo_owner_slot;              // per halo scalar: index into the gathered records (rank * record + 3 * pose + c), head excluded
   DevArray<double> pcg_rec, pcg_head;

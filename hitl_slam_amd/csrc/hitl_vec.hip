@@ -461,6 +461,25 @@ __global__ void k_pack_owned(int nhead, const double* __restrict__ head, const d
   if (t < maxcnt) rec[nhead + t] = (t < cnt) ? vec[off + t] : 0.0;
 }
 
+// the same record with only the two ends of the owned range: entries [0, edge) and [cnt - edge, cnt) of the owned part (all of
+// it when cnt <= maxcnt = 2 * edge), zero-padded to maxcnt
+__global__ void k_pack_edges(int nhead, const double* __restrict__ head, const double* __restrict__ vec, int off, int cnt, int edge, int maxcnt,
+                             double* __restrict__ rec) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < nhead) rec[t] = head[t];
+  if (t < maxcnt) {
+    double v = 0.0;
+    if (cnt <= maxcnt) { if (t < cnt) v = vec[off + t]; }
+    else v = (t < edge) ? vec[off + t] : vec[off + cnt - edge + (t - edge)];
+    rec[nhead + t] = v;
+  }
+}
+
+void launch_pack_edges(hipStream_t st, int nhead, const double* head, const double* vec, int off, int cnt, int edge, int maxcnt, double* rec) {
+  const int tot = std::max(maxcnt, nhead);
+  hipLaunchKernelGGL(k_pack_edges, dim3((tot + 255) / 256), dim3(256), 0, st, nhead, head, vec, off, cnt, edge, maxcnt, rec);
+}
+
 void launch_pack_owned(hipStream_t st, int nhead, const double* head, const double* vec, int off, int cnt, int maxcnt, double* rec) {
   const int tot = std::max(maxcnt, nhead);
   hipLaunchKernelGGL(k_pack_owned, dim3((tot + 255) / 256), dim3(256), 0, st, nhead, head, vec, off, cnt, maxcnt, rec);
