@@ -65,6 +65,8 @@ static void make_rel_tf(const float* pi, const float* pj, const float* csi, cons
   t[6] = cosf(dth); t[7] = sinf(dth);
 }
 
+constexpr int kKdRedoCap = 1 << 18;       // (candidate, point) entries of the redo list of k_match_kd_tgt's fast attempt
+
 int ensure_kd_trees(hitl_solver* s) {      // BuildKDTrees: once per map (JointOptimization.cpp:1307, kdtrees_.size() == 0)
   if (s->kd_built) return HITL_OK;
   if (kd_build_lds_bytes(s->max_scan) > (size_t)150 * 1024)
@@ -102,7 +104,7 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
   const bool device_tables = window <= band_cap;
   const bool kd_tgt = kd && device_tables && match_kd_tgt_applies(slots, (int)window, mp);
   if (kd) {
-    const size_t need = kd_tgt ? match_kd_tgt_lds_bytes(s->max_scan, 64) : match_kd_lds_bytes(s->max_scan);
+    const size_t need = kd_tgt ? match_kd_tgt_lds_bytes(s->max_scan, 64, true) : match_kd_lds_bytes(s->max_scan);
     if (need > (size_t)150 * 1024 || kd_build_lds_bytes(s->max_scan) > (size_t)150 * 1024)
       return fail(HITL_ERR_UNSUPPORTED, "find_correspondences (kd_tree_search): a scan of " + std::to_string(s->max_scan) +
                   " points exceeds the LDS budget of the tree kernels (limit ~7300 points for windowed searches, ~5000 for wider ones)");
@@ -195,7 +197,10 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
       const int kd_block = dev_switches().kd_block, kd_refill = dev_switches().kd_refill;
       if (mp.skip > 1 && hipMemsetAsync(d_table.p, 0xFF, sizeof(uint16_t) * (size_t)cnt * slots * s->max_scan, st) != hipSuccess)
         return fail(HITL_ERR_HIP, "find_correspondences: clearing the candidate table failed");
-      launch_match_kd_tgt(st, mv, s->max_scan, slots, (int)window, d_tf.p, mp, s->kd_pts.p, s->kd_meta.p, d_table.p, d_counts.p, kd_block, kd_refill);
+      TRYC(s->d_kd_ovf.resize(1 + 2 * (size_t)kKdRedoCap));
+      if (hipMemsetAsync(s->d_kd_ovf.p, 0, sizeof(int), st) != hipSuccess) return fail(HITL_ERR_HIP, "find_correspondences: clearing the redo counter failed");
+      launch_match_kd_tgt(st, mv, s->max_scan, slots, (int)window, d_tf.p, mp, s->kd_pts.p, s->kd_meta.p, d_table.p, d_counts.p, kd_block, kd_refill,
+                          s->d_kd_ovf.p, s->d_kd_ovf.p + 1, dev_switches().kd_redo_cap, s->kd_full_depth);
     } else if (kd) launch_match_kd(st, mv, s->max_scan, slots, d_tgt.p, d_tf.p, mp, s->kd_pts.p, s->kd_meta.p, d_table.p, d_counts.p, i0, cnt);
     else launch_match(st, mv, s->max_scan, slots, d_tgt.p, d_tf.p, mp, d_table.p, d_counts.p, i0, cnt);
     if (hipGetLastError() != hipSuccess) return fail(HITL_ERR_HIP, "find_correspondences: the match kernel could not be launched");
@@ -213,8 +218,23 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
     launch_pair_count_scan(st, n, slots, (int)window, min_count, s->own_lo, s->own_hi, d_counts.p, s->pose_pair_off.p, d_pmo.p,
                            s->inc_off.p, d_maxd.p, d_tot.p + 5, d_tot.p);
     int64_t tot[5] = {0, 0, 0, 0, 0};
+    int kd_ovf = 0;
+    if (kd_tgt && hipMemcpyAsync(&kd_ovf, s->d_kd_ovf.p, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess)
+      return fail(HITL_ERR_HIP, "find_correspondences: reading the overflow flag failed");
     if (hipMemcpyAsync(tot, d_tot.p, sizeof(tot), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
       return fail(HITL_ERR_HIP, std::string("match kernel: ") + hipGetErrorString(hipGetLastError()));
+    if (kd_tgt && kd_ovf > dev_switches().kd_redo_cap && !s->kd_full_depth) {
+      // more walks overflowed the fast frame stack than the redo list holds: the search is void.  Once more with stacks as deep
+      // as the trees (and from now on for this map)
+      s->kd_full_depth = true;
+      TRYC(d_counts.zero(st));
+      TRYC(match_tile(0, n));
+      launch_pair_count_scan(st, n, slots, (int)window, min_count, s->own_lo, s->own_hi, d_counts.p, s->pose_pair_off.p, d_pmo.p,
+                             s->inc_off.p, d_maxd.p, d_tot.p + 5, d_tot.p);
+      if (hipMemcpyAsync(tot, d_tot.p, sizeof(tot), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+        return fail(HITL_ERR_HIP, std::string("match kernel (full-depth repeat): ") + hipGetErrorString(hipGetLastError()));
+      mark("k_match repeated with full-depth stacks");
+    }
     mark("k_match + pair counts");
     const int P = (int)tot[0];
     const int Wb = std::min(std::max((int)tot[2], std::max(s->min_band_poses, 1)), band_cap);

@@ -34,6 +34,8 @@ struct DevSwitches {
   int stf_variant = 0;             // HITL_STF_VARIANT: instantiation of k_linearize_stf
   int kd_block = 256;              // HITL_KD_BLOCK: workgroup size of k_match_kd_tgt (64 / 128 / 256)
   int lm_ahead = 3;                // HITL_LM_AHEAD: LM iterations the host queues ahead of the device-driven loop
+  int kd_cap = 0;                  // HITL_KD_CAP: frame-stack entries per lane of k_match_kd_tgt's first attempt (0 = 5); tests force the full-depth repeat with 1
+  int kd_redo_cap = 1 << 18;       // HITL_KD_REDO_CAP: entries of the redo list behind the fast attempt (tests shrink it to force the full-depth repeat)
   int kd_refill = 16;              // HITL_KD_REFILL: idle lanes per wave that trigger a refill from the query queue
   size_t cand_tile_bytes = (size_t)4 << 30;   // HITL_CAND_TILE_BYTES: candidate-table budget of the tiled search
   int cr_plan[16] = {0};           // HITL_CR_PLAN: chunk sizes of the fused stages
@@ -232,7 +234,7 @@ void launch_match(hipStream_t st, const MapView& map, int max_scan, int slots, c
 // kd_tree_search: the reference's own trees and pruned walk (kdtree.cpp:37-197), bit for bit
 size_t kd_build_lds_bytes(int max_scan);
 size_t match_kd_lds_bytes(int max_scan);
-size_t match_kd_tgt_lds_bytes(int max_scan, int block);
+size_t match_kd_tgt_lds_bytes(int max_scan, int block, bool full_depth);
 void launch_kd_build(hipStream_t st, const MapView& map, int max_scan, float4* kd_pts, uint32_t* kd_meta);
 void launch_match_kd(hipStream_t st, const MapView& map, int max_scan, int slots, const int* cand_tgt, const float* cand_tf, MatchParams mp,
                      const float4* kd_pts, const uint32_t* kd_meta, uint16_t* table, int* counts, int i0 = 0, int n_tile = -1);
@@ -241,7 +243,9 @@ void launch_match_kd(hipStream_t st, const MapView& map, int max_scan, int slots
 // that trigger a refill from the queue
 bool match_kd_tgt_applies(int slots, int window, const MatchParams& mp);
 void launch_match_kd_tgt(hipStream_t st, const MapView& map, int max_scan, int slots, int window, const float* cand_tf, MatchParams mp,
-                         const float4* kd_pts, const uint32_t* kd_meta, uint16_t* table, int* counts, int block, int refill_min);
+                         const float4* kd_pts, const uint32_t* kd_meta, uint16_t* table, int* counts, int block, int refill_min,
+                         int* redo_count /* walks that needed more frames than the launch provisioned ... */, int* redo_list /* ... (candidate, point) each,
+                         repeated by k_match_kd_redo behind the main kernel; a count beyond redo_cap voids the search */, int redo_cap, bool full_depth);
 void launch_compact(hipStream_t st, const MapView& map, int max_scan, int slots, int n_kept,
                     const int* kept_cand /* index into n*slots */, const int64_t* match_off, const uint16_t* table,
                     uint32_t* matches, int i0 = 0);

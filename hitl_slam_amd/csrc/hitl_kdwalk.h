@@ -2,21 +2,26 @@
 //
 // The reference walk is a recursion whose pruning uses each call's LOCAL best (the point-to-plane distance found so far
 // inside that sub-tree), so its result depends on the tree and cannot be replaced by a closed form.  This header restates
-// it, decision for decision, as `kd_step`: one call = one node evaluation of one query.  A wave calls it for its 64
-// queries in lock step; lanes are at different nodes and different depths of their own trees walk.
+// it, decision for decision, as `kd_step`: one call = at most one node evaluation of one query.  A wave calls it for its 64
+// queries in lock step; lanes are at different nodes and different depths of their own walks.
 //
-// What a recursion frame keeps, and where it went:
-//   * the frame's segment [lo, lo + n) -- recovered from the child's segment, the side the child hangs on and one parity
-//     bit (the in-order layout makes the split deterministic: node at lo + n/2, children [lo, n/2) and [lo+n/2+1, n-n/2-1));
-//   * the stage the frame is in -- 3 bits; with the parity bit 4 bits per level in a 64-bit register (16 levels = scans
-//     of up to 65535 points);
-//   * the node's own score and plane distance -- recomputed from the node when its near child returns (one LDS read);
-//   * the running best of a frame that went down a SECOND child (the far side of the split plane, or the right child
-//     after the left one when the query lies on the plane) -- the only values that really have to be stored: a small
-//     (best, winner) stack, touched by the few frames that take the far side.
-// A frame whose plane distance is at least the gate (|pd| >= thr) has its own point outside the gate and can never take
-// the far side: it hands its child's result through.  Such frames are not pushed at all while the stack is empty (the
-// walk starts at the first node the query comes close to), and pop without a node read otherwise.
+// Which recursion frames have to exist.  A frame (a call on node X) does three things after its near child returns:
+// merge the child's result with X's own point (the child wins only if strictly better), decide whether the far side of
+// the split plane is searched too -- `|pd| < min(best, thr)` with the MERGED best, which is never larger than X's own
+// score -- and hand the result up.  If at the first visit already |pd| >= min(own score, thr) (or the query lies off the
+// plane and there is no far child), the far side can never be taken whatever the child returns: the frame only merges.
+// Merging is a minimum with ties to the outer frame, so a run of merge-only frames folds into ONE running value, the
+// INCUMBENT (inc): visiting such a node costs an evaluation and no frame.  Only frames that may still take the far side
+// ("real" frames, 1.1 on average for a 400-point tree, 6 at most seen) are pushed: they keep the incumbent of the run above
+// them, their segment and which child was taken first; the run below them starts with an empty incumbent, because a real
+// frame's far-side test must see the result of its own sub-tree only.  When a real frame takes its second child, the
+// merged value becomes the incumbent of that child's run (the final merge of kdtree.cpp:189-192 is again a minimum with
+// ties to the earlier value).  Steps per query: nodes visited + real frames + second descents = 12.6 on scan queries; the
+// first state machine (round 3, first half: every frame within reach of the gate pushed, its segment recovered through a
+// parity bit, its score recomputed on return) needed 17.4.
+// The TOP frame lives in registers (t_inc, t_seg, t_oc): a pop feeds the node read of the same step, and through LDS that
+// would be two dependent round trips per step (measured: slower than the 17.4-step machine).  The frame below the top is
+// read from LDS at the start of every step and only consumed at its end, when a pop refills the registers.
 //
 // No intrinsics: compiled by hipcc for the device and by g++ for the CPU check in tests/ (-ffp-contract=off on both sides:
 // every fp32 operation is a single IEEE mul/add in the order of the reference).
@@ -33,61 +38,56 @@ struct float4 { float x, y, z, w; };
 
 namespace hitl {
 
-enum KdCode : uint32_t {      // what the parent does when this child returns
-  KD_LEFT_NEAR = 0,           // child = left, taken first (pd <= 0): merge, then maybe the right child
-  KD_RIGHT_NEAR = 1,          // child = right, taken first (pd > 0): merge, then maybe the left child
-  KD_FINAL_R = 2,             // child = right, taken second: merge with the stored best, return
-  KD_FINAL_L = 3,             // child = left, taken second
-  KD_PASS_L = 4,              // child = left, parent out of reach (|pd| >= thr): hand the result through
-  KD_PASS_R = 5,
+enum KdCode : uint32_t {      // what a pushed frame does when the run below it returns
+  KD_LEFT_NEAR = 0,           // the left child was taken first (pd <= 0): merge, then maybe the right child
+  KD_RIGHT_NEAR = 1,          // the right child was taken first (pd > 0): merge, then maybe the left child
+  KD_FINAL = 2,               // the second child was taken: its run carried the merged value as incumbent, hand the result up
 };
 
 struct KdWalk {
   float qx, qy;               // query in the target's frame
-  int lo, n;                  // segment of the node to evaluate next (mode 0) / of the child that just returned (mode 1)
-  int mode;                   // 0 = enter (lo, n); 1 = returning (ret_d, ret_c) from (lo, n); 2 = finished
+  int lo, n;                  // segment of the node to evaluate next (mode 0)
+  int mode;                   // 0 = enter (lo, n); 1 = the run below returned (ret_d, ret_c); 2 = finished
   float ret_d; int ret_c;     // FindNearestPointNormal's return value and the tree position of *neighbor_node (-1: never set)
-  uint64_t stk;               // 4 bits per pushed frame under a sentinel bit
-  int ssp;                    // depth of the stored-best stack
-  int ovf;                    // the stored-best stack was too small for this query: the result is void (the caller repeats the search with a full-depth stack)
+  float inc_d; int inc_c;     // incumbent of the current run of merge-only frames
+  int sp;                     // frames on the stack (the top one in t_*, the others in LDS entries 0 .. sp-2)
+  float t_inc; uint32_t t_seg, t_oc;   // top frame: saved incumbent's distance, segment lo | n << 16, saved incumbent's position + 1 | code << 20
+  int ovf;                    // the frame stack was too small for this query: the result is void
 };
 
 HITL_HD void kd_begin(KdWalk& w, float qx, float qy, int m) {
   w.qx = qx; w.qy = qy; w.lo = 0; w.n = m; w.mode = (m > 0) ? 0 : 2;
-  w.ret_d = 3.402823466e+38f; w.ret_c = -1; w.stk = 1ull; w.ssp = 0;
+  w.ret_d = 3.402823466e+38f; w.ret_c = -1; w.inc_d = 3.402823466e+38f; w.inc_c = -1; w.sp = 0; w.ovf = 0;
 }
 
-// One step of one query: at most one pop and at most one node evaluation.  Written as straight-line selects -- the 64 lanes
-// of a wave are in all states at once, so every branch would be taken by somebody; masked-off work is cheaper than the
-// exec-mask bookkeeping of ~40 nested branches (first version: 150 instruction slots per step).
+// One step of one query: at most one frame popped and at most one node evaluated, as straight-line selects (the 64 lanes of
+// a wave are in all states at once: masked-off work is cheaper than the exec-mask bookkeeping of nested branches).
 // pts[pos] = (x, y, nx, ny) of the tree node at in-order position pos (position 0 must be readable even for an empty
-// tree), meta[pos] = original index | split plane << 16.  sv_best / sv_out: this lane's stored-best stack, entry e at
-// [e * stride], entries 0 .. cap (entry cap is a write-only dump for lanes that store nothing).
-HITL_HD void kd_step(KdWalk& w, const float4* pts, const uint32_t* meta, float thr, float thr2, float* sv_best, int* sv_out, int stride, int cap) {
+// tree), meta[pos] = original index | split plane << 16.  st_inc / st_seg / st_oc: this lane's frame stack below the top,
+// entry e at [e * stride], entries 0 .. cap (entry cap is a write-only dump for lanes that store nothing).
+HITL_HD void kd_step(KdWalk& w, const float4* pts, const uint32_t* meta, float thr, float thr2, float* st_inc, uint32_t* st_seg, uint32_t* st_oc,
+                     int stride, int cap) {
   constexpr float kFltMax = 3.402823466e+38f, kFltMin = 1.175494351e-38f;
-  // ---- a returning lane pops one frame ----
+  // the frame below the top, in case this step pops (consumed at the end of the step only)
+  const int bi = (w.sp >= 2) ? ((w.sp - 2 < cap) ? w.sp - 2 : cap) : 0;
+  const float b_inc = st_inc[bi * stride];
+  const uint32_t b_seg = st_seg[bi * stride], b_oc = st_oc[bi * stride];
+  // ---- the run below returned: its result against the run's incumbent (ties to the incumbent: the outer frame) ----
   const bool m1 = (w.mode == 1);
-  const bool empty = (w.stk == 1ull);
+  const bool ret_wins = w.ret_d < w.inc_d;
+  const float rd = ret_wins ? w.ret_d : w.inc_d;
+  const int rc = ret_wins ? w.ret_c : w.inc_c;
+  const bool empty = (w.sp == 0);
   const bool popping = m1 && !empty;
-  const uint32_t e = (uint32_t)w.stk & 15u;
-  const uint32_t code = e & 7u;
-  const int par = (int)(e >> 3);
-  const bool left = ((0x19u >> code) & 1u) != 0;                 // KD_LEFT_NEAR, KD_FINAL_L, KD_PASS_L: the child hangs on the left
-  const int pn = left ? 2 * w.n + par : 2 * w.n + 2 - par;         // n -> (n/2, n - n/2 - 1) inverted with the parity bit
-  const int plo = left ? w.lo : w.lo - (pn >> 1) - 1;
-  w.stk = popping ? (w.stk >> 4) : w.stk;
-  w.lo = popping ? plo : w.lo;
-  w.n = popping ? pn : w.n;
-  const bool ret_eval = popping && code < KD_FINAL_R;              // near child returned: the node is read again
-  const bool is_final = popping && (code == KD_FINAL_R || code == KD_FINAL_L);
-  const int si = (w.ssp > 0) ? ((w.ssp <= cap) ? w.ssp - 1 : cap) : 0;     // entries past cap were never stored (ovf is set)
-  const float sb = sv_best[si * stride];
-  const int so = sv_out[si * stride];
-  const bool take_saved = is_final && !(w.ret_d < sb);             // kdtree.cpp:189-192 (and :174-177 for pd == 0)
-  w.ret_d = take_saved ? sb : w.ret_d;
-  w.ret_c = take_saved ? so : w.ret_c;
-  w.ssp -= is_final ? 1 : 0;
+  const uint32_t code = w.t_oc >> 20;
+  const float f_inc = w.t_inc;
+  const int f_inc_c = (int)(w.t_oc & 0xfffffu) - 1;
+  const bool is_final = popping && code == KD_FINAL;
+  const bool ret_eval = popping && code != KD_FINAL;               // a near child's run returned: the frame's node is read again
+  w.ret_d = (m1 ? rd : w.ret_d); w.ret_c = (m1 ? rc : w.ret_c);
   w.mode = (m1 && empty) ? 2 : w.mode;
+  w.lo = ret_eval ? (int)(w.t_seg & 0xffffu) : w.lo;
+  w.n = ret_eval ? (int)(w.t_seg >> 16) : w.n;
   // ---- node of (lo, n): kdtree.cpp:145-156 ----
   const bool enter = (w.mode == 0);
   const int n = w.n, ind = n >> 1, pos = w.lo + ind;
@@ -101,39 +101,52 @@ HITL_HD void kd_step(KdWalk& w, const float4* pts, const uint32_t* meta, float t
   const int out = ingate ? pos : -1;
   const float pd = (split ? w.qy : w.qx) - (split ? g.y : g.x);
   const float apd = __builtin_fabsf(pd);
-  // ---- the near child returned (ret_d, ret_c): kdtree.cpp:165-168 / :174-177, then :183-186 ----
-  const bool child_wins = w.ret_d < best;
-  const float mb = child_wins ? w.ret_d : best;
-  const int mo = child_wins ? w.ret_c : out;
+  const bool has_right = ind < n - 1, has_left = ind > 0;
+  // ---- a near child's run returned (rd, rc): kdtree.cpp:165-168 / :174-177, then :183-186 ----
+  const bool child_wins = rd < best;
+  const float mb = child_wins ? rd : best;
+  const int mo = child_wins ? rc : out;
   const float lim = (mb < thr) ? mb : thr;
   // KD_LEFT_NEAR: the right child, as the second near one (pd == 0) or as the far side; KD_RIGHT_NEAR: pd > 0, the left child exists
-  const bool go = ret_eval && ((code == KD_LEFT_NEAR) ? ((ind < n - 1) && (pd == 0.0f || apd < lim)) : (apd < lim));
+  const bool go = ret_eval && ((code == KD_LEFT_NEAR) ? (has_right && (pd == 0.0f || apd < lim)) : (apd < lim));
+  const bool ret_here = ret_eval && !go;                           // the frame returns the merged value into the outer run
   // ---- first visit: kdtree.cpp:149-151, :161, :170 ----
   const bool early = enter && ingate && sc < kFltMin;
-  const bool go_l = enter && !early && pd <= 0.0f && ind > 0;
-  const bool go_r = enter && !early && !go_l && pd >= 0.0f && ind < n - 1;
+  const bool go_l = enter && !early && pd <= 0.0f && has_left;
+  const bool go_r = enter && !early && !go_l && pd >= 0.0f && has_right;
   const bool no_child = enter && !early && !go_l && !go_r;         // other_tree stays NULL (kdtree.cpp:159, :183)
-  // own point outside the gate, no second near child (pd != 0), far side never taken (|pd| < min(best, thr) needs |pd| < thr):
-  // the frame hands its child's result through.  (|pd| >= thr > 0 implies the first condition; spelled out so that any thr is exact.)
-  const bool pass = !ingate && (pd != 0.0f) && !(apd < thr);
-  const bool push_enter = (go_l || go_r) && !(pass && w.stk == 1ull);
-  const uint32_t code_enter = (go_l ? 0u : 1u) + (pass ? 4u : 0u);
-  const uint32_t code_go = (code == KD_LEFT_NEAR) ? (uint32_t)KD_FINAL_R : (uint32_t)KD_FINAL_L;
-  // ---- stored best of a frame that takes its second child ----
-  const bool fits = w.ssp < cap;
-  const int wi = (go && fits) ? w.ssp : cap;
-  sv_best[wi * stride] = mb;
-  sv_out[wi * stride] = mo;
-  w.ovf |= (go && !fits) ? 1 : 0;
-  w.ssp += go ? 1 : 0;
-  const bool push = go || push_enter;
-  const uint64_t pushed = (w.stk << 4) | (uint64_t)((go ? code_go : code_enter) | ((uint32_t)(n & 1) << 3));
-  w.stk = push ? pushed : w.stk;
+  // the far side can never be taken, whatever the near child returns: |pd| >= min(own score, thr) >= min(merged, thr) and the
+  // query is off the plane -- or there is no far child (a left child without a right sibling)
+  const float lim0 = (best < thr) ? best : thr;
+  const bool merge_only = ((pd != 0.0f) && !(apd < lim0)) || (go_l && !has_right);
+  const bool fold = (go_l || go_r) && merge_only;                  // own point into the incumbent, no frame
+  const bool push = (go_l || go_r) && !merge_only;
+  const bool own_beats_inc = best < w.inc_d;
+  // ---- the frame stack.  push: the old top goes to LDS entry sp - 1, the new frame (outer incumbent, segment, first child)
+  //      becomes the top.  go: the top's code becomes KD_FINAL.  is_final / ret_here: the top is dropped, the frame below
+  //      comes up from LDS ----
+  const bool spill = push && w.sp > 0;
+  const bool fits = w.sp - 1 < cap;
+  const int wi = (spill && fits) ? w.sp - 1 : cap;
+  st_inc[wi * stride] = w.t_inc; st_seg[wi * stride] = w.t_seg; st_oc[wi * stride] = w.t_oc;
+  w.ovf |= (spill && !fits) ? 1 : 0;
+  const bool pop = is_final || ret_here;
+  const uint32_t n_oc_push = (uint32_t)(w.inc_c + 1) | ((go_l ? (uint32_t)KD_LEFT_NEAR : (uint32_t)KD_RIGHT_NEAR) << 20);
+  const uint32_t n_oc_go = (w.t_oc & 0xfffffu) | ((uint32_t)KD_FINAL << 20);
+  w.t_oc = push ? n_oc_push : (go ? n_oc_go : (pop ? b_oc : w.t_oc));
+  w.t_seg = push ? ((uint32_t)w.lo | ((uint32_t)n << 16)) : (pop ? b_seg : w.t_seg);
+  w.t_inc = push ? w.inc_d : (pop ? b_inc : w.t_inc);
+  w.sp += (push ? 1 : 0) - (pop ? 1 : 0);
+  // ---- the incumbent of the run that continues ----
+  //   fold: min(inc, own), ties to inc;  push: a fresh run;  go: the merged value;  is_final / ret_here: the outer incumbent comes back
+  const float inc_d = fold ? (own_beats_inc ? best : w.inc_d) : (push ? kFltMax : (go ? mb : (pop ? f_inc : w.inc_d)));
+  const int inc_c = fold ? (own_beats_inc ? out : w.inc_c) : (push ? -1 : (go ? mo : (pop ? f_inc_c : w.inc_c)));
+  w.inc_d = inc_d; w.inc_c = inc_c;
+  // ---- where the walk goes ----
   const bool to_right = go_r || (go && code == KD_LEFT_NEAR);
   const bool to_left = go_l || (go && code != KD_LEFT_NEAR);
   w.lo = to_right ? w.lo + ind + 1 : w.lo;
   w.n = to_right ? n - ind - 1 : (to_left ? ind : n);
-  const bool ret_here = ret_eval && !go;
   w.ret_d = early ? 0.0f : (no_child ? best : (ret_here ? mb : w.ret_d));
   w.ret_c = early ? pos : (no_child ? out : (ret_here ? mo : w.ret_c));
   w.mode = (early || no_child) ? 1 : (go ? 0 : w.mode);

@@ -250,16 +250,31 @@ void launch_kd_build(hipStream_t st, const MapView& map, int max_scan, float4* k
 // k_match_kd (source-major, targets in order, counters in LDS) serves every other case with the same `kd_step`.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kKdMaxSrc = 2 * kMaxBandPoses;      // slots of a windowed search inside the band
+static int kd_depth(int max_scan) { int d = 1; while ((1 << d) <= max_scan) ++d; return d + 1; }
+// Frame-stack entries per lane below the register-resident top.  The stack is provisioned per lane in LDS and decides how
+// many workgroups a CU holds (C4: full depth 10 -> 3 workgroups of 256, search 9.1 ms; 5 entries -> 6 workgroups, 6.8 ms).
+// Scan queries need 1.1 frames on average and 6 or fewer in all but ~1 of 10^5 walks, so the fast attempt gives every lane
+// kKdFastCap entries; a walk that wants more is put on a list and repeated by k_match_kd_redo right behind (full depth, private
+// stack).  If even the list overflows (never seen; HITL_KD_CAP=1 in the tests) the host repeats the whole search at full depth.
+constexpr int kKdFastCap = 5;
+static int kd_tgt_cap(int max_scan, bool full) {
+  const int d = kd_depth(max_scan);
+  if (full) return d;
+  const int c = dev_switches().kd_cap > 0 ? dev_switches().kd_cap : kKdFastCap;
+  return c < d ? c : d;
+}
 
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_match_kd_tgt(MapView map, int chunk, int max_scan, int slots, int window, int depth, int refill_min,
                                                          const float* __restrict__ cand_tf, MatchParams mp,
                                                          const float4* __restrict__ kd_pts, const uint32_t* __restrict__ kd_meta,
-                                                         uint16_t* __restrict__ table, int* __restrict__ counts) {
+                                                         uint16_t* __restrict__ table, int* __restrict__ counts, int* __restrict__ redo_count,
+                                                         int* __restrict__ redo_list, int redo_cap) {
   extern __shared__ float4 s_tgt[];                 // [max_scan] target tree points (in-order layout)
   uint32_t* s_meta = (uint32_t*)(s_tgt + max_scan); // [max_scan] original index | split << 16
-  float* sv_best = (float*)(s_meta + max_scan);     // [depth + 1][BLOCK] stored-best stack of kd_step (+ its dump entry)
-  int* sv_out = (int*)(sv_best + (size_t)(depth + 1) * BLOCK);
+  float* st_inc = (float*)(s_meta + max_scan);      // [depth + 1][BLOCK] frame stack of kd_step below its register-resident top (+ a dump entry):
+  uint32_t* st_seg = (uint32_t*)(st_inc + (size_t)(depth + 1) * BLOCK);      // saved incumbent, segment,
+  uint32_t* st_oc = st_seg + (size_t)(depth + 1) * BLOCK;                    // incumbent position | code
   __shared__ int s_next, s_total, s_nsrc;
   __shared__ int s_count[kKdMaxSrc], s_cand[kKdMaxSrc], s_start[kKdMaxSrc + 1];
   __shared__ long long s_obs[kKdMaxSrc];
@@ -291,10 +306,12 @@ __global__ __launch_bounds__(BLOCK) void k_match_kd_tgt(MapView map, int chunk, 
   for (int t = threadIdx.x; t < ns * 8; t += BLOCK) s_tf[t >> 3][t & 7] = cand_tf[(size_t)s_cand[t >> 3] * 8 + (t & 7)];
   __syncthreads();
   const float thr = mp.thr, thr2 = mp.thr * mp.thr;
-  float* my_best = sv_best + threadIdx.x;
-  int* my_out = sv_out + threadIdx.x;
+  float* my_inc = st_inc + threadIdx.x;
+  uint32_t* my_seg = st_seg + threadIdx.x;
+  uint32_t* my_oc = st_oc + threadIdx.x;
   KdWalk w;
-  w.mode = 2; w.qx = w.qy = 0.0f; w.lo = w.n = 0; w.ret_d = 0.0f; w.ret_c = -1; w.stk = 1ull; w.ssp = 0; w.ovf = 0;
+  w.mode = 2; w.qx = w.qy = 0.0f; w.lo = w.n = 0; w.ret_d = 0.0f; w.ret_c = -1; w.inc_d = 0.0f; w.inc_c = -1; w.sp = 0; w.ovf = 0;
+  w.t_inc = 0.0f; w.t_seg = 0u; w.t_oc = 0u;
   bool have = false;                                // this lane holds a query (running or finished, not yet written)
   int src = 0, k = 0;
   float nqx = 0.0f, nqy = 0.0f;
@@ -307,7 +324,10 @@ __global__ __launch_bounds__(BLOCK) void k_match_kd_tgt(MapView map, int chunk, 
       if (idle) {
         if (have) {                                 // finish: JointOptimization.cpp:606-621 on the walk's winner
           uint16_t res = 0xFFFFu;
-          if (w.ret_c >= 0 && w.ret_d < thr) {
+          if (w.ovf) {                              // the walk needed more frames than this launch gives a lane: k_match_kd_redo repeats it
+            const int at = atomicAdd(redo_count, 1);
+            if (at < redo_cap) { redo_list[2 * at] = s_cand[src]; redo_list[2 * at + 1] = k; }
+          } else if (w.ret_c >= 0 && w.ret_d < thr) {
             const float4 g = s_tgt[w.ret_c];
             const float cosang = g.z * nqx + g.w * nqy;
             if (cosang > mp.min_cos) { res = (uint16_t)(s_meta[w.ret_c] & 0xffffu); atomicAdd(&s_count[src], 1); }
@@ -339,10 +359,49 @@ __global__ __launch_bounds__(BLOCK) void k_match_kd_tgt(MapView map, int chunk, 
         break;
       }
     }
-    kd_step(w, s_tgt, s_meta, thr, thr2, my_best, my_out, BLOCK, depth);
+    kd_step(w, s_tgt, s_meta, thr, thr2, my_inc, my_seg, my_oc, BLOCK, depth);
   }
   __syncthreads();
   if ((int)threadIdx.x < ns) counts[s_cand[threadIdx.x]] = s_count[threadIdx.x];
+}
+
+// The few walks of k_match_kd_tgt's fast attempt that needed a deeper frame stack (about 1 query in 10^5 on corridor maps),
+// once more: one thread per listed (candidate, source point), the tree read where it lies in global memory, a private
+// full-depth stack.  Results go where the first pass would have put them; the candidate's count is completed atomically
+// (integer adds: order-free, bit-reproducible).
+__global__ __launch_bounds__(64) void k_match_kd_redo(MapView map, int max_scan, int slots, int window, const float* __restrict__ cand_tf, MatchParams mp,
+                                                      const float4* __restrict__ kd_pts, const uint32_t* __restrict__ kd_meta,
+                                                      uint16_t* __restrict__ table, int* __restrict__ counts, const int* __restrict__ redo_count,
+                                                      const int* __restrict__ redo_list, int redo_cap) {
+  constexpr int kDeep = 18;                                    // scans of up to 65535 points: 17 levels
+  const int total = min(*redo_count, redo_cap);
+  const float thr = mp.thr, thr2 = mp.thr * mp.thr;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+    const int cand = redo_list[2 * t], k = redo_list[2 * t + 1];
+    const int i = cand / slots, sl = cand % slots;
+    const int jj = max(0, i - window) + sl;
+    const int j = (jj >= i) ? jj + 1 : jj;                     // the slot layout of fill_candidates
+    const int64_t oj = map.obs_off[j];
+    const int mj = (int)(map.obs_off[j + 1] - oj);
+    const float4 a = map.obs[map.obs_off[i] + k];
+    const float* tf = cand_tf + (size_t)cand * 8;
+    const float qx = (tf[0] * a.x + tf[1] * a.y) + tf[4];
+    const float qy = (tf[2] * a.x + tf[3] * a.y) + tf[5];
+    float st_inc[kDeep];
+    uint32_t st_seg[kDeep], st_oc[kDeep];
+    KdWalk w;
+    w.t_inc = 0.0f; w.t_seg = 0u; w.t_oc = 0u;
+    kd_begin(w, qx, qy, mj);
+    while (w.mode != 2) kd_step(w, kd_pts + oj, kd_meta + oj, thr, thr2, st_inc, st_seg, st_oc, 1, kDeep - 1);
+    uint16_t res = 0xFFFFu;
+    if (w.ret_c >= 0 && w.ret_d < thr) {
+      const float nqx = tf[6] * a.z - tf[7] * a.w, nqy = tf[7] * a.z + tf[6] * a.w;
+      const float4 g = kd_pts[oj + w.ret_c];
+      const float cosang = g.z * nqx + g.w * nqy;
+      if (cosang > mp.min_cos) { res = (uint16_t)(kd_meta[oj + w.ret_c] & 0xffffu); atomicAdd(&counts[cand], 1); }
+    }
+    table[(size_t)cand * max_scan + k] = res;
+  }
 }
 
 // source-major form (any number of slots, tiles of source poses): targets in ascending order, the per-point counters of
@@ -354,8 +413,9 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_kd(MapView map, int chunk
   extern __shared__ float4 s_tgt[];                 // [max_scan] target tree points (in-order layout)
   uint32_t* s_meta = (uint32_t*)(s_tgt + max_scan); // [max_scan] original index | split << 16
   int* s_cnt = (int*)(s_meta + max_scan);           // [max_scan] accepted matches per source point
-  float* sv_best = (float*)(s_cnt + max_scan);      // [depth + 1][kMatchBlock] stored-best stack of kd_step (+ its dump entry)
-  int* sv_out = (int*)(sv_best + (size_t)(depth + 1) * kMatchBlock);
+  float* st_inc = (float*)(s_cnt + max_scan);       // [depth + 1][kMatchBlock] frame stack of kd_step below its register-resident top (+ a dump entry)
+  uint32_t* st_seg = (uint32_t*)(st_inc + (size_t)(depth + 1) * kMatchBlock);
+  uint32_t* st_oc = st_seg + (size_t)(depth + 1) * kMatchBlock;
   __shared__ int s_pair_count;
   const int b = blockIdx.x;
   const int idx = b >> 3;
@@ -387,9 +447,9 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_kd(MapView map, int chunk
         const float qx = (m00 * ax + m01 * ay) + tx;
         const float qy = (m10 * ax + m11 * ay) + ty;
         KdWalk w;
-        w.ovf = 0;
+        w.ovf = 0; w.t_inc = 0.0f; w.t_seg = 0u; w.t_oc = 0u;
         kd_begin(w, qx, qy, mj);
-        while (w.mode != 2) kd_step(w, s_tgt, s_meta, thr, thr2, sv_best + threadIdx.x, sv_out + threadIdx.x, kMatchBlock, depth);
+        while (w.mode != 2) kd_step(w, s_tgt, s_meta, thr, thr2, st_inc + threadIdx.x, st_seg + threadIdx.x, st_oc + threadIdx.x, kMatchBlock, depth);
         if (w.ret_c >= 0 && w.ret_d < thr) {
           const float anx = a.z, any = a.w;
           const float nqx = cr * anx - sr * any, nqy = sr * anx + cr * any;
@@ -406,10 +466,9 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_kd(MapView map, int chunk
   }
 }
 
-static int kd_depth(int max_scan) { int d = 1; while ((1 << d) <= max_scan) ++d; return d + 1; }
 
 size_t match_kd_lds_bytes(int max_scan) {
-  return (size_t)std::max(max_scan, 1) * (sizeof(float4) + 2 * sizeof(int)) + (size_t)(kd_depth(max_scan) + 1) * kMatchBlock * 8;
+  return (size_t)std::max(max_scan, 1) * (sizeof(float4) + 2 * sizeof(int)) + (size_t)(kd_depth(max_scan) + 1) * kMatchBlock * 12;
 }
 
 void launch_match_kd(hipStream_t st, const MapView& map, int max_scan, int slots, const int* cand_tgt, const float* cand_tf, MatchParams mp,
@@ -429,25 +488,30 @@ bool match_kd_tgt_applies(int slots, int window, const MatchParams& mp) {
 
 template <int BLOCK>
 static void launch_match_kd_tgt_t(hipStream_t st, const MapView& map, int max_scan, int slots, int window, int refill_min, const float* cand_tf,
-                                  MatchParams mp, const float4* kd_pts, const uint32_t* kd_meta, uint16_t* table, int* counts) {
+                                  MatchParams mp, const float4* kd_pts, const uint32_t* kd_meta, uint16_t* table, int* counts, int* redo_count,
+                                  int* redo_list, int redo_cap, bool full_depth) {
   const int chunk = (map.n_poses + 7) / 8;
-  const int depth = kd_depth(max_scan);
-  const size_t lds = match_kd_tgt_lds_bytes(max_scan, BLOCK);
+  const int depth = kd_tgt_cap(max_scan, full_depth);
+  const size_t lds = match_kd_tgt_lds_bytes(max_scan, BLOCK, full_depth);
   if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_match_kd_tgt<BLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k_match_kd_tgt<BLOCK>, dim3(8 * chunk), dim3(BLOCK), lds, st, map, chunk, max_scan, slots, window, depth, refill_min, cand_tf, mp,
-                     kd_pts, kd_meta, table, counts);
+                     kd_pts, kd_meta, table, counts, redo_count, redo_list, redo_cap);
+  if (!full_depth)
+    hipLaunchKernelGGL(k_match_kd_redo, dim3(256), dim3(64), 0, st, map, max_scan, slots, window, cand_tf, mp, kd_pts, kd_meta, table, counts, redo_count,
+                       redo_list, redo_cap);
 }
 
-size_t match_kd_tgt_lds_bytes(int max_scan, int block) {
-  return (size_t)max_scan * (sizeof(float4) + sizeof(uint32_t)) + (size_t)(kd_depth(max_scan) + 1) * block * 8;
+size_t match_kd_tgt_lds_bytes(int max_scan, int block, bool full_depth) {
+  return (size_t)max_scan * (sizeof(float4) + sizeof(uint32_t)) + (size_t)(kd_tgt_cap(max_scan, full_depth) + 1) * block * 12;
 }
 
 void launch_match_kd_tgt(hipStream_t st, const MapView& map, int max_scan, int slots, int window, const float* cand_tf, MatchParams mp,
-                         const float4* kd_pts, const uint32_t* kd_meta, uint16_t* table, int* counts, int block, int refill_min) {
-  while (block > 64 && match_kd_tgt_lds_bytes(max_scan, block) > (size_t)150 * 1024) block /= 2;     // long scans: fewer lanes share the tree
-  if (block == 64) launch_match_kd_tgt_t<64>(st, map, max_scan, slots, window, refill_min, cand_tf, mp, kd_pts, kd_meta, table, counts);
-  else if (block == 256) launch_match_kd_tgt_t<256>(st, map, max_scan, slots, window, refill_min, cand_tf, mp, kd_pts, kd_meta, table, counts);
-  else launch_match_kd_tgt_t<128>(st, map, max_scan, slots, window, refill_min, cand_tf, mp, kd_pts, kd_meta, table, counts);
+                         const float4* kd_pts, const uint32_t* kd_meta, uint16_t* table, int* counts, int block, int refill_min, int* redo_count,
+                         int* redo_list, int redo_cap, bool full_depth) {
+  while (block > 64 && match_kd_tgt_lds_bytes(max_scan, block, full_depth) > (size_t)150 * 1024) block /= 2;     // long scans: fewer lanes share the tree
+  if (block == 64) launch_match_kd_tgt_t<64>(st, map, max_scan, slots, window, refill_min, cand_tf, mp, kd_pts, kd_meta, table, counts, redo_count, redo_list, redo_cap, full_depth);
+  else if (block == 256) launch_match_kd_tgt_t<256>(st, map, max_scan, slots, window, refill_min, cand_tf, mp, kd_pts, kd_meta, table, counts, redo_count, redo_list, redo_cap, full_depth);
+  else launch_match_kd_tgt_t<128>(st, map, max_scan, slots, window, refill_min, cand_tf, mp, kd_pts, kd_meta, table, counts, redo_count, redo_list, redo_cap, full_depth);
 }
 
 size_t match_lds_bytes(int max_scan) {

@@ -435,6 +435,8 @@ void read_dev_switches() {
   d.force_rccl = on("HITL_FORCE_RCCL"); d.device_lm = on("HITL_DEVICE_LM");
   d.stf_variant = (int)num("HITL_STF_VARIANT", 0);
   d.kd_block = (int)num("HITL_KD_BLOCK", d.kd_block);
+  d.kd_cap = (int)num("HITL_KD_CAP", 0);
+  d.kd_redo_cap = (int)std::max(1ll, std::min((long long)(1 << 18), num("HITL_KD_REDO_CAP", d.kd_redo_cap)));
   d.lm_ahead = (int)std::max(1ll, std::min(16ll, num("HITL_LM_AHEAD", d.lm_ahead)));
   d.kd_refill = (int)std::max(1ll, std::min(64ll, num("HITL_KD_REFILL", d.kd_refill)));
   d.cand_tile_bytes = (size_t)std::max(1ll, num("HITL_CAND_TILE_BYTES", (long long)d.cand_tile_bytes));
@@ -570,7 +572,7 @@ void hitl_solver_destroy(hitl_solver* s) {
                            &s->ob_hi, &s->ob_fwd, &s->ob_rev, &s->obadj_off, &s->obadj_ent, &s->hc_off})
     v->release();
   s->d_cand_tgt.release(); s->d_cand_counts.release(); s->d_cand_kept.release(); s->d_cand_tf.release(); s->d_cand_table.release();
-  s->pairM.release(); s->kd_pts.release(); s->kd_meta.release(); s->world_xy.release();
+  s->pairM.release(); s->kd_pts.release(); s->kd_meta.release(); s->d_kd_ovf.release(); s->world_xy.release();
   s->matches.release(); s->odom_A.release(); s->hc_tgt.release(); s->odom_rr.release(); s->hc_type.release();
   if (s->nccl) (void)ncclCommDestroy(s->nccl);
   s->comm_send.release(); s->comm_recv.release(); s->fixed.release(); s->if_cols.release(); s->halo_idx.release();
@@ -691,7 +693,7 @@ int hitl_solver_set_map(hitl_solver* s, int64_t n_poses, const int64_t* obs_offs
   if (cov9) TRY(s->cov9.upload(cov9, (size_t)n_poses * 9, st));   // carried like covariances_; no live factor reads it
   HIP_TRY(hipStreamSynchronize(st));
   // a new map invalidates correspondences, human rows and the KD-trees
-  s->kd_built = false;
+  s->kd_built = false; s->kd_full_depth = false;
   s->n_pairs = 0; s->n_matches = 0; s->pose_pair_off.n = 0;
   s->h_hc.clear();
   return ensure_empty_pair_tables(s);

@@ -94,6 +94,8 @@ struct hitl_solver {
   DevArray<uint16_t> d_cand_table;
   DevArray<float4> kd_pts;                     // opt-in (kd_tree_search): every scan in KD in-order layout
   DevArray<uint32_t> kd_meta;                  //   original index | split plane << 16
+  bool kd_full_depth = false;                  //   a walk on this map once needed more frames than the fast attempt provisions: full-depth stacks from then on
+  DevArray<int> d_kd_ovf;                      //   k_match_kd_tgt: [0] = walks that overflowed the fast frame stack, [1 ..] = their (candidate, point) list
   bool kd_built = false;                       //   trees belong to the resident map
   DevArray<float> world_xy;                    // hitl_solver_transform_scans*: world x of every observation, then world y
   // pose pairs with >= 1 accepted match in the last search (info_mat_, JointOptimization.cpp:624-625): either derivable from

@@ -20,6 +20,7 @@
 #ifndef HITL_GPU_H_
 #define HITL_GPU_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus

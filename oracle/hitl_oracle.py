@@ -19,8 +19,8 @@ _lib = None
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "hitl_oracle.c")
-    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, "hitl_oracle.c"), os.path.join(_HERE, "hitl_oracle.h"), os.path.join(_HERE, "..", "include", "hitl_gpu.h")]
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return LIB_PATH
 

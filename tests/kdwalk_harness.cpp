@@ -54,8 +54,8 @@ void kdw_build(int m, const float* x, const float* y, const float* nx, const flo
 int64_t kdw_check(int m, const float* pts4, const uint32_t* meta, int64_t nq, const float* qx, const float* qy, float thr,
                   int32_t* pos_new, float* d_new, int32_t* pos_old, float* d_old, int32_t* evals, int cap) {
   const float4* pts = reinterpret_cast<const float4*>(pts4);
-  std::vector<float> sv_best(64), st_best(64), st_pd(64);
-  std::vector<int> sv_out(64);
+  std::vector<float> f_inc(64), st_best(64), st_pd(64);
+  std::vector<uint32_t> f_seg(64), f_oc(64);
   std::vector<uint32_t> st_seg(64), st_out(64);
   int64_t bad = 0;
   const float thr2 = thr * thr;
@@ -65,7 +65,8 @@ int64_t kdw_check(int m, const float* pts4, const uint32_t* meta, int64_t nq, co
     int it = 0;
     int deep = 0;
     w.ovf = 0;
-    while (w.mode != 2) { kd_step(w, pts, meta, thr, thr2, sv_best.data(), sv_out.data(), 1, cap); ++it; deep = std::max(deep, w.ssp); }
+    w.t_inc = 0.0f; w.t_seg = 0; w.t_oc = 0;
+    while (w.mode != 2) { kd_step(w, pts, meta, thr, thr2, f_inc.data(), f_seg.data(), f_oc.data(), 1, cap); ++it; deep = std::max(deep, w.sp); }
     pos_new[q] = w.ret_c; d_new[q] = w.ret_d; evals[q] = it | (deep << 16) | (w.ovf << 30);
     int po = -1;
     float dd = 3.402823466e+38f;
@@ -85,8 +86,8 @@ int64_t kdw_sim(int m, const float* pts4, const uint32_t* meta, int64_t nq, cons
   const float thr2 = thr * thr;
   std::vector<KdWalk> w(lanes);
   std::vector<std::vector<float>> sb(lanes, std::vector<float>(64));
-  std::vector<std::vector<int>> so(lanes, std::vector<int>(64));
-  for (auto& x : w) { x.mode = 2; x.lo = x.n = 0; x.stk = 1ull; x.ssp = 0; x.ovf = 0; x.ret_d = 0.0f; x.ret_c = -1; x.qx = x.qy = 0.0f; }
+  std::vector<std::vector<uint32_t>> so(lanes, std::vector<uint32_t>(64)), sq(lanes, std::vector<uint32_t>(64));
+  for (auto& x : w) { x.mode = 2; x.lo = x.n = 0; x.sp = 0; x.ovf = 0; x.ret_d = 0.0f; x.ret_c = -1; x.inc_d = 0.0f; x.inc_c = -1; x.qx = x.qy = 0.0f; x.t_inc = 0.0f; x.t_seg = 0; x.t_oc = 0; }
   int64_t next = 0, iters = 0, b = 0, rf = 0;
   for (;;) {
     int idle = 0;
@@ -96,7 +97,7 @@ int64_t kdw_sim(int m, const float* pts4, const uint32_t* meta, int64_t nq, cons
       ++rf;
       for (auto& x : w) if (x.mode == 2 && next < nq) { kd_begin(x, qx[next], qy[next], m); ++next; }
     }
-    for (int l = 0; l < lanes; ++l) if (w[l].mode != 2) { kd_step(w[l], pts, meta, thr, thr2, sb[l].data(), so[l].data(), 1, 62); ++b; }
+    for (int l = 0; l < lanes; ++l) if (w[l].mode != 2) { kd_step(w[l], pts, meta, thr, thr2, sb[l].data(), so[l].data(), sq[l].data(), 1, 62); ++b; }
     ++iters;
   }
   *busy = b; *refills = rf;

@@ -126,3 +126,12 @@ def test_libm_pairing_assumption_holds_on_this_host(lib):
         s1, c1, s2, c2 = m.sinf(float(x)), m.cosf(float(x)), m.sinf(float(-x)), m.cosf(float(-x))
         assert np.float32(s.value).tobytes() == np.float32(s1).tobytes() and np.float32(c.value).tobytes() == np.float32(c1).tobytes()
         assert np.float32(s2).tobytes() == np.float32(-np.float32(s1)).tobytes() and np.float32(c2).tobytes() == np.float32(c1).tobytes()
+
+
+def test_header_is_self_contained_c():
+    """include/hitl_gpu.h compiles on its own as C (a maintainer's first include; round 3 shipped a `size_t` without <stddef.h>
+    for an hour, which only the `make native` build of the oracle on the GPU box noticed)."""
+    import subprocess
+    for std in ("-std=c99", "-std=gnu11"):
+        subprocess.check_call(["gcc", std, "-fsyntax-only", "-Wall", "-Werror", "-x", "c", HEADER])
+    subprocess.check_call(["g++", "-std=c++11", "-fsyntax-only", "-Wall", "-Werror", "-x", "c++", HEADER])

@@ -396,6 +396,28 @@ def test_kd_tree_search_reproduces_the_reference_walk(shape):
     g.close()
 
 
+@pytest.mark.parametrize("redo_cap", [None, 16])
+def test_kd_search_when_the_fast_frame_stack_overflows(monkeypatch, redo_cap):
+    """The target-major walk kernel runs with a frame stack of 5 entries per lane (that is what lets 6 workgroups share a CU);
+    a walk that needs more is listed and repeated by k_match_kd_redo (one thread per walk, full depth), and if even the list
+    overflows the whole search is repeated with stacks as deep as the trees.  Forced here with ONE entry per lane (thousands of
+    walks overflow) and, in the second case, a list of 16: same index sets as the oracle either way."""
+    import hitl_slam_amd as H
+    prob = Problem(60, 128, ppf=30)
+    want = oracle_corr(prob, window=3, method=1)
+    monkeypatch.setenv("HITL_KD_CAP", "1")
+    if redo_cap:
+        monkeypatch.setenv("HITL_KD_REDO_CAP", str(redo_cap))
+    g = prob.load(H.Solver())
+    for _ in range(2):                       # with the tiny list: the second call goes straight to the full-depth stacks
+        g.find_correspondences(prob.init, 3)
+        for a, b in zip(g.get_correspondences(), want):
+            assert np.array_equal(a, b)
+    g.close()
+    monkeypatch.delenv("HITL_KD_CAP", raising=False)
+    monkeypatch.delenv("HITL_KD_REDO_CAP", raising=False)
+
+
 def test_kd_tree_search_on_ragged_and_empty_scans():
     """Scans of different lengths (one empty, one with a single point) through the tree kernels."""
     import hitl_slam_amd as H
