@@ -694,6 +694,7 @@ int hitl_solver_set_map(hitl_solver* s, int64_t n_poses, const int64_t* obs_offs
   HIP_TRY(hipStreamSynchronize(st));
   // a new map invalidates correspondences, human rows and the KD-trees
   s->kd_built = false; s->kd_full_depth = false;
+  s->adj_window = 0; s->adj_slots = 0; s->h_adj.clear();      // info_mat: no search on this map yet
   s->n_pairs = 0; s->n_matches = 0; s->pose_pair_off.n = 0;
   s->h_hc.clear();
   return ensure_empty_pair_tables(s);
