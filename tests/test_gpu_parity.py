@@ -396,6 +396,52 @@ def test_kd_tree_search_reproduces_the_reference_walk(shape):
     g.close()
 
 
+def test_kd_trees_equal_the_reference_build():
+    """BuildKDTrees on the GPU (k_kd_build: level-by-level stable rank sort of a 16-bit permutation in LDS), read back through
+    hitl_solver_get_kd_trees, against two CPU builds by the rules of kdtree.cpp:37-139: the recursive C++ build of the walk
+    harness and the mirror's literal Python recursion (pointer-style nodes, flattened here to the in-order layout).  Node for
+    node: coordinates, normals, original index, split plane -- on scans of several lengths, incl. one of a single point."""
+    import ctypes as C
+    import os
+    import subprocess
+    import sys
+    import hitl_slam_amd as H
+    import test_kdwalk_cpu as T
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import mirror as M
+    os.makedirs(os.path.dirname(T.LIB), exist_ok=True)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", T.LIB, T.SRC])
+    lib = C.CDLL(T.LIB)
+    prob = Problem(24, 90, ppf=12)
+    rng = np.random.default_rng(4)
+    keep = [np.sort(rng.permutation(90)[:int(k)]) for k in rng.integers(1, 91, size=24)]
+    keep[3] = np.array([17])
+    off = np.concatenate([[0], np.cumsum([len(k) for k in keep])]).astype(np.int64)
+    sel = np.concatenate([prob.off[i] + k for i, k in enumerate(keep)]).astype(np.int64)
+    px, py, nx, ny = [np.ascontiguousarray(a[sel]) for a in (prob.px, prob.py, prob.nx, prob.ny)]
+    g = H.Solver()
+    g.set_map(off, px, py, nx, ny, prob.cov)
+    pts, meta = g.get_kd_trees()
+    g.close()
+
+    def flatten(nd, lo, n, out_pts, out_meta):
+        if nd is None:
+            return
+        pos = lo + n // 2
+        out_pts[pos] = (nd.pt[0], nd.pt[1], nd.nrm[0], nd.nrm[1])
+        out_meta[pos] = nd.index | (nd.split << 16)
+        flatten(nd.left, lo, n // 2, out_pts, out_meta)
+        flatten(nd.right, lo + n // 2 + 1, n - n // 2 - 1, out_pts, out_meta)
+    for i in range(24):
+        a, b = off[i], off[i + 1]
+        hp, hm = T.build_tree(lib, px[a:b], py[a:b], nx[a:b], ny[a:b])
+        assert np.array_equal(hm[:b - a], meta[a:b]) and np.array_equal(hp[:b - a].view(np.uint32), pts[a:b].view(np.uint32)), i
+        root = M.kd_build([(np.float32(px[o]), np.float32(py[o]), np.float32(nx[o]), np.float32(ny[o]), int(o - a)) for o in range(a, b)])
+        mp, mm = np.zeros((b - a, 4), np.float32), np.zeros(b - a, np.uint32)
+        flatten(root, 0, int(b - a), mp, mm)
+        assert np.array_equal(mm, meta[a:b]) and np.array_equal(mp.view(np.uint32), pts[a:b].view(np.uint32)), i
+
+
 @pytest.mark.parametrize("redo_cap", [None, 16])
 def test_kd_search_when_the_fast_frame_stack_overflows(monkeypatch, redo_cap):
     """The target-major walk kernel runs with a frame stack of 5 entries per lane (that is what lets 6 workgroups share a CU);
