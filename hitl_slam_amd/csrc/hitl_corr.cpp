@@ -70,7 +70,7 @@ constexpr int kKdRedoCap = 1 << 18;       // (candidate, point) entries of the r
 int ensure_kd_trees(hitl_solver* s) {      // BuildKDTrees: once per map (JointOptimization.cpp:1307, kdtrees_.size() == 0)
   if (s->kd_built) return HITL_OK;
   if (kd_build_lds_bytes(s->max_scan) > (size_t)150 * 1024)
-    return fail(HITL_ERR_UNSUPPORTED, "kd_tree_search: a scan of " + std::to_string(s->max_scan) + " points exceeds the LDS budget of the tree build (limit ~8500 points)");
+    return fail(HITL_ERR_UNSUPPORTED, "kd_tree_search: a scan of " + std::to_string(s->max_scan) + " points exceeds the LDS budget of the tree build (limit ~5900 points)");
   int rc = s->kd_pts.resize((size_t)std::max<int64_t>(s->n_obs, 1));
   if (rc != HITL_OK) return rc;
   rc = s->kd_meta.resize((size_t)std::max<int64_t>(s->n_obs, 1));
@@ -107,7 +107,7 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
     const size_t need = kd_tgt ? match_kd_tgt_lds_bytes(s->max_scan, 64, true) : match_kd_lds_bytes(s->max_scan);
     if (need > (size_t)150 * 1024 || kd_build_lds_bytes(s->max_scan) > (size_t)150 * 1024)
       return fail(HITL_ERR_UNSUPPORTED, "find_correspondences (kd_tree_search): a scan of " + std::to_string(s->max_scan) +
-                  " points exceeds the LDS budget of the tree kernels (limit ~7300 points for windowed searches, ~5000 for wider ones)");
+                  " points exceeds the LDS budget of the tree kernels (limit ~5900 points: the tree build; the walk kernels would take ~7300 / ~5000)");
   }
   if (match_lds_bytes(s->max_scan) > (size_t)160 * 1024)
     return fail(HITL_ERR_UNSUPPORTED, "find_correspondences: a scan of " + std::to_string(s->max_scan) +

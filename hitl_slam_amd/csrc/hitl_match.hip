@@ -138,13 +138,16 @@ constexpr int kKdBlock = 256;
 
 // one workgroup per scan; level by level: split plane per live segment (one thread walks the segment: the fp32 sums of
 // kdtree.cpp:40-58 are order-dependent), stable rank sort inside every segment, the median becomes a node.
-// LDS: the scan's coordinates stay where they are (ox, oy); what is sorted is a 16-bit permutation (cur -> nxt), so a scan
-// costs 18 bytes per point and scans of ~8000 points fit (the limit of the brute-force matcher's staging is 7900).
+// LDS: the scan's coordinates by original index (ox, oy), the 16-bit permutation that is being sorted (cur -> nxt) and the
+// coordinates in the CURRENT order (cx, cy: gathered by all threads once per level, so that the sequential sums and the
+// rank counts read contiguous memory instead of chasing the permutation): 26 bytes per point, scans of ~6000 points.
 __global__ __launch_bounds__(kKdBlock) void k_kd_build(MapView map, int max_scan, float4* __restrict__ kd_pts, uint32_t* __restrict__ kd_meta) {
   extern __shared__ float s_raw[];
   float* ox = s_raw;                                    // coordinates by original index
   float* oy = ox + max_scan;
-  uint32_t* seg = (uint32_t*)(oy + max_scan);           // lo | n << 16 of the segment the element at this position is in (n == 0: already a node)
+  float* cx = oy + max_scan;                            // coordinates in the current order
+  float* cy = cx + max_scan;
+  uint32_t* seg = (uint32_t*)(cy + max_scan);           // lo | n << 16 of the segment the element at this position is in (n == 0: already a node)
   uint16_t* cur = (uint16_t*)(seg + max_scan);          // original index of the element at this position
   uint16_t* nxt = cur + max_scan;
   unsigned char* s_plane = (unsigned char*)(nxt + max_scan);   // split plane of the live segment that starts at this position
@@ -156,25 +159,24 @@ __global__ __launch_bounds__(kKdBlock) void k_kd_build(MapView map, int max_scan
   if (m <= 0) return;
   for (int p = threadIdx.x; p < m; p += kKdBlock) {
     const float4 v = map.obs[o + p];
-    ox[p] = v.x; oy[p] = v.y; cur[p] = (uint16_t)p; seg[p] = (uint32_t)m << 16; s_plane[p] = 0; s_split[p] = 0;
+    ox[p] = v.x; oy[p] = v.y; cx[p] = v.x; cy[p] = v.y; cur[p] = (uint16_t)p; seg[p] = (uint32_t)m << 16; s_plane[p] = 0; s_split[p] = 0;
   }
   __syncthreads();
   for (;;) {
     if (threadIdx.x == 0) s_live = 0;
     __syncthreads();
-    // 1. split plane of every live segment (its first position does the sequential sums)
+    // 1. split plane of every live segment (its first position does the sequential sums, in the order of the segment)
     for (int p = threadIdx.x; p < m; p += kKdBlock) {
       const uint32_t sg = seg[p];
       const int n = (int)(sg >> 16);
       if (n > 0 && (int)(sg & 0xffffu) == p) {
         float mx = 0.0f, my = 0.0f;
-        for (int q = p; q < p + n; ++q) { const int e = cur[q]; mx = mx + ox[e]; my = my + oy[e]; }
+        for (int q = p; q < p + n; ++q) { mx = mx + cx[q]; my = my + cy[q]; }
         mx = mx / (float)n; my = my / (float)n;
         float sx = 0.0f, sy = 0.0f;
         for (int q = p; q < p + n; ++q) {
-          const int e = cur[q];
-          sx = sx + (ox[e] - mx) * (ox[e] - mx);
-          sy = sy + (oy[e] - my) * (oy[e] - my);
+          sx = sx + (cx[q] - mx) * (cx[q] - mx);
+          sy = sy + (cy[q] - my) * (cy[q] - my);
         }
         int plane = 0;
         float best = 0.0f;
@@ -193,11 +195,11 @@ __global__ __launch_bounds__(kKdBlock) void k_kd_build(MapView map, int max_scan
       int dst = p;
       if (n > 0) {
         const int lo = (int)(sg & 0xffffu);
-        const float* co = s_plane[lo] ? oy : ox;
-        const float key = co[cur[p]];
+        const float* co = s_plane[lo] ? cy : cx;
+        const float key = co[p];
         int rank = 0;
         for (int q = lo; q < lo + n; ++q) {
-          const float kq = co[cur[q]];
+          const float kq = co[q];
           rank += (kq < key || (kq == key && q < p)) ? 1 : 0;
         }
         dst = lo + rank;
@@ -205,11 +207,12 @@ __global__ __launch_bounds__(kKdBlock) void k_kd_build(MapView map, int max_scan
       nxt[dst] = cur[p];
     }
     __syncthreads();
-    // 3. the median of a segment becomes its node; the two halves are the next level's segments
+    // 3. the median of a segment becomes its node; the two halves are the next level's segments; coordinates follow the new order
     for (int p = threadIdx.x; p < m; p += kKdBlock) {
       const uint32_t sg = seg[p];
       const int n = (int)(sg >> 16);
-      cur[p] = nxt[p];
+      const int e = nxt[p];
+      cur[p] = (uint16_t)e; cx[p] = ox[e]; cy[p] = oy[e];
       if (n > 0) {
         const int lo = (int)(sg & 0xffffu), ind = n / 2;
         if (p == lo + ind) { s_split[p] = s_plane[lo]; seg[p] = (uint32_t)lo; }
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(kKdBlock) void k_kd_build(MapView map, int max_scan
   }
 }
 
-size_t kd_build_lds_bytes(int max_scan) { return (size_t)((max_scan + 3) & ~3) * 18; }
+size_t kd_build_lds_bytes(int max_scan) { return (size_t)((max_scan + 3) & ~3) * 26; }
 
 void launch_kd_build(hipStream_t st, const MapView& map, int max_scan, float4* kd_pts, uint32_t* kd_meta) {
   max_scan = (max_scan + 3) & ~3;            // keeps the 4-, 2- and 1-byte arrays aligned behind one another
