@@ -6,6 +6,7 @@
 //   k_cr_selinv_level, k_cov_extract : diagonal blocks of the inverse from the same factors (pose covariances).
 // All arithmetic is fp64.
 
+#include <cstdio>
 #include <cstdlib>
 #include <vector>
 
@@ -689,9 +690,28 @@ __device__ __forceinline__ void lds_barrier() {
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
-template <int B>
-__global__ __launch_bounds__(B >= 12 ? 512 : 1024) void k_cr_chunk(CrView cr, CrStage sg, CrSource src, double* w, double* x) {
+// Development build (-DHITL_CR_PROBE): thread 0 of one workgroup per stage records the shader clock at the phase boundaries of
+// k_cr_chunk; hitl_cr_probe_dump() prints the differences.  Not compiled into the shipped library.
+#ifdef HITL_CR_PROBE
+__device__ unsigned long long g_cr_probe[3 * 64];
+#define CR_PROBE(slot) do { if (tid == 0 && blockIdx.x == (gridDim.x > 600 ? 600 : gridDim.x / 2)) g_cr_probe[(sg.top ? 2 : (sg.S == 1 ? 0 : 1)) * 64 + (slot)] = clock64(); } while (0)
+#define CR_PROBE_IN(slot) do { if (s == 4 && q == wave) { __builtin_amdgcn_s_waitcnt(0); CR_PROBE(slot); } } while (0)
+#else
+#define CR_PROBE(slot) do { } while (0)
+#define CR_PROBE_IN(slot) do { } while (0)
+#endif
+
+// KIND 1: the first stage of the LM path's factor-solve (tiles cut from the band rows, one right-hand side, no previous stage,
+// not the top) with those facts known at compile time: fewer live values, a register budget that lets more workgroups share a CU.
+#ifndef HITL_CR_WAVES
+#define HITL_CR_WAVES 8
+#endif
+template <int B, int KIND>
+__global__ __launch_bounds__((B >= 12 || KIND == 1) ? 512 : 1024) __attribute__((amdgpu_waves_per_eu(KIND == 1 ? HITL_CR_WAVES : 4)))
+void k_cr_chunk(CrView cr, CrStage sg_in, CrSource src, double* w, double* x) {
   extern __shared__ double lds[];
+  CrStage sg = sg_in;
+  if (KIND == 1) { sg.top = 0; sg.has_prev = 0; sg.nrhs = 1; sg.nsl = sg.M + 1; sg.S = 1; }
   if (cr.lm != nullptr) {                                  // device-driven LM loop (uniform branch)
     if (cr.lm->done) return;
     if (src.Hband != nullptr && src.lm != nullptr) {       // the first stage: the CURRENT buffers, today's trust region
@@ -703,9 +723,8 @@ __global__ __launch_bounds__(B >= 12 ? 512 : 1024) void k_cr_chunk(CrView cr, Cr
   const int M = sg.M, S = sg.S;
   const int nsl = sg.nsl;                                 // local slots: 0 .. M (a chunk) / 0 .. alive-1 (the top)
   double* sD = lds;                                       // nsl tiles: D_u, later P_a of an eliminated u
-  double* sL = sD + (size_t)nsl * BB;                     // nsl tiles: L_u (coupling u <-> u - s)
-  double* sPb = sL + (size_t)nsl * BB;                    // nsl tiles: P_b of an eliminated u
-  double* sG = sPb + (size_t)nsl * BB;                    // per wave: Gl, Gr of the node it is eliminating (2 tiles)
+  double* sL = sD + (size_t)nsl * BB;                     // nsl tiles: L_u (coupling u <-> u - s), later P_b of an eliminated u
+  double* sG = sL + (size_t)nsl * BB;                     // per wave: Gl, Gr of the node it is eliminating (2 tiles)
   const int NR = sg.nrhs;                                 // right-hand sides; vector v of local node u lives at [(v * nsl + u) * B]
   double* sW = sG + (size_t)(blockDim.x >> 6) * 2 * BB;   // NR x nsl vectors: right-hand sides
   double* sCa = sW + (size_t)NR * nsl * B;                // NR x nsl vectors: Gl_u^T w_u (for a)
@@ -716,36 +735,48 @@ __global__ __launch_bounds__(B >= 12 ? 512 : 1024) void k_cr_chunk(CrView cr, Cr
   double* accWL = accWR + (size_t)NR * B;                 // NR vectors
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int wave = tid >> 6, lane = tid & 63, NW = nthr >> 6;
+  CR_PROBE(0);
   const int64_t base = (int64_t)blockIdx.x * M;            // in stage nodes
   const int64_t nst = ((int64_t)cr.nsb + S - 1) / S;       // stage nodes alive: 0 .. nst-1
   // local slots that exist: u with base + u < nst
   const int u_last = (int)((nst - 1 - base < M) ? (nst - 1 - base) : M);     // >= 0
-  const bool has_w = (w != nullptr) && NR > 0;
-  const bool from_src = src.Hband != nullptr;             // host: only with S == 1, no previous stage, one right-hand side
+  const bool has_w = KIND == 1 || ((w != nullptr) && NR > 0);
+  const bool from_src = KIND == 1 || src.Hband != nullptr;   // host: only with S == 1, no previous stage
   const size_t pws = (size_t)4 * sg.np * B;               // doubles of one right-hand side's contribution arrays
   const double* PLp = cr.P + (size_t)(sg.prev_par * 2 + 0) * sg.np * BB;
   const double* PRp = cr.P + (size_t)(sg.prev_par * 2 + 1) * sg.np * BB;
   const double* WLp = cr.Pw + (size_t)(sg.prev_par * 2 + 0) * sg.np * B;
   const double* WRp = cr.Pw + (size_t)(sg.prev_par * 2 + 1) * sg.np * B;
   // ---- first stage straight from the band blocks: stage the band rows of this chunk's poses (and of the super-block on its
-  //      left, for L of local 0) with coalesced loads; the tiles are then cut from LDS.  The staging area lies over sPb / sG
-  //      (idle until the first elimination) when it fits there, behind everything else otherwise (cr_chunk_src_extra) ----
-  const int src_rl = (src.Wb + 1) * 9 + 4;
-  const int src_p0 = from_src ? (int)((base > 0 ? base - 1 : 0) * src.Wb) : 0;
+  //      left, for L of local 0) with coalesced loads; the tiles are then cut from LDS.  The staging area lies over everything
+  //      behind the tiles (sG .. accWL, idle until the tiles are cut; cr_chunk_src_extra extends the allocation when it is longer) ----
+  const int Wb = (KIND == 1) ? B / 3 : src.Wb;            // a super-block is Wb poses: a constant of the first-stage instantiation
+  const int src_rl = (Wb + 1) * 9 + 4;
+  const int src_p0 = from_src ? (int)((base > 0 ? base - 1 : 0) * Wb) : 0;
   double* sRec = nullptr;
+  // KIND 1: this thread's right-hand-side entry (-S g) is requested before anything else, so that its memory round trip
+  // overlaps the staging of the band rows instead of following the tile cut
+  double rhs_v = 0.0;
+  const bool rhs_mine = KIND == 1 && tid < (u_last + 1) * B;
+  if (rhs_mine) rhs_v = cr_source_rhs(src, (int)(base + tid / B), tid % B);
   if (from_src) {
-    const int p1 = min(src.n_poses, (int)(base + u_last + 1) * src.Wb);
+    const int p1 = min(src.n_poses, (int)(base + u_last + 1) * Wb);
     const int np_st = max(p1 - src_p0, 0);
-    const size_t need = (size_t)(nsl + 1) * src.Wb * src_rl, avail = (size_t)nsl * BB + (size_t)NW * 2 * BB;
-    sRec = (need <= avail) ? sPb : accWL + (size_t)NR * B;
-    const int hl = (src.Wb + 1) * 9;
+    sRec = sG;
+    const int hl = (Wb + 1) * 9;
     const double* Hg = src.Hband + (size_t)src_p0 * hl;
+    if (KIND == 1 && (hl & 1) == 0) {                       // 16-byte loads (hl = 36 doubles per pose, records of 40)
+      const double2* Hg2 = reinterpret_cast<const double2*>(Hg);
+      const int h2 = hl / 2;
+      for (int e = tid; e < np_st * h2; e += nthr) *reinterpret_cast<double2*>(sRec + (size_t)(e / h2) * src_rl + 2 * (e % h2)) = Hg2[e];
+    } else
     for (int e = tid; e < np_st * hl; e += nthr) sRec[(size_t)(e / hl) * src_rl + e % hl] = Hg[e];
     for (int e = tid; e < np_st * 4; e += nthr) {
       const int pp = e >> 2, c = e & 3;
       sRec[(size_t)pp * src_rl + hl + c] = (c < 3) ? src.scale[3 * (src_p0 + pp) + c] : (src.fixed[src_p0 + pp] ? 1.0 : 0.0);
     }
     lds_barrier();
+    CR_PROBE(1);
   }
   // ---- load: D (folded with the previous stage's contributions), L, w of local 0 .. u_last ----
   for (int e = tid; e < (u_last + 1) * BB; e += nthr) {
@@ -756,7 +787,7 @@ __global__ __launch_bounds__(B >= 12 ? 512 : 1024) void k_cr_chunk(CrView cr, Cr
     if (from_src) {
       // first stage straight from the band blocks (k_build_system's arithmetic): only the nodes that outlive this stage
       // -- the chunk boundaries -- need their D in memory, where the next stage folds the contributions into it
-      cr_source_tile_rec(sRec, src_rl, src_p0, src.n_poses, src.Wb, src.mu, src.min_diag, src.max_diag, B, (int)sn, q, d, l);
+      cr_source_tile_rec(sRec, src_rl, src_p0, src.n_poses, Wb, src.mu, src.min_diag, src.max_diag, B, (int)sn, q, d, l);
       if (u == 0 || (u == M && sn == nst - 1)) cr.D[g] = d;
     } else {
       d = cr.D[g];
@@ -769,7 +800,16 @@ __global__ __launch_bounds__(B >= 12 ? 512 : 1024) void k_cr_chunk(CrView cr, Cr
     // one chunk -- except the very last node when it is local node M of the last chunk (no chunk on its right).
     if ((u == 0 || (u == M && sn == nst - 1)) && sg.has_prev && !sg.top) cr.D[g] = d;
   }
-  if (has_w)
+  CR_PROBE(2);
+  if (from_src) lds_barrier();                            // the staging area is overwritten from here on
+  if (KIND == 1) {
+    if (rhs_mine) {
+      const size_t g = (size_t)(base * B) + tid;            // S == 1: node (base + u), row q  <->  base * B + u * B + q
+      src.rhs[g] = rhs_v;
+      w[g] = rhs_v;
+      sW[tid] = rhs_v;
+    }
+  } else if (has_w)
     for (int e = tid; e < NR * (u_last + 1) * B; e += nthr) {
       const int rv = e / ((u_last + 1) * B), e2 = e % ((u_last + 1) * B);
       const int u = e2 / B, q = e2 % B;
@@ -789,6 +829,8 @@ __global__ __launch_bounds__(B >= 12 ? 512 : 1024) void k_cr_chunk(CrView cr, Cr
     }
   for (int e = tid; e < 2 * BB + 2 * NR * B; e += nthr) accR[e] = 0.0;   // accR, accL, accWR, accWL are contiguous
   lds_barrier();
+  CR_PROBE(3);
+  int probe_slot = 4; (void)probe_slot;
   const int u_hi = sg.top ? u_last : ((u_last < M) ? u_last : M - 1);    // largest local node that may be eliminated
   for (int s = 1; s < M; s *= 2) {
     // ---- eliminate u = s, 3s, 5s .. <= u_hi ----
@@ -801,17 +843,25 @@ __global__ __launch_bounds__(B >= 12 ? 512 : 1024) void k_cr_chunk(CrView cr, Cr
       double* Du = sD + (size_t)u * BB;
       double* Lu = sL + (size_t)u * BB;
       double* Lb = sL + (size_t)(has_b ? b : u) * BB;
+      // column c of [D_u | I | L_u | L_b^T]: one LDS address and stride per lane, every lane loads (idle lanes read D_u) and the
+      // choice is a select -- the empty asm keeps the compiler from turning the select back into four divergent load blocks
       double col[B];
+      int c_id = (grp == 1) ? c : -1;                       // row of the 1 in this lane's identity column
+      asm volatile("" : "+v"(c_id));                        // formed here, not kept as B loop-invariant doubles across the whole kernel
+      {
+        const double* sp = (grp == 2) ? Lu + c : (grp == 3) ? Lb + c * B : Du + c;
+        const int st = (grp == 3) ? 1 : B;
+        const bool rd = (grp == 0) || (grp == 2) || (grp == 3 && has_b);
 #pragma unroll
-      for (int r = 0; r < B; ++r) {
-        double v = 0.0;
-        if (grp == 0) v = Du[r * B + c];
-        else if (grp == 1) v = (r == c) ? 1.0 : 0.0;
-        else if (grp == 2) v = Lu[r * B + c];
-        else if (grp == 3 && has_b) v = Lb[c * B + r];      // column c of L_b^T
-        col[r] = v;
+        for (int r = 0; r < B; ++r) {
+          double v = sp[r * st];
+          asm volatile("" : "+v"(v));
+          col[r] = rd ? v : ((r == c_id) ? 1.0 : 0.0);
+        }
       }
+      CR_PROBE_IN(40);
       gauss_jordan_cols<B>(col);
+      CR_PROBE_IN(41);
       const size_t gn = (size_t)((base + u) * S) * BB;
       if (grp >= 1 && grp <= 3) {
         double* dst = (grp == 1) ? cr.Dinv + gn : (grp == 2) ? cr.Gl + gn : cr.Gr + gn;
@@ -820,7 +870,7 @@ __global__ __launch_bounds__(B >= 12 ? 512 : 1024) void k_cr_chunk(CrView cr, Cr
       }
       // The three products its neighbours need, on three lane groups at once: Gl / Gr go to this wave's scratch tiles, then
       // lane (g, c) forms column c of   g = 0: P_a = L_u^T Gl -> slot of D_u (dead since the load above)
-      //                                  g = 1: P_b = L_b Gr   -> sPb[u]
+      //                                  g = 1: P_b = L_b Gr   -> slot of L_u (dead once the products are formed)
       //                                  g = 2: -L_b Gl        -> L_b in place (new coupling b <-> a)
       // The left operands are wave-uniform LDS reads per group.  In-place safety: every q-step reads column / row data of
       // L_u and L_b, all writes happen after the last q-step (program order within the wave).
@@ -833,6 +883,7 @@ __global__ __launch_bounds__(B >= 12 ? 512 : 1024) void k_cr_chunk(CrView cr, Cr
           if (grp == 2) sCa[((size_t)rv * nsl + u) * B + c] = cw; else sCb[((size_t)rv * nsl + u) * B + c] = cw;
         }
       }
+      CR_PROBE_IN(42);
       double* Gs = sG + (size_t)wave * 2 * BB;
       if (grp == 2 || grp == 3) {
         double* dstg = Gs + (grp == 3 ? BB : 0);
@@ -843,41 +894,51 @@ __global__ __launch_bounds__(B >= 12 ? 512 : 1024) void k_cr_chunk(CrView cr, Cr
       // The three B x B products on the matrix pipe: v_mfma_f64_16x16x4_f64 holds a whole (zero-padded) 16 x 16 result per wave,
       // lane l feeds A[l & 15][4 step + (l >> 4)] and B[4 step + (l >> 4)][l & 15] and receives rows (l >> 4) + 4 reg of column
       // l & 15: ceil(B / 4) steps per product instead of B^2 broadcast reads and FMAs on a third of the lanes.
+      CR_PROBE_IN(43);
       {
         const int mr = lane & 15, mk = lane >> 4;
+        const int mrc = (mr < B) ? mr : B - 1;                             // lanes outside the tile read a valid address and feed zeros
         v4f64 c1 = {0.0, 0.0, 0.0, 0.0}, c2 = c1, c3 = c1;
 #pragma unroll
         for (int ks = 0; ks < (B + 3) / 4; ++ks) {
           const int k = 4 * ks + mk;
+          const int kc = (k < B) ? k : B - 1;
           const bool in = (k < B) && (mr < B);
-          const double a_lut = in ? Lu[k * B + mr] : 0.0;                  // L_u^T[mr][k]
-          const double a_lb = (in && has_b) ? Lb[mr * B + k] : 0.0;        // L_b[mr][k]
-          const double b_gl = in ? Gs[k * B + mr] : 0.0;                   // Gl[k][mr]
-          const double b_gr = in ? Gs[BB + k * B + mr] : 0.0;              // Gr[k][mr]
+          double a_lut = Lu[kc * B + mrc];                                 // L_u^T[mr][k]
+          double a_lb = Lb[mrc * B + kc];                                  // L_b[mr][k]
+          double b_gl = Gs[kc * B + mrc];                                  // Gl[k][mr]
+          double b_gr = Gs[BB + kc * B + mrc];                             // Gr[k][mr]
+          asm volatile("" : "+v"(a_lut), "+v"(a_lb), "+v"(b_gl), "+v"(b_gr));      // unconditional loads, then selects (see the column load)
+          a_lut = in ? a_lut : 0.0;
+          a_lb = (in && has_b) ? a_lb : 0.0;
+          b_gl = in ? b_gl : 0.0;
+          b_gr = in ? b_gr : 0.0;
           c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a_lut, b_gl, c1, 0, 0, 0);    // P_a = L_u^T Gl
           c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a_lb, b_gr, c2, 0, 0, 0);     // P_b = L_b Gr
           c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a_lb, b_gl, c3, 0, 0, 0);     // L_b Gl
         }
-        double* Pb = sPb + (size_t)u * BB;
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
           const int row = mk + 4 * rg;
           if (row < B && mr < B) {
             Du[row * B + mr] = c1[rg];                                     // slot of D_u (dead since the load above)
-            Pb[row * B + mr] = c2[rg];
-            if (has_b) Lb[row * B + mr] = -c3[rg];                         // new coupling b <-> a, in place (all reads are behind us)
+            Lu[row * B + mr] = c2[rg];                                     // slot of L_u (every read of it is behind us: program order within the wave)
+            if (has_b) Lb[row * B + mr] = -c3[rg];                         // new coupling b <-> a, in place
           }
         }
       }
+      CR_PROBE_IN(44);
     }
+    CR_PROBE(probe_slot++);
     lds_barrier();
+    CR_PROBE(probe_slot++);
     // ---- survivors j = 0, 2s, 4s .. subtract what their eliminated neighbours left (left one first) ----
     const int nsv = M / (2 * s) + 1;
     for (int e = tid; e < nsv * BB; e += nthr) {
       const int j = 2 * s * (e / BB), q = e % BB;
       if (j > u_last) continue;
       const bool hl_ = (j - s >= 1), hr_ = (j + s <= u_hi) && (j + s < M || sg.top);
-      const double pl = hl_ ? sPb[(size_t)(j - s) * BB + q] : 0.0;                 // P_b of the left neighbour
+      const double pl = hl_ ? sL[(size_t)(j - s) * BB + q] : 0.0;                  // P_b of the left neighbour
       const double pr = hr_ ? sD[(size_t)(j + s) * BB + q] : 0.0;                  // P_a of the right neighbour
       if (j == 0) accR[q] += pr;
       else if (j == M) accL[q] += pl;
@@ -897,6 +958,7 @@ __global__ __launch_bounds__(B >= 12 ? 512 : 1024) void k_cr_chunk(CrView cr, Cr
         else sW[(vb + j) * B + q] = (sW[(vb + j) * B + q] - pl) - pr;
       }
     lds_barrier();
+    CR_PROBE(probe_slot++);
     // the right-hand side of a node is final once it is eliminated: the back-substitution reads it from global memory
     if (has_w)
       for (int e = tid; e < NR * (M / (2 * s)) * B; e += nthr) {
@@ -927,6 +989,7 @@ __global__ __launch_bounds__(B >= 12 ? 512 : 1024) void k_cr_chunk(CrView cr, Cr
         if (u_last == M) WLn[vo + c1 * B + e] = accWL[e2];
         if (u_last == M && base + M == nst - 1) WRn[vo + c1 * B + e] = 0.0;
       }
+    CR_PROBE(probe_slot++);
     return;
   }
   // ---- top: the root ----
@@ -958,6 +1021,7 @@ __global__ __launch_bounds__(B >= 12 ? 512 : 1024) void k_cr_chunk(CrView cr, Cr
       for (int c = 0; c < B; ++c) v += sL[q * B + c] * sW[(size_t)rv * nsl * B + c];
       x[sg.wstride * rv + q] = v;
     }
+  CR_PROBE(probe_slot++);
 }
 
 // Back-substitution of one stage: x is known at the chunk's two boundary nodes; thread (u, r) owns row r of interior
@@ -1112,14 +1176,19 @@ struct CrPlan { CrStage st[8]; int n; };
 
 static size_t cr_chunk_lds_bytes(int M, int B, int threads, int nrhs) {
   const int nr = nrhs > 0 ? nrhs : 1;
-  return sizeof(double) * ((size_t)(M + 1) * (3 * B * B + 3 * B * nr) + (size_t)(threads / 64) * 2 * B * B + 2 * B * B + 2 * B * nr);
+  return sizeof(double) * ((size_t)(M + 1) * (2 * B * B + 3 * B * nr) + (size_t)(threads / 64) * 2 * B * B + 2 * B * B + 2 * B * nr);
 }
-// extra dynamic LDS of a first stage that stages its band rows (k_cr_chunk, from_src) when they do not fit over sPb / sG
-static size_t cr_chunk_src_extra(int nsl, int B, int threads, int Wb) {
-  const size_t need = (size_t)(nsl + 1) * Wb * ((Wb + 1) * 9 + 4), avail = (size_t)nsl * B * B + (size_t)(threads / 64) * 2 * B * B;
-  return (need <= avail) ? 0 : need * sizeof(double);
+// extra dynamic LDS of a first stage that stages its band rows (k_cr_chunk, from_src) when they are longer than what lies behind the tiles
+static size_t cr_chunk_src_extra(int nsl, int B, int threads, int Wb, int nrhs) {
+  const int nr = nrhs > 0 ? nrhs : 1;
+  const size_t need = (size_t)(nsl + 1) * Wb * ((Wb + 1) * 9 + 4);
+  const size_t avail = (size_t)nsl * 3 * B * nr + (size_t)(threads / 64) * 2 * B * B + 2 * B * B + 2 * B * nr;
+  return (need <= avail) ? 0 : (need - avail) * sizeof(double);
 }
-static int cr_chunk_threads(int M, int B) { return (M <= 2) ? 64 : (M <= 4) ? 128 : (M <= 8) ? 256 : (M >= 32 && B < 12) ? 1024 : 512; }
+static int cr_chunk_threads(int M, int B, int stage = 1) {
+  if (stage == 0 && dev_switches().cr_threads >= 64) return dev_switches().cr_threads & ~63;
+  return (M <= 2) ? 64 : (M <= 4) ? 128 : (M <= 8) ? 256 : (M >= 32 && B < 12) ? 1024 : 512;
+}
 
 // stages of the fused factorisation for nsb super-blocks (host): chunks of 16 at stride 1, chunks of 32 above, then the top.
 // (Chunks of M = 2 -- one wave per eliminated node, no barrier -- were measured for the wide first levels and are not
@@ -1164,16 +1233,17 @@ static bool cr_factor_fused(hipStream_t st, const CrView& cr, double* w, double*
   if (nrhs > cr.pw_rhs) return false;                     // contribution arrays are sized for cr.pw_rhs right-hand sides
   static bool raised = false;
   if (!raised) {
-    raised = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cr_chunk<B>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess;
+    raised = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cr_chunk<B, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess &&
+             hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cr_chunk<B, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess;
     if (!raised) { (void)hipGetLastError(); return false; }
   }
   const CrPlan pl = cr_plan(cr.nsb, B, cr.np, nrhs, wstride);
   for (int t = 0; t < pl.n; ++t) {                        // every stage must fit its LDS budget, else the level-per-launch path
     const CrStage& g = pl.st[t];
     if (g.M < 2 || g.M > 64 || (g.M & (g.M - 1)) != 0) return false;         // a forced plan (HITL_CR_PLAN) with an unusable chunk size
-    const int thr = cr_chunk_threads(g.M, B);
+    const int thr = cr_chunk_threads(g.M, B, t);
     const bool use_src = (src != nullptr && t == 0);
-    if (cr_chunk_lds_bytes(g.nsl - 1, B, thr, nrhs) + (use_src ? cr_chunk_src_extra(g.nsl, B, thr, src->Wb) : 0) > 128 * 1024) return false;
+    if (cr_chunk_lds_bytes(g.nsl - 1, B, thr, nrhs) + (use_src ? cr_chunk_src_extra(g.nsl, B, thr, src->Wb, nrhs) : 0) > 128 * 1024) return false;
     int bthr = (g.M - (g.top ? 0 : 1)) * B;
     bthr = (bthr + 63) & ~63;
     if (bthr > 1024) return false;                                           // never with M <= 64, B <= 12
@@ -1183,11 +1253,14 @@ static bool cr_factor_fused(hipStream_t st, const CrView& cr, double* w, double*
     const CrStage& g = pl.st[t];
     const int64_t alive = ((int64_t)cr.nsb + g.S - 1) / g.S;
     const int chunks = g.top ? 1 : (int)((alive - 1 + g.M - 1) / g.M);       // chunks with at least one interior or boundary-M node
-    const int thr = cr_chunk_threads(g.M, B);
+    const int thr = cr_chunk_threads(g.M, B, t);
     const bool use_src = (src != nullptr && t == 0);
-    const size_t lds = cr_chunk_lds_bytes(g.nsl - 1, B, thr, nrhs) + (use_src ? cr_chunk_src_extra(g.nsl, B, thr, src->Wb) : 0);
+    const size_t lds = cr_chunk_lds_bytes(g.nsl - 1, B, thr, nrhs) + (use_src ? cr_chunk_src_extra(g.nsl, B, thr, src->Wb, nrhs) : 0);
     CrSource none = {};
-    hipLaunchKernelGGL(k_cr_chunk<B>, dim3(chunks > 0 ? chunks : 1), dim3(thr), lds, st, cr, g, use_src ? *src : none, w, x);
+    if (use_src && nrhs == 1 && !g.top && !g.has_prev && g.S == 1 && thr <= 512 && 3 * src->Wb == B && (g.M + 1) * B <= thr)
+      hipLaunchKernelGGL((k_cr_chunk<B, 1>), dim3(chunks > 0 ? chunks : 1), dim3(thr), lds, st, cr, g, *src, w, x);
+    else
+      hipLaunchKernelGGL((k_cr_chunk<B, 0>), dim3(chunks > 0 ? chunks : 1), dim3(thr), lds, st, cr, g, use_src ? *src : none, w, x);
   }
   if (w != nullptr && x != nullptr) {
     for (int t = pl.n - 1; t >= 0; --t) {
@@ -1289,6 +1362,20 @@ static void cr_solve_t(hipStream_t st, const CrView& cr, double* w, double* x, i
   cr_fwd_t<B>(st, cr, w, nrhs, stride);
   cr_back_t<B>(st, cr, w, x, nrhs, stride);
 }
+
+#ifdef HITL_CR_PROBE
+extern "C" void hitl_cr_probe_dump() {
+  unsigned long long h[3 * 64];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_cr_probe), sizeof(h)) != hipSuccess) return;
+  for (int st = 0; st < 3; ++st) {
+    fprintf(stderr, "cr probe stage %d:", st);
+    unsigned long long prev = h[st * 64];
+    for (int k = 1; k < 64; ++k)
+      if (h[st * 64 + k] != 0) { fprintf(stderr, " [%d]%llu", k, h[st * 64 + k] - prev); prev = h[st * 64 + k]; }
+    fprintf(stderr, "\n");
+  }
+}
+#endif
 
 void launch_cr_factor(hipStream_t st, const CrView& cr) {
   switch (cr.B) {

@@ -40,6 +40,7 @@ struct DevSwitches {
   size_t cand_tile_bytes = (size_t)4 << 30;   // HITL_CAND_TILE_BYTES: candidate-table budget of the tiled search
   int cr_plan[16] = {0};           // HITL_CR_PLAN: chunk sizes of the fused stages
   int cr_plan_n = 0;
+  int cr_threads = 0;              // HITL_CR_THREADS: workgroup size of the first fused stage (0 = by chunk size)
 };
 const DevSwitches& dev_switches();
 void read_dev_switches();          // hitl_solver_create only

@@ -440,6 +440,7 @@ void read_dev_switches() {
   d.lm_ahead = (int)std::max(1ll, std::min(16ll, num("HITL_LM_AHEAD", d.lm_ahead)));
   d.kd_refill = (int)std::max(1ll, std::min(64ll, num("HITL_KD_REFILL", d.kd_refill)));
   d.cand_tile_bytes = (size_t)std::max(1ll, num("HITL_CAND_TILE_BYTES", (long long)d.cand_tile_bytes));
+  d.cr_threads = (int)num("HITL_CR_THREADS", 0);
   if (const char* e = std::getenv("HITL_CR_PLAN"))
     for (const char* q = e; *q && d.cr_plan_n < 16;) { d.cr_plan[d.cr_plan_n++] = std::atoi(q); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
   g_dev = d;
