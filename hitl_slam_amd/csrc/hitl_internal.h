@@ -196,6 +196,7 @@ void launch_spmv_residual_step_lm(hipStream_t st, int n_poses, int npad, const F
                                   double* x1, double* q, double* partials, double2* cs, const LmDev* lm);
 // the decision of one LM iteration (Ceres' trust-region rules) from the partial sums of the band pass and of
 // the candidate's linearisation; progress[0..7] (pinned host memory) = iterations completed, done, termination, cost, ...
+size_t lm_decide_lds_bytes(int nblk_step, int nblk_lin);   // dynamic LDS of k_lm_decide: the device-driven loop applies while it fits
 void launch_lm_decide(hipStream_t st, LmDev* lm, LmOpts o, const double* step_partials, int nblk_step, const double* lin_partials0,
                       const double* lin_partials1, int nblk_lin, double* progress_pinned);
 void launch_pack_owned(hipStream_t st, int nhead, const double* head, const double* vec, int off, int cnt, int maxcnt, double* rec);

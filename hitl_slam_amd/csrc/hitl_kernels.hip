@@ -477,51 +477,72 @@ __global__ __launch_bounds__(kAsmBlock) void k_assemble(MapView map, PairView pr
   double gi[3] = {0, 0, 0};
   double H1[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // odometry part of block (i, i+1), produced by lane 1
   double cost = 0.0;
-  if (act && fv.with_stf) {
-    for (int e = fv.inc_off[i] + r; e < fv.inc_off[i + 1]; e += 4) {
-      const int ent = fv.inc_ent[e];
-      const double* RJ = lin.pairRJ + (size_t)kPairRJ * (ent >> 1);
-      const int co = 2 + 3 * (ent & 1);
-      const double r0 = RJ[0], r1 = RJ[1];
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        const double ja0 = RJ[co + a], ja1 = RJ[6 + co + a];
-        gi[a] += ja0 * r0 + ja1 * r1;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) Hd[a * 3 + c] += ja0 * RJ[co + c] + ja1 * RJ[6 + co + c];
-      }
-      if ((ent & 1) == 0) cost += 0.5 * (r0 * r0 + r1 * r1);      // a pair's cost is counted at its source pose
-    }
+  // the band block (i, i + d) of this lane: its two pair indices are requested first, their memory round trip runs under the
+  // incidence loop instead of after it
+  const int d = r + 1;
+  int fwd = -1, rev = -1;
+  if (act && fv.with_stf && d <= Wb && i + d < n) {
+    fwd = fv.band_pair[((size_t)i * Wb + (d - 1)) * 2];
+    rev = fv.band_pair[((size_t)i * Wb + (d - 1)) * 2 + 1];
   }
-  if (act && fv.with_odom) {
-    OdomEval o;
-    if (r == 0 && i >= 1) {  // edge (i-1, i): this pose is pose2 (columns 3..5)
-      eval_odom(x + 3 * (i - 1), x + 3 * i, fv.odom_A[i], fv.odom_rr[i], fv.sig_r, fv.sig_t, fv.sig_a, o);
+  if (act && fv.with_stf) {
+    // incidence entries e = r (mod 4), four at a time: the entry words of a batch are loaded together, then the pair records
+    // of the batch, then the sums in entry order (the order of the one-entry-at-a-time loop: same bits)
+    const int e1 = fv.inc_off[i + 1];
+    for (int eb = fv.inc_off[i] + r; eb < e1; eb += 16) {
+      int ent[4];
 #pragma unroll
-      for (int a = 0; a < 3; ++a) {
+      for (int k = 0; k < 4; ++k) ent[k] = (eb + 4 * k < e1) ? fv.inc_ent[eb + 4 * k] : -1;
+      double rj[4][8];
 #pragma unroll
-        for (int m = 0; m < 3; ++m) {
-          gi[a] += o.J[m * 6 + 3 + a] * o.r[m];
+      for (int k = 0; k < 4; ++k) {
+        if (ent[k] >= 0) {
+          const double* RJ = lin.pairRJ + (size_t)kPairRJ * (ent[k] >> 1);
+          const int co = 2 + 3 * (ent[k] & 1);
+          rj[k][0] = RJ[0]; rj[k][1] = RJ[1];
 #pragma unroll
-          for (int c = 0; c < 3; ++c) Hd[a * 3 + c] += o.J[m * 6 + 3 + a] * o.J[m * 6 + 3 + c];
+          for (int a = 0; a < 3; ++a) { rj[k][2 + a] = RJ[co + a]; rj[k][5 + a] = RJ[6 + co + a]; }
         }
       }
-      cost += 0.5 * (o.r[0] * o.r[0] + o.r[1] * o.r[1] + o.r[2] * o.r[2]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (ent[k] >= 0) {
+          const double r0 = rj[k][0], r1 = rj[k][1];
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            const double ja0 = rj[k][2 + a], ja1 = rj[k][5 + a];
+            gi[a] += ja0 * r0 + ja1 * r1;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) Hd[a * 3 + c] += ja0 * rj[k][2 + c] + ja1 * rj[k][5 + c];
+          }
+          if ((ent[k] & 1) == 0) cost += 0.5 * (r0 * r0 + r1 * r1);      // a pair's cost is counted at its source pose
+        }
+      }
     }
-    if (r == 1 && i + 1 < n) {  // edge (i, i+1): this pose is pose1 (columns 0..2)
-      eval_odom(x + 3 * i, x + 3 * (i + 1), fv.odom_A[i + 1], fv.odom_rr[i + 1], fv.sig_r, fv.sig_t, fv.sig_a, o);
+  }
+  if (act && fv.with_odom && r < 2) {
+    // lane 0: edge (i-1, i), this pose is pose2 (columns 3..5); lane 1: edge (i, i+1), this pose is pose1 (columns 0..2).
+    // ONE call site: both lanes evaluate their edge together (two call sites run one after the other in a diverged wave,
+    // and the functor's sincos / atan2 / divisions are most of this kernel's instructions)
+    const int ea = i - 1 + r;
+    if (ea >= 0 && ea + 1 < n) {
+      OdomEval o;
+      eval_odom(x + 3 * ea, x + 3 * (ea + 1), fv.odom_A[ea + 1], fv.odom_rr[ea + 1], fv.sig_r, fv.sig_t, fv.sig_a, o);
+      const bool second = (r == 0);
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
 #pragma unroll
         for (int m = 0; m < 3; ++m) {
-          gi[a] += o.J[m * 6 + a] * o.r[m];
+          const double ja = second ? o.J[m * 6 + 3 + a] : o.J[m * 6 + a];
+          gi[a] += ja * o.r[m];
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
-            Hd[a * 3 + c] += o.J[m * 6 + a] * o.J[m * 6 + c];
-            H1[a * 3 + c] += o.J[m * 6 + a] * o.J[m * 6 + 3 + c];
+            Hd[a * 3 + c] += ja * (second ? o.J[m * 6 + 3 + c] : o.J[m * 6 + c]);
+            if (!second) H1[a * 3 + c] += ja * o.J[m * 6 + 3 + c];
           }
         }
       }
+      if (second) cost += 0.5 * (o.r[0] * o.r[0] + o.r[1] * o.r[1] + o.r[2] * o.r[2]);
     }
   }
   if (act && fv.with_hc && r == 2) {
@@ -574,13 +595,10 @@ __global__ __launch_bounds__(kAsmBlock) void k_assemble(MapView map, PairView pr
       if (gi[0] != gi[0] || gi[1] != gi[1] || gi[2] != gi[2]) pose_gmax = gi[0] + gi[1] + gi[2];  // NaN propagates
       if (!is_owned) pose_gmax = 0.0;
     }
-    const int d = r + 1;             // this lane's band block (i, i+d)
-    if (d <= Wb) {
+    if (d <= Wb) {                   // this lane's band block (i, i+d)
       double blk[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
       if (i + d < n) {
         if (fv.with_stf) {
-          const int fwd = fv.band_pair[((size_t)i * Wb + (d - 1)) * 2];
-          const int rev = fv.band_pair[((size_t)i * Wb + (d - 1)) * 2 + 1];
           if (fwd >= 0) {  // pair (i -> i+d): block = J0^T J1
             const double* J = lin.pairRJ + (size_t)kPairRJ * fwd + 2;
 #pragma unroll

@@ -73,7 +73,7 @@ static int spin_sync(hitl_solver* s) {
   if (!dev_switches().event_sync) {
     volatile double* flag = s->h_scalars + 15;
     const double seq = (double)(++s->sync_seq);
-    launch_host_flag(s->stream, s->h_scalars + 15, seq);
+    launch_host_flag(s->stream, s->h_scalars + 15, seq);   // (hipStreamWriteValue64 instead of this one-thread kernel: measured, no difference)
     for (uint32_t spins = 1;; ++spins) {
       if (*flag == seq) { std::atomic_thread_fence(std::memory_order_acquire); return HITL_OK; }
       if ((spins & 0xfffffu) == 0) {                       // every million polls: is the stream still alive?
@@ -622,6 +622,7 @@ constexpr int kLmEventPairs = 32;
 
 static bool lm_device_loop_applies(hitl_solver* s, const FactorView& fv) {
   if (!dev_switches().device_lm || s->dist_mode() || fv.n_offband != 0 || s->opt.timing_level >= 2) return false;
+  if (lm_decide_lds_bytes(spmv_blocks(s->npad), assemble_blocks(s->n)) > (size_t)150 * 1024) return false;   // C5's 200 000 poses: 4 x the partials of C4 (46 KB)
   const LinView lv0 = s->lin_view(0), lv1 = s->lin_view(1);
   CrView cr = s->cr_view();
   cr.lm = s->lm_dev.p;
@@ -761,6 +762,7 @@ int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float* poses
   if (!(cost == cost) || !(gmax == gmax)) { term = HITL_FAILURE; done = true; }
   else if (gmax <= o.gradient_tolerance) { term = HITL_CONVERGENCE; done = true; }
   bool dev_loop = false;
+  const double t_loop = now_ms();
   if (!done && o.max_num_iterations > 0 && lm_device_loop_applies(s, fv)) {
     // decisions on the device, iterations queued ahead (single GPU, banded): see lm_device_loop
     double* xf = nullptr;
@@ -838,7 +840,8 @@ int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float* poses
       if (radius < o.min_trust_region_radius) { term = HITL_CONVERGENCE; break; }
     }
   }
-  (void)dev_loop;
+  if (dev_switches().timing)
+    std::fprintf(stderr, "lm_solve: before the loop %.3f ms, %s loop %.3f ms (%d iterations)\n", t_loop - t_start, dev_loop ? "device-driven" : "host-driven", now_ms() - t_loop, iter);
   S.termination = term; S.iterations = iter;
   S.final_cost = cost; S.final_gradient_max_norm = gmax; S.final_trust_region_radius = radius;
   {  // CopyParams (JointOptimization.cpp:380-390): fp64 -> fp32, theta through angle_mod

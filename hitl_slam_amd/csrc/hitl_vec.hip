@@ -232,40 +232,33 @@ void launch_spmv_residual_step_lm(hipStream_t st, int n_poses, int npad, const F
 // submap and off-band paths, and is the default: HITL_DEVICE_LM=1 selects this one).  The per-workgroup partial sums are added in index
 // order, one sequence per lane -- the same order the host used, so both loops take bit-identical decisions.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(320) void k_lm_decide(LmDev* lm, LmOpts o, const double* __restrict__ sp, int nblk_step, const double* __restrict__ lp0,
-                                                   const double* __restrict__ lp1, int nblk_lin, volatile double* progress) {
+__global__ __launch_bounds__(1024) void k_lm_decide(LmDev* lm, LmOpts o, const double* __restrict__ sp, int nblk_step, const double* __restrict__ lp0,
+                                                    const double* __restrict__ lp1, int nblk_lin, volatile double* progress) {
 #pragma clang fp contract(off)      // the host loop is compiled without contraction: 1 - q*q*q must round like there
-  if (lm->done) return;
   // Nine sums over the per-workgroup partials (7 of the band pass, cost and max |g| of the candidate's linearisation), each
   // in the fixed order of ordered_sum32 (hitl_host.h; the host-driven loop adds them the same way): 32 lanes take the terms
-  // b = lane, lane + 32, ... in ascending order, then the 32 lane sums are added from lane 0 up.  The partials are staged
-  // through LDS by the whole workgroup (a dependent chain of global loads would cost ~0.5 us per term).
-  __shared__ double buf[4096];
+  // b = lane, lane + 32, ... in ascending order, then the 32 lane sums are added from lane 0 up.  Every partial -- and the
+  // loop state -- is requested in ONE round of loads by the whole workgroup (both linearisation buffers: which one is the
+  // candidate's is only known once the state has arrived) and staged through LDS.
+  extern __shared__ double buf[];                        // 8 nblk_step + 4 nblk_lin
   __shared__ double part[9][32];
   __shared__ double tot[9];
-  const int tid = threadIdx.x, grp = tid >> 5, j = tid & 31;
-  const double* lp = (lm->cur ^ 1) ? lp1 : lp0;        // the candidate's linearisation
-  double acc = 0.0;
-  for (int base = 0; base < nblk_step; base += 512) {                         // 512 = 16 x 32: lane j keeps the terms b = j (mod 32)
-    const int cnt = min(512, nblk_step - base);
-    for (int e = tid; e < cnt * 8; e += 320) buf[e] = sp[(size_t)base * 8 + e];
-    __syncthreads();
-    if (grp < 7)
-      for (int b = j; b < cnt; b += 32) acc += buf[8 * b + grp];
-    __syncthreads();
+  __shared__ LmDev s_state;
+  const int tid = threadIdx.x, nthr = blockDim.x, grp = tid >> 5, j = tid & 31;
+  const int n1 = 8 * nblk_step, n2 = 2 * nblk_lin;
+  for (int e = tid; e < n1; e += nthr) buf[e] = sp[e];
+  for (int e = tid; e < n2; e += nthr) { buf[n1 + e] = lp0[e]; buf[n1 + n2 + e] = lp1[e]; }
+  if (tid == 0) s_state = *lm;
+  __syncthreads();
+  if (s_state.done) return;
+  const double* lp = buf + n1 + ((s_state.cur ^ 1) ? n2 : 0);      // the candidate's linearisation
+  if (grp < 9) {
+    double acc = 0.0;
+    if (grp < 7) { for (int b = j; b < nblk_step; b += 32) acc += buf[8 * b + grp]; }
+    else if (grp == 7) { for (int b = j; b < nblk_lin; b += 32) acc += lp[2 * b]; }
+    else { for (int b = j; b < nblk_lin; b += 32) { const double g = lp[2 * b + 1]; if (g > acc || g != g) acc = g; } }
+    part[grp][j] = acc;
   }
-  for (int base = 0; base < nblk_lin; base += 2048) {
-    const int cnt = min(2048, nblk_lin - base);
-    for (int e = tid; e < cnt * 2; e += 320) buf[e] = lp[(size_t)base * 2 + e];
-    __syncthreads();
-    if (grp == 7) {
-      for (int b = j; b < cnt; b += 32) acc += buf[2 * b];
-    } else if (grp == 8) {
-      for (int b = j; b < cnt; b += 32) { const double g = buf[2 * b + 1]; if (g > acc || g != g) acc = g; }
-    }
-    __syncthreads();
-  }
-  if (grp < 9) part[grp][j] = acc;
   __syncthreads();
   if (tid < 9) {
     double t = 0.0;
@@ -276,7 +269,7 @@ __global__ __launch_bounds__(320) void k_lm_decide(LmDev* lm, LmOpts o, const do
   __syncthreads();
   if (tid != 0) return;
   const double rr = tot[0], bb = tot[1], dt_rhs = tot[2], dt_q = tot[3], step2 = tot[4], xn2 = tot[5], bad = tot[6], cand_cost = tot[7], cand_gmax = tot[8];
-  LmDev s = *lm;
+  LmDev s = s_state;
   ++s.iter;
   const bool ok = (rr == rr) && !(rr > o.guard2 * bb);          // the factorisation did not break down
   const double mcc = dt_rhs - 0.5 * dt_q;                        // model_cost_change; rhs = -S g
@@ -320,8 +313,12 @@ __global__ __launch_bounds__(320) void k_lm_decide(LmDev* lm, LmOpts o, const do
 
 void launch_lm_decide(hipStream_t st, LmDev* lm, LmOpts o, const double* step_partials, int nblk_step, const double* lin_partials0,
                       const double* lin_partials1, int nblk_lin, double* progress_pinned) {
-  hipLaunchKernelGGL(k_lm_decide, dim3(1), dim3(320), 0, st, lm, o, step_partials, nblk_step, lin_partials0, lin_partials1, nblk_lin, progress_pinned);
+  const size_t lds = sizeof(double) * ((size_t)8 * nblk_step + (size_t)4 * nblk_lin);
+  static bool raised = false;
+  if (!raised) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lm_decide), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); raised = true; }
+  hipLaunchKernelGGL(k_lm_decide, dim3(1), dim3(1024), lds, st, lm, o, step_partials, nblk_step, lin_partials0, lin_partials1, nblk_lin, progress_pinned);
 }
+size_t lm_decide_lds_bytes(int nblk_step, int nblk_lin) { return sizeof(double) * ((size_t)8 * nblk_step + (size_t)4 * nblk_lin); }
 
 void launch_spmv_step(hipStream_t st, int n_poses, int npad, const FactorView& fv, const LinView& lin,
                       const double* scale, const double* dt, const double* rhs, const double* x, double* q, double* xc,
