@@ -34,7 +34,10 @@ struct SpmvAux {
   double* x_alt;
 };
 
-template <int MODE>
+// WB > 0: the band is WB poses wide (known at compile time): the two block loops are unrolled with clamped addresses, so that
+// all of a row's block, scale and vector loads are in flight together instead of one loop iteration's at a time (a thread's
+// chain of dependent memory round trips is what this kernel waits for: there is less than one wave per SIMD).
+template <int MODE, int WB = 0>
 __global__ __launch_bounds__(128) void k_spmv(int n_poses, int npad, FactorView fv, LinView lin,
                                                const double* __restrict__ scale, double mu, double min_diag,
                                                double max_diag, const double* __restrict__ v, double* __restrict__ y,
@@ -71,9 +74,35 @@ __global__ __launch_bounds__(128) void k_spmv(int n_poses, int npad, FactorView 
       // Columns of constant poses are not part of the linear system (MODE 0/1).  In MODE 2 they
       // ARE included: v then carries the neighbouring submap's step on the halo poses (0 for pose 0),
       // so owned rows see the cross-cut coupling in the model cost change.
-      const int Wb = fv.band_poses, W1 = Wb + 1;
+      const int Wb = (WB > 0) ? WB : fv.band_poses, W1 = Wb + 1;
       double acc[3] = {0, 0, 0};
       const double* Hi = lin.Hband + (size_t)i * W1 * 9;
+      if (WB > 0 && kStep) {
+        // same blocks, same order, same sums as the loops below (kStep: no column is skipped)
+        double bl[2 * WB + 1][9], vv[2 * WB + 1][3];
+        bool ok[2 * WB + 1];
+#pragma unroll
+        for (int k = 0; k <= 2 * WB; ++k) {
+          const int d = (k <= WB) ? k : k - WB;               // k <= WB: block (i, i + d);  k > WB: block (i - d, i), used transposed
+          const int j = (k <= WB) ? i + d : i - d;
+          ok[k] = (k <= WB) ? (j < n_poses) : (j >= 0);
+          const int jc = ok[k] ? j : i;
+          const double* blk = (k <= WB) ? Hi + d * 9 : lin.Hband + ((size_t)jc * W1 + d) * 9;
+#pragma unroll
+          for (int e = 0; e < 9; ++e) bl[k][e] = blk[e];
+#pragma unroll
+          for (int e = 0; e < 3; ++e) vv[k][e] = scale[3 * jc + e] * v[3 * jc + e];
+        }
+#pragma unroll
+        for (int k = 0; k <= 2 * WB; ++k) {
+          if (!ok[k]) continue;
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            if (k <= WB) acc[a] += bl[k][a * 3] * vv[k][0] + bl[k][a * 3 + 1] * vv[k][1] + bl[k][a * 3 + 2] * vv[k][2];
+            else acc[a] += bl[k][a] * vv[k][0] + bl[k][3 + a] * vv[k][1] + bl[k][6 + a] * vv[k][2];
+          }
+        }
+      } else {
       for (int d = 0; d <= Wb && i + d < n_poses; ++d) {
         const int j = i + d;
         if (!kStep && !aux.all_cols && fv.fixed[j]) continue;
@@ -89,6 +118,7 @@ __global__ __launch_bounds__(128) void k_spmv(int n_poses, int npad, FactorView 
         const double v0 = scale[3 * j] * v[3 * j], v1 = scale[3 * j + 1] * v[3 * j + 1], v2 = scale[3 * j + 2] * v[3 * j + 2];
 #pragma unroll
         for (int a = 0; a < 3; ++a) acc[a] += blk[a] * v0 + blk[3 + a] * v1 + blk[6 + a] * v2;
+      }
       }
       if (fv.with_stf && fv.n_offband > 0 && fv.ob_acc != nullptr) {
 #pragma unroll
@@ -215,14 +245,16 @@ void launch_spmv_residual_step(hipStream_t st, int n_poses, int npad, const Fact
                                double* partials, double2* cs) {
   SpmvAux aux = {rhs, nullptr, x, xc, partials, cs, 0};
   spmv_offband(st, n_poses, fv, lin, scale, v, true);
-  hipLaunchKernelGGL(k_spmv<3>, dim3(spmv_blocks(npad)), dim3(128), 0, st, n_poses, npad, fv, lin, scale, mu, min_diag, max_diag, v, q, aux);
+  if (fv.band_poses == 3) hipLaunchKernelGGL((k_spmv<3, 3>), dim3(spmv_blocks(npad)), dim3(128), 0, st, n_poses, npad, fv, lin, scale, mu, min_diag, max_diag, v, q, aux);
+  else hipLaunchKernelGGL((k_spmv<3, 0>), dim3(spmv_blocks(npad)), dim3(128), 0, st, n_poses, npad, fv, lin, scale, mu, min_diag, max_diag, v, q, aux);
 }
 
 void launch_spmv_residual_step_lm(hipStream_t st, int n_poses, int npad, const FactorView& fv, const LinView& lin0, const LinView& lin1,
                                   const double* scale, double min_diag, double max_diag, const double* v, const double* rhs, double* x0,
                                   double* x1, double* q, double* partials, double2* cs, const LmDev* lm) {
   SpmvAux aux = {rhs, nullptr, x0, nullptr, partials, cs, 0, lm, lin1, x1};
-  hipLaunchKernelGGL(k_spmv<3>, dim3(spmv_blocks(npad)), dim3(128), 0, st, n_poses, npad, fv, lin0, scale, 1.0, min_diag, max_diag, v, q, aux);
+  if (fv.band_poses == 3) hipLaunchKernelGGL((k_spmv<3, 3>), dim3(spmv_blocks(npad)), dim3(128), 0, st, n_poses, npad, fv, lin0, scale, 1.0, min_diag, max_diag, v, q, aux);
+  else hipLaunchKernelGGL((k_spmv<3, 0>), dim3(spmv_blocks(npad)), dim3(128), 0, st, n_poses, npad, fv, lin0, scale, 1.0, min_diag, max_diag, v, q, aux);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
