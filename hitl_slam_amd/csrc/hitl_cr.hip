@@ -707,7 +707,7 @@ __device__ unsigned long long g_cr_probe[3 * 64];
 #define HITL_CR_WAVES 8
 #endif
 template <int B, int KIND>
-__global__ __launch_bounds__((B >= 12 || KIND == 1) ? 512 : 1024) __attribute__((amdgpu_waves_per_eu(KIND == 1 ? HITL_CR_WAVES : 4)))
+__global__ __launch_bounds__((B >= 12 || KIND == 1) ? 512 : 1024) __attribute__((amdgpu_waves_per_eu((KIND == 1 && B == 9) ? HITL_CR_WAVES : 4)))
 void k_cr_chunk(CrView cr, CrStage sg_in, CrSource src, double* w, double* x) {
   extern __shared__ double lds[];
   CrStage sg = sg_in;
