@@ -183,6 +183,7 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
   const MapView mv = s->map_view();
   if (kd && !s->kd_built) {
     TRYC(ensure_kd_trees(s));
+    if (timing) (void)hipStreamSynchronize(s->stream);     // the phase line is the build itself, not its enqueue
     mark("k_kd_build");
   }
   // one tile of source poses [i0, i0 + cnt): upload its candidates, match

@@ -170,11 +170,32 @@ __global__ __launch_bounds__(kKdBlock) void k_kd_build(MapView map, int max_scan
       const uint32_t sg = seg[p];
       const int n = (int)(sg >> 16);
       if (n > 0 && (int)(sg & 0xffffu) == p) {
+        // the sums run in segment order (fp32, order-dependent); eight elements are loaded at a time so that the adds wait for
+        // one LDS round trip per eight elements instead of one each
         float mx = 0.0f, my = 0.0f;
-        for (int q = p; q < p + n; ++q) { mx = mx + cx[q]; my = my + cy[q]; }
+        int q = p;
+        for (; q + 8 <= p + n; q += 8) {
+          float vx[8], vy[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) { vx[k] = cx[q + k]; vy[k] = cy[q + k]; }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) { mx = mx + vx[k]; my = my + vy[k]; }
+        }
+        for (; q < p + n; ++q) { mx = mx + cx[q]; my = my + cy[q]; }
         mx = mx / (float)n; my = my / (float)n;
         float sx = 0.0f, sy = 0.0f;
-        for (int q = p; q < p + n; ++q) {
+        q = p;
+        for (; q + 8 <= p + n; q += 8) {
+          float vx[8], vy[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) { vx[k] = cx[q + k]; vy[k] = cy[q + k]; }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            sx = sx + (vx[k] - mx) * (vx[k] - mx);
+            sy = sy + (vy[k] - my) * (vy[k] - my);
+          }
+        }
+        for (; q < p + n; ++q) {
           sx = sx + (cx[q] - mx) * (cx[q] - mx);
           sy = sy + (cy[q] - my) * (cy[q] - my);
         }
@@ -198,7 +219,15 @@ __global__ __launch_bounds__(kKdBlock) void k_kd_build(MapView map, int max_scan
         const float* co = s_plane[lo] ? cy : cx;
         const float key = co[p];
         int rank = 0;
-        for (int q = lo; q < lo + n; ++q) {
+        int q = lo;
+        for (; q + 8 <= lo + n; q += 8) {                  // eight keys per LDS round trip
+          float k8[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) k8[k] = co[q + k];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) rank += (k8[k] < key || (k8[k] == key && q + k < p)) ? 1 : 0;
+        }
+        for (; q < lo + n; ++q) {
           const float kq = co[q];
           rank += (kq < key || (kq == key && q < p)) ? 1 : 0;
         }
