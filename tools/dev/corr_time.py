@@ -1,7 +1,7 @@
 """Development helper: timing breakdown of hitl_solver_find_correspondences on the C4 map (HITL_TIMING=1 prints the phases)."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import hitl_slam_amd as H
 from tools import hitl_synth as S
 n, m = 50000, 400

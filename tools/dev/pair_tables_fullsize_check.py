@@ -1,7 +1,7 @@
 """Development helper: device-built pair tables against host-built ones on the 50k x 400 map: same lists -> bit-identical solve."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import hitl_slam_amd as H
 from tools import hitl_synth as S
 n, m = 50000, 400

@@ -2,8 +2,8 @@
 cyclic reduction (nsb = 1034: the last super-block is local node M of the last second-stage chunk) against the oracle."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import hitl_slam_amd as H
 from oracle import hitl_oracle as O
 from conftest import Problem
