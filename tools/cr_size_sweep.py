@@ -4,8 +4,8 @@ iteration count and termination for every size (structural edge cases of the fus
 different iteration count).  usage: cr_size_sweep.py out.jsonl"""
 import json, os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import hitl_slam_amd as H
 from conftest import Problem
 
