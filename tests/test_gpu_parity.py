@@ -318,6 +318,40 @@ def test_device_driven_lm_loop_equals_the_host_driven_one(monkeypatch, shape, la
     monkeypatch.delenv("HITL_DEVICE_LM", raising=False)
 
 
+@pytest.mark.parametrize("shape", [(150, 64, 50, 3, 0, 3), (97, 48, 97, 2, 4, 2), (64, 40, 64, 1, 2, 4), (333, 32, 111, 2, 0, 3)])
+def test_first_stage_instantiation_equals_the_separate_build(monkeypatch, shape):
+    """The first fused cyclic-reduction stage of the LM path cuts its tiles and right-hand side from the band rows itself (its own
+    instantiation of k_cr_chunk: facts of that stage known at compile time, a register budget for four workgroups per CU).
+    HITL_CR_UNFUSED_BUILD=1 forms the same system with k_build_system and runs the generic instantiation: same arithmetic in the
+    same order -- poses to the last bit, same iteration counts and costs, for band widths of 2, 3 and 4 poses (B = 6, 9, 12)."""
+    import hitl_slam_amd as H
+    n, m, ppf, groups, kind, window = shape
+    prob = Problem(n, m, ppf=ppf, groups=groups, kind=kind, window=window)
+    g = H.Solver()
+    prob.load(g)
+    g.find_correspondences(prob.init, window)
+    corr = g.get_correspondences()
+    g.close()
+    for mode in (0, 2):
+        res = []
+        for unfused in (False, True):
+            if unfused:
+                monkeypatch.setenv("HITL_CR_UNFUSED_BUILD", "1")
+            else:
+                monkeypatch.delenv("HITL_CR_UNFUSED_BUILD", raising=False)
+            s = H.Solver()               # the switches are read at create
+            prob.load(s, corr=corr)
+            p, sm = s.solve(mode, prob.init)
+            res.append((p, sm.termination, sm.iterations, sm.successful_steps, sm.final_cost, sm.final_trust_region_radius, sm.band_poses))
+            s.close()
+        f, u = res
+        assert np.array_equal(f[0].view(np.uint32), u[0].view(np.uint32)), (mode, np.abs(f[0] - u[0]).max())
+        assert f[1:] == u[1:], (mode, f[1:], u[1:])
+        if mode == 2:
+            assert f[6] == window
+    monkeypatch.delenv("HITL_CR_UNFUSED_BUILD", raising=False)
+
+
 def test_timing_levels_do_not_change_results(small_problem):
     """hitl_options.timing_level only decides how many device-timing events a solve records (0: none, 1: every 4th
     linearisation, 2: all + linear-solver time): poses, cost and iteration count are identical, the timers behave as
