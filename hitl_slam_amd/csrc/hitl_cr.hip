@@ -1027,14 +1027,26 @@ void k_cr_chunk(CrView cr, CrStage sg_in, CrSource src, double* w, double* x) {
 // Back-substitution of one stage: x is known at the chunk's two boundary nodes; thread (u, r) owns row r of interior
 // node u, fetches its three coefficient rows ONCE (all loads of the launch are in flight together), forms
 // v = (Dinv_u w_u)[r] and then only touches LDS: x_u[r] = v - Gl_u[r,:] x_{u-s} - Gr_u[r,:] x_{u+s}, level by level.
+// nrhs > 1 (submap ranks: the interface columns): one workgroup per (chunk, right-hand side), numbered so that the nrhs
+// workgroups of a chunk land on the SAME XCD one after the other (workgroups go to the 8 XCDs round-robin by index): the
+// chunk's 3 x 81 x (M - 1) coefficient doubles come from HBM once and from that XCD's L2 for the other right-hand sides,
+// instead of nrhs times from HBM (a (chunks, nrhs) grid puts the workgroups of a chunk ~1000 dispatches apart).
 template <int B>
-__global__ __launch_bounds__(1024) void k_cr_chunk_back(CrView cr, int S, int M, int top, const double* __restrict__ w, double* __restrict__ x, size_t wstride) {
+__global__ __launch_bounds__(1024) void k_cr_chunk_back(CrView cr, int S, int M, int top, const double* __restrict__ w, double* __restrict__ x, size_t wstride,
+                                                        int chunks, int nrhs) {
   if (cr.lm != nullptr && cr.lm->done) return;
   extern __shared__ double sx[];                         // (M + 1) * B
   const int tid = threadIdx.x;
-  w += wstride * blockIdx.y;                             // one right-hand side per workgroup row
-  x += wstride * blockIdx.y;
-  const int64_t base = (int64_t)blockIdx.x * M;
+  int chunk = blockIdx.x, rv = 0;
+  if (nrhs > 1) {
+    const int xcd = blockIdx.x & 7, t = blockIdx.x >> 3;
+    rv = t % nrhs;
+    chunk = (t / nrhs) * 8 + xcd;
+    if (chunk >= chunks) return;
+  }
+  w += wstride * rv;
+  x += wstride * rv;
+  const int64_t base = (int64_t)chunk * M;
   const int64_t nst = ((int64_t)cr.nsb + S - 1) / S;
   const int u_last = (int)((nst - 1 - base < M) ? (nst - 1 - base) : M);
   const int u = 1 + tid / B, r = tid % B;
@@ -1270,7 +1282,8 @@ static bool cr_factor_fused(hipStream_t st, const CrView& cr, double* w, double*
       const int chunks = g.top ? 1 : (int)((alive - 1 + g.M - 1) / g.M);
       int thr = (g.M - (g.top ? 0 : 1)) * B;
       thr = (thr + 63) & ~63;
-      hipLaunchKernelGGL(k_cr_chunk_back<B>, dim3(chunks, nrhs), dim3(thr), sizeof(double) * (g.M + 1) * B, st, cr, g.S, g.M, g.top, w, x, wstride);
+      const int grid = (nrhs > 1) ? 8 * nrhs * ((chunks + 7) / 8) : chunks;
+      hipLaunchKernelGGL(k_cr_chunk_back<B>, dim3(grid), dim3(thr), sizeof(double) * (g.M + 1) * B, st, cr, g.S, g.M, g.top, w, x, wstride, chunks, nrhs);
     }
   }
   return true;
@@ -1302,7 +1315,7 @@ static bool cr_solve_fused(hipStream_t st, const CrView& cr, const double* w_in,
     int thr = (g.M - (g.top ? 0 : 1)) * B;
     thr = (thr + 63) & ~63;
     if (thr > 1024) return false;
-    hipLaunchKernelGGL(k_cr_chunk_back<B>, dim3(chunks, 1), dim3(thr), sizeof(double) * (g.M + 1) * B, st, cr, g.S, g.M, g.top, w, x, (size_t)0);
+    hipLaunchKernelGGL(k_cr_chunk_back<B>, dim3(chunks), dim3(thr), sizeof(double) * (g.M + 1) * B, st, cr, g.S, g.M, g.top, w, x, (size_t)0, chunks, 1);
   }
   return true;
 }

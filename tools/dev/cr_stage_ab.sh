@@ -18,7 +18,7 @@ for f in glob.glob("$OUT/trace/*/*kernel_trace.csv"):
     groups, cur = [], None
     for t, d, k in rows:
         if "k_linearize_stf" in k or "k_assemble" in k: cur = None
-        elif "k_cr_chunk<" in k or "k_cr_chunk_back<" in k:
+        elif "k_cr_chunk<" in k or "k_cr_chunk_back" in k:
             if cur is None: cur = []; groups.append(cur)
             cur.append(d)
     groups = [g for g in groups if len(g) == 6][4:]
