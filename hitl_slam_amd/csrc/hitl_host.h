@@ -64,6 +64,33 @@ struct DevArray {
   }
 };
 
+// page-locked host staging buffer that lives as long as its owner (uploads from it are real DMA, queued without a copy through
+// a bounce buffer, and need no synchronisation before the function that filled it returns)
+template <typename T>
+struct PinnedArray {
+  T* p = nullptr;
+  size_t cap = 0;
+  PinnedArray() = default;
+  PinnedArray(const PinnedArray&) = delete;
+  PinnedArray& operator=(const PinnedArray&) = delete;
+  ~PinnedArray() { release(); }
+  int resize(size_t count) {
+    if (count <= cap && p) return HITL_OK;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    const size_t want = std::max<size_t>(count, 1);
+    HIP_TRY(hipHostMalloc((void**)&p, want * sizeof(T)));
+    cap = want;
+    return HITL_OK;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
 // what hitl_cycle.cpp needs from a solver (defined in hitl_solver.cpp)
 struct SolverCtx {
   int device;

@@ -731,11 +731,12 @@ int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float* poses
   const int n = s->n, n3 = 3 * n;
   hitl_summary S;
   std::memset(&S, 0, sizeof(S));
-  {  // SetParams (JointOptimization.cpp:392-402): fp32 -> fp64
-    std::vector<double> hx(s->npad, 0.0);
+  {  // SetParams (JointOptimization.cpp:392-402): fp32 -> fp64, through a page-locked buffer the solver keeps (queued, not waited for)
+    TRY(s->h_x.resize(s->npad));
+    double* hx = s->h_x.p;
     for (int t = 0; t < n3; ++t) hx[t] = (double)poses_in[t];
-    HIP_TRY(hipMemcpyAsync(s->x.p, hx.data(), sizeof(double) * s->npad, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    for (int t = n3; t < s->npad; ++t) hx[t] = 0.0;
+    HIP_TRY(hipMemcpyAsync(s->x.p, hx, sizeof(double) * s->npad, hipMemcpyHostToDevice, st));
   }
   double* xcur = s->x.p;
   double* xcand = s->xc.p;
@@ -845,8 +846,9 @@ int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float* poses
   S.termination = term; S.iterations = iter;
   S.final_cost = cost; S.final_gradient_max_norm = gmax; S.final_trust_region_radius = radius;
   {  // CopyParams (JointOptimization.cpp:380-390): fp64 -> fp32, theta through angle_mod
-    std::vector<double> hx(n3);
-    HIP_TRY(hipMemcpyAsync(hx.data(), xcur, sizeof(double) * n3, hipMemcpyDeviceToHost, st));
+    TRY(s->h_x.resize(s->npad));
+    double* hx = s->h_x.p;                                 // page-locked: a direct DMA instead of a copy through a bounce buffer
+    HIP_TRY(hipMemcpyAsync(hx, xcur, sizeof(double) * n3, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     for (int i = 0; i < n; ++i) {
       poses_out[3 * i] = (float)hx[3 * i];

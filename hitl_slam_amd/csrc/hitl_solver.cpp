@@ -225,20 +225,30 @@ static void hc_target(const hitl_human_constraint_t& row, const float* a, float4
 }
 
 int setup_factors(hitl_solver* s, const float* poses, const float* poses_global, bool with_odom_hc) {
+  // Per solve: the odometry measurements re-derived from the current fp32 poses (JointOptimization.cpp:748-769) and the human
+  // rows' targets (they depend on the anchor poses).  Staged in page-locked buffers the solver keeps: no allocation, real DMA,
+  // and no synchronisation here -- the stream orders the uploads before the first kernel that reads them, and the buffers are
+  // not touched again before the solve has returned.
   const int n = s->n;
-  std::vector<float4> A(n, make_float4(0, 0, 0, 0));
-  std::vector<float2> rr(n, make_float2(0, 0));
-  std::vector<int> hc_off(n + 1, 0);
-  std::vector<uint32_t> hc_type;
-  std::vector<float4> hc_tgt;
+  hipStream_t st = s->stream;
+  TRY(s->h_odom_A.resize(n)); TRY(s->h_odom_rr.resize(n)); TRY(s->h_hc_off.resize((size_t)n + 1));
+  float4* A = s->h_odom_A.p;
+  float2* rr = s->h_odom_rr.p;
+  A[0] = make_float4(0, 0, 0, 0); rr[0] = make_float2(0, 0);
+  const size_t H = with_odom_hc ? s->h_hc.size() : 0;
+  TRY(s->h_hc_type.resize(H)); TRY(s->h_hc_tgt.resize(H));          // (at least one element each)
+  uint32_t* hc_type = s->h_hc_type.p;
+  float4* hc_tgt = s->h_hc_tgt.p;
+  hc_type[0] = 0; hc_tgt[0] = make_float4(0, 0, 0, 0);
   s->num_hc_residuals = 0;
   if (with_odom_hc) {
     for (int i = 1; i < n; ++i) odom_setup(poses + 3 * (i - 1), poses + 3 * i, &A[i], &rr[i]);
-    const size_t H = s->h_hc.size();
+    int* hc_off = s->h_hc_off.p;
+    std::fill(hc_off, hc_off + n + 1, 0);
     for (size_t h = 0; h < H; ++h) hc_off[s->h_hc[h].constrained_pose_id + 1]++;
     for (int i = 0; i < n; ++i) hc_off[i + 1] += hc_off[i];
-    hc_type.resize(H); hc_tgt.resize(H);
-    std::vector<int> fill(hc_off.begin(), hc_off.end() - 1);
+    std::vector<int> fill(H ? n : 0);
+    if (H) std::copy(hc_off, hc_off + n, fill.begin());
     for (size_t h = 0; h < H; ++h) {  // stable: rows of one pose keep their caller order
       const hitl_human_constraint_t& row = s->h_hc[h];
       const int dst = fill[row.constrained_pose_id]++;
@@ -248,12 +258,14 @@ int setup_factors(hitl_solver* s, const float* poses, const float* poses_global,
       else if (row.type == HITL_HC_COLINEAR) s->num_hc_residuals += 2;
       else if (row.type == HITL_HC_PERPENDICULAR || row.type == HITL_HC_PARALLEL) s->num_hc_residuals += 1;
     }
+  } else {
+    std::fill(A, A + n, make_float4(0, 0, 0, 0));
+    std::fill(rr, rr + n, make_float2(0, 0));
+    std::fill(s->h_hc_off.p, s->h_hc_off.p + n + 1, 0);
   }
-  if (hc_type.empty()) { hc_type.push_back(0); hc_tgt.push_back(make_float4(0, 0, 0, 0)); }
-  hipStream_t st = s->stream;
-  TRY(s->odom_A.upload(A, st)); TRY(s->odom_rr.upload(rr, st));
-  TRY(s->hc_off.upload(hc_off, st)); TRY(s->hc_type.upload(hc_type, st)); TRY(s->hc_tgt.upload(hc_tgt, st));
-  HIP_TRY(hipStreamSynchronize(st));  // host vectors go out of scope
+  TRY(s->odom_A.upload(A, (size_t)n, st)); TRY(s->odom_rr.upload(rr, (size_t)n, st));
+  TRY(s->hc_off.upload(s->h_hc_off.p, (size_t)n + 1, st));
+  TRY(s->hc_type.upload(hc_type, std::max<size_t>(H, 1), st)); TRY(s->hc_tgt.upload(hc_tgt, std::max<size_t>(H, 1), st));
   return HITL_OK;
 }
 

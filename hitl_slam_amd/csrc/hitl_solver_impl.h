@@ -111,6 +111,12 @@ struct hitl_solver {
   DevArray<double> ob_acc;                     // per-pose sums of the off-band products (k_spmv_offband)
 
   // ---- per-solve factor tables ----
+  PinnedArray<float4> h_odom_A;                // host staging of the per-solve tables (setup_factors) and of the start state (lm_solve)
+  PinnedArray<float2> h_odom_rr;
+  PinnedArray<int> h_hc_off;
+  PinnedArray<uint32_t> h_hc_type;
+  PinnedArray<float4> h_hc_tgt;
+  PinnedArray<double> h_x;
   DevArray<float4> odom_A, hc_tgt;
   DevArray<float2> odom_rr;
   DevArray<int> hc_off;
