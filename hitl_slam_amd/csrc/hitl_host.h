@@ -115,6 +115,24 @@ static inline double ordered_sum32(const double* v, int n, int stride) {
   for (int q = 0; q < 32; ++q) t += p[q];
   return t;
 }
+// K sums over records of `stride` doubles (term b of sum k is v[b * stride + k]) in ONE pass over the records: the same order per
+// sum as ordered_sum32 (same bits), each cache line of the pinned partials touched once instead of K times
+template <int K>
+static inline void ordered_sum32_records(const double* v, int n, int stride, double* out) {
+  double p[32][K];
+  for (int q = 0; q < 32; ++q)
+    for (int k = 0; k < K; ++k) p[q][k] = 0.0;
+  for (int b = 0; b < n; ++b) {
+    const double* r = v + (size_t)b * stride;
+    double* pq = p[b & 31];
+    for (int k = 0; k < K; ++k) pq[k] += r[k];
+  }
+  for (int k = 0; k < K; ++k) {
+    double t = 0.0;
+    for (int q = 0; q < 32; ++q) t += p[q][k];
+    out[k] = t;
+  }
+}
 int solver_allgather(hitl_solver* s, const void* send, void* recv, int64_t bytes_per_rank);   // the submap transport, host buffers
 
 }  // namespace hitl

@@ -206,7 +206,7 @@ static int read_step_partials(hitl_solver* s, double* rr, double* bb, StepScalar
 static int finish_step_partials(hitl_solver* s, double* rr, double* bb, StepScalars* ss) {
   const int nblk = spmv_blocks(s->npad);
   double acc[7];
-  for (int k = 0; k < 7; ++k) acc[k] = ordered_sum32(s->h_partials + k, nblk, 8);     // the order k_lm_decide uses
+  ordered_sum32_records<7>(s->h_partials, nblk, 8, acc);     // the order k_lm_decide uses (ordered_sum32 per sum), one pass over the records
   if (rr) *rr = acc[0];
   if (bb) *bb = acc[1];
   if (ss) { ss->dt_rhs = acc[2]; ss->dt_q = acc[3]; ss->step2 = acc[4]; ss->xn2 = acc[5]; ss->bad = acc[6]; }
