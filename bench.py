@@ -428,6 +428,22 @@ def main():
         except Exception as e:
             result["stf_moments_mode"] = {"failed": repr(e)}
 
+    # ---- mode A on the same resident map: odometry + human rows only (SolveHumanConstraints, JointOptimization.cpp:1064-1138 --
+    #      the solve the shipped binary runs after every correction; the headline above is mode C) ----
+    if world == 1:
+        try:
+            outa, summa = solver.solve(H.MODE_ODOM_HC, init_l)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                outa, summa = solver.solve(H.MODE_ODOM_HC, init_l)
+            torch.cuda.synchronize()
+            result["mode_a_resolve_ms"] = (time.perf_counter() - t0) * 1e3 / args.steps
+            result["mode_a_lm_iterations"] = int(summa.iterations)
+        except Exception as e:
+            result["mode_a_resolve_ms"] = None
+            result["mode_a_error"] = repr(e)
+
     # ---- the opt-in brute-force definition of the correspondence query on the same map (kd_tree_search = 0) ----
     if world == 1:
         try:
