@@ -1199,6 +1199,12 @@ static size_t cr_chunk_src_extra(int nsl, int B, int threads, int Wb, int nrhs) 
 }
 static int cr_chunk_threads(int M, int B, int stage = 1) {
   if (stage == 0 && dev_switches().cr_threads >= 64) return dev_switches().cr_threads & ~63;
+  // first stage of the narrow bands: a node costs a wave whatever the tile size, and thousands of chunks queue for the CUs' 32
+  // wave slots -- fewer waves per workgroup (the first level in several passes) puts more chunks on a CU at once.  Measured at
+  // 40 000 - 50 000 poses: B = 3: 128 threads 4.9 ms per mode-A solve against 5.6 with 512; B = 6: 256 threads 5.5 against 5.9;
+  // B = 9 and 12: 512 stays best (HITL_CR_THREADS sweeps)
+  if (stage == 0 && M == 16 && B == 3) return 128;
+  if (stage == 0 && M == 16 && B == 6) return 256;
   return (M <= 2) ? 64 : (M <= 4) ? 128 : (M <= 8) ? 256 : (M >= 32 && B < 12) ? 1024 : 512;
 }
 
