@@ -1224,7 +1224,9 @@ static CrPlan cr_plan(int nsb, int B, int np, int nrhs, size_t wstride) {
     const int64_t alive = ((int64_t)nsb + S - 1) / S;
     int Mtop = 2;
     while (Mtop < alive) Mtop *= 2;                        // interior u = 1 .. alive-1 < Mtop
-    const bool fits_top = alive <= 40 && cr_chunk_lds_bytes((int)alive, B, cr_chunk_threads(64, B), nrhs) <= lds_cap;
+    // the top takes every remaining node in one workgroup: up to 40 of them (128 of the 3 x 3 tiles of the one-pose band: seven
+    // levels in one launch instead of a stage of its own in front of a two-level top)
+    const bool fits_top = alive <= (B == 3 ? 128 : 40) && cr_chunk_lds_bytes((int)alive, B, cr_chunk_threads(64, B), nrhs) <= lds_cap;
     CrStage& g = pl.st[pl.n++];
     g.S = S; g.has_prev = prev ? 1 : 0; g.prev_par = par; g.next_par = par ^ 1; g.np = np; g.nrhs = nrhs; g.wstride = wstride;
     if (fits_top || pl.n == 8) { g.M = Mtop; g.top = 1; g.nsl = (int)alive + 1; break; }
@@ -1258,13 +1260,13 @@ static bool cr_factor_fused(hipStream_t st, const CrView& cr, double* w, double*
   const CrPlan pl = cr_plan(cr.nsb, B, cr.np, nrhs, wstride);
   for (int t = 0; t < pl.n; ++t) {                        // every stage must fit its LDS budget, else the level-per-launch path
     const CrStage& g = pl.st[t];
-    if (g.M < 2 || g.M > 64 || (g.M & (g.M - 1)) != 0) return false;         // a forced plan (HITL_CR_PLAN) with an unusable chunk size
+    if (g.M < 2 || g.M > (B == 3 ? 128 : 64) || (g.M & (g.M - 1)) != 0) return false;   // a forced plan (HITL_CR_PLAN) with an unusable chunk size
     const int thr = cr_chunk_threads(g.M, B, t);
     const bool use_src = (src != nullptr && t == 0);
     if (cr_chunk_lds_bytes(g.nsl - 1, B, thr, nrhs) + (use_src ? cr_chunk_src_extra(g.nsl, B, thr, src->Wb, nrhs) : 0) > 128 * 1024) return false;
     int bthr = (g.M - (g.top ? 0 : 1)) * B;
     bthr = (bthr + 63) & ~63;
-    if (bthr > 1024) return false;                                           // never with M <= 64, B <= 12
+    if (bthr > 1024) return false;                                           // never with M <= 64, B <= 12 (or M = 128, B = 3)
   }
   if (validate) return true;
   for (int t = 0; t < pl.n; ++t) {
