@@ -76,13 +76,35 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` started directly: N ranks are needed and this process is not one of them.  Start them
+        # as CHILD processes (torch.distributed.run, one rank per GPU) before this process has imported torch or touched
+        # the GPU -- never a re-exec -- relay rank 0's JSON line and exit with the launcher's code.  A run labelled
+        # n_gpus = N is therefore always N ranks; it can never be one rank with a label.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.stderr.write("bench.py: --gpus %d without WORLD_SIZE: launching %d ranks: %s\n" % (args.gpus, args.gpus, " ".join(cmd)))
+        sys.exit(subprocess.call(cmd, env=env))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: the number of ranks IS the number of GPUs of a run; "
+                         "start one rank per GPU (torch.distributed.run --nproc-per-node %d)\n" % (args.gpus, world, args.gpus))
+        sys.exit(4)
 
     import torch
     import torch.distributed as dist
     use_dist = world > 1
+    if args.backend == "nccl" and use_dist and torch.cuda.device_count() < world:      # device_count() does not initialise the GPU
+        sys.stderr.write("bench.py: %d ranks over RCCL need %d GPUs, this node shows %d (use --backend gloo to let ranks share a "
+                         "GPU for debugging)\n" % (world, world, torch.cuda.device_count()))
+        sys.exit(5)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
     dev_index = local_rank % torch.cuda.device_count()
@@ -256,6 +278,8 @@ def main():
             dist.destroy_process_group()
         return
 
+    if world > 1 and comm_ranks != args.gpus:
+        raise SystemExit("bench.py: the communicator holds %d ranks but the line would say n_gpus = %d" % (comm_ranks, args.gpus))
     ms_per_step = elapsed * 1e3 / args.steps
     avg_stf_ms = stf_ms / max(stf_calls, 1)
     alg_bytes = algorithmic_bytes_stf(n_obs, n_matches_l, n_local, n_pairs_l)
@@ -306,7 +330,8 @@ def main():
                    "matches_per_obs": n_matches_l / max(n_obs, 1), "window": wl["window"],
                    "human_constraint_rows": rows[1], "mode": "C (joint)", "band_poses": int(summ.band_poses),
                    "parallelism": ("%d pose-range submaps, 1 per GPU, one global LM; exchange: %s" % (world, comm_kind)) if world > 1 else "single GPU",
-                   "comm": comm_kind, "comm_ranks": comm_ranks if world > 1 else 1},
+                   "comm": comm_kind, "comm_ranks": comm_ranks if world > 1 else 1,
+                   "ranks_share_gpus": bool(world > 1 and torch.cuda.device_count() < world)},
         "resolve_ms": ms_per_step,
         "gn_iters_per_sec": iters_all / elapsed,
         "lm_iterations_per_resolve": summ.iterations,

@@ -83,6 +83,7 @@ int ensure_kd_trees(hitl_solver* s) {      // BuildKDTrees: once per map (JointO
 
 int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
   HIP_TRY(hipSetDevice(s->device));
+  s->min_band_poses = 1;      // a new correspondence set: the band a submap rank once widened to belongs to the old one (prepare re-derives it)
   const bool timing = dev_switches().timing;
   auto t_prev = std::chrono::steady_clock::now();
   auto mark = [&](const char* what) {

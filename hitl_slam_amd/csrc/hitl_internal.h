@@ -31,7 +31,8 @@ struct DevSwitches {
   bool device_lm = false;          // HITL_DEVICE_LM: accept / reject / terminate decided on the device (k_lm_decide), iterations queued ahead.
                                    // Measured (round 3): gap-free kernel timeline, but the decision kernel costs what the host turn-around
                                    // cost -- 4-8 us per iteration SLOWER on every workload -- so the host-driven loop stays the default
-  int stf_variant = 0;             // HITL_STF_VARIANT: instantiation of k_linearize_stf
+  int stf_variant = 0;             // HITL_STF_VARIANT: instantiation of k_linearize_stf (1xx: one wave per pair, one pose per workgroup; 2xx: the half-wave kernel
+                                   // although the persistent one applies)
   int kd_block = 256;              // HITL_KD_BLOCK: workgroup size of k_match_kd_tgt (64 / 128 / 256)
   int lm_ahead = 3;                // HITL_LM_AHEAD: LM iterations the host queues ahead of the device-driven loop
   int kd_cap = 0;                  // HITL_KD_CAP: frame-stack entries per lane of k_match_kd_tgt's first attempt (0 = 5); tests force the full-depth repeat with 1
@@ -150,6 +151,22 @@ void launch_linearize_stf_moments(hipStream_t st, const PairView& pr, const doub
 void launch_linearize_stf(hipStream_t st, const MapView& map, const PairView& pr, int max_scan, int64_t map_obs_count, int64_t n_matches,
                           const double* x, const double2* cs, float corr, float std_dev, double* pairRJ,
                           const LmDev* lm = nullptr, const double* x_alt = nullptr, double* pairRJ_alt = nullptr);
+// round 4: the persistent, wave-per-pair form of the same linearisation (k_linearize_stf_p).  It walks a step table (one
+// step = one source pose and up to six of its directed pairs) built once per correspondence set by launch_build_stf_steps:
+// step_off[n_poses + 1] (step_off[n_poses] = number of steps, read by the kernel itself), steps[] of stf_step_bytes() each
+// (at most n_poses + n_pairs / 6 of them).  Applies to scans of <= 2048 points; grid = workgroups (4 per CU).
+size_t stf_step_bytes();
+void launch_build_stf_steps(hipStream_t st, const MapView& map, const PairView& pr, int* step_off, void* steps);
+void launch_linearize_stf_steps(hipStream_t st, int max_scan, int grid, const void* steps, const int* n_steps, const float4* obs,
+                                const uint32_t* matches, const double* x, const double2* cs, float corr, float std_dev, double* pairRJ);
+// round 4: one wave per workgroup, every wave on its own run of pairs, software-pipelined over pairs (k_linearize_stf_s).
+// recs: one stf_pair_rec_bytes() record per pair (launch_build_stf_pair_recs, once per correspondence set; *max_len receives
+// the largest match count of a pair: the kernel holds at most stf_stream_max_len() matches of a pair in registers).
+size_t stf_pair_rec_bytes();
+int stf_stream_max_len();
+void launch_build_stf_pair_recs(hipStream_t st, const MapView& map, const PairView& pr, void* recs, int* max_len);
+void launch_linearize_stf_stream(hipStream_t st, int max_scan, int cu_count, const void* recs, const int* pose_pair_off, int n_poses, const int64_t* obs_off,
+                                 const float4* obs, const uint32_t* matches, const double* x, const double2* cs, float corr, float std_dev, double* pairRJ);
 void launch_pack_obs(hipStream_t st, int64_t n, const float* px, const float* py, const float* nx, const float* ny,
                      float4* obs);
 void launch_assemble(hipStream_t st, const MapView& map, const PairView& pr, const FactorView& fv,

@@ -37,6 +37,12 @@ static int enqueue_linearize(hitl_solver* s, const FactorView& fv, const double*
   if (fv.with_stf) {
     if (s->opt.stf_moments)
       launch_linearize_stf_moments(st, pv, s->pairM.p, xdev, s->pose_cs.p, s->opt.point_correlation_factor, s->opt.laser_std_dev, lv.pairRJ);
+    else if (s->stf_recs_of == s->corr_generation && s->stf_stream_fits && stf_stream_apply(s))
+      launch_linearize_stf_stream(st, s->max_scan, s->cu_count, s->stf_recs.p, s->pose_pair_off.p, s->n, s->obs_off.p, s->obs.p, s->matches.p, xdev,
+                                  s->pose_cs.p, s->opt.point_correlation_factor, s->opt.laser_std_dev, lv.pairRJ);
+    else if (s->stf_steps_of == s->corr_generation && stf_steps_apply(s))
+      launch_linearize_stf_steps(st, s->max_scan, 4 * s->cu_count, s->stf_steps.p, s->stf_step_off.p + s->n, s->obs.p, s->matches.p, xdev,
+                                 s->pose_cs.p, s->opt.point_correlation_factor, s->opt.laser_std_dev, lv.pairRJ);
     else
       launch_linearize_stf(st, mv, pv, s->max_scan, s->n_obs, s->n_matches, xdev, s->pose_cs.p, s->opt.point_correlation_factor, s->opt.laser_std_dev, lv.pairRJ);
   }

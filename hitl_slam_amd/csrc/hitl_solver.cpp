@@ -231,6 +231,12 @@ int setup_factors(hitl_solver* s, const float* poses, const float* poses_global,
   // not touched again before the solve has returned.
   const int n = s->n;
   hipStream_t st = s->stream;
+  if (s->staging_queued) {
+    // uploads of an earlier call may still read the pinned staging buffers refilled below (a solve that returned early on an
+    // error never drained the stream): wait for them -- on an idle stream this returns at once
+    HIP_TRY(hipStreamSynchronize(st));
+    s->staging_queued = false;
+  }
   TRY(s->h_odom_A.resize(n)); TRY(s->h_odom_rr.resize(n)); TRY(s->h_hc_off.resize((size_t)n + 1));
   float4* A = s->h_odom_A.p;
   float2* rr = s->h_odom_rr.p;
@@ -247,9 +253,18 @@ int setup_factors(hitl_solver* s, const float* poses, const float* poses_global,
     const int nt = (n >= 20000) ? (int)std::max(1u, std::min(4u, std::thread::hardware_concurrency())) : 1;
     auto edges = [&](int lo, int hi) { for (int i = lo; i < hi; ++i) odom_setup(poses + 3 * (i - 1), poses + 3 * i, &A[i], &rr[i]); };
     if (nt > 1) {
+      // std::thread's constructor may throw (std::system_error: no thread to be had); nothing may leave through the C ABI:
+      // whatever range got no thread is done here
       std::vector<std::thread> th;
-      for (int t = 1; t < nt; ++t) th.emplace_back(edges, 1 + (int)((int64_t)(n - 1) * t / nt), 1 + (int)((int64_t)(n - 1) * (t + 1) / nt));
+      int started = 1;
+      try {
+        for (int t = 1; t < nt; ++t) {
+          th.emplace_back(edges, 1 + (int)((int64_t)(n - 1) * t / nt), 1 + (int)((int64_t)(n - 1) * (t + 1) / nt));
+          started = t + 1;
+        }
+      } catch (...) {}
       edges(1, 1 + (n - 1) / nt);
+      for (int t = started; t < nt; ++t) edges(1 + (int)((int64_t)(n - 1) * t / nt), 1 + (int)((int64_t)(n - 1) * (t + 1) / nt));
       for (auto& x : th) x.join();
     } else edges(1, n);
     int* hc_off = s->h_hc_off.p;
@@ -272,6 +287,7 @@ int setup_factors(hitl_solver* s, const float* poses, const float* poses_global,
     std::fill(rr, rr + n, make_float2(0, 0));
     std::fill(s->h_hc_off.p, s->h_hc_off.p + n + 1, 0);
   }
+  s->staging_queued = true;       // from the first queued copy on, also when one of the later uploads fails
   TRY(s->odom_A.upload(A, (size_t)n, st)); TRY(s->odom_rr.upload(rr, (size_t)n, st));
   TRY(s->hc_off.upload(s->h_hc_off.p, (size_t)n + 1, st));
   TRY(s->hc_type.upload(hc_type, std::max<size_t>(H, 1), st)); TRY(s->hc_tgt.upload(hc_tgt, std::max<size_t>(H, 1), st));
@@ -316,6 +332,26 @@ static int prepare_local(hitl_solver* s, int mode, const float* poses_ref, const
     HIP_TRY(hipGetLastError());
     s->moments_of = s->corr_generation;
   }
+  if (!s->opt.stf_moments && mode != HITL_MODE_ODOM_HC && s->n_pairs > 0 && stf_steps_apply(s) && s->stf_steps_of != s->corr_generation) {
+    // once per correspondence set: the step table the persistent linearisation walks
+    TRY(s->stf_step_off.resize((size_t)s->n + 1));
+    TRY(s->stf_steps.resize(((size_t)s->n + (size_t)s->n_pairs / 6 + 2) * stf_step_bytes()));
+    launch_build_stf_steps(s->stream, s->map_view(), s->pair_view(), s->stf_step_off.p, s->stf_steps.p);
+    HIP_TRY(hipGetLastError());
+    s->stf_steps_of = s->corr_generation;
+  }
+  if (!s->opt.stf_moments && mode != HITL_MODE_ODOM_HC && s->n_pairs > 0 && stf_stream_apply(s) && s->stf_recs_of != s->corr_generation) {
+    // once per correspondence set: the pair records the stream linearisation walks, and whether every pair fits its registers
+    TRY(s->stf_recs.resize((size_t)s->n_pairs * stf_pair_rec_bytes()));
+    TRY(s->stf_max_len.resize(1));
+    launch_build_stf_pair_recs(s->stream, s->map_view(), s->pair_view(), s->stf_recs.p, s->stf_max_len.p);
+    HIP_TRY(hipGetLastError());
+    int max_len = 0;
+    HIP_TRY(hipMemcpyAsync(&max_len, s->stf_max_len.p, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    s->stf_stream_fits = max_len <= stf_stream_max_len();
+    s->stf_recs_of = s->corr_generation;
+  }
   TRY(setup_factors(s, poses_ref, poses_global, mode != HITL_MODE_STF_ONLY));
   return HITL_OK;
 }
@@ -328,7 +364,7 @@ int prepare(hitl_solver* s, int mode, const float* poses_ref, const float* poses
   if (s->dist_mode()) {
     // interface width = how deep (in poses) any factor reaches across a cut, maximised over all
     // ranks: 1 when only the odometry edges straddle the cuts, up to the pose band otherwise
-    int wi_local = 1;
+    int wi_local = 1, min_Wb = Wb;
     if (mode != HITL_MODE_ODOM_HC && local_rc == HITL_OK && ensure_host_pairs(s) == HITL_OK)
       for (int p = 0; p < s->n_pairs; ++p) {
         const int a = std::min(s->h_pair_src[p], s->h_pair_tgt[p]), b = std::max(s->h_pair_src[p], s->h_pair_tgt[p]);
@@ -340,15 +376,16 @@ int prepare(hitl_solver* s, int mode, const float* poses_ref, const float* poses
       // point: a rank that failed above (or holds pose pairs outside the band, which submap solves do not support yet)
       // must not let the others walk into the collectives of the LM loop alone
       const bool offband_here = (mode != HITL_MODE_ODOM_HC) && s->n_offband > 0;
-      double mine[3] = {(double)wi_local, (double)local_rc, offband_here ? 1.0 : 0.0};
-      std::vector<double> all((size_t)3 * s->world);
+      double mine[4] = {(double)wi_local, (double)local_rc, offband_here ? 1.0 : 0.0, (double)Wb};
+      std::vector<double> all((size_t)4 * s->world);
       TRY(comm_allgather(s, mine, all.data(), sizeof(mine)));
       int worst = HITL_OK;
       bool any_offband = false;
       for (int r = 0; r < s->world; ++r) {
-        wi_local = std::max(wi_local, (int)all[(size_t)3 * r]);
-        if ((int)all[(size_t)3 * r + 1] != HITL_OK && worst == HITL_OK) worst = (int)all[(size_t)3 * r + 1];
-        any_offband = any_offband || all[(size_t)3 * r + 2] != 0.0;
+        wi_local = std::max(wi_local, (int)all[(size_t)4 * r]);
+        if ((int)all[(size_t)4 * r + 1] != HITL_OK && worst == HITL_OK) worst = (int)all[(size_t)4 * r + 1];
+        any_offband = any_offband || all[(size_t)4 * r + 2] != 0.0;
+        min_Wb = std::min(min_Wb, (int)all[(size_t)4 * r + 3]);
       }
       if (local_rc != HITL_OK) return local_rc;
       if (worst != HITL_OK) return fail(worst, "another rank failed while preparing the solve");
@@ -363,12 +400,22 @@ int prepare(hitl_solver* s, int mode, const float* poses_ref, const float* poses
       const int cap = std::min(std::max((int)s->opt.max_band_poses, 1), kMaxBandPoses);
       if (s->Wi > cap)
         return fail(HITL_ERR_UNSUPPORTED, "a factor reaches " + std::to_string(s->Wi) + " poses across a cut, further than the pose band may be wide (max_band_poses)");
+      int widen_rc = HITL_OK;
       if (s->Wi > Wb) {
-        s->min_band_poses = s->Wi;
-        TRY(ensure_host_pairs(s));
-        TRY(build_pair_structures(s));
-        Wb = s->band_pairs_Wb;
-        TRY(prepare_local(s, mode, poses_ref, poses_global, Wb));
+        s->min_band_poses = s->Wi;       // reset by set_map / set_partition / every new correspondence set
+        widen_rc = ensure_host_pairs(s);
+        if (widen_rc == HITL_OK) widen_rc = build_pair_structures(s);
+        if (widen_rc == HITL_OK) { Wb = s->band_pairs_Wb; widen_rc = prepare_local(s, mode, poses_ref, poses_global, Wb); }
+      }
+      if (s->Wi > min_Wb) {
+        // somebody rebuilt its tables (every rank knows from the gathered bands): agree on the outcome before anyone enters
+        // the LM loop's collectives -- a rank that ran out of memory here must not leave the others waiting in them
+        double mine_w = (double)widen_rc;
+        std::vector<double> all_w((size_t)s->world);
+        TRY(comm_allgather(s, &mine_w, all_w.data(), sizeof(mine_w)));
+        if (widen_rc != HITL_OK) return widen_rc;
+        for (int r = 0; r < s->world; ++r)
+          if ((int)all_w[(size_t)r] != HITL_OK) return fail((int)all_w[(size_t)r], "another rank failed while widening its pose band to the interface");
       }
     }
     if (s->dist_pcg) {
@@ -564,6 +611,10 @@ int hitl_solver_create(const hitl_options* opt, hitl_solver** out) {
   std::memset(s->h_scalars, 0, sizeof(double) * (kNumScalars + 8));
   if (s->lm_dev.resize(1) != HITL_OK) return bail(HITL_ERR_OUT_OF_MEMORY, "hipMalloc failed");     // a recycled pinned block may hold an old sequence word (spin_sync polls it)
   if (s->d_scalars.resize(kNumScalars) != HITL_OK) return bail(HITL_ERR_OUT_OF_MEMORY, "hipMalloc failed");
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, o.device) == hipSuccess && cus > 0) s->cu_count = cus;
+  }
   s->rank = o.rank;
   s->world = o.world_size;
   s->force_dist = dev_switches().force_dist;
@@ -666,6 +717,7 @@ int hitl_solver_set_partition(hitl_solver* s, int64_t global_begin, int64_t n_gl
   s->hl = (s->world > 1 && s->rank > 0) ? halo_poses : 0;
   s->hh = (s->world > 1 && s->rank < s->world - 1) ? halo_poses : 0;
   s->n = 0;   // a map must be (re)installed for this range
+  s->min_band_poses = 1;
   return HITL_OK;
 }
 
@@ -675,6 +727,7 @@ int hitl_solver_set_map(hitl_solver* s, int64_t n_poses, const int64_t* obs_offs
   if (n_poses > (int64_t)1 << 30) return fail(HITL_ERR_UNSUPPORTED, "set_map: more than 2^30 poses");
   if (s->world > 1 && s->g_n == 0) return fail(HITL_ERR_NOT_READY, "set_map: call hitl_solver_set_partition first when world_size > 1");
   if (s->world == 1) { s->g_begin = 0; s->g_n = n_poses; s->hl = s->hh = 0; }
+  s->min_band_poses = 1;
   // submap rank: n_poses = hl halo poses + owned poses + hh halo poses, i.e. global [g_begin - hl, ...)
   if (s->world > 1 && (n_poses <= s->hl + s->hh || s->g_begin - s->hl + n_poses > s->g_n)) return fail(HITL_ERR_INVALID_ARGUMENT, "set_map: the local range [begin - halo, end + halo) does not fit the global pose count");
   if (s->world > 1 && s->rank == s->world - 1 && s->g_begin - s->hl + n_poses != s->g_n) return fail(HITL_ERR_INVALID_ARGUMENT, "set_map: the last rank's range must end at the last global pose");
@@ -752,6 +805,7 @@ int hitl_solver_set_correspondences(hitl_solver* s, int64_t n_pairs, const int32
   if (s->n <= 0) return fail(HITL_ERR_NOT_READY, "set_correspondences before set_map");
   if (n_pairs > 0 && (!pair_src || !pair_tgt || !match_offset || !src_idx || !tgt_idx)) return fail(HITL_ERR_INVALID_ARGUMENT, "set_correspondences: null array");
   HIP_TRY(hipSetDevice(s->device));
+  s->min_band_poses = 1;                       // a new correspondence set (see find_correspondences)
   const int P = (int)n_pairs;
   const int shift = s->hl - (int)s->g_begin;   // GLOBAL pose id -> local index
   for (int p = 0; p < P; ++p) {

@@ -17,6 +17,7 @@ struct hitl_solver {
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr, ev_sync = nullptr;
+  bool staging_queued = false;  // copies out of the pinned staging buffers (setup_factors, the start state) may still be in flight
   int64_t lin_launches = 0;     // linearisations queued so far (every 4th is bracketed by events at timing_level 1)
   bool lin_timed = false;       // the linearisation in flight is bracketed
   double* h_scalars = nullptr;  // pinned, kNumScalars + 8: [15] = sequence word of spin_sync, [kNumScalars ..] = progress record of the device-driven LM loop
@@ -103,6 +104,14 @@ struct hitl_solver {
   int adj_window = 0, adj_slots = 0;
   std::vector<std::pair<int, int>> h_adj;
   int min_band_poses = 1;                      // lower bound of the pose band (a submap rank: the interface width of the whole partition)
+  DevArray<int> stf_step_off;                  // persistent linearisation (k_linearize_stf_p): first step of every pose, [n] = number of steps
+  DevArray<char> stf_steps;                    //   the step records
+  int64_t stf_steps_of = -1;                   //   correspondence-set generation the table belongs to
+  int cu_count = 256;                          // compute units of the device (grid of the persistent kernels)
+  DevArray<char> stf_recs;                     // stream linearisation (k_linearize_stf_s): one record per pair
+  DevArray<int> stf_max_len;                   //   largest match count of a pair (device scalar)
+  int64_t stf_recs_of = -1;                    //   correspondence-set generation the records belong to
+  bool stf_stream_fits = false;                //   every pair of that set fits the kernel's registers
   DevArray<double> pairM;                      // opt-in (stf_moments): 2 x 15 moments per pair
   int64_t moments_of = -1;                     // correspondence-set generation the moments belong to
   int64_t corr_generation = 0;                 // bumped whenever the pair tables change
@@ -163,6 +172,13 @@ struct LinResult { double cost, gmax; float stf_ms; int timed; };
 static inline double angle_mod(double a) {  // shared/math/util.h:433-439
   return a - 6.28318530717958647692 * std::rint(a / 6.28318530717958647692);
 }
+
+// which linearisation kernel: HITL_STF_VARIANT 0 / 500 = the half-wave kernel (default), 1..99 = its other instantiations,
+// 100..199 = one wave per pair / one pose per workgroup, 300 = one wave per workgroup streaming its own run of pairs,
+// 400 = persistent workgroups over a step table.  The three round-4 kernels are measured alternatives (profiles/ROUND_LOG.md);
+// all are held to the oracle by tests/test_gpu_edge.py::test_linearisation_kernels_on_awkward_pair_lists
+static inline bool stf_steps_apply(const hitl_solver* s) { return s->max_scan <= 2048 && dev_switches().stf_variant == 400; }
+static inline bool stf_stream_apply(const hitl_solver* s) { return s->max_scan <= 1024 && dev_switches().stf_variant == 300; }
 
 // hitl_solver.cpp
 int build_pair_structures(hitl_solver* s);

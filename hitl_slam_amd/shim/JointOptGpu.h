@@ -15,9 +15,11 @@
 #ifndef HITL_JOINT_OPT_GPU_H_
 #define HITL_JOINT_OPT_GPU_H_
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -99,28 +101,53 @@ class JointOptGpuT {
   }
   // opt-in moments form of the scan-to-scan factors (hitl_options.stf_moments); call before the first Run()
   void SetStfMoments(bool on) { stf_moments_ = on; }
+  // host time of the last Run(): the map fingerprint alone, and the whole call up to CopyParams (fingerprint, marshaling,
+  // search, solve); threads the fingerprint may use (default: min(8, hardware threads); 1 = no threads at all)
+  double LastFingerprintMs() const { return fingerprint_ms_; }
+  double LastRunMs() const { return run_ms_; }
+  void SetHashThreads(int t) { hash_threads_ = t < 1 ? 1 : t; }
+
+  // 64-bit fingerprint of all scans: every bit of every point and normal and every scan size enters it
+  unsigned long long Fingerprint() const {
+    const size_t n = robot_frame_point_clouds_.size();
+    std::vector<unsigned long long> per(n, 0ull);
+    int nt = hash_threads_ > 0 ? hash_threads_ : (int)std::thread::hardware_concurrency();
+    if (nt < 1) nt = 1;
+    if (nt > 8 && hash_threads_ <= 0) nt = 8;
+    if ((size_t)nt > n / 64 + 1) nt = (int)(n / 64 + 1);
+    const JointOptGpuT* self = this;
+    unsigned long long* out = per.data();
+    bool threaded = false;
+    if (nt > 1) {
+      std::vector<std::thread> th;
+      try {
+        for (int t = 0; t < nt; ++t) th.push_back(std::thread(&JointOptGpuT::HashRange, self, n * t / nt, n * (t + 1) / nt, out));
+        threaded = true;
+      } catch (...) { threaded = false; }            // no thread to be had: the started ones finish, then the serial loop redoes all
+      for (size_t t = 0; t < th.size(); ++t) th[t].join();
+    }
+    if (!threaded) HashRange(this, 0, n, out);
+    unsigned long long h = 0x9e3779b97f4a7c15ull ^ (unsigned long long)n;
+    for (size_t i = 0; i < n; ++i) { h = (h ^ per[i]) * 0x100000001b3ull; h ^= h >> 29; }
+    return h;
+  }
 
   int RunStatus() {
     if (!Solver()) return create_status_;
     const size_t n = poses_.size();
     if (n == 0 || robot_frame_point_clouds_.size() != n || robot_frame_normal_clouds_.size() != n) return HITL_ERR_INVALID_ARGUMENT;
-    // == BuildKDTrees on the first call (:1307).  The scans normally never change afterwards; a different map -- any bit of
-    // any point or normal, any scan size -- is uploaded again.  The fingerprint reads every coordinate once (O(n_obs), the
-    // cost of the repack below; 4 lanes of FNV-1a over the 32-bit patterns) -- a sample would miss an edited point.
-    unsigned long long lane[4] = {1469598103934665603ull, 1099511628211ull * 31, 0x9e3779b97f4a7c15ull, 0xc2b2ae3d27d4eb4full};
-    for (size_t i = 0; i < n; ++i) {
-      const size_t m = robot_frame_point_clouds_[i].size();
-      if (robot_frame_normal_clouds_[i].size() != m) return HITL_ERR_INVALID_ARGUMENT;
-      lane[0] = (lane[0] ^ (unsigned long long)m) * 1099511628211ull;
-      for (size_t k = 0; k < m; ++k) {
-        const float v[4] = {robot_frame_point_clouds_[i][k].x(), robot_frame_point_clouds_[i][k].y(),
-                            robot_frame_normal_clouds_[i][k].x(), robot_frame_normal_clouds_[i][k].y()};
-        unsigned int bits[4];
-        std::memcpy(bits, v, sizeof(bits));
-        for (int q = 0; q < 4; ++q) lane[q] = (lane[q] ^ bits[q]) * 1099511628211ull;
-      }
-    }
-    const unsigned long long print = lane[0] ^ (lane[1] * 3) ^ (lane[2] * 5) ^ (lane[3] * 7);
+    // == BuildKDTrees on the first call (:1307).  The scans normally never change afterwards, but HitLSLAM::Run re-copies
+    // every cloud into this object before every solve (HitLSLAM.cpp:450-454), so neither pointers nor sizes can say "same
+    // map": a different map -- any bit of any point or normal, any scan size -- is uploaded again, the same map is not.
+    // The fingerprint therefore reads every coordinate on every Run(); it is the one O(n_obs) host cost of a steady-state
+    // call, so it runs over the raw 64-bit words of each scan with four independent multiply-mix chains, scans spread over
+    // a few threads (20 M observations = 320 MB: ~4 ms on 8 threads, measured by tests/shim_driver.cpp, against 25-50 ms
+    // for the byte-serial form of round 3).  LastFingerprintMs() / LastRunMs() report what a call spent.
+    const std::chrono::steady_clock::time_point t_run0 = std::chrono::steady_clock::now();
+    for (size_t i = 0; i < n; ++i)
+      if (robot_frame_normal_clouds_[i].size() != robot_frame_point_clouds_[i].size()) return HITL_ERR_INVALID_ARGUMENT;
+    const unsigned long long print = Fingerprint();
+    fingerprint_ms_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_run0).count();
     if (map_poses_ != n || map_print_ != print) {
       std::vector<int64_t> off(n + 1, 0);
       for (size_t i = 0; i < n; ++i) off[i + 1] = off[i] + (int64_t)robot_frame_point_clouds_[i].size();
@@ -161,6 +188,7 @@ class JointOptGpuT {
     for (size_t i = 0; i < n; ++i) {   // == CopyParams (:380-390)
       poses_[i].translation.x() = xyt[3 * i]; poses_[i].translation.y() = xyt[3 * i + 1]; poses_[i].angle = xyt[3 * i + 2];
     }
+    run_ms_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_run0).count();   // what JointOpt::Run costs the caller
     if (want_info_mat) {
       int64_t ne = 0;
       st = hitl_solver_get_info_mat(solver_, mode_, &ne, NULL, NULL);
@@ -193,6 +221,42 @@ class JointOptGpuT {
   }
 
  private:
+  static unsigned long long HashBytes(const void* data, size_t bytes, unsigned long long seed) {
+    const unsigned char* p = static_cast<const unsigned char*>(data);
+    unsigned long long a = seed ^ 0xcbf29ce484222325ull, b = seed + 0x9e3779b97f4a7c15ull, c = ~seed, d = seed * 0xc2b2ae3d27d4eb4full + 1;
+    const unsigned long long K = 0x100000001b3ull * 0x9e3779b97f4a7c15ull | 1ull;
+    size_t k = 0;
+    for (; k + 32 <= bytes; k += 32) {
+      unsigned long long w[4];
+      std::memcpy(w, p + k, 32);
+      a = (a ^ w[0]) * K; b = (b ^ w[1]) * K; c = (c ^ w[2]) * K; d = (d ^ w[3]) * K;
+      a ^= a >> 31; b ^= b >> 31; c ^= c >> 31; d ^= d >> 31;
+    }
+    for (; k < bytes; ++k) { a = (a ^ p[k]) * K; a ^= a >> 31; }
+    return ((a * 3) ^ (b * 5) ^ (c * 7) ^ (d * 11)) + (unsigned long long)bytes;
+  }
+  // scans [i0, i1): Vec2f that is two packed floats (Eigen::Vector2f) is hashed as raw memory, anything else through x() / y()
+  static void HashRange(const JointOptGpuT* self, size_t i0, size_t i1, unsigned long long* out) {
+    for (size_t i = i0; i < i1; ++i) {
+      const std::vector<Vec2f>& P = self->robot_frame_point_clouds_[i];
+      const std::vector<Vec2f>& N = self->robot_frame_normal_clouds_[i];
+      const size_t m = P.size();
+      unsigned long long h = 0x1000193ull * (unsigned long long)(m + 1);
+      if (m > 0) {
+        if (sizeof(Vec2f) == 2 * sizeof(float)) {
+          h ^= HashBytes(&P[0], m * sizeof(Vec2f), 1);
+          h = h * 0x100000001b3ull ^ HashBytes(&N[0], m * sizeof(Vec2f), 2);
+        } else {
+          std::vector<float> tmp(4 * m);
+          for (size_t k = 0; k < m; ++k) { tmp[4 * k] = P[k].x(); tmp[4 * k + 1] = P[k].y(); tmp[4 * k + 2] = N[k].x(); tmp[4 * k + 3] = N[k].y(); }
+          h ^= HashBytes(&tmp[0], tmp.size() * sizeof(float), 3);
+        }
+      }
+      out[i] = h;
+    }
+  }
+  int hash_threads_ = 0;
+  double fingerprint_ms_ = 0.0, run_ms_ = 0.0;
   int mode_;
   int64_t stf_window_;
   hitl_solver* solver_;

@@ -46,3 +46,44 @@ def test_bench_source_keeps_the_oracle_in_its_lane():
     i = src.index("from oracle import")
     assert "CPU baseline" in src[max(0, i - 900):i]
     assert "no CPU fallback" in src          # a missing GPU is an error, not a detour
+
+
+def _run_bench(args, env_extra=None, timeout=900):
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_refuses_a_rank_count_that_differs_from_gpus():
+    """`--gpus N` inside a launcher that started another number of ranks is refused before anything touches a GPU: the line may never
+    say n_gpus = N for a run of fewer ranks (a one-rank run used to be labelled 8 GPUs)."""
+    r = _run_bench(["--gpus", "4"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, timeout=120)
+    assert r.returncode == 4 and "WORLD_SIZE=1" in r.stderr and r.stdout.strip() == ""
+    r = _run_bench(["--gpus", "1"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"}, timeout=120)
+    assert r.returncode == 4 and r.stdout.strip() == ""
+
+
+@pytest.mark.gpu
+def test_bench_started_directly_with_gpus_2_launches_two_ranks():
+    """`python bench.py --gpus 2 --backend gloo` with no launcher around it: bench.py starts the two ranks itself (children of a
+    parent that never touched the GPU), they share this box's GPU over gloo, and the line says what ran: n_gpus = comm_ranks = 2."""
+    r = _run_bench(["--gpus", "2", "--backend", "gloo", "--poses", "6000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1
+    j = json.loads(line[0])
+    assert j["n_gpus"] == 2 and j["config"]["comm_ranks"] == 2 and j["config"]["ranks_share_gpus"] is True
+    assert j["config"]["n_poses_total"] == 12000 and j["lm_iterations_per_resolve"] > 0 and j["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_refuses_rccl_with_more_ranks_than_gpus():
+    """Two RCCL ranks on a one-GPU box: a clear non-zero exit, not a hang and not a mislabelled line."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has two GPUs: the refusal cannot be provoked")
+    r = _run_bench(["--gpus", "2", "--poses", "6000", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], timeout=300)
+    assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "need 2 GPUs" in r.stderr

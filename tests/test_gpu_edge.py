@@ -237,3 +237,51 @@ def test_pcg_preconditioner_at_stage_boundaries(n, band):
     pg, sg = _check(g, o, 2, prob.init)
     assert sg.num_offband_pairs > 0 and sg.linear_iterations > sg.iterations
     g.close(); o.close()
+
+
+def _random_corr(prob, pairs, rng):
+    """A correspondence set with prescribed (source, target, match count) triples: random point pairs (the linearisation does not care
+    whether a match is a good one)."""
+    ps = np.array([p[0] for p in pairs], np.int32)
+    pt = np.array([p[1] for p in pairs], np.int32)
+    lens = np.array([p[2] for p in pairs], np.int64)
+    mo = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    i0 = np.concatenate([rng.integers(0, prob.off[a + 1] - prob.off[a], l) for a, l in zip(ps, lens)]).astype(np.int32)
+    i1 = np.concatenate([rng.integers(0, prob.off[b + 1] - prob.off[b], l) for b, l in zip(pt, lens)]).astype(np.int32)
+    return ps, pt, mo, i0, i1
+
+
+@pytest.mark.parametrize("variant", ["0", "300", "400", "106"])
+def test_linearisation_kernels_on_awkward_pair_lists(variant, monkeypatch):
+    """Round 4's linearisation kernels against the oracle on the shapes their pipelines have to get right: pairs of 1, 63, 64, 65,
+    127, 128, 129, 256, 383, 384, 385 and 511 matches (partial trip only / full trips only / both), a pose without pairs in the
+    middle of a run, a pose with more pairs than the tail buffer holds (9 and 14), pairs in both directions of one pose pair, the
+    last pose as a source, and -- one set further down -- a pair of 512 matches, which the stream kernel does not take
+    (the half-wave kernel runs instead).  HITL_STF_VARIANT: 0 = default (the half-wave kernel of rounds 1-3), 300 = stream kernel,
+    400 = persistent workgroups, 106 = one wave per pair and one pose per workgroup."""
+    import hitl_slam_amd as H
+    from oracle import hitl_oracle as O
+    monkeypatch.setenv("HITL_STF_VARIANT", variant)
+    prob = Problem(40, 600, ppf=40, groups=1, kind=4, window=3)
+    rng = np.random.default_rng(7)
+    lens = [1, 63, 64, 65, 127, 128, 129, 256, 383, 384, 385, 511]
+    pairs = []
+    for k, l in enumerate(lens):                      # poses 0 .. 11: one or two pairs each, both directions
+        pairs.append((k, k + 1, l))
+        if k % 3 == 0:
+            pairs.append((k, k + 2, lens[(k + 5) % len(lens)]))
+    pairs += [(14, 13, 200), (14, 15, 300)]           # pose 12, 13 have no pair as a source
+    pairs += [(20, 20 + d, 100 + 17 * d) for d in (-3, -2, -1, 1, 2, 3)] + [(20, 25, 90), (20, 27, 130), (20, 30, 140)]     # 9 pairs
+    pairs += [(22, j, 50 + j) for j in range(23, 37)]                                                                       # 14 pairs
+    pairs += [(39, 38, 333), (39, 37, 12)]            # the last pose
+    pairs.sort(key=lambda p: (p[0], p[1]))
+    corr = _random_corr(prob, pairs, rng)
+    for extra in ([], [(5, 9, 512)]):
+        c = corr if not extra else _random_corr(prob, sorted(pairs + extra, key=lambda p: (p[0], p[1])), rng)
+        g, o = prob.load(H.Solver(), corr=c), prob.load(O.OracleSolver(), corr=c)
+        x = prob.init.astype(np.float64) + 0.003 * rng.standard_normal(prob.init.shape)
+        cg, gg, rg, jg = g.linearize(H.MODE_JOINT, prob.init, x)
+        co, go, ro, jo = o.linearize(H.MODE_JOINT, prob.init, x)
+        assert np.abs(rg - ro).max() <= 1e-11 * np.abs(ro).max() and np.abs(jg - jo).max() <= 1e-9 * np.abs(jo).max()
+        assert abs(cg - co) <= 1e-10 * co and np.abs(gg - go).max() <= 1e-9 * np.abs(go).max()
+        g.close(); o.close()

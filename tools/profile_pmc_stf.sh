@@ -2,6 +2,7 @@
 # Runs on the GPU box: memory-path counters of k_linearize_stf (one counter group per rocprofv3 --pmc pass, no trace domains).
 set -u
 TAG=${1:-r02}
+export HITL_STF_VARIANT=${2:-0}
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 OUT=gpurun_out/pmcstf_${TAG}
