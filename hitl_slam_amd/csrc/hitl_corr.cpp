@@ -82,6 +82,7 @@ int ensure_kd_trees(hitl_solver* s) {      // BuildKDTrees: once per map (JointO
 }
 
 int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
+  RoctxRange r_all("hitl:find_correspondences");
   HIP_TRY(hipSetDevice(s->device));
   s->min_band_poses = 1;      // a new correspondence set: the band a submap rank once widened to belongs to the old one (prepare re-derives it)
   const bool timing = dev_switches().timing;

@@ -13,6 +13,21 @@ namespace hitl {
 
 int fail(int code, const std::string& msg);   // records the message behind hitl_last_error(); returns code
 
+// roctx ranges around the phases of a call (the counterpart of the reference's FunctionTimer scopes, shared/util/timer.h:135-161;
+// SURVEY.md 5.1): with HITL_ROCTX=1 in the environment of hitl_solver_create the library resolves roctxRangePushA / roctxRangePop
+// from librocprofiler-sdk-roctx.so (rocprofv3 --marker-trace shows them) at run time; without it, or without that library, a
+// range is two untaken branches.  Nothing links against the profiler.
+struct RoctxApi { int (*push)(const char*) = nullptr; int (*pop)() = nullptr; };
+const RoctxApi& roctx_api();
+void roctx_resolve(bool enable);            // hitl_solver_create only
+struct RoctxRange {
+  bool on;
+  explicit RoctxRange(const char* name) : on(roctx_api().push != nullptr) { if (on) roctx_api().push(name); }
+  ~RoctxRange() { if (on) roctx_api().pop(); }
+  RoctxRange(const RoctxRange&) = delete;
+  RoctxRange& operator=(const RoctxRange&) = delete;
+};
+
 #define HIP_TRY(expr)                                                                           \
   do {                                                                                          \
     hipError_t e_ = (expr);                                                                     \

@@ -22,6 +22,7 @@ constexpr int kMatchPad = 512;            // readable words behind the last matc
 // nothing on a launch or solve path calls getenv -- and kept per process: the values the last hitl_solver_create saw.
 struct DevSwitches {
   bool timing = false;             // HITL_TIMING: phase times of find_correspondences / prepare on stderr
+                                   // (HITL_ROCTX: roctx ranges around the phases, hitl_host.h)
   bool event_sync = false;         // HITL_EVENT_SYNC: event instead of the pinned-memory flag in the LM loop
   bool cr_legacy = false;          // HITL_CR_LEGACY: level-per-launch cyclic reduction
   bool cr_unfused_build = false;   // HITL_CR_UNFUSED_BUILD: k_build_system as its own launch
@@ -33,6 +34,7 @@ struct DevSwitches {
                                    // cost -- 4-8 us per iteration SLOWER on every workload -- so the host-driven loop stays the default
   int stf_variant = 0;             // HITL_STF_VARIANT: instantiation of k_linearize_stf (1xx: one wave per pair, one pose per workgroup; 2xx: the half-wave kernel
                                    // although the persistent one applies)
+  int stf_waves_per_cu = 0;        // HITL_STF_WAVES_PER_CU: cap on the resident waves per CU of the stream linearisation (0 = what fits)
   int kd_block = 256;              // HITL_KD_BLOCK: workgroup size of k_match_kd_tgt (64 / 128 / 256)
   int lm_ahead = 3;                // HITL_LM_AHEAD: LM iterations the host queues ahead of the device-driven loop
   int kd_cap = 0;                  // HITL_KD_CAP: frame-stack entries per lane of k_match_kd_tgt's first attempt (0 = 5); tests force the full-depth repeat with 1
@@ -150,13 +152,17 @@ void launch_linearize_stf_moments(hipStream_t st, const PairView& pr, const doub
 // CANDIDATE's buffers (lm->cur ^ 1) and returns at once when lm->done
 void launch_linearize_stf(hipStream_t st, const MapView& map, const PairView& pr, int max_scan, int64_t map_obs_count, int64_t n_matches,
                           const double* x, const double2* cs, float corr, float std_dev, double* pairRJ,
-                          const LmDev* lm = nullptr, const double* x_alt = nullptr, double* pairRJ_alt = nullptr);
+                          const LmDev* lm = nullptr, const double* x_alt = nullptr, double* pairRJ_alt = nullptr,
+                          const void* pose_recs = nullptr /* launch_build_stf_pose_recs: one stf_pose_rec_bytes() record per pose, or null */);
+size_t stf_pose_rec_bytes();
+void launch_build_stf_pose_recs(hipStream_t st, const MapView& map, const PairView& pr, void* recs);
 // round 4: the persistent, wave-per-pair form of the same linearisation (k_linearize_stf_p).  It walks a step table (one
 // step = one source pose and up to six of its directed pairs) built once per correspondence set by launch_build_stf_steps:
 // step_off[n_poses + 1] (step_off[n_poses] = number of steps, read by the kernel itself), steps[] of stf_step_bytes() each
 // (at most n_poses + n_pairs / 6 of them).  Applies to scans of <= 2048 points; grid = workgroups (4 per CU).
 size_t stf_step_bytes();
 void launch_build_stf_steps(hipStream_t st, const MapView& map, const PairView& pr, int* step_off, void* steps);
+int stf_steps_grid(int max_scan, int cu_count);
 void launch_linearize_stf_steps(hipStream_t st, int max_scan, int grid, const void* steps, const int* n_steps, const float4* obs,
                                 const uint32_t* matches, const double* x, const double2* cs, float corr, float std_dev, double* pairRJ);
 // round 4: one wave per workgroup, every wave on its own run of pairs, software-pipelined over pairs (k_linearize_stf_s).
@@ -164,8 +170,10 @@ void launch_linearize_stf_steps(hipStream_t st, int max_scan, int grid, const vo
 // the largest match count of a pair: the kernel holds at most stf_stream_max_len() matches of a pair in registers).
 size_t stf_pair_rec_bytes();
 int stf_stream_max_len();
-void launch_build_stf_pair_recs(hipStream_t st, const MapView& map, const PairView& pr, void* recs, int* max_len);
-void launch_linearize_stf_stream(hipStream_t st, int max_scan, int cu_count, const void* recs, const int* pose_pair_off, int n_poses, const int64_t* obs_off,
+int stf_stream_waves(int max_scan, int cu_count);      // waves (= workgroups) of the kernel for this map on this device
+// wave_cnt[n_waves], wave_off[n_waves + 1] (scratch / where each wave's records start), recs[n_pairs]
+void launch_build_stf_pair_recs(hipStream_t st, const MapView& map, const PairView& pr, int n_waves, int* wave_cnt, int* wave_off, void* recs, int* max_len);
+void launch_linearize_stf_stream(hipStream_t st, int max_scan, int n_waves, const void* recs, const int* wave_off, const int64_t* obs_off,
                                  const float4* obs, const uint32_t* matches, const double* x, const double2* cs, float corr, float std_dev, double* pairRJ);
 void launch_pack_obs(hipStream_t st, int64_t n, const float* px, const float* py, const float* nx, const float* ny,
                      float4* obs);

@@ -108,6 +108,25 @@ __device__ __forceinline__ void stf_match(StfAcc& a, double ax, double ay, doubl
   a.S1 += e1 * e1; a.A1x += e1 * mx; a.A1y += e1 * my; a.T10 += e1 * d10;
 }
 
+// The same match with w = R01 p1 + t01 formed directly (two fused multiply-adds per component instead of a product and an add):
+// two instructions fewer.  u = R01 p1 is then never formed, so the sum that needed it changes: instead of T01 = sum e0 (-cross(n0, u))
+// the lane accumulates T00 = sum e0 cross(n0, w), and the pair's tail recovers T01 = cross(A0, t01) - T00 (w = u + t01).
+template <bool WEIGHTED>
+__device__ __forceinline__ void stf_match_w(StfAcc& a, double ax, double ay, double anx, double any, const float4 tv, double cR, double sR,
+                                            double t01x, double t01y, double wgt) {
+  const double bx = tv.x, by = tv.y, bnx = tv.z, bny = tv.w;
+  const double wx = fma(cR, bx, fma(-sR, by, t01x)), wy = fma(sR, bx, fma(cR, by, t01y));   // w = R01 p1 + t01
+  const double mx = cR * bnx - sR * bny, my = sR * bnx + cR * bny;                            // n1' = R01 n1
+  const double qx = wx - ax, qy = wy - ay;                                                    // q = R0^T delta
+  double e0 = anx * qx + any * qy;                                                            // e0 / k
+  double e1 = mx * qx + my * qy;                                                              // e1 / k
+  if (WEIGHTED) { e0 *= wgt; e1 *= wgt; }
+  const double d00 = anx * wy - any * wx;                                                     //  cross(n0, w)
+  const double d10 = mx * ay - my * ax;                                                       //  cross(n1', p0)
+  a.S0 += e0 * e0; a.A0x += e0 * anx; a.A0y += e0 * any; a.T01 += e0 * d00;                   // (the T01 slot holds T00 here)
+  a.S1 += e1 * e1; a.A1x += e1 * mx; a.A1y += e1 * my; a.T10 += e1 * d10;
+}
+
 // SRC: 0 = source scan read from global memory (scans beyond the LDS budget), 1 = staged in LDS as float4 (<= 4096
 // points), 2 = staged in LDS widened to fp64 (<= 2048 points)
 // OFF32: every observation and every index word lies within 4 GB of its array base, so a gather / index fetch is
@@ -127,7 +146,7 @@ __device__ __forceinline__ void stf_source(const double2* s_scan8, const double2
   }
 }
 
-template <int SRC, bool OFF32, int AHEAD, int MINB>
+template <int SRC, bool OFF32, int AHEAD, int MINB, bool WFOLD = false>
 __global__ __launch_bounds__(kStfBlock, MINB) void k_linearize_stf(MapView map, PairView pr, int chunk,
                                                                     const double* __restrict__ x, const double2* __restrict__ cs,
                                                                     double kf, double* __restrict__ pairRJ, StfLm lmsel) {
@@ -212,8 +231,13 @@ __global__ __launch_bounds__(kStfBlock, MINB) void k_linearize_stf(MapView map, 
           stf_source<SRC>(s_scan8, s_scanN, s_scan4, src_g, u1, ax1, ay1, anx1, any1);
           ua[d] = HITL_IDX(2 * kStfSub * (d + AHEAD)); ub[d] = HITL_IDX(2 * kStfSub * (d + AHEAD) + kStfSub);   // trip t + d + AHEAD
           __builtin_amdgcn_sched_barrier(0);      // keep the index prefetch ahead of the arithmetic (the scheduler sinks it otherwise)
-          stf_match<false>(acc, ax0, ay0, anx0, any0, tv0, cR, sR, t01x, t01y, 1.0);
-          stf_match<false>(acc, ax1, ay1, anx1, any1, tv1, cR, sR, t01x, t01y, 1.0);
+          if (WFOLD) {
+            stf_match_w<false>(acc, ax0, ay0, anx0, any0, tv0, cR, sR, t01x, t01y, 1.0);
+            stf_match_w<false>(acc, ax1, ay1, anx1, any1, tv1, cR, sR, t01x, t01y, 1.0);
+          } else {
+            stf_match<false>(acc, ax0, ay0, anx0, any0, tv0, cR, sR, t01x, t01y, 1.0);
+            stf_match<false>(acc, ax1, ay1, anx1, any1, tv1, cR, sR, t01x, t01y, 1.0);
+          }
         }
       }
       if (OFF32) mo += 8u * kStfSub * AHEAD; else mp += 2 * kStfSub * AHEAD;
@@ -227,8 +251,13 @@ __global__ __launch_bounds__(kStfBlock, MINB) void k_linearize_stf(MapView map, 
       const float4 tv0 = HITL_TGT(u0), tv1 = HITL_TGT(u1);
       stf_source<SRC>(s_scan8, s_scanN, s_scan4, src_g, u0, ax0, ay0, anx0, any0);
       stf_source<SRC>(s_scan8, s_scanN, s_scan4, src_g, u1, ax1, ay1, anx1, any1);
-      stf_match<true>(acc, ax0, ay0, anx0, any0, tv0, cR, sR, t01x, t01y, v0 ? 1.0 : 0.0);
-      stf_match<true>(acc, ax1, ay1, anx1, any1, tv1, cR, sR, t01x, t01y, v1 ? 1.0 : 0.0);
+      if (WFOLD) {
+        stf_match_w<true>(acc, ax0, ay0, anx0, any0, tv0, cR, sR, t01x, t01y, v0 ? 1.0 : 0.0);
+        stf_match_w<true>(acc, ax1, ay1, anx1, any1, tv1, cR, sR, t01x, t01y, v1 ? 1.0 : 0.0);
+      } else {
+        stf_match<true>(acc, ax0, ay0, anx0, any0, tv0, cR, sR, t01x, t01y, v0 ? 1.0 : 0.0);
+        stf_match<true>(acc, ax1, ay1, anx1, any1, tv1, cR, sR, t01x, t01y, v1 ? 1.0 : 0.0);
+      }
     }
     // reduce-scatter over the 32 lanes of this pair: after the three exchange steps lane hl holds the 4-lane partial of
     // value (hl >> 2); two more exchanges complete it
@@ -245,9 +274,10 @@ __global__ __launch_bounds__(kStfBlock, MINB) void k_linearize_stf(MapView map, 
     //   sum e0 cross(n0, w) = cross(A0, t01) - T01 (w = u + t01),   sum e1 cross(n1', t01 - p0) = cross(A1, t01) - T10
     if ((hl & 3) == 0) s_tot[sub][hl >> 2] = tot;
     if (hl == 0 && live) {          // same wave: the LDS writes above are complete before these reads (in-order LDS queue)
-      const double S0 = s_tot[sub][0], A0x = s_tot[sub][1], A0y = s_tot[sub][2], T01 = s_tot[sub][3];
+      const double S0 = s_tot[sub][0], A0x = s_tot[sub][1], A0y = s_tot[sub][2], Tq = s_tot[sub][3];
       const double S1 = s_tot[sub][4], A1x = s_tot[sub][5], A1y = s_tot[sub][6], T10 = s_tot[sub][7];
-      const double T00 = (A0x * t01y - A0y * t01x) - T01;
+      const double Tr = (A0x * t01y - A0y * t01x) - Tq;            // WFOLD: the lanes summed T00 (stf_match_w), T01 follows; else the other way round
+      const double T00 = WFOLD ? Tq : Tr, T01 = WFOLD ? Tr : Tq;
       const double T11 = (A1x * t01y - A1y * t01x) - T10;
       const double inv_n = 1.0 / (double)len;
       const double a0 = S0 * inv_n, a1 = S1 * inv_n;
@@ -300,7 +330,7 @@ __device__ __forceinline__ float4 gload_f4(gbytes_t p) {
 // (u & 0xffff) << 4 in one instruction (SDWA word select feeding the shift): the byte offset of source point u.lo16 in an LDS plane
 __device__ __forceinline__ uint32_t lo16_shl4(uint32_t u) {
   uint32_t r;
-  asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(4u), "v"(u));
+  asm("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(u));
   return r;
 }
 typedef double d2raw_t __attribute__((ext_vector_type(2)));
@@ -311,6 +341,293 @@ __device__ __forceinline__ double dpp_f64(double v) {
   const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
   const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
+}
+
+// ===========================================================================================
+// k_linearize_stf_r (round 4, VERDICT r3 lever (a)): the half-wave kernel with a PER-POSE DESCRIPTOR RECORD.
+// A workgroup's life starts with a chain of dependent loads: pose -> (pair range, scan range) -> per pair (target pose, match
+// range) -> (target scan offset, target state, first index words) -> gathers: four rounds of ~1 us under load before the first
+// trip of 50 000 workgroups.  The record (128 B = one cache line per pose, written once per correspondence set by
+// k_stf_pose_recs) holds what the first two rounds fetch -- pair range, scan range and, for the pose's first six pairs, target
+// pose, target scan byte offset, first match and match count -- so the chain is record -> (states, index words, scan) ->
+// gathers.  Pairs beyond the sixth of a pose (wider bands, all-pairs sets) take the old loads.
+// ===========================================================================================
+struct alignas(16) StfPoseSlot { uint32_t tgt_b; uint32_t m_begin; int len; int j; };     // OFF32: both offsets fit 32 bits
+struct alignas(128) StfPoseRec { int p_begin, n_pairs, mi, pad0; int64_t src_off; int64_t pad1; StfPoseSlot s[kStfBlock / kStfSub]; };
+static_assert(sizeof(StfPoseRec) == 128, "one cache line per pose");
+
+__global__ void k_stf_pose_recs(MapView map, PairView pr, StfPoseRec* __restrict__ recs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= map.n_poses) return;
+  StfPoseRec r;
+  const int p0 = pr.pose_pair_off[i], p1 = pr.pose_pair_off[i + 1];
+  const int64_t oi = map.obs_off[i];
+  r.p_begin = p0; r.n_pairs = p1 - p0; r.mi = (int)(map.obs_off[i + 1] - oi); r.pad0 = 0; r.src_off = oi; r.pad1 = 0;
+  for (int w = 0; w < kStfBlock / kStfSub; ++w) {
+    const int p = (p0 + w < p1) ? p0 + w : p0;                      // slots without a pair repeat the first one with length 0
+    StfPoseSlot q;
+    if (p0 < p1) {
+      q.j = pr.pair_tgt[p]; q.tgt_b = (uint32_t)(map.obs_off[q.j] << 4); q.m_begin = (uint32_t)pr.match_off[p];
+      q.len = (p0 + w < p1) ? (int)(pr.match_off[p + 1] - pr.match_off[p]) : 0;
+    } else { q.j = i; q.tgt_b = (uint32_t)(oi << 4); q.m_begin = 0; q.len = 0; }
+    r.s[w] = q;
+  }
+  recs[i] = r;
+}
+void launch_build_stf_pose_recs(hipStream_t st, const MapView& map, const PairView& pr, void* recs) {
+  hipLaunchKernelGGL(k_stf_pose_recs, dim3((map.n_poses + 127) / 128), dim3(128), 0, st, map, pr, reinterpret_cast<StfPoseRec*>(recs));
+}
+size_t stf_pose_rec_bytes() { return sizeof(StfPoseRec); }
+
+template <int MINB>
+__global__ __launch_bounds__(kStfBlock, MINB) void k_linearize_stf_r(MapView map, PairView pr, const StfPoseRec* __restrict__ recs, int chunk,
+                                                                     const double* __restrict__ x, const double2* __restrict__ cs, double kf,
+                                                                     double* __restrict__ pairRJ, StfLm lmsel) {
+  if (lmsel.lm != nullptr) {                    // device-driven LM loop: the candidate's buffers (uniform branch, scalar loads)
+    if (lmsel.lm->done) return;
+    if ((lmsel.lm->cur ^ 1) != 0) { x = lmsel.x_alt; pairRJ = lmsel.pairRJ_alt; }
+  }
+  __shared__ double s_tot[kStfBlock / kStfSub][kStfSums];           // the 8 totals of each half-wave's pair
+  extern __shared__ double s_scan_raw_r[];
+  double2* s_scan8 = reinterpret_cast<double2*>(s_scan_raw_r);        // (px, py) plane, then the (nx, ny) plane
+  const int b = blockIdx.x;
+  const int idx = b >> 3;
+  const int i = (b & 7) * chunk + idx;
+  if (idx >= chunk || i >= map.n_poses) return;
+  const StfPoseRec* __restrict__ rec = recs + i;
+  const int p_begin = rec->p_begin, n_pairs = rec->n_pairs;           // scalar loads: the whole header is one 32-byte read
+  if (n_pairs == 0) return;
+  const int p_end = p_begin + n_pairs;
+  const int mi = rec->mi;
+  const int64_t oi = rec->src_off;
+  double2* s_scanN = s_scan8 + mi;
+  const float4* __restrict__ src_g = map.obs + oi;
+  const int lane = threadIdx.x & 63;
+  const int sub = threadIdx.x / kStfSub;        // pair slot of this half-wave within the workgroup
+  const int hl = threadIdx.x & (kStfSub - 1);   // lane within the half-wave
+  const uint32_t* __restrict__ mt = pr.matches;
+  const char* __restrict__ mtb = reinterpret_cast<const char*>(mt);
+  const char* __restrict__ obs_b = reinterpret_cast<const char*>(map.obs);
+  constexpr int kSlots = kStfBlock / kStfSub;
+  // round 1 of this half-wave's pair: one 16-byte read of the record
+  const StfPoseSlot sl = rec->s[sub];
+  int p = p_begin + sub;
+  bool live = p < p_end;
+  int j = sl.j;
+  uint32_t tgt_b = sl.tgt_b;
+  uint32_t m_begin32 = sl.m_begin;
+  int len = sl.len;
+  for (int k = threadIdx.x; k < mi; k += kStfBlock) {
+    const float4 o = src_g[k];
+    s_scan8[k] = make_double2((double)o.x, (double)o.y);
+    s_scanN[k] = make_double2((double)o.z, (double)o.w);
+  }
+  const double xi = uniform_f64(x[3 * i]), yi = uniform_f64(x[3 * i + 1]);
+  const double2 cs0 = cs[i];
+  const double c0 = uniform_f64(cs0.x), s0 = uniform_f64(cs0.y);
+  bool staged = false;
+  for (int pb = p_begin;;) {                            // workgroup-uniform trip count
+#define HITL_RTGT(u) (*reinterpret_cast<const float4*>(obs_b + (tgt_b + (__builtin_amdgcn_ubfe((u), 16, 16) << 4))))
+    const double xj = x[3 * j], yj = x[3 * j + 1];
+    const double2 cs1 = cs[j];
+    uint32_t mo = (m_begin32 + (uint32_t)hl) << 2;
+#define HITL_RIDX(k) (*reinterpret_cast<const uint32_t*>(mtb + (mo + 4u * (uint32_t)(k))))
+    uint32_t ua = HITL_RIDX(0), ub = HITL_RIDX(kStfSub);
+    if (!staged) { __syncthreads(); staged = true; }    // the source scan is in LDS
+    const double ddx = xj - xi, ddy = yj - yi;
+    const double cR = c0 * cs1.x + s0 * cs1.y, sR = c0 * cs1.y - s0 * cs1.x;   // R01 = R0^T R1
+    const double t01x = c0 * ddx + s0 * ddy, t01y = c0 * ddy - s0 * ddx;       // R0^T (t1 - t0)
+    StfAcc acc = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int nfull = len >> 6, rem = len & 63;
+    double ax0, ay0, anx0, any0, ax1, ay1, anx1, any1;
+    for (int t = 0; t < nfull; ++t) {
+      const uint32_t u0 = ua, u1 = ub;
+      const float4 tv0 = HITL_RTGT(u0), tv1 = HITL_RTGT(u1);
+      stf_source<2>(s_scan8, s_scanN, nullptr, src_g, u0, ax0, ay0, anx0, any0);
+      stf_source<2>(s_scan8, s_scanN, nullptr, src_g, u1, ax1, ay1, anx1, any1);
+      ua = HITL_RIDX(2 * kStfSub); ub = HITL_RIDX(3 * kStfSub);                 // trip t + 1
+      __builtin_amdgcn_sched_barrier(0);      // keep the index prefetch ahead of the arithmetic (the scheduler sinks it otherwise)
+      stf_match_w<false>(acc, ax0, ay0, anx0, any0, tv0, cR, sR, t01x, t01y, 1.0);
+      stf_match_w<false>(acc, ax1, ay1, anx1, any1, tv1, cR, sR, t01x, t01y, 1.0);
+      mo += 8u * kStfSub;
+    }
+    if (rem > 0) {      // the last, partial trip: lanes past the end take index 0 (valid) with weight 0
+      const bool v0 = hl < rem, v1 = hl + kStfSub < rem;
+      const uint32_t u0 = v0 ? ua : 0u, u1 = v1 ? ub : 0u;
+      const float4 tv0 = HITL_RTGT(u0), tv1 = HITL_RTGT(u1);
+      stf_source<2>(s_scan8, s_scanN, nullptr, src_g, u0, ax0, ay0, anx0, any0);
+      stf_source<2>(s_scan8, s_scanN, nullptr, src_g, u1, ax1, ay1, anx1, any1);
+      stf_match_w<true>(acc, ax0, ay0, anx0, any0, tv0, cR, sR, t01x, t01y, v0 ? 1.0 : 0.0);
+      stf_match_w<true>(acc, ax1, ay1, anx1, any1, tv1, cR, sR, t01x, t01y, v1 ? 1.0 : 0.0);
+    }
+    double v[kStfSums] = {acc.S0, acc.A0x, acc.A0y, acc.T01, acc.S1, acc.A1x, acc.A1y, acc.T10};
+    HITL_XSTEP(16, 4)
+    HITL_XSTEP(8, 2)
+    HITL_XSTEP(4, 1)
+    double tot = v[0];
+    tot += swz_xor<2>(tot);
+    tot += swz_xor<1>(tot);
+    if ((hl & 3) == 0) s_tot[sub][hl >> 2] = tot;
+    if (hl == 0 && live) {          // same wave: the LDS writes above are complete before these reads (in-order LDS queue)
+      const double S0 = s_tot[sub][0], A0x = s_tot[sub][1], A0y = s_tot[sub][2], T00 = s_tot[sub][3];
+      const double S1 = s_tot[sub][4], A1x = s_tot[sub][5], A1y = s_tot[sub][6], T10 = s_tot[sub][7];
+      const double T01 = (A0x * t01y - A0y * t01x) - T00;          // the lanes summed T00 (stf_match_w)
+      const double T11 = (A1x * t01y - A1y * t01x) - T10;
+      const double inv_n = 1.0 / (double)len;
+      const double a0 = S0 * inv_n, a1 = S1 * inv_n;
+      const double i0 = (S0 != 0.0) ? rsqrt(a0) : 0.0, i1 = (S1 != 0.0) ? rsqrt(a1) : 0.0;
+      const double f0 = kf * inv_n * i0, f1 = kf * inv_n * i1;
+      const double g0x = c0 * A0x - s0 * A0y, g0y = s0 * A0x + c0 * A0y;   // R0 * sum e0' n0
+      const double g1x = c0 * A1x - s0 * A1y, g1y = s0 * A1x + c0 * A1y;   // R0 * sum e1' n1'
+      double* o = pairRJ + (size_t)kPairRJ * p;
+      o[0] = kf * a0 * i0; o[1] = kf * a1 * i1;
+      o[2] = -f0 * g0x; o[3] = -f0 * g0y; o[4] = f0 * T00; o[5] = f0 * g0x; o[6] = f0 * g0y; o[7] = f0 * T01;
+      o[8] = -f1 * g1x; o[9] = -f1 * g1y; o[10] = f1 * T10; o[11] = f1 * g1x; o[12] = f1 * g1y; o[13] = f1 * T11;
+    }
+#undef HITL_RTGT
+#undef HITL_RIDX
+    pb += kSlots;
+    if (pb >= p_end) break;
+    // pairs beyond the record's six: the old dependent loads (wider bands, all-pairs sets)
+    p = pb + sub; live = p < p_end;
+    const int pc = live ? p : p_begin;
+    j = pr.pair_tgt[pc];
+    tgt_b = (uint32_t)map.obs_off[j] << 4;
+    const int64_t mb64 = pr.match_off[pc];
+    m_begin32 = (uint32_t)mb64;
+    len = live ? (int)(pr.match_off[pc + 1] - mb64) : 0;
+  }
+}
+
+// ===========================================================================================
+// k_linearize_stf_h (round 4): the half-wave kernel of rounds 1-3 (k_linearize_stf<2, true, 1, 7>, still the fastest structure
+// measured: profiles/r04_stf_levers.md) with ten of a trip's 78 vector instructions removed:
+//   * the dynamic LDS segment starts at LDS address 0 and the plane stride is a template constant, so a source point's two
+//     reads are `ds_read_b128 v, off` and `ds_read_b128 v, off offset:16*CAP` with off = (u & 0xffff) << 4 from ONE
+//     SDWA shift -- no base additions, no mask (-6 per trip);
+//   * w = R01 p1 + t01 by fused multiply-adds (stf_match_w: -4 per trip); the lane sums T00 instead of T01.
+// Same decomposition otherwise: one workgroup (192 threads) per source pose, one 32-lane half-wave per directed pair, index
+// words one trip ahead, blockIdx -> pose keeps consecutive poses on one XCD.
+// ===========================================================================================
+template <int CAP, int MINB, int FLAGS>
+__global__ __launch_bounds__(kStfBlock, MINB) void k_linearize_stf_h(MapView map, PairView pr, int chunk, const double* __restrict__ x,
+                                                                     const double2* __restrict__ cs, double kf, double* __restrict__ pairRJ, StfLm lmsel) {
+  if (lmsel.lm != nullptr) {                    // device-driven LM loop: the candidate's buffers (uniform branch, scalar loads)
+    if (lmsel.lm->done) return;
+    if ((lmsel.lm->cur ^ 1) != 0) { x = lmsel.x_alt; pairRJ = lmsel.pairRJ_alt; }
+  }
+  extern __shared__ double s_raw_h[];
+  if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) double*)s_raw_h != 0u) __builtin_trap();   // the trips address the planes from LDS address 0
+  double2* s_pts = reinterpret_cast<double2*>(s_raw_h);                       // [CAP] (px, py), then [CAP] (nx, ny)
+  double (*s_tot)[kStfSums] = reinterpret_cast<double (*)[kStfSums]>(s_raw_h + 4 * CAP);   // the 8 totals of each half-wave's pair
+  const int b = blockIdx.x;
+  const int idx = b >> 3;
+  const int i = (b & 7) * chunk + idx;
+  if (idx >= chunk || i >= map.n_poses) return;
+  const int p_begin = pr.pose_pair_off[i], p_end = pr.pose_pair_off[i + 1];
+  if (p_begin == p_end) return;
+  const int64_t oi = map.obs_off[i];
+  const int mi = (int)(map.obs_off[i + 1] - oi);
+  const float4* __restrict__ src_g = map.obs + oi;
+  const int lane = threadIdx.x & 63;
+  const int sub = threadIdx.x / kStfSub;        // pair slot of this half-wave within the workgroup
+  const int hl = threadIdx.x & (kStfSub - 1);   // lane within the half-wave
+  const char* __restrict__ mtb = reinterpret_cast<const char*>(pr.matches);
+  const char* __restrict__ obs_b = reinterpret_cast<const char*>(map.obs);
+  constexpr int kSlots = kStfBlock / kStfSub;
+  int p = p_begin + sub;
+  bool live = p < p_end;
+  int pc = live ? p : p_begin;
+  int j = pr.pair_tgt[pc];
+  int64_t m_begin = pr.match_off[pc];
+  int64_t m_end = pr.match_off[pc + 1];
+  for (int k = threadIdx.x; k < mi; k += kStfBlock) {
+    const float4 o = src_g[k];
+    s_pts[k] = make_double2((double)o.x, (double)o.y);
+    s_pts[k + CAP] = make_double2((double)o.z, (double)o.w);
+  }
+  const double xi = uniform_f64(x[3 * i]), yi = uniform_f64(x[3 * i + 1]);
+  const double2 cs0 = cs[i];
+  const double c0 = uniform_f64(cs0.x), s0 = uniform_f64(cs0.y);
+  bool staged = false;
+  for (int pb = p_begin;;) {                            // workgroup-uniform trip count
+    const int64_t oj = map.obs_off[j];
+    const uint32_t tgt_b = (uint32_t)oj << 4;                                   // byte offset of the target scan
+#define HITL_HTGT(u) (*reinterpret_cast<const float4*>(obs_b + (tgt_b + (__builtin_amdgcn_ubfe((u), 16, 16) << 4))))
+    const double xj = x[3 * j], yj = x[3 * j + 1];
+    const double2 cs1 = cs[j];
+    const int len = live ? (int)(m_end - m_begin) : 0;                          // a pair holds < 65536 matches
+    uint32_t mo = ((uint32_t)m_begin + (uint32_t)hl) << 2;
+#define HITL_HIDX(k) (*reinterpret_cast<const uint32_t*>(mtb + (mo + 4u * (uint32_t)(k))))
+    uint32_t ua = HITL_HIDX(0), ub = HITL_HIDX(kStfSub);
+    if (!staged) { __syncthreads(); staged = true; }    // the source scan is in LDS
+    const double ddx = xj - xi, ddy = yj - yi;
+    const double cR = c0 * cs1.x + s0 * cs1.y, sR = c0 * cs1.y - s0 * cs1.x;   // R01 = R0^T R1
+    const double t01x = c0 * ddx + s0 * ddy, t01y = c0 * ddy - s0 * ddx;       // R0^T (t1 - t0)
+    StfAcc acc = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int nfull = len >> 6, rem = len & 63;
+    for (int t = 0; t < nfull; ++t) {
+      const uint32_t u0 = ua, u1 = ub;
+      const float4 tv0 = HITL_HTGT(u0), tv1 = HITL_HTGT(u1);
+      const lds_d2_t l0 = (lds_d2_t)(uintptr_t)((FLAGS & 2) ? ((u0 & 0xffffu) << 4) : lo16_shl4(u0)), l1 = (lds_d2_t)(uintptr_t)((FLAGS & 2) ? ((u1 & 0xffffu) << 4) : lo16_shl4(u1));
+      const d2raw_t a0 = l0[0], n0 = l0[CAP], a1 = l1[0], n1 = l1[CAP];
+      ua = HITL_HIDX(2 * kStfSub); ub = HITL_HIDX(3 * kStfSub);                 // trip t + 1
+      __builtin_amdgcn_sched_barrier(0);      // keep the index prefetch ahead of the arithmetic (the scheduler sinks it otherwise)
+      if (FLAGS & 1) {
+        stf_match<false>(acc, a0.x, a0.y, n0.x, n0.y, tv0, cR, sR, t01x, t01y, 1.0);
+        stf_match<false>(acc, a1.x, a1.y, n1.x, n1.y, tv1, cR, sR, t01x, t01y, 1.0);
+      } else {
+        stf_match_w<false>(acc, a0.x, a0.y, n0.x, n0.y, tv0, cR, sR, t01x, t01y, 1.0);
+        stf_match_w<false>(acc, a1.x, a1.y, n1.x, n1.y, tv1, cR, sR, t01x, t01y, 1.0);
+      }
+      mo += 8u * kStfSub;
+    }
+    if (rem > 0) {      // the last, partial trip: lanes past the end take index 0 (valid) with weight 0
+      const bool v0 = hl < rem, v1 = hl + kStfSub < rem;
+      const uint32_t u0 = v0 ? ua : 0u, u1 = v1 ? ub : 0u;
+      const float4 tv0 = HITL_HTGT(u0), tv1 = HITL_HTGT(u1);
+      const lds_d2_t l0 = (lds_d2_t)(uintptr_t)((FLAGS & 2) ? ((u0 & 0xffffu) << 4) : lo16_shl4(u0)), l1 = (lds_d2_t)(uintptr_t)((FLAGS & 2) ? ((u1 & 0xffffu) << 4) : lo16_shl4(u1));
+      const d2raw_t a0 = l0[0], n0 = l0[CAP], a1 = l1[0], n1 = l1[CAP];
+      if (FLAGS & 1) {
+        stf_match<true>(acc, a0.x, a0.y, n0.x, n0.y, tv0, cR, sR, t01x, t01y, v0 ? 1.0 : 0.0);
+        stf_match<true>(acc, a1.x, a1.y, n1.x, n1.y, tv1, cR, sR, t01x, t01y, v1 ? 1.0 : 0.0);
+      } else {
+        stf_match_w<true>(acc, a0.x, a0.y, n0.x, n0.y, tv0, cR, sR, t01x, t01y, v0 ? 1.0 : 0.0);
+        stf_match_w<true>(acc, a1.x, a1.y, n1.x, n1.y, tv1, cR, sR, t01x, t01y, v1 ? 1.0 : 0.0);
+      }
+    }
+    double v[kStfSums] = {acc.S0, acc.A0x, acc.A0y, acc.T01, acc.S1, acc.A1x, acc.A1y, acc.T10};
+    HITL_XSTEP(16, 4)
+    HITL_XSTEP(8, 2)
+    HITL_XSTEP(4, 1)
+    double tot = v[0];
+    tot += swz_xor<2>(tot);
+    tot += swz_xor<1>(tot);
+    if ((hl & 3) == 0) s_tot[sub][hl >> 2] = tot;
+    if (hl == 0 && live) {          // same wave: the LDS writes above are complete before these reads (in-order LDS queue)
+      const double S0 = s_tot[sub][0], A0x = s_tot[sub][1], A0y = s_tot[sub][2], Tq = s_tot[sub][3];
+      const double S1 = s_tot[sub][4], A1x = s_tot[sub][5], A1y = s_tot[sub][6], T10 = s_tot[sub][7];
+      const double Tr = (A0x * t01y - A0y * t01x) - Tq;            // sum e0 (-cross(n0, u)),  u = w - t01 (or the other way round)
+      const double T00 = (FLAGS & 1) ? Tr : Tq, T01 = (FLAGS & 1) ? Tq : Tr;
+      const double T11 = (A1x * t01y - A1y * t01x) - T10;
+      const double inv_n = 1.0 / (double)len;
+      const double a0 = S0 * inv_n, a1 = S1 * inv_n;
+      const double i0 = (S0 != 0.0) ? rsqrt(a0) : 0.0, i1 = (S1 != 0.0) ? rsqrt(a1) : 0.0;
+      const double f0 = kf * inv_n * i0, f1 = kf * inv_n * i1;
+      const double g0x = c0 * A0x - s0 * A0y, g0y = s0 * A0x + c0 * A0y;   // R0 * sum e0' n0
+      const double g1x = c0 * A1x - s0 * A1y, g1y = s0 * A1x + c0 * A1y;   // R0 * sum e1' n1'
+      double* o = pairRJ + (size_t)kPairRJ * p;
+      o[0] = kf * a0 * i0; o[1] = kf * a1 * i1;
+      o[2] = -f0 * g0x; o[3] = -f0 * g0y; o[4] = f0 * T00; o[5] = f0 * g0x; o[6] = f0 * g0y; o[7] = f0 * T01;
+      o[8] = -f1 * g1x; o[9] = -f1 * g1y; o[10] = f1 * T10; o[11] = f1 * g1x; o[12] = f1 * g1y; o[13] = f1 * T11;
+    }
+#undef HITL_HTGT
+#undef HITL_HIDX
+    pb += kSlots;
+    if (pb >= p_end) break;
+    p = pb + sub; live = p < p_end; pc = live ? p : p_begin;
+    j = pr.pair_tgt[pc]; m_begin = pr.match_off[pc]; m_end = pr.match_off[pc + 1];
+  }
 }
 
 // CAP: points per LDS plane (compile-time: the normals are read at a constant offset from the points' address)
@@ -565,15 +882,18 @@ __global__ __launch_bounds__(kStfWBlock, 6) void k_linearize_stf_p(const StfStep
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   double* sc = reinterpret_cast<double*>(reinterpret_cast<char*>(s_raw_p) + kScratch) + wave * 256;
   const int S = *n_steps_p;
-  const uint32_t per = (uint32_t)S / gridDim.x, extra = (uint32_t)S - per * gridDim.x;      // runs of per or per + 1 steps
-  const int s0 = (int)(blockIdx.x * per + min(blockIdx.x, extra)), s1 = s0 + (int)per + (blockIdx.x < extra ? 1 : 0);
-  if (s0 >= s1) return;
+  // XCD-interleaved steps (see k_stf_stream_count: contiguous runs per workgroup put 4x the L2 in front of an XCD, 46 % hits):
+  // XCD k = blockIdx % 8 owns an eighth of the steps, its workgroups take them round-robin, sd steps apart
+  const int sd = (int)(gridDim.x >> 3);
+  const int chunk8 = (S + 7) / 8;
+  const int s0 = (int)(blockIdx.x & 7) * chunk8 + (int)(blockIdx.x >> 3), s1 = min(((int)(blockIdx.x & 7) + 1) * chunk8, S);
+  if (sd < 1 || s0 >= s1) return;
   const int lane4 = lane << 2;
 
   // ---- first step of the run: records, scan, constants, all behind one another (once per workgroup) ----
   i8v H = sload8(&steps[s0].h), P = sload8(&steps[s0].s[wave]);
   i8v H1 = H, P1 = P;
-  if (s0 + 1 < s1) { H1 = sload8(&steps[s0 + 1].h); P1 = sload8(&steps[s0 + 1].s[wave]); }
+  if (s0 + sd < s1) { H1 = sload8(&steps[s0 + sd].h); P1 = sload8(&steps[s0 + sd].s[wave]); }
   {
     const int mi = H[2];
     const float4* src = obs + i64_of(H[4], H[5]);
@@ -604,10 +924,10 @@ __global__ __launch_bounds__(kStfWBlock, 6) void k_linearize_stf_p(const StfStep
   }
   lds_only_barrier();
 
-  for (int s = s0; s < s1; ++s) {
-    const bool has_next = s + 1 < s1;                       // uniform
+  for (int s = s0; s < s1; s += sd) {
+    const bool has_next = s + sd < s1;                      // uniform
     const bool live = wave < H[1];
-    const bool next_first = has_next && H1[3] != 0;
+    const bool next_first = has_next;                       // the next step is another pose (or another round of one sd steps away: staged again)
     const int mi1 = H1[2];
     // ---- the next pose's scan: LDS-DMA into the staging area, this wave's 64-point pieces.  Issued BEHIND the first trip's
     //      gathers: the compiler does not know about it, and its wait for the index words in front of those gathers would
@@ -695,7 +1015,7 @@ __global__ __launch_bounds__(kStfWBlock, 6) void k_linearize_stf_p(const StfStep
     if (has_next) {
       const int i1 = H1[0], j1 = P1[5];
       xi4 = sload4(x + 3 * (size_t)i1); ci4 = sload4(cs + i1); xj4 = sload4(x + 3 * (size_t)j1); cj4 = sload4(cs + j1);
-      if (s + 2 < s1) { H2 = sload8(&steps[s + 2].h); P2 = sload8(&steps[s + 2].s[wave]); }
+      if (s + 2 * sd < s1) { H2 = sload8(&steps[s + 2 * sd].h); P2 = sload8(&steps[s + 2 * sd].s[wave]); }
       tgt1 = uniform_gptr(obs + i64_of(P1[0], P1[1]));
       mb1 = uniform_gptr(matches + i64_of(P1[2], P1[3]));
       ua1 = *(const uint32_t __attribute__((address_space(1)))*)(mb1 + lane4);
@@ -755,6 +1075,21 @@ __global__ __launch_bounds__(kStfWBlock, 6) void k_linearize_stf_p(const StfStep
 
 size_t stf_p_lds_bytes(int cap) { return (size_t)48 * cap + (size_t)kStfWWaves * 2048 + (size_t)kStfRing * kStfRingStride * 8; }
 
+// workgroups of the persistent kernel: what is resident at once, as the runtime counts it (at most 4 per CU by registers)
+int stf_steps_grid(int cap, int cu_count) {
+  int per_cu = 0;
+  hipError_t e;
+  if (cap <= 416) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_linearize_stf_p<416>, kStfWBlock, stf_p_lds_bytes(416));
+  else if (cap <= 512) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_linearize_stf_p<512>, kStfWBlock, stf_p_lds_bytes(512));
+  else if (cap <= 1024) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_linearize_stf_p<1024>, kStfWBlock, stf_p_lds_bytes(1024));
+  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_linearize_stf_p<2048>, kStfWBlock, stf_p_lds_bytes(2048));
+  if (e != hipSuccess || per_cu < 1) per_cu = 1;
+  per_cu = std::min(per_cu, 4);
+  if (per_cu > 1) --per_cu;            // the runtime's answer is one high for this LDS size (measured: a fourth workgroup per CU waits for a slot)
+  if (dev_switches().stf_waves_per_cu > 0) per_cu = std::min(4, dev_switches().stf_waves_per_cu);     // HITL_STF_WAVES_PER_CU: workgroups per CU here
+  return std::max(8, (per_cu * cu_count) & ~7);
+}
+
 void launch_linearize_stf_steps(hipStream_t st, int cap, int grid, const void* steps, const int* n_steps, const float4* obs, const uint32_t* matches,
                                 const double* x, const double2* cs, float corr, float std_dev, double* pairRJ) {
   const double kf = (double)corr / (double)std_dev;
@@ -788,16 +1123,60 @@ void launch_linearize_stf_steps(hipStream_t st, int cap, int grid, const void* s
 struct alignas(32) StfPairRec { int64_t tgt_off, m_begin; int len, j, i, pad; };
 constexpr int kStfSFull = 3;          // full trips of a pair held in registers
 constexpr int kStfSMaxLen = 128 * kStfSFull + 127;
-constexpr int kStfSSlots = 8;         // pairs whose totals wait for their tail
+constexpr int kStfSSlots = 6;         // pairs whose totals wait for their tail (a pose of the 3-pose band has 6)
 constexpr int kStfSSlotD = 12;        // doubles per slot: 8 totals, t01x, t01y, n, pair index
 
-__global__ void k_stf_pair_recs(MapView map, PairView pr, StfPairRec* __restrict__ recs) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= pr.n_pairs) return;
-  StfPairRec r;
-  r.j = pr.pair_tgt[p]; r.i = pr.pair_src[p];
-  r.tgt_off = map.obs_off[r.j]; r.m_begin = pr.match_off[p]; r.len = (int)(pr.match_off[p + 1] - pr.match_off[p]); r.pad = 0;
-  recs[p] = r;
+// Which poses a wave works on decides what the L2 of its XCD has to hold.  Contiguous runs per wave (first version of this
+// kernel) put 384 waves x 7 scans = 17 MB of target scans in front of a 4 MB L2: 18 % hit rate, 3.2x the HBM reads, 438 us.
+// Here XCD k (waves b with b % 8 == k, as the hardware hands workgroups round-robin to the XCDs) owns a contiguous eighth of
+// the poses and its waves take them INTERLEAVED: wave w of the XCD works on poses base + w, base + w + W, base + w + 2 W ...
+// (W waves per XCD), so that at any moment the waves of an XCD sit inside a window of a few hundred consecutive poses that
+// slides through the XCD's range -- the scans i +- 3 a pose gathers from were read moments ago by its neighbours.
+// The records of a wave's pairs are laid out in the order the wave visits them: the kernel walks recs[wave_off[b] .. wave_off[b + 1]).
+__device__ __forceinline__ void stf_wave_poses(int g, int n_waves, int n_poses, int& first, int& last, int& stride) {
+  const int xcd = g & 7, w = g >> 3, W = n_waves >> 3;                 // n_waves is a multiple of 8
+  const int chunk = (n_poses + 7) / 8;
+  first = xcd * chunk + w; last = min((xcd + 1) * chunk, n_poses); stride = W;
+}
+__global__ void k_stf_stream_count(int n_waves, int n_poses, const int* __restrict__ pose_pair_off, int* __restrict__ cnt) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_waves) return;
+  int first, last, stride, c = 0;
+  stf_wave_poses(g, n_waves, n_poses, first, last, stride);
+  for (int i = first; i < last; i += stride) c += pose_pair_off[i + 1] - pose_pair_off[i];
+  cnt[g] = c;
+}
+__global__ __launch_bounds__(1024) void k_excl_scan_small(int n, const int* __restrict__ in, int* __restrict__ out) {   // out[0..n], one workgroup
+  __shared__ int sums[1024];
+  const int t = threadIdx.x, per = (n + 1023) / 1024;
+  const int a = min(n, t * per), b = min(n, a + per);
+  int c = 0;
+  for (int i = a; i < b; ++i) c += in[i];
+  sums[t] = c;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const int v = (t >= d) ? sums[t - d] : 0;
+    __syncthreads();
+    sums[t] += v;
+    __syncthreads();
+  }
+  int run = sums[t] - c;
+  for (int i = a; i < b; ++i) { const int v = in[i]; out[i] = run; run += v; }
+  if (t == 1023) out[n] = sums[1023];
+}
+__global__ void k_stf_stream_fill(int n_waves, MapView map, PairView pr, const int* __restrict__ wave_off, StfPairRec* __restrict__ recs) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_waves) return;
+  int first, last, stride;
+  stf_wave_poses(g, n_waves, map.n_poses, first, last, stride);
+  StfPairRec* out = recs + wave_off[g];
+  for (int i = first; i < last; i += stride)
+    for (int p = pr.pose_pair_off[i]; p < pr.pose_pair_off[i + 1]; ++p) {
+      StfPairRec r;
+      r.j = pr.pair_tgt[p]; r.i = i;
+      r.tgt_off = map.obs_off[r.j]; r.m_begin = pr.match_off[p]; r.len = (int)(pr.match_off[p + 1] - pr.match_off[p]); r.pad = p;
+      *out++ = r;
+    }
 }
 // largest number of matches of a pair (the stream kernel holds <= kStfSMaxLen per pair in registers)
 __global__ void k_stf_max_len(PairView pr, int* __restrict__ out) {
@@ -806,9 +1185,11 @@ __global__ void k_stf_max_len(PairView pr, int* __restrict__ out) {
   for (int m = 32; m >= 1; m >>= 1) v = max(v, __shfl_xor(v, m, WAVE));
   if ((threadIdx.x & 63) == 0 && v > 0) atomicMax(out, v);
 }
-void launch_build_stf_pair_recs(hipStream_t st, const MapView& map, const PairView& pr, void* recs, int* max_len) {
+void launch_build_stf_pair_recs(hipStream_t st, const MapView& map, const PairView& pr, int n_waves, int* wave_cnt, int* wave_off, void* recs, int* max_len) {
   if (pr.n_pairs == 0) return;
-  hipLaunchKernelGGL(k_stf_pair_recs, dim3((pr.n_pairs + 255) / 256), dim3(256), 0, st, map, pr, reinterpret_cast<StfPairRec*>(recs));
+  hipLaunchKernelGGL(k_stf_stream_count, dim3((n_waves + 255) / 256), dim3(256), 0, st, n_waves, map.n_poses, pr.pose_pair_off, wave_cnt);
+  hipLaunchKernelGGL(k_excl_scan_small, dim3(1), dim3(1024), 0, st, n_waves, wave_cnt, wave_off);
+  hipLaunchKernelGGL(k_stf_stream_fill, dim3((n_waves + 63) / 64), dim3(64), 0, st, n_waves, map, pr, wave_off, reinterpret_cast<StfPairRec*>(recs));
   (void)hipMemsetAsync(max_len, 0, sizeof(int), st);
   hipLaunchKernelGGL(k_stf_max_len, dim3((pr.n_pairs + 255) / 256), dim3(256), 0, st, pr, max_len);
 }
@@ -818,7 +1199,7 @@ int stf_stream_max_len() { return kStfSMaxLen; }
 // (u & 0xffff) << 5: byte offset of source point u.lo16 in the interleaved fp64 scan (32 B per point)
 __device__ __forceinline__ uint32_t lo16_shl5(uint32_t u) {
   uint32_t r;
-  asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(5u), "v"(u));
+  asm("v_lshlrev_b32_sdwa %0, 5, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(u));
   return r;
 }
 __device__ __forceinline__ void swap32_f64(double& a, double& b) {   // a <- [a.lo32 | b.lo32], b <- [a.hi32 | b.hi32] (halves of the wave)
@@ -847,9 +1228,9 @@ __device__ __forceinline__ double stf_reduce8(const StfAcc& a, int lane) {
   return tot;
 }
 
-struct StfSet { uint32_t u[2 * kStfSFull]; uint32_t ru[2]; float4 g[2 * kStfSFull]; };
+struct StfSet { uint32_t u[2 * kStfSFull]; uint32_t ru[2]; float4 g[2 * kStfSFull]; float4 rg[2]; };
 
-__global__ __launch_bounds__(64, 3) void k_linearize_stf_s(const StfPairRec* __restrict__ recs, const int* __restrict__ pose_pair_off, int n_poses,
+__global__ __launch_bounds__(64, 3) void k_linearize_stf_s(const StfPairRec* __restrict__ recs, const int* __restrict__ wave_off,
                                                            const int64_t* __restrict__ obs_off, const float4* __restrict__ obs,
                                                            const uint32_t* __restrict__ matches, const double* __restrict__ x,
                                                            const double2* __restrict__ cs, double kf, double* __restrict__ pairRJ, int tot_off) {
@@ -859,10 +1240,7 @@ __global__ __launch_bounds__(64, 3) void k_linearize_stf_s(const StfPairRec* __r
   double* s_tot = s_raw_s + tot_off;                                 // [kStfSSlots][kStfSSlotD]
   const int lane = threadIdx.x;
   const int lane4 = lane << 2;
-  const uint32_t per = (uint32_t)n_poses / gridDim.x, extra = (uint32_t)n_poses - per * gridDim.x;
-  const int i0 = (int)(blockIdx.x * per + min(blockIdx.x, extra)), i1 = i0 + (int)per + (blockIdx.x < extra ? 1 : 0);
-  if (i0 >= i1) return;
-  const int P0 = pose_pair_off[i0], P1 = pose_pair_off[i1];
+  const int P0 = wave_off[blockIdx.x], P1 = wave_off[blockIdx.x + 1];      // this wave's records, in the order it visits its pairs
   if (P0 >= P1) return;
 
 #define HITL_SREC(q) sload8(recs + (q))
@@ -883,8 +1261,10 @@ __global__ __launch_bounds__(64, 3) void k_linearize_stf_s(const StfPairRec* __r
   }
 #define HITL_SGATHER(SET, R)                                                                                           \
   {                                                                                                                     \
-    const int F_ = (R)[4] >> 7;                                                                                         \
+    const int F_ = (R)[4] >> 7, r_ = (R)[4] & 127;                                                                      \
     const gbytes_t tb_ = uniform_gptr(obs + i64_of((R)[0], (R)[1]));                                                    \
+    SET.ru[0] = (lane < r_) ? SET.ru[0] : 0u; SET.ru[1] = (lane + 64 < r_) ? SET.ru[1] : 0u;   /* lanes past the partial trip: point 0, weight 0 */ \
+    SET.rg[0] = HITL_STGT(tb_, SET.ru[0]); SET.rg[1] = HITL_STGT(tb_, SET.ru[1]);                                       \
     _Pragma("unroll") for (int k_ = 0; k_ < kStfSFull; ++k_) {      /* trips the pair does not have gather point 0 (one line, broadcast) */ \
       const uint32_t ua_ = (k_ < F_) ? SET.u[2 * k_] : 0u, ub_ = (k_ < F_) ? SET.u[2 * k_ + 1] : 0u;                    \
       SET.g[2 * k_] = HITL_STGT(tb_, ua_); SET.g[2 * k_ + 1] = HITL_STGT(tb_, ub_);                                     \
@@ -924,45 +1304,55 @@ __global__ __launch_bounds__(64, 3) void k_linearize_stf_s(const StfPairRec* __r
   }
   int pend = 0;                           // pairs of the current pose whose totals wait in LDS
 
+  // source points of full trip K (index words X.u[2K], X.u[2K+1]) into staging set S; a trip the pair does not have reads point 0
+#define HITL_SLDS(S, X, K)                                                                                               \
+  {                                                                                                                     \
+    const uint32_t wa_ = ((K) < F) ? X.u[2 * (K)] : 0u, wb_ = ((K) < F) ? X.u[2 * (K) + 1] : 0u;                        \
+    const lds_d2_t l0_ = (lds_d2_t)(uintptr_t)lo16_shl5(wa_), l1_ = (lds_d2_t)(uintptr_t)lo16_shl5(wb_);                \
+    S##a0 = l0_[0]; S##n0 = l0_[1]; S##a1 = l1_[0]; S##n1 = l1_[1];                                                     \
+  }
   // one pair: X = its set (index words + gathers in registers), Y = the set that takes the next pair's gathers
 #define HITL_SITER(X, Y)                                                                                               \
   {                                                                                                                     \
     const bool has1 = q + 1 < P1;                                                                                       \
     const int len = R0[4], F = len >> 7, r = len & 127;                                                                 \
-    /* every request below is unconditional (pairs past the end of the run repeat its last pair): no load sits under a branch */ \
-    R3 = HITL_SREC(min(q + 3, P1 - 1));                                                                                 \
-    const i4v xi4 = sload4(x + 3 * (size_t)R1[6]), ci4 = sload4(cs + R1[6]), xj4 = sload4(x + 3 * (size_t)R1[5]), cj4 = sload4(cs + R1[5]); \
-    const gbytes_t tb = uniform_gptr(obs + i64_of(R0[0], R0[1]));                                                       \
-    const bool v0 = lane < r, v1 = lane + 64 < r;                                                                       \
-    const uint32_t ur0 = v0 ? X.ru[0] : 0u, ur1 = v1 ? X.ru[1] : 0u;                                                    \
-    const float4 rg0 = HITL_STGT(tb, ur0), rg1 = HITL_STGT(tb, ur1);     /* the partial trip: requested first, used last */ \
+    /* every request is unconditional (pairs past the end of the run repeat its last pair): no load sits under a branch */ \
     _Pragma("unroll") for (int k_ = 0; k_ < 2 * kStfSFull; ++k_) Y.u[k_] = C.u[k_];                                     \
     Y.ru[0] = C.ru[0]; Y.ru[1] = C.ru[1];                                                                               \
-    HITL_SGATHER(Y, R1)                                                                                                 \
+    HITL_SGATHER(Y, R1)                  /* pair q + 1: all of its gathers, used one iteration from now */                \
     HITL_SLOAD_IDX(C, R2)                /* index words of pair q + 2: a whole pair's arithmetic to arrive */             \
+    const bool v0 = lane < r, v1 = lane + 64 < r;                                                                       \
     StfAcc acc = {0, 0, 0, 0, 0, 0, 0, 0};                                                                              \
-    _Pragma("unroll") for (int k_ = 0; k_ < kStfSFull; ++k_)                                                            \
-      if (k_ < F) {                                                                                                     \
-        const lds_d2_t l0 = (lds_d2_t)(uintptr_t)lo16_shl5(X.u[2 * k_]), l1 = (lds_d2_t)(uintptr_t)lo16_shl5(X.u[2 * k_ + 1]); \
-        const d2raw_t a0 = l0[0], n0 = l0[1], a1 = l1[0], n1 = l1[1];                                                   \
-        stf_match<false>(acc, a0.x, a0.y, n0.x, n0.y, X.g[2 * k_], cR, sR, t01x, t01y, 1.0);                            \
-        stf_match<false>(acc, a1.x, a1.y, n1.x, n1.y, X.g[2 * k_ + 1], cR, sR, t01x, t01y, 1.0);                        \
-      }                                                                                                                 \
-    if (r > 0) {                                                                                                        \
-      const lds_d2_t l0 = (lds_d2_t)(uintptr_t)lo16_shl5(ur0);                                                          \
-      const d2raw_t a0 = l0[0], n0 = l0[1];                                                                             \
-      stf_match<true>(acc, a0.x, a0.y, n0.x, n0.y, rg0, cR, sR, t01x, t01y, v0 ? 1.0 : 0.0);                            \
-      if (r > 64) {                                                                                                     \
-        const lds_d2_t l1 = (lds_d2_t)(uintptr_t)lo16_shl5(ur1);                                                        \
-        const d2raw_t a1 = l1[0], n1 = l1[1];                                                                           \
-        stf_match<true>(acc, a1.x, a1.y, n1.x, n1.y, rg1, cR, sR, t01x, t01y, v1 ? 1.0 : 0.0);                          \
-      }                                                                                                                 \
+    /* source points out of LDS one trip ahead of the arithmetic that uses them (two staging sets, P and Q, that alternate) */ \
+    d2raw_t Pa0, Pn0, Pa1, Pn1, Qa0, Qn0, Qa1, Qn1;                                                                     \
+    { const lds_d2_t l0 = (lds_d2_t)(uintptr_t)lo16_shl5(X.ru[0]), l1 = (lds_d2_t)(uintptr_t)lo16_shl5(X.ru[1]);        \
+      Pa0 = l0[0]; Pn0 = l0[1]; Pa1 = l1[0]; Pn1 = l1[1]; }                                                             \
+    HITL_SLDS(Q, X, 0)                                                                                                     \
+    stf_match<true>(acc, Pa0.x, Pa0.y, Pn0.x, Pn0.y, X.rg[0], cR, sR, t01x, t01y, v0 ? 1.0 : 0.0);                      \
+    if (r > 64) stf_match<true>(acc, Pa1.x, Pa1.y, Pn1.x, Pn1.y, X.rg[1], cR, sR, t01x, t01y, v1 ? 1.0 : 0.0);          \
+    if (F > 0) {                                                                                                        \
+      HITL_SLDS(P, X, 1)                                                                                                   \
+      stf_match<false>(acc, Qa0.x, Qa0.y, Qn0.x, Qn0.y, X.g[0], cR, sR, t01x, t01y, 1.0);                               \
+      stf_match<false>(acc, Qa1.x, Qa1.y, Qn1.x, Qn1.y, X.g[1], cR, sR, t01x, t01y, 1.0);                               \
     }                                                                                                                   \
+    if (F > 1) {                                                                                                        \
+      HITL_SLDS(Q, X, 2)                                                                                                   \
+      stf_match<false>(acc, Pa0.x, Pa0.y, Pn0.x, Pn0.y, X.g[2], cR, sR, t01x, t01y, 1.0);                               \
+      stf_match<false>(acc, Pa1.x, Pa1.y, Pn1.x, Pn1.y, X.g[3], cR, sR, t01x, t01y, 1.0);                               \
+    }                                                                                                                   \
+    if (F > 2) {                                                                                                        \
+      stf_match<false>(acc, Qa0.x, Qa0.y, Qn0.x, Qn0.y, X.g[4], cR, sR, t01x, t01y, 1.0);                               \
+      stf_match<false>(acc, Qa1.x, Qa1.y, Qn1.x, Qn1.y, X.g[5], cR, sR, t01x, t01y, 1.0);                               \
+    }                                                                                                                   \
+    /* records and pose states for the next iterations: behind the last LDS read of this pair, in front of a reduction that */ \
+    /* touches neither LDS nor memory -- the scalar loads are back before anything has to wait for them */                   \
+    R3 = HITL_SREC(min(q + 3, P1 - 1));                                                                                 \
+    const i4v xi4 = sload4(x + 3 * (size_t)R1[6]), ci4 = sload4(cs + R1[6]), xj4 = sload4(x + 3 * (size_t)R1[5]), cj4 = sload4(cs + R1[5]); \
     const double tot = stf_reduce8(acc, lane);                                                                          \
     {                                                                                                                   \
       double* st_ = s_tot + pend * kStfSSlotD;                                                                          \
       if ((lane & 7) == 0) st_[lane >> 3] = tot;                                                                        \
-      if (lane == 0) { st_[8] = t01x; st_[9] = t01y; st_[10] = (double)len; st_[11] = (double)q; }                      \
+      if (lane == 0) { st_[8] = t01x; st_[9] = t01y; st_[10] = (double)len; st_[11] = (double)R0[7]; }                  \
     }                                                                                                                   \
     ++pend;                                                                                                             \
     const bool pose_ends = !has1 || R1[6] != R0[6];                                                                     \
@@ -1000,6 +1390,7 @@ __global__ __launch_bounds__(64, 3) void k_linearize_stf_s(const StfPairRec* __r
     ++q;
   }
 #undef HITL_SITER
+#undef HITL_SLDS
 #undef HITL_SSCAN
 #undef HITL_SCONST
 #undef HITL_SGATHER
@@ -1009,15 +1400,24 @@ __global__ __launch_bounds__(64, 3) void k_linearize_stf_s(const StfPairRec* __r
 #undef HITL_SREC
 }
 
-void launch_linearize_stf_stream(hipStream_t st, int max_scan, int cu_count, const void* recs, const int* pose_pair_off, int n_poses, const int64_t* obs_off,
+// waves (= workgroups) of the stream kernel: as many as fit one CU's LDS, at most 3 per SIMD (registers); a multiple of 8 (XCDs)
+int stf_stream_waves(int max_scan, int cu_count) {
+  const size_t lds = (size_t)32 * max_scan + (size_t)kStfSSlots * kStfSSlotD * 8;
+  // every wave must be resident at once (a second round of workgroups would double the launch): ask the runtime how many
+  // fit a CU with this much LDS (the allocation granule is the device's business), never more than 3 per SIMD
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_linearize_stf_s, 64, lds) != hipSuccess || per_cu < 1)
+    per_cu = std::max(1, (int)(((size_t)160 * 1024) / (lds + 1024)));
+  per_cu = std::max(1, std::min(per_cu, 12));
+  if (dev_switches().stf_waves_per_cu > 0) per_cu = std::min(per_cu, dev_switches().stf_waves_per_cu);     // HITL_STF_WAVES_PER_CU (development)
+  return std::max(8, (per_cu * cu_count) & ~7);
+}
+void launch_linearize_stf_stream(hipStream_t st, int max_scan, int n_waves, const void* recs, const int* wave_off, const int64_t* obs_off,
                                  const float4* obs, const uint32_t* matches, const double* x, const double2* cs, float corr, float std_dev, double* pairRJ) {
   const double kf = (double)corr / (double)std_dev;
   const int tot_off = 4 * max_scan;                                                       // doubles
   const size_t lds = (size_t)32 * max_scan + (size_t)kStfSSlots * kStfSSlotD * 8;
-  int per_cu = (int)(((size_t)160 * 1024) / lds);
-  per_cu = std::max(1, std::min(per_cu, 12));                                             // 3 waves per SIMD by registers
-  const int grid = std::min(n_poses, per_cu * cu_count);
-  hipLaunchKernelGGL(k_linearize_stf_s, dim3(grid), dim3(64), lds, st, reinterpret_cast<const StfPairRec*>(recs), pose_pair_off, n_poses, obs_off, obs,
+  hipLaunchKernelGGL(k_linearize_stf_s, dim3(n_waves), dim3(64), lds, st, reinterpret_cast<const StfPairRec*>(recs), wave_off, obs_off, obs,
                      matches, x, cs, kf, pairRJ, tot_off);
 }
 
@@ -1130,7 +1530,8 @@ void launch_pose_trig(hipStream_t st, int n_poses, const double* x, double2* cs)
 }
 
 void launch_linearize_stf(hipStream_t st, const MapView& map, const PairView& pr, int max_scan, int64_t map_obs_count, int64_t n_matches, const double* x,
-                          const double2* cs, float corr, float std_dev, double* pairRJ, const LmDev* lm, const double* x_alt, double* pairRJ_alt) {
+                          const double2* cs, float corr, float std_dev, double* pairRJ, const LmDev* lm, const double* x_alt, double* pairRJ_alt,
+                          const void* pose_recs) {
   const StfLm lmsel = {lm, x_alt, pairRJ_alt};
   if (pr.n_pairs == 0) return;
   const int chunk = (map.n_poses + 7) / 8;
@@ -1144,6 +1545,21 @@ void launch_linearize_stf(hipStream_t st, const MapView& map, const PairView& pr
   // SIMD (5, 6, 7 exist; 7 only with 1 or 2 trips ahead).  Unset: the default below.
   const int variant = dev_switches().stf_variant;
   const int src = ((size_t)cap * 32 <= 64 * 1024) ? 2 : ((size_t)cap * 16 <= 64 * 1024) ? 1 : 0;
+  if ((variant == 0 || variant == 700) && src == 2 && off32 && pose_recs != nullptr) {      // the half-wave kernel behind a per-pose descriptor record
+    hipLaunchKernelGGL((k_linearize_stf_r<7>), grid, block, (size_t)cap * 32, st, map, pr, reinterpret_cast<const StfPoseRec*>(pose_recs), chunk, x, cs, kf,
+                       pairRJ, lmsel);
+    return;
+  }
+  if ((variant >= 600 && variant < 700) && src == 2 && off32) {      // the half-wave kernel, instruction diet of round 4 (60x: ablations)
+    const int caph = max_scan <= 416 ? 416 : max_scan <= 512 ? 512 : max_scan <= 1024 ? 1024 : 2048;
+    const size_t ldsh = (size_t)caph * 32 + (size_t)(kStfBlock / kStfSub) * kStfSums * 8;
+#define HITL_STFH_GO(CAP, MB, FL) hipLaunchKernelGGL((k_linearize_stf_h<CAP, MB, FL>), grid, block, ldsh, st, map, pr, chunk, x, cs, kf, pairRJ, lmsel)
+    if (caph == 416) {
+      if (variant == 601) HITL_STFH_GO(416, 7, 1); else if (variant == 602) HITL_STFH_GO(416, 7, 2); else if (variant == 603) HITL_STFH_GO(416, 7, 3); else HITL_STFH_GO(416, 7, 0);
+    } else if (caph == 512) HITL_STFH_GO(512, 7, 0); else if (caph == 1024) HITL_STFH_GO(1024, 7, 0); else HITL_STFH_GO(2048, 7, 0);
+#undef HITL_STFH_GO
+    return;
+  }
   if (variant >= 100 && variant < 200 && src == 2) {                // one wave per directed pair (k_linearize_stf_w)
     const dim3 wblock(kStfWBlock);
     const int capw = cap <= 512 ? 512 : cap <= 1024 ? 1024 : 2048;
@@ -1161,7 +1577,8 @@ void launch_linearize_stf(hipStream_t st, const MapView& map, const PairView& pr
   const size_t lds = (src == 2) ? (size_t)cap * 32 : (src == 1) ? (size_t)cap * 16 : 0;
 #define HITL_STF_GO(SRC, O32, AH, MINB) hipLaunchKernelGGL((k_linearize_stf<SRC, O32, AH, MINB>), grid, block, lds, st, map, pr, chunk, x, cs, kf, pairRJ, lmsel)
   if (src == 2 && off32 && minb == 7) {
-    if (ahead == 1) HITL_STF_GO(2, true, 1, 7); else HITL_STF_GO(2, true, 2, 7);
+    if (variant == 501 || variant == 0 || variant == 700) hipLaunchKernelGGL((k_linearize_stf<2, true, 1, 7, true>), grid, block, lds, st, map, pr, chunk, x, cs, kf, pairRJ, lmsel);
+    else if (ahead == 1) HITL_STF_GO(2, true, 1, 7); else HITL_STF_GO(2, true, 2, 7);
   } else if (src == 2 && off32) {
     if (minb == 6) { if (ahead == 1) HITL_STF_GO(2, true, 1, 6); else if (ahead == 2) HITL_STF_GO(2, true, 2, 6); else HITL_STF_GO(2, true, 3, 6); }
     else { if (ahead == 1) HITL_STF_GO(2, true, 1, 5); else if (ahead == 2) HITL_STF_GO(2, true, 2, 5); else HITL_STF_GO(2, true, 3, 5); }

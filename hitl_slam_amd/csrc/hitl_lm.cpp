@@ -38,13 +38,14 @@ static int enqueue_linearize(hitl_solver* s, const FactorView& fv, const double*
     if (s->opt.stf_moments)
       launch_linearize_stf_moments(st, pv, s->pairM.p, xdev, s->pose_cs.p, s->opt.point_correlation_factor, s->opt.laser_std_dev, lv.pairRJ);
     else if (s->stf_recs_of == s->corr_generation && s->stf_stream_fits && stf_stream_apply(s))
-      launch_linearize_stf_stream(st, s->max_scan, s->cu_count, s->stf_recs.p, s->pose_pair_off.p, s->n, s->obs_off.p, s->obs.p, s->matches.p, xdev,
+      launch_linearize_stf_stream(st, s->max_scan, s->stf_waves, s->stf_recs.p, s->stf_wave_off.p, s->obs_off.p, s->obs.p, s->matches.p, xdev,
                                   s->pose_cs.p, s->opt.point_correlation_factor, s->opt.laser_std_dev, lv.pairRJ);
     else if (s->stf_steps_of == s->corr_generation && stf_steps_apply(s))
-      launch_linearize_stf_steps(st, s->max_scan, 4 * s->cu_count, s->stf_steps.p, s->stf_step_off.p + s->n, s->obs.p, s->matches.p, xdev,
+      launch_linearize_stf_steps(st, s->max_scan, stf_steps_grid(s->max_scan, s->cu_count), s->stf_steps.p, s->stf_step_off.p + s->n, s->obs.p, s->matches.p, xdev,
                                  s->pose_cs.p, s->opt.point_correlation_factor, s->opt.laser_std_dev, lv.pairRJ);
     else
-      launch_linearize_stf(st, mv, pv, s->max_scan, s->n_obs, s->n_matches, xdev, s->pose_cs.p, s->opt.point_correlation_factor, s->opt.laser_std_dev, lv.pairRJ);
+      launch_linearize_stf(st, mv, pv, s->max_scan, s->n_obs, s->n_matches, xdev, s->pose_cs.p, s->opt.point_correlation_factor, s->opt.laser_std_dev, lv.pairRJ,
+                           nullptr, nullptr, nullptr, s->stf_pose_recs_of == s->corr_generation ? s->stf_pose_recs.p : nullptr);
   }
   if (s->lin_timed) HIP_TRY(hipEventRecord(s->ev1, st));
   launch_assemble(st, mv, pv, fv, xdev, lv);
@@ -686,7 +687,7 @@ static int lm_device_loop(hitl_solver* s, const FactorView& fv, int cur, double 
           launch_linearize_stf_moments(st, pv, s->pairM.p, xb[0], s->pose_cs.p, o.point_correlation_factor, o.laser_std_dev, lv0.pairRJ, s->lm_dev.p, xb[1], lv1.pairRJ);
         else
           launch_linearize_stf(st, mv, pv, s->max_scan, s->n_obs, s->n_matches, xb[0], s->pose_cs.p, o.point_correlation_factor, o.laser_std_dev, lv0.pairRJ,
-                               s->lm_dev.p, xb[1], lv1.pairRJ);
+                               s->lm_dev.p, xb[1], lv1.pairRJ, s->stf_pose_recs_of == s->corr_generation ? s->stf_pose_recs.p : nullptr);
       }
       if (timed) { HIP_TRY(hipEventRecord(s->lm_events[2 * pairs_used + 1], st)); pair_iter[pairs_used] = queued + 1; ++pairs_used; }
       launch_assemble(st, mv, pv, fv, xb[0], lv0, s->lm_dev.p, xb[1], &lv1);
@@ -730,8 +731,9 @@ int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float* poses
                     hitl_summary* summary) {
   const double t_start = now_ms();
   const hitl_options& o = s->opt;
+  RoctxRange r_solve(mode == HITL_MODE_ODOM_HC ? "hitl:solve mode A" : mode == HITL_MODE_STF_ONLY ? "hitl:solve mode B" : "hitl:solve mode C");
   FactorView fv;
-  TRY(prepare(s, mode, poses_in, poses_global, &fv));
+  { RoctxRange r("hitl:prepare"); TRY(prepare(s, mode, poses_in, poses_global, &fv)); }
   if (dev_switches().timing) std::fprintf(stderr, "lm_solve: prepare (factor tables)   %.3f ms\n", now_ms() - t_start);
   hipStream_t st = s->stream;
   const int n = s->n, n3 = 3 * n;
@@ -748,7 +750,7 @@ int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float* poses
   double* xcand = s->xc.p;
   int cur = 0;
   LinResult lr;
-  TRY(run_linearize_dist(s, fv, xcur, cur, &lr));
+  { RoctxRange r("hitl:initial linearisation"); TRY(run_linearize_dist(s, fv, xcur, cur, &lr)); }
   S.linearize_ms += lr.stf_ms; S.linearize_calls++; S.linearize_timed_calls += lr.timed;
   double cost = lr.cost, gmax = lr.gmax;
   S.initial_cost = cost;
@@ -781,6 +783,7 @@ int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float* poses
   while (!done) {
     if (iter >= o.max_num_iterations) { term = HITL_NO_CONVERGENCE; break; }
     ++iter;
+    RoctxRange r_iter("hitl:lm iteration");
     int lin_iters = 0;
     bool ok = true;
     const bool time_solver = o.timing_level >= 2;
@@ -790,16 +793,18 @@ int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float* poses
     LinResult lr_spec = {0.0, 0.0, 0.f, 0};
     bool have_spec = false;
     if (fused) {
-      TRY(enqueue_linear_solve_banded(s, fv, cur, radius, xcur, xcand));
+      { RoctxRange r("hitl:queue linear solve + step"); TRY(enqueue_linear_solve_banded(s, fv, cur, radius, xcur, xcand)); }
       if (time_solver) HIP_TRY(hipEventRecord(s->ev3, st));
-      TRY(enqueue_linearize(s, fv, xcand, cur ^ 1, /*direct=*/true, /*have_trig=*/true));   // partial sums are written to pinned host memory by the kernels
-      TRY(spin_sync(s));
+      { RoctxRange r("hitl:queue linearisation of the candidate");
+        TRY(enqueue_linearize(s, fv, xcand, cur ^ 1, /*direct=*/true, /*have_trig=*/true)); }   // partial sums are written to pinned host memory by the kernels
+      { RoctxRange r("hitl:wait for the device"); TRY(spin_sync(s)); }
       double rr, bb;
       TRY(finish_step_partials(s, &rr, &bb, &ss));
       const double guard = std::max(std::max(o.linear_solver_tolerance, 1e-15), 1e-9);
       if (!(rr == rr) || rr > guard * guard * bb) ok = false;   // the factorisation broke down
       lin_iters = 1;
     } else {
+      RoctxRange r(s->dist_mode() ? "hitl:submap linear solve + exchange" : "hitl:off-band PCG solve");
       if (s->dist_mode()) { TRY(linear_solve_and_step_dist(s, fv, cur, radius, xcur, xcand, &lin_iters, &ok, &ss, &lr_spec)); have_spec = true; }
       else TRY(linear_solve_and_step(s, fv, cur, radius, xcur, xcand, &lin_iters, &ok, &ss));
       if (time_solver) { HIP_TRY(hipEventRecord(s->ev3, st)); HIP_TRY(hipEventSynchronize(s->ev3)); }

@@ -6,6 +6,8 @@
 // Levenberg-Marquardt loop of hitl_lm.cpp; FindSTFCorrespondences (:561-642) is driven from hitl_corr.cpp.
 // There is no CPU fallback anywhere in this library.
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -340,11 +342,20 @@ static int prepare_local(hitl_solver* s, int mode, const float* poses_ref, const
     HIP_TRY(hipGetLastError());
     s->stf_steps_of = s->corr_generation;
   }
+  if (!s->opt.stf_moments && mode != HITL_MODE_ODOM_HC && s->n_pairs > 0 && s->stf_pose_recs_of != s->corr_generation) {
+    // once per correspondence set: the per-pose descriptor records (what the first two dependent load rounds of a workgroup fetch)
+    TRY(s->stf_pose_recs.resize((size_t)s->n * stf_pose_rec_bytes()));
+    launch_build_stf_pose_recs(s->stream, s->map_view(), s->pair_view(), s->stf_pose_recs.p);
+    HIP_TRY(hipGetLastError());
+    s->stf_pose_recs_of = s->corr_generation;
+  }
   if (!s->opt.stf_moments && mode != HITL_MODE_ODOM_HC && s->n_pairs > 0 && stf_stream_apply(s) && s->stf_recs_of != s->corr_generation) {
     // once per correspondence set: the pair records the stream linearisation walks, and whether every pair fits its registers
     TRY(s->stf_recs.resize((size_t)s->n_pairs * stf_pair_rec_bytes()));
     TRY(s->stf_max_len.resize(1));
-    launch_build_stf_pair_recs(s->stream, s->map_view(), s->pair_view(), s->stf_recs.p, s->stf_max_len.p);
+    s->stf_waves = stf_stream_waves(s->max_scan, s->cu_count);
+    TRY(s->stf_wave_cnt.resize((size_t)s->stf_waves)); TRY(s->stf_wave_off.resize((size_t)s->stf_waves + 1));
+    launch_build_stf_pair_recs(s->stream, s->map_view(), s->pair_view(), s->stf_waves, s->stf_wave_cnt.p, s->stf_wave_off.p, s->stf_recs.p, s->stf_max_len.p);
     HIP_TRY(hipGetLastError());
     int max_len = 0;
     HIP_TRY(hipMemcpyAsync(&max_len, s->stf_max_len.p, sizeof(int), hipMemcpyDeviceToHost, s->stream));
@@ -502,6 +513,7 @@ void read_dev_switches() {
   d.cr_unfused_build = on("HITL_CR_UNFUSED_BUILD"); d.stf_addr64 = on("HITL_STF_ADDR64"); d.force_dist = on("HITL_FORCE_DIST");
   d.force_rccl = on("HITL_FORCE_RCCL"); d.device_lm = on("HITL_DEVICE_LM");
   d.stf_variant = (int)num("HITL_STF_VARIANT", 0);
+  d.stf_waves_per_cu = (int)num("HITL_STF_WAVES_PER_CU", 0);
   d.kd_block = (int)num("HITL_KD_BLOCK", d.kd_block);
   d.kd_cap = (int)num("HITL_KD_CAP", 0);
   d.kd_redo_cap = (int)std::max(1ll, std::min((long long)(1 << 18), num("HITL_KD_REDO_CAP", d.kd_redo_cap)));
@@ -512,6 +524,21 @@ void read_dev_switches() {
   if (const char* e = std::getenv("HITL_CR_PLAN"))
     for (const char* q = e; *q && d.cr_plan_n < 16;) { d.cr_plan[d.cr_plan_n++] = std::atoi(q); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
   g_dev = d;
+  roctx_resolve(on("HITL_ROCTX"));
+}
+
+static RoctxApi g_roctx;
+const RoctxApi& roctx_api() { return g_roctx; }
+void roctx_resolve(bool enable) {
+  if (!enable) { g_roctx = RoctxApi(); return; }
+  if (g_roctx.push) return;
+  for (const char* lib : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+    void* h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) continue;
+    auto push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+    auto pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+    if (push && pop) { g_roctx.push = push; g_roctx.pop = pop; return; }
+  }
 }
 }  // namespace hitl
 

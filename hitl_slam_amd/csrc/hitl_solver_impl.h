@@ -108,8 +108,12 @@ struct hitl_solver {
   DevArray<char> stf_steps;                    //   the step records
   int64_t stf_steps_of = -1;                   //   correspondence-set generation the table belongs to
   int cu_count = 256;                          // compute units of the device (grid of the persistent kernels)
+  DevArray<char> stf_pose_recs;                // per-pose descriptor records of the half-wave linearisation (k_linearize_stf_r)
+  int64_t stf_pose_recs_of = -1;               //   correspondence-set generation they belong to
   DevArray<char> stf_recs;                     // stream linearisation (k_linearize_stf_s): one record per pair
   DevArray<int> stf_max_len;                   //   largest match count of a pair (device scalar)
+  DevArray<int> stf_wave_cnt, stf_wave_off;    //   pairs per wave, first record of every wave
+  int stf_waves = 0;                           //   waves the records are laid out for
   int64_t stf_recs_of = -1;                    //   correspondence-set generation the records belong to
   bool stf_stream_fits = false;                //   every pair of that set fits the kernel's registers
   DevArray<double> pairM;                      // opt-in (stf_moments): 2 x 15 moments per pair
