@@ -355,6 +355,11 @@ def main():
                      "compulsory_bytes_this_layout": compulsory,
                      "avg_launch_ms": avg_stf_ms, "launches": stf_launches, "launches_bracketed_by_hip_events": stf_calls,
                      # counter digests describe ONE profiled workload: reported only when this run is that workload
+                     # the contract's "bound: hbm" is a label: HBM is the unit this kernel loads least.  What it issues is fp64 VALU work:
+                     # vector instructions per launch (PMC SQ_INSTS_VALU of the committed profile of THIS workload) x 4 cycles (a wave64
+                     # fp64 / fp32 / integer instruction holds its SIMD for 4) / (1024 SIMDs x the live launch time x 2.4 GHz)
+                     "fp64_issue_frac": ((pmc or {}).get("valu_instructions_per_launch", 0) * 4.0 / (1024 * avg_stf_ms * 1e-3 * 2.4e9)
+                                         if traffic_source and avg_stf_ms > 0 and (pmc or {}).get("valu_instructions_per_launch") else None),
                      "limiter": (pmc or {}).get("limiter") if traffic_source else None,
                      "utilisation_counters": pmc if traffic_source else None,
                      "profiled": bool(traffic_source)},

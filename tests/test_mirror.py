@@ -134,3 +134,90 @@ def test_solves_agree(case, late):
         assert abs(s["final_cost"] - so.final_cost) <= 1e-9 * so.final_cost
         assert np.abs(s["poses"] - po).max() <= 1e-6
     o.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 4: the correction cycle and the covariance recovery (tests/golden/mirror_cycle.py) against the oracle
+# ---------------------------------------------------------------------------------------------------------------------
+import mirror_cycle as MC  # noqa: E402
+
+
+def test_the_cycle_mirror_and_the_fixture_maker_are_independent_of_the_oracle():
+    import ast
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for name, allowed in (("mirror_cycle.py", {"ctypes", "math", "numpy", "mirror"}),
+                          ("make_golden_cycle.py", {"os", "sys", "numpy", "mirror", "mirror_cycle", "hitl_slam_amd", "tools"}),
+                          ("make_golden.py", None)):
+        src = open(os.path.join(here, name)).read()
+        mods = set()
+        for node in ast.walk(ast.parse(src)):
+            if isinstance(node, ast.Import):
+                mods |= {a.name.split(".")[0] for a in node.names}
+            elif isinstance(node, ast.ImportFrom):
+                mods.add((node.module or "").split(".")[0])
+        assert "oracle" not in mods, (name, mods)
+        if allowed is not None:
+            assert mods <= allowed, (name, mods)
+
+
+def _eq32(a, b):
+    return np.array_equal(np.asarray(a, np.float32).view(np.uint32), np.asarray(b, np.float32).view(np.uint32))
+
+
+@pytest.mark.parametrize("ctype", [2, 4, 5, 6])
+@pytest.mark.parametrize("swap", [False, True])
+def test_correction_cycle_stage_by_stage_against_the_oracle(ctype, swap):
+    """One user correction through every stage of HitLSLAM::Run, mirror (literal float32 loops) against oracle (closed forms,
+    explicit index arithmetic), all four correction types, and with the two selections given in the other order (the 'bad
+    user' branch of OrderAndFilterUserInput, which swaps them back): index sets, fp32 poses, covariances and rows BIT FOR BIT."""
+    from tests.cycle_scenario import Scenario
+    sc = Scenario(n_poses=70, obs=60, seed=20260107 + ctype, first_piece=(10.5, 17.5))
+    pr = sc.prob
+    clicks = sc.selected.copy()
+    if swap:
+        clicks = np.concatenate([clicks[4:], clicks[:4]])
+    o = O.OracleSolver()
+    pr.load(o)
+    wx, wy = MC.transform_clouds(sc.poses, pr.off, pr.px, pr.py)
+    owx, owy = o.transform_scans(sc.poses)
+    assert _eq32(wx, owx) and _eq32(wy, owy)
+    assert np.array_equal(MC.verify_points(wx, wy, clicks.reshape(-1, 2), 0.05), o.verify_points(sc.poses, clicks.reshape(-1, 2), 0.05))
+    seg, inl, pas, its = MC.fit_segments(wx, wy, clicks.reshape(2, 4))
+    oseg, oinl, opas, oits = o.fit_segments(sc.poses, clicks.reshape(2, 4))
+    assert _eq32(seg, oseg) and np.array_equal(inl, oinl) and np.array_equal(pas, opas) and np.array_equal(its, oits)
+    counts = MC.observation_sets(wx, wy, pr.off, seg.reshape(-1), 0.03)
+    ocounts, _ = o.observation_sets(sc.poses, seg.reshape(-1), 0.03, want_mask=False)
+    assert np.array_equal(counts, ocounts)
+    od, ood = MC.order_user_input(counts, seg.reshape(-1)), o.order_user_input(ocounts, seg.reshape(-1))
+    assert np.array_equal(od["corrected"], ood["corrected"]) and np.array_equal(od["anchor"], ood["anchor"])
+    assert od["bounds"] == tuple(ood["bounds"]) and _eq32(od["seg_xy8"], ood["seg_xy8"]) and od["bounds"][0] >= 0
+    if swap:
+        assert _eq32(od["seg_xy8"][:4], seg.reshape(-1)[4:])        # the selections were swapped back
+    p2, corr, rows = MC.apply_explicit_correction(ctype, od["seg_xy8"], sc.poses, od["corrected"], od["anchor"])
+    op2, ocorr, orows = o.apply_explicit_correction(ctype, ood["seg_xy8"], sc.poses, ood["corrected"], ood["anchor"])
+    assert _eq32(p2, op2) and _eq32(corr, ocorr) and len(rows) == len(orows)
+    for k, f in enumerate(("type", "constrained_pose_id", "anchor_pose_id")):
+        assert np.array_equal(np.array([r[k] for r in rows]), orows[f])
+    for k, f in ((3, "delta_parallel"), (4, "delta_perpendicular"), (5, "delta_angle"), (6, "relative_penalty_dir")):
+        assert _eq32(np.array([r[k] for r in rows], np.float32), orows[f]), f
+    p3, cov3 = MC.backprop(p2, sc.cov, od["bounds"][0], od["bounds"][1], corr)
+    op3, ocov3 = o.backprop(op2, sc.cov, ood["bounds"][0], ood["bounds"][1], ocorr)
+    assert _eq32(p3, op3) and _eq32(cov3, ocov3)
+    assert _eq32(MC.normalize_angles(p3), o.normalize_angles(op3))
+    o.close()
+
+
+def test_covariance_blocks_against_the_oracle():
+    """vector_mapping.cpp:2772-2812: dense pseudo-inverse of the mirror's J^T J against the oracle's banded inverse, robot frame."""
+    prob = Problem(40, 30, ppf=20, groups=2, kind=0)
+    o = O.OracleSolver()
+    prob.load(o)
+    po, _ = o.solve(abi.MODE_ODOM_HC, prob.init)
+    So = o.pose_covariances(abi.MODE_ODOM_HC, po)
+    rows = prob.rows[0][:prob.rows[1]]
+    hc = [(int(r.type), int(r.constrained_pose_id), int(r.anchor_pose_id), np.float32(r.delta_parallel), np.float32(r.delta_perpendicular),
+           np.float32(r.delta_angle), np.float32(r.relative_penalty_dir)) for r in rows]
+    Sm = MC.pose_covariances(M.Problem(M.MODE_ODOM_HC, po, hc, None, None), po)
+    scale = np.abs(So).max(axis=(1, 2))[:, None, None] + 1e-300
+    assert (np.abs(Sm - So) / scale).max() < 1e-7
+    o.close()
