@@ -411,7 +411,9 @@ def main():
             cyc["pre_solve_stages_ms"] = pre
             # what ONE interactive correction costs end to end on this map: pre-solve stages + new correspondences + the re-solve
             # + the world-frame re-projection for the display (HitLSLAM::Run, HitLSLAM.cpp:380-480)
-            result["interactive_correction_ms"] = pre + match_ms + ms_per_step + cyc["transform_scans_ms"]
+            # (re-projection into the page-locked buffers Solver.run_correction uses by default since round 4; the pageable-memory
+            # figure stays in correction_cycle.transform_scans_ms)
+            result["interactive_correction_ms"] = pre + match_ms + ms_per_step + cyc["transform_scans_pinned_host_ms"]
             cyc.update(all_points_verified=bool(int(seen.sum()) == 4), fit_passes=[int(v) for v in pas], fit_inliers=[int(v) for v in inl],
                        anchors=int(od["anchor"].size), corrected=int(od["corrected"].size), new_rows=int(new_rows.size),
                        backprop_bounds=[int(od["bounds"][0]), int(od["bounds"][1])],

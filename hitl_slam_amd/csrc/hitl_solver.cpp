@@ -748,6 +748,26 @@ int hitl_solver_set_partition(hitl_solver* s, int64_t global_begin, int64_t n_gl
   return HITL_OK;
 }
 
+int hitl_solver_set_partition_range(hitl_solver* s, int64_t global_begin, int64_t global_end, int64_t n_global_poses, int32_t halo_poses) {
+  if (!s || global_begin < 0 || n_global_poses < 1 || global_end <= global_begin || global_end > n_global_poses)
+    return fail(HITL_ERR_INVALID_ARGUMENT, "set_partition_range: bad range");
+  if (s->world == 1 && (global_begin != 0 || global_end != n_global_poses)) return fail(HITL_ERR_INVALID_ARGUMENT, "set_partition_range: a single-GPU solver owns the whole map");
+  if (s->world > 1 && ((s->rank == 0) != (global_begin == 0))) return fail(HITL_ERR_INVALID_ARGUMENT, "set_partition_range: rank 0 (and only rank 0) starts at pose 0");
+  if (s->world > 1 && ((s->rank == s->world - 1) != (global_end == n_global_poses))) return fail(HITL_ERR_INVALID_ARGUMENT, "set_partition_range: the last rank (and only it) ends at the last pose");
+  if (s->world > 1 && halo_poses == 0) return fail(HITL_ERR_INVALID_ARGUMENT, "set_partition_range: halo_poses must be >= 1, or < 0 for the whole map");
+  // halo_poses < 0: the rank holds the scans of the WHOLE map and owns the rows of [begin, end) -- pose pairs may then reach
+  // any distance across the cuts (the reference's all-pairs search, revisits); otherwise the halos are clipped at the map's ends
+  const int64_t h = (halo_poses < 0) ? n_global_poses : (int64_t)halo_poses;
+  s->g_begin = global_begin;
+  s->g_n = n_global_poses;
+  s->halo_req = (s->world > 1) ? (int)std::min<int64_t>(h, n_global_poses) : 0;
+  s->hl = (s->world > 1) ? (int)std::min<int64_t>(h, global_begin) : 0;
+  s->hh = (s->world > 1) ? (int)std::min<int64_t>(h, n_global_poses - global_end) : 0;
+  s->n = 0;   // a map must be (re)installed for this range
+  s->min_band_poses = 1;
+  return HITL_OK;
+}
+
 int hitl_solver_set_map(hitl_solver* s, int64_t n_poses, const int64_t* obs_offset, const float* px, const float* py,
                         const float* nx, const float* ny, const float* cov9) {
   if (!s || !obs_offset || n_poses < 1) return fail(HITL_ERR_INVALID_ARGUMENT, "set_map: null solver/offsets or n_poses < 1");

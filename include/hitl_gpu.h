@@ -372,6 +372,12 @@ typedef struct hitl_comm_ops {
 } hitl_comm_ops;
 int hitl_solver_set_comm(hitl_solver*, const hitl_comm_ops* ops);
 int hitl_solver_set_partition(hitl_solver*, int64_t global_begin, int64_t n_global_poses, int32_t halo_poses);
+/* The same with the owned range [global_begin, global_end) spelled out, so that the halos can be clipped at the ends of the
+ * map: the rank then holds the scans of [begin - min(halo, begin), end + min(halo, n_global - end)).  halo_poses < 0 =
+ * REPLICATED SCANS: every rank holds the whole map (C4 is 320 MB of 288 GB) and owns the rows of its pose range -- a pose pair
+ * may then reach any distance across any number of cuts (the reference's all-pairs loop, JointOptimization.cpp:575-635, and
+ * revisits; the off-band blocks go through the distributed PCG), where a finite halo refuses pairs that reach deeper than it. */
+int hitl_solver_set_partition_range(hitl_solver*, int64_t global_begin, int64_t global_end, int64_t n_global_poses, int32_t halo_poses);
 /* one small all-gather through the active communicator, payload verified (bring-up check) */
 int hitl_solver_comm_selftest(hitl_solver*);
 /* ranks the active transport really holds: ncclCommCount of the built-in RCCL communicator, world_size for a caller

@@ -36,6 +36,9 @@ def main():
         assert len(cuts) == world + 1 and cuts[-1] == n_per * world
         b, e = cuts[rank], cuts[rank + 1]
     lo, hi = b - (halo if rank > 0 else 0), e + (halo if rank < world - 1 else 0)
+    replicated = halo < 0                         # every rank holds the whole map (hitl_solver_set_partition_range, halo < 0)
+    if replicated:
+        lo, hi = 0, n_per * world
     M = 48
     opt = H.default_options()
     opt.rank, opt.world_size = rank, world
@@ -46,7 +49,10 @@ def main():
     s = H.Solver(opt)
     ops, keep = torch_allgather_ops()
     s.set_comm(ops, keep)
-    s.set_partition(b, prob.n, halo)
+    if replicated:
+        s.set_partition_range(b, e, prob.n, -1)
+    else:
+        s.set_partition(b, prob.n, halo)
     sl = slice(lo * M, hi * M)
     s.set_map(np.arange(hi - lo + 1, dtype=np.int64) * M, prob.px[sl], prob.py[sl], prob.nx[sl], prob.ny[sl], prob.cov[lo:hi])
     s.set_human_constraints(prob.rows)

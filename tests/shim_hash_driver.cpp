@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "JointOptGpu.h"
@@ -66,6 +67,28 @@ int main(int argc, char** argv) {
     for (size_t k = 0; k < jo.robot_frame_point_clouds_[i].size(); ++k) sum += a[k] + b[k];
   }
   const double floor_ms = ms_since(t0);
+  // argv[3] == "run" (a GPU is present): what JointOpt::Run costs its caller at this size in mode A (the solve the shipped binary
+  // runs), first call (map upload) and steady state (same map: fingerprint + marshaling + solve)
+  if (argc > 3 && std::string(argv[3]) == "run") {
+    jo.poses_.resize(n); jo.covariances_.resize(n);
+    for (size_t i = 0; i < n; ++i) {
+      jo.poses_[i].translation.v[0] = 0.3f * (float)i; jo.poses_[i].translation.v[1] = 0.01f * (float)(i % 7); jo.poses_[i].angle = 0.001f * (float)(i % 11);
+      for (int q = 0; q < 9; ++q) jo.covariances_[i].m[q] = (q % 4 == 0) ? 1e-4f : 0.f;
+    }
+    std::vector<HC> group;
+    for (int k = 0; k < 20; ++k) {
+      HC h; h.type = 4; h.constrained_pose_id = (int)(n / 2 + 40 * k); h.anchor_pose_id = 10 + k; h.delta_parallel = 0.3f * (float)(n / 2 + 40 * k - 10 - k);
+      h.delta_perpendicular = 0.f; h.delta_angle = 0.f; h.relative_penalty_dir = 1.5707963f;
+      group.push_back(h);
+    }
+    jo.human_constraints_.push_back(group);
+    jo.SetMode(HITL_MODE_ODOM_HC, 3);
+    if (jo.RunStatus() != HITL_OK) { std::fprintf(stderr, "shim run failed: %s\n", hitl_last_error()); return 2; }
+    const double first_ms = jo.LastRunMs();
+    if (jo.RunStatus() != HITL_OK) return 3;
+    std::printf("run_first_ms %.3f run_steady_ms %.3f fingerprint_ms %.3f solve_ms %.3f iterations %d\n", first_ms, jo.LastRunMs(), jo.LastFingerprintMs(),
+                jo.Summary().total_ms, jo.Summary().iterations);
+  }
   std::printf("%.3f %.3f %d %d %d %.3f %llu\n", serial, threaded, (int)(h1 == h8 && h_back == h1), (int)(h_edit != h1), (int)(h_size != h1), floor_ms, sum);
   return 0;
 }

@@ -81,8 +81,13 @@ def test_bench_started_directly_with_gpus_2_launches_two_ranks():
 @pytest.mark.gpu
 def test_bench_refuses_rccl_with_more_ranks_than_gpus():
     """Two RCCL ranks on a one-GPU box: a clear non-zero exit, not a hang and not a mislabelled line."""
-    import torch
-    if torch.cuda.device_count() >= 2:
+    import subprocess
+    import sys
+    # (torch is asked in a child: importing it into the test process next to the OpenMP oracle and the HIP library ends the
+    # interpreter with a double free at exit)
+    n_dev = int(subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True,
+                               timeout=300).stdout.strip() or 0)
+    if n_dev >= 2:
         pytest.skip("this box has two GPUs: the refusal cannot be provoked")
     r = _run_bench(["--gpus", "2", "--poses", "6000", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], timeout=300)
     assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

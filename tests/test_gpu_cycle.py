@@ -85,6 +85,10 @@ def test_full_cycle_parity_other_maps(seed):
     d = rg["poses"].astype(np.float64) - ro["poses"]
     d[:, 2] = np.angle(np.exp(1j * d[:, 2]))
     assert np.abs(d[:, :2]).max() < 1e-4 and np.abs(d[:, 2]).max() < 1e-4
+    # the display clouds of the cycle's last step (transformPointCloudsToWorldFrame): page-locked buffers the Solver keeps,
+    # bit for bit the pageable-memory form at the same poses
+    wx, wy = g.transform_scans(rg["poses"])
+    assert np.array_equal(rg["world"][0].view(np.uint32), wx.view(np.uint32)) and np.array_equal(rg["world"][1].view(np.uint32), wy.view(np.uint32))
     g.close(); o.close()
 
 

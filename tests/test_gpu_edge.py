@@ -285,3 +285,43 @@ def test_linearisation_kernels_on_awkward_pair_lists(variant, monkeypatch):
         assert np.abs(rg - ro).max() <= 1e-11 * np.abs(ro).max() and np.abs(jg - jo).max() <= 1e-9 * np.abs(jo).max()
         assert abs(cg - co) <= 1e-10 * co and np.abs(gg - go).max() <= 1e-9 * np.abs(go).max()
         g.close(); o.close()
+
+
+_SWITCHES = [
+    {}, {"HITL_TIMING": "1"}, {"HITL_EVENT_SYNC": "1"}, {"HITL_CR_LEGACY": "1"}, {"HITL_CR_UNFUSED_BUILD": "1"}, {"HITL_STF_ADDR64": "1"},
+    {"HITL_DEVICE_LM": "1"}, {"HITL_DEVICE_LM": "1", "HITL_LM_AHEAD": "1"}, {"HITL_FORCE_DIST": "1"}, {"HITL_ROCTX": "1"},
+    {"HITL_STF_VARIANT": "500"}, {"HITL_STF_VARIANT": "501"}, {"HITL_STF_VARIANT": "26"}, {"HITL_STF_VARIANT": "106"}, {"HITL_STF_VARIANT": "300"},
+    {"HITL_STF_VARIANT": "300", "HITL_STF_WAVES_PER_CU": "5"}, {"HITL_STF_VARIANT": "400"}, {"HITL_STF_VARIANT": "400", "HITL_STF_WAVES_PER_CU": "2"},
+    {"HITL_STF_VARIANT": "600"}, {"HITL_STF_VARIANT": "700"},
+    {"HITL_KD_BLOCK": "64"}, {"HITL_KD_BLOCK": "128", "HITL_KD_REFILL": "4"}, {"HITL_KD_CAP": "1"}, {"HITL_KD_CAP": "2", "HITL_KD_REDO_CAP": "8"},
+    {"HITL_CAND_TILE_BYTES": "200000"}, {"HITL_CR_PLAN": "2,4,0"}, {"HITL_CR_THREADS": "256"},
+    # several at once: the switches nobody would combine on purpose
+    {"HITL_TIMING": "1", "HITL_EVENT_SYNC": "1", "HITL_CR_UNFUSED_BUILD": "1", "HITL_STF_VARIANT": "300", "HITL_KD_BLOCK": "64", "HITL_KD_CAP": "2",
+     "HITL_CAND_TILE_BYTES": "300000", "HITL_ROCTX": "1"},
+    {"HITL_DEVICE_LM": "1", "HITL_CR_THREADS": "256", "HITL_STF_ADDR64": "1", "HITL_KD_REFILL": "32", "HITL_STF_VARIANT": "500"},
+    {"HITL_CR_LEGACY": "1", "HITL_STF_VARIANT": "400", "HITL_KD_BLOCK": "128", "HITL_EVENT_SYNC": "1"},
+]
+
+
+@pytest.mark.parametrize("env", _SWITCHES, ids=lambda e: ",".join("%s=%s" % (k[5:], v) for k, v in sorted(e.items())) or "none")
+def test_every_development_switch_still_solves_like_the_oracle(env, monkeypatch):
+    """The HITL_* environment switches of the library (A/B measurement aids, read once at hitl_solver_create):
+    under each of them, and under combinations nobody tests on purpose, the search returns the oracle's index sets and the solve
+    walks the oracle's LM path (a surface nobody tested in combination)."""
+    import hitl_slam_amd as H
+    from oracle import hitl_oracle as O
+    for k in ("HITL_TIMING", "HITL_EVENT_SYNC", "HITL_CR_LEGACY", "HITL_CR_UNFUSED_BUILD", "HITL_STF_ADDR64", "HITL_DEVICE_LM", "HITL_LM_AHEAD",
+              "HITL_FORCE_DIST", "HITL_ROCTX", "HITL_STF_VARIANT", "HITL_STF_WAVES_PER_CU", "HITL_KD_BLOCK", "HITL_KD_REFILL", "HITL_KD_CAP",
+              "HITL_KD_REDO_CAP", "HITL_CAND_TILE_BYTES", "HITL_CR_PLAN", "HITL_CR_THREADS"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    prob = Problem(150, 64, ppf=50, groups=3, kind=0)
+    g, o = prob.load(H.Solver()), prob.load(O.OracleSolver())
+    g.find_correspondences(prob.init, 3)
+    o.find_correspondences(prob.init, 3, 1)
+    for a, b in zip(g.get_correspondences(), o.get_correspondences()):
+        assert np.array_equal(a, b)
+    for mode in (H.MODE_ODOM_HC, H.MODE_JOINT):
+        _check(g, o, mode, prob.init)
+    g.close(); o.close()

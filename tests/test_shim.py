@@ -104,3 +104,20 @@ def test_shim_map_fingerprint_sees_every_bit_and_stays_off_the_critical_path(tmp
           % (serial, threaded, floor_ms))
     # memory-bound: within 2.5x of reading the bytes at all on whatever host this runs (this container gives threads nothing)
     assert min(float(serial), float(threaded)) < 2.5 * float(floor_ms) + 5.0
+
+
+@pytest.mark.gpu
+def test_shim_run_cost_at_the_quoted_size(tmp_path):
+    """What JointOpt::Run (the shim) costs its caller at 50 000 poses x 400 observations in mode A, map upload and steady state:
+    the number INTEGRATION.md quotes (the content fingerprint runs on every call and appeared in no measurement)."""
+    exe = str(tmp_path / "shim_hash_driver")
+    subprocess.check_call(["g++", "-std=c++11", "-O2", "-Wall", "-pthread", "-I", os.path.join(ROOT, "include"), "-I",
+                           os.path.join(ROOT, "hitl_slam_amd", "shim"), os.path.join(ROOT, "tests", "shim_hash_driver.cpp"), "-o", exe,
+                           "-L", CSRC, "-lhitlgpu", "-Wl,-rpath," + CSRC, "-Wl,-rpath,/opt/rocm/lib"])
+    r = subprocess.run([exe, "50000", "400", "run"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("run_first_ms")][0].split()
+    vals = dict(zip(line[0::2], line[1::2]))
+    print("shim Run() at 50 000 x 400, mode A:", vals, "| hash line:", r.stdout.splitlines()[-1])
+    assert float(vals["run_steady_ms"]) < float(vals["run_first_ms"])              # the map did not go up again
+    assert float(vals["fingerprint_ms"]) < 0.5 * float(vals["run_steady_ms"]) + 20.0

@@ -6,7 +6,9 @@ the distributed result must equal the oracle's GLOBAL solve on the same correspo
 
   band1   : window 3 with the band capped at 1 pose -> pairs at distance 2 and 3 are off the band, inside and across the cuts
   allpairs: two ranks, each holding the whole map (halo = the other rank's range), all-pairs search: the reference's own
-            configuration on a single corridor, where poses see each other far beyond any band"""
+            configuration on a single corridor, where poses see each other far beyond any band
+  *_replicated_3ranks: three ranks with REPLICATED SCANS (hitl_solver_set_partition_range, halo < 0): every rank holds the
+            whole map and owns the rows of its pose range, so a pair may reach any distance across both cuts"""
 import json
 import os
 import subprocess
@@ -28,6 +30,10 @@ CASES = {
     "band1_floor_cut": (2, 60, 6, 3, 1, 30),
     "allpairs_replicated": (2, 12, 12, 0, 4, 24),
     "band1_uneven_3ranks": (3, 40, 6, 3, 1, 120),      # ranks own 23, 60 and 37 poses (HITL_TEST_CUTS below)
+    # replicated scans (halo < 0, round 4): pose pairs that reach deeper across the cuts than any halo, on three ranks --
+    # the reference's all-pairs loop over a single corridor, and a window of 8 poses with the band capped at 1
+    "allpairs_replicated_3ranks": (3, 8, -1, 0, 4, 24),
+    "window8_replicated_3ranks": (3, 30, -1, 8, 1, 90),
 }
 CUTS = {"band1_uneven_3ranks": "0,23,83,120"}
 
