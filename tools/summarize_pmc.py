@@ -11,7 +11,7 @@ vals = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(out, "p*", "*", "*counter_collection.csv")):
     for row in csv.DictReader(open(f)):
         vals[row["Kernel_Name"].split("(")[0]][row["Counter_Name"]].append(float(row["Counter_Value"]))
-keep = ["k_linearize_stf<", "k_cr_level", "k_cr_top_lds", "k_assemble", "k_match", "k_cr_backward_tree", "k_linearize_stf_moments", "k_cr_chunk", "k_spmv", "k_kd_build"]
+keep = ["k_linearize_stf", "k_cr_level", "k_cr_top_lds", "k_assemble", "k_match", "k_cr_backward_tree", "k_linearize_stf_moments", "k_cr_chunk", "k_spmv", "k_kd_build"]
 ctrs = sorted({c for k in vals for c in vals[k]})
 print("# PMC counters, mean per dispatch (%s)\n" % out)
 print("| kernel | dispatches | " + " | ".join(ctrs) + " |")
@@ -22,7 +22,7 @@ for k in sorted(vals):
     n = max(len(v) for v in vals[k].values())
     print("| %s | %d | " % (k[:48], n) + " | ".join(("%.4g" % (sum(vals[k][c]) / len(vals[k][c])) if vals[k].get(c) else "-") for c in ctrs) + " |")
 for k in vals:
-    if "k_linearize_stf<" in k:
+    if "k_linearize_stf" in k and "moments" not in k:
         v = {c: sum(x) / len(x) for c, x in vals[k].items()}
         print("\n## k_linearize_stf, derived\n")
         if "SQ_WAVE_CYCLES" in v:
