@@ -431,7 +431,7 @@ __global__ __launch_bounds__(kStfBlock, MINB) void k_linearize_stf_r(MapView map
     const double xj = x[3 * j], yj = x[3 * j + 1];
     const double2 cs1 = cs[j];
     uint32_t mo = (m_begin32 + (uint32_t)hl) << 2;
-#define HITL_RIDX(k) __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(mtb + (mo + 4u * (uint32_t)(k))))   /* streamed once: keep L2 for the scans */
+#define HITL_RIDX(k) (*reinterpret_cast<const uint32_t*>(mtb + (mo + 4u * (uint32_t)(k))))
     uint32_t ua = HITL_RIDX(0), ub = HITL_RIDX(kStfSub);
     if (!staged) { __syncthreads(); staged = true; }    // the source scan is in LDS
     const double ddx = xj - xi, ddy = yj - yi;
