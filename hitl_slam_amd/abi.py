@@ -116,7 +116,8 @@ class Summary(C.Structure):
         ("linear_solver_ms", C.c_double),
         ("linearize_calls", C.c_int32),
         ("linearize_timed_calls", C.c_int32),
-        ("reserved", C.c_double * 6),
+        ("submap_linear_solver", C.c_double),
+        ("reserved", C.c_double * 5),
     ]
 
     def as_dict(self):

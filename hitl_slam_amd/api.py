@@ -659,13 +659,14 @@ def comm_unique_id(lib_path=None):
     return buf.raw
 
 
-def partition_range(obs_offset, rank, world_size, lib_path=None):
-    """Pose range [begin, end) owned by `rank` (host-only; no GPU needed)."""
+def partition_range(obs_offset, rank, world_size, lib_path=None, align=1):
+    """Pose range [begin, end) owned by `rank` (host-only; no GPU needed).  align > 1: cuts on multiples of `align` poses, which
+    lets the ranks' linear solves take the separator form when `align` is a multiple of the pose band."""
     lib = load_library(lib_path)
     off = _as(obs_offset, np.int64)
     b, e = C.c_int64(), C.c_int64()
-    lib.hitl_partition_range.argtypes = [C.c_int64, _i64p, C.c_int32, C.c_int32, _i64p, _i64p]
-    st = lib.hitl_partition_range(len(off) - 1, _ptr(off, _i64p), rank, world_size, C.byref(b), C.byref(e))
+    lib.hitl_partition_range_aligned.argtypes = [C.c_int64, _i64p, C.c_int32, C.c_int32, C.c_int32, _i64p, _i64p]
+    st = lib.hitl_partition_range_aligned(len(off) - 1, _ptr(off, _i64p), rank, world_size, int(align), C.byref(b), C.byref(e))
     if st != abi.OK:
         raise HitlError(st, "hitl_partition_range")
     return b.value, e.value

@@ -668,6 +668,10 @@ static int cr_top_start(int nsb, int B, int nrhs) {
 //     P_a = L_u^T Gl   (into the slot of L_u)     P_b = L_b Gr   (into the slot of D_u)     L_b <- -L_b Gl
 // plus Gl^T w_u, Gr^T w_u; after one barrier the survivors subtract what their two neighbours left for them.
 // ===========================================================================================
+// where stage node sn lives in D / L / w / x: at sn * S -- except the right separator of a submap rank's chain (cr.rsep), which is
+// stage node nst - 1 of every stage and stays at its true index nsb - 1  (needs `cr`, `S` and `rsep_sn` in scope)
+#define CR_ADDR(sn) (((sn) == rsep_sn) ? (int64_t)cr.nsb - 1 : (int64_t)(sn) * S)
+
 struct CrStage {
   int S;          // global stride of this stage's nodes
   int M;          // nodes per chunk (power of two); local node u <-> global node (chunk * M + u) * S
@@ -737,9 +741,15 @@ void k_cr_chunk(CrView cr, CrStage sg_in, CrSource src, double* w, double* x) {
   const int wave = tid >> 6, lane = tid & 63, NW = nthr >> 6;
   CR_PROBE(0);
   const int64_t base = (int64_t)blockIdx.x * M;            // in stage nodes
-  const int64_t nst = ((int64_t)cr.nsb + S - 1) / S;       // stage nodes alive: 0 .. nst-1
+  const int64_t nst = cr_stage_nodes(cr, S);               // stage nodes alive: 0 .. nst-1
   // local slots that exist: u with base + u < nst
   const int u_last = (int)((nst - 1 - base < M) ? (nst - 1 - base) : M);     // >= 0
+  // The chunk's right boundary (never eliminated here): local node M of a full chunk -- or, on a chain whose last node is a
+  // separator (cr.rsep), the last node wherever it falls: it sits in slot u_last of the last chunk, lives at its true index
+  // nsb - 1, and is the right neighbour of every eliminated node whose regular one (u + s) would lie beyond it.
+  const bool has_rb = (u_last == M) || (cr.rsep != 0);
+  const bool last_is_rb = has_rb && (base + u_last == nst - 1);
+  const int64_t rsep_sn = cr.rsep ? nst - 1 : -1;
   const bool has_w = KIND == 1 || ((w != nullptr) && NR > 0);
   const bool from_src = KIND == 1 || src.Hband != nullptr;   // host: only with S == 1, no previous stage
   const size_t pws = (size_t)4 * sg.np * B;               // doubles of one right-hand side's contribution arrays
@@ -782,13 +792,13 @@ void k_cr_chunk(CrView cr, CrStage sg_in, CrSource src, double* w, double* x) {
   for (int e = tid; e < (u_last + 1) * BB; e += nthr) {
     const int u = e / BB, q = e % BB;
     const int64_t sn = base + u;                           // stage node index == slot of the previous stage's arrays
-    const size_t g = (size_t)(sn * S) * BB + q;
+    const size_t g = (size_t)CR_ADDR(sn) * BB + q;
     double d, l;
     if (from_src) {
       // first stage straight from the band blocks (k_build_system's arithmetic): only the nodes that outlive this stage
       // -- the chunk boundaries -- need their D in memory, where the next stage folds the contributions into it
       cr_source_tile_rec(sRec, src_rl, src_p0, src.n_poses, Wb, src.mu, src.min_diag, src.max_diag, B, (int)sn, q, d, l);
-      if (u == 0 || (u == M && sn == nst - 1)) cr.D[g] = d;
+      if (u == 0 || (last_is_rb && u == u_last)) cr.D[g] = d;
     } else {
       d = cr.D[g];
       l = cr.L[g];
@@ -798,7 +808,7 @@ void k_cr_chunk(CrView cr, CrStage sg_in, CrSource src, double* w, double* x) {
     sL[e] = l;
     // A boundary node stays alive: keep its folded value where the next stage reads it.  Every boundary is local node 0 of
     // one chunk -- except the very last node when it is local node M of the last chunk (no chunk on its right).
-    if ((u == 0 || (u == M && sn == nst - 1)) && sg.has_prev && !sg.top) cr.D[g] = d;
+    if ((u == 0 || (last_is_rb && u == u_last)) && sg.has_prev && !sg.top) cr.D[g] = d;
   }
   CR_PROBE(2);
   if (from_src) lds_barrier();                            // the staging area is overwritten from here on
@@ -814,7 +824,7 @@ void k_cr_chunk(CrView cr, CrStage sg_in, CrSource src, double* w, double* x) {
       const int rv = e / ((u_last + 1) * B), e2 = e % ((u_last + 1) * B);
       const int u = e2 / B, q = e2 % B;
       const int64_t sn = base + u;
-      const size_t g = sg.wstride * rv + (size_t)(sn * S) * B + q;
+      const size_t g = sg.wstride * rv + (size_t)CR_ADDR(sn) * B + q;
       double v;
       if (from_src) {
         // right-hand side 0: -S g, kept for the back-substitution and the caller; the others: unit vectors (submap interface columns)
@@ -824,21 +834,21 @@ void k_cr_chunk(CrView cr, CrStage sg_in, CrSource src, double* w, double* x) {
       } else v = w[g];
       if (sg.has_prev) v = (v - WLp[pws * rv + (size_t)sn * B + q]) - WRp[pws * rv + (size_t)sn * B + q];
       sW[((size_t)rv * nsl + u) * B + q] = v;
-      if (sg.has_prev && (u == 0 || u == M) == false) w[g] = v;          // interior: the back-substitution reads the folded w
-      if ((u == 0 || (u == M && sn == nst - 1)) && sg.has_prev && !sg.top) w[g] = v;
+      if (sg.has_prev && (u == 0 || (has_rb && u == u_last)) == false) w[g] = v;          // interior: the back-substitution reads the folded w
+      if ((u == 0 || (last_is_rb && u == u_last)) && sg.has_prev && !sg.top) w[g] = v;
     }
   for (int e = tid; e < 2 * BB + 2 * NR * B; e += nthr) accR[e] = 0.0;   // accR, accL, accWR, accWL are contiguous
   lds_barrier();
   CR_PROBE(3);
   int probe_slot = 4; (void)probe_slot;
-  const int u_hi = sg.top ? u_last : ((u_last < M) ? u_last : M - 1);    // largest local node that may be eliminated
+  const int u_hi = (!sg.top && has_rb) ? u_last - 1 : u_last;            // largest local node that may be eliminated
   for (int s = 1; s < M; s *= 2) {
     // ---- eliminate u = s, 3s, 5s .. <= u_hi ----
     for (int q = wave;; q += NW) {
       const int u = s * (2 * q + 1);
       if (u > u_hi) break;
-      const int b = u + s;
-      const bool has_b = (b <= u_last) && (sg.top ? true : true);
+      const int b = (has_rb && u + s > u_last) ? u_last : u + s;
+      const bool has_b = (b <= u_last);
       const int grp = lane / B, c = lane % B;
       double* Du = sD + (size_t)u * BB;
       double* Lu = sL + (size_t)u * BB;
@@ -936,28 +946,39 @@ void k_cr_chunk(CrView cr, CrStage sg_in, CrSource src, double* w, double* x) {
     lds_barrier();
     CR_PROBE(probe_slot++);
     // ---- survivors j = 0, 2s, 4s .. subtract what their eliminated neighbours left (left one first) ----
+    // (the last entry of the enumeration is the chunk's right boundary: j = M in a full chunk, slot u_last on a separator
+    // chain; the node that left something for it at this level -- if any -- is the last multiple of s below it when that is an
+    // ODD multiple: M - s in a full chunk)
     const int nsv = M / (2 * s) + 1;
+    const int rb_t = has_rb ? (u_last - 1) / s : 0;
+    const int rb_u = rb_t * s;                                                     // >= 1 whenever rb_t is odd
     for (int e = tid; e < nsv * BB; e += nthr) {
-      const int j = 2 * s * (e / BB), q = e % BB;
-      if (j > u_last) continue;
-      const bool hl_ = (j - s >= 1), hr_ = (j + s <= u_hi) && (j + s < M || sg.top);
-      const double pl = hl_ ? sL[(size_t)(j - s) * BB + q] : 0.0;                  // P_b of the left neighbour
+      const int idx = e / BB, q = e % BB;
+      const bool isb = has_rb && idx == nsv - 1;
+      const int j = isb ? u_last : 2 * s * idx;
+      if (!isb && j >= u_last + (has_rb ? 0 : 1)) continue;
+      const bool hl_ = isb ? ((rb_t & 1) != 0) : (j - s >= 1);
+      const bool hr_ = !isb && (j + s <= u_hi) && (j + s < M || sg.top);
+      const double pl = hl_ ? sL[(size_t)(isb ? rb_u : j - s) * BB + q] : 0.0;     // P_b of the left neighbour
       const double pr = hr_ ? sD[(size_t)(j + s) * BB + q] : 0.0;                  // P_a of the right neighbour
-      if (j == 0) accR[q] += pr;
-      else if (j == M) accL[q] += pl;
+      if (isb) accL[q] += pl;
+      else if (j == 0) accR[q] += pr;
       else sD[(size_t)j * BB + q] = (sD[(size_t)j * BB + q] - pl) - pr;
     }
     if (has_w)
       for (int e = tid; e < NR * nsv * B; e += nthr) {
         const int rv = e / (nsv * B), e2 = e % (nsv * B);
-        const int j = 2 * s * (e2 / B), q = e2 % B;
-        if (j > u_last) continue;
-        const bool hl_ = (j - s >= 1), hr_ = (j + s <= u_hi) && (j + s < M || sg.top);
+        const int idx = e2 / B, q = e2 % B;
+        const bool isb = has_rb && idx == nsv - 1;
+        const int j = isb ? u_last : 2 * s * idx;
+        if (!isb && j >= u_last + (has_rb ? 0 : 1)) continue;
+        const bool hl_ = isb ? ((rb_t & 1) != 0) : (j - s >= 1);
+        const bool hr_ = !isb && (j + s <= u_hi) && (j + s < M || sg.top);
         const size_t vb = (size_t)rv * nsl;
-        const double pl = hl_ ? sCb[(vb + (j - s)) * B + q] : 0.0;
+        const double pl = hl_ ? sCb[(vb + (isb ? rb_u : j - s)) * B + q] : 0.0;
         const double pr = hr_ ? sCa[(vb + (j + s)) * B + q] : 0.0;
-        if (j == 0) accWR[(size_t)rv * B + q] += pr;
-        else if (j == M) accWL[(size_t)rv * B + q] += pl;
+        if (isb) accWL[(size_t)rv * B + q] += pl;
+        else if (j == 0) accWR[(size_t)rv * B + q] += pr;
         else sW[(vb + j) * B + q] = (sW[(vb + j) * B + q] - pl) - pr;
       }
     lds_barrier();
@@ -980,8 +1001,8 @@ void k_cr_chunk(CrView cr, CrStage sg_in, CrSource src, double* w, double* x) {
     for (int e = tid; e < BB; e += nthr) {
       PRn[c0 * BB + e] = accR[e];
       if (blockIdx.x == 0) PLn[e] = 0.0;                                           // node 0 has no chunk on its left
-      if (u_last == M) { PLn[c1 * BB + e] = accL[e]; cr.L[(size_t)((base + M) * S) * BB + e] = sL[(size_t)M * BB + e]; }
-      if (u_last == M && base + M == nst - 1) PRn[c1 * BB + e] = 0.0;              // the last node has no chunk on its right
+      if (has_rb) { PLn[c1 * BB + e] = accL[e]; cr.L[(size_t)CR_ADDR(base + u_last) * BB + e] = sL[(size_t)u_last * BB + e]; }
+      if (last_is_rb) PRn[c1 * BB + e] = 0.0;                                      // the last node has no chunk on its right
     }
     if (has_w)
       for (int e2 = tid; e2 < NR * B; e2 += nthr) {
@@ -989,8 +1010,8 @@ void k_cr_chunk(CrView cr, CrStage sg_in, CrSource src, double* w, double* x) {
         const size_t vo = pws * rv;
         WRn[vo + c0 * B + e] = accWR[e2];
         if (blockIdx.x == 0) WLn[vo + e] = 0.0;
-        if (u_last == M) WLn[vo + c1 * B + e] = accWL[e2];
-        if (u_last == M && base + M == nst - 1) WRn[vo + c1 * B + e] = 0.0;
+        if (has_rb) WLn[vo + c1 * B + e] = accWL[e2];
+        if (last_is_rb) WRn[vo + c1 * B + e] = 0.0;
       }
     CR_PROBE(probe_slot++);
     return;
@@ -1050,10 +1071,12 @@ __global__ __launch_bounds__(1024) void k_cr_chunk_back(CrView cr, int S, int M,
   w += wstride * rv;
   x += wstride * rv;
   const int64_t base = (int64_t)chunk * M;
-  const int64_t nst = ((int64_t)cr.nsb + S - 1) / S;
+  const int64_t nst = cr_stage_nodes(cr, S);
   const int u_last = (int)((nst - 1 - base < M) ? (nst - 1 - base) : M);
+  const bool has_rb = !top && ((u_last == M) || (cr.rsep != 0));     // see k_cr_chunk: the right boundary sits in slot u_last
+  const int64_t rsep_sn = cr.rsep ? nst - 1 : -1;
   const int u = 1 + tid / B, r = tid % B;
-  const bool mine = (u < M || top) && u <= u_last && (tid < (M - (top ? 0 : 1)) * B) && u <= M;
+  const bool mine = u <= (has_rb ? u_last - 1 : u_last) && (tid < (M - (top ? 0 : 1)) * B) && u <= M;
   double gl[B], gr[B], v = 0.0;
 #pragma unroll
   for (int c = 0; c < B; ++c) { gl[c] = 0.0; gr[c] = 0.0; }
@@ -1069,18 +1092,19 @@ __global__ __launch_bounds__(1024) void k_cr_chunk_back(CrView cr, int S, int M,
   for (int e = tid; e < (M + 1) * B; e += blockDim.x) sx[e] = 0.0;
   __syncthreads();
   if (tid < 2 * B) {                                      // the two boundary nodes (known)
-    const int ub = (tid < B) ? 0 : M, rr = tid % B;
-    if (ub <= u_last && !(top && ub == M)) sx[(size_t)ub * B + rr] = x[(size_t)((base + ub) * S) * B + rr];
+    const int ub = (tid < B) ? 0 : u_last, rr = tid % B;
+    if (tid < B || has_rb) sx[(size_t)ub * B + rr] = x[(size_t)CR_ADDR(base + ub) * B + rr];
   }
   __syncthreads();
   for (int s = M / 2; s >= 1; s /= 2) {
     if (mine && (u & (2 * s - 1)) == s) {                 // u is eliminated at local stride s
+      const int b = (has_rb && u + s > u_last) ? u_last : u + s;
       const double* xl = sx + (size_t)(u - s) * B;
-      const double* xr = sx + (size_t)((u + s <= M) ? (u + s) : u) * B;
+      const double* xr = sx + (size_t)((b <= M) ? b : u) * B;
       double acc = v;
 #pragma unroll
       for (int c = 0; c < B; ++c) acc -= gl[c] * xl[c];
-      if (u + s <= M) {
+      if (b <= M) {
 #pragma unroll
         for (int c = 0; c < B; ++c) acc -= gr[c] * xr[c];   // zero-filled beyond the last node; Gr is zero there too
       }
@@ -1216,7 +1240,8 @@ static int cr_chunk_threads(int M, int B, int stage = 1) {
 // faster: a node costs a whole wave's instruction stream either way; chunks of 4 or 8 at 2 waves per workgroup: 56 / 68 us for
 // the first stage against 54 us for chunks of 16.)  HITL_CR_PLAN="2,2,16,32" (development) overrides
 // the chunk sizes of the first stages.
-static CrPlan cr_plan(int nsb, int B, int np, int nrhs, size_t wstride) {
+static CrPlan cr_plan(const CrView& crv, int B, int np, int nrhs, size_t wstride) {
+  const int nsb = crv.nsb; (void)nsb;
   CrPlan pl;
   pl.n = 0;
   const size_t lds_cap = 128 * 1024;
@@ -1224,7 +1249,7 @@ static CrPlan cr_plan(int nsb, int B, int np, int nrhs, size_t wstride) {
   int S = 1, par = 0;
   bool prev = false;
   for (;;) {
-    const int64_t alive = ((int64_t)nsb + S - 1) / S;
+    const int64_t alive = cr_stage_nodes(crv, S);
     int Mtop = 2;
     while (Mtop < alive) Mtop *= 2;                        // interior u = 1 .. alive-1 < Mtop
     // the top takes every remaining node in one workgroup: up to 40 of them (128 of the 3 x 3 tiles of the one-pose band: seven
@@ -1232,7 +1257,8 @@ static CrPlan cr_plan(int nsb, int B, int np, int nrhs, size_t wstride) {
     const bool fits_top = alive <= (B == 3 ? 128 : 40) && cr_chunk_lds_bytes((int)alive, B, cr_chunk_threads(64, B), nrhs) <= lds_cap;
     CrStage& g = pl.st[pl.n++];
     g.S = S; g.has_prev = prev ? 1 : 0; g.prev_par = par; g.next_par = par ^ 1; g.np = np; g.nrhs = nrhs; g.wstride = wstride;
-    if (fits_top || pl.n == 8) { g.M = Mtop; g.top = 1; g.nsl = (int)alive + 1; break; }
+    // (a separator chain ends in an ordinary chunk -- both ends stay -- that holds every remaining node)
+    if (fits_top || pl.n == 8) { g.M = Mtop; g.top = crv.rsep ? 0 : 1; g.nsl = (int)alive + 1; break; }
     int M = (pl.n == 1) ? 16 : 32;       // measured on C4 (tools/cr_plans.sh): 16,32,top = 111 us; 2,2,16,.. = 117; 2,2,2,32,.. = 125
     if (cr_chunk_lds_bytes(M, B, cr_chunk_threads(M, B), nrhs) > lds_cap) M = 16;      // many right-hand sides (submap solve): smaller chunks
     if (cr_chunk_lds_bytes(M, B, cr_chunk_threads(M, B), nrhs) > lds_cap) M = 8;
@@ -1249,7 +1275,7 @@ int cr_contrib_slots(int nsb) { return nsb / 2 + 3; }     // boundary nodes of t
 // first launch, so a `false` never leaves half a factorisation behind for the level-per-launch fallback.
 template <int B>
 static bool cr_factor_fused(hipStream_t st, const CrView& cr, double* w, double* x, int nrhs, size_t wstride, const CrSource* src = nullptr,
-                            bool validate = false) {
+                            bool validate = false, int phase = 3 /* 1: the forward stages only, 2: the back-substitution only */) {
   if (cr.P == nullptr || cr.Pw == nullptr) return false;
   if (w == nullptr) nrhs = 0;
   if (src != nullptr && (x == nullptr || nrhs != 1 + src->n_unit)) return false;
@@ -1260,7 +1286,7 @@ static bool cr_factor_fused(hipStream_t st, const CrView& cr, double* w, double*
              hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cr_chunk<B, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess;
     if (!raised) { (void)hipGetLastError(); return false; }
   }
-  const CrPlan pl = cr_plan(cr.nsb, B, cr.np, nrhs, wstride);
+  const CrPlan pl = cr_plan(cr, B, cr.np, nrhs, wstride);
   for (int t = 0; t < pl.n; ++t) {                        // every stage must fit its LDS budget, else the level-per-launch path
     const CrStage& g = pl.st[t];
     if (g.M < 2 || g.M > (B == 3 ? 128 : 64) || (g.M & (g.M - 1)) != 0) return false;   // a forced plan (HITL_CR_PLAN) with an unusable chunk size
@@ -1272,23 +1298,24 @@ static bool cr_factor_fused(hipStream_t st, const CrView& cr, double* w, double*
     if (bthr > 1024) return false;                                           // never with M <= 64, B <= 12 (or M = 128, B = 3)
   }
   if (validate) return true;
-  for (int t = 0; t < pl.n; ++t) {
+  for (int t = 0; t < pl.n && (phase & 1); ++t) {
     const CrStage& g = pl.st[t];
-    const int64_t alive = ((int64_t)cr.nsb + g.S - 1) / g.S;
+    const int64_t alive = cr_stage_nodes(cr, g.S);
     const int chunks = g.top ? 1 : (int)((alive - 1 + g.M - 1) / g.M);       // chunks with at least one interior or boundary-M node
     const int thr = cr_chunk_threads(g.M, B, t);
     const bool use_src = (src != nullptr && t == 0);
     const size_t lds = cr_chunk_lds_bytes(g.nsl - 1, B, thr, nrhs) + (use_src ? cr_chunk_src_extra(g.nsl, B, thr, src->Wb, nrhs) : 0);
     CrSource none = {};
-    if (use_src && nrhs == 1 && !g.top && !g.has_prev && g.S == 1 && thr <= 512 && 3 * src->Wb == B && (g.M + 1) * B <= thr)
+    if (use_src && nrhs == 1 && !g.top && !g.has_prev && g.S == 1 && thr <= 512 && 3 * src->Wb == B && (g.M + 1) * B <= thr &&
+        !(cr.rsep && t == pl.n - 1))
       hipLaunchKernelGGL((k_cr_chunk<B, 1>), dim3(chunks > 0 ? chunks : 1), dim3(thr), lds, st, cr, g, *src, w, x);
     else
       hipLaunchKernelGGL((k_cr_chunk<B, 0>), dim3(chunks > 0 ? chunks : 1), dim3(thr), lds, st, cr, g, use_src ? *src : none, w, x);
   }
-  if (w != nullptr && x != nullptr) {
+  if (w != nullptr && x != nullptr && (phase & 2)) {
     for (int t = pl.n - 1; t >= 0; --t) {
       const CrStage& g = pl.st[t];
-      const int64_t alive = ((int64_t)cr.nsb + g.S - 1) / g.S;
+      const int64_t alive = cr_stage_nodes(cr, g.S);
       if (alive <= 1) continue;
       const int chunks = g.top ? 1 : (int)((alive - 1 + g.M - 1) / g.M);
       int thr = (g.M - (g.top ? 0 : 1)) * B;
@@ -1309,10 +1336,11 @@ static bool cr_solve_fused(hipStream_t st, const CrView& cr, const double* w_in,
     raised = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cr_chunk_fwd<B>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess;
     if (!raised) { (void)hipGetLastError(); return false; }
   }
-  const CrPlan pl = cr_plan(cr.nsb, B, cr.np, 1, 0);
+  if (cr.rsep) return false;
+  const CrPlan pl = cr_plan(cr, B, cr.np, 1, 0);
   for (int t = 0; t < pl.n; ++t) {
     const CrStage& g = pl.st[t];
-    const int64_t alive = ((int64_t)cr.nsb + g.S - 1) / g.S;
+    const int64_t alive = cr_stage_nodes(cr, g.S);
     const int chunks = g.top ? 1 : (int)((alive - 1 + g.M - 1) / g.M);
     const size_t lds = sizeof(double) * ((size_t)g.nsl * (2 * B * B + 3 * B) + 2 * B);
     if (lds > 128 * 1024) return false;
@@ -1492,6 +1520,131 @@ void launch_cr_solve(hipStream_t st, const CrView& cr, const double* rhs, double
     if (rhs != w) (void)hipMemcpyAsync(w, rhs, sizeof(double) * (size_t)cr.nsb * cr.B, hipMemcpyDeviceToDevice, st);
     launch_cr_solve_multi(st, cr, w, x, 1, 0);
   }
+}
+
+// ===========================================================================================
+// Submap ranks, separator form: see hitl_internal.h.  The chain's fused stages run with chain.rsep = 1 (k_cr_chunk keeps the last
+// node as the right boundary of the last chunk of every stage; the last stage is an ordinary chunk holding every remaining node).
+// ===========================================================================================
+template <int B>
+static int cr_sep_last_parity(const CrView& chain) {
+  const CrPlan pl = cr_plan(chain, B, chain.np, 1, 0);
+  return pl.st[pl.n - 1].next_par;
+}
+
+bool cr_sep_applies(const CrView& chain, const CrSource& src, double* w, double* x) {
+  if (!chain.rsep || chain.nsb < 2 || dev_switches().cr_legacy || dev_switches().cr_unfused_build) return false;
+  switch (chain.B) {
+    case 3: return cr_factor_fused<3>(nullptr, chain, w, x, 1, 0, &src, true);
+    case 6: return cr_factor_fused<6>(nullptr, chain, w, x, 1, 0, &src, true);
+    case 9: return cr_factor_fused<9>(nullptr, chain, w, x, 1, 0, &src, true);
+    default: return cr_factor_fused<12>(nullptr, chain, w, x, 1, 0, &src, true);
+  }
+}
+
+void launch_cr_sep_forward(hipStream_t st, const CrView& chain, const CrSource& src, double* w, double* x) {
+  switch (chain.B) {
+    case 3: (void)cr_factor_fused<3>(st, chain, w, x, 1, 0, &src, false, 1); break;
+    case 6: (void)cr_factor_fused<6>(st, chain, w, x, 1, 0, &src, false, 1); break;
+    case 9: (void)cr_factor_fused<9>(st, chain, w, x, 1, 0, &src, false, 1); break;
+    default: (void)cr_factor_fused<12>(st, chain, w, x, 1, 0, &src, false, 1); break;
+  }
+}
+
+void launch_cr_sep_backward(hipStream_t st, const CrView& chain, double* w, double* x) {
+  switch (chain.B) {
+    case 3: (void)cr_factor_fused<3>(st, chain, w, x, 1, 0, nullptr, false, 2); break;
+    case 6: (void)cr_factor_fused<6>(st, chain, w, x, 1, 0, nullptr, false, 2); break;
+    case 9: (void)cr_factor_fused<9>(st, chain, w, x, 1, 0, nullptr, false, 2); break;
+    default: (void)cr_factor_fused<12>(st, chain, w, x, 1, 0, nullptr, false, 2); break;
+  }
+}
+
+// the rank's exchange record from what the forward stages left: D / w of F and R folded with the last stage's contributions (the
+// order every stage folds in: left chunk's first), the coupling R <-> F, the raw cross-cut block F x (the Wb poses below the cut)
+// and the Jacobi scales of the separators' poses (0 for a constant pose and for the padding rows of a short last block)
+__global__ void k_sep_record(CrView cr, int par, const double* __restrict__ w, const double* __restrict__ Hband, const double* __restrict__ scale,
+                             const unsigned char* __restrict__ fixed, SepGeom gm, double* __restrict__ rec) {
+  const int B = cr.B, BB = B * B, Wb = gm.Wb, W1 = Wb + 1;
+  const size_t np = (size_t)cr.np;
+  const double* PL = cr.P + (size_t)(par * 2 + 0) * np * BB;
+  const double* PR = cr.P + (size_t)(par * 2 + 1) * np * BB;
+  const double* WL = cr.Pw + (size_t)(par * 2 + 0) * np * B;
+  const double* WR = cr.Pw + (size_t)(par * 2 + 1) * np * B;
+  const size_t rn = (size_t)cr.nsb - 1;
+  for (int e = threadIdx.x; e < BB; e += blockDim.x) {
+    rec[e] = (cr.D[e] - PL[e]) - PR[e];
+    rec[BB + e] = (cr.D[rn * BB + e] - PL[BB + e]) - PR[BB + e];
+    rec[2 * BB + e] = cr.L[rn * BB + e];
+    const int a = e / B, b = e % B, ap = a / 3, r = a % 3, bp = b / 3, c = b % 3;
+    double v = 0.0;
+    const int i3 = gm.own_lo - Wb + bp, d = (Wb + ap) - bp;        // row pose own_lo + ap, column pose own_lo - Wb + bp
+    if (gm.rank > 0 && i3 >= 0 && d <= Wb && gm.own_lo + ap < gm.own_hi) v = Hband[((size_t)i3 * W1 + d) * 9 + c * 3 + r];
+    rec[3 * BB + e] = v;
+  }
+  for (int e = threadIdx.x; e < B; e += blockDim.x) {
+    rec[4 * BB + e] = (w[e] - WL[e]) - WR[e];
+    rec[4 * BB + B + e] = (w[rn * B + e] - WL[B + e]) - WR[B + e];
+    const int pf = gm.own_lo + e / 3, pr = gm.r_pose0 + e / 3;
+    rec[4 * BB + 2 * B + e] = (pf < gm.own_hi && !fixed[pf]) ? scale[3 * pf + e % 3] : 0.0;
+    rec[4 * BB + 3 * B + e] = (pr < gm.own_hi && !fixed[pr]) ? scale[3 * pr + e % 3] : 0.0;
+  }
+}
+
+void launch_sep_record(hipStream_t st, const CrView& chain, const double* w, const double* Hband_local, const double* scale_local,
+                       const unsigned char* fixed_local, const SepGeom& gm, double* rec) {
+  int par = 0;
+  switch (chain.B) {
+    case 3: par = cr_sep_last_parity<3>(chain); break;
+    case 6: par = cr_sep_last_parity<6>(chain); break;
+    case 9: par = cr_sep_last_parity<9>(chain); break;
+    default: par = cr_sep_last_parity<12>(chain); break;
+  }
+  hipLaunchKernelGGL(k_sep_record, dim3(1), dim3(192), 0, st, chain, par, w, Hband_local, scale_local, fixed_local, gm, rec);
+}
+
+// the chain of all ranks' separators: node 2g = F of rank g (coupled to R of rank g - 1 by its scaled cross-cut block), node
+// 2g + 1 = R of rank g (coupled to F by K)
+__global__ void k_sep_build(CrView red, const double* __restrict__ rec_all, int rec_len, double* __restrict__ w2) {
+  const int B = red.B, BB = B * B;
+  const int node = blockIdx.x, g = node >> 1, isR = node & 1;
+  const double* rc = rec_all + (size_t)rec_len * g;
+  const double* rp = rec_all + (size_t)rec_len * (g > 0 ? g - 1 : 0);
+  for (int e = threadIdx.x; e < BB; e += blockDim.x) {
+    red.D[(size_t)node * BB + e] = rc[isR ? BB + e : e];
+    double l;
+    if (isR) l = rc[2 * BB + e];
+    else l = (g > 0) ? rc[4 * BB + 2 * B + e / B] * rc[3 * BB + e] * rp[4 * BB + 3 * B + e % B] : 0.0;
+    red.L[(size_t)node * BB + e] = l;
+  }
+  for (int e = threadIdx.x; e < B; e += blockDim.x) w2[(size_t)node * B + e] = rc[4 * BB + isR * B + e];
+}
+
+__global__ void k_sep_scatter(int B, const double* __restrict__ rec_all, int rec_len, const double* __restrict__ x2, SepGeom gm,
+                              double* __restrict__ dt, double* __restrict__ scale) {
+  const int BB = B * B, me = gm.rank, Wb = gm.Wb;
+  for (int t = threadIdx.x; t < B; t += blockDim.x) {
+    dt[3 * gm.own_lo + t] = x2[(size_t)(2 * me) * B + t];
+    dt[3 * gm.r_pose0 + t] = x2[(size_t)(2 * me + 1) * B + t];
+  }
+  for (int t = threadIdx.x; t < 3 * gm.halo_lo; t += blockDim.x) {          // the last halo_lo poses of the previous rank's R
+    const int sc = 3 * (Wb - gm.halo_lo) + t, dst = 3 * (gm.own_lo - gm.halo_lo) + t;
+    dt[dst] = x2[(size_t)(2 * (me - 1) + 1) * B + sc];
+    scale[dst] = rec_all[(size_t)rec_len * (me - 1) + 4 * BB + 3 * B + sc];
+  }
+  for (int t = threadIdx.x; t < 3 * gm.halo_hi; t += blockDim.x) {          // the first halo_hi poses of the next rank's F
+    const int dst = 3 * gm.own_hi + t;
+    dt[dst] = x2[(size_t)(2 * (me + 1)) * B + t];
+    scale[dst] = rec_all[(size_t)rec_len * (me + 1) + 4 * BB + 2 * B + t];
+  }
+}
+
+void launch_sep_solve(hipStream_t st, const CrView& red, const double* rec_all, double* w2, double* x2, const SepGeom& gm, double* dt_local,
+                      double* scale_local) {
+  const int rl = sep_rec_len(red.B);
+  hipLaunchKernelGGL(k_sep_build, dim3(red.nsb), dim3(192), 0, st, red, rec_all, rl, w2);
+  launch_cr_factor_solve(st, red, w2, x2, 1, 0);
+  hipLaunchKernelGGL(k_sep_scatter, dim3(1), dim3(64), 0, st, red.B, rec_all, rl, x2, gm, dt_local, scale_local);
 }
 
 // ===========================================================================================

@@ -29,6 +29,7 @@ struct DevSwitches {
   bool stf_addr64 = false;         // HITL_STF_ADDR64: 64-bit addressing instantiations of k_linearize_stf
   bool force_dist = false;         // HITL_FORCE_DIST: one rank takes the submap code path
   bool force_rccl = false;         // HITL_FORCE_RCCL: in-library RCCL communicator with one rank
+  bool dist_columns = false;       // HITL_DIST_COLUMNS: submap ranks keep the interface-column form of the linear solve although the separator form applies
   bool device_lm = false;          // HITL_DEVICE_LM: accept / reject / terminate decided on the device (k_lm_decide), iterations queued ahead.
                                    // Measured (round 3): gap-free kernel timeline, but the decision kernel costs what the host turn-around
                                    // cost -- 4-8 us per iteration SLOWER on every workload -- so the host-driven loop stays the default
@@ -138,7 +139,15 @@ struct CrView {             // block-tridiagonal system + cyclic-reduction facto
   int np = 0;                 // cr_contrib_slots(nsb)
   int pw_rhs = 1;             // right-hand sides Pw is sized for
   const LmDev* lm = nullptr;  // device-driven LM loop: the fused stage kernels return at once when lm->done
+  // Submap ranks (round 4): the chain's LAST node is a separator like its first one -- never eliminated; the fused stages leave
+  // the Schur complement of everything between the two onto them (D, L, w of both nodes + the last stage's contribution slots 0 / 1).
+  // It lives at its true index nsb - 1 and takes part in every stage as the node behind the last regular one (fused stages only).
+  int rsep = 0;
 };
+// stage nodes alive at stride S (the right separator counts as one), and where stage node sn lives in D / L / w / x
+__host__ __device__ inline int64_t cr_stage_nodes(const CrView& cr, int S) {
+  return cr.rsep ? ((int64_t)cr.nsb - 2) / S + 2 : ((int64_t)cr.nsb + S - 1) / S;
+}
 int cr_contrib_slots(int nsb);
 
 // ---- kernel launchers (hitl_kernels.hip) -------------------------------------------------
@@ -210,6 +219,28 @@ bool cr_build_factor_solve_is_fused(const CrView& cr, const CrSource& src, doubl
 // the same with src.n_unit unit right-hand sides behind the first one (w, x: 1 + n_unit vectors `stride` apart)
 void launch_cr_build_factor_solve_multi(hipStream_t st, const CrView& cr, const CrSource& src, double* w, double* x, size_t stride);
 void launch_cr_solve(hipStream_t st, const CrView& cr, const double* rhs, double* w, double* x);   // x = M^-1 rhs; w = work vector (may be rhs itself: overwritten)
+
+// ---- submap ranks, separator form (round 4).  `chain` views the rank's OWNED super-blocks only (first node
+// F, last node R, chain.rsep = 1; src / w / x shifted to the first owned pose).  Forward: the fused stages eliminate everything
+// between F and R and leave the Schur complement onto the two; launch_sep_record writes the rank's exchange record
+//   [ D~_F | D~_R | K (R <-> F) | C_lo (F x the previous rank's R, unscaled) | w~_F | w~_R | scales of F | scales of R ]
+// (sep_rec_len doubles); launch_sep_solve builds the 2 * world node chain of all ranks' separators from the gathered records,
+// solves it (the same fused cyclic reduction on a second, tiny CrView) and scatters: x at this rank's F and R, and the steps +
+// Jacobi scales of the neighbours' separator poses into this rank's halo entries.  Backward: the stages' back-substitution.
+static inline int sep_rec_len(int B) { return 4 * B * B + 4 * B; }
+bool cr_sep_applies(const CrView& chain, const CrSource& src, double* w, double* x);
+void launch_cr_sep_forward(hipStream_t st, const CrView& chain, const CrSource& src, double* w, double* x);
+void launch_cr_sep_backward(hipStream_t st, const CrView& chain, double* w, double* x);
+struct SepGeom {            // local pose indices of a rank's separators and the halo poses the neighbours' separators cover
+  int own_lo, own_hi;       // owned poses [own_lo, own_hi)
+  int r_pose0;              // first pose of R
+  int halo_lo, halo_hi;     // poses [own_lo - halo_lo, own_lo) and [own_hi, own_hi + halo_hi) receive the neighbours' steps (<= Wb each)
+  int rank, world, Wb;
+};
+void launch_sep_record(hipStream_t st, const CrView& chain, const double* w, const double* Hband_local, const double* scale_local,
+                       const unsigned char* fixed_local, const SepGeom& gm, double* rec);
+void launch_sep_solve(hipStream_t st, const CrView& red, const double* rec_all, double* w2, double* x2, const SepGeom& gm, double* dt_local,
+                      double* scale_local);
 // y = (S H S [+ D^2]) v ; damping added when mu > 0
 void launch_spmv(hipStream_t st, int n_poses, int npad, const FactorView& fv, const LinView& lin,
                  const double* scale, double mu, double min_diag, double max_diag, const double* v, double* y, bool all_cols = false);

@@ -146,6 +146,29 @@ int comm_allgather_dev(hitl_solver* s, const void* send_dev, void* recv_host, in
   return comm_allgather(s, stage.data(), recv_host, bytes);
 }
 
+// all-gather from device memory to device memory: RCCL takes the record where it lies and delivers where the next kernel reads
+// -- no host synchronisation at all; a caller callback (host buffers) is fed through `stage`, which must stay untouched until
+// the stream has been synchronised again (the upload of the gathered records reads it)
+int comm_allgather_d2d(hitl_solver* s, const void* send_dev, void* recv_dev, int64_t bytes, std::vector<double>& stage) {
+  hipStream_t st = s->stream;
+  if (s->nccl && !s->comm.allgather) {
+    const ncclResult_t r = ncclAllGather(send_dev, recv_dev, (size_t)bytes, ncclChar, s->nccl, st);
+    if (r != ncclSuccess) return fail(HITL_ERR_COMM, std::string("ncclAllGather: ") + ncclGetErrorString(r));
+    return HITL_OK;
+  }
+  if (s->world == 1 && !s->comm.allgather) {
+    HIP_TRY(hipMemcpyAsync(recv_dev, send_dev, (size_t)bytes, hipMemcpyDeviceToDevice, st));
+    return HITL_OK;
+  }
+  const size_t words = (size_t)(bytes + 7) / 8;
+  stage.resize(words * (size_t)(1 + s->world));
+  HIP_TRY(hipMemcpyAsync(stage.data(), send_dev, (size_t)bytes, hipMemcpyDeviceToHost, st));
+  TRY(spin_sync(s));
+  TRY(comm_allgather(s, stage.data(), stage.data() + words, bytes));
+  HIP_TRY(hipMemcpyAsync(recv_dev, stage.data() + words, (size_t)bytes * s->world, hipMemcpyHostToDevice, st));
+  return HITL_OK;
+}
+
 static inline double nan_max(double a, double b) { return (b > a || b != b) ? b : a; }
 
 // local linearisation (every rank evaluates all factors touching its owned poses, so its rows are
@@ -423,6 +446,26 @@ static int linear_solve_and_step_dist(hitl_solver* s, const FactorView& fv, int 
   if (s->dist_pcg) {
     TRY(dist_pcg_solve(s, fv, lv, cr, mu, iters, ok));
     nh = s->n_halo;                      // dt and scale already hold the owners' values on every halo row
+  } else if (s->dist_sep) {
+    // Separator form (round 4): the rank's first and last owned super-blocks F and R stay, the fused stages eliminate everything
+    // between them -- ONE right-hand side, the same kernels and cost as the single-GPU factorisation whatever the interface
+    // width -- and leave the Schur complement onto the two.  One all-gather of a 4 B^2 + 4 B record; every rank then solves the
+    // same block-tridiagonal chain of the 2 * world separators ON THE DEVICE (the tiny top stage of the same cyclic reduction)
+    // and back-substitutes between its own two.  The neighbours' separators cover this rank's halo poses: their steps and
+    // scales come out of the same solve.  With RCCL nothing here waits for the host.
+    const int lo = s->own_lo;
+    const CrView chain = s->sep_chain_view();
+    const CrSource src = {lv.Hband + (size_t)lo * (Wb + 1) * 9, lv.g + 3 * (size_t)lo, s->scale.p + 3 * (size_t)lo, s->fixed.p + lo, mu, mind, maxd,
+                          s->own_hi - lo, Wb, s->rhs.p + 3 * (size_t)lo, nullptr, 0};
+    double* w = s->wv.p + 3 * (size_t)lo;
+    double* x = s->dt.p + 3 * (size_t)lo;
+    launch_cr_sep_forward(st, chain, src, w, x);
+    launch_sep_record(st, chain, w, lv.Hband, s->scale.p, s->fixed.p, s->sep_geom, s->sep_rec.p);
+    HIP_TRY(hipGetLastError());
+    TRY(comm_allgather_d2d(s, s->sep_rec.p, s->sep_all.p, (int64_t)sizeof(double) * sep_rec_len(s->B), s->sep_host));
+    launch_sep_solve(st, s->sep_red_view(), s->sep_all.p, s->sep_w2.p, s->sep_x2.p, s->sep_geom, s->dt.p, s->scale.p);
+    launch_cr_sep_backward(st, chain, w, x);
+    nh = s->n_halo;
   } else {
   {
     // build + factorise + solve for b and the interface unit vectors in one pass: z0 and Z = M^{-1} [E_F, E_L]; the first
@@ -758,6 +801,7 @@ int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float* poses
   S.num_matches = fv.with_stf ? s->n_matches_owned : 0;
   S.num_offband_pairs = fv.n_offband;
   S.band_poses = fv.band_poses;
+  S.submap_linear_solver = !s->dist_mode() ? 0.0 : s->dist_pcg ? 3.0 : s->dist_sep ? 2.0 : 1.0;
   S.num_hc_residuals = s->num_hc_residuals;
   // odometry edges are owned by the rank owning their second pose
   const int n_edges = (s->own_hi - s->own_lo) - ((s->g_begin == 0) ? 1 : 0);

@@ -151,7 +151,9 @@ int ensure_empty_pair_tables(hitl_solver* s) {
 int ensure_work(hitl_solver* s, int Wb) {
   const int n = s->n;
   s->B = 3 * Wb;
-  s->nsb = (n + Wb - 1) / Wb;
+  // (a submap rank: one super-block of slack -- the chain of its owned poses starts at own_lo, not at a multiple of Wb, and its
+  // last block may reach up to Wb - 1 poses past the end)
+  s->nsb = (n + Wb - 1) / Wb + (s->dist_mode() ? 1 : 0);
   s->npad = s->nsb * s->B;
   const size_t npad = (size_t)s->npad;
   for (DevArray<double>* v : {&s->x, &s->xc, &s->scale, &s->rhs, &s->dt, &s->wv, &s->qv, &s->rv, &s->zv, &s->pv}) {
@@ -375,7 +377,8 @@ int prepare(hitl_solver* s, int mode, const float* poses_ref, const float* poses
   if (s->dist_mode()) {
     // interface width = how deep (in poses) any factor reaches across a cut, maximised over all
     // ranks: 1 when only the odometry edges straddle the cuts, up to the pose band otherwise
-    int wi_local = 1, min_Wb = Wb;
+    int wi_local = 1, min_Wb = Wb, max_Wb = Wb;
+    bool sep_cand = !dev_switches().dist_columns;          // the separator form of the linear solve (hitl_internal.h) is a candidate
     if (mode != HITL_MODE_ODOM_HC && local_rc == HITL_OK && ensure_host_pairs(s) == HITL_OK)
       for (int p = 0; p < s->n_pairs; ++p) {
         const int a = std::min(s->h_pair_src[p], s->h_pair_tgt[p]), b = std::max(s->h_pair_src[p], s->h_pair_tgt[p]);
@@ -387,22 +390,33 @@ int prepare(hitl_solver* s, int mode, const float* poses_ref, const float* poses
       // point: a rank that failed above (or holds pose pairs outside the band, which submap solves do not support yet)
       // must not let the others walk into the collectives of the LM loop alone
       const bool offband_here = (mode != HITL_MODE_ODOM_HC) && s->n_offband > 0;
-      double mine[4] = {(double)wi_local, (double)local_rc, offband_here ? 1.0 : 0.0, (double)Wb};
-      std::vector<double> all((size_t)4 * s->world);
+      double mine[5] = {(double)wi_local, (double)local_rc, offband_here ? 1.0 : 0.0, (double)Wb, (double)(s->own_hi - s->own_lo)};
+      std::vector<double> all((size_t)5 * s->world);
       TRY(comm_allgather(s, mine, all.data(), sizeof(mine)));
       int worst = HITL_OK;
       bool any_offband = false;
       for (int r = 0; r < s->world; ++r) {
-        wi_local = std::max(wi_local, (int)all[(size_t)4 * r]);
-        if ((int)all[(size_t)4 * r + 1] != HITL_OK && worst == HITL_OK) worst = (int)all[(size_t)4 * r + 1];
-        any_offband = any_offband || all[(size_t)4 * r + 2] != 0.0;
-        min_Wb = std::min(min_Wb, (int)all[(size_t)4 * r + 3]);
+        wi_local = std::max(wi_local, (int)all[(size_t)5 * r]);
+        if ((int)all[(size_t)5 * r + 1] != HITL_OK && worst == HITL_OK) worst = (int)all[(size_t)5 * r + 1];
+        any_offband = any_offband || all[(size_t)5 * r + 2] != 0.0;
+        min_Wb = std::min(min_Wb, (int)all[(size_t)5 * r + 3]);
+        max_Wb = std::max(max_Wb, (int)all[(size_t)5 * r + 3]);
       }
       if (local_rc != HITL_OK) return local_rc;
       if (worst != HITL_OK) return fail(worst, "another rank failed while preparing the solve");
       s->dist_pcg = any_offband;
+      // The separator form wants ONE band width on all ranks (the records are B x B tiles), every rank but the last owning a
+      // multiple of it (its last super-block is full: nothing couples across it) and at least two super-blocks per rank.
+      // Decided from the gathered values: the same verdict everywhere.
+      if (any_offband || max_Wb > std::min(std::max((int)s->opt.max_band_poses, 1), kMaxBandPoses)) sep_cand = false;
+      for (int r = 0; r < s->world && sep_cand; ++r) {
+        const int64_t cnt = (int64_t)all[(size_t)5 * r + 4];
+        if (cnt <= max_Wb || (r + 1 < s->world && cnt % max_Wb != 0)) sep_cand = false;
+      }
     }
     s->Wi = wi_local;
+    s->dist_sep = false;
+    const int band_target = sep_cand ? std::max(max_Wb, s->Wi) : s->Wi;      // (mode A: 1 everywhere)
     if (!s->dist_pcg && mode != HITL_MODE_ODOM_HC) {
       // The interface width is a maximum over ALL ranks; the band of this rank comes from its own kept pairs.  A rank that
       // holds only short pairs while a cut elsewhere is crossed by longer ones widens its band to the interface (the exact
@@ -412,13 +426,13 @@ int prepare(hitl_solver* s, int mode, const float* poses_ref, const float* poses
       if (s->Wi > cap)
         return fail(HITL_ERR_UNSUPPORTED, "a factor reaches " + std::to_string(s->Wi) + " poses across a cut, further than the pose band may be wide (max_band_poses)");
       int widen_rc = HITL_OK;
-      if (s->Wi > Wb) {
-        s->min_band_poses = s->Wi;       // reset by set_map / set_partition / every new correspondence set
+      if (band_target > Wb) {
+        s->min_band_poses = band_target; // reset by set_map / set_partition / every new correspondence set
         widen_rc = ensure_host_pairs(s);
         if (widen_rc == HITL_OK) widen_rc = build_pair_structures(s);
         if (widen_rc == HITL_OK) { Wb = s->band_pairs_Wb; widen_rc = prepare_local(s, mode, poses_ref, poses_global, Wb); }
       }
-      if (s->Wi > min_Wb) {
+      if (band_target > min_Wb) {
         // somebody rebuilt its tables (every rank knows from the gathered bands): agree on the outcome before anyone enters
         // the LM loop's collectives -- a rank that ran out of memory here must not leave the others waiting in them
         double mine_w = (double)widen_rc;
@@ -483,11 +497,41 @@ int prepare(hitl_solver* s, int mode, const float* poses_ref, const float* poses
     }
     const int Wi = s->Wi, nc = 6 * Wi;
     if (Wi > Wb) return fail(HITL_ERR_UNSUPPORTED, "a factor reaches further across a cut than the pose band");
+    if (sep_cand) {
+      // every rank checks that its own chain runs as fused stages, then all agree (one more tiny exchange, once per prepare)
+      s->sep_nsb = (s->own_hi - s->own_lo + Wb - 1) / Wb;
+      CrSource probe = {};
+      probe.Wb = Wb;
+      double mine_s = (Wb == band_target && cr_sep_applies(s->sep_chain_view(), probe, s->wv.p, s->dt.p)) ? 1.0 : 0.0;
+      std::vector<double> all_s((size_t)s->world);
+      TRY(comm_allgather(s, &mine_s, all_s.data(), sizeof(mine_s)));
+      s->dist_sep = true;
+      for (int r = 0; r < s->world; ++r) if (all_s[(size_t)r] == 0.0) s->dist_sep = false;
+    }
     std::vector<int> cols(nc), hidx;
     for (int p = 0; p < Wi; ++p)
       for (int c = 0; c < 3; ++c) { cols[3 * p + c] = 3 * (s->own_lo + p) + c; cols[3 * Wi + 3 * p + c] = 3 * (s->own_hi - Wi + p) + c; }
+    if (s->dist_sep) {
+      // the neighbours' separators cover up to Wb poses beyond either cut: all of them that are held here take their steps from them
+      SepGeom& gm = s->sep_geom;
+      gm.own_lo = s->own_lo; gm.own_hi = s->own_hi; gm.r_pose0 = s->own_lo + (s->sep_nsb - 1) * Wb;
+      gm.halo_lo = s->rank > 0 ? std::min(s->hl, Wb) : 0;
+      gm.halo_hi = s->rank < s->world - 1 ? std::min(s->hh, Wb) : 0;
+      gm.rank = s->rank; gm.world = s->world; gm.Wb = Wb;
+      for (int p = 0; p < gm.halo_lo; ++p) for (int c = 0; c < 3; ++c) hidx.push_back(3 * (s->own_lo - gm.halo_lo + p) + c);
+      for (int p = 0; p < gm.halo_hi; ++p) for (int c = 0; c < 3; ++c) hidx.push_back(3 * (s->own_hi + p) + c);
+      s->n_halo = (int)hidx.size();
+      const size_t rl = (size_t)sep_rec_len(s->B), nn = (size_t)2 * s->world, bb2 = nn * s->B * s->B;
+      TRY(s->sep_rec.resize(rl)); TRY(s->sep_all.resize(rl * s->world));
+      TRY(s->sep_w2.resize(nn * s->B)); TRY(s->sep_x2.resize(nn * s->B));
+      TRY(s->sep_D.resize(bb2)); TRY(s->sep_L.resize(bb2)); TRY(s->sep_Dinv.resize(bb2)); TRY(s->sep_Gl.resize(bb2)); TRY(s->sep_Gr.resize(bb2));
+      const size_t np2 = (size_t)cr_contrib_slots((int)nn);
+      TRY(s->sep_P.resize(4 * np2 * s->B * s->B)); TRY(s->sep_Pw.resize(4 * np2 * s->B));
+      TRY(s->dt.zero(s->stream));          // rows outside the chain and the filled halo entries stay zero
+    } else {
     if (s->rank > 0) for (int p = 0; p < Wi; ++p) for (int c = 0; c < 3; ++c) hidx.push_back(3 * (s->own_lo - Wi + p) + c);
     if (s->rank < s->world - 1) for (int p = 0; p < Wi; ++p) for (int c = 0; c < 3; ++c) hidx.push_back(3 * (s->own_hi + p) + c);
+    }
     TRY(s->if_cols.upload(cols, s->stream));
     if (hidx.empty()) hidx.push_back(0);
     TRY(s->halo_idx.upload(hidx, s->stream));
@@ -511,7 +555,7 @@ void read_dev_switches() {
   auto num = [](const char* name, long long dflt) { const char* e = std::getenv(name); return e ? std::atoll(e) : dflt; };
   d.timing = on("HITL_TIMING"); d.event_sync = on("HITL_EVENT_SYNC"); d.cr_legacy = on("HITL_CR_LEGACY");
   d.cr_unfused_build = on("HITL_CR_UNFUSED_BUILD"); d.stf_addr64 = on("HITL_STF_ADDR64"); d.force_dist = on("HITL_FORCE_DIST");
-  d.force_rccl = on("HITL_FORCE_RCCL"); d.device_lm = on("HITL_DEVICE_LM");
+  d.force_rccl = on("HITL_FORCE_RCCL"); d.device_lm = on("HITL_DEVICE_LM"); d.dist_columns = on("HITL_DIST_COLUMNS");
   d.stf_variant = (int)num("HITL_STF_VARIANT", 0);
   d.stf_waves_per_cu = (int)num("HITL_STF_WAVES_PER_CU", 0);
   d.kd_block = (int)num("HITL_KD_BLOCK", d.kd_block);
@@ -1288,8 +1332,13 @@ int hitl_comm_unique_id(void* out128) {
 
 int hitl_partition_range(int64_t n_poses, const int64_t* obs_offset, int32_t rank, int32_t world_size, int64_t* begin,
                          int64_t* end) {
-  // contiguous pose ranges balanced by observation count
-  if (n_poses < 1 || !obs_offset || world_size < 1 || rank < 0 || rank >= world_size || !begin || !end)
+  return hitl_partition_range_aligned(n_poses, obs_offset, rank, world_size, 1, begin, end);
+}
+
+int hitl_partition_range_aligned(int64_t n_poses, const int64_t* obs_offset, int32_t rank, int32_t world_size, int32_t align,
+                                 int64_t* begin, int64_t* end) {
+  // contiguous pose ranges balanced by observation count, cuts on multiples of `align`
+  if (n_poses < 1 || !obs_offset || world_size < 1 || rank < 0 || rank >= world_size || !begin || !end || align < 1)
     return fail(HITL_ERR_INVALID_ARGUMENT, "partition_range: bad arguments");
   const int64_t total = obs_offset[n_poses] - obs_offset[0];
   // every rank computes the whole cut list, so neighbouring ranges always abut
@@ -1302,6 +1351,12 @@ int hitl_partition_range(int64_t n_poses, const int64_t* obs_offset, int32_t ran
     } else {
       const double goal = (double)total * (double)r / (double)world_size;
       c = std::lower_bound(obs_offset, obs_offset + n_poses + 1, (int64_t)std::llround(goal) + obs_offset[0]) - obs_offset;
+    }
+    if (align > 1 && n_poses >= (int64_t)2 * align * world_size) {
+      // nearest multiple, at least two blocks of `align` behind the previous cut and room for two per rank still to come
+      c = (c + align / 2) / align * align;
+      c = std::max<int64_t>(c, cuts[r - 1] + 2 * (int64_t)align);
+      c = std::min<int64_t>(c, (n_poses - 2 * (int64_t)align * (world_size - r)) / align * align);
     }
     if (n_poses >= world_size) c = std::min<int64_t>(std::max<int64_t>(c, cuts[r - 1] + 1), n_poses - (world_size - r));
     else c = std::min<int64_t>(std::max<int64_t>(c, cuts[r - 1]), n_poses);

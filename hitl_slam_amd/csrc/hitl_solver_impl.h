@@ -58,6 +58,26 @@ struct hitl_solver {
   bool force_dist = false;            // HITL_FORCE_DIST (development): a single rank takes the submap code path (profiling its kernels)
   bool dist_mode() const { return world > 1 || force_dist; }
   bool dist_pcg = false;
+  // Separator form of the submap solve (round 4; hitl_internal.h): applies when every pose pair is inside the band and every rank
+  // but the last owns a multiple of the (common) band width; the interface-column form above remains for everything else and for
+  // the covariance correction.
+  bool dist_sep = false;
+  int sep_nsb = 0;                               // super-blocks of the chain of owned poses (first = F, last = R)
+  SepGeom sep_geom = {};
+  DevArray<double> sep_rec, sep_all, sep_w2, sep_x2;          // this rank's record, all ranks' records, the separator chain's rhs / solution
+  DevArray<double> sep_D, sep_L, sep_Dinv, sep_Gl, sep_Gr, sep_P, sep_Pw;   // the separator chain (2 * world nodes)
+  std::vector<double> sep_host;                  // host side of the record exchange when a caller callback carries it
+  CrView sep_chain_view() {                      // the owned super-blocks as a chain whose last node stays
+    CrView c = cr_view();
+    c.nsb = sep_nsb; c.rsep = 1; c.pw_rhs = cr_pw_rhs;
+    return c;
+  }
+  CrView sep_red_view() {
+    CrView c;
+    c.nsb = 2 * world; c.B = B; c.D = sep_D.p; c.L = sep_L.p; c.Dinv = sep_Dinv.p; c.Gl = sep_Gl.p; c.Gr = sep_Gr.p;
+    c.P = sep_P.p; c.Pw = sep_Pw.p; c.np = cr_contrib_slots(2 * world); c.pw_rhs = 1;
+    return c;
+  }
   std::vector<int64_t> part_begin, part_count;   // owned global range of every rank
   int maxown = 0;                                // widest owned range, in poses
   int pcg_edge = 0;                              // owned poses at either end of a rank's range that travel in the PCG exchange record

@@ -157,7 +157,12 @@ typedef struct hitl_summary {
   double linear_solver_ms;
   int32_t linearize_calls;
   int32_t linearize_timed_calls; /* how many of them were bracketed by events (hitl_options.timing_level) */
-  double reserved[6];
+  /* how a pose-range submap rank solved its linear systems: 0 = single GPU; 1 = interface columns (1 + 6 Wi right-hand sides
+   * through the rank's own factorisation, dense interface system); 2 = separators (each rank eliminates between its first and
+   * last super-block, one chain of 2 * world_size separator blocks: needs every rank but the last to own a multiple of the
+   * pose band -- hitl_partition_range_aligned); 3 = distributed PCG (pose pairs outside the band). */
+  double submap_linear_solver;
+  double reserved[5];
 } hitl_summary;
 
 typedef struct hitl_solver hitl_solver;   /* opaque; owns device memory */
@@ -390,6 +395,12 @@ int hitl_solver_comm_ranks(hitl_solver*, int32_t* ranks, int32_t* kind);
 int hitl_comm_unique_id(void* out128);
 int hitl_partition_range(int64_t n_poses, const int64_t* obs_offset, int32_t rank,
                          int32_t world_size, int64_t* begin, int64_t* end);
+/* The same with every cut moved to the nearest multiple of `align` poses (counted from pose 0), so that every rank but the
+ * last owns a multiple of it.  With align = a common multiple of the pose bands the solves may use (the search window; 12
+ * covers bands of 1, 2, 3, 4 and 6 poses) the ranks' linear solves take the separator form (hitl_summary.submap_linear_solver
+ * = 2), whose cost does not depend on how many poses a factor reaches across a cut. */
+int hitl_partition_range_aligned(int64_t n_poses, const int64_t* obs_offset, int32_t rank, int32_t world_size, int32_t align,
+                                 int64_t* begin, int64_t* end);
 
 /* ---- file formats either side of the path (host-only, no GPU needed) ----
  * hitl_io_load_stfs_covars   == loadPoseGraph      (HitLSLAM_main.cpp:192-300): rows of 16 numbers

@@ -26,15 +26,23 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("mode,ppf,world,moments,cuts,windows",
-                         [(0, 30, 2, 0, None, None), (2, 30, 2, 0, None, None), (2, 120, 2, 0, None, None), (0, 120, 2, 0, None, None),
-                          (2, 120, 3, 0, None, None), (2, 40, 3, 0, None, None), (2, 120, 2, 1, None, None),
-                          (2, 120, 3, 0, "0,23,83,120", None),      # uneven submaps: 23, 60 and 37 poses
+# `form`: how the ranks' linear solves must have run (hitl_summary.submap_linear_solver): 2 = separators (every rank but the last
+# owns a multiple of the pose band: 60-pose ranks with a band of 3 or 1, the cut lists 0,39,81,120 / 0,42,72,120), 1 = interface
+# columns (40-pose ranks with a band of 3, uneven cuts, or HITL_DIST_COLUMNS=1 on a partition the separators would take)
+@pytest.mark.parametrize("mode,ppf,world,moments,cuts,windows,form",
+                         [(0, 30, 2, 0, None, None, 2), (2, 30, 2, 0, None, None, 2), (2, 120, 2, 0, None, None, 2), (0, 120, 2, 0, None, None, 2),
+                          (2, 120, 3, 0, None, None, 1), (2, 40, 3, 0, None, None, 1), (2, 120, 2, 1, None, None, 2),
+                          (2, 120, 3, 0, "0,23,83,120", None, 1),      # uneven submaps: 23, 60 and 37 poses
                           # rank 0 = the first floor, matched within +-1 pose only: its own band is one pose wide while the cut
                           # between ranks 1 and 2 (inside the second floor) is crossed by pairs three poses long.  Every rank must
                           # widen its band to the interface of the whole partition (round 2: rank 0 alone refused and the others hung)
-                          (2, 40, 3, 0, "0,40,70,120", "1,3,3")])
-def test_submaps_equal_the_global_solve(tmp_path, mode, ppf, world, moments, cuts, windows):
+                          (2, 40, 3, 0, "0,40,70,120", "1,3,3", 1),
+                          # round 4, the separator form on three ranks: uneven block-aligned submaps (the middle rank has a separator
+                          # pair on both sides), mode A on them (band of one pose), the rank with the narrow band widening to the
+                          # common one, and the column form forced on a partition the separators would take
+                          (2, 120, 3, 0, "0,39,81,120", None, 2), (0, 120, 3, 0, "0,39,81,120", None, 2), (2, 42, 3, 0, "0,42,72,120", "1,3,3", 2),
+                          (2, 120, 2, 0, None, None, -1)])
+def test_submaps_equal_the_global_solve(tmp_path, mode, ppf, world, moments, cuts, windows, form):
     from oracle import hitl_oracle as O
     out = str(tmp_path / "res")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", HITL_TEST_STF_MOMENTS=str(moments))
@@ -42,6 +50,9 @@ def test_submaps_equal_the_global_solve(tmp_path, mode, ppf, world, moments, cut
         env["HITL_TEST_CUTS"] = cuts
     if windows:
         env["HITL_TEST_WINDOWS"] = windows
+    if form == -1:
+        env["HITL_DIST_COLUMNS"] = "1"
+        form = 1
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_submap_worker.py"), out, str(mode), str(ppf)]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
@@ -121,6 +132,7 @@ def test_submaps_equal_the_global_solve(tmp_path, mode, ppf, world, moments, cut
     po, so = o.solve(mode, prob.init)
     for x in res:
         sm = x["summary"]
+        assert sm["submap_linear_solver"] == form, sm["submap_linear_solver"]
         assert sm["termination"] == so.termination and sm["iterations"] == so.iterations
         assert sm["successful_steps"] == so.successful_steps
         assert abs(sm["final_cost"] - so.final_cost) <= 1e-8 * so.final_cost
