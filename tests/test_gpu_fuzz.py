@@ -61,7 +61,9 @@ def test_seeded_problem(n, obs, ppf, window, kind, groups, seed):
 def test_solver_paths_agree_over_many_map_sizes(tmp_path):
     """Structural fuzz of the linear solve: the same LM solves (mode A: band of one pose; mode C, window 3) over a few dozen
     map sizes through (1) the fused cyclic-reduction stages, (2) the level-per-launch kernels (HITL_CR_LEGACY) and (3) the
-    submap code path on a single rank (HITL_FORCE_DIST: multi-right-hand-side stages, interface system of one rank).  All three
+    submap code path on a single rank (HITL_FORCE_DIST) in both of its forms -- separators (the chain of owned super-blocks with
+    its last node kept: the irregular right boundary of every stage's last chunk) and, with HITL_DIST_COLUMNS, interface columns
+    (multi-right-hand-side stages, interface system of one rank).  All four
     are exact solves of the same systems: iteration counts, terminations and costs must agree for every size (a chunk-boundary
     bug of the fused stages showed up as FAILURE on one size in 32)."""
     import json
@@ -70,19 +72,21 @@ def test_solver_paths_agree_over_many_map_sizes(tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for tag, extra in (("fused", {}), ("legacy", {"HITL_CR_LEGACY": "1"}), ("dist", {"HITL_FORCE_DIST": "1"})):
+    for tag, extra in (("fused", {}), ("legacy", {"HITL_CR_LEGACY": "1"}), ("dist", {"HITL_FORCE_DIST": "1"}),
+                       ("distcols", {"HITL_FORCE_DIST": "1", "HITL_DIST_COLUMNS": "1"})):
         out = str(tmp_path / (tag + ".jsonl"))
         env = dict(os.environ, HITL_SWEEP_QUICK="1", **extra)
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "cr_size_sweep.py"), out], env=env, cwd=root, capture_output=True,
                            text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
         res[tag] = [json.loads(l) for l in open(out)]
-    assert len(res["fused"]) == len(res["legacy"]) == len(res["dist"]) >= 30
-    for a, b, c in zip(res["fused"], res["legacy"], res["dist"]):
-        assert "err" not in a and "err" not in b and "err" not in c, (a, b, c)
-        assert a["n"] == b["n"] == c["n"] and a["term"] != 2
-        assert a["it"] == b["it"] == c["it"] and a["term"] == b["term"] == c["term"], (a, b, c)
+    assert len(res["fused"]) == len(res["legacy"]) == len(res["dist"]) == len(res["distcols"]) >= 30
+    for a, b, c, d in zip(res["fused"], res["legacy"], res["dist"], res["distcols"]):
+        assert "err" not in a and "err" not in b and "err" not in c and "err" not in d, (a, b, c, d)
+        assert a["n"] == b["n"] == c["n"] == d["n"] and a["term"] != 2
+        assert a["it"] == b["it"] == c["it"] == d["it"] and a["term"] == b["term"] == c["term"] == d["term"], (a, b, c, d)
         assert abs(a["cost"] - b["cost"]) <= 1e-9 * max(abs(b["cost"]), 1e-12) and abs(c["cost"] - b["cost"]) <= 1e-8 * max(abs(b["cost"]), 1e-12)
+        assert abs(d["cost"] - b["cost"]) <= 1e-8 * max(abs(b["cost"]), 1e-12)
 
 
 def test_solves_are_reproducible_run_to_run(tmp_path):

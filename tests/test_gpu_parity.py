@@ -283,6 +283,59 @@ def test_in_library_rccl_allgather_world1():
     assert r.returncode == 0 and "rccl self-test ok" in r.stdout, (r.returncode, r.stdout[-400:], r.stderr[-800:])
 
 
+@pytest.mark.parametrize("columns", [0, 1])
+def test_submap_solve_through_in_library_rccl_world1(columns):
+    """The submap code path of ONE rank with the built-in RCCL communicator carrying its exchanges (HITL_FORCE_DIST +
+    HITL_FORCE_RCCL: the only way RCCL can run on a 1-GPU box).  Separator form (default): the record goes from device memory to
+    device memory through ncclAllGather and the separator chain is solved on the device -- nothing of the linear solve waits for
+    the host; interface-column form (HITL_DIST_COLUMNS=1): the gathered records come to the host.  Both must walk the oracle's LM
+    path.  Own process, like the self-test above."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from oracle import hitl_oracle as O
+    code = (
+        "import ctypes as C, json, sys\n"
+        "sys.path.insert(0, 'tests')\n"
+        "import hitl_slam_amd as H\n"
+        "from hitl_slam_amd.api import comm_unique_id\n"
+        "from conftest import Problem\n"
+        "uid = comm_unique_id()\n"
+        "buf = (C.c_char * 128).from_buffer_copy(uid)\n"
+        "opt = H.default_options()\n"
+        "opt.rccl_unique_id = C.cast(buf, C.c_void_p)\n"
+        "s = H.Solver(opt)\n"
+        "assert s.comm_ranks(True) == (1, 1), s.comm_ranks(True)\n"
+        "prob = Problem(150, 64, ppf=50, groups=3, kind=0)\n"
+        "prob.load(s)\n"
+        "s.find_correspondences(prob.init, 3)\n"
+        "out = {}\n"
+        "for mode in (0, 2):\n"
+        "    p, sm = s.solve(mode, prob.init)\n"
+        "    out[str(mode)] = dict(poses=p.tolist(), summary=sm.as_dict())\n"
+        "s.close()\n"
+        "print('RESULT ' + json.dumps(out))\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HITL_FORCE_RCCL="1", HITL_FORCE_DIST="1", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    if columns:
+        env["HITL_DIST_COLUMNS"] = "1"
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=root, timeout=300)
+    assert r.returncode == 0 and "RESULT " in r.stdout, (r.returncode, r.stdout[-400:], r.stderr[-1500:])
+    res = json.loads(r.stdout[r.stdout.index("RESULT ") + 7:].splitlines()[0])
+    prob = Problem(150, 64, ppf=50, groups=3, kind=0)
+    o = prob.load(O.OracleSolver())
+    o.find_correspondences(prob.init, 3, 1)
+    for mode in (0, 2):
+        po, so = o.solve(mode, prob.init)
+        sm, pg = res[str(mode)]["summary"], np.array(res[str(mode)]["poses"], np.float32)
+        assert sm["submap_linear_solver"] == (1 if columns else 2)
+        assert sm["termination"] == so.termination and sm["iterations"] == so.iterations and sm["successful_steps"] == so.successful_steps
+        assert abs(sm["final_cost"] - so.final_cost) <= 1e-8 * so.final_cost
+        assert np.abs(pg - po).max() <= 1e-4
+    o.close()
+
+
 @pytest.mark.parametrize("late", [0, 1])
 @pytest.mark.parametrize("shape", [(60, 90, 30, 2, 4), (150, 64, 50, 3, 0), (40, 48, 40, 1, 2)])
 def test_device_driven_lm_loop_equals_the_host_driven_one(monkeypatch, shape, late):

@@ -1,12 +1,14 @@
 #!/bin/bash
 # Runs on the GPU box: kernel trace of the C4 re-solve on the plain path and on the submap code path taken by ONE rank
-# (HITL_FORCE_DIST=1): busy time per LM iteration and the kernels behind it.
+# (HITL_FORCE_DIST=1; separator form and interface-column form): busy time per LM iteration and the kernels behind it.
 cd "${GRAFT_REPO_ROOT:-/root/repo}" || exit 1
 export TMPDIR=/tmp
-for mode in plain dist; do
+for mode in plain dist distcols; do
   OUT=gpurun_out/disttr_$mode
   rm -rf $OUT; mkdir -p $OUT
-  if [ "$mode" = "dist" ]; then export HITL_FORCE_DIST=1; else unset HITL_FORCE_DIST; fi
+  unset HITL_FORCE_DIST HITL_DIST_COLUMNS
+  if [ "$mode" != "plain" ]; then export HITL_FORCE_DIST=1; fi           # dist: the separator form (default since round 4)
+  if [ "$mode" = "distcols" ]; then export HITL_DIST_COLUMNS=1; fi       # distcols: the interface-column form (rounds 2-3)
   timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 tools/dev/solve_c4.py > $OUT/out.txt 2> $OUT/err.txt < /dev/null
   echo "== $mode: $(tail -1 $OUT/out.txt)"
   python3 - <<PY

@@ -17,7 +17,7 @@ for _ in range(int(os.environ.get("REPS", "4"))):
     t0 = time.perf_counter()
     poses, summ = s.solve(H.MODE_JOINT, init)
     ts.append((time.perf_counter() - t0) * 1e3)
-print("solve ms", " ".join("%.2f" % t for t in ts), "iterations", summ.iterations, "cost %.15g" % summ.final_cost)
+print("solve ms", " ".join("%.2f" % t for t in ts), "iterations", summ.iterations, "cost %.15g" % summ.final_cost, "submap form", int(summ.submap_linear_solver))
 
 if os.environ.get("CR_PROBE"):          # development build with -DHITL_CR_PROBE only
     from hitl_slam_amd.api import load_library
