@@ -67,6 +67,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--timing-level", type=int, default=1, help="hitl_options.timing_level: 1 = every 4th stf launch bracketed by "
                     "HIP events (default), 2 = all launches + linear-solver timing")
+    ap.add_argument("--cut-align", type=int, default=12,
+                    help="N > 1: the cuts between the ranks' pose ranges are moved to multiples of this many poses, so that every rank but the "
+                         "last owns a multiple of the pose band and the linear solves take the separator form (12 covers bands of 1, 2, 3, 4 "
+                         "and 6 poses); 0 = cuts between floors, only an odometry edge across a cut (rounds 2-3: the interface-column form)")
     ap.add_argument("--comm", default="auto", choices=["auto", "rccl", "torch"],
                     help="N>1 exchange: rccl = in-library ncclAllGather (exit non-zero if it cannot be used), torch = "
                          "torch.distributed all_gather callback, auto = rccl, else torch -- the transport used is in the JSON")
@@ -140,6 +144,8 @@ def main():
     else:
         n_global = wl["poses"] * world
         cuts = [r * wl["poses"] for r in range(world + 1)]
+    if world > 1 and args.cut_align > 1 and min(cuts[r + 1] - cuts[r] for r in range(world)) >= 4 * args.cut_align:
+        cuts = [0] + [int(round(c / args.cut_align)) * args.cut_align for c in cuts[1:-1]] + [n_global]
     n_local = cuts[rank + 1] - cuts[rank]
     seed = 20260102 + 1000 * {"c2": 2, "c4": 4, "c5": 5}[args.workload]
 
@@ -331,6 +337,9 @@ def main():
                    "human_constraint_rows": rows[1], "mode": "C (joint)", "band_poses": int(summ.band_poses),
                    "parallelism": ("%d pose-range submaps, 1 per GPU, one global LM; exchange: %s" % (world, comm_kind)) if world > 1 else "single GPU",
                    "comm": comm_kind, "comm_ranks": comm_ranks if world > 1 else 1,
+                   "submap_linear_solver": {0: "none (single GPU)", 1: "interface columns", 2: "separators", 3: "distributed PCG"}.get(
+                       int(summ.submap_linear_solver), "?"),
+                   "cuts": cuts if world > 1 else None,
                    "ranks_share_gpus": bool(world > 1 and torch.cuda.device_count() < world)},
         "resolve_ms": ms_per_step,
         "gn_iters_per_sec": iters_all / elapsed,

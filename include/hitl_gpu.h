@@ -356,12 +356,16 @@ int hitl_solver_linearize(hitl_solver*, int32_t mode, const float* poses_ref_xyt
  *   hitl_solver_solve(mode, poses_in GLOBAL, poses_out GLOBAL, summary)
  *        every rank takes identical LM decisions; poses_out receives the owned range (other
  *        entries are copied from poses_in); summary costs/iterations are global.
- * Per LM iteration the ranks exchange TWO small all-gathers: the interface rows of the local
- * multi-rhs cyclic-reduction solve + Jacobi scales + cross-cut blocks (<= 5 KB per rank; the
- * coupling is then eliminated exactly by a 6*band*world interface system solved identically on
- * every rank); then 7 doubles per rank: the step scalars together with (cost, |g|max) of the
- * candidate, whose linearisation is queued speculatively behind the step.  (cost, |g|max) of the
- * initial linearisation travel once, before the loop.
+ * Per LM iteration the ranks exchange TWO small all-gathers.  The first belongs to the linear solve and has two forms
+ * (hitl_summary.submap_linear_solver): separators (round 4; when every rank but the last owns a multiple of the pose
+ * band, see hitl_partition_range_aligned) -- each rank eliminates everything between its first and last owned
+ * super-block and contributes their Schur complement (4 B^2 + 4 B doubles, B = 3 * band); the chain of 2 * world
+ * separators is solved on the device, identically on every rank, and with the built-in RCCL transport the host is
+ * not involved at all -- or interface columns (any partition): the interface rows of a multi-rhs solve + Jacobi
+ * scales + cross-cut blocks (<= 5 KB per rank) and a 6*band*world interface system solved on the host.  Both
+ * eliminate the coupling exactly.  The second all-gather carries 7 doubles per rank: the step scalars together with
+ * (cost, |g|max) of the candidate, whose linearisation is queued speculatively behind the step.  (cost, |g|max) of
+ * the initial linearisation travel once, before the loop.
  * Pose pairs farther apart than the band (window > max_band_poses, the reference's all-pairs search
  * JointOptimization.cpp:575-635, revisits) on ANY rank switch all ranks to a distributed PCG: block-Jacobi
  * preconditioner = each rank's own band factorisation, two all-gathers per CG iteration -- (r.z, r.r, b.b) + the

@@ -85,6 +85,17 @@ def test_partition_range_covers_and_balances(lib):
         assert max(loads) - min(loads) <= 2 * counts.max()
     # more ranks than poses is the caller's problem, but must not crash
     assert partition_range(np.array([0, 5, 9]), 0, 2) == (0, 1)
+    # cuts on multiples of `align` poses (the separator form of the submap solve needs every rank but the last to own a multiple
+    # of the pose band): still a tiling, still balanced to within one block, at least two blocks per rank; maps too short for that
+    # keep the unaligned cuts
+    for w in (2, 3, 8):
+        for align in (3, 12):
+            rs = [partition_range(off, r, w, align=align) for r in range(w)]
+            assert rs[0][0] == 0 and rs[-1][1] == 1000 and all(a[1] == b[0] for a, b in zip(rs[:-1], rs[1:]))
+            assert all(e % align == 0 for _, e in rs[:-1]) and all(e - b >= 2 * align for b, e in rs)
+            plain = [partition_range(off, r, w) for r in range(w)]
+            assert all(abs(a[1] - p[1]) <= align for a, p in zip(rs, plain))
+    assert [partition_range(np.arange(41) * 7, r, 4, align=12) for r in range(4)] == [partition_range(np.arange(41) * 7, r, 4) for r in range(4)]
 
 
 @pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")

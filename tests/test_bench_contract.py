@@ -76,6 +76,15 @@ def test_bench_started_directly_with_gpus_2_launches_two_ranks():
     j = json.loads(line[0])
     assert j["n_gpus"] == 2 and j["config"]["comm_ranks"] == 2 and j["config"]["ranks_share_gpus"] is True
     assert j["config"]["n_poses_total"] == 12000 and j["lm_iterations_per_resolve"] > 0 and j["value"] > 0
+    # the cut (6000) is a multiple of the pose band: the ranks' linear solves take the separator form; the interface-column form
+    # (rounds 2-3, HITL_DIST_COLUMNS=1) solves the same systems: same LM path
+    assert j["config"]["submap_linear_solver"] == "separators" and j["config"]["cuts"] == [0, 6000, 12000]
+    r2 = _run_bench(["--gpus", "2", "--backend", "gloo", "--poses", "6000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                    {"HITL_DIST_COLUMNS": "1"})
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    j2 = json.loads([ln for ln in r2.stdout.splitlines() if ln.startswith("{")][0])
+    assert j2["config"]["submap_linear_solver"] == "interface columns"
+    assert j2["lm_iterations_per_resolve"] == j["lm_iterations_per_resolve"] and abs(j2["final_cost"] - j["final_cost"]) <= 1e-9 * j["final_cost"]
 
 
 @pytest.mark.gpu
