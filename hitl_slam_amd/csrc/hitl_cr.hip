@@ -1639,6 +1639,29 @@ __global__ void k_sep_scatter(int B, const double* __restrict__ rec_all, int rec
   }
 }
 
+// Selected inversion in separator form: the chain of all ranks' separators is built and factorised as in launch_sep_solve, its
+// own selected inversion gives the blocks of the GLOBAL inverse at this rank's two separators (diagonal blocks of F and R and
+// the block between them), and the rank's chain is then walked down from those instead of from a root.  Sd / So: nsb tiles
+// each, indexed by chain node; Sd2 / So2: scratch of 2 * world tiles each.
+__global__ void k_sep_selinv_seed(int B, int me, int rnode, const double* __restrict__ Sd2, const double* __restrict__ So2,
+                                  double* __restrict__ Sd, double* __restrict__ So) {
+  const int BB = B * B;
+  for (int e = threadIdx.x; e < BB; e += blockDim.x) {
+    Sd[e] = Sd2[(size_t)(2 * me) * BB + e];
+    Sd[(size_t)rnode * BB + e] = Sd2[(size_t)(2 * me + 1) * BB + e];
+    So[e] = So2[(size_t)(2 * me) * BB + e];
+  }
+}
+
+void launch_sep_selinv(hipStream_t st, const CrView& red, const double* rec_all, double* w2, double* x2, const SepGeom& gm, const CrView& chain,
+                       double* Sd2, double* So2, double* Sd, double* So) {
+  hipLaunchKernelGGL(k_sep_build, dim3(red.nsb), dim3(192), 0, st, red, rec_all, sep_rec_len(red.B), w2);
+  launch_cr_factor_solve(st, red, w2, x2, 1, 0);
+  launch_cr_selinv(st, red, Sd2, So2);
+  hipLaunchKernelGGL(k_sep_selinv_seed, dim3(1), dim3(192), 0, st, red.B, gm.rank, chain.nsb - 1, Sd2, So2, Sd, So);
+  launch_cr_selinv(st, chain, Sd, So);
+}
+
 void launch_sep_solve(hipStream_t st, const CrView& red, const double* rec_all, double* w2, double* x2, const SepGeom& gm, double* dt_local,
                       double* scale_local) {
   const int rl = sep_rec_len(red.B);
@@ -1662,9 +1685,11 @@ template <int B>
 __global__ __launch_bounds__(WAVE) void k_cr_selinv_level(CrView cr, int s, double* Sd, double* So) {
   __shared__ double sGl[B * B], sGr[B * B], sAA[B * B], sBB[B * B], sAB[B * B], sM1[B * B], sM2[B * B];
   const int k = s * (2 * blockIdx.x + 1);
-  if (k >= cr.nsb) return;
+  if (k >= cr.nsb - (cr.rsep ? 1 : 0)) return;
   const size_t BB = (size_t)B * B;
-  const int a = k - s, b = k + s;
+  // (a chain whose last node is a separator: it is never eliminated, and it is the right neighbour of every node whose regular
+  // one would lie beyond the last regular node -- the tree the fused stages of k_cr_chunk build with cr.rsep)
+  const int a = k - s, b = (cr.rsep && k + s > cr.nsb - 2) ? cr.nsb - 1 : k + s;
   const bool has_b = b < cr.nsb;
   lds_load<B>(sGl, cr.Gl + (size_t)k * BB);
   lds_load<B>(sAA, Sd + (size_t)a * BB);
@@ -1695,11 +1720,13 @@ __global__ __launch_bounds__(WAVE) void k_cr_selinv_level(CrView cr, int s, doub
 
 template <int B>
 static void cr_selinv_t(hipStream_t st, const CrView& cr, double* Sd, double* So) {
-  (void)hipMemcpyAsync(Sd, cr.Dinv, sizeof(double) * B * B, hipMemcpyDeviceToDevice, st);   // root
+  // root; on a separator chain the caller has put the blocks of its two ends (Sd[0], Sd[nsb - 1], So[0]) there already
+  if (!cr.rsep) (void)hipMemcpyAsync(Sd, cr.Dinv, sizeof(double) * B * B, hipMemcpyDeviceToDevice, st);
+  const int nreg = cr.nsb - (cr.rsep ? 1 : 0);          // nodes 0 .. nreg - 1 take part in the elimination tree
   int s_last = 0;
-  for (int s = 1; s < cr.nsb; s *= 2) s_last = s;
+  for (int s = 1; s < nreg; s *= 2) s_last = s;
   for (int s = s_last; s >= 1; s /= 2) {
-    const int n_elim = (cr.nsb - s + 2 * s - 1) / (2 * s);
+    const int n_elim = (nreg - s + 2 * s - 1) / (2 * s);
     hipLaunchKernelGGL(k_cr_selinv_level<B>, dim3(n_elim), dim3(WAVE), 0, st, cr, s, Sd, So);
   }
 }

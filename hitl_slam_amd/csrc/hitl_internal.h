@@ -241,6 +241,8 @@ void launch_sep_record(hipStream_t st, const CrView& chain, const double* w, con
                        const unsigned char* fixed_local, const SepGeom& gm, double* rec);
 void launch_sep_solve(hipStream_t st, const CrView& red, const double* rec_all, double* w2, double* x2, const SepGeom& gm, double* dt_local,
                       double* scale_local);
+void launch_sep_selinv(hipStream_t st, const CrView& red, const double* rec_all, double* w2, double* x2, const SepGeom& gm, const CrView& chain,
+                       double* Sd2, double* So2, double* Sd, double* So);   // diagonal blocks of the GLOBAL inverse over the chain's nodes
 // y = (S H S [+ D^2]) v ; damping added when mu > 0
 void launch_spmv(hipStream_t st, int n_poses, int npad, const FactorView& fv, const LinView& lin,
                  const double* scale, double mu, double min_diag, double max_diag, const double* v, double* y, bool all_cols = false);

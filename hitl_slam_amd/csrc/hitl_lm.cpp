@@ -645,6 +645,35 @@ int dist_cov_correction(hitl_solver* s, const FactorView& fv, int buf, double* S
   return HITL_OK;
 }
 
+// The same in separator form (ranks whose linear solves take it): no interface columns at all.  The rank's chain is
+// factorised between its two separators (J^T J itself: no trust-region diagonal), the separator chain of all ranks is built
+// from the gathered records, factorised and selectively inverted -- that yields the blocks of the GLOBAL inverse at this rank's
+// F and R and between them -- and the rank's own tree is walked down from those.  Sd / So are indexed by CHAIN node (node k
+// = owned poses own_lo + k * Wb ..).
+int dist_cov_sep(hitl_solver* s, const FactorView& fv, int buf, double* Sd, double* So) {
+  hipStream_t st = s->stream;
+  const LinView lv = s->lin_view(buf);
+  const int Wb = fv.band_poses, lo = s->own_lo;
+  const CrView chain = s->sep_chain_view();
+  const CrView red = s->sep_red_view();
+  const CrSource src = {lv.Hband + (size_t)lo * (Wb + 1) * 9, lv.g + 3 * (size_t)lo, s->scale.p + 3 * (size_t)lo, s->fixed.p + lo, INFINITY,
+                        s->opt.min_lm_diagonal, s->opt.max_lm_diagonal, s->own_hi - lo, Wb, s->rhs.p + 3 * (size_t)lo, nullptr, 0};
+  double* w = s->wv.p + 3 * (size_t)lo;
+  double* x = s->dt.p + 3 * (size_t)lo;
+  launch_cr_sep_forward(st, chain, src, w, x);
+  launch_sep_record(st, chain, w, lv.Hband, s->scale.p, s->fixed.p, s->sep_geom, s->sep_rec.p);
+  HIP_TRY(hipGetLastError());
+  TRY(comm_allgather_d2d(s, s->sep_rec.p, s->sep_all.p, (int64_t)sizeof(double) * sep_rec_len(s->B), s->sep_host));
+  DevArray<double> Sd2, So2;
+  const size_t bb2 = (size_t)red.nsb * red.B * red.B;
+  TRY(Sd2.resize(bb2)); TRY(So2.resize(bb2));
+  launch_sep_selinv(st, red, s->sep_all.p, s->sep_w2.p, s->sep_x2.p, s->sep_geom, chain, Sd2.p, So2.p, Sd, So);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(st));       // the scratch tiles go out of scope here; the step buffers (dt, wv, rhs) were only borrowed
+  HIP_TRY(hipMemsetAsync(s->dt.p, 0, sizeof(double) * s->npad, st));
+  return HITL_OK;
+}
+
 static double now_ms() {
   using namespace std::chrono;
   return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();

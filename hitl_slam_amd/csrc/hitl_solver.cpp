@@ -535,9 +535,11 @@ int prepare(hitl_solver* s, int mode, const float* poses_ref, const float* poses
     TRY(s->if_cols.upload(cols, s->stream));
     if (hidx.empty()) hidx.push_back(0);
     TRY(s->halo_idx.upload(hidx, s->stream));
-    TRY(s->iface_dev.resize((size_t)nc * (nc + 2) + 2 * (size_t)(nc / 2) * (nc / 2)));   // interface rows + the two cross-cut blocks
-    TRY(s->rhsN.resize((size_t)(1 + nc) * s->npad)); TRY(s->zN.resize((size_t)(1 + nc) * s->npad));
-    TRY(s->coef_dev.resize((size_t)3 * nc));      // coefficients | halo steps | halo scales: one upload per LM iteration
+    if (!s->dist_sep) {                           // the interface-column form's buffers (the separator form needs none of them)
+      TRY(s->iface_dev.resize((size_t)nc * (nc + 2) + 2 * (size_t)(nc / 2) * (nc / 2)));   // interface rows + the two cross-cut blocks
+      TRY(s->rhsN.resize((size_t)(1 + nc) * s->npad)); TRY(s->zN.resize((size_t)(1 + nc) * s->npad));
+      TRY(s->coef_dev.resize((size_t)3 * nc));    // coefficients | halo steps | halo scales: one upload per LM iteration
+    }
     HIP_TRY(hipStreamSynchronize(s->stream));
   }
   *fv = factor_view(s, mode, Wb);
@@ -1177,9 +1179,16 @@ int hitl_solver_pose_covariances(hitl_solver* s, int32_t mode, const float* pose
     for (size_t i = 0; i < nl; ++i) { const float a = -in[3 * i + 2]; rot[i] = make_float2(cosf(a), sinf(a)); }
     TRY(Sd.resize((size_t)crd.nsb * crd.B * crd.B)); TRY(So.resize((size_t)crd.nsb * crd.B * crd.B)); TRY(d_out.resize(9 * nl));
     TRY(d_rot.upload(rot, sd));
+    if (s->dist_sep) {
+      // separator form: tiles by chain node (node k = owned poses own_lo + k * Wb ..), extraction over the owned range
+      TRY(dist_cov_sep(s, fvd, 0, Sd.p, So.p));
+      const size_t lo = (size_t)s->own_lo;
+      launch_cov_extract(sd, s->own_hi - s->own_lo, fvd.band_poses, crd.B, Sd.p, s->scale.p + 3 * lo, s->fixed.p + lo, d_rot.p + lo, d_out.p + 9 * lo);
+    } else {
     TRY(dist_cov_correction(s, fvd, 0, Sd.p, So.p));
     // halo poses are constant locally: the extraction treats them like pose 0 (zero block); only the owned range goes out
     launch_cov_extract(sd, s->n, fvd.band_poses, crd.B, Sd.p, s->scale.p, s->fixed.p, d_rot.p, d_out.p);
+    }
     std::memset(cov9, 0, sizeof(double) * 9 * (size_t)s->g_n);
     const size_t own = (size_t)(s->own_hi - s->own_lo);
     HIP_TRY(hipMemcpyAsync(cov9 + 9 * (size_t)s->g_begin, d_out.p + 9 * (size_t)s->own_lo, sizeof(double) * 9 * own, hipMemcpyDeviceToHost, sd));

@@ -218,6 +218,7 @@ int run_linearize(hitl_solver* s, const FactorView& fv, const double* xdev, int 
 int dist_cov_correction(hitl_solver* s, const FactorView& fv, int buf, double* Sd, double* So);   // submap ranks: global-inverse correction of the selected inversion
 int run_linearize_dist(hitl_solver* s, const FactorView& fv, const double* xdev, int buf, LinResult* out);   // cost / |g|max summed over the ranks
 int comm_allgather(hitl_solver* s, const void* send, void* recv, int64_t bytes);
+int dist_cov_sep(hitl_solver* s, const FactorView& fv, int buf, double* Sd, double* So);      // separator form: Sd / So by chain node
 int comm_allgather_dev(hitl_solver* s, const void* send_dev, void* recv_host, int64_t bytes, std::vector<double>& stage);   // send record in device memory
 int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float* poses_global, float* poses_out, hitl_summary* summary);
 // hitl_corr.cpp
