@@ -22,7 +22,7 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libhitlgpu.so")
+LIB_PATH = os.environ.get("HITL_LIBHITLGPU") or os.path.join(_HERE, "csrc", "libhitlgpu.so")   # (the variable: same-box A/B runs against another build)
 
 _f32p = C.POINTER(C.c_float)
 _f64p = C.POINTER(C.c_double)

@@ -670,7 +670,7 @@ static int cr_top_start(int nsb, int B, int nrhs) {
 // ===========================================================================================
 // where stage node sn lives in D / L / w / x: at sn * S -- except the right separator of a submap rank's chain (cr.rsep), which is
 // stage node nst - 1 of every stage and stays at its true index nsb - 1  (needs `cr`, `S` and `rsep_sn` in scope)
-#define CR_ADDR(sn) (((sn) == rsep_sn) ? (int64_t)cr.nsb - 1 : (int64_t)(sn) * S)
+#define CR_ADDR(sn) ((RS && (sn) == rsep_sn) ? (int64_t)cr.nsb - 1 : (int64_t)(sn) * S)
 
 struct CrStage {
   int S;          // global stride of this stage's nodes
@@ -710,7 +710,10 @@ __device__ unsigned long long g_cr_probe[3 * 64];
 #ifndef HITL_CR_WAVES
 #define HITL_CR_WAVES 8
 #endif
-template <int B, int KIND>
+// RS: the chain's last node is a separator (CrView::rsep), known at compile time: the plain instantiations keep the code -- and the
+// registers -- they had before submap ranks learnt the separator form (a runtime flag cost the first stage 3 % and the 3 x 3
+// tiles of the one-pose band 8 %: same-box A/B, tools/dev/lib_ab.sh).
+template <int B, int KIND, bool RS = false>
 __global__ __launch_bounds__((B >= 12 || KIND == 1) ? 512 : 1024) __attribute__((amdgpu_waves_per_eu((KIND == 1 && B == 9) ? HITL_CR_WAVES : 4)))
 void k_cr_chunk(CrView cr, CrStage sg_in, CrSource src, double* w, double* x) {
   extern __shared__ double lds[];
@@ -741,15 +744,17 @@ void k_cr_chunk(CrView cr, CrStage sg_in, CrSource src, double* w, double* x) {
   const int wave = tid >> 6, lane = tid & 63, NW = nthr >> 6;
   CR_PROBE(0);
   const int64_t base = (int64_t)blockIdx.x * M;            // in stage nodes
-  const int64_t nst = cr_stage_nodes(cr, S);               // stage nodes alive: 0 .. nst-1
+  const int64_t nst = RS ? ((int64_t)cr.nsb - 2) / S + 2 : ((int64_t)cr.nsb + S - 1) / S;   // stage nodes alive: 0 .. nst-1 (cr_stage_nodes)
   // local slots that exist: u with base + u < nst
   const int u_last = (int)((nst - 1 - base < M) ? (nst - 1 - base) : M);     // >= 0
   // The chunk's right boundary (never eliminated here): local node M of a full chunk -- or, on a chain whose last node is a
   // separator (cr.rsep), the last node wherever it falls: it sits in slot u_last of the last chunk, lives at its true index
   // nsb - 1, and is the right neighbour of every eliminated node whose regular one (u + s) would lie beyond it.
-  const bool has_rb = (u_last == M) || (cr.rsep != 0);
-  const bool last_is_rb = has_rb && (base + u_last == nst - 1);
-  const int64_t rsep_sn = cr.rsep ? nst - 1 : -1;
+  const bool has_rb = (u_last == M) || RS;
+  const int rbs = RS ? u_last : M;                         // slot of the right boundary (when there is one)
+  const bool last_is_rb = has_rb && (base + rbs == nst - 1);
+  const int64_t rsep_sn = RS ? nst - 1 : -1;
+  (void)rsep_sn;
   const bool has_w = KIND == 1 || ((w != nullptr) && NR > 0);
   const bool from_src = KIND == 1 || src.Hband != nullptr;   // host: only with S == 1, no previous stage
   const size_t pws = (size_t)4 * sg.np * B;               // doubles of one right-hand side's contribution arrays
@@ -798,7 +803,7 @@ void k_cr_chunk(CrView cr, CrStage sg_in, CrSource src, double* w, double* x) {
       // first stage straight from the band blocks (k_build_system's arithmetic): only the nodes that outlive this stage
       // -- the chunk boundaries -- need their D in memory, where the next stage folds the contributions into it
       cr_source_tile_rec(sRec, src_rl, src_p0, src.n_poses, Wb, src.mu, src.min_diag, src.max_diag, B, (int)sn, q, d, l);
-      if (u == 0 || (last_is_rb && u == u_last)) cr.D[g] = d;
+      if (u == 0 || (u == rbs && sn == nst - 1)) cr.D[g] = d;
     } else {
       d = cr.D[g];
       l = cr.L[g];
@@ -808,7 +813,7 @@ void k_cr_chunk(CrView cr, CrStage sg_in, CrSource src, double* w, double* x) {
     sL[e] = l;
     // A boundary node stays alive: keep its folded value where the next stage reads it.  Every boundary is local node 0 of
     // one chunk -- except the very last node when it is local node M of the last chunk (no chunk on its right).
-    if ((u == 0 || (last_is_rb && u == u_last)) && sg.has_prev && !sg.top) cr.D[g] = d;
+    if ((u == 0 || (u == rbs && sn == nst - 1)) && sg.has_prev && !sg.top) cr.D[g] = d;
   }
   CR_PROBE(2);
   if (from_src) lds_barrier();                            // the staging area is overwritten from here on
@@ -834,21 +839,22 @@ void k_cr_chunk(CrView cr, CrStage sg_in, CrSource src, double* w, double* x) {
       } else v = w[g];
       if (sg.has_prev) v = (v - WLp[pws * rv + (size_t)sn * B + q]) - WRp[pws * rv + (size_t)sn * B + q];
       sW[((size_t)rv * nsl + u) * B + q] = v;
-      if (sg.has_prev && (u == 0 || (has_rb && u == u_last)) == false) w[g] = v;          // interior: the back-substitution reads the folded w
-      if ((u == 0 || (last_is_rb && u == u_last)) && sg.has_prev && !sg.top) w[g] = v;
+      if (sg.has_prev && (u == 0 || u == rbs) == false) w[g] = v;          // interior: the back-substitution reads the folded w
+      if ((u == 0 || (u == rbs && sn == nst - 1)) && sg.has_prev && !sg.top) w[g] = v;
     }
   for (int e = tid; e < 2 * BB + 2 * NR * B; e += nthr) accR[e] = 0.0;   // accR, accL, accWR, accWL are contiguous
   lds_barrier();
   CR_PROBE(3);
   int probe_slot = 4; (void)probe_slot;
-  const int u_hi = (!sg.top && has_rb) ? u_last - 1 : u_last;            // largest local node that may be eliminated
+  const int u_hi = RS ? ((!sg.top) ? u_last - 1 : u_last)
+                      : (sg.top ? u_last : ((u_last < M) ? u_last : M - 1));   // largest local node that may be eliminated
   for (int s = 1; s < M; s *= 2) {
     // ---- eliminate u = s, 3s, 5s .. <= u_hi ----
     for (int q = wave;; q += NW) {
       const int u = s * (2 * q + 1);
       if (u > u_hi) break;
-      const int b = (has_rb && u + s > u_last) ? u_last : u + s;
-      const bool has_b = (b <= u_last);
+      const int b = (RS && u + s > u_last) ? u_last : u + s;
+      const bool has_b = RS ? true : (b <= u_last);
       const int grp = lane / B, c = lane % B;
       double* Du = sD + (size_t)u * BB;
       double* Lu = sL + (size_t)u * BB;
@@ -946,40 +952,61 @@ void k_cr_chunk(CrView cr, CrStage sg_in, CrSource src, double* w, double* x) {
     lds_barrier();
     CR_PROBE(probe_slot++);
     // ---- survivors j = 0, 2s, 4s .. subtract what their eliminated neighbours left (left one first) ----
-    // (the last entry of the enumeration is the chunk's right boundary: j = M in a full chunk, slot u_last on a separator
-    // chain; the node that left something for it at this level -- if any -- is the last multiple of s below it when that is an
-    // ODD multiple: M - s in a full chunk)
+    // (separator chain: the last entry of the enumeration is the chunk's right boundary, slot u_last; the node that left something
+    // for it at this level -- if any -- is the last multiple of s below it when that is an ODD multiple: M - s in a full chunk)
     const int nsv = M / (2 * s) + 1;
-    const int rb_t = has_rb ? (u_last - 1) / s : 0;
+    const int rb_t = RS ? (u_last - 1) / s : 0;
     const int rb_u = rb_t * s;                                                     // >= 1 whenever rb_t is odd
     for (int e = tid; e < nsv * BB; e += nthr) {
-      const int idx = e / BB, q = e % BB;
-      const bool isb = has_rb && idx == nsv - 1;
-      const int j = isb ? u_last : 2 * s * idx;
-      if (!isb && j >= u_last + (has_rb ? 0 : 1)) continue;
-      const bool hl_ = isb ? ((rb_t & 1) != 0) : (j - s >= 1);
-      const bool hr_ = !isb && (j + s <= u_hi) && (j + s < M || sg.top);
-      const double pl = hl_ ? sL[(size_t)(isb ? rb_u : j - s) * BB + q] : 0.0;     // P_b of the left neighbour
-      const double pr = hr_ ? sD[(size_t)(j + s) * BB + q] : 0.0;                  // P_a of the right neighbour
-      if (isb) accL[q] += pl;
-      else if (j == 0) accR[q] += pr;
-      else sD[(size_t)j * BB + q] = (sD[(size_t)j * BB + q] - pl) - pr;
+      if (RS) {
+        const int idx = e / BB, q = e % BB;
+        const bool isb = idx == nsv - 1;
+        const int j = isb ? u_last : 2 * s * idx;
+        if (!isb && j >= u_last) continue;
+        const bool hl_ = isb ? ((rb_t & 1) != 0) : (j - s >= 1);
+        const bool hr_ = !isb && (j + s <= u_hi);
+        const double pl = hl_ ? sL[(size_t)(isb ? rb_u : j - s) * BB + q] : 0.0;   // P_b of the left neighbour
+        const double pr = hr_ ? sD[(size_t)(j + s) * BB + q] : 0.0;                // P_a of the right neighbour
+        if (isb) accL[q] += pl;
+        else if (j == 0) accR[q] += pr;
+        else sD[(size_t)j * BB + q] = (sD[(size_t)j * BB + q] - pl) - pr;
+      } else {
+        const int j = 2 * s * (e / BB), q = e % BB;
+        if (j > u_last) continue;
+        const bool hl_ = (j - s >= 1), hr_ = (j + s <= u_hi) && (j + s < M || sg.top);
+        const double pl = hl_ ? sL[(size_t)(j - s) * BB + q] : 0.0;                // P_b of the left neighbour
+        const double pr = hr_ ? sD[(size_t)(j + s) * BB + q] : 0.0;                // P_a of the right neighbour
+        if (j == 0) accR[q] += pr;
+        else if (j == M) accL[q] += pl;
+        else sD[(size_t)j * BB + q] = (sD[(size_t)j * BB + q] - pl) - pr;
+      }
     }
     if (has_w)
       for (int e = tid; e < NR * nsv * B; e += nthr) {
         const int rv = e / (nsv * B), e2 = e % (nsv * B);
-        const int idx = e2 / B, q = e2 % B;
-        const bool isb = has_rb && idx == nsv - 1;
-        const int j = isb ? u_last : 2 * s * idx;
-        if (!isb && j >= u_last + (has_rb ? 0 : 1)) continue;
-        const bool hl_ = isb ? ((rb_t & 1) != 0) : (j - s >= 1);
-        const bool hr_ = !isb && (j + s <= u_hi) && (j + s < M || sg.top);
         const size_t vb = (size_t)rv * nsl;
-        const double pl = hl_ ? sCb[(vb + (isb ? rb_u : j - s)) * B + q] : 0.0;
-        const double pr = hr_ ? sCa[(vb + (j + s)) * B + q] : 0.0;
-        if (isb) accWL[(size_t)rv * B + q] += pl;
-        else if (j == 0) accWR[(size_t)rv * B + q] += pr;
-        else sW[(vb + j) * B + q] = (sW[(vb + j) * B + q] - pl) - pr;
+        if (RS) {
+          const int idx = e2 / B, q = e2 % B;
+          const bool isb = idx == nsv - 1;
+          const int j = isb ? u_last : 2 * s * idx;
+          if (!isb && j >= u_last) continue;
+          const bool hl_ = isb ? ((rb_t & 1) != 0) : (j - s >= 1);
+          const bool hr_ = !isb && (j + s <= u_hi);
+          const double pl = hl_ ? sCb[(vb + (isb ? rb_u : j - s)) * B + q] : 0.0;
+          const double pr = hr_ ? sCa[(vb + (j + s)) * B + q] : 0.0;
+          if (isb) accWL[(size_t)rv * B + q] += pl;
+          else if (j == 0) accWR[(size_t)rv * B + q] += pr;
+          else sW[(vb + j) * B + q] = (sW[(vb + j) * B + q] - pl) - pr;
+        } else {
+          const int j = 2 * s * (e2 / B), q = e2 % B;
+          if (j > u_last) continue;
+          const bool hl_ = (j - s >= 1), hr_ = (j + s <= u_hi) && (j + s < M || sg.top);
+          const double pl = hl_ ? sCb[(vb + (j - s)) * B + q] : 0.0;
+          const double pr = hr_ ? sCa[(vb + (j + s)) * B + q] : 0.0;
+          if (j == 0) accWR[(size_t)rv * B + q] += pr;
+          else if (j == M) accWL[(size_t)rv * B + q] += pl;
+          else sW[(vb + j) * B + q] = (sW[(vb + j) * B + q] - pl) - pr;
+        }
       }
     lds_barrier();
     CR_PROBE(probe_slot++);
@@ -1001,7 +1028,7 @@ void k_cr_chunk(CrView cr, CrStage sg_in, CrSource src, double* w, double* x) {
     for (int e = tid; e < BB; e += nthr) {
       PRn[c0 * BB + e] = accR[e];
       if (blockIdx.x == 0) PLn[e] = 0.0;                                           // node 0 has no chunk on its left
-      if (has_rb) { PLn[c1 * BB + e] = accL[e]; cr.L[(size_t)CR_ADDR(base + u_last) * BB + e] = sL[(size_t)u_last * BB + e]; }
+      if (has_rb) { PLn[c1 * BB + e] = accL[e]; cr.L[(size_t)CR_ADDR(base + rbs) * BB + e] = sL[(size_t)rbs * BB + e]; }
       if (last_is_rb) PRn[c1 * BB + e] = 0.0;                                      // the last node has no chunk on its right
     }
     if (has_w)
@@ -1055,7 +1082,7 @@ void k_cr_chunk(CrView cr, CrStage sg_in, CrSource src, double* w, double* x) {
 // workgroups of a chunk land on the SAME XCD one after the other (workgroups go to the 8 XCDs round-robin by index): the
 // chunk's 3 x 81 x (M - 1) coefficient doubles come from HBM once and from that XCD's L2 for the other right-hand sides,
 // instead of nrhs times from HBM (a (chunks, nrhs) grid puts the workgroups of a chunk ~1000 dispatches apart).
-template <int B>
+template <int B, bool RS = false>
 __global__ __launch_bounds__(1024) void k_cr_chunk_back(CrView cr, int S, int M, int top, const double* __restrict__ w, double* __restrict__ x, size_t wstride,
                                                         int chunks, int nrhs) {
   if (cr.lm != nullptr && cr.lm->done) return;
@@ -1071,12 +1098,14 @@ __global__ __launch_bounds__(1024) void k_cr_chunk_back(CrView cr, int S, int M,
   w += wstride * rv;
   x += wstride * rv;
   const int64_t base = (int64_t)chunk * M;
-  const int64_t nst = cr_stage_nodes(cr, S);
+  const int64_t nst = RS ? ((int64_t)cr.nsb - 2) / S + 2 : ((int64_t)cr.nsb + S - 1) / S;
   const int u_last = (int)((nst - 1 - base < M) ? (nst - 1 - base) : M);
-  const bool has_rb = !top && ((u_last == M) || (cr.rsep != 0));     // see k_cr_chunk: the right boundary sits in slot u_last
-  const int64_t rsep_sn = cr.rsep ? nst - 1 : -1;
+  const bool has_rb = !top && ((u_last == M) || RS);     // see k_cr_chunk: on a separator chain the right boundary sits in slot u_last
+  const int64_t rsep_sn = RS ? nst - 1 : -1;
+  (void)rsep_sn;
   const int u = 1 + tid / B, r = tid % B;
-  const bool mine = u <= (has_rb ? u_last - 1 : u_last) && (tid < (M - (top ? 0 : 1)) * B) && u <= M;
+  const bool mine = RS ? (u <= (has_rb ? u_last - 1 : u_last) && (tid < (M - (top ? 0 : 1)) * B) && u <= M)
+                       : ((u < M || top) && u <= u_last && (tid < (M - (top ? 0 : 1)) * B) && u <= M);
   double gl[B], gr[B], v = 0.0;
 #pragma unroll
   for (int c = 0; c < B; ++c) { gl[c] = 0.0; gr[c] = 0.0; }
@@ -1092,13 +1121,13 @@ __global__ __launch_bounds__(1024) void k_cr_chunk_back(CrView cr, int S, int M,
   for (int e = tid; e < (M + 1) * B; e += blockDim.x) sx[e] = 0.0;
   __syncthreads();
   if (tid < 2 * B) {                                      // the two boundary nodes (known)
-    const int ub = (tid < B) ? 0 : u_last, rr = tid % B;
-    if (tid < B || has_rb) sx[(size_t)ub * B + rr] = x[(size_t)CR_ADDR(base + ub) * B + rr];
+    const int ub = (tid < B) ? 0 : (RS ? u_last : M), rr = tid % B;
+    if (RS ? (tid < B || has_rb) : (ub <= u_last && !(top && ub == M))) sx[(size_t)ub * B + rr] = x[(size_t)CR_ADDR(base + ub) * B + rr];
   }
   __syncthreads();
   for (int s = M / 2; s >= 1; s /= 2) {
     if (mine && (u & (2 * s - 1)) == s) {                 // u is eliminated at local stride s
-      const int b = (has_rb && u + s > u_last) ? u_last : u + s;
+      const int b = (RS && has_rb && u + s > u_last) ? u_last : u + s;
       const double* xl = sx + (size_t)(u - s) * B;
       const double* xr = sx + (size_t)((b <= M) ? b : u) * B;
       double acc = v;
@@ -1283,7 +1312,9 @@ static bool cr_factor_fused(hipStream_t st, const CrView& cr, double* w, double*
   static bool raised = false;
   if (!raised) {
     raised = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cr_chunk<B, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess &&
-             hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cr_chunk<B, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess;
+             hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cr_chunk<B, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess &&
+             hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cr_chunk<B, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess &&
+             hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cr_chunk<B, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess;
     if (!raised) { (void)hipGetLastError(); return false; }
   }
   const CrPlan pl = cr_plan(cr, B, cr.np, nrhs, wstride);
@@ -1307,8 +1338,11 @@ static bool cr_factor_fused(hipStream_t st, const CrView& cr, double* w, double*
     const size_t lds = cr_chunk_lds_bytes(g.nsl - 1, B, thr, nrhs) + (use_src ? cr_chunk_src_extra(g.nsl, B, thr, src->Wb, nrhs) : 0);
     CrSource none = {};
     if (use_src && nrhs == 1 && !g.top && !g.has_prev && g.S == 1 && thr <= 512 && 3 * src->Wb == B && (g.M + 1) * B <= thr &&
-        !(cr.rsep && t == pl.n - 1))
-      hipLaunchKernelGGL((k_cr_chunk<B, 1>), dim3(chunks > 0 ? chunks : 1), dim3(thr), lds, st, cr, g, *src, w, x);
+        !(cr.rsep && t == pl.n - 1)) {
+      if (cr.rsep) hipLaunchKernelGGL((k_cr_chunk<B, 1, true>), dim3(chunks > 0 ? chunks : 1), dim3(thr), lds, st, cr, g, *src, w, x);
+      else hipLaunchKernelGGL((k_cr_chunk<B, 1>), dim3(chunks > 0 ? chunks : 1), dim3(thr), lds, st, cr, g, *src, w, x);
+    } else if (cr.rsep)
+      hipLaunchKernelGGL((k_cr_chunk<B, 0, true>), dim3(chunks > 0 ? chunks : 1), dim3(thr), lds, st, cr, g, use_src ? *src : none, w, x);
     else
       hipLaunchKernelGGL((k_cr_chunk<B, 0>), dim3(chunks > 0 ? chunks : 1), dim3(thr), lds, st, cr, g, use_src ? *src : none, w, x);
   }
@@ -1321,7 +1355,10 @@ static bool cr_factor_fused(hipStream_t st, const CrView& cr, double* w, double*
       int thr = (g.M - (g.top ? 0 : 1)) * B;
       thr = (thr + 63) & ~63;
       const int grid = (nrhs > 1) ? 8 * nrhs * ((chunks + 7) / 8) : chunks;
-      hipLaunchKernelGGL(k_cr_chunk_back<B>, dim3(grid), dim3(thr), sizeof(double) * (g.M + 1) * B, st, cr, g.S, g.M, g.top, w, x, wstride, chunks, nrhs);
+      if (cr.rsep)
+        hipLaunchKernelGGL((k_cr_chunk_back<B, true>), dim3(grid), dim3(thr), sizeof(double) * (g.M + 1) * B, st, cr, g.S, g.M, g.top, w, x, wstride, chunks, nrhs);
+      else
+        hipLaunchKernelGGL((k_cr_chunk_back<B, false>), dim3(grid), dim3(thr), sizeof(double) * (g.M + 1) * B, st, cr, g.S, g.M, g.top, w, x, wstride, chunks, nrhs);
     }
   }
   return true;
@@ -1354,7 +1391,7 @@ static bool cr_solve_fused(hipStream_t st, const CrView& cr, const double* w_in,
     int thr = (g.M - (g.top ? 0 : 1)) * B;
     thr = (thr + 63) & ~63;
     if (thr > 1024) return false;
-    hipLaunchKernelGGL(k_cr_chunk_back<B>, dim3(chunks), dim3(thr), sizeof(double) * (g.M + 1) * B, st, cr, g.S, g.M, g.top, w, x, (size_t)0, chunks, 1);
+    hipLaunchKernelGGL((k_cr_chunk_back<B, false>), dim3(chunks), dim3(thr), sizeof(double) * (g.M + 1) * B, st, cr, g.S, g.M, g.top, w, x, (size_t)0, chunks, 1);
   }
   return true;
 }
