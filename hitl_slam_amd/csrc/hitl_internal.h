@@ -247,6 +247,8 @@ void launch_sep_selinv(hipStream_t st, const CrView& red, const double* rec_all,
 void launch_spmv(hipStream_t st, int n_poses, int npad, const FactorView& fv, const LinView& lin,
                  const double* scale, double mu, double min_diag, double max_diag, const double* v, double* y, bool all_cols = false);
 void launch_host_flag(hipStream_t st, double* flag_pinned, double seq);
+// (dt.rhs, dt.q, |step|^2, |x|^2, bad, cost, max |g|) of a submap rank from its per-workgroup partials, in ordered_sum32's order
+void launch_sum_partials(hipStream_t st, const double* step_partials, int nblk_step, const double* lin_partials, int nblk_lin, double* rec7);
 // device-driven LM loop: the band pass on the CURRENT buffers (lin0 / lin1, x0 / x1 picked by lm->cur; mu = lm->radius),
 // candidate state into the other x buffer, partials into device memory
 void launch_spmv_residual_step_lm(hipStream_t st, int n_poses, int npad, const FactorView& fv, const LinView& lin0, const LinView& lin1,

@@ -20,7 +20,8 @@ namespace hitl {
 // one pass over every factor at state xdev: residuals, Jacobians, J^T J blocks, gradient, cost.
 // enqueue_linearize only queues the kernels and the copy of the per-workgroup partials (behind the step partials in
 // the pinned buffer); finish_linearize adds them up once the stream has been synchronised.
-static int enqueue_linearize(hitl_solver* s, const FactorView& fv, const double* xdev, int buf, bool direct = false, bool have_trig = false) {
+static int enqueue_linearize(hitl_solver* s, const FactorView& fv, const double* xdev, int buf, bool direct = false, bool have_trig = false,
+                             bool device_only = false /* the partials stay in device memory (launch_sum_partials adds them up there) */) {
   hipStream_t st = s->stream;
   const MapView mv = s->map_view();
   const PairView pv = s->pair_view();
@@ -51,7 +52,7 @@ static int enqueue_linearize(hitl_solver* s, const FactorView& fv, const double*
   launch_assemble(st, mv, pv, fv, xdev, lv);
   HIP_TRY(hipGetLastError());
   const int nblk = assemble_blocks(s->n);
-  if (!direct) HIP_TRY(hipMemcpyAsync(host, lv.partials, sizeof(double) * 2 * nblk, hipMemcpyDeviceToHost, st));
+  if (!direct && !device_only) HIP_TRY(hipMemcpyAsync(host, lv.partials, sizeof(double) * 2 * nblk, hipMemcpyDeviceToHost, st));
   return HITL_OK;
 }
 
@@ -537,20 +538,39 @@ static int linear_solve_and_step_dist(hitl_solver* s, const FactorView& fv, int 
   }
   // model-cost pieces over the owned rows (halo columns carry the neighbours' steps), candidate state
   double2* cs_out = fv.with_stf ? s->pose_cs.p : nullptr;      // the trig table of the candidate, written by the two kernels that form it
-  launch_spmv_step(st, n, npad, fv, lv, s->scale.p, s->dt.p, s->rhs.p, xcur, s->qv.p, xcand, s->h_partials, cs_out);   // partials straight into pinned host memory
+  // With the built-in RCCL transport the whole exchange stays on the device (round 4): the per-workgroup partials are added up
+  // by a kernel (the host's order), the 7 scalars go device -> device through ncclAllGather, one copy brings all ranks' scalars
+  // to the host and the host waits ONCE.  A caller callback (host buffers) keeps the older flow: partials straight into pinned
+  // memory, one wait, host sums, callback.
+  const bool on_device = s->nccl != nullptr && !s->comm.allgather;
+  double* step_out = on_device ? s->step_partials.p : s->h_partials;
+  launch_spmv_step(st, n, npad, fv, lv, s->scale.p, s->dt.p, s->rhs.p, xcur, s->qv.p, xcand, step_out, cs_out);
   launch_halo_candidate(st, nh, s->halo_idx.p, xcur, s->scale.p, s->dt.p, xcand, cs_out);
   HIP_TRY(hipGetLastError());
   // The candidate does not depend on any host decision, so its linearisation is queued right here and its two scalars
   // ride in the same all-gather as the step scalars (exchanges 3 and 1 merged: 7 doubles per rank).
-  if (spec) TRY(enqueue_linearize(s, fv, xcand, buf ^ 1, /*direct=*/true, /*have_trig=*/true));
-  TRY(spin_sync(s));                     // host vectors above stay alive until here
-  StepScalars loc;
-  TRY(finish_step_partials(s, nullptr, nullptr, &loc));
-  LinResult lloc = {0.0, 0.0, 0.f, 0};
-  if (spec) TRY(finish_linearize(s, fv, &lloc));
-  double r2[7] = {loc.dt_rhs, loc.dt_q, loc.step2, loc.xn2, loc.bad, lloc.cost, lloc.gmax};
+  if (spec) TRY(enqueue_linearize(s, fv, xcand, buf ^ 1, /*direct=*/!on_device, /*have_trig=*/true, /*device_only=*/on_device));
   std::vector<double> all2((size_t)7 * W);
-  TRY(comm_allgather(s, r2, all2.data(), sizeof(r2)));
+  LinResult lloc = {0.0, 0.0, 0.f, 0};
+  if (on_device) {
+    TRY(s->comm_send.resize(sizeof(double) * 8)); TRY(s->comm_recv.resize(sizeof(double) * 7 * (size_t)W));
+    double* rec7 = reinterpret_cast<double*>(s->comm_send.p);
+    launch_sum_partials(st, s->step_partials.p, spmv_blocks(npad), spec ? s->lin_view(buf ^ 1).partials : nullptr, assemble_blocks(n), rec7);
+    const ncclResult_t r = ncclAllGather(rec7, s->comm_recv.p, 7 * sizeof(double), ncclChar, s->nccl, st);
+    if (r != ncclSuccess) return fail(HITL_ERR_COMM, std::string("ncclAllGather: ") + ncclGetErrorString(r));
+    double* host_all = s->h_partials;                      // pinned; nothing else lands there on this path
+    HIP_TRY(hipMemcpyAsync(host_all, s->comm_recv.p, sizeof(double) * 7 * (size_t)W, hipMemcpyDeviceToHost, st));
+    TRY(spin_sync(s));                   // host vectors above stay alive until here
+    std::memcpy(all2.data(), host_all, sizeof(double) * 7 * (size_t)W);
+    if (spec) { lloc.timed = s->lin_timed ? 1 : 0; if (s->lin_timed) HIP_TRY(hipEventElapsedTime(&lloc.stf_ms, s->ev0, s->ev1)); }
+  } else {
+    TRY(spin_sync(s));                     // host vectors above stay alive until here
+    StepScalars loc;
+    TRY(finish_step_partials(s, nullptr, nullptr, &loc));
+    if (spec) TRY(finish_linearize(s, fv, &lloc));
+    double r2[7] = {loc.dt_rhs, loc.dt_q, loc.step2, loc.xn2, loc.bad, lloc.cost, lloc.gmax};
+    TRY(comm_allgather(s, r2, all2.data(), sizeof(r2)));
+  }
   ss->dt_rhs = ss->dt_q = ss->step2 = ss->xn2 = ss->bad = 0.0;
   double cost = 0.0, gmax = 0.0;
   for (int g = 0; g < W; ++g) {          // rank order on every rank: identical sums everywhere

@@ -264,6 +264,34 @@ void launch_spmv_residual_step_lm(hipStream_t st, int n_poses, int npad, const F
 // submap and off-band paths, and is the default: HITL_DEVICE_LM=1 selects this one).  The per-workgroup partial sums are added in index
 // order, one sequence per lane -- the same order the host used, so both loops take bit-identical decisions.
 // ---------------------------------------------------------------------------------------------------------------------
+// The scalars a submap rank contributes to the exchange that ends an LM iteration -- (dt.rhs, dt.q, |step|^2, |x|^2, bad,
+// cost, max |g| of the candidate) -- summed from the per-workgroup partials ON THE DEVICE, in the order of ordered_sum32 (the
+// host's), so that with the built-in RCCL transport the record can travel device -> device and the host waits once per
+// iteration instead of twice (round 4).  lp == null: no linearisation was queued (cost, max |g| = 0).
+__global__ __launch_bounds__(512) void k_sum_partials(const double* __restrict__ sp, int nblk_step, const double* __restrict__ lp, int nblk_lin,
+                                                      double* __restrict__ rec7) {
+  __shared__ double part[7][32];
+  const int tid = threadIdx.x, grp = tid >> 5, j = tid & 31;
+  if (grp < 7) {
+    double acc = 0.0;
+    if (grp < 5) { for (int b = j; b < nblk_step; b += 32) acc += sp[8 * b + 2 + grp]; }
+    else if (lp != nullptr && grp == 5) { for (int b = j; b < nblk_lin; b += 32) acc += lp[2 * b]; }
+    else if (lp != nullptr) { for (int b = j; b < nblk_lin; b += 32) { const double g = lp[2 * b + 1]; if (g > acc || g != g) acc = g; } }
+    part[grp][j] = acc;
+  }
+  __syncthreads();
+  if (tid < 7) {
+    double t = 0.0;
+    if (tid != 6) { for (int q = 0; q < 32; ++q) t += part[tid][q]; }
+    else { for (int q = 0; q < 32; ++q) { const double g = part[6][q]; if (g > t || g != g) t = g; } }
+    rec7[tid] = t;
+  }
+}
+
+void launch_sum_partials(hipStream_t st, const double* step_partials, int nblk_step, const double* lin_partials, int nblk_lin, double* rec7) {
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(512), 0, st, step_partials, nblk_step, lin_partials, nblk_lin, rec7);
+}
+
 __global__ __launch_bounds__(1024) void k_lm_decide(LmDev* lm, LmOpts o, const double* __restrict__ sp, int nblk_step, const double* __restrict__ lp0,
                                                     const double* __restrict__ lp1, int nblk_lin, volatile double* progress) {
 #pragma clang fp contract(off)      // the host loop is compiled without contraction: 1 - q*q*q must round like there

@@ -8,7 +8,13 @@ n, m = 50000, 400
 p = S.params(n, m, seed=20264102, poses_per_floor=200)
 gt, init, cov = S.poses(p)
 off, px, py, nx, ny = S.scans(p)
-s = H.Solver()
+opt = H.default_options()
+if os.environ.get("HITL_FORCE_RCCL"):           # one-rank RCCL communicator: the exchanges of the submap path really go through ncclAllGather
+    import ctypes as C
+    from hitl_slam_amd.api import comm_unique_id
+    _uid = (C.c_char * 128).from_buffer_copy(comm_unique_id())
+    opt.rccl_unique_id = C.cast(_uid, C.c_void_p)
+s = H.Solver(opt)
 s.set_map(off, px, py, nx, ny, cov)
 s.set_human_constraints(S.constraints(p, gt, 50, kind=4))
 s.find_correspondences(init, 3)
