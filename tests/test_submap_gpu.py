@@ -177,3 +177,36 @@ def test_mode_b_on_submap_ranks_reaches_the_global_cost_level(tmp_path, world):
         assert sm["termination"] in (0, 1) and sm["final_cost"] < sm["initial_cost"]
         assert abs(sm["final_cost"] - so.final_cost) <= 2e-2 * so.final_cost
         assert np.abs(got - po[x["begin"]:x["end"]]).max() <= 3e-2      # along the weakly observed corridor direction (1.5e-2 on 2 ranks, 9e-4 on 3)
+
+
+@pytest.mark.parametrize("world,window", [(2, 1), (2, 2), (3, 2), (2, 4), (3, 4)])
+def test_separator_form_at_other_band_widths(tmp_path, world, window):
+    """Round 4: the separator form with super-blocks of 1, 2 and 4 poses (B = 3, 6, 12; the other cases run B = 9 and, in mode A,
+    B = 3): 60-pose ranks (two) and 40-pose ranks (three) inside one corridor are multiples of each band, so the solve AND the pose
+    covariances on the ranks take it; both must equal the oracle's global solve / dense global inverse."""
+    from oracle import hitl_oracle as O
+    out = str(tmp_path / "res")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", HITL_TEST_WINDOW=str(window), HITL_TEST_HALO=str(2 * window))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_submap_worker.py"), out, "2", "120"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = [json.load(open("%s.%d" % (out, k))) for k in range(world)]
+    prob = Problem(120, 48, ppf=120, groups=2, kind=0)
+    o = prob.load(O.OracleSolver())
+    o.find_correspondences(prob.init, window, 1)
+    ops = o.get_correspondences()
+    assert np.abs(ops[0] - ops[1]).max() == window
+    So = o.pose_covariances(2, prob.init)
+    po, so = o.solve(2, prob.init)
+    for x in res:
+        sm = x["summary"]
+        assert sm["submap_linear_solver"] == 2 and sm["band_poses"] == window
+        assert sm["termination"] == so.termination and sm["iterations"] == so.iterations and sm["successful_steps"] == so.successful_steps
+        assert abs(sm["final_cost"] - so.final_cost) <= 1e-8 * so.final_cost
+        b, e = x["begin"], x["end"]
+        got = np.array(x["poses"], np.float32)[b:e]
+        assert np.abs(got - po[b:e]).max() <= 1e-4
+        Sg = np.array(x["cov"])
+        scale = np.abs(So[b:e]).max(axis=(1, 2))[:, None, None] + 1e-300
+        assert (np.abs(Sg[b:e] - So[b:e]) / scale).max() < 1e-6
