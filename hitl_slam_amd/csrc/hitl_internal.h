@@ -41,6 +41,7 @@ struct DevSwitches {
   int kd_cap = 0;                  // HITL_KD_CAP: frame-stack entries per lane of k_match_kd_tgt's first attempt (0 = 5); tests force the full-depth repeat with 1
   int kd_redo_cap = 1 << 18;       // HITL_KD_REDO_CAP: entries of the redo list behind the fast attempt (tests shrink it to force the full-depth repeat)
   int kd_refill = 16;              // HITL_KD_REFILL: idle lanes per wave that trigger a refill from the query queue
+  int kd_fast = 1;                 // HITL_KD_FAST: kd_step_fast calls behind every kd_step of k_match_kd_tgt (0, 1, 2)
   size_t cand_tile_bytes = (size_t)4 << 30;   // HITL_CAND_TILE_BYTES: candidate-table budget of the tiled search
   int cr_plan[16] = {0};           // HITL_CR_PLAN: chunk sizes of the fused stages
   int cr_plan_n = 0;

@@ -152,6 +152,45 @@ HITL_HD void kd_step(KdWalk& w, const float4* pts, const uint32_t* meta, float t
   w.mode = (early || no_child) ? 1 : (go ? 0 : w.mode);
 }
 
+// The cheap half of kd_step (round 4): a query that is about to ENTER a node and will not push a frame there -- the node ends the
+// run (early return, no child on the query's side) or folds into the incumbent and the walk descends -- takes exactly the
+// transition kd_step would give it; every other lane (returning runs, finished queries, nodes whose far side may still be taken:
+// those need the frame stack) is left untouched for the next kd_step.  Four of five steps of a scan query are of this kind, and
+// without the stack, the pops and the return logic the step costs about a third of kd_step's instructions: the kernels alternate
+// the two.  Same expressions as kd_step, so the walk -- winner and distance bits -- cannot change.
+HITL_HD void kd_step_fast(KdWalk& w, const float4* pts, const uint32_t* meta, float thr, float thr2) {
+  constexpr float kFltMax = 3.402823466e+38f, kFltMin = 1.175494351e-38f;
+  const bool enter = (w.mode == 0);
+  const int n = w.n, ind = n >> 1, pos = w.lo + ind;
+  const int rp = enter ? pos : 0;
+  const float4 g = pts[rp];
+  const int split = (int)(meta[rp] >> 16);
+  const float dx = g.x - w.qx, dy = g.y - w.qy;
+  const bool ingate = dx * dx + dy * dy < thr2;
+  const float sc = __builtin_fabsf(g.z * (w.qx - g.x) + g.w * (w.qy - g.y));
+  const float best = ingate ? sc : kFltMax;
+  const int out = ingate ? pos : -1;
+  const float pd = (split ? w.qy : w.qx) - (split ? g.y : g.x);
+  const float apd = __builtin_fabsf(pd);
+  const bool has_right = ind < n - 1, has_left = ind > 0;
+  const bool early = enter && ingate && sc < kFltMin;
+  const bool go_l = enter && !early && pd <= 0.0f && has_left;
+  const bool go_r = enter && !early && !go_l && pd >= 0.0f && has_right;
+  const bool no_child = enter && !early && !go_l && !go_r;
+  const float lim0 = (best < thr) ? best : thr;
+  const bool merge_only = ((pd != 0.0f) && !(apd < lim0)) || (go_l && !has_right);
+  const bool fold = (go_l || go_r) && merge_only;          // (go_l || go_r) && !merge_only would push: not here
+  const bool own_beats_inc = best < w.inc_d;
+  w.inc_d = (fold && own_beats_inc) ? best : w.inc_d;
+  w.inc_c = (fold && own_beats_inc) ? out : w.inc_c;
+  const bool to_right = fold && go_r, to_left = fold && go_l;
+  w.lo = to_right ? w.lo + ind + 1 : w.lo;
+  w.n = to_right ? n - ind - 1 : (to_left ? ind : n);
+  w.ret_d = early ? 0.0f : (no_child ? best : w.ret_d);
+  w.ret_c = early ? pos : (no_child ? out : w.ret_c);
+  w.mode = (early || no_child) ? 1 : w.mode;
+}
+
 // The same walk as a literal unrolling of the recursion onto an explicit frame stack (round 2's kernel; bit for bit the
 // CPU restatement's method 1 up to 105.9 M matches): kept as the yardstick `kd_step` is held to.
 HITL_HD float kd_find_nearest_point_normal(const float4* __restrict__ pts, const uint32_t* __restrict__ meta, int m,

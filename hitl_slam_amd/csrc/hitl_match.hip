@@ -296,7 +296,9 @@ static int kd_tgt_cap(int max_scan, bool full) {
   return c < d ? c : d;
 }
 
-template <int BLOCK>
+// FAST: kd_step_fast calls behind every kd_step (hitl_kdwalk.h: the cheap transitions of a walk need neither the frame stack nor
+// the return logic)
+template <int BLOCK, int FAST = 1>
 __global__ __launch_bounds__(BLOCK) void k_match_kd_tgt(MapView map, int chunk, int max_scan, int slots, int window, int depth, int refill_min,
                                                          const float* __restrict__ cand_tf, MatchParams mp,
                                                          const float4* __restrict__ kd_pts, const uint32_t* __restrict__ kd_meta,
@@ -392,6 +394,8 @@ __global__ __launch_bounds__(BLOCK) void k_match_kd_tgt(MapView map, int chunk, 
       }
     }
     kd_step(w, s_tgt, s_meta, thr, thr2, my_inc, my_seg, my_oc, BLOCK, depth);
+#pragma unroll
+    for (int f = 0; f < FAST; ++f) kd_step_fast(w, s_tgt, s_meta, thr, thr2);
   }
   __syncthreads();
   if ((int)threadIdx.x < ns) counts[s_cand[threadIdx.x]] = s_count[threadIdx.x];
@@ -525,9 +529,15 @@ static void launch_match_kd_tgt_t(hipStream_t st, const MapView& map, int max_sc
   const int chunk = (map.n_poses + 7) / 8;
   const int depth = kd_tgt_cap(max_scan, full_depth);
   const size_t lds = match_kd_tgt_lds_bytes(max_scan, BLOCK, full_depth);
-  if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_match_kd_tgt<BLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(k_match_kd_tgt<BLOCK>, dim3(8 * chunk), dim3(BLOCK), lds, st, map, chunk, max_scan, slots, window, depth, refill_min, cand_tf, mp,
-                     kd_pts, kd_meta, table, counts, redo_count, redo_list, redo_cap);
+  const int fast = dev_switches().kd_fast;
+#define HITL_KD_GO(F)                                                                                                                                  \
+  do {                                                                                                                                                 \
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_match_kd_tgt<BLOCK, F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((k_match_kd_tgt<BLOCK, F>), dim3(8 * chunk), dim3(BLOCK), lds, st, map, chunk, max_scan, slots, window, depth, refill_min, cand_tf, mp,      \
+                       kd_pts, kd_meta, table, counts, redo_count, redo_list, redo_cap);                                                                             \
+  } while (0)
+  if (fast == 0) HITL_KD_GO(0); else if (fast == 2) HITL_KD_GO(2); else HITL_KD_GO(1);
+#undef HITL_KD_GO
   if (!full_depth)
     hipLaunchKernelGGL(k_match_kd_redo, dim3(256), dim3(64), 0, st, map, max_scan, slots, window, cand_tf, mp, kd_pts, kd_meta, table, counts, redo_count,
                        redo_list, redo_cap);

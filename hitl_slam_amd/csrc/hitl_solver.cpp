@@ -565,6 +565,7 @@ void read_dev_switches() {
   d.kd_redo_cap = (int)std::max(1ll, std::min((long long)(1 << 18), num("HITL_KD_REDO_CAP", d.kd_redo_cap)));
   d.lm_ahead = (int)std::max(1ll, std::min(16ll, num("HITL_LM_AHEAD", d.lm_ahead)));
   d.kd_refill = (int)std::max(1ll, std::min(64ll, num("HITL_KD_REFILL", d.kd_refill)));
+  d.kd_fast = (int)std::max(0ll, std::min(2ll, num("HITL_KD_FAST", d.kd_fast)));
   d.cand_tile_bytes = (size_t)std::max(1ll, num("HITL_CAND_TILE_BYTES", (long long)d.cand_tile_bytes));
   d.cr_threads = (int)num("HITL_CR_THREADS", 0);
   if (const char* e = std::getenv("HITL_CR_PLAN"))

@@ -51,8 +51,15 @@ void kdw_build(int m, const float* x, const float* y, const float* nx, const flo
 }
 
 // returns the number of queries on which the two walks disagree (distance bits or winner)
+// fast: kd_step_fast calls behind every kd_step (the kernels' schedule); `evals` then counts the pairs
+int64_t kdw_check2(int m, const float* pts4, const uint32_t* meta, int64_t nq, const float* qx, const float* qy, float thr,
+                   int32_t* pos_new, float* d_new, int32_t* pos_old, float* d_old, int32_t* evals, int cap, int fast);
 int64_t kdw_check(int m, const float* pts4, const uint32_t* meta, int64_t nq, const float* qx, const float* qy, float thr,
                   int32_t* pos_new, float* d_new, int32_t* pos_old, float* d_old, int32_t* evals, int cap) {
+  return kdw_check2(m, pts4, meta, nq, qx, qy, thr, pos_new, d_new, pos_old, d_old, evals, cap, 0);
+}
+int64_t kdw_check2(int m, const float* pts4, const uint32_t* meta, int64_t nq, const float* qx, const float* qy, float thr,
+                   int32_t* pos_new, float* d_new, int32_t* pos_old, float* d_old, int32_t* evals, int cap, int fast) {
   const float4* pts = reinterpret_cast<const float4*>(pts4);
   std::vector<float> f_inc(64), st_best(64), st_pd(64);
   std::vector<uint32_t> f_seg(64), f_oc(64);
@@ -66,7 +73,10 @@ int64_t kdw_check(int m, const float* pts4, const uint32_t* meta, int64_t nq, co
     int deep = 0;
     w.ovf = 0;
     w.t_inc = 0.0f; w.t_seg = 0; w.t_oc = 0;
-    while (w.mode != 2) { kd_step(w, pts, meta, thr, thr2, f_inc.data(), f_seg.data(), f_oc.data(), 1, cap); ++it; deep = std::max(deep, w.sp); }
+    while (w.mode != 2) {
+      kd_step(w, pts, meta, thr, thr2, f_inc.data(), f_seg.data(), f_oc.data(), 1, cap); ++it; deep = std::max(deep, w.sp);
+      for (int f = 0; f < fast; ++f) kd_step_fast(w, pts, meta, thr, thr2);
+    }
     pos_new[q] = w.ret_c; d_new[q] = w.ret_d; evals[q] = it | (deep << 16) | (w.ovf << 30);
     int po = -1;
     float dd = 3.402823466e+38f;
@@ -80,8 +90,14 @@ int64_t kdw_check(int m, const float* pts4, const uint32_t* meta, int64_t nq, co
 // lock-step simulation: `lanes` lanes share a queue of nq queries (handed out in order); idle lanes are refilled when at
 // least `refill_min` of them are idle (or nothing else is running).  Returns wave iterations; *busy = lane-iterations that
 // evaluated or popped something.
+int64_t kdw_sim2(int m, const float* pts4, const uint32_t* meta, int64_t nq, const float* qx, const float* qy, float thr, int lanes,
+                 int refill_min, int64_t* busy, int64_t* refills, int fast);
 int64_t kdw_sim(int m, const float* pts4, const uint32_t* meta, int64_t nq, const float* qx, const float* qy, float thr, int lanes,
                 int refill_min, int64_t* busy, int64_t* refills) {
+  return kdw_sim2(m, pts4, meta, nq, qx, qy, thr, lanes, refill_min, busy, refills, 0);
+}
+int64_t kdw_sim2(int m, const float* pts4, const uint32_t* meta, int64_t nq, const float* qx, const float* qy, float thr, int lanes,
+                 int refill_min, int64_t* busy, int64_t* refills, int fast) {
   const float4* pts = reinterpret_cast<const float4*>(pts4);
   const float thr2 = thr * thr;
   std::vector<KdWalk> w(lanes);
@@ -98,6 +114,8 @@ int64_t kdw_sim(int m, const float* pts4, const uint32_t* meta, int64_t nq, cons
       for (auto& x : w) if (x.mode == 2 && next < nq) { kd_begin(x, qx[next], qy[next], m); ++next; }
     }
     for (int l = 0; l < lanes; ++l) if (w[l].mode != 2) { kd_step(w[l], pts, meta, thr, thr2, sb[l].data(), so[l].data(), sq[l].data(), 1, 62); ++b; }
+    for (int f = 0; f < fast; ++f)
+      for (int l = 0; l < lanes; ++l) if (w[l].mode != 2) kd_step_fast(w[l], pts, meta, thr, thr2);
     ++iters;
   }
   *busy = b; *refills = rf;

@@ -26,7 +26,9 @@ def kdw():
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", LIB, SRC])
     lib = C.CDLL(LIB)
     lib.kdw_check.restype = C.c_int64
+    lib.kdw_check2.restype = C.c_int64
     lib.kdw_sim.restype = C.c_int64
+    lib.kdw_sim2.restype = C.c_int64
     return lib
 
 
@@ -43,13 +45,15 @@ def build_tree(lib, x, y, nx, ny):
     return pts, meta
 
 
-def check(lib, pts, meta, m, qx, qy, thr, cap=62):
+def check(lib, pts, meta, m, qx, qy, thr, cap=62, fast=0):
+    """fast: kd_step_fast calls behind every kd_step (1 = the schedule the kernels run)"""
     nq = len(qx)
     qx, qy = np.ascontiguousarray(qx, np.float32), np.ascontiguousarray(qy, np.float32)
     pn, po = np.zeros(nq, np.int32), np.zeros(nq, np.int32)
     dn, do = np.zeros(nq, np.float32), np.zeros(nq, np.float32)
     ev = np.zeros(nq, np.int32)
-    bad = lib.kdw_check(C.c_int(m), _p(pts), _p(meta), C.c_int64(nq), _p(qx), _p(qy), C.c_float(thr), _p(pn), _p(dn), _p(po), _p(do), _p(ev), C.c_int(cap))
+    bad = lib.kdw_check2(C.c_int(m), _p(pts), _p(meta), C.c_int64(nq), _p(qx), _p(qy), C.c_float(thr), _p(pn), _p(dn), _p(po), _p(do), _p(ev), C.c_int(cap),
+                         C.c_int(fast))
     return bad, pn, dn, po, do, ev
 
 
@@ -69,7 +73,7 @@ def scan_queries(prob, i, j):
 def test_state_machine_equals_the_recursion_on_scan_queries(kdw):
     prob = Problem(40, 400, ppf=20)
     total = 0
-    evals = []
+    evals, evals_fast = [], []
     for j in range(0, prob.n, 3):
         a, b = prob.off[j], prob.off[j + 1]
         pts, meta = build_tree(kdw, prob.px[a:b], prob.py[a:b], prob.nx[a:b], prob.ny[a:b])
@@ -80,6 +84,11 @@ def test_state_machine_equals_the_recursion_on_scan_queries(kdw):
             qx, qy = scan_queries(prob, i, j)
             bad, pn, dn, po, do, ev = check(kdw, pts, meta, b - a, qx, qy, 0.15)
             assert bad == 0, (i, j, np.nonzero((pn != po) | (dn.view(np.uint32) != do.view(np.uint32)))[0][:5])
+            for fast in (1, 2):       # kd_step_fast behind every kd_step: the same walk in fewer rounds
+                badf, pnf, dnf, _, _, evf = check(kdw, pts, meta, b - a, qx, qy, 0.15, fast=fast)
+                assert badf == 0 and np.array_equal(pnf, pn) and np.array_equal(dnf.view(np.uint32), dn.view(np.uint32))
+                if fast == 1:
+                    evals_fast.append(evf)
             total += len(qx)
             evals.append(ev)
     evals = np.concatenate(evals)
@@ -87,6 +96,7 @@ def test_state_machine_equals_the_recursion_on_scan_queries(kdw):
     assert total > 20000 and not (evals >> 30).any()
     # design figures, not a parity statement: steps per query (a 400-point tree has 9 levels) and how deep the stack of
     # real frames gets (frames that may still take the far side of their split plane; the rest fold into the incumbent)
+    print("\nkd_step + kd_step_fast alternating: %.1f rounds per query" % (np.concatenate(evals_fast) & 0xffff).mean())
     print("\nkd_step: %d queries, steps per query mean %.1f, p50 %d, p99 %d, max %d; frame-stack depth: %s"
           % (total, steps.mean(), np.median(steps), np.percentile(steps, 99), steps.max(),
              ", ".join("%d: %.4f" % (d, (deep == d).mean()) for d in range(deep.max() + 1))))
@@ -113,6 +123,8 @@ def test_state_machine_equals_the_recursion_on_adversarial_sets(kdw, seed):
         for thr in (0.15, 0.07, 3.0, 1e-3):
             bad, pn, dn, po, do, ev = check(kdw, pts, meta, m, qx, qy, thr)
             assert bad == 0, (m, thr, np.nonzero((pn != po) | (dn.view(np.uint32) != do.view(np.uint32)))[0][:5])
+            badf, pnf, dnf, _, _, _ = check(kdw, pts, meta, m, qx, qy, thr, fast=1)
+            assert badf == 0 and np.array_equal(pnf, pn) and np.array_equal(dnf.view(np.uint32), dn.view(np.uint32))
             if m >= 31 and thr == 0.15:
                 assert (dn == 0).any()        # the FLT_MIN early return was exercised
             # a frame stack that is too small must say so, never answer wrongly (the kernels size it for the tree's depth).
