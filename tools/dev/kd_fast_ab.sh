@@ -3,7 +3,7 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 for rep in 1 2; do
-for f in 0 1 2; do
+for f in ${KDF:-0 1 2}; do
   OUT=gpurun_out/kdfast_$f
   rm -rf $OUT; mkdir -p $OUT
   HITL_KD_FAST=$f REPS=4 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/t -- python3 tools/dev/search_time.py > $OUT/out.txt 2> $OUT/err.txt
