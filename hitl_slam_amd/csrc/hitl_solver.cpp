@@ -390,17 +390,19 @@ int prepare(hitl_solver* s, int mode, const float* poses_ref, const float* poses
       // point: a rank that failed above (or holds pose pairs outside the band, which submap solves do not support yet)
       // must not let the others walk into the collectives of the LM loop alone
       const bool offband_here = (mode != HITL_MODE_ODOM_HC) && s->n_offband > 0;
-      double mine[5] = {(double)wi_local, (double)local_rc, offband_here ? 1.0 : 0.0, (double)Wb, (double)(s->own_hi - s->own_lo)};
-      std::vector<double> all((size_t)5 * s->world);
+      // (the last entry: this rank is willing to take the separator form -- HITL_DIST_COLUMNS is a per-process switch, and a rank
+      // that differs from the others must not leave them waiting in the separator form's own exchange below)
+      double mine[6] = {(double)wi_local, (double)local_rc, offband_here ? 1.0 : 0.0, (double)Wb, (double)(s->own_hi - s->own_lo), sep_cand ? 1.0 : 0.0};
+      std::vector<double> all((size_t)6 * s->world);
       TRY(comm_allgather(s, mine, all.data(), sizeof(mine)));
       int worst = HITL_OK;
       bool any_offband = false;
       for (int r = 0; r < s->world; ++r) {
-        wi_local = std::max(wi_local, (int)all[(size_t)5 * r]);
-        if ((int)all[(size_t)5 * r + 1] != HITL_OK && worst == HITL_OK) worst = (int)all[(size_t)5 * r + 1];
-        any_offband = any_offband || all[(size_t)5 * r + 2] != 0.0;
-        min_Wb = std::min(min_Wb, (int)all[(size_t)5 * r + 3]);
-        max_Wb = std::max(max_Wb, (int)all[(size_t)5 * r + 3]);
+        wi_local = std::max(wi_local, (int)all[(size_t)6 * r]);
+        if ((int)all[(size_t)6 * r + 1] != HITL_OK && worst == HITL_OK) worst = (int)all[(size_t)6 * r + 1];
+        any_offband = any_offband || all[(size_t)6 * r + 2] != 0.0;
+        min_Wb = std::min(min_Wb, (int)all[(size_t)6 * r + 3]);
+        max_Wb = std::max(max_Wb, (int)all[(size_t)6 * r + 3]);
       }
       if (local_rc != HITL_OK) return local_rc;
       if (worst != HITL_OK) return fail(worst, "another rank failed while preparing the solve");
@@ -409,9 +411,9 @@ int prepare(hitl_solver* s, int mode, const float* poses_ref, const float* poses
       // multiple of it (its last super-block is full: nothing couples across it) and at least two super-blocks per rank.
       // Decided from the gathered values: the same verdict everywhere.
       if (any_offband || max_Wb > std::min(std::max((int)s->opt.max_band_poses, 1), kMaxBandPoses)) sep_cand = false;
-      for (int r = 0; r < s->world && sep_cand; ++r) {
-        const int64_t cnt = (int64_t)all[(size_t)5 * r + 4];
-        if (cnt <= max_Wb || (r + 1 < s->world && cnt % max_Wb != 0)) sep_cand = false;
+      for (int r = 0; r < s->world; ++r) {
+        const int64_t cnt = (int64_t)all[(size_t)6 * r + 4];
+        if (cnt <= max_Wb || (r + 1 < s->world && cnt % max_Wb != 0) || all[(size_t)6 * r + 5] == 0.0) sep_cand = false;
       }
     }
     s->Wi = wi_local;

@@ -40,6 +40,8 @@ def main():
     if replicated:
         lo, hi = 0, n_per * world
     M = 48
+    if os.environ.get("HITL_TEST_COLUMNS_RANK") == str(rank):       # ONE rank asks for the interface-column form: all must follow
+        os.environ["HITL_DIST_COLUMNS"] = "1"
     opt = H.default_options()
     opt.rank, opt.world_size = rank, world
     opt.device = rank % max(torch.cuda.device_count(), 1)

@@ -41,7 +41,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
                           # pair on both sides), mode A on them (band of one pose), the rank with the narrow band widening to the
                           # common one, and the column form forced on a partition the separators would take
                           (2, 120, 3, 0, "0,39,81,120", None, 2), (0, 120, 3, 0, "0,39,81,120", None, 2), (2, 42, 3, 0, "0,42,72,120", "1,3,3", 2),
-                          (2, 120, 2, 0, None, None, -1)])
+                          (2, 120, 2, 0, None, None, -1),
+                          # HITL_DIST_COLUMNS is a per-process switch: set on rank 1 only, BOTH ranks must fall back to the columns
+                          # (the verdict travels in prepare's exchange; a rank deciding alone would leave the other in a collective)
+                          (2, 120, 2, 0, None, None, -2)])
 def test_submaps_equal_the_global_solve(tmp_path, mode, ppf, world, moments, cuts, windows, form):
     from oracle import hitl_oracle as O
     out = str(tmp_path / "res")
@@ -52,6 +55,9 @@ def test_submaps_equal_the_global_solve(tmp_path, mode, ppf, world, moments, cut
         env["HITL_TEST_WINDOWS"] = windows
     if form == -1:
         env["HITL_DIST_COLUMNS"] = "1"
+        form = 1
+    if form == -2:
+        env["HITL_TEST_COLUMNS_RANK"] = "1"
         form = 1
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_submap_worker.py"), out, str(mode), str(ppf)]
