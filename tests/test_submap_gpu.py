@@ -185,20 +185,24 @@ def test_mode_b_on_submap_ranks_reaches_the_global_cost_level(tmp_path, world):
         assert np.abs(got - po[x["begin"]:x["end"]]).max() <= 3e-2      # along the weakly observed corridor direction (1.5e-2 on 2 ranks, 9e-4 on 3)
 
 
-@pytest.mark.parametrize("world,window", [(2, 1), (2, 2), (3, 2), (2, 4), (3, 4)])
-def test_separator_form_at_other_band_widths(tmp_path, world, window):
+@pytest.mark.parametrize("world,window,nper,halo", [(2, 1, 60, 2), (2, 2, 60, 4), (3, 2, 40, 4), (2, 4, 60, 8), (3, 4, 40, 8),
+                                                    (3, 3, 30, -1), (2, 3, 60, 3)])
+def test_separator_form_at_other_band_widths(tmp_path, world, window, nper, halo):
     """Round 4: the separator form with super-blocks of 1, 2 and 4 poses (B = 3, 6, 12; the other cases run B = 9 and, in mode A,
-    B = 3): 60-pose ranks (two) and 40-pose ranks (three) inside one corridor are multiples of each band, so the solve AND the pose
-    covariances on the ranks take it; both must equal the oracle's global solve / dense global inverse."""
+    B = 3): ranks whose pose counts are multiples of the band inside one corridor, so the solve AND the pose covariances on the
+    ranks take it; both must equal the oracle's global solve / dense global inverse.  Also: three ranks holding REPLICATED scans
+    (halo < 0: every rank has the whole map resident), and halos exactly as deep as the band."""
     from oracle import hitl_oracle as O
     out = str(tmp_path / "res")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", HITL_TEST_WINDOW=str(window), HITL_TEST_HALO=str(2 * window))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", HITL_TEST_WINDOW=str(window), HITL_TEST_HALO=str(halo),
+               HITL_TEST_NPER=str(nper))
+    n = nper * world
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_submap_worker.py"), out, "2", "120"]
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_submap_worker.py"), out, "2", str(n)]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     res = [json.load(open("%s.%d" % (out, k))) for k in range(world)]
-    prob = Problem(120, 48, ppf=120, groups=2, kind=0)
+    prob = Problem(n, 48, ppf=n, groups=2, kind=0)
     o = prob.load(O.OracleSolver())
     o.find_correspondences(prob.init, window, 1)
     ops = o.get_correspondences()
