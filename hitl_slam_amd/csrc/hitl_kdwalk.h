@@ -103,11 +103,13 @@ HITL_HD void kd_step(KdWalk& w, const float4* pts, const uint32_t* meta, float t
   const int split = (int)(meta[rp] >> 16);
   const float dx = g.x - w.qx, dy = g.y - w.qy;
   const bool ingate = dx * dx + dy * dy < thr2;
-  const float sc = __builtin_fabsf(g.z * (w.qx - g.x) + g.w * (w.qy - g.y));
+  // kdtree.cpp:150 scores with (q - p) and :157 splits on q - p as well; q - p is the exact negative of dx / dy, products and sums of
+  // exact negatives are exact negatives, and only |.|, the sign and the zero test of the results are used: same bits from dx, dy
+  const float sc = __builtin_fabsf(g.z * dx + g.w * dy);
   const float best = ingate ? sc : kFltMax;
   const int out = ingate ? pos : -1;
-  const float pd = (split ? w.qy : w.qx) - (split ? g.y : g.x);
-  const float apd = __builtin_fabsf(pd);
+  const float npd = split ? dy : dx;                    // -(q - p) along the split plane: pd <= 0 <=> npd >= 0, pd >= 0 <=> npd <= 0
+  const float apd = __builtin_fabsf(npd);
   const bool has_right = ind < n - 1, has_left = ind > 0;
   // ---- a near child's run returned (rd, rc): kdtree.cpp:165-168 / :174-177, then :183-186 ----
   const bool child_wins = rd < best;
@@ -116,18 +118,18 @@ HITL_HD void kd_step(KdWalk& w, const float4* pts, const uint32_t* meta, float t
   const float lim = (mb < thr) ? mb : thr;
   // KD_LEFT_NEAR: the right child, as the second near one (pd == 0) or as the far side; KD_RIGHT_NEAR: pd > 0, the left child exists
   const bool near_lim = apd < lim;
-  const bool go_if_left = has_right & ((pd == 0.0f) | near_lim);
+  const bool go_if_left = has_right & ((npd == 0.0f) | near_lim);
   const bool go = ret_eval & ((code == KD_LEFT_NEAR) ? go_if_left : near_lim);
   const bool ret_here = ret_eval & !go;                           // the frame returns the merged value into the outer run
   // ---- first visit: kdtree.cpp:149-151, :161, :170 ----
   const bool early = enter & ingate & (sc < kFltMin);
-  const bool go_l = enter & !early & (pd <= 0.0f) & has_left;
-  const bool go_r = enter & !early & !go_l & (pd >= 0.0f) & has_right;
+  const bool go_l = enter & !early & (npd >= 0.0f) & has_left;
+  const bool go_r = enter & !early & !go_l & (npd <= 0.0f) & has_right;
   const bool no_child = enter & !early & !go_l & !go_r;         // other_tree stays NULL (kdtree.cpp:159, :183)
   // the far side can never be taken, whatever the near child returns: |pd| >= min(own score, thr) >= min(merged, thr) and the
   // query is off the plane -- or there is no far child (a left child without a right sibling)
   const float lim0 = (best < thr) ? best : thr;
-  const bool merge_only = ((pd != 0.0f) & !(apd < lim0)) | (go_l & !has_right);
+  const bool merge_only = ((npd != 0.0f) & !(apd < lim0)) | (go_l & !has_right);
   const bool fold = (go_l | go_r) & merge_only;                  // own point into the incumbent, no frame
   const bool push = (go_l | go_r) & !merge_only;
   const bool own_beats_inc = best < w.inc_d;
@@ -176,18 +178,20 @@ HITL_HD void kd_step_fast(KdWalk& w, const float4* pts, const uint32_t* meta, fl
   const int split = (int)(meta[rp] >> 16);
   const float dx = g.x - w.qx, dy = g.y - w.qy;
   const bool ingate = dx * dx + dy * dy < thr2;
-  const float sc = __builtin_fabsf(g.z * (w.qx - g.x) + g.w * (w.qy - g.y));
+  // kdtree.cpp:150 scores with (q - p) and :157 splits on q - p as well; q - p is the exact negative of dx / dy, products and sums of
+  // exact negatives are exact negatives, and only |.|, the sign and the zero test of the results are used: same bits from dx, dy
+  const float sc = __builtin_fabsf(g.z * dx + g.w * dy);
   const float best = ingate ? sc : kFltMax;
   const int out = ingate ? pos : -1;
-  const float pd = (split ? w.qy : w.qx) - (split ? g.y : g.x);
-  const float apd = __builtin_fabsf(pd);
+  const float npd = split ? dy : dx;                    // -(q - p) along the split plane: pd <= 0 <=> npd >= 0, pd >= 0 <=> npd <= 0
+  const float apd = __builtin_fabsf(npd);
   const bool has_right = ind < n - 1, has_left = ind > 0;
   const bool early = enter & ingate & (sc < kFltMin);
-  const bool go_l = enter & !early & (pd <= 0.0f) & has_left;
-  const bool go_r = enter & !early & !go_l & (pd >= 0.0f) & has_right;
+  const bool go_l = enter & !early & (npd >= 0.0f) & has_left;
+  const bool go_r = enter & !early & !go_l & (npd <= 0.0f) & has_right;
   const bool no_child = enter & !early & !go_l & !go_r;
   const float lim0 = (best < thr) ? best : thr;
-  const bool merge_only = ((pd != 0.0f) & !(apd < lim0)) | (go_l & !has_right);
+  const bool merge_only = ((npd != 0.0f) & !(apd < lim0)) | (go_l & !has_right);
   const bool fold = (go_l | go_r) & merge_only;          // (go_l || go_r) && !merge_only would push: not here
   const bool own_beats_inc = best < w.inc_d;
   w.inc_d = (fold & own_beats_inc) ? best : w.inc_d;
