@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <atomic>
 #include <thread>
 
 #include "hitl_solver_impl.h"
@@ -131,24 +132,47 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
   // a handful of threads: spawning 32 cost more than the trigonometry (hardware_concurrency() also counts CPUs a container's
   // quota does not grant)
   const int nt = (int)std::max(1u, std::min(12u, std::thread::hardware_concurrency()));
-  auto run = [&](int64_t lo, int64_t hi, auto&& body) {
-    std::vector<std::thread> th;
+  // ONE team of threads for consecutive phases over [lo, hi) (spawning a team costs ~0.15 ms: more than either phase of a
+  // 50 000-pose map): every member takes its slice of phase 0, waits for the others, takes its slice of phase 1, ...  A thread
+  // that cannot be started only makes the team smaller (the members learn its size once spawning is over).
+  auto run_phases = [&](int64_t lo, int64_t hi, int n_phases, auto&& body /* (phase, a, b) */) {
+    std::atomic<int> team{0};
+    std::vector<std::atomic<int>> arrived((size_t)std::max(n_phases, 1));
+    for (auto& a : arrived) a.store(0, std::memory_order_relaxed);
     const int64_t len = hi - lo;
-    for (int t = 1; t < nt; ++t) th.emplace_back([&, t]() { body(lo + len * t / nt, lo + len * (t + 1) / nt); });
-    body(lo, lo + len / nt);
+    auto member = [&](int t) {
+      int sz;
+      while ((sz = team.load(std::memory_order_acquire)) == 0) std::this_thread::yield();
+      for (int ph = 0; ph < n_phases; ++ph) {
+        body(ph, lo + len * t / sz, lo + len * (t + 1) / sz);
+        arrived[(size_t)ph].fetch_add(1, std::memory_order_acq_rel);
+        if (ph + 1 < n_phases) while (arrived[(size_t)ph].load(std::memory_order_acquire) < sz) std::this_thread::yield();
+      }
+    };
+    std::vector<std::thread> th;
+    int spawned = 0;
+    try {
+      th.reserve((size_t)nt);
+      for (int t = 1; t < nt; ++t) { th.emplace_back(member, t); ++spawned; }
+    } catch (...) {}        // (std::system_error: no more threads) -- the ones that exist do the work
+    team.store(spawned + 1, std::memory_order_release);
+    member(0);
     for (auto& x : th) x.join();
   };
+  auto run = [&](int64_t lo, int64_t hi, auto&& body) { run_phases(lo, hi, 1, [&](int, int64_t a, int64_t b) { body(a, b); }); };
   const bool libm_ok = libm_sincos_exact();
-  run(0, n, [&](int64_t a, int64_t b) {
+  auto pose_trig = [&](int64_t a, int64_t b) {
     for (int64_t i = a; i < b; ++i) {
       if (libm_ok) sincosf(poses[3 * i + 2], &cs[2 * i + 1], &cs[2 * i]);
       else { cs[2 * i] = cosf(poses[3 * i + 2]); cs[2 * i + 1] = sinf(poses[3 * i + 2]); }
     }
-  });
+  };
+  if (!device_tables) { run(0, n, pose_trig); mark("pose trigonometry"); }      // (one tile: the trigonometry shares a team with the candidates below)
   // candidates of the source poses [i0, i1) into cand_tgt / cand_tf (indexed from i0)
-  auto fill_candidates = [&](int64_t i0, int64_t i1) {
+  auto fill_candidates = [&](int64_t i0, int64_t i1, bool with_pose_trig = false) {
     const bool paired = libm_ok && i0 == 0 && i1 == n;        // the mirror of a candidate lies in the same tile only when there is one tile
-    run(i0, i1, [&](int64_t a, int64_t b) {
+    run_phases(i0, i1, with_pose_trig ? 2 : 1, [&](int ph, int64_t a, int64_t b) {
+      if (with_pose_trig && ph == 0) { pose_trig(a, b); return; }
       for (int64_t i = a; i < b; ++i) {
         int slot = 0;
         const int64_t j0 = std::max<int64_t>(0, i - window), j1 = std::min<int64_t>(n - 1, i + window);
@@ -174,7 +198,7 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
       }
     });
   };
-  if (device_tables) fill_candidates(0, n);
+  if (device_tables) fill_candidates(0, n, /*with_pose_trig=*/true);
   mark("candidate transforms");
   hipStream_t st = s->stream;
   DevArray<int>&d_tgt = s->d_cand_tgt, &d_counts = s->d_cand_counts, &d_kept = s->d_cand_kept;   // device scratch, kept too
