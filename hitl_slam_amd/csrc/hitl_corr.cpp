@@ -169,7 +169,13 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
   };
   if (!device_tables) { run(0, n, pose_trig); mark("pose trigonometry"); }      // (one tile: the trigonometry shares a team with the candidates below)
   // candidates of the source poses [i0, i1) into cand_tgt / cand_tf (indexed from i0)
-  auto fill_candidates = [&](int64_t i0, int64_t i1, bool with_pose_trig = false) {
+  // A windowed search over the whole map on one tile forms the transforms themselves on the device (k_cand_tf: the same
+  // operations in the same order) and keeps on the host only what needs the C library: the (cos, sin) of every pose and of
+  // every candidate's angle difference.  2 floats per candidate instead of 8 to compute, store and upload.
+  const bool tf_on_device = device_tables && !dev_switches().cand_tf_host;
+  std::vector<float>& cand_trig = s->h_cand_trig;
+  if (tf_on_device && cand_trig.size() != (size_t)n * slots * 2) cand_trig.resize((size_t)n * slots * 2);
+  auto fill_candidates = [&](int64_t i0, int64_t i1, bool with_pose_trig = false, bool trig_only = false) {
     const bool paired = libm_ok && i0 == 0 && i1 == n;        // the mirror of a candidate lies in the same tile only when there is one tile
     run_phases(i0, i1, with_pose_trig ? 2 : 1, [&](int ph, int64_t a, int64_t b) {
       if (with_pose_trig && ph == 0) { pose_trig(a, b); return; }
@@ -179,6 +185,23 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
         for (int64_t j = j0; j <= j1; ++j) {
           if (j == i) continue;
           cand_tgt[(size_t)(i - i0) * slots + slot] = (int)j;
+          if (trig_only) {                    // (i0 == 0: one tile)
+            float* tr = &cand_trig[((size_t)i * slots + slot) * 2];
+            if (!paired) {
+              const float dth = (float)((double)poses[3 * j + 2] - (double)poses[3 * i + 2]);
+              tr[0] = cosf(dth); tr[1] = sinf(dth);
+            } else if (j > i) {               // one sincosf for the candidate and its mirror (see below)
+              const float dth = (float)((double)poses[3 * j + 2] - (double)poses[3 * i + 2]);
+              float sn, cn;
+              sincosf(dth, &sn, &cn);
+              tr[0] = cn; tr[1] = sn;
+              const int64_t jj0 = std::max<int64_t>(0, j - window);
+              float* tm = &cand_trig[((size_t)j * slots + (size_t)(i - jj0)) * 2];
+              tm[0] = cn; tm[1] = -sn;
+            }
+            ++slot;
+            continue;
+          }
           float* t = &cand_tf[((size_t)(i - i0) * slots + slot) * 8];
           make_rel_tf(poses + 3 * i, poses + 3 * j, &cs[2 * i], &cs[2 * j], t, !paired);
           if (paired && j > i) {
@@ -198,7 +221,7 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
       }
     });
   };
-  if (device_tables) fill_candidates(0, n, /*with_pose_trig=*/true);
+  if (device_tables) fill_candidates(0, n, /*with_pose_trig=*/true, /*trig_only=*/tf_on_device);
   mark("candidate transforms");
   hipStream_t st = s->stream;
   DevArray<int>&d_tgt = s->d_cand_tgt, &d_counts = s->d_cand_counts, &d_kept = s->d_cand_kept;   // device scratch, kept too
@@ -214,7 +237,32 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
   }
   // one tile of source poses [i0, i0 + cnt): upload its candidates, match
   auto match_tile = [&](int i0, int cnt) -> int {
-    TRYC(d_tgt.upload(cand_tgt.data(), (size_t)cnt * slots, st));
+    if (!(tf_on_device && kd_tgt)) TRYC(d_tgt.upload(cand_tgt.data(), (size_t)cnt * slots, st));     // (the target-major kernel derives its candidates from the window)
+    if (tf_on_device) {
+      TRYC(s->d_cand_poses.upload(poses, (size_t)3 * n, st));
+      TRYC(s->d_cand_cs.upload(cs.data(), (size_t)2 * n, st));
+      TRYC(s->d_cand_trig.upload(cand_trig.data(), (size_t)n * slots * 2, st));
+      TRYC(d_tf.resize((size_t)n * slots * 8));
+      launch_cand_tf(st, n, slots, (int)window, s->d_cand_poses.p, s->d_cand_cs.p, s->d_cand_trig.p, d_tf.p);
+      if (dev_switches().cand_tf_check) {
+        // development / tests: every candidate through the host routine as well, bit for bit
+        std::vector<float> dev((size_t)n * slots * 8), host(8);
+        if (hipMemcpyAsync(dev.data(), d_tf.p, dev.size() * sizeof(float), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+          return fail(HITL_ERR_HIP, "find_correspondences: reading the candidate transforms back failed");
+        for (int64_t i = 0; i < n; ++i) {
+          int slot = 0;
+          const int64_t j0 = std::max<int64_t>(0, i - window), j1 = std::min<int64_t>(n - 1, i + window);
+          for (int64_t j = j0; j <= j1; ++j) {
+            if (j == i) continue;
+            make_rel_tf(poses + 3 * i, poses + 3 * j, &cs[2 * i], &cs[2 * j], host.data(), true);
+            if (std::memcmp(host.data(), &dev[((size_t)i * slots + slot) * 8], 8 * sizeof(float)) != 0)
+              return fail(HITL_ERR_SOLVER_FAILURE, "HITL_CAND_TF_CHECK: the device's transform of candidate (" + std::to_string(i) + ", " + std::to_string(j) +
+                                                   ") differs from the host's");
+            ++slot;
+          }
+        }
+      }
+    } else
     TRYC(d_tf.upload(cand_tf.data(), (size_t)cnt * slots * 8, st));
     TRYC(d_counts.resize((size_t)cnt * slots));
     TRYC(d_counts.zero(st));

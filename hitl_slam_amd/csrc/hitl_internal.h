@@ -42,6 +42,8 @@ struct DevSwitches {
   int kd_redo_cap = 1 << 18;       // HITL_KD_REDO_CAP: entries of the redo list behind the fast attempt (tests shrink it to force the full-depth repeat)
   int kd_refill = 16;              // HITL_KD_REFILL: idle lanes per wave that trigger a refill from the query queue
   int kd_fast = 1;                 // HITL_KD_FAST: kd_step_fast calls behind every kd_step of k_match_kd_tgt (0, 1, 2)
+  bool cand_tf_host = false;       // HITL_CAND_TF_HOST: the candidate transforms of a windowed search on the host (rounds 1-3), uploaded
+  bool cand_tf_check = false;      // HITL_CAND_TF_CHECK: the device's candidate transforms held to the host routine, bit for bit (tests)
   size_t cand_tile_bytes = (size_t)4 << 30;   // HITL_CAND_TILE_BYTES: candidate-table budget of the tiled search
   int cr_plan[16] = {0};           // HITL_CR_PLAN: chunk sizes of the fused stages
   int cr_plan_n = 0;
@@ -305,6 +307,8 @@ void launch_match_kd(hipStream_t st, const MapView& map, int max_scan, int slots
 // candidates, slots <= cap (the per-point cap cannot bind); block = 64 / 128 / 256 threads, refill_min = idle lanes per wave
 // that trigger a refill from the queue
 bool match_kd_tgt_applies(int slots, int window, const MatchParams& mp);
+// candidate transforms of a windowed search over the whole map on the device; trig = (cos, sin) of theta_j - theta_i per candidate (host libm)
+void launch_cand_tf(hipStream_t st, int n, int slots, int window, const float* poses, const float* cs, const float* trig, float* cand_tf);
 void launch_match_kd_tgt(hipStream_t st, const MapView& map, int max_scan, int slots, int window, const float* cand_tf, MatchParams mp,
                          const float4* kd_pts, const uint32_t* kd_meta, uint16_t* table, int* counts, int block, int refill_min,
                          int* redo_count /* walks that needed more frames than the launch provisioned ... */, int* redo_list /* ... (candidate, point) each,

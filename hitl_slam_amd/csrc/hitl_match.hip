@@ -517,6 +517,47 @@ void launch_match_kd(hipStream_t st, const MapView& map, int max_scan, int slots
                      mp, kd_pts, kd_meta, table, counts, i0, n_tile);
 }
 
+// Candidate transforms of a windowed search on the device (round 4): RelativePoseTransform (JointOptimization.cpp:296-305) in
+// fp32 with exactly the operations, in exactly the order, of make_rel_tf (hitl_corr.cpp) -- multiplications, additions and one
+// correctly rounded division, no contraction in this file -- from the poses, the per-pose (cos, sin) and the per-candidate
+// (cos, sin) of the angle difference, which stay with the host's libm (the only part whose bits a GPU cannot be trusted to
+// reproduce).  One thread per candidate (i, slot): j = slot-th pose of [i - window, i + window] without i; slots past the end
+// of the list get zeros.  HITL_CAND_TF_CHECK=1 holds every launch to the host routine, bit for bit.
+__global__ void k_cand_tf(int n, int slots, int window, const float* __restrict__ poses, const float* __restrict__ cs,
+                          const float* __restrict__ trig, float* __restrict__ cand_tf) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n * slots) return;
+  const int i = c / slots, slot = c % slots;
+  const int j0 = max(0, i - window), j1 = min(n - 1, i + window);
+  int j = j0 + slot;
+  if (j >= i) ++j;
+  float* t = cand_tf + (size_t)c * 8;
+  if (j > j1) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = 0.0f;
+    return;
+  }
+  const float* pi = poses + 3 * (size_t)i;
+  const float* pj = poses + 3 * (size_t)j;
+  const float ci = cs[2 * i], si = cs[2 * i + 1], cj = cs[2 * j], sj = cs[2 * j + 1];
+  const float nsj = -sj, nsi = -si;
+  const float det = cj * cj - sj * nsj;
+  const float invdet = 1.0f / det;
+  const float a00 = cj * invdet, a01 = (-nsj) * invdet, a10 = (-sj) * invdet, a11 = cj * invdet;
+  t[0] = a00 * ci + a01 * si; t[1] = a00 * nsi + a01 * ci;
+  t[2] = a10 * ci + a11 * si; t[3] = a10 * nsi + a11 * ci;
+  const float ix = (-a00) * pj[0] + (-a01) * pj[1], iy = (-a10) * pj[0] + (-a11) * pj[1];
+  t[4] = (a00 * pi[0] + a01 * pi[1]) + ix;
+  t[5] = (a10 * pi[0] + a11 * pi[1]) + iy;
+  t[6] = trig[2 * (size_t)c]; t[7] = trig[2 * (size_t)c + 1];
+}
+
+void launch_cand_tf(hipStream_t st, int n, int slots, int window, const float* poses, const float* cs, const float* trig, float* cand_tf) {
+  const int tot = n * slots;
+  if (tot <= 0) return;
+  hipLaunchKernelGGL(k_cand_tf, dim3((tot + 255) / 256), dim3(256), 0, st, n, slots, window, poses, cs, trig, cand_tf);
+}
+
 // target-major search over the whole map (a windowed search inside the band whose slots cannot reach the per-point cap)
 bool match_kd_tgt_applies(int slots, int window, const MatchParams& mp) {
   return window >= 1 && 2 * window <= kKdMaxSrc && slots <= 2 * window && slots <= mp.cap && mp.skip >= 1;

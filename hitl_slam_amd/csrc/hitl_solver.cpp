@@ -568,6 +568,7 @@ void read_dev_switches() {
   d.lm_ahead = (int)std::max(1ll, std::min(16ll, num("HITL_LM_AHEAD", d.lm_ahead)));
   d.kd_refill = (int)std::max(1ll, std::min(64ll, num("HITL_KD_REFILL", d.kd_refill)));
   d.kd_fast = (int)std::max(0ll, std::min(2ll, num("HITL_KD_FAST", d.kd_fast)));
+  d.cand_tf_host = on("HITL_CAND_TF_HOST"); d.cand_tf_check = on("HITL_CAND_TF_CHECK");
   d.cand_tile_bytes = (size_t)std::max(1ll, num("HITL_CAND_TILE_BYTES", (long long)d.cand_tile_bytes));
   d.cr_threads = (int)num("HITL_CR_THREADS", 0);
   if (const char* e = std::getenv("HITL_CR_PLAN"))
@@ -721,6 +722,7 @@ void hitl_solver_destroy(hitl_solver* s) {
                            &s->ob_hi, &s->ob_fwd, &s->ob_rev, &s->obadj_off, &s->obadj_ent, &s->hc_off})
     v->release();
   s->d_cand_tgt.release(); s->d_cand_counts.release(); s->d_cand_kept.release(); s->d_cand_tf.release(); s->d_cand_table.release();
+  s->d_cand_trig.release(); s->d_cand_poses.release(); s->d_cand_cs.release();
   s->pairM.release(); s->kd_pts.release(); s->kd_meta.release(); s->d_kd_ovf.release(); s->world_xy.release();
   s->matches.release(); s->odom_A.release(); s->hc_tgt.release(); s->odom_rr.release(); s->hc_type.release();
   if (s->nccl) (void)ncclCommDestroy(s->nccl);

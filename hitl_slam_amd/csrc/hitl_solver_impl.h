@@ -112,6 +112,8 @@ struct hitl_solver {
   bool host_pairs_stale = false;               // h_pair_src / h_pair_tgt / h_perm / h_match_off not yet fetched from the device
   bool obadj_nonzero = true;                   // the off-band adjacency on the device is not known to be the empty one
   DevArray<float> d_cand_tf;
+  DevArray<float> d_cand_trig, d_cand_poses, d_cand_cs;      // device-side candidate transforms: (cos, sin) per candidate, poses, (cos, sin) per pose
+  std::vector<float> h_cand_trig;
   DevArray<uint16_t> d_cand_table;
   DevArray<float4> kd_pts;                     // opt-in (kd_tree_search): every scan in KD in-order layout
   DevArray<uint32_t> kd_meta;                  //   original index | split plane << 16

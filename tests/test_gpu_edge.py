@@ -294,6 +294,7 @@ _SWITCHES = [
     {"HITL_STF_VARIANT": "300", "HITL_STF_WAVES_PER_CU": "5"}, {"HITL_STF_VARIANT": "400"}, {"HITL_STF_VARIANT": "400", "HITL_STF_WAVES_PER_CU": "2"},
     {"HITL_STF_VARIANT": "600"}, {"HITL_STF_VARIANT": "700"},
     {"HITL_KD_BLOCK": "64"}, {"HITL_KD_BLOCK": "128", "HITL_KD_REFILL": "4"}, {"HITL_KD_CAP": "1"}, {"HITL_KD_CAP": "2", "HITL_KD_REDO_CAP": "8"}, {"HITL_KD_FAST": "0"}, {"HITL_KD_FAST": "2", "HITL_KD_CAP": "1"},
+    {"HITL_CAND_TF_CHECK": "1"}, {"HITL_CAND_TF_HOST": "1"},
     {"HITL_CAND_TILE_BYTES": "200000"}, {"HITL_CR_PLAN": "2,4,0"}, {"HITL_CR_THREADS": "256"},
     # several at once: the switches nobody would combine on purpose
     {"HITL_TIMING": "1", "HITL_EVENT_SYNC": "1", "HITL_CR_UNFUSED_BUILD": "1", "HITL_STF_VARIANT": "300", "HITL_KD_BLOCK": "64", "HITL_KD_CAP": "2",
@@ -313,7 +314,7 @@ def test_every_development_switch_still_solves_like_the_oracle(env, monkeypatch)
     from oracle import hitl_oracle as O
     for k in ("HITL_TIMING", "HITL_EVENT_SYNC", "HITL_CR_LEGACY", "HITL_CR_UNFUSED_BUILD", "HITL_STF_ADDR64", "HITL_DEVICE_LM", "HITL_LM_AHEAD",
               "HITL_FORCE_DIST", "HITL_DIST_COLUMNS", "HITL_ROCTX", "HITL_STF_VARIANT", "HITL_STF_WAVES_PER_CU", "HITL_KD_BLOCK", "HITL_KD_REFILL", "HITL_KD_CAP",
-              "HITL_KD_REDO_CAP", "HITL_KD_FAST", "HITL_CAND_TILE_BYTES", "HITL_CR_PLAN", "HITL_CR_THREADS"):
+              "HITL_KD_REDO_CAP", "HITL_KD_FAST", "HITL_CAND_TF_CHECK", "HITL_CAND_TF_HOST", "HITL_CAND_TILE_BYTES", "HITL_CR_PLAN", "HITL_CR_THREADS"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
