@@ -623,16 +623,27 @@ __global__ __launch_bounds__(64) void k_compact(MapView map, int max_scan, int s
   const uint16_t* row = table + (size_t)cand * max_scan;
   int64_t w = match_off[p];
   const int lane = threadIdx.x;
-  for (int base = 0; base < mi; base += 64) {
-    const int k = base + lane;
-    const uint16_t v = (k < mi) ? row[k] : (uint16_t)0xFFFFu;
-    const bool hit = (v != 0xFFFFu);
-    const unsigned long long mask = __ballot(hit);
-    if (hit) {
-      const int rank = __popcll(mask & ((1ull << lane) - 1ull));
-      matches[w + rank] = (uint32_t)k | ((uint32_t)v << 16);
+  // eight 64-entry pieces of the row are requested together (one memory round trip per 512 entries instead of eight: a 400-point
+  // row is one round), then compacted in order
+  constexpr int U = 8;
+  for (int base0 = 0; base0 < mi; base0 += 64 * U) {
+    uint16_t v[U];
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      const int k = base0 + 64 * q + lane;
+      v[q] = (k < mi) ? row[k] : (uint16_t)0xFFFFu;
     }
-    w += __popcll(mask);
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      const int k = base0 + 64 * q + lane;
+      const bool hit = (v[q] != 0xFFFFu);
+      const unsigned long long mask = __ballot(hit);
+      if (hit) {
+        const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+        matches[w + rank] = (uint32_t)k | ((uint32_t)v[q] << 16);
+      }
+      w += __popcll(mask);
+    }
   }
 }
 

@@ -12,7 +12,7 @@ for lib in "$@"; do
 import csv, glob
 for fn in glob.glob("$OUT/t/*/*kernel_stats.csv"):
     for r in csv.DictReader(open(fn)):
-        if "k_match_kd_tgt" in r["Name"]: print("%-40s %-36s avg %.1f us   %s" % ("$lib", r["Name"].split("(")[0].replace("void hitl::","")[:36], float(r["AverageNs"]) / 1e3, open("$OUT/out.txt").read().strip().split("pairs")[0]))
+        if "k_match_kd_tgt" in r["Name"] or "k_compact" in r["Name"]: print("%-40s %-36s avg %.1f us   %s" % ("$lib", r["Name"].split("(")[0].replace("void hitl::","")[:36], float(r["AverageNs"]) / 1e3, open("$OUT/out.txt").read().strip().split("pairs")[0]))
 PY
 done
 done
