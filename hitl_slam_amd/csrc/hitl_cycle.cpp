@@ -18,17 +18,6 @@ using namespace hitl;
 
 namespace {
 
-int upload_pose_rt(const SolverCtx& cx, const float* poses, DevArray<float>* T4) {
-  poses += 3 * (size_t)cx.pose_base;     // submap rank: the caller's array is the GLOBAL one
-  std::vector<float> t((size_t)4 * cx.n);
-  for (int i = 0; i < cx.n; ++i) {      // Rotation2Df(angle), Translation2f: fp32 trig on the host
-    t[4 * i] = cosf(poses[3 * i + 2]); t[4 * i + 1] = sinf(poses[3 * i + 2]); t[4 * i + 2] = poses[3 * i]; t[4 * i + 3] = poses[3 * i + 1];
-  }
-  TRY(T4->upload(t, cx.stream));
-  HIP_TRY(hipStreamSynchronize(cx.stream));
-  return HITL_OK;
-}
-
 struct FitEval { double cost, g, h; };
 
 // one evaluation of the 1-parameter problem of SegFitEM at theta: residuals and derivatives on the device,
@@ -144,16 +133,16 @@ int hitl_solver_fit_segments(hitl_solver* s, const float* poses_xyt, int32_t n_s
   own.n_poses = n_own; own.obs_off = cx.map.obs_off + cx.own_lo;
   std::vector<float2> h_pts, h_all;
   std::vector<int64_t> h_m;
-  DevArray<float> T4;
+  const float* T4 = nullptr;
   DevArray<int> d_cnt;
   DevArray<int64_t> d_off;
   DevArray<float2> d_pts;
   DevArray<double> d_partial;
-  int rc = upload_pose_rt(cx, poses_xyt, &T4);
+  int rc = solver_pose_rt(s, poses_xyt + 3 * (size_t)cx.pose_base, &T4);     // submap rank: the caller's array is the GLOBAL one
   if (rc == HITL_OK) rc = d_cnt.resize((size_t)n_own);
   std::vector<int> h_cnt((size_t)n_own);
   std::vector<int64_t> h_off((size_t)n_own + 1);
-  const float* T4own = T4.p + (size_t)4 * cx.own_lo;
+  const float* T4own = (rc == HITL_OK) ? T4 + (size_t)4 * cx.own_lo : nullptr;
   for (int k = 0; k < n_segments && rc == HITL_OK; ++k) {
     float* sp = seg_xy4 + 4 * k;
     const double thresh = 0.05;
@@ -207,7 +196,7 @@ int hitl_solver_fit_segments(hitl_solver* s, const float* poses_xyt, int32_t n_s
     if (lm_iterations) lm_iterations[k] = it_total;
   }
   (void)hipStreamSynchronize(cx.stream);
-  T4.release(); d_cnt.release(); d_off.release(); d_pts.release(); d_partial.release();
+  d_cnt.release(); d_off.release(); d_pts.release(); d_partial.release();
   return rc;
 }
 

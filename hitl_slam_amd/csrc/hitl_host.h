@@ -149,5 +149,9 @@ static inline void ordered_sum32_records(const double* v, int n, int stride, dou
   }
 }
 int solver_allgather(hitl_solver* s, const void* send, void* recv, int64_t bytes_per_rank);   // the submap transport, host buffers
+// (cos, sin, x, y) of every resident pose in device memory, for the observation scans: the entry points of one correction
+// (verify, endpoint fit, observation sets) pass the SAME poses one after the other; the table -- 2 x 50 000 fp32 libm calls on the
+// host + an upload -- is rebuilt only when the poses differ from the last call's.  `poses_local` = the rank's resident poses.
+int solver_pose_rt(hitl_solver* s, const float* poses_local, const float** T4_dev);
 
 }  // namespace hitl

@@ -46,6 +46,24 @@ int solver_ctx(hitl_solver* s, SolverCtx* out) {
 
 int solver_allgather(hitl_solver* s, const void* send, void* recv, int64_t bytes_per_rank) { return comm_allgather(s, send, recv, bytes_per_rank); }
 
+int solver_pose_rt(hitl_solver* s, const float* poses, const float** T4_dev) {
+  const size_t n = (size_t)s->n;
+  if (s->pose_rt.p != nullptr && s->pose_rt_of.size() == 3 * n && std::memcmp(s->pose_rt_of.data(), poses, sizeof(float) * 3 * n) == 0) {
+    *T4_dev = s->pose_rt.p;
+    return HITL_OK;
+  }
+  std::vector<float> t(4 * n);
+  for (size_t i = 0; i < n; ++i) {      // Rotation2Df(angle), Translation2f: fp32 trig on the host
+    t[4 * i] = cosf(poses[3 * i + 2]); t[4 * i + 1] = sinf(poses[3 * i + 2]); t[4 * i + 2] = poses[3 * i]; t[4 * i + 3] = poses[3 * i + 1];
+  }
+  s->pose_rt_of.clear();                // (not valid until the upload has completed)
+  TRY(s->pose_rt.upload(t, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  s->pose_rt_of.assign(poses, poses + 3 * n);
+  *T4_dev = s->pose_rt.p;
+  return HITL_OK;
+}
+
 // ---------------------------------------------------------------------------------------
 // derived pair structures (host, O(P)); called whenever the correspondence set changes
 // ---------------------------------------------------------------------------------------
@@ -1241,32 +1259,24 @@ int hitl_solver_pose_covariances(hitl_solver* s, int32_t mode, const float* pose
 
 // ---- observation scans either side of the solve -------------------------
 namespace {
-int obs_scan_prepare(hitl_solver* s, const float* poses, DevArray<float>* T4) {
+int obs_scan_prepare(hitl_solver* s, const float* poses, const float** T4) {
   if (!s || !poses) return fail(HITL_ERR_INVALID_ARGUMENT, "observation scan: null argument");
   if (s->n <= 0) return fail(HITL_ERR_NOT_READY, "observation scan before set_map");
   HIP_TRY(hipSetDevice(s->device));
   // submap rank: poses is the GLOBAL array; the rank's resident scans (halos included) start at global pose g_begin - hl
-  poses += 3 * (size_t)(s->g_begin - s->hl);
-  std::vector<float> t((size_t)4 * s->n);
-  for (int i = 0; i < s->n; ++i) {      // Rotation2Df(angle), Translation2f: fp32 trig on the host
-    t[4 * i] = cosf(poses[3 * i + 2]); t[4 * i + 1] = sinf(poses[3 * i + 2]); t[4 * i + 2] = poses[3 * i]; t[4 * i + 3] = poses[3 * i + 1];
-  }
-  TRY(T4->upload(t, s->stream));
-  HIP_TRY(hipStreamSynchronize(s->stream));
-  return HITL_OK;
+  return solver_pose_rt(s, poses + 3 * (size_t)(s->g_begin - s->hl), T4);
 }
 }  // namespace
 
 // world x of every observation, then world y, in a buffer the solver keeps (no 160 MB allocation per call)
 static int transform_scans_resident(hitl_solver* s, const float* poses_xyt) {
-  DevArray<float> T4;
+  const float* T4 = nullptr;
   int rc = obs_scan_prepare(s, poses_xyt, &T4);
   if (rc == HITL_OK) rc = s->world_xy.resize((size_t)2 * std::max<int64_t>(s->n_obs, 1));
   if (rc == HITL_OK) {
-    launch_transform(s->stream, s->map_view(), T4.p, s->world_xy.p, s->world_xy.p + s->n_obs);
+    launch_transform(s->stream, s->map_view(), T4, s->world_xy.p, s->world_xy.p + s->n_obs);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s->stream) != hipSuccess) rc = fail(HITL_ERR_HIP, "transform_scans failed");
   }
-  T4.release();
   return rc;
 }
 
@@ -1299,26 +1309,26 @@ void hitl_host_free(void* p) { if (p) (void)hipHostFree(p); }
 int hitl_solver_verify_points(hitl_solver* s, const float* poses_xyt, int32_t n_points, const float* points_xy,
                               float threshold, int32_t* seen) {
   if (n_points < 0 || n_points > 16 || (n_points > 0 && (!points_xy || !seen))) return fail(HITL_ERR_INVALID_ARGUMENT, "verify_points: 0..16 points");
-  DevArray<float> T4;
+  const float* T4 = nullptr;
   DevArray<int> d_seen;
   int rc = obs_scan_prepare(s, poses_xyt, &T4);
   if (rc == HITL_OK) rc = d_seen.resize(16);
   if (rc == HITL_OK) rc = d_seen.zero(s->stream);
   if (rc == HITL_OK) {
-    launch_verify(s->stream, s->map_view(), T4.p, n_points, points_xy, threshold, d_seen.p);
+    launch_verify(s->stream, s->map_view(), T4, n_points, points_xy, threshold, d_seen.p);
     int h[16];
     if (hipMemcpyAsync(h, d_seen.p, sizeof(h), hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
         hipStreamSynchronize(s->stream) != hipSuccess) rc = fail(HITL_ERR_HIP, "verify_points failed");
     else for (int q = 0; q < n_points; ++q) seen[q] = h[q];
   }
-  T4.release(); d_seen.release();
+  d_seen.release();
   return rc;
 }
 
 int hitl_solver_observation_sets(hitl_solver* s, const float* poses_xyt, const float* seg_xy8, double threshold,
                                  int32_t* counts, uint8_t* mask) {
   if (!seg_xy8 || !counts) return fail(HITL_ERR_INVALID_ARGUMENT, "observation_sets: null argument");
-  DevArray<float> T4;
+  const float* T4 = nullptr;
   DevArray<int> d_cnt;
   DevArray<unsigned char> d_mask;
   int rc = obs_scan_prepare(s, poses_xyt, &T4);
@@ -1326,12 +1336,12 @@ int hitl_solver_observation_sets(hitl_solver* s, const float* poses_xyt, const f
   if (rc == HITL_OK) rc = d_cnt.zero(s->stream);
   if (rc == HITL_OK && mask) rc = d_mask.resize((size_t)s->n_obs);
   if (rc == HITL_OK) {
-    launch_obs_sets(s->stream, s->map_view(), T4.p, seg_xy8, threshold, d_cnt.p, mask ? d_mask.p : nullptr);
+    launch_obs_sets(s->stream, s->map_view(), T4, seg_xy8, threshold, d_cnt.p, mask ? d_mask.p : nullptr);
     hipError_t e = hipMemcpyAsync(counts, d_cnt.p, sizeof(int) * 2 * (size_t)s->n, hipMemcpyDeviceToHost, s->stream);
     if (e == hipSuccess && mask) e = hipMemcpyAsync(mask, d_mask.p, (size_t)s->n_obs, hipMemcpyDeviceToHost, s->stream);
     if (e != hipSuccess || hipStreamSynchronize(s->stream) != hipSuccess) rc = fail(HITL_ERR_HIP, "observation_sets failed");
   }
-  T4.release(); d_cnt.release(); d_mask.release();
+  d_cnt.release(); d_mask.release();
   return rc;
 }
 

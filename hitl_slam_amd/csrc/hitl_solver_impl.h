@@ -121,6 +121,8 @@ struct hitl_solver {
   DevArray<int> d_kd_ovf;                      //   k_match_kd_tgt: [0] = walks that overflowed the fast frame stack, [1 ..] = their (candidate, point) list
   bool kd_built = false;                       //   trees belong to the resident map
   DevArray<float> world_xy;                    // hitl_solver_transform_scans*: world x of every observation, then world y
+  DevArray<float> pose_rt;                     // solver_pose_rt: (cos, sin, x, y) per resident pose ...
+  std::vector<float> pose_rt_of;               // ... of these poses (n * 3)
   // pose pairs with >= 1 accepted match in the last search (info_mat_, JointOptimization.cpp:624-625): either derivable from
   // the candidate counts still on the device (windowed search: adj_window > 0), or collected on the host (tiled search)
   int adj_window = 0, adj_slots = 0;
