@@ -378,17 +378,19 @@ int hitl_solver_backprop(hitl_solver* s, int64_t n_poses, float* poses, float* c
   }
   DevArray<float> d_poses, d_cov, d_piv, d_tw, d_xf, d_trans;
   DevArray<int> d_sync;
-  int rc = d_poses.upload(poses, (size_t)3 * n_poses, cx.stream);
-  if (rc == HITL_OK) rc = d_cov.upload(cov9, (size_t)9 * n_poses, cx.stream);
+  // the kernels touch poses lo .. hi and covariances lo .. hi - 1 only: that span travels, not the whole chain (a correction's span
+  // is a few dozen poses of 50 000)
+  int rc = d_poses.upload(poses + 3 * (size_t)lo, (size_t)3 * (L + 1), cx.stream);
+  if (rc == HITL_OK) rc = d_cov.upload(cov9 + 9 * (size_t)lo, (size_t)9 * L, cx.stream);
   if (rc == HITL_OK) rc = d_piv.upload(piv, cx.stream);
   if (rc == HITL_OK) rc = d_tw.upload(tw, cx.stream);
   if (rc == HITL_OK) rc = d_xf.resize((size_t)4 * L);
   if (rc == HITL_OK) rc = d_trans.resize(2);
   if (rc == HITL_OK) rc = d_sync.resize((size_t)backprop_blocks(L) + 1);
   if (rc == HITL_OK) {
-    launch_backprop(cx.stream, d_poses.p, d_cov.p, lo, hi, d_piv.p, d_tw.p, d_xf.p, d_sync.p, destx, desty, trans_beta, rot_beta, d_trans.p);
-    hipError_t e = hipMemcpyAsync(poses, d_poses.p, sizeof(float) * 3 * (size_t)n_poses, hipMemcpyDeviceToHost, cx.stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(cov9, d_cov.p, sizeof(float) * 9 * (size_t)n_poses, hipMemcpyDeviceToHost, cx.stream);
+    launch_backprop(cx.stream, d_poses.p, d_cov.p, 0, L, d_piv.p, d_tw.p, d_xf.p, d_sync.p, destx, desty, trans_beta, rot_beta, d_trans.p);
+    hipError_t e = hipMemcpyAsync(poses + 3 * (size_t)lo, d_poses.p, sizeof(float) * 3 * (size_t)(L + 1), hipMemcpyDeviceToHost, cx.stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(cov9 + 9 * (size_t)lo, d_cov.p, sizeof(float) * 9 * (size_t)L, hipMemcpyDeviceToHost, cx.stream);
     if (e != hipSuccess || hipStreamSynchronize(cx.stream) != hipSuccess) rc = fail(HITL_ERR_HIP, "backprop: kernels failed");
   }
   d_poses.release(); d_cov.release(); d_piv.release(); d_tw.release(); d_xf.release(); d_trans.release(); d_sync.release();
