@@ -12,9 +12,11 @@ human constraints" on one GPU (configs[3]'s map at 1 GPU, the size the north-sta
 ">= 10x lower wall-clock per full batch re-solve ... at 1 GPU" is quoted on).
 --workload c2 selects configs[1] (1k x 360, 2 colinear constraints).
 
-With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) the trajectory is
-N times longer and split into N pose-range submaps, one per rank (weak scaling).  Ranks cut
-the map where it shards naturally (between floors: no scan overlap, one odometry edge).
+With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) the run is the one
+BASELINE.json names for that GPU count: --gpus 2 | 4 split the SAME 50k x 400 map into N
+pose-range submaps (configs[3], "scaling": "strong"); --gpus 8 splits the 200k x 512
+campus map into 8 (configs[4], --workload c5).  `--scaling weak` keeps the rounds 2-4 run
+(every rank gets a whole copy of the workload's trajectory length: N x the poses).
 
 Prints ONE JSON line on rank 0.
 """
@@ -32,13 +34,14 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: (poses per GPU, obs per pose, constraint groups per submap, constraint kind, window)
-    "c4": dict(poses=50000, obs=400, groups=50, kind=0, window=3,
+    # name: poses of the map BASELINE.json names, obs per pose, constraint groups of that map, constraint kind, window,
+    #       weak_poses = poses PER GPU of a `--scaling weak` run (c5: the named map is 8 such pieces)
+    "c4": dict(poses=50000, obs=400, groups=50, kind=0, window=3, weak_poses=50000, baseline="configs[3]",
                desc="synthetic multi-floor: 50k poses x 400 obs/pose, 50 human constraints (mixed), mode C"),
-    "c2": dict(poses=1000, obs=360, groups=2, kind=4, window=3,
+    "c2": dict(poses=1000, obs=360, groups=2, kind=4, window=3, weak_poses=1000, baseline="configs[1]",
                desc="synthetic corridor: 1k poses x 360 obs/pose, 2 colinearity constraints, mode C"),
-    "c5": dict(poses=25000, obs=512, groups=25, kind=0, window=3,
-               desc="synthetic campus-scale: 200k poses x 512 obs/pose over 8 submaps, 200 mixed constraints, mode C"),
+    "c5": dict(poses=200000, obs=512, groups=200, kind=0, window=3, weak_poses=25000, baseline="configs[4]",
+               desc="synthetic campus-scale: 200k poses x 512 obs/pose, 200 mixed constraints, mode C"),
 }
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
@@ -57,13 +60,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
-    ap.add_argument("--poses", type=int, default=0, help="override poses per GPU")
+    ap.add_argument("--workload", default="auto", choices=["auto"] + sorted(WORKLOADS),
+                    help="auto = what BASELINE.json names for the GPU count: c4 (50k x 400) at 1, 2 and 4 GPUs, c5 (200k x 512) at 8")
+    ap.add_argument("--poses", type=int, default=0, help="override the map's poses (strong: of the whole map; weak: per GPU)")
     ap.add_argument("--obs", type=int, default=0, help="override observations per pose")
     ap.add_argument("--cpu-sample-poses", type=int, default=6000, help="poses in the 1-thread sample of the cpu_baseline leg")
     ap.add_argument("--cpu-budget-s", type=float, default=30.0, help="CPU seconds the cpu_baseline leg may spend on repeats of the full workload")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="N>1: weak = N x the workload's poses (default), strong = the SAME map split into N pose-range submaps")
+    ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong"],
+                    help="N>1: strong (auto) = the SAME named map split into N pose-range submaps (BASELINE configs[3] / [4]); "
+                         "weak = N x the workload's per-GPU poses.  N=1 is the named map on one GPU either way (labelled weak)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--timing-level", type=int, default=1, help="hitl_options.timing_level: 1 = every 4th stf launch bracketed by "
                     "HIP events (default), 2 = all launches + linear-solver timing")
@@ -77,6 +82,10 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo lets several ranks share one GPU (debugging on a 1-GPU box)")
     args = ap.parse_args()
+    if args.workload == "auto":
+        args.workload = "c5" if args.gpus == 8 else "c4"
+    if args.scaling == "auto":
+        args.scaling = "strong" if args.gpus > 1 else "weak"
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -85,13 +94,10 @@ def main():
         # as CHILD processes (torch.distributed.run, one rank per GPU) before this process has imported torch or touched
         # the GPU -- never a re-exec -- relay rank 0's JSON line and exit with the launcher's code.  A run labelled
         # n_gpus = N is therefore always N ranks; it can never be one rank with a label.
-        import socket
         import subprocess
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        # (--standalone: the launcher picks a free rendezvous port itself -- no bind/close/reuse race)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+               "--nproc-per-node", str(args.gpus), os.path.abspath(__file__)] + sys.argv[1:]
         env = dict(os.environ)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         sys.stderr.write("bench.py: --gpus %d without WORLD_SIZE: launching %d ranks: %s\n" % (args.gpus, args.gpus, " ".join(cmd)))
@@ -126,6 +132,10 @@ def main():
     from tools import hitl_synth as S
 
     wl = dict(WORKLOADS[args.workload])
+    named_poses = wl["poses"]
+    if args.scaling == "weak" and world > 1:
+        wl["groups"] = max(1, int(round(wl["groups"] * wl["weak_poses"] / wl["poses"])))
+        wl["poses"] = wl["weak_poses"]                                              # per GPU
     if args.poses:
         wl["groups"] = max(1, int(round(wl["groups"] * args.poses / wl["poses"])))   # constraint density of the named workload
         wl["poses"] = args.poses
@@ -140,7 +150,8 @@ def main():
         cuts = [0] + [int(round(r * n_global / world / ppf)) * ppf for r in range(1, world)] + [n_global]
         if any(cuts[r + 1] - cuts[r] < 4 * wl["window"] + 2 for r in range(world)):
             cuts = [r * n_global // world for r in range(world)] + [n_global]
-        wl["groups"] = max(1, wl["groups"] // world)
+        # (the human constraints stay those of the whole map: every rank is handed all rows -- global pose ids -- and keeps the
+        # ones that constrain a pose it owns; anchors may lie on any rank, their targets come from the global start poses)
     else:
         n_global = wl["poses"] * world
         cuts = [r * wl["poses"] for r in range(world + 1)]
@@ -157,7 +168,8 @@ def main():
     halo = 2 * wl["window"] if use_dist else 0               # scans + state of the neighbours' nearest poses
     lo, hi = begin - (halo if rank > 0 else 0), end + (halo if rank < world - 1 else 0)
     off, px, py, nx, ny = S.scans(p, lo, hi)
-    rows = S.constraints(p, gt, wl["groups"], kind=wl["kind"], begin=begin, end=end)
+    strong = args.scaling == "strong" and world > 1
+    rows = S.constraints(p, gt, wl["groups"], kind=wl["kind"], begin=0 if strong else begin, end=n_global if strong else end)
     init_l = np.ascontiguousarray(init[begin:end])
     gen_s = time.time() - t0
 
@@ -331,7 +343,10 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": wl["desc"], "poses_per_gpu": n_local, "obs_per_pose": M, "n_poses_total": n_global,
+        "config": {"workload": wl["desc"] + ((" -- BASELINE.json %s" % wl["baseline"]) if n_global == named_poses and not args.obs else
+                                              " -- NOT a BASELINE.json size (%d poses in all)" % n_global) +
+                               ((", split into %d pose-range submaps (%s scaling)" % (world, args.scaling)) if world > 1 else ""),
+                   "poses_per_gpu": n_local, "obs_per_pose": M, "n_poses_total": n_global,
                    "n_obs_per_gpu": n_obs, "matches_per_gpu": int(n_matches_l), "pairs_per_gpu": int(n_pairs_l),
                    "matches_per_obs": n_matches_l / max(n_obs, 1), "window": wl["window"],
                    "human_constraint_rows": rows[1], "mode": "C (joint)", "band_poses": int(summ.band_poses),

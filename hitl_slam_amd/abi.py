@@ -117,7 +117,9 @@ class Summary(C.Structure):
         ("linearize_calls", C.c_int32),
         ("linearize_timed_calls", C.c_int32),
         ("submap_linear_solver", C.c_double),
-        ("reserved", C.c_double * 5),
+        ("hbm_bytes", C.c_double),
+        ("pcie_bytes", C.c_double),
+        ("reserved", C.c_double * 3),
     ]
 
     def as_dict(self):

@@ -116,11 +116,22 @@ class SolverBase(object):
     # -- lifetime --------------------------------------------------------------------------
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
-            if getattr(self, "_world_buf", None) is not None:      # the page-locked display clouds of world_clouds()
-                self.host_free(self._world_buf)
-                self._world_buf = None
+            self._drop_world_buf()                                  # the page-locked display clouds of world_clouds()
             self._fn("destroy")(self._h)
             self._h = C.c_void_p()
+
+    def _drop_world_buf(self):
+        """Frees the page-locked display buffers of world_clouds().  Views handed out earlier point into them: they are
+        shrunk to length 0 first, so that a stale view cannot read (or write) freed memory."""
+        buf = getattr(self, "_world_buf", None)
+        if buf is not None and hasattr(self, "host_free"):
+            for v in getattr(self, "_world_views", ()):
+                try:
+                    v.resize(0, refcheck=False)
+                except Exception:
+                    pass
+            self.host_free(buf)
+        self._world_buf, self._world_buf_len, self._world_views = None, 0, ()
 
     def __del__(self):
         try:
@@ -146,6 +157,7 @@ class SolverBase(object):
                                         _ptr(nx, _f32p), _ptr(ny, _f32p), _ptr(cov9, _f32p)), "set_map")
         self.n_poses = n
         self.obs_offset = obs_offset
+        self._drop_world_buf()          # sized by the previous map's observation count (a larger map overflowed them)
 
     def set_human_constraints(self, rows):
         if isinstance(rows, np.ndarray) and rows.dtype == abi.HC_DTYPE:
@@ -308,9 +320,12 @@ class SolverBase(object):
         return poses.reshape(-1, 3)
 
     def run_correction(self, ctype, selected_points_xy8, poses_xyt, cov9, constraint_groups, mode=abi.MODE_ODOM_HC,
-                       select_threshold=0.05, stf_window=3, find_corr_kwargs=None, reproject=True):
+                       select_threshold=0.05, stf_window=3, find_corr_kwargs=None, reproject=False):
         """One whole HitLSLAM::Run (HitLSLAM.cpp:380-480) on this backend.  constraint_groups is the session's list of
-        row arrays (human_constraints_); returns dict(poses, cov9, constraint_groups, summary, status, ...)."""
+        row arrays (human_constraints_); returns dict(poses, cov9, constraint_groups, summary, status, ...).
+        reproject=True adds out["world"] = world_clouds(poses): the whole map's world-frame clouds copied to the host (8 bytes
+        per observation: 160 MB at 20 M observations, and as much page-locked memory held by this object) -- off by default,
+        callers that only want poses and covariances do not pay for it."""
         poses = np.array(poses_xyt, np.float32).reshape(-1, 3)
         cov = np.array(cov9, np.float32).reshape(-1, 9)
         pts = np.array(selected_points_xy8, np.float32).reshape(-1)
@@ -345,9 +360,15 @@ class SolverBase(object):
 
     def world_clouds(self, poses_xyt):
         """The display clouds (HitLSLAM::transformPointCloudsToWorldFrame): (world_x, world_y).  hitl_slam_amd.Solver lands
-        them in page-locked buffers it keeps (views valid until the next call / close); the base form is transform_scans."""
+        them in page-locked buffers it keeps: the returned arrays are VIEWS, overwritten by the next call and emptied
+        (length 0) by set_map() / close(), which free the buffers; copy them to keep them.  The base form is transform_scans."""
         if hasattr(self, "transform_scans_pinned"):
+            n_obs = int(self.obs_offset[-1])
+            if getattr(self, "_world_buf", None) is not None and getattr(self, "_world_buf_len", 0) < n_obs:
+                self._drop_world_buf()                             # never write n_obs floats into a smaller block
             wx, wy, self._world_buf = self.transform_scans_pinned(poses_xyt, getattr(self, "_world_buf", None))
+            self._world_buf_len = max(getattr(self, "_world_buf_len", 0), n_obs)
+            self._world_views = (wx, wy)
             return wx, wy
         return self.transform_scans(poses_xyt)
 
@@ -463,6 +484,25 @@ def load_library(path=None):
                               "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
         _lib_cache[path] = C.CDLL(path, mode=C.RTLD_GLOBAL)
     return _lib_cache[path]
+
+
+def set_test_switch(name, value=1, lib_path=None):
+    """hitl_test_set_switch (csrc/hitl_host.h): a TEST hook of the library, not part of its C ABI -- forces a code path small
+    test maps do not reach by themselves (e.g. "stf_addr64", "cr_legacy", "kd_cap") for every Solver created afterwards in
+    this process.  name=None clears every hook."""
+    lib = load_library(lib_path)
+    lib.hitl_test_set_switch.argtypes = [C.c_char_p, C.c_longlong]
+    lib.hitl_test_set_switch.restype = C.c_int
+    if lib.hitl_test_set_switch(None if name is None else name.encode(), int(value)) != 0:
+        raise KeyError("hitl_test_set_switch: no test switch named %r" % (name,))
+
+
+def apply_test_switches_from_env(var="HITL_TEST_SWITCHES"):
+    """For test WORKER processes (tests/_submap_worker.py, tools/cr_size_sweep.py): 'name=value,name=value' in the named
+    environment variable -> set_test_switch calls.  The library itself never reads that variable."""
+    for item in filter(None, os.environ.get(var, "").split(",")):
+        k, _, v = item.partition("=")
+        set_test_switch(k.strip(), int(v or 1))
 
 
 class Solver(SolverBase):

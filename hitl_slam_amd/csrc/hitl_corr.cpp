@@ -172,7 +172,7 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
   // A windowed search over the whole map on one tile forms the transforms themselves on the device (k_cand_tf: the same
   // operations in the same order) and keeps on the host only what needs the C library: the (cos, sin) of every pose and of
   // every candidate's angle difference.  2 floats per candidate instead of 8 to compute, store and upload.
-  const bool tf_on_device = device_tables && !dev_switches().cand_tf_host;
+  const bool tf_on_device = device_tables;
   std::vector<float>& cand_trig = s->h_cand_trig;
   if (tf_on_device && cand_trig.size() != (size_t)n * slots * 2) cand_trig.resize((size_t)n * slots * 2);
   auto fill_candidates = [&](int64_t i0, int64_t i1, bool with_pose_trig = false, bool trig_only = false) {
@@ -256,7 +256,7 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
             if (j == i) continue;
             make_rel_tf(poses + 3 * i, poses + 3 * j, &cs[2 * i], &cs[2 * j], host.data(), true);
             if (std::memcmp(host.data(), &dev[((size_t)i * slots + slot) * 8], 8 * sizeof(float)) != 0)
-              return fail(HITL_ERR_SOLVER_FAILURE, "HITL_CAND_TF_CHECK: the device's transform of candidate (" + std::to_string(i) + ", " + std::to_string(j) +
+              return fail(HITL_ERR_SOLVER_FAILURE, "cand_tf_check: the device's transform of candidate (" + std::to_string(i) + ", " + std::to_string(j) +
                                                    ") differs from the host's");
             ++slot;
           }
@@ -269,12 +269,11 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
     TRYC(d_table.resize((size_t)cnt * slots * s->max_scan));
     if (kd_tgt) {
       // the per-point cap cannot bind (slots <= cap): every (source, target) pair is independent, one workgroup per target tree
-      const int kd_block = dev_switches().kd_block, kd_refill = dev_switches().kd_refill;
       if (mp.skip > 1 && hipMemsetAsync(d_table.p, 0xFF, sizeof(uint16_t) * (size_t)cnt * slots * s->max_scan, st) != hipSuccess)
         return fail(HITL_ERR_HIP, "find_correspondences: clearing the candidate table failed");
       TRYC(s->d_kd_ovf.resize(1 + 2 * (size_t)kKdRedoCap));
       if (hipMemsetAsync(s->d_kd_ovf.p, 0, sizeof(int), st) != hipSuccess) return fail(HITL_ERR_HIP, "find_correspondences: clearing the redo counter failed");
-      launch_match_kd_tgt(st, mv, s->max_scan, slots, (int)window, d_tf.p, mp, s->kd_pts.p, s->kd_meta.p, d_table.p, d_counts.p, kd_block, kd_refill,
+      launch_match_kd_tgt(st, mv, s->max_scan, slots, (int)window, d_tf.p, mp, s->kd_pts.p, s->kd_meta.p, d_table.p, d_counts.p,
                           s->d_kd_ovf.p, s->d_kd_ovf.p + 1, dev_switches().kd_redo_cap, s->kd_full_depth);
     } else if (kd) launch_match_kd(st, mv, s->max_scan, slots, d_tgt.p, d_tf.p, mp, s->kd_pts.p, s->kd_meta.p, d_table.p, d_counts.p, i0, cnt);
     else launch_match(st, mv, s->max_scan, slots, d_tgt.p, d_tf.p, mp, d_table.p, d_counts.p, i0, cnt);

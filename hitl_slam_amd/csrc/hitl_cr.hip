@@ -1254,11 +1254,10 @@ static size_t cr_chunk_src_extra(int nsl, int B, int threads, int Wb, int nrhs) 
   return (need <= avail) ? 0 : (need - avail) * sizeof(double);
 }
 static int cr_chunk_threads(int M, int B, int stage = 1) {
-  if (stage == 0 && dev_switches().cr_threads >= 64) return dev_switches().cr_threads & ~63;
   // first stage of the narrow bands: a node costs a wave whatever the tile size, and thousands of chunks queue for the CUs' 32
   // wave slots -- fewer waves per workgroup (the first level in several passes) puts more chunks on a CU at once.  Measured at
   // 40 000 - 50 000 poses: B = 3: 128 threads 4.9 ms per mode-A solve against 5.6 with 512; B = 6: 256 threads 5.5 against 5.9;
-  // B = 9 and 12: 512 stays best (HITL_CR_THREADS sweeps)
+  // B = 9 and 12: 512 stays best (workgroup-size sweeps of round 3)
   if (stage == 0 && M == 16 && B == 3) return 128;
   if (stage == 0 && M == 16 && B == 6) return 256;
   return (M <= 2) ? 64 : (M <= 4) ? 128 : (M <= 8) ? 256 : (M >= 32 && B < 12) ? 1024 : 512;
@@ -1267,14 +1266,12 @@ static int cr_chunk_threads(int M, int B, int stage = 1) {
 // stages of the fused factorisation for nsb super-blocks (host): chunks of 16 at stride 1, chunks of 32 above, then the top.
 // (Chunks of M = 2 -- one wave per eliminated node, no barrier -- were measured for the wide first levels and are not
 // faster: a node costs a whole wave's instruction stream either way; chunks of 4 or 8 at 2 waves per workgroup: 56 / 68 us for
-// the first stage against 54 us for chunks of 16.)  HITL_CR_PLAN="2,2,16,32" (development) overrides
-// the chunk sizes of the first stages.
+// the first stage against 54 us for chunks of 16.)
 static CrPlan cr_plan(const CrView& crv, int B, int np, int nrhs, size_t wstride) {
   const int nsb = crv.nsb; (void)nsb;
   CrPlan pl;
   pl.n = 0;
   const size_t lds_cap = 128 * 1024;
-  const std::vector<int> forced(dev_switches().cr_plan, dev_switches().cr_plan + dev_switches().cr_plan_n);
   int S = 1, par = 0;
   bool prev = false;
   for (;;) {
@@ -1291,7 +1288,6 @@ static CrPlan cr_plan(const CrView& crv, int B, int np, int nrhs, size_t wstride
     int M = (pl.n == 1) ? 16 : 32;       // measured on C4 (tools/cr_plans.sh): 16,32,top = 111 us; 2,2,16,.. = 117; 2,2,2,32,.. = 125
     if (cr_chunk_lds_bytes(M, B, cr_chunk_threads(M, B), nrhs) > lds_cap) M = 16;      // many right-hand sides (submap solve): smaller chunks
     if (cr_chunk_lds_bytes(M, B, cr_chunk_threads(M, B), nrhs) > lds_cap) M = 8;
-    if ((size_t)pl.n <= forced.size() && forced[pl.n - 1] >= 2) M = forced[pl.n - 1];
     g.M = M; g.top = 0; g.nsl = g.M + 1;
     S *= g.M; par ^= 1; prev = true;
   }
@@ -1320,7 +1316,7 @@ static bool cr_factor_fused(hipStream_t st, const CrView& cr, double* w, double*
   const CrPlan pl = cr_plan(cr, B, cr.np, nrhs, wstride);
   for (int t = 0; t < pl.n; ++t) {                        // every stage must fit its LDS budget, else the level-per-launch path
     const CrStage& g = pl.st[t];
-    if (g.M < 2 || g.M > (B == 3 ? 128 : 64) || (g.M & (g.M - 1)) != 0) return false;   // a forced plan (HITL_CR_PLAN) with an unusable chunk size
+    if (g.M < 2 || g.M > (B == 3 ? 128 : 64) || (g.M & (g.M - 1)) != 0) return false;
     const int thr = cr_chunk_threads(g.M, B, t);
     const bool use_src = (src != nullptr && t == 0);
     if (cr_chunk_lds_bytes(g.nsl - 1, B, thr, nrhs) + (use_src ? cr_chunk_src_extra(g.nsl, B, thr, src->Wb, nrhs) : 0) > 128 * 1024) return false;

@@ -9,6 +9,12 @@
 
 struct hitl_solver;
 
+// Test hook, exported by libhitlgpu.so but NOT part of the C ABI (include/hitl_gpu.h does not declare it and no caller needs it):
+// sets one of the DevSwitches test fields (hitl_internal.h: "cr_legacy", "cr_unfused_build", "stf_addr64", "device_lm", "lm_ahead",
+// "kd_cap", "kd_redo_cap", "cand_tf_check", "cand_tile_bytes") for every solver this process creates afterwards;
+// name == NULL clears them all.  Returns 0, or -1 for an unknown name.  tests/ drive it through ctypes.
+extern "C" int hitl_test_set_switch(const char* name, long long value);
+
 namespace hitl {
 
 int fail(int code, const std::string& msg);   // records the message behind hitl_last_error(); returns code

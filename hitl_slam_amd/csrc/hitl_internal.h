@@ -18,36 +18,30 @@ constexpr int kPairRJ = 14;               // r0, r1, J[2][6] per directed STF pa
 constexpr int kNumScalars = 16;           // device scalar scratch (doubles)
 constexpr int kMatchPad = 512;            // readable words behind the last match (k_linearize_stf fetches one trip ahead)
 
-// Development switches (environment variables; DESIGN.md section 5 lists them).  Read in ONE place, hitl_solver_create --
-// nothing on a launch or solve path calls getenv -- and kept per process: the values the last hitl_solver_create saw.
+// Process-wide switches, read in ONE place (hitl_solver_create -> read_dev_switches; nothing on a launch or solve path calls
+// getenv) and kept per process: the values the last hitl_solver_create saw.
+//  * Environment variables a maintainer may need (INTEGRATION.md lists exactly these): HITL_TIMING, HITL_ROCTX, HITL_FORCE_DIST,
+//    HITL_DIST_COLUMNS, HITL_FORCE_RCCL.
+//  * Test hooks: fields only hitl_test_set_switch() (hitl_host.h; exported, NOT part of include/hitl_gpu.h) can set.  They force
+//    code paths a small test map would not reach by itself (64-bit addressing, the level-per-launch cyclic reduction that backs
+//    the fused stages up, overflow of the search's frame stacks ...).  None is read from the environment.
 struct DevSwitches {
-  bool timing = false;             // HITL_TIMING: phase times of find_correspondences / prepare on stderr
+  bool timing = false;             // HITL_TIMING: phase times of find_correspondences / prepare / lm_solve on stderr
                                    // (HITL_ROCTX: roctx ranges around the phases, hitl_host.h)
-  bool event_sync = false;         // HITL_EVENT_SYNC: event instead of the pinned-memory flag in the LM loop
-  bool cr_legacy = false;          // HITL_CR_LEGACY: level-per-launch cyclic reduction
-  bool cr_unfused_build = false;   // HITL_CR_UNFUSED_BUILD: k_build_system as its own launch
-  bool stf_addr64 = false;         // HITL_STF_ADDR64: 64-bit addressing instantiations of k_linearize_stf
   bool force_dist = false;         // HITL_FORCE_DIST: one rank takes the submap code path
   bool force_rccl = false;         // HITL_FORCE_RCCL: in-library RCCL communicator with one rank
   bool dist_columns = false;       // HITL_DIST_COLUMNS: submap ranks keep the interface-column form of the linear solve although the separator form applies
-  bool device_lm = false;          // HITL_DEVICE_LM: accept / reject / terminate decided on the device (k_lm_decide), iterations queued ahead.
-                                   // Measured (round 3): gap-free kernel timeline, but the decision kernel costs what the host turn-around
-                                   // cost -- 4-8 us per iteration SLOWER on every workload -- so the host-driven loop stays the default
-  int stf_variant = 0;             // HITL_STF_VARIANT: instantiation of k_linearize_stf (1xx: one wave per pair, one pose per workgroup; 2xx: the half-wave kernel
-                                   // although the persistent one applies)
-  int stf_waves_per_cu = 0;        // HITL_STF_WAVES_PER_CU: cap on the resident waves per CU of the stream linearisation (0 = what fits)
-  int kd_block = 256;              // HITL_KD_BLOCK: workgroup size of k_match_kd_tgt (64 / 128 / 256)
-  int lm_ahead = 3;                // HITL_LM_AHEAD: LM iterations the host queues ahead of the device-driven loop
-  int kd_cap = 0;                  // HITL_KD_CAP: frame-stack entries per lane of k_match_kd_tgt's first attempt (0 = 5); tests force the full-depth repeat with 1
-  int kd_redo_cap = 1 << 18;       // HITL_KD_REDO_CAP: entries of the redo list behind the fast attempt (tests shrink it to force the full-depth repeat)
-  int kd_refill = 16;              // HITL_KD_REFILL: idle lanes per wave that trigger a refill from the query queue
-  int kd_fast = 1;                 // HITL_KD_FAST: kd_step_fast calls behind every kd_step of k_match_kd_tgt (0, 1, 2)
-  bool cand_tf_host = false;       // HITL_CAND_TF_HOST: the candidate transforms of a windowed search on the host (rounds 1-3), uploaded
-  bool cand_tf_check = false;      // HITL_CAND_TF_CHECK: the device's candidate transforms held to the host routine, bit for bit (tests)
-  size_t cand_tile_bytes = (size_t)4 << 30;   // HITL_CAND_TILE_BYTES: candidate-table budget of the tiled search
-  int cr_plan[16] = {0};           // HITL_CR_PLAN: chunk sizes of the fused stages
-  int cr_plan_n = 0;
-  int cr_threads = 0;              // HITL_CR_THREADS: workgroup size of the first fused stage (0 = by chunk size)
+  // ---- test hooks ----
+  bool cr_legacy = false;          // "cr_legacy": the level-per-launch cyclic reduction (the fallback of the fused stages)
+  bool cr_unfused_build = false;   // "cr_unfused_build": k_build_system as its own launch in front of the generic first stage
+  bool stf_addr64 = false;         // "stf_addr64": the 64-bit addressing instantiations of k_linearize_stf (arrays beyond 4 GB)
+  bool device_lm = false;          // "device_lm": accept / reject / terminate decided on the device (k_lm_decide), iterations queued ahead.
+                                   // Measured (round 3): 4-8 us per iteration SLOWER than the host-driven loop on every workload
+  int lm_ahead = 3;                // "lm_ahead": LM iterations the host queues ahead of the device-driven loop
+  int kd_cap = 0;                  // "kd_cap": frame-stack entries per lane of k_match_kd_tgt's first attempt (0 = 5); 1 forces the redo walks
+  int kd_redo_cap = 1 << 18;       // "kd_redo_cap": entries of the redo list behind the fast attempt (shrunk to force the full-depth repeat)
+  bool cand_tf_check = false;      // "cand_tf_check": the device's candidate transforms held to the host routine, bit for bit
+  size_t cand_tile_bytes = (size_t)4 << 30;   // "cand_tile_bytes": candidate-table budget of the tiled search (shrunk to force several tiles)
 };
 const DevSwitches& dev_switches();
 void read_dev_switches();          // hitl_solver_create only
@@ -168,25 +162,6 @@ void launch_linearize_stf(hipStream_t st, const MapView& map, const PairView& pr
                           const void* pose_recs = nullptr /* launch_build_stf_pose_recs: one stf_pose_rec_bytes() record per pose, or null */);
 size_t stf_pose_rec_bytes();
 void launch_build_stf_pose_recs(hipStream_t st, const MapView& map, const PairView& pr, void* recs);
-// round 4: the persistent, wave-per-pair form of the same linearisation (k_linearize_stf_p).  It walks a step table (one
-// step = one source pose and up to six of its directed pairs) built once per correspondence set by launch_build_stf_steps:
-// step_off[n_poses + 1] (step_off[n_poses] = number of steps, read by the kernel itself), steps[] of stf_step_bytes() each
-// (at most n_poses + n_pairs / 6 of them).  Applies to scans of <= 2048 points; grid = workgroups (4 per CU).
-size_t stf_step_bytes();
-void launch_build_stf_steps(hipStream_t st, const MapView& map, const PairView& pr, int* step_off, void* steps);
-int stf_steps_grid(int max_scan, int cu_count);
-void launch_linearize_stf_steps(hipStream_t st, int max_scan, int grid, const void* steps, const int* n_steps, const float4* obs,
-                                const uint32_t* matches, const double* x, const double2* cs, float corr, float std_dev, double* pairRJ);
-// round 4: one wave per workgroup, every wave on its own run of pairs, software-pipelined over pairs (k_linearize_stf_s).
-// recs: one stf_pair_rec_bytes() record per pair (launch_build_stf_pair_recs, once per correspondence set; *max_len receives
-// the largest match count of a pair: the kernel holds at most stf_stream_max_len() matches of a pair in registers).
-size_t stf_pair_rec_bytes();
-int stf_stream_max_len();
-int stf_stream_waves(int max_scan, int cu_count);      // waves (= workgroups) of the kernel for this map on this device
-// wave_cnt[n_waves], wave_off[n_waves + 1] (scratch / where each wave's records start), recs[n_pairs]
-void launch_build_stf_pair_recs(hipStream_t st, const MapView& map, const PairView& pr, int n_waves, int* wave_cnt, int* wave_off, void* recs, int* max_len);
-void launch_linearize_stf_stream(hipStream_t st, int max_scan, int n_waves, const void* recs, const int* wave_off, const int64_t* obs_off,
-                                 const float4* obs, const uint32_t* matches, const double* x, const double2* cs, float corr, float std_dev, double* pairRJ);
 void launch_pack_obs(hipStream_t st, int64_t n, const float* px, const float* py, const float* nx, const float* ny,
                      float4* obs);
 void launch_assemble(hipStream_t st, const MapView& map, const PairView& pr, const FactorView& fv,
@@ -304,13 +279,13 @@ void launch_kd_build(hipStream_t st, const MapView& map, int max_scan, float4* k
 void launch_match_kd(hipStream_t st, const MapView& map, int max_scan, int slots, const int* cand_tgt, const float* cand_tf, MatchParams mp,
                      const float4* kd_pts, const uint32_t* kd_meta, uint16_t* table, int* counts, int i0 = 0, int n_tile = -1);
 // target-major form of the same search (one workgroup per target tree, one queue of all its queries): whole map, windowed
-// candidates, slots <= cap (the per-point cap cannot bind); block = 64 / 128 / 256 threads, refill_min = idle lanes per wave
-// that trigger a refill from the queue
+// candidates, slots <= cap (the per-point cap cannot bind); workgroups of 256 threads (128 / 64 where a long scan's tree
+// would not leave room for the frame stacks), a wave refills from the queue when 16 of its lanes are idle
 bool match_kd_tgt_applies(int slots, int window, const MatchParams& mp);
 // candidate transforms of a windowed search over the whole map on the device; trig = (cos, sin) of theta_j - theta_i per candidate (host libm)
 void launch_cand_tf(hipStream_t st, int n, int slots, int window, const float* poses, const float* cs, const float* trig, float* cand_tf);
 void launch_match_kd_tgt(hipStream_t st, const MapView& map, int max_scan, int slots, int window, const float* cand_tf, MatchParams mp,
-                         const float4* kd_pts, const uint32_t* kd_meta, uint16_t* table, int* counts, int block, int refill_min,
+                         const float4* kd_pts, const uint32_t* kd_meta, uint16_t* table, int* counts,
                          int* redo_count /* walks that needed more frames than the launch provisioned ... */, int* redo_list /* ... (candidate, point) each,
                          repeated by k_match_kd_redo behind the main kernel; a count beyond redo_cap voids the search */, int redo_cap, bool full_depth);
 void launch_compact(hipStream_t st, const MapView& map, int max_scan, int slots, int n_kept,

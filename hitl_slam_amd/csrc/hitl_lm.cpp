@@ -38,12 +38,6 @@ static int enqueue_linearize(hitl_solver* s, const FactorView& fv, const double*
   if (fv.with_stf) {
     if (s->opt.stf_moments)
       launch_linearize_stf_moments(st, pv, s->pairM.p, xdev, s->pose_cs.p, s->opt.point_correlation_factor, s->opt.laser_std_dev, lv.pairRJ);
-    else if (s->stf_recs_of == s->corr_generation && s->stf_stream_fits && stf_stream_apply(s))
-      launch_linearize_stf_stream(st, s->max_scan, s->stf_waves, s->stf_recs.p, s->stf_wave_off.p, s->obs_off.p, s->obs.p, s->matches.p, xdev,
-                                  s->pose_cs.p, s->opt.point_correlation_factor, s->opt.laser_std_dev, lv.pairRJ);
-    else if (s->stf_steps_of == s->corr_generation && stf_steps_apply(s))
-      launch_linearize_stf_steps(st, s->max_scan, stf_steps_grid(s->max_scan, s->cu_count), s->stf_steps.p, s->stf_step_off.p + s->n, s->obs.p, s->matches.p, xdev,
-                                 s->pose_cs.p, s->opt.point_correlation_factor, s->opt.laser_std_dev, lv.pairRJ);
     else
       launch_linearize_stf(st, mv, pv, s->max_scan, s->n_obs, s->n_matches, xdev, s->pose_cs.p, s->opt.point_correlation_factor, s->opt.laser_std_dev, lv.pairRJ,
                            nullptr, nullptr, nullptr, s->stf_pose_recs_of == s->corr_generation ? s->stf_pose_recs.p : nullptr);
@@ -75,30 +69,22 @@ static int finish_linearize(hitl_solver* s, const FactorView& fv, LinResult* out
 
 // Wait for the stream without sleeping on an interrupt: the LM loop turns around in tens of microseconds.  A one-thread
 // kernel behind the queued work stores a sequence number into pinned host memory and the host polls that word: ~0.25 ms per
-// re-solve cheaper than hipEventRecord + hipEventQuery (HITL_EVENT_SYNC=1 brings those back).  The kernels in front of it
+// re-solve cheaper than hipEventRecord + hipEventQuery (measured in round 2).  The kernels in front of it
 // have completed -- and their own stores to pinned memory (the partial sums) are visible -- before it starts.
 static int spin_sync(hitl_solver* s) {
-  if (!dev_switches().event_sync) {
-    volatile double* flag = s->h_scalars + 15;
-    const double seq = (double)(++s->sync_seq);
-    launch_host_flag(s->stream, s->h_scalars + 15, seq);   // (hipStreamWriteValue64 instead of this one-thread kernel: measured, no difference)
-    for (uint32_t spins = 1;; ++spins) {
-      if (*flag == seq) { std::atomic_thread_fence(std::memory_order_acquire); return HITL_OK; }
-      if ((spins & 0xfffffu) == 0) {                       // every million polls: is the stream still alive?
-        const hipError_t e = hipStreamQuery(s->stream);
-        if (e == hipSuccess) {
-          if (*flag == seq) { std::atomic_thread_fence(std::memory_order_acquire); return HITL_OK; }
-          return fail(HITL_ERR_HIP, "the stream drained without delivering the host flag");
-        }
-        if (e != hipErrorNotReady) return fail(HITL_ERR_HIP, std::string("while waiting for the stream: ") + hipGetErrorString(e));
+  volatile double* flag = s->h_scalars + 15;
+  const double seq = (double)(++s->sync_seq);
+  launch_host_flag(s->stream, s->h_scalars + 15, seq);   // (hipStreamWriteValue64 instead of this one-thread kernel: measured, no difference)
+  for (uint32_t spins = 1;; ++spins) {
+    if (*flag == seq) { std::atomic_thread_fence(std::memory_order_acquire); return HITL_OK; }
+    if ((spins & 0xfffffu) == 0) {                       // every million polls: is the stream still alive?
+      const hipError_t e = hipStreamQuery(s->stream);
+      if (e == hipSuccess) {
+        if (*flag == seq) { std::atomic_thread_fence(std::memory_order_acquire); return HITL_OK; }
+        return fail(HITL_ERR_HIP, "the stream drained without delivering the host flag");
       }
+      if (e != hipErrorNotReady) return fail(HITL_ERR_HIP, std::string("while waiting for the stream: ") + hipGetErrorString(e));
     }
-  }
-  HIP_TRY(hipEventRecord(s->ev_sync, s->stream));
-  for (;;) {
-    const hipError_t e = hipEventQuery(s->ev_sync);
-    if (e == hipSuccess) return HITL_OK;
-    if (e != hipErrorNotReady) return fail(HITL_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(e));
   }
 }
 
@@ -694,6 +680,23 @@ int dist_cov_sep(hitl_solver* s, const FactorView& fv, int buf, double* Sd, doub
   return HITL_OK;
 }
 
+// hitl_summary.hbm_bytes: what one linearisation / one linear solve / one band pass streams through device memory, from the sizes
+// of the arrays each launch reads and writes once (this layout's compulsory bytes; DESIGN.md section 4 lists them per kernel)
+struct ByteModel { double linearize, solve, step; };
+static ByteModel byte_model(const hitl_solver* s, const FactorView& fv) {
+  const double n = s->n, P = fv.with_stf ? (double)s->n_pairs : 0.0, C = fv.with_stf ? (double)s->n_matches : 0.0;
+  const double O = fv.with_stf ? (double)s->n_obs : 0.0, Wb = fv.band_poses, B = 3.0 * Wb, nsb = std::ceil(n / Wb);
+  ByteModel m;
+  const double stf = s->opt.stf_moments ? (double)kPairMomStride * 8.0 * P + 112.0 * P + 40.0 * n
+                                        : 16.0 * O + 4.0 * C + 24.0 * n + 112.0 * P + 128.0 * n;       // k_linearize_stf_r (P > 0 only)
+  const double assemble = 224.0 * P + 8.0 * P + 8.0 * Wb * n       // pair rows read at both ends + band blocks, incidence + band tables
+                        + 72.0 * (Wb + 1.0) * n + 24.0 * n + 24.0 * n + 24.0 * n + 16.0 * n;   // Hband + g out, state, odometry tables in
+  m.linearize = (P > 0 ? stf : 0.0) + assemble;
+  m.solve = 72.0 * (Wb + 1.0) * n + 48.0 * n + 2.0 * 3.0 * 8.0 * B * B * nsb + 4.0 * 24.0 * n;   // band rows in, Dinv / Gl / Gr out and back in, vectors
+  m.step = 72.0 * (Wb + 1.0) * n + 10.0 * 24.0 * n;
+  return m;
+}
+
 static double now_ms() {
   using namespace std::chrono;
   return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
@@ -710,7 +713,7 @@ static double now_ms() {
 // are current, the radius, and whether the loop is over are read from LmDev on the device.  Launches queued behind the
 // terminating iteration return at once.  Same statements, same sums in the same order as the host loop below: identical
 // iteration sequences and bit-identical poses (tests/test_gpu_parity.py A/B).
-// OPT-IN (HITL_DEVICE_LM=1).  Measured on MI355X (tools/dev/lm_ab.py, lm_ab2.py): the kernel trace of this loop has no gaps
+// OPT-IN (test hook device_lm).  Measured on MI355X (tools/dev/lm_ab.py, lm_ab2.py): the kernel trace of this loop has no gaps
 // between launches (the host-driven loop: ~40 us per iteration in the round-2 trace), yet its wall clock is 4-8 us per
 // iteration LONGER on every workload tried (C4 18.65 vs 18.15 ms, C2 1.20 vs 1.16 ms, moments mode 7.39 vs 7.15 ms,
 // mode A 5.13 vs 5.01 ms; queue depth 1..6 makes no difference): k_lm_decide (sums of ~4700 partials, a system-scope fence
@@ -844,6 +847,9 @@ int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float* poses
   LinResult lr;
   { RoctxRange r("hitl:initial linearisation"); TRY(run_linearize_dist(s, fv, xcur, cur, &lr)); }
   S.linearize_ms += lr.stf_ms; S.linearize_calls++; S.linearize_timed_calls += lr.timed;
+  const ByteModel bm = byte_model(s, fv);
+  const double pcie_per_iter = 8.0 * (8.0 * spmv_blocks(s->npad) + 2.0 * assemble_blocks(n) + 1.0);   // partial sums + the flag, written to pinned memory
+  S.pcie_bytes = 8.0 * s->npad + 4.0 * 3.0 * n + s->prepare_pcie_bytes + 16.0 * assemble_blocks(n);     // poses in (fp64), out, factor tables, first partials
   double cost = lr.cost, gmax = lr.gmax;
   S.initial_cost = cost;
   S.num_pairs = fv.with_stf ? s->n_pairs_owned : 0;
@@ -948,6 +954,8 @@ int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float* poses
   if (dev_switches().timing)
     std::fprintf(stderr, "lm_solve: before the loop %.3f ms, %s loop %.3f ms (%d iterations)\n", t_loop - t_start, dev_loop ? "device-driven" : "host-driven", now_ms() - t_loop, iter);
   S.termination = term; S.iterations = iter;
+  S.hbm_bytes = bm.linearize * S.linearize_calls + (bm.solve + bm.step) * S.linear_iterations;
+  S.pcie_bytes += pcie_per_iter * iter + 8.0 * 3.0 * n;
   S.final_cost = cost; S.final_gradient_max_norm = gmax; S.final_trust_region_radius = radius;
   {  // CopyParams (JointOptimization.cpp:380-390): fp64 -> fp32, theta through angle_mod
     TRY(s->h_x.resize(s->npad));

@@ -287,7 +287,7 @@ static int kd_depth(int max_scan) { int d = 1; while ((1 << d) <= max_scan) ++d;
 // many workgroups a CU holds (C4: full depth 10 -> 3 workgroups of 256, search 9.1 ms; 5 entries -> 6 workgroups, 6.8 ms).
 // Scan queries need 1.1 frames on average and 6 or fewer in all but ~1 of 10^5 walks, so the fast attempt gives every lane
 // kKdFastCap entries; a walk that wants more is put on a list and repeated by k_match_kd_redo right behind (full depth, private
-// stack).  If even the list overflows (never seen; HITL_KD_CAP=1 in the tests) the host repeats the whole search at full depth.
+// stack).  If even the list overflows (never seen; the test hook kd_cap = 1 forces it) the host repeats the whole search at full depth.
 constexpr int kKdFastCap = 5;
 static int kd_tgt_cap(int max_scan, bool full) {
   const int d = kd_depth(max_scan);
@@ -522,7 +522,7 @@ void launch_match_kd(hipStream_t st, const MapView& map, int max_scan, int slots
 // correctly rounded division, no contraction in this file -- from the poses, the per-pose (cos, sin) and the per-candidate
 // (cos, sin) of the angle difference, which stay with the host's libm (the only part whose bits a GPU cannot be trusted to
 // reproduce).  One thread per candidate (i, slot): j = slot-th pose of [i - window, i + window] without i; slots past the end
-// of the list get zeros.  HITL_CAND_TF_CHECK=1 holds every launch to the host routine, bit for bit.
+// of the list get zeros.  The test hook cand_tf_check holds every launch to the host routine, bit for bit.
 __global__ void k_cand_tf(int n, int slots, int window, const float* __restrict__ poses, const float* __restrict__ cs,
                           const float* __restrict__ trig, float* __restrict__ cand_tf) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -563,22 +563,18 @@ bool match_kd_tgt_applies(int slots, int window, const MatchParams& mp) {
   return window >= 1 && 2 * window <= kKdMaxSrc && slots <= 2 * window && slots <= mp.cap && mp.skip >= 1;
 }
 
+constexpr int kKdRefillMin = 16;      // idle lanes per wave that trigger a refill from the query queue (sweeps of rounds 3-4: 4 .. 32 within 2 %)
 template <int BLOCK>
-static void launch_match_kd_tgt_t(hipStream_t st, const MapView& map, int max_scan, int slots, int window, int refill_min, const float* cand_tf,
+static void launch_match_kd_tgt_t(hipStream_t st, const MapView& map, int max_scan, int slots, int window, const float* cand_tf,
                                   MatchParams mp, const float4* kd_pts, const uint32_t* kd_meta, uint16_t* table, int* counts, int* redo_count,
                                   int* redo_list, int redo_cap, bool full_depth) {
   const int chunk = (map.n_poses + 7) / 8;
   const int depth = kd_tgt_cap(max_scan, full_depth);
   const size_t lds = match_kd_tgt_lds_bytes(max_scan, BLOCK, full_depth);
-  const int fast = dev_switches().kd_fast;
-#define HITL_KD_GO(F)                                                                                                                                  \
-  do {                                                                                                                                                 \
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_match_kd_tgt<BLOCK, F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    hipLaunchKernelGGL((k_match_kd_tgt<BLOCK, F>), dim3(8 * chunk), dim3(BLOCK), lds, st, map, chunk, max_scan, slots, window, depth, refill_min, cand_tf, mp,      \
-                       kd_pts, kd_meta, table, counts, redo_count, redo_list, redo_cap);                                                                             \
-  } while (0)
-  if (fast == 0) HITL_KD_GO(0); else if (fast == 2) HITL_KD_GO(2); else HITL_KD_GO(1);
-#undef HITL_KD_GO
+  // one kd_step_fast behind every kd_step (0 and 2 were measured in round 4: 15 % slower / no gain)
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_match_kd_tgt<BLOCK, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((k_match_kd_tgt<BLOCK, 1>), dim3(8 * chunk), dim3(BLOCK), lds, st, map, chunk, max_scan, slots, window, depth, kKdRefillMin, cand_tf, mp,
+                     kd_pts, kd_meta, table, counts, redo_count, redo_list, redo_cap);
   if (!full_depth)
     hipLaunchKernelGGL(k_match_kd_redo, dim3(256), dim3(64), 0, st, map, max_scan, slots, window, cand_tf, mp, kd_pts, kd_meta, table, counts, redo_count,
                        redo_list, redo_cap);
@@ -589,12 +585,13 @@ size_t match_kd_tgt_lds_bytes(int max_scan, int block, bool full_depth) {
 }
 
 void launch_match_kd_tgt(hipStream_t st, const MapView& map, int max_scan, int slots, int window, const float* cand_tf, MatchParams mp,
-                         const float4* kd_pts, const uint32_t* kd_meta, uint16_t* table, int* counts, int block, int refill_min, int* redo_count,
+                         const float4* kd_pts, const uint32_t* kd_meta, uint16_t* table, int* counts, int* redo_count,
                          int* redo_list, int redo_cap, bool full_depth) {
+  int block = 256;                                     // 64 / 128 threads: 13.5 / 9.4 ms against 8.6 at C4 (round 3)
   while (block > 64 && match_kd_tgt_lds_bytes(max_scan, block, full_depth) > (size_t)150 * 1024) block /= 2;     // long scans: fewer lanes share the tree
-  if (block == 64) launch_match_kd_tgt_t<64>(st, map, max_scan, slots, window, refill_min, cand_tf, mp, kd_pts, kd_meta, table, counts, redo_count, redo_list, redo_cap, full_depth);
-  else if (block == 256) launch_match_kd_tgt_t<256>(st, map, max_scan, slots, window, refill_min, cand_tf, mp, kd_pts, kd_meta, table, counts, redo_count, redo_list, redo_cap, full_depth);
-  else launch_match_kd_tgt_t<128>(st, map, max_scan, slots, window, refill_min, cand_tf, mp, kd_pts, kd_meta, table, counts, redo_count, redo_list, redo_cap, full_depth);
+  if (block == 64) launch_match_kd_tgt_t<64>(st, map, max_scan, slots, window, cand_tf, mp, kd_pts, kd_meta, table, counts, redo_count, redo_list, redo_cap, full_depth);
+  else if (block == 256) launch_match_kd_tgt_t<256>(st, map, max_scan, slots, window, cand_tf, mp, kd_pts, kd_meta, table, counts, redo_count, redo_list, redo_cap, full_depth);
+  else launch_match_kd_tgt_t<128>(st, map, max_scan, slots, window, cand_tf, mp, kd_pts, kd_meta, table, counts, redo_count, redo_list, redo_cap, full_depth);
 }
 
 size_t match_lds_bytes(int max_scan) {

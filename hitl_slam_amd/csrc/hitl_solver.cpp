@@ -313,6 +313,7 @@ int setup_factors(hitl_solver* s, const float* poses, const float* poses_global,
   TRY(s->odom_A.upload(A, (size_t)n, st)); TRY(s->odom_rr.upload(rr, (size_t)n, st));
   TRY(s->hc_off.upload(s->h_hc_off.p, (size_t)n + 1, st));
   TRY(s->hc_type.upload(hc_type, std::max<size_t>(H, 1), st)); TRY(s->hc_tgt.upload(hc_tgt, std::max<size_t>(H, 1), st));
+  s->prepare_pcie_bytes = (double)n * (sizeof(float4) + sizeof(float2)) + ((double)n + 1) * sizeof(int) + (double)std::max<size_t>(H, 1) * (sizeof(uint32_t) + sizeof(float4));
   return HITL_OK;
 }
 
@@ -354,34 +355,12 @@ static int prepare_local(hitl_solver* s, int mode, const float* poses_ref, const
     HIP_TRY(hipGetLastError());
     s->moments_of = s->corr_generation;
   }
-  if (!s->opt.stf_moments && mode != HITL_MODE_ODOM_HC && s->n_pairs > 0 && stf_steps_apply(s) && s->stf_steps_of != s->corr_generation) {
-    // once per correspondence set: the step table the persistent linearisation walks
-    TRY(s->stf_step_off.resize((size_t)s->n + 1));
-    TRY(s->stf_steps.resize(((size_t)s->n + (size_t)s->n_pairs / 6 + 2) * stf_step_bytes()));
-    launch_build_stf_steps(s->stream, s->map_view(), s->pair_view(), s->stf_step_off.p, s->stf_steps.p);
-    HIP_TRY(hipGetLastError());
-    s->stf_steps_of = s->corr_generation;
-  }
   if (!s->opt.stf_moments && mode != HITL_MODE_ODOM_HC && s->n_pairs > 0 && s->stf_pose_recs_of != s->corr_generation) {
     // once per correspondence set: the per-pose descriptor records (what the first two dependent load rounds of a workgroup fetch)
     TRY(s->stf_pose_recs.resize((size_t)s->n * stf_pose_rec_bytes()));
     launch_build_stf_pose_recs(s->stream, s->map_view(), s->pair_view(), s->stf_pose_recs.p);
     HIP_TRY(hipGetLastError());
     s->stf_pose_recs_of = s->corr_generation;
-  }
-  if (!s->opt.stf_moments && mode != HITL_MODE_ODOM_HC && s->n_pairs > 0 && stf_stream_apply(s) && s->stf_recs_of != s->corr_generation) {
-    // once per correspondence set: the pair records the stream linearisation walks, and whether every pair fits its registers
-    TRY(s->stf_recs.resize((size_t)s->n_pairs * stf_pair_rec_bytes()));
-    TRY(s->stf_max_len.resize(1));
-    s->stf_waves = stf_stream_waves(s->max_scan, s->cu_count);
-    TRY(s->stf_wave_cnt.resize((size_t)s->stf_waves)); TRY(s->stf_wave_off.resize((size_t)s->stf_waves + 1));
-    launch_build_stf_pair_recs(s->stream, s->map_view(), s->pair_view(), s->stf_waves, s->stf_wave_cnt.p, s->stf_wave_off.p, s->stf_recs.p, s->stf_max_len.p);
-    HIP_TRY(hipGetLastError());
-    int max_len = 0;
-    HIP_TRY(hipMemcpyAsync(&max_len, s->stf_max_len.p, sizeof(int), hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(hipStreamSynchronize(s->stream));
-    s->stf_stream_fits = max_len <= stf_stream_max_len();
-    s->stf_recs_of = s->corr_generation;
   }
   TRY(setup_factors(s, poses_ref, poses_global, mode != HITL_MODE_STF_ONLY));
   return HITL_OK;
@@ -570,31 +549,43 @@ int prepare(hitl_solver* s, int mode, const float* poses_ref, const float* poses
 
 namespace hitl {
 static DevSwitches g_dev;
+static DevSwitches g_test_hooks;          // what hitl_test_set_switch has set; only the test-hook fields are ever taken from it
 const DevSwitches& dev_switches() { return g_dev; }
 void read_dev_switches() {
-  DevSwitches d;
+  DevSwitches d = g_test_hooks;
   auto on = [](const char* name) { return std::getenv(name) != nullptr; };
-  auto num = [](const char* name, long long dflt) { const char* e = std::getenv(name); return e ? std::atoll(e) : dflt; };
-  d.timing = on("HITL_TIMING"); d.event_sync = on("HITL_EVENT_SYNC"); d.cr_legacy = on("HITL_CR_LEGACY");
-  d.cr_unfused_build = on("HITL_CR_UNFUSED_BUILD"); d.stf_addr64 = on("HITL_STF_ADDR64"); d.force_dist = on("HITL_FORCE_DIST");
-  d.force_rccl = on("HITL_FORCE_RCCL"); d.device_lm = on("HITL_DEVICE_LM"); d.dist_columns = on("HITL_DIST_COLUMNS");
-  d.stf_variant = (int)num("HITL_STF_VARIANT", 0);
-  d.stf_waves_per_cu = (int)num("HITL_STF_WAVES_PER_CU", 0);
-  d.kd_block = (int)num("HITL_KD_BLOCK", d.kd_block);
-  d.kd_cap = (int)num("HITL_KD_CAP", 0);
-  d.kd_redo_cap = (int)std::max(1ll, std::min((long long)(1 << 18), num("HITL_KD_REDO_CAP", d.kd_redo_cap)));
-  d.lm_ahead = (int)std::max(1ll, std::min(16ll, num("HITL_LM_AHEAD", d.lm_ahead)));
-  d.kd_refill = (int)std::max(1ll, std::min(64ll, num("HITL_KD_REFILL", d.kd_refill)));
-  d.kd_fast = (int)std::max(0ll, std::min(2ll, num("HITL_KD_FAST", d.kd_fast)));
-  d.cand_tf_host = on("HITL_CAND_TF_HOST"); d.cand_tf_check = on("HITL_CAND_TF_CHECK");
-  d.cand_tile_bytes = (size_t)std::max(1ll, num("HITL_CAND_TILE_BYTES", (long long)d.cand_tile_bytes));
-  d.cr_threads = (int)num("HITL_CR_THREADS", 0);
-  if (const char* e = std::getenv("HITL_CR_PLAN"))
-    for (const char* q = e; *q && d.cr_plan_n < 16;) { d.cr_plan[d.cr_plan_n++] = std::atoi(q); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
+  // the five environment switches; everything else a DevSwitches field can be is a test hook
+  d.timing = on("HITL_TIMING");
+  d.force_dist = on("HITL_FORCE_DIST");
+  d.force_rccl = on("HITL_FORCE_RCCL");
+  d.dist_columns = on("HITL_DIST_COLUMNS");
   g_dev = d;
   roctx_resolve(on("HITL_ROCTX"));
 }
+}  // namespace hitl
 
+// Test hook (declared in hitl_host.h, exported, not part of the C ABI of include/hitl_gpu.h): sets one of the DevSwitches
+// test fields for every solver created afterwards in this process; name == nullptr clears all of them.  Returns 0, or -1 for
+// an unknown name.
+extern "C" int hitl_test_set_switch(const char* name, long long value) {
+  using namespace hitl;
+  if (name == nullptr) { g_test_hooks = DevSwitches(); return 0; }
+  const std::string k(name);
+  DevSwitches& d = g_test_hooks;
+  if (k == "cr_legacy") d.cr_legacy = value != 0;
+  else if (k == "cr_unfused_build") d.cr_unfused_build = value != 0;
+  else if (k == "stf_addr64") d.stf_addr64 = value != 0;
+  else if (k == "device_lm") d.device_lm = value != 0;
+  else if (k == "lm_ahead") d.lm_ahead = (int)std::max(1ll, std::min(16ll, value));
+  else if (k == "kd_cap") d.kd_cap = (int)std::max(0ll, value);
+  else if (k == "kd_redo_cap") d.kd_redo_cap = (int)std::max(1ll, std::min((long long)(1 << 18), value));
+  else if (k == "cand_tf_check") d.cand_tf_check = value != 0;
+  else if (k == "cand_tile_bytes") d.cand_tile_bytes = (size_t)std::max(1ll, value);
+  else return -1;
+  return 0;
+}
+
+namespace hitl {
 static RoctxApi g_roctx;
 const RoctxApi& roctx_api() { return g_roctx; }
 void roctx_resolve(bool enable) {
@@ -700,7 +691,7 @@ int hitl_solver_create(const hitl_options* opt, hitl_solver** out) {
   s->device = o.device;
   auto bail = [&](int code, const std::string& m) { hitl_solver_destroy(s); return fail(code, m); };
   if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) return bail(HITL_ERR_HIP, "hipStreamCreate failed");
-  for (hipEvent_t* e : {&s->ev0, &s->ev1, &s->ev2, &s->ev3, &s->ev_sync})
+  for (hipEvent_t* e : {&s->ev0, &s->ev1, &s->ev2, &s->ev3})
     if (hipEventCreate(e) != hipSuccess) return bail(HITL_ERR_HIP, "hipEventCreate failed");
   if (hipHostMalloc((void**)&s->h_scalars, sizeof(double) * (kNumScalars + 8)) != hipSuccess) return bail(HITL_ERR_HIP, "hipHostMalloc failed");
   std::memset(s->h_scalars, 0, sizeof(double) * (kNumScalars + 8));
@@ -747,7 +738,7 @@ void hitl_solver_destroy(hitl_solver* s) {
   s->comm_send.release(); s->comm_recv.release(); s->fixed.release(); s->if_cols.release(); s->halo_idx.release();
   s->iface_dev.release(); s->rhsN.release(); s->zN.release(); s->coef_dev.release(); s->halo_val.release(); s->halo_sc.release();
   if (s->h_scalars) (void)hipHostFree(s->h_scalars);
-  for (hipEvent_t e : {s->ev0, s->ev1, s->ev2, s->ev3, s->ev_sync}) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : {s->ev0, s->ev1, s->ev2, s->ev3}) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : s->lm_events) if (e) (void)hipEventDestroy(e);
   s->lm_dev.release();
   if (s->stream) (void)hipStreamDestroy(s->stream);

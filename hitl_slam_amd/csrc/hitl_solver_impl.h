@@ -16,7 +16,7 @@ struct hitl_solver {
   hitl_options opt;
   int device = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr, ev_sync = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
   bool staging_queued = false;  // copies out of the pinned staging buffers (setup_factors, the start state) may still be in flight
   int64_t lin_launches = 0;     // linearisations queued so far (every 4th is bracketed by events at timing_level 1)
   bool lin_timed = false;       // the linearisation in flight is bracketed
@@ -117,6 +117,10 @@ struct hitl_solver {
   DevArray<uint16_t> d_cand_table;
   DevArray<float4> kd_pts;                     // opt-in (kd_tree_search): every scan in KD in-order layout
   DevArray<uint32_t> kd_meta;                  //   original index | split plane << 16
+  double prepare_pcie_bytes = 0.0;             // host -> device bytes of the last prepare() (factor tables): hitl_summary.pcie_bytes
+  int cu_count = 256;                          // compute units of the device
+  DevArray<char> stf_pose_recs;                // per-pose descriptor records of the half-wave linearisation (k_linearize_stf_r)
+  int64_t stf_pose_recs_of = -1;               //   correspondence-set generation they belong to
   bool kd_full_depth = false;                  //   a walk on this map once needed more frames than the fast attempt provisions: full-depth stacks from then on
   DevArray<int> d_kd_ovf;                      //   k_match_kd_tgt: [0] = walks that overflowed the fast frame stack, [1 ..] = their (candidate, point) list
   bool kd_built = false;                       //   trees belong to the resident map
@@ -128,18 +132,6 @@ struct hitl_solver {
   int adj_window = 0, adj_slots = 0;
   std::vector<std::pair<int, int>> h_adj;
   int min_band_poses = 1;                      // lower bound of the pose band (a submap rank: the interface width of the whole partition)
-  DevArray<int> stf_step_off;                  // persistent linearisation (k_linearize_stf_p): first step of every pose, [n] = number of steps
-  DevArray<char> stf_steps;                    //   the step records
-  int64_t stf_steps_of = -1;                   //   correspondence-set generation the table belongs to
-  int cu_count = 256;                          // compute units of the device (grid of the persistent kernels)
-  DevArray<char> stf_pose_recs;                // per-pose descriptor records of the half-wave linearisation (k_linearize_stf_r)
-  int64_t stf_pose_recs_of = -1;               //   correspondence-set generation they belong to
-  DevArray<char> stf_recs;                     // stream linearisation (k_linearize_stf_s): one record per pair
-  DevArray<int> stf_max_len;                   //   largest match count of a pair (device scalar)
-  DevArray<int> stf_wave_cnt, stf_wave_off;    //   pairs per wave, first record of every wave
-  int stf_waves = 0;                           //   waves the records are laid out for
-  int64_t stf_recs_of = -1;                    //   correspondence-set generation the records belong to
-  bool stf_stream_fits = false;                //   every pair of that set fits the kernel's registers
   DevArray<double> pairM;                      // opt-in (stf_moments): 2 x 15 moments per pair
   int64_t moments_of = -1;                     // correspondence-set generation the moments belong to
   int64_t corr_generation = 0;                 // bumped whenever the pair tables change
@@ -200,13 +192,6 @@ struct LinResult { double cost, gmax; float stf_ms; int timed; };
 static inline double angle_mod(double a) {  // shared/math/util.h:433-439
   return a - 6.28318530717958647692 * std::rint(a / 6.28318530717958647692);
 }
-
-// which linearisation kernel: HITL_STF_VARIANT 0 / 500 = the half-wave kernel (default), 1..99 = its other instantiations,
-// 100..199 = one wave per pair / one pose per workgroup, 300 = one wave per workgroup streaming its own run of pairs,
-// 400 = persistent workgroups over a step table.  The three round-4 kernels are measured alternatives (profiles/ROUND_LOG.md);
-// all are held to the oracle by tests/test_gpu_edge.py::test_linearisation_kernels_on_awkward_pair_lists
-static inline bool stf_steps_apply(const hitl_solver* s) { return s->max_scan <= 2048 && dev_switches().stf_variant == 400; }
-static inline bool stf_stream_apply(const hitl_solver* s) { return s->max_scan <= 1024 && dev_switches().stf_variant == 300; }
 
 // hitl_solver.cpp
 int build_pair_structures(hitl_solver* s);

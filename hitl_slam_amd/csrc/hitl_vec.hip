@@ -261,7 +261,7 @@ void launch_spmv_residual_step_lm(hipStream_t st, int n_poses, int npad, const F
 // The decision of one Levenberg-Marquardt iteration on the device (round 3; until round 2 the host took it after a
 // synchronisation, which left the GPU idle for ~40 us per iteration).  Ceres' trust-region rules as restated in SURVEY.md
 // A.4 / DESIGN.md section 2, the same statements in the same order as the host loop of lm_solve (which remains for the
-// submap and off-band paths, and is the default: HITL_DEVICE_LM=1 selects this one).  The per-workgroup partial sums are added in index
+// submap and off-band paths, and is the default: the test hook device_lm selects this one).  The per-workgroup partial sums are added in index
 // order, one sequence per lane -- the same order the host used, so both loops take bit-identical decisions.
 // ---------------------------------------------------------------------------------------------------------------------
 // The scalars a submap rank contributes to the exchange that ends an LM iteration -- (dt.rhs, dt.q, |step|^2, |x|^2, bad,

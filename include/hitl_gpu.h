@@ -162,7 +162,14 @@ typedef struct hitl_summary {
    * last super-block, one chain of 2 * world_size separator blocks: needs every rank but the last to own a multiple of the
    * pose band -- hitl_partition_range_aligned); 3 = distributed PCG (pose pairs outside the band). */
   double submap_linear_solver;
-  double reserved[5];
+  /* bytes this solve moved (the counterpart of the reference's FunctionTimer / summary prints, JointOptimization.cpp:1158-1202;
+   * SURVEY.md 5.1 "per-phase ms, iterations, CG iterations, bytes moved").  hbm_bytes: what the solve's kernels stream through
+   * device memory, counted from the array sizes each launch reads and writes once (compulsory bytes of this layout; the PMC
+   * counters of profiles/ sit within a few per cent of it); pcie_bytes: host <-> device copies and pinned-memory writes inside
+   * hitl_solver_solve (poses in and out, factor tables, the per-iteration partial sums). */
+  double hbm_bytes;
+  double pcie_bytes;
+  double reserved[3];
 } hitl_summary;
 
 typedef struct hitl_solver hitl_solver;   /* opaque; owns device memory */
@@ -177,7 +184,8 @@ void hitl_solver_destroy(hitl_solver*);
 
 /* Replaces: the hand-off of robot_frame_point_clouds_, robot_frame_normal_clouds_ and
  * covariances_ (HitLSLAM.cpp:450-454; JointOptimization.h:62-71) and BuildKDTrees
- * (JointOptimization.cpp:514-537; no tree is built -- matching is brute force in LDS).
+ * (JointOptimization.cpp:514-537: with kd_tree_search = 1, the default, every scan's median-split tree is built on the
+ * device by the first hitl_solver_find_correspondences after a map load and kept until the next set_map).
  * SoA robot-frame scans: obs_offset has n_poses+1 entries; cov9 (n_poses*9) may be NULL.
  * Arrays are copied to the device; the caller keeps ownership.  In a multi-GPU solver
  * every rank passes the WHOLE map's obs_offset but may pass scan data only for the poses

@@ -20,6 +20,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture
+def switches():
+    """Test hooks of libhitlgpu.so (hitl_test_set_switch, csrc/hitl_host.h): `switches(stf_addr64=1, kd_cap=1)` sets them for
+    the solvers the test creates afterwards; all are cleared when the test ends."""
+    import hitl_slam_amd as H
+
+    def setter(**kw):
+        for k, v in kw.items():
+            H.set_test_switch(k, v)
+    yield setter
+    H.set_test_switch(None)
+
+
 @pytest.fixture(scope="session", autouse=True)
 def _native_built():
     """Build the oracle and the synthetic-map tool (gcc, seconds).  libhitlgpu.so is built by

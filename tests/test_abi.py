@@ -39,9 +39,10 @@ def test_struct_layout_matches_ctypes_mirror(lib):
 #include <stddef.h>
 #include "hitl_gpu.h"
 int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(hitl_human_constraint_t), sizeof(hitl_options), sizeof(hitl_summary),
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(hitl_human_constraint_t), sizeof(hitl_options), sizeof(hitl_summary),
          offsetof(hitl_options, function_tolerance), offsetof(hitl_options, rccl_unique_id),
-         offsetof(hitl_summary, initial_cost), offsetof(hitl_summary, linearize_calls));
+         offsetof(hitl_summary, initial_cost), offsetof(hitl_summary, linearize_calls),
+         offsetof(hitl_summary, hbm_bytes), offsetof(hitl_summary, pcie_bytes));
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as d:
@@ -56,6 +57,7 @@ int main(void) {
     assert got[4] == abi.Options.rccl_unique_id.offset
     assert got[5] == abi.Summary.initial_cost.offset
     assert got[6] == abi.Summary.linearize_calls.offset
+    assert got[7] == abi.Summary.hbm_bytes.offset and got[8] == abi.Summary.pcie_bytes.offset
 
 
 def test_defaults_agree_between_c_and_python(lib):

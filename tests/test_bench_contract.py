@@ -69,22 +69,55 @@ def test_bench_refuses_a_rank_count_that_differs_from_gpus():
 def test_bench_started_directly_with_gpus_2_launches_two_ranks():
     """`python bench.py --gpus 2 --backend gloo` with no launcher around it: bench.py starts the two ranks itself (children of a
     parent that never touched the GPU), they share this box's GPU over gloo, and the line says what ran: n_gpus = comm_ranks = 2."""
-    r = _run_bench(["--gpus", "2", "--backend", "gloo", "--poses", "6000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+    r = _run_bench(["--gpus", "2", "--backend", "gloo", "--scaling", "weak", "--poses", "6000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(line) == 1
     j = json.loads(line[0])
-    assert j["n_gpus"] == 2 and j["config"]["comm_ranks"] == 2 and j["config"]["ranks_share_gpus"] is True
+    assert j["n_gpus"] == 2 and j["config"]["comm_ranks"] == 2 and j["config"]["ranks_share_gpus"] is True and j["scaling"] == "weak"
     assert j["config"]["n_poses_total"] == 12000 and j["lm_iterations_per_resolve"] > 0 and j["value"] > 0
     # the cut (6000) is a multiple of the pose band: the ranks' linear solves take the separator form; the interface-column form
     # (rounds 2-3, HITL_DIST_COLUMNS=1) solves the same systems: same LM path
     assert j["config"]["submap_linear_solver"] == "separators" and j["config"]["cuts"] == [0, 6000, 12000]
-    r2 = _run_bench(["--gpus", "2", "--backend", "gloo", "--poses", "6000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+    r2 = _run_bench(["--gpus", "2", "--backend", "gloo", "--scaling", "weak", "--poses", "6000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
                     {"HITL_DIST_COLUMNS": "1"})
     assert r2.returncode == 0, r2.stderr[-2000:]
     j2 = json.loads([ln for ln in r2.stdout.splitlines() if ln.startswith("{")][0])
     assert j2["config"]["submap_linear_solver"] == "interface columns"
     assert j2["lm_iterations_per_resolve"] == j["lm_iterations_per_resolve"] and abs(j2["final_cost"] - j["final_cost"]) <= 1e-9 * j["final_cost"]
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_defaults_to_the_named_map_split_in_two():
+    """without --scaling, N > 1 ranks split the SAME map (BASELINE configs[3]: the 50k map on 4 GPUs; here a
+    6000-pose stand-in on two ranks sharing the box's GPU): "scaling": "strong", n_poses_total = the map's poses, and the LM path
+    of the split solve is the single-GPU one (one global LM loop, exact separator solve)."""
+    r = _run_bench(["--gpus", "2", "--backend", "gloo", "--poses", "6000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert j["scaling"] == "strong" and j["n_gpus"] == 2 and j["config"]["comm_ranks"] == 2
+    assert j["config"]["n_poses_total"] == 6000 and j["config"]["cuts"][0] == 0 and j["config"]["cuts"][-1] == 6000
+    assert j["config"]["submap_linear_solver"] == "separators"
+    r1 = _run_bench(["--gpus", "1", "--poses", "6000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    j1 = json.loads([ln for ln in r1.stdout.splitlines() if ln.startswith("{")][0])
+    assert j1["scaling"] == "weak" and j1["config"]["n_poses_total"] == 6000
+    assert j1["lm_iterations_per_resolve"] == j["lm_iterations_per_resolve"] and abs(j1["final_cost"] - j["final_cost"]) <= 1e-7 * j1["final_cost"]
+
+
+def test_bench_defaults_name_baseline_configs():
+    """What `--gpus N` runs without further flags (parsed from bench.py's own tables; no GPU): N = 1, 2, 4 -> the 50k x 400 map
+    (configs[3]), N = 8 -> the 200k x 512 map (configs[4]); N > 1 splits that map (strong)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert b.WORKLOADS["c4"]["poses"] == 50000 and b.WORKLOADS["c4"]["obs"] == 400 and b.WORKLOADS["c4"]["groups"] == 50
+    assert b.WORKLOADS["c5"]["poses"] == 200000 and b.WORKLOADS["c5"]["obs"] == 512 and b.WORKLOADS["c5"]["groups"] == 200
+    assert b.WORKLOADS["c2"]["poses"] == 1000 and b.WORKLOADS["c2"]["obs"] == 360
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'args.workload = "c5" if args.gpus == 8 else "c4"' in src
+    assert 'args.scaling = "strong" if args.gpus > 1 else "weak"' in src
 
 
 @pytest.mark.gpu

@@ -78,9 +78,9 @@ def test_full_cycle_parity_other_maps(seed):
     g, o = Solver(), O.OracleSolver()
     sc2.prob.load(g)
     sc2.prob.load(o)
-    rg = g.run_correction(4, sc2.selected, sc2.poses, sc2.cov, [])
+    rg = g.run_correction(4, sc2.selected, sc2.poses, sc2.cov, [], reproject=True)
     ro = o.run_correction(4, sc2.selected, sc2.poses, sc2.cov, [])
-    assert rg["status"] == ro["status"] == "ok"
+    assert rg["status"] == ro["status"] == "ok" and "world" not in ro          # re-projection is opt-in (160 MB at 20 M observations)
     assert rg["order"]["bounds"] == ro["order"]["bounds"] and np.array_equal(rg["order"]["corrected"], ro["order"]["corrected"])
     d = rg["poses"].astype(np.float64) - ro["poses"]
     d[:, 2] = np.angle(np.exp(1j * d[:, 2]))
@@ -89,7 +89,18 @@ def test_full_cycle_parity_other_maps(seed):
     # bit for bit the pageable-memory form at the same poses
     wx, wy = g.transform_scans(rg["poses"])
     assert np.array_equal(rg["world"][0].view(np.uint32), wx.view(np.uint32)) and np.array_equal(rg["world"][1].view(np.uint32), wy.view(np.uint32))
+    # a LARGER map loaded into the same solver: the page-locked buffers are sized by the map they were allocated for (ADVICE r4:
+    # they used to be reused unconditionally -- a heap overflow); set_map drops them and empties the views handed out before
+    old_view = rg["world"][0]
+    from tests.conftest import Problem
+    big = Problem(130, 128, seed=seed + 7, groups=0)
+    big.load(g)
+    assert old_view.size == 0
+    wx3, wy3 = g.world_clouds(big.init)
+    ex3, ey3 = g.transform_scans(big.init)
+    assert wx3.size == ex3.size > wx.size and np.array_equal(wx3.view(np.uint32), ex3.view(np.uint32)) and np.array_equal(wy3.view(np.uint32), ey3.view(np.uint32))
     g.close(); o.close()
+    assert wx3.size == 0            # close() frees the buffers: the views it handed out are emptied, not left dangling
 
 
 @pytest.mark.parametrize("ctype", [2, 4, 5, 6])

@@ -154,14 +154,14 @@ def test_long_scans():
 
 
 @pytest.mark.parametrize("obs, addr64", [(3000, False), (700, True), (3000, True), (5000, True)])
-def test_linearisation_layout_variants(obs, addr64, monkeypatch):
+def test_linearisation_layout_variants(obs, addr64, switches):
     """The instantiations of k_linearize_stf the default-size tests never reach: the fp32 source scan in LDS (2049-4096 points
-    per scan), and the 64-bit addressing path (arrays beyond 4 GB; forced here through HITL_STF_ADDR64) in all three source
-    layouts.  One linearisation against the oracle plus the whole solve."""
+    per scan), and the 64-bit addressing path (arrays beyond 4 GB; forced here through the test hook stf_addr64) in all three
+    source layouts.  One linearisation against the oracle plus the whole solve."""
     import hitl_slam_amd as H
     from oracle import hitl_oracle as O
     if addr64:
-        monkeypatch.setenv("HITL_STF_ADDR64", "1")
+        switches(stf_addr64=1)
     prob = Problem(10, obs, ppf=10, groups=1, kind=4, window=2)
     corr = oracle_corr(prob, window=2)
     g, o = prob.load(H.Solver(), corr=corr), prob.load(O.OracleSolver(), corr=corr)
@@ -251,17 +251,18 @@ def _random_corr(prob, pairs, rng):
     return ps, pt, mo, i0, i1
 
 
-@pytest.mark.parametrize("variant", ["0", "300", "400", "106"])
-def test_linearisation_kernels_on_awkward_pair_lists(variant, monkeypatch):
-    """Round 4's linearisation kernels against the oracle on the shapes their pipelines have to get right: pairs of 1, 63, 64, 65,
-    127, 128, 129, 256, 383, 384, 385 and 511 matches (partial trip only / full trips only / both), a pose without pairs in the
-    middle of a run, a pose with more pairs than the tail buffer holds (9 and 14), pairs in both directions of one pose pair, the
-    last pose as a source, and -- one set further down -- a pair of 512 matches, which the stream kernel does not take
-    (the half-wave kernel runs instead).  HITL_STF_VARIANT: 0 = default (the half-wave kernel of rounds 1-3), 300 = stream kernel,
-    400 = persistent workgroups, 106 = one wave per pair and one pose per workgroup."""
+@pytest.mark.parametrize("addr64", [0, 1], ids=["record", "general"])
+def test_linearisation_kernels_on_awkward_pair_lists(addr64, switches):
+    """The two linearisation kernels the library ships -- k_linearize_stf_r (half-waves behind a per-pose record: the default) and
+    the general k_linearize_stf (taken when the arrays outgrow 32-bit offsets; forced by the test hook stf_addr64) -- against the
+    oracle on the shapes their trip loops have to get right: pairs of 1, 63, 64, 65, 127, 128, 129, 256, 383, 384, 385 and 511
+    matches (partial trip only / full trips only / both), a pose without pairs in the middle of a run, a pose with more pairs than
+    the record holds (9 and 14), pairs in both directions of one pose pair, the last pose as a source, and -- one set further
+    down -- a pair of 512 matches."""
     import hitl_slam_amd as H
     from oracle import hitl_oracle as O
-    monkeypatch.setenv("HITL_STF_VARIANT", variant)
+    if addr64:
+        switches(stf_addr64=1)
     prob = Problem(40, 600, ppf=40, groups=1, kind=4, window=3)
     rng = np.random.default_rng(7)
     lens = [1, 63, 64, 65, 127, 128, 129, 256, 383, 384, 385, 511]
@@ -287,37 +288,31 @@ def test_linearisation_kernels_on_awkward_pair_lists(variant, monkeypatch):
         g.close(); o.close()
 
 
+# (environment variables, test hooks): the five variables INTEGRATION.md lists + every hitl_test_set_switch hook, alone and combined
 _SWITCHES = [
-    {}, {"HITL_TIMING": "1"}, {"HITL_EVENT_SYNC": "1"}, {"HITL_CR_LEGACY": "1"}, {"HITL_CR_UNFUSED_BUILD": "1"}, {"HITL_STF_ADDR64": "1"},
-    {"HITL_DEVICE_LM": "1"}, {"HITL_DEVICE_LM": "1", "HITL_LM_AHEAD": "1"}, {"HITL_FORCE_DIST": "1"}, {"HITL_FORCE_DIST": "1", "HITL_DIST_COLUMNS": "1"}, {"HITL_ROCTX": "1"},
-    {"HITL_STF_VARIANT": "500"}, {"HITL_STF_VARIANT": "501"}, {"HITL_STF_VARIANT": "26"}, {"HITL_STF_VARIANT": "106"}, {"HITL_STF_VARIANT": "300"},
-    {"HITL_STF_VARIANT": "300", "HITL_STF_WAVES_PER_CU": "5"}, {"HITL_STF_VARIANT": "400"}, {"HITL_STF_VARIANT": "400", "HITL_STF_WAVES_PER_CU": "2"},
-    {"HITL_STF_VARIANT": "600"}, {"HITL_STF_VARIANT": "700"},
-    {"HITL_KD_BLOCK": "64"}, {"HITL_KD_BLOCK": "128", "HITL_KD_REFILL": "4"}, {"HITL_KD_CAP": "1"}, {"HITL_KD_CAP": "2", "HITL_KD_REDO_CAP": "8"}, {"HITL_KD_FAST": "0"}, {"HITL_KD_FAST": "2", "HITL_KD_CAP": "1"},
-    {"HITL_CAND_TF_CHECK": "1"}, {"HITL_CAND_TF_HOST": "1"},
-    {"HITL_CAND_TILE_BYTES": "200000"}, {"HITL_CR_PLAN": "2,4,0"}, {"HITL_CR_THREADS": "256"},
+    ({}, {}), ({"HITL_TIMING": "1"}, {}), ({"HITL_ROCTX": "1"}, {}), ({"HITL_FORCE_DIST": "1"}, {}), ({"HITL_FORCE_DIST": "1", "HITL_DIST_COLUMNS": "1"}, {}),
+    ({}, {"cr_legacy": 1}), ({}, {"cr_unfused_build": 1}), ({}, {"stf_addr64": 1}), ({}, {"device_lm": 1}), ({}, {"device_lm": 1, "lm_ahead": 1}),
+    ({}, {"kd_cap": 1}), ({}, {"kd_cap": 2, "kd_redo_cap": 8}), ({}, {"cand_tf_check": 1}), ({}, {"cand_tile_bytes": 200000}),
     # several at once: the switches nobody would combine on purpose
-    {"HITL_TIMING": "1", "HITL_EVENT_SYNC": "1", "HITL_CR_UNFUSED_BUILD": "1", "HITL_STF_VARIANT": "300", "HITL_KD_BLOCK": "64", "HITL_KD_CAP": "2",
-     "HITL_CAND_TILE_BYTES": "300000", "HITL_ROCTX": "1"},
-    {"HITL_DEVICE_LM": "1", "HITL_CR_THREADS": "256", "HITL_STF_ADDR64": "1", "HITL_KD_REFILL": "32", "HITL_STF_VARIANT": "500"},
-    {"HITL_CR_LEGACY": "1", "HITL_STF_VARIANT": "400", "HITL_KD_BLOCK": "128", "HITL_EVENT_SYNC": "1"},
-    {"HITL_FORCE_DIST": "1", "HITL_CR_LEGACY": "1"}, {"HITL_FORCE_DIST": "1", "HITL_CR_PLAN": "2,4,0", "HITL_EVENT_SYNC": "1"},
+    ({"HITL_TIMING": "1", "HITL_ROCTX": "1"}, {"cr_unfused_build": 1, "kd_cap": 2, "cand_tile_bytes": 300000}),
+    ({}, {"device_lm": 1, "stf_addr64": 1, "cand_tf_check": 1}),
+    ({"HITL_FORCE_DIST": "1"}, {"cr_legacy": 1}), ({"HITL_FORCE_DIST": "1", "HITL_DIST_COLUMNS": "1"}, {"stf_addr64": 1, "kd_cap": 1}),
 ]
 
 
-@pytest.mark.parametrize("env", _SWITCHES, ids=lambda e: ",".join("%s=%s" % (k[5:], v) for k, v in sorted(e.items())) or "none")
-def test_every_development_switch_still_solves_like_the_oracle(env, monkeypatch):
-    """The HITL_* environment switches of the library (A/B measurement aids, read once at hitl_solver_create):
-    under each of them, and under combinations nobody tests on purpose, the search returns the oracle's index sets and the solve
-    walks the oracle's LM path (a surface nobody tested in combination)."""
+@pytest.mark.parametrize("env, hooks", _SWITCHES,
+                         ids=lambda e: ",".join("%s=%s" % (k.replace("HITL_", ""), v) for k, v in sorted(e.items())) or "-")
+def test_every_switch_still_solves_like_the_oracle(env, hooks, monkeypatch, switches):
+    """The process-wide switches of the library (read once at hitl_solver_create): the five environment
+    variables a maintainer may set and the test hooks that force rarely-taken code paths -- under each of them, and under
+    combinations nobody tests on purpose, the search returns the oracle's index sets and the solve walks the oracle's LM path."""
     import hitl_slam_amd as H
     from oracle import hitl_oracle as O
-    for k in ("HITL_TIMING", "HITL_EVENT_SYNC", "HITL_CR_LEGACY", "HITL_CR_UNFUSED_BUILD", "HITL_STF_ADDR64", "HITL_DEVICE_LM", "HITL_LM_AHEAD",
-              "HITL_FORCE_DIST", "HITL_DIST_COLUMNS", "HITL_ROCTX", "HITL_STF_VARIANT", "HITL_STF_WAVES_PER_CU", "HITL_KD_BLOCK", "HITL_KD_REFILL", "HITL_KD_CAP",
-              "HITL_KD_REDO_CAP", "HITL_KD_FAST", "HITL_CAND_TF_CHECK", "HITL_CAND_TF_HOST", "HITL_CAND_TILE_BYTES", "HITL_CR_PLAN", "HITL_CR_THREADS"):
+    for k in ("HITL_TIMING", "HITL_FORCE_DIST", "HITL_DIST_COLUMNS", "HITL_ROCTX", "HITL_FORCE_RCCL"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
+    switches(**hooks)
     prob = Problem(150, 64, ppf=50, groups=3, kind=0)
     g, o = prob.load(H.Solver()), prob.load(O.OracleSolver())
     g.find_correspondences(prob.init, 3)
@@ -327,3 +322,23 @@ def test_every_development_switch_still_solves_like_the_oracle(env, monkeypatch)
     for mode in (H.MODE_ODOM_HC, H.MODE_JOINT):
         _check(g, o, mode, prob.init)
     g.close(); o.close()
+
+
+def test_summary_reports_the_bytes_a_solve_moved():
+    """hitl_summary.hbm_bytes / pcie_bytes ("per-phase ms, iterations, CG iterations, bytes moved"): counted from the
+    array sizes each launch streams.  Mode C moves at least the scans and the packed match words once per linearisation; mode A
+    (no scan-to-scan factors) moves neither; the host link carries the poses both ways plus a few KB per LM iteration."""
+    import hitl_slam_amd as H
+    prob = Problem(150, 64, ppf=50, groups=3, kind=0)
+    g = prob.load(H.Solver())
+    g.find_correspondences(prob.init, 3)
+    n_pairs, n_matches = g.correspondence_counts()
+    n_obs = int(prob.off[-1])
+    _, sc = g.solve(H.MODE_JOINT, prob.init)
+    _, sa = g.solve(H.MODE_ODOM_HC, prob.init)
+    assert sc.hbm_bytes >= sc.linearize_calls * (16 * n_obs + 4 * n_matches + 112 * n_pairs) > 0
+    assert 0 < sa.hbm_bytes < sa.linearize_calls * 16 * n_obs + sa.iterations * 4000 * prob.n
+    assert sa.hbm_bytes / max(sa.iterations, 1) < sc.hbm_bytes / max(sc.iterations, 1)
+    for sm in (sc, sa):
+        assert 20 * prob.n + 12 * prob.n <= sm.pcie_bytes <= 20 * prob.n + 24 * prob.n + 4096 * (sm.iterations + 4) + 64 * prob.n
+    g.close()

@@ -60,7 +60,7 @@ def test_seeded_problem(n, obs, ppf, window, kind, groups, seed):
 
 def test_solver_paths_agree_over_many_map_sizes(tmp_path):
     """Structural fuzz of the linear solve: the same LM solves (mode A: band of one pose; mode C, window 3) over a few dozen
-    map sizes through (1) the fused cyclic-reduction stages, (2) the level-per-launch kernels (HITL_CR_LEGACY) and (3) the
+    map sizes through (1) the fused cyclic-reduction stages, (2) the level-per-launch kernels (test hook cr_legacy) and (3) the
     submap code path on a single rank (HITL_FORCE_DIST) in both of its forms -- separators (the chain of owned super-blocks with
     its last node kept: the irregular right boundary of every stage's last chunk) and, with HITL_DIST_COLUMNS, interface columns
     (multi-right-hand-side stages, interface system of one rank).  All four
@@ -72,7 +72,7 @@ def test_solver_paths_agree_over_many_map_sizes(tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for tag, extra in (("fused", {}), ("legacy", {"HITL_CR_LEGACY": "1"}), ("dist", {"HITL_FORCE_DIST": "1"}),
+    for tag, extra in (("fused", {}), ("legacy", {"HITL_TEST_SWITCHES": "cr_legacy=1"}), ("dist", {"HITL_FORCE_DIST": "1"}),
                        ("distcols", {"HITL_FORCE_DIST": "1", "HITL_DIST_COLUMNS": "1"})):
         out = str(tmp_path / (tag + ".jsonl"))
         env = dict(os.environ, HITL_SWEEP_QUICK="1", **extra)

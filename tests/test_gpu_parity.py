@@ -338,26 +338,20 @@ def test_submap_solve_through_in_library_rccl_world1(columns):
 
 @pytest.mark.parametrize("late", [0, 1])
 @pytest.mark.parametrize("shape", [(60, 90, 30, 2, 4), (150, 64, 50, 3, 0), (40, 48, 40, 1, 2)])
-def test_device_driven_lm_loop_equals_the_host_driven_one(monkeypatch, shape, late):
+def test_device_driven_lm_loop_equals_the_host_driven_one(switches, shape, late):
     """Round 3: accept / reject / terminate are decided on the device (k_lm_decide) and the host queues iterations ahead.  The
     host-driven loop of rounds 1-2 remains the default (measured 4-8 us per iteration faster: the decision kernel costs what the
-    hidden part of the host's turn-around did not; HITL_DEVICE_LM=1 selects the device-driven loop): both take bit-identical
+    hidden part of the host's turn-around did not; the test hook device_lm selects the device-driven loop): both take bit-identical
     decisions -- same poses to the last bit, same iteration / accepted / rejected counts, same costs, same
     final trust region -- in every mode, for both orders of the tolerance tests, and when the iteration cap ends the solve."""
     import hitl_slam_amd as H
     n, m, ppf, groups, kind = shape
     prob = Problem(n, m, ppf=ppf, groups=groups, kind=kind)
     corr = oracle_corr(prob)
-    # both loops launch the half-wave linearisation kernel (the one that can pick its buffers from the loop state): bit-identical
-    # decisions need the same sums (round 4's alternative kernels add the matches of a pair in another order: last bits)
-    monkeypatch.setenv("HITL_STF_VARIANT", "500")
     for mode, cap in ((0, 100), (1, 100), (2, 100), (2, 3), (2, 1)):
         res = []
         for host in (False, True):
-            if not host:
-                monkeypatch.setenv("HITL_DEVICE_LM", "1")
-            else:
-                monkeypatch.delenv("HITL_DEVICE_LM", raising=False)
+            switches(device_lm=0 if host else 1)
             o = H.default_options()
             o.tolerances_after_accept = late
             o.max_num_iterations = cap
@@ -371,15 +365,13 @@ def test_device_driven_lm_loop_equals_the_host_driven_one(monkeypatch, shape, la
         d, h = res
         assert np.array_equal(d[0].view(np.uint32), h[0].view(np.uint32)) and np.array_equal(d[11].view(np.uint32), h[11].view(np.uint32))
         assert d[1:11] == h[1:11] and d[12:] == h[12:], (mode, cap, d[1:11], h[1:11])
-    monkeypatch.delenv("HITL_DEVICE_LM", raising=False)
-    monkeypatch.delenv("HITL_STF_VARIANT", raising=False)
 
 
 @pytest.mark.parametrize("shape", [(150, 64, 50, 3, 0, 3), (97, 48, 97, 2, 4, 2), (64, 40, 64, 1, 2, 4), (333, 32, 111, 2, 0, 3)])
-def test_first_stage_instantiation_equals_the_separate_build(monkeypatch, shape):
+def test_first_stage_instantiation_equals_the_separate_build(switches, shape):
     """The first fused cyclic-reduction stage of the LM path cuts its tiles and right-hand side from the band rows itself (its own
     instantiation of k_cr_chunk: facts of that stage known at compile time, a register budget for four workgroups per CU).
-    HITL_CR_UNFUSED_BUILD=1 forms the same system with k_build_system and runs the generic instantiation: same arithmetic in the
+    The test hook cr_unfused_build forms the same system with k_build_system and runs the generic instantiation: same arithmetic in the
     same order -- poses to the last bit, same iteration counts and costs, for band widths of 2, 3 and 4 poses (B = 6, 9, 12)."""
     import hitl_slam_amd as H
     n, m, ppf, groups, kind, window = shape
@@ -392,10 +384,7 @@ def test_first_stage_instantiation_equals_the_separate_build(monkeypatch, shape)
     for mode in (0, 2):
         res = []
         for unfused in (False, True):
-            if unfused:
-                monkeypatch.setenv("HITL_CR_UNFUSED_BUILD", "1")
-            else:
-                monkeypatch.delenv("HITL_CR_UNFUSED_BUILD", raising=False)
+            switches(cr_unfused_build=1 if unfused else 0)
             s = H.Solver()               # the switches are read at create
             prob.load(s, corr=corr)
             p, sm = s.solve(mode, prob.init)
@@ -406,7 +395,6 @@ def test_first_stage_instantiation_equals_the_separate_build(monkeypatch, shape)
         assert f[1:] == u[1:], (mode, f[1:], u[1:])
         if mode == 2:
             assert f[6] == window
-    monkeypatch.delenv("HITL_CR_UNFUSED_BUILD", raising=False)
 
 
 def test_timing_levels_do_not_change_results(small_problem):
@@ -534,7 +522,7 @@ def test_kd_trees_equal_the_reference_build():
 
 
 @pytest.mark.parametrize("redo_cap", [None, 16])
-def test_kd_search_when_the_fast_frame_stack_overflows(monkeypatch, redo_cap):
+def test_kd_search_when_the_fast_frame_stack_overflows(switches, redo_cap):
     """The target-major walk kernel runs with a frame stack of 5 entries per lane (that is what lets 6 workgroups share a CU);
     a walk that needs more is listed and repeated by k_match_kd_redo (one thread per walk, full depth), and if even the list
     overflows the whole search is repeated with stacks as deep as the trees.  Forced here with ONE entry per lane (thousands of
@@ -542,17 +530,15 @@ def test_kd_search_when_the_fast_frame_stack_overflows(monkeypatch, redo_cap):
     import hitl_slam_amd as H
     prob = Problem(60, 128, ppf=30)
     want = oracle_corr(prob, window=3, method=1)
-    monkeypatch.setenv("HITL_KD_CAP", "1")
+    switches(kd_cap=1)
     if redo_cap:
-        monkeypatch.setenv("HITL_KD_REDO_CAP", str(redo_cap))
+        switches(kd_redo_cap=redo_cap)
     g = prob.load(H.Solver())
     for _ in range(2):                       # with the tiny list: the second call goes straight to the full-depth stacks
         g.find_correspondences(prob.init, 3)
         for a, b in zip(g.get_correspondences(), want):
             assert np.array_equal(a, b)
     g.close()
-    monkeypatch.delenv("HITL_KD_CAP", raising=False)
-    monkeypatch.delenv("HITL_KD_REDO_CAP", raising=False)
 
 
 def test_kd_tree_search_on_ragged_and_empty_scans():
@@ -606,7 +592,7 @@ def test_device_built_pair_tables_equal_the_host_built_ones(shape):
 
 
 @pytest.mark.parametrize("kd", [0, 1])
-def test_tiled_candidate_table_gives_the_same_sets(monkeypatch, kd):
+def test_tiled_candidate_table_gives_the_same_sets(switches, kd):
     """Windows wider than the band (the reference's all-pairs search above all) are matched tile by tile over the source
     poses so that the candidate table stays inside a budget whatever the map.  With the budget forced down to a handful of
     poses per tile the index sets, and the solve on them, are those of the single-tile run and of the oracle."""
@@ -616,10 +602,7 @@ def test_tiled_candidate_table_gives_the_same_sets(monkeypatch, kd):
     opt.kd_tree_search = kd
     sets = {}
     for budget in (None, 7 * 59 * 90 * 2, 1):            # one tile / 7 poses per tile / one pose per tile
-        if budget is None:
-            monkeypatch.delenv("HITL_CAND_TILE_BYTES", raising=False)
-        else:
-            monkeypatch.setenv("HITL_CAND_TILE_BYTES", str(budget))
+        switches(cand_tile_bytes=(4 << 30) if budget is None else budget)
         g = prob.load(H.Solver(opt))
         for window in (0, 6):
             g.find_correspondences(prob.init, window)

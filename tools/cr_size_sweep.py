@@ -1,5 +1,5 @@
 """Development helper: LM solves over many map sizes, results as JSON lines (n, mode, iterations, termination, cost).
-Run once as is and once with HITL_CR_LEGACY=1 (level-per-launch cyclic reduction) and diff: the two paths must agree on
+Run once as is and once with HITL_TEST_SWITCHES=cr_legacy=1 (the library's test hook: level-per-launch cyclic reduction) and diff: the two paths must agree on
 iteration count and termination for every size (structural edge cases of the fused stages show up as FAILURE or as a
 different iteration count).  usage: cr_size_sweep.py out.jsonl"""
 import json, os, sys
@@ -8,6 +8,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import hitl_slam_amd as H
 from conftest import Problem
+from hitl_slam_amd.api import apply_test_switches_from_env
+apply_test_switches_from_env()          # HITL_TEST_SWITCHES="cr_legacy=1": read by this script, not by the library
 
 rng = np.random.default_rng(7)
 sizes_a = sorted(set(list(range(1000, 1100, 3)) + list(range(16370, 16430, 5)) + list(range(20460, 20520, 5)) + list(range(32760, 33300, 37))

@@ -1,4 +1,5 @@
-cd "${GRAFT_REPO_ROOT:-/root/repo}"
+#!/bin/bash
+cd "${GRAFT_REPO_ROOT:-/root/repo}" || exit 1
 for cfg in "plain" "sep" "cols" "sep_rccl" "cols_rccl"; do
   unset HITL_FORCE_DIST HITL_DIST_COLUMNS HITL_FORCE_RCCL
   case $cfg in

@@ -1,4 +1,5 @@
-cd "${GRAFT_REPO_ROOT:-/root/repo}"
+#!/bin/bash
+cd "${GRAFT_REPO_ROOT:-/root/repo}" || exit 1
 export TMPDIR=/tmp
 HITL_TIMING=1 REPS=3 python3 tools/dev/search_time.py 2>&1 | tail -40
 rm -rf gpurun_out/searchtr; mkdir -p gpurun_out/searchtr
