@@ -121,17 +121,11 @@ class SolverBase(object):
             self._h = C.c_void_p()
 
     def _drop_world_buf(self):
-        """Frees the page-locked display buffers of world_clouds().  Views handed out earlier point into them: they are
-        shrunk to length 0 first, so that a stale view cannot read (or write) freed memory."""
+        """Frees the page-locked staging buffers of world_clouds() (set_map: they are sized by the map; close)."""
         buf = getattr(self, "_world_buf", None)
         if buf is not None and hasattr(self, "host_free"):
-            for v in getattr(self, "_world_views", ()):
-                try:
-                    v.resize(0, refcheck=False)
-                except Exception:
-                    pass
             self.host_free(buf)
-        self._world_buf, self._world_buf_len, self._world_views = None, 0, ()
+        self._world_buf, self._world_buf_len = None, 0
 
     def __del__(self):
         try:
@@ -358,18 +352,19 @@ class SolverBase(object):
             out["world"] = self.world_clouds(poses)
         return out
 
-    def world_clouds(self, poses_xyt):
+    def world_clouds(self, poses_xyt, copy=True):
         """The display clouds (HitLSLAM::transformPointCloudsToWorldFrame): (world_x, world_y).  hitl_slam_amd.Solver lands
-        them in page-locked buffers it keeps: the returned arrays are VIEWS, overwritten by the next call and emptied
-        (length 0) by set_map() / close(), which free the buffers; copy them to keep them.  The base form is transform_scans."""
+        them in page-locked staging buffers it keeps (sized by the resident map, dropped by set_map() / close()) and
+        returns COPIES the caller owns.  copy=False returns views into the staging buffers instead (no 8-byte-per-observation
+        copy): valid only until the next world_clouds() / set_map() / close() of this solver -- a view kept longer reads freed
+        memory.  The base form is transform_scans."""
         if hasattr(self, "transform_scans_pinned"):
             n_obs = int(self.obs_offset[-1])
             if getattr(self, "_world_buf", None) is not None and getattr(self, "_world_buf_len", 0) < n_obs:
                 self._drop_world_buf()                             # never write n_obs floats into a smaller block
             wx, wy, self._world_buf = self.transform_scans_pinned(poses_xyt, getattr(self, "_world_buf", None))
             self._world_buf_len = max(getattr(self, "_world_buf_len", 0), n_obs)
-            self._world_views = (wx, wy)
-            return wx, wy
+            return (np.array(wx), np.array(wy)) if copy else (wx, wy)
         return self.transform_scans(poses_xyt)
 
     def pose_covariances(self, mode, poses_xyt):

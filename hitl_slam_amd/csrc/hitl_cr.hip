@@ -697,12 +697,18 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 // Development build (-DHITL_CR_PROBE): thread 0 of one workgroup per stage records the shader clock at the phase boundaries of
 // k_cr_chunk; hitl_cr_probe_dump() prints the differences.  Not compiled into the shipped library.
 #ifdef HITL_CR_PROBE
+__device__ unsigned long long g_seq_probe[4 * 4096];       // k_cr_seq: per workgroup (start, after staging, wave 0 done, hardware id), 100 MHz clock
+#define SEQ_PROBE(slot, val) do { if (lane == 0 && wave == 0 && blockIdx.x < 4096) g_seq_probe[4 * blockIdx.x + (slot)] = (val); } while (0)
+__device__ unsigned long long g_seq_node_probe[16];       // shader clock at the phase boundaries of ONE node (workgroup 500, wave 0, u = 3)
+#define SEQ_T(slot) do { if (probe_on) { __builtin_amdgcn_s_waitcnt(0); if (lane == 0) g_seq_node_probe[slot] = clock64(); } } while (0)
 __device__ unsigned long long g_cr_probe[3 * 64];
 #define CR_PROBE(slot) do { if (tid == 0 && blockIdx.x == (gridDim.x > 600 ? 600 : gridDim.x / 2)) g_cr_probe[(sg.top ? 2 : (sg.S == 1 ? 0 : 1)) * 64 + (slot)] = clock64(); } while (0)
 #define CR_PROBE_IN(slot) do { if (s == 4 && q == wave) { __builtin_amdgcn_s_waitcnt(0); CR_PROBE(slot); } } while (0)
 #else
 #define CR_PROBE(slot) do { } while (0)
 #define CR_PROBE_IN(slot) do { } while (0)
+#define SEQ_PROBE(slot, val) do { } while (0)
+#define SEQ_T(slot) do { } while (0)
 #endif
 
 // KIND 1: the first stage of the LM path's factor-solve (tiles cut from the band rows, one right-hand side, no previous stage,
@@ -1240,6 +1246,499 @@ __global__ __launch_bounds__(512) void k_cr_chunk_fwd(CrView cr, CrStage sg, con
     }
 }
 
+// ===========================================================================================
+// First stage of the LM path's factor-solve in TWO-WAY SEQUENTIAL order (round 5).
+//
+// The cyclic-reduction stage above eliminates a chunk's M - 1 interior nodes level by level: log2 M levels, a workgroup
+// barrier and a survivor pass per level, and from the second level on most of the workgroup's waves wait.  At the FIRST stage
+// (16 667 super-blocks on 1024 SIMDs) that is not a latency problem but a throughput one: 49 us for 15 600 node eliminations.
+// Here the same eliminations -- the same [D | I | L_u | L_b^T] Gauss-Jordan, the same three products on the matrix pipe, the same
+// Dinv / Gl / Gr per node, the same contributions handed to the next stage -- run in another ORDER: the chunk's interior nodes
+// 1 .. U are a chain; wave 0 eliminates it from the left end (node u with neighbours a = the chunk's left boundary and
+// b = u + 1: the fill F_u = coupling u <-> left boundary travels along), wave 1 from the right end (neighbours a = u - 1 and
+// b = the right boundary, fill E_u), and wave 0 finishes with the node in the middle, whose two neighbours are the boundaries.
+// No barrier but the one before the middle node, no idle wave, products accumulate in the matrix pipe's registers, and
+// a workgroup is two waves: every chunk of the map is resident at once.  Tiles are cut from the staged band rows one node
+// ahead of their use instead of all up front (LDS: the rows + seven tiles per wave).
+// Back-substitution (k_cr_seq_back): x_mid from the two boundaries, then the two half-chains outwards, one step per node.
+// The elimination tree differs from the balanced one, so Dinv / Gl / Gr of a node mean "towards ITS neighbours a and b" of this
+// order: only k_cr_seq_back reads them (selected inversion and the PCG preconditioner factorise through the stages above).
+// ===========================================================================================
+// (every LDS pointer of this kernel carries its address space in its type: a pointer picked at run time -- tD[cur] -- would otherwise
+// decay to a generic one, whose loads are FLAT instructions that wait for the node's global stores as well)
+typedef __attribute__((address_space(3))) double ldsd;
+
+template <int B>
+struct SeqNodeOut { v4f64 c1, c2, c3; double cw; };
+
+// Tiles are cut from the staged band rows through per-lane DESCRIPTORS formed once per kernel: which words of the records of a
+// node's own poses (and of the super-block on its left) an entry needs do not depend on the node, only their common base does.  A
+// cut is then a handful of independent LDS reads and multiplications per entry -- k_build_system's arithmetic in its order (value
+// * (scale_a * scale_b) for D, (value * scale_a) * scale_b for L, the LM diagonal on top), no index arithmetic, no branches.
+// Records of poses beyond the end of the map are staged as constant poses, so there is no bounds test either.
+// D entries are cut in the matrix pipe's result layout (lane l: rows (l >> 4) + 4 rg of column l & 15): the product that is
+// subtracted from them sits in exactly those registers.  L entries in linear order (entry e = lane + 64 t).
+template <int B>
+struct SeqCutDesc {
+  static constexpr int NT = (B * B + WAVE - 1) / WAVE;
+  int dh[3], dsa[3], dsb[3];      // D, rg = 0..2: value word, scale words of the row / column pose (flag word = scale word - comp + 3 -> dfa, dfb)
+  int dfa[3], dfb[3];
+  int lh[NT], lsa[NT], ls3[NT], lfa[NT], lf3[NT];
+  unsigned dmask;                 // bit rg: entry exists; bit 4 + rg: it is a diagonal entry
+  unsigned lmask;                 // bit t: entry exists; bit 8 + t: inside the band (d <= Wb)
+};
+
+template <int B>
+__device__ __forceinline__ void seq_cut_desc(SeqCutDesc<B>& q, int lane) {
+  constexpr int Wb = B / 3, rl = (Wb + 1) * 9 + 4, so = (Wb + 1) * 9, BB = B * B;
+  const int mr = lane & 15, mk = lane >> 4;
+  q.dmask = 0; q.lmask = 0;
+#pragma unroll
+  for (int rg = 0; rg < 3; ++rg) {
+    const int a = mk + 4 * rg, b = mr;
+    const bool ok = a < B && b < B;
+    const int ac = ok ? a : 0, bc = ok ? b : 0;
+    const int pa = ac / 3, ca = ac % 3, pb = bc / 3, cb = bc % 3;
+    q.dh[rg] = (pb >= pa) ? pa * rl + (pb - pa) * 9 + ca * 3 + cb : pb * rl + (pa - pb) * 9 + cb * 3 + ca;
+    q.dsa[rg] = pa * rl + so + ca; q.dsb[rg] = pb * rl + so + cb;
+    q.dfa[rg] = pa * rl + so + 3; q.dfb[rg] = pb * rl + so + 3;
+    if (ok) q.dmask |= 1u << rg;
+    if (ok && a == b) q.dmask |= 16u << rg;
+  }
+#pragma unroll
+  for (int t = 0; t < SeqCutDesc<B>::NT; ++t) {
+    const int e = lane + WAVE * t;
+    const bool ok = e < BB;
+    const int ec = ok ? e : 0;
+    const int a = ec / B, b = ec % B, pa = a / 3, ca = a % 3, pb = b / 3, cb = b % 3;
+    const int d = Wb + pa - pb;                                   // pose distance row pose (this node) - column pose (the node on the left)
+    const bool band = d <= Wb;
+    q.lh[t] = (pb - Wb) * rl + (band ? d : 0) * 9 + cb * 3 + ca;
+    q.lsa[t] = pa * rl + so + ca; q.lfa[t] = pa * rl + so + 3;
+    q.ls3[t] = (pb - Wb) * rl + so + cb; q.lf3[t] = (pb - Wb) * rl + so + 3;
+    if (ok) q.lmask |= 1u << t;
+    if (ok && band) q.lmask |= 256u << t;
+  }
+}
+
+// D of the node whose first pose record sits at nb, in the result layout: d[rg] (0 where the lane has no entry)
+template <int B>
+__device__ __forceinline__ void seq_cut_d(const SeqCutDesc<B>& q, const ldsd* nb, double inv_mu, double min_diag, double max_diag, double (&d)[3]) {
+  double h[3], sa[3], sb[3], fa[3], fb[3];
+#pragma unroll
+  for (int rg = 0; rg < 3; ++rg) { h[rg] = nb[q.dh[rg]]; sa[rg] = nb[q.dsa[rg]]; sb[rg] = nb[q.dsb[rg]]; fa[rg] = nb[q.dfa[rg]]; fb[rg] = nb[q.dfb[rg]]; }
+#pragma unroll
+  for (int rg = 0; rg < 3; ++rg) {
+    const bool diag = (q.dmask >> (4 + rg)) & 1u;
+    double v = (fb[rg] != 0.0) ? 0.0 : h[rg] * (sa[rg] * sb[rg]);
+    const double dg = v + fmin(fmax(v, min_diag), max_diag) * inv_mu;
+    v = diag ? dg : v;
+    d[rg] = (fa[rg] != 0.0) ? (diag ? 1.0 : 0.0) : v;
+  }
+}
+
+// L (coupling to the node on the left) of the node at nb into an LDS tile, linear order
+template <int B>
+__device__ __forceinline__ void seq_cut_l(const SeqCutDesc<B>& q, const ldsd* nb, ldsd* tile, int lane) {
+  constexpr int NT = SeqCutDesc<B>::NT;
+  double h[NT], sa[NT], s3[NT], fa[NT], f3[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) { h[t] = nb[q.lh[t]]; sa[t] = nb[q.lsa[t]]; s3[t] = nb[q.ls3[t]]; fa[t] = nb[q.lfa[t]]; f3[t] = nb[q.lf3[t]]; }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const bool band = (q.lmask >> (8 + t)) & 1u;
+    const double v = (band && fa[t] == 0.0 && f3[t] == 0.0) ? h[t] * sa[t] * s3[t] : 0.0;
+    if ((q.lmask >> t) & 1u) tile[lane + WAVE * t] = v;
+  }
+}
+
+// tile[row][col] = d - acc (result layout -> row-major LDS tile); ZERO_D: the tile receives -acc
+template <int B>
+__device__ __forceinline__ void seq_put_d(ldsd* tile, const double (&d)[3], const v4f64& acc, unsigned dmask, int lane) {
+  const int mr = lane & 15, mk = lane >> 4;
+#pragma unroll
+  for (int rg = 0; rg < 3; ++rg)
+    if ((dmask >> rg) & 1u) tile[(mk + 4 * rg) * B + mr] = d[rg] - acc[rg];
+}
+template <int B>
+__device__ __forceinline__ void seq_put_neg(ldsd* tile, const v4f64& acc, double sign, unsigned dmask, int lane) {
+  const int mr = lane & 15, mk = lane >> 4;
+#pragma unroll
+  for (int rg = 0; rg < 3; ++rg)
+    if ((dmask >> rg) & 1u) tile[(mk + 4 * rg) * B + mr] = sign * acc[rg];
+}
+
+// one node: columns from LDS tiles, Gauss-Jordan, factors to global memory, (G^T w)[c] in the lanes of groups 2 / 3, the three
+// products accumulated INTO o.c1 / o.c2 / o.c3 (the caller zeroes what must start fresh).  add_d: D = Du + Dadd (the middle node)
+template <int B>
+__device__ __forceinline__ void seq_node(double* __restrict__ gDinv, double* __restrict__ gGl, double* __restrict__ gGr, const ldsd* Du, const ldsd* Dadd,
+                                         bool add_d, const ldsd* Lu, const ldsd* Lb, ldsd* Gs, const ldsd* wu, SeqNodeOut<B>& o, int lane, bool probe_on = false) {
+  constexpr int BB = B * B;
+  const int grp = lane / B, c = lane % B;
+  (void)probe_on;
+  SEQ_T(2);
+  double col[B];
+  int c_id = (grp == 1) ? c : -1;
+  asm volatile("" : "+v"(c_id));
+  {
+    const ldsd* sp = (grp == 2) ? Lu + c : (grp == 3) ? Lb + c * B : Du + c;
+    const int st = (grp == 3) ? 1 : B;
+    const bool rd = (grp == 0) || (grp == 2) || (grp == 3);
+    double vv[B];
+#pragma unroll
+    for (int r = 0; r < B; ++r) vv[r] = sp[r * st];
+    if (add_d) {                                             // (wave-uniform) the middle node: what the left sweep left + what the right sweep left
+      double va[B];
+#pragma unroll
+      for (int r = 0; r < B; ++r) va[r] = Dadd[r * B + c];
+#pragma unroll
+      for (int r = 0; r < B; ++r) vv[r] = (grp == 0) ? vv[r] + va[r] : vv[r];
+    }
+#pragma unroll
+    for (int r = 0; r < B; ++r) asm volatile("" : "+v"(vv[r]));
+#pragma unroll
+    for (int r = 0; r < B; ++r) col[r] = rd ? vv[r] : ((r == c_id) ? 1.0 : 0.0);
+  }
+  SEQ_T(3);
+  gauss_jordan_cols<B>(col);
+  SEQ_T(4);
+  if (grp >= 1 && grp <= 3) {
+    double* dst = (grp == 1) ? gDinv : (grp == 2) ? gGl : gGr;
+#pragma unroll
+    for (int r = 0; r < B; ++r) dst[r * B + c] = col[r];
+  }
+  double cw = 0.0;
+  if (grp == 2 || grp == 3) {
+    double wr[B];
+#pragma unroll
+    for (int r = 0; r < B; ++r) wr[r] = wu[r];
+#pragma unroll
+    for (int r = 0; r < B; ++r) cw += col[r] * wr[r];                              // (G^T w_u)[c]
+    ldsd* dstg = Gs + (grp == 3 ? BB : 0);
+#pragma unroll
+    for (int r = 0; r < B; ++r) dstg[r * B + c] = col[r];
+  }
+  o.cw = cw;
+  SEQ_T(5);
+  {
+    const int mr = lane & 15, mk = lane >> 4;
+    const int mrc = (mr < B) ? mr : B - 1;
+#pragma unroll
+    for (int ks = 0; ks < (B + 3) / 4; ++ks) {
+      const int k = 4 * ks + mk;
+      const int kc = (k < B) ? k : B - 1;
+      const bool in = (k < B) && (mr < B);
+      double a_lut = Lu[kc * B + mrc];                                 // L_u^T[mr][k]
+      double a_lb = Lb[mrc * B + kc];                                  // L_b[mr][k]
+      double b_gl = Gs[kc * B + mrc];                                  // Gl[k][mr]
+      double b_gr = Gs[BB + kc * B + mrc];                             // Gr[k][mr]
+      asm volatile("" : "+v"(a_lut), "+v"(a_lb), "+v"(b_gl), "+v"(b_gr));
+      a_lut = in ? a_lut : 0.0;
+      a_lb = in ? a_lb : 0.0;
+      b_gl = in ? b_gl : 0.0;
+      b_gr = in ? b_gr : 0.0;
+      o.c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a_lut, b_gl, o.c1, 0, 0, 0);    // += L_u^T Gl   (onto neighbour a)
+      o.c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a_lb, b_gr, o.c2, 0, 0, 0);     // += L_b Gr     (onto neighbour b)
+      o.c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a_lb, b_gl, o.c3, 0, 0, 0);     // += L_b Gl     (minus the new coupling b <-> a)
+    }
+  }
+  SEQ_T(6);
+}
+
+constexpr int kCrSeqThreads = 128;
+// Chunk size of the two-way stage.  A workgroup is two waves and every chunk is resident from the start, so the stage ends when the
+// fullest compute unit does: with 1042 chunks of 16 on 256 CUs, 18 CUs hold five workgroups and finish 10 us after the rest
+// (per-workgroup timeline, tools/dev/seq_probe.sh).  Chunks are therefore sized so that no CU holds more than four; short chains keep
+// chunks of 8 (fewer nodes in sequence per wave; the stages above are latency-bound either way).
+static int cr_seq_chunk(int nsb, int B) {
+  const int top = (B == 3 ? 128 : 40) - 1;                 // what the top stage takes in one workgroup (cr_plan)
+  int m = (nsb - 1 + 4 * 256 - 1) / (4 * 256);
+  if (m < 8) {
+    m = 8;
+    for (int k = 8; k <= 24; ++k)                            // short chains: the smallest chunk that hands the top stage everything at once
+      if ((nsb + k - 1) / k <= top) { m = k; break; }
+  }
+  return m > 24 ? 24 : m;
+}
+template <int B>
+static size_t cr_seq_lds_bytes(int M) {
+  const int Wb = B / 3, rl = (Wb + 1) * 9 + 4;
+  return sizeof(double) * ((size_t)(M + 2) * Wb * rl + (size_t)(M + 1) * B + 2 * (size_t)(7 * B * B + 3 * B));
+}
+
+template <int B>
+__global__ __launch_bounds__(kCrSeqThreads) void k_cr_seq(CrView cr, CrStage sg, CrSource src, double* w) {
+  if (cr.lm != nullptr) {                                  // device-driven LM loop (uniform branch): the CURRENT buffers, today's trust region
+    if (cr.lm->done) return;
+    if (src.lm != nullptr) {
+      if (src.lm->cur) { src.Hband = src.Hband_alt; src.g = src.g_alt; }
+      src.mu = src.lm->radius;
+    }
+  }
+  extern __shared__ double lds_raw[];
+  ldsd* lds = (ldsd*)lds_raw;
+  constexpr int BB = B * B, Wb = B / 3;
+  constexpr int src_rl = (Wb + 1) * 9 + 4;
+  const int M = sg.M;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int grp = lane / B, c = lane % B;
+  const int64_t base = (int64_t)blockIdx.x * M;
+  const int64_t nst = cr.nsb;                                  // first stage: stride 1, every node alive
+  const int u_last = (int)((nst - 1 - base < M) ? (nst - 1 - base) : M);
+  const bool has_rb = (u_last == M);                           // the chunk ends in a boundary node (kept for the next stage)
+  const int U = has_rb ? M - 1 : u_last;                       // interior nodes 1 .. U  (>= 1)
+  const int mid = (U + 1) / 2;                                 // left sweep 1 .. mid-1, right sweep U .. mid+1, then mid
+  const bool last_is_rb = has_rb && (base + M == nst - 1);
+  double* const gDinv = cr.Dinv + (size_t)base * BB;           // this chunk's factor tiles
+  double* const gGl = cr.Gl + (size_t)base * BB;
+  double* const gGr = cr.Gr + (size_t)base * BB;
+  double* const gw = w + (size_t)base * B;
+  const int n_poses = src.n_poses;
+  const double inv_mu = 1.0 / src.mu, min_diag = src.min_diag, max_diag = src.max_diag;
+  SEQ_PROBE(0, wall_clock64());
+  SEQ_PROBE(3, (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32));
+  ldsd* sRec = lds;
+  ldsd* sW = sRec + (M + 2) * Wb * src_rl;                     // raw right-hand sides of local nodes 0 .. u_last
+  constexpr int kWaveLds = 7 * BB + 3 * B;
+  ldsd* T = sW + (M + 1) * B + wave * kWaveLds;
+  // per wave: tD[2] (D of the current / next node), tL[2], tF (the travelling fill: F_u on the left sweep, E_u on the right),
+  // tG (Gl, Gr of the node being eliminated; at the end wave 1's accL), tw[2] (w'_u of the current / next node), tacc (wave 1's accWL)
+  ldsd* const tF = T + 4 * BB;
+  ldsd* const tG = T + 5 * BB;
+  ldsd* const tacc = T + 7 * BB + 2 * B;
+#define SEQ_TD(i) (T + (i) * BB)
+#define SEQ_TL(i) (T + (2 + (i)) * BB)
+#define SEQ_TW(i) (T + 7 * BB + (i) * B)
+  const ldsd* T1 = sW + (M + 1) * B + kWaveLds;                // wave 1's block, as wave 0 sees it
+  // ---- stage the band rows of this chunk's poses and of the super-block on its left (k_cr_chunk's prologue); poses beyond the
+  //      end of the map are staged as constant poses ----
+  const int src_p0 = (int)((base > 0 ? base - 1 : 0) * Wb);
+  {
+    const int p_end = (int)(base + u_last + 1) * Wb;           // one past the last pose of the chunk's last node
+    const int p1 = min(n_poses, p_end);
+    const int np_st = max(p1 - src_p0, 0);
+    constexpr int hl = (Wb + 1) * 9;
+    const double* Hg = src.Hband + (size_t)src_p0 * hl;
+    if ((hl & 1) == 0) {
+      const double2* Hg2 = reinterpret_cast<const double2*>(Hg);
+      constexpr int h2 = hl / 2;
+      for (int e = tid; e < np_st * h2; e += kCrSeqThreads) {
+        const double2 v = Hg2[e];
+        ldsd* d = sRec + (e / h2) * src_rl + 2 * (e % h2);
+        d[0] = v.x; d[1] = v.y;
+      }
+    } else
+      for (int e = tid; e < np_st * hl; e += kCrSeqThreads) sRec[(e / hl) * src_rl + e % hl] = Hg[e];
+    for (int e = tid; e < np_st * 4; e += kCrSeqThreads) {
+      const int pp = e >> 2, cc = e & 3;
+      sRec[pp * src_rl + hl + cc] = (cc < 3) ? src.scale[3 * (src_p0 + pp) + cc] : (src.fixed[src_p0 + pp] ? 1.0 : 0.0);
+    }
+    for (int e = tid; e < (p_end - src_p0 - np_st) * src_rl; e += kCrSeqThreads)      // padding poses of the map's last super-block
+      sRec[np_st * src_rl + e] = (e % src_rl == hl + 3) ? 1.0 : 0.0;
+    for (int e = tid; e < (u_last + 1) * B; e += kCrSeqThreads) {
+      const int u = e / B;
+      const double v = cr_source_rhs(src, (int)(base + u), e % B);
+      src.rhs[(size_t)(base * B) + e] = v;                     // the copy the residual check and the step bookkeeping read
+      sW[e] = v;
+      if (u == 0 || (u == M && last_is_rb)) gw[e] = v;         // boundary nodes: raw (the next stage folds the contributions in);
+    }                                                          // interior nodes: their final value, once, when they are eliminated
+  }
+  SeqCutDesc<B> q;
+  seq_cut_desc<B>(q, lane);
+  const ldsd* nb0 = sRec + ((int)base * Wb - src_p0) * src_rl;  // first pose record of local node 0; node u: + u * Wb * src_rl
+  constexpr int kNodeRec = Wb * src_rl;
+  lds_barrier();
+  SEQ_PROBE(1, wall_clock64());
+  SeqNodeOut<B> o;
+  const v4f64 zero4 = {0.0, 0.0, 0.0, 0.0};
+  o.c1 = zero4; o.c2 = zero4; o.c3 = zero4; o.cw = 0.0;
+  double accw = 0.0;                                           // lanes of group 2 (wave 0: accWR) / group 3 (wave 1: accWL)
+  double dn[3];
+  const int mr_ = lane & 15, mk_ = lane >> 4;
+  int cur = 0;
+  if (wave == 0) {
+    // boundary node 0 keeps its raw D in memory; node 1 opens the chain: D_1, F_1 = L_1
+    seq_cut_d<B>(q, nb0, inv_mu, min_diag, max_diag, dn);
+#pragma unroll
+    for (int rg = 0; rg < 3; ++rg)
+      if ((q.dmask >> rg) & 1u) cr.D[(size_t)base * BB + (mk_ + 4 * rg) * B + mr_] = dn[rg];
+    seq_cut_d<B>(q, nb0 + kNodeRec, inv_mu, min_diag, max_diag, dn);
+    seq_put_d<B>(SEQ_TD(0), dn, zero4, q.dmask, lane);
+    seq_cut_l<B>(q, nb0 + kNodeRec, tF, lane);
+    if (lane < B) SEQ_TW(0)[lane] = sW[B + lane];
+    for (int u = 1; u < mid; ++u) {
+      const int nxt = cur ^ 1;
+#ifdef HITL_CR_PROBE
+      const bool probe_on = (blockIdx.x == 500 && (u == 3 || u == 4));
+      if (u == 4) { __builtin_amdgcn_s_waitcnt(0); if (probe_on && lane == 0) g_seq_node_probe[8] = clock64(); }
+      else SEQ_T(0);
+#else
+      const bool probe_on = false;
+#endif
+      const ldsd* nbn = nb0 + (u + 1) * kNodeRec;
+      seq_cut_d<B>(q, nbn, inv_mu, min_diag, max_diag, dn);                                            // D_{u+1} (registers), L_{u+1}
+      seq_cut_l<B>(q, nbn, SEQ_TL(0), lane);
+      if (u == 3) SEQ_T(1);
+      if (lane < B) gw[u * B + lane] = SEQ_TW(cur)[lane];                                          // final right-hand side of node u
+      o.c2 = zero4; o.c3 = zero4;
+      seq_node<B>(gDinv + (size_t)u * BB, gGl + (size_t)u * BB, gGr + (size_t)u * BB, SEQ_TD(cur), SEQ_TD(cur), false, tF, SEQ_TL(0), tG, SEQ_TW(cur), o, lane,
+                  probe_on && u == 3);
+      seq_put_d<B>(SEQ_TD(nxt), dn, o.c2, q.dmask, lane);                                          // D'_{u+1} = D_{u+1} - L_{u+1} Gr
+      seq_put_neg<B>(tF, o.c3, -1.0, q.dmask, lane);                                               // F_{u+1} = -L_{u+1} Gl
+      if (u == 3) SEQ_T(7);
+      if (grp == 2) accw += o.cw;
+      if (grp == 3) SEQ_TW(nxt)[c] = sW[(u + 1) * B + c] - o.cw;
+      cur = nxt;
+    }
+  } else {
+    // right sweep; E_U = L_{U+1} when the chunk ends in a boundary node (whose raw D stays in memory if nobody else owns it)
+    if (has_rb) {
+      seq_cut_l<B>(q, nb0 + M * kNodeRec, tF, lane);
+      if (last_is_rb) {
+        seq_cut_d<B>(q, nb0 + M * kNodeRec, inv_mu, min_diag, max_diag, dn);
+#pragma unroll
+        for (int rg = 0; rg < 3; ++rg)
+          if ((q.dmask >> rg) & 1u) cr.D[(size_t)(base + M) * BB + (mk_ + 4 * rg) * B + mr_] = dn[rg];
+      }
+    } else
+      for (int e = lane; e < BB; e += WAVE) tF[e] = 0.0;
+    if (U > mid) {
+      seq_cut_d<B>(q, nb0 + U * kNodeRec, inv_mu, min_diag, max_diag, dn);
+      seq_put_d<B>(SEQ_TD(0), dn, zero4, q.dmask, lane);
+      seq_cut_l<B>(q, nb0 + U * kNodeRec, SEQ_TL(0), lane);
+      if (lane < B) SEQ_TW(0)[lane] = sW[U * B + lane];
+    } else {                                                   // nothing to sweep: nothing pending for the middle node
+      for (int e = lane; e < BB; e += WAVE) SEQ_TD(0)[e] = 0.0;
+      if (lane < B) SEQ_TW(0)[lane] = 0.0;
+    }
+    for (int u = U; u > mid; --u) {
+      const int nxt = cur ^ 1;
+      const bool to_mid = (u - 1 == mid);                      // what this node leaves for the middle node is handed over as a difference
+      const ldsd* nbn = nb0 + (u - 1) * kNodeRec;
+      seq_cut_d<B>(q, nbn, inv_mu, min_diag, max_diag, dn);                                            // D_{u-1} (or 0), L_{u-1}
+      if (to_mid) { dn[0] = 0.0; dn[1] = 0.0; dn[2] = 0.0; }
+      seq_cut_l<B>(q, nbn, SEQ_TL(nxt), lane);
+      if (lane < B) gw[u * B + lane] = SEQ_TW(cur)[lane];
+      o.c1 = zero4; o.c3 = zero4;
+      seq_node<B>(gDinv + (size_t)u * BB, gGl + (size_t)u * BB, gGr + (size_t)u * BB, SEQ_TD(cur), SEQ_TD(cur), false, SEQ_TL(cur), tF, tG, SEQ_TW(cur), o, lane);
+      seq_put_d<B>(SEQ_TD(nxt), dn, o.c1, q.dmask, lane);                                          // D''_{u-1} = D_{u-1} - L_u^T Gl
+      seq_put_neg<B>(tF, o.c3, -1.0, q.dmask, lane);                                               // E_{u-1} = -E_u Gl
+      if (grp == 3) accw += o.cw;
+      if (grp == 2) SEQ_TW(nxt)[c] = (to_mid ? 0.0 : sW[(u - 1) * B + c]) - o.cw;
+      cur = nxt;
+    }
+    // hand-over for the middle node: pending D and w differences (slot 0), E_mid (tF), accL (-> tG), accWL (-> tacc)
+    seq_put_neg<B>(tG, o.c2, 1.0, q.dmask, lane);
+    if (grp == 3) tacc[c] = accw;
+    if (cur != 0) {                                            // wave 0 looks at slot 0
+      for (int e = lane; e < BB; e += WAVE) SEQ_TD(0)[e] = SEQ_TD(1)[e];
+      if (lane < B) SEQ_TW(0)[lane] = SEQ_TW(1)[lane];
+    }
+  }
+  lds_barrier();
+  if (wave != 0) return;
+  // ---- the middle node: neighbours = the chunk's two boundaries ----
+  const ldsd* bD = T1, *bF = T1 + 4 * BB, *bAccL = T1 + 5 * BB, *bw = T1 + 7 * BB, *bAccW = T1 + 7 * BB + 2 * B;
+  if (lane < B) { const double wm = SEQ_TW(cur)[lane] + bw[lane]; SEQ_TW(cur)[lane] = wm; gw[mid * B + lane] = wm; }
+  o.c2 = zero4; o.c3 = zero4;
+  seq_node<B>(gDinv + (size_t)mid * BB, gGl + (size_t)mid * BB, gGr + (size_t)mid * BB, SEQ_TD(cur), bD, true, tF, bF, tG, SEQ_TW(cur), o, lane);
+#undef SEQ_TD
+#undef SEQ_TL
+#undef SEQ_TW
+  // ---- hand the boundary contributions to the next stage (its node index = this chunk index (+1)) ----
+  {
+    double* PLn = cr.P + (size_t)(sg.next_par * 2 + 0) * sg.np * BB;
+    double* PRn = cr.P + (size_t)(sg.next_par * 2 + 1) * sg.np * BB;
+    double* WLn = cr.Pw + (size_t)(sg.next_par * 2 + 0) * sg.np * B;
+    double* WRn = cr.Pw + (size_t)(sg.next_par * 2 + 1) * sg.np * B;
+    const size_t c0 = (size_t)blockIdx.x, c1 = c0 + 1;
+    const int mr = lane & 15, mk = lane >> 4;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const int row = mk + 4 * rg;
+      if (row < B && mr < B) {
+        const int e = row * B + mr;
+        PRn[c0 * BB + e] = o.c1[rg];
+        if (blockIdx.x == 0) PLn[e] = 0.0;                                          // node 0 has no chunk on its left
+        if (has_rb) { PLn[c1 * BB + e] = o.c2[rg] + bAccL[e]; cr.L[(size_t)(base + M) * BB + e] = -o.c3[rg]; }
+        if (last_is_rb) PRn[c1 * BB + e] = 0.0;                                     // the last node has no chunk on its right
+      }
+    }
+    if (grp == 2) {
+      WRn[c0 * B + c] = accw + o.cw;
+      if (blockIdx.x == 0) WLn[c] = 0.0;
+      if (last_is_rb) WRn[c1 * B + c] = 0.0;
+    }
+    if (grp == 3 && has_rb) WLn[c1 * B + c] = bAccW[c] + o.cw;
+  }
+  SEQ_PROBE(2, wall_clock64());
+}
+
+// Back-substitution of the two-way stage: thread (u, r) owns row r of interior node u and fetches its three coefficient rows
+// once; x_mid from the two boundaries, then one node per step outwards on both half-chains (left: neighbours (0, u + 1), right:
+// (u - 1, M)).  The part of a row that only needs the boundary values is taken off before the chain starts.
+template <int B>
+__global__ __launch_bounds__(256) void k_cr_seq_back(CrView cr, int M, const double* __restrict__ w, double* __restrict__ x) {
+  if (cr.lm != nullptr && cr.lm->done) return;
+  extern __shared__ double sx[];                         // (M + 1) * B
+  const int tid = threadIdx.x;
+  const int64_t base = (int64_t)blockIdx.x * M;
+  const int64_t nst = cr.nsb;
+  const int u_last = (int)((nst - 1 - base < M) ? (nst - 1 - base) : M);
+  const bool has_rb = (u_last == M);
+  const int U = has_rb ? M - 1 : u_last;
+  const int mid = (U + 1) / 2;
+  const int u = 1 + tid / B, r = tid % B;
+  const bool mine = u <= U;
+  double gl[B], gr[B], v = 0.0;
+#pragma unroll
+  for (int c = 0; c < B; ++c) { gl[c] = 0.0; gr[c] = 0.0; }
+  if (mine) {
+    const size_t gn = (size_t)(base + u);
+    const double* Di = cr.Dinv + gn * B * B + (size_t)r * B;
+    const double* Gl = cr.Gl + gn * B * B + (size_t)r * B;
+    const double* Gr = cr.Gr + gn * B * B + (size_t)r * B;
+    const double* wk = w + gn * B;
+#pragma unroll
+    for (int c = 0; c < B; ++c) { v += Di[c] * wk[c]; gl[c] = Gl[c]; gr[c] = Gr[c]; }
+  }
+  if (tid < 2 * B) {
+    const int ub = (tid < B) ? 0 : M, rr = tid % B;
+    sx[(size_t)ub * B + rr] = (ub == 0 || has_rb) ? x[(size_t)(base + ub) * B + rr] : 0.0;
+  }
+  __syncthreads();
+  if (mine) {
+    const double* x0 = sx, *xM = sx + (size_t)M * B;
+    if (u <= mid) {
+#pragma unroll
+      for (int c = 0; c < B; ++c) v -= gl[c] * x0[c];
+    }
+    if (u >= mid) {
+#pragma unroll
+      for (int c = 0; c < B; ++c) v -= gr[c] * xM[c];
+    }
+    if (u == mid) { sx[(size_t)u * B + r] = v; x[(size_t)(base + u) * B + r] = v; }
+  }
+  __syncthreads();
+  const int steps = max(mid - 1, U - mid);
+  for (int k = 1; k <= steps; ++k) {
+    if (mine && (u == mid - k || u == mid + k)) {
+      const double* xn = sx + (size_t)((u < mid) ? u + 1 : u - 1) * B;
+      double acc = v;
+      if (u < mid) {
+#pragma unroll
+        for (int c = 0; c < B; ++c) acc -= gr[c] * xn[c];
+      } else {
+#pragma unroll
+        for (int c = 0; c < B; ++c) acc -= gl[c] * xn[c];
+      }
+      sx[(size_t)u * B + r] = acc;
+      x[(size_t)(base + u) * B + r] = acc;
+    }
+    __syncthreads();
+  }
+}
+
 struct CrPlan { CrStage st[8]; int n; };
 
 static size_t cr_chunk_lds_bytes(int M, int B, int threads, int nrhs) {
@@ -1267,7 +1766,8 @@ static int cr_chunk_threads(int M, int B, int stage = 1) {
 // (Chunks of M = 2 -- one wave per eliminated node, no barrier -- were measured for the wide first levels and are not
 // faster: a node costs a whole wave's instruction stream either way; chunks of 4 or 8 at 2 waves per workgroup: 56 / 68 us for
 // the first stage against 54 us for chunks of 16.)
-static CrPlan cr_plan(const CrView& crv, int B, int np, int nrhs, size_t wstride) {
+// m0 > 0: the first stage is the two-way sequential one (k_cr_seq) with chunks of m0 nodes (any size >= 2, not only powers of two)
+static CrPlan cr_plan(const CrView& crv, int B, int np, int nrhs, size_t wstride, int m0 = 0) {
   const int nsb = crv.nsb; (void)nsb;
   CrPlan pl;
   pl.n = 0;
@@ -1288,6 +1788,7 @@ static CrPlan cr_plan(const CrView& crv, int B, int np, int nrhs, size_t wstride
     int M = (pl.n == 1) ? 16 : 32;       // measured on C4 (tools/cr_plans.sh): 16,32,top = 111 us; 2,2,16,.. = 117; 2,2,2,32,.. = 125
     if (cr_chunk_lds_bytes(M, B, cr_chunk_threads(M, B), nrhs) > lds_cap) M = 16;      // many right-hand sides (submap solve): smaller chunks
     if (cr_chunk_lds_bytes(M, B, cr_chunk_threads(M, B), nrhs) > lds_cap) M = 8;
+    if (pl.n == 1 && m0 >= 2) M = m0;
     g.M = M; g.top = 0; g.nsl = g.M + 1;
     S *= g.M; par ^= 1; prev = true;
   }
@@ -1313,9 +1814,18 @@ static bool cr_factor_fused(hipStream_t st, const CrView& cr, double* w, double*
              hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cr_chunk<B, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess;
     if (!raised) { (void)hipGetLastError(); return false; }
   }
-  const CrPlan pl = cr_plan(cr, B, cr.np, nrhs, wstride);
+  // the LM path's first stage (tiles from the band rows, one right-hand side, a single GPU's chain): two-way sequential order
+  // (long chains only: the stage is about instruction throughput; on a short chain -- C2: 334 super-blocks -- a wave's 4-5 node
+  // eliminations in sequence cost more than the 4 levels of the cyclic-reduction stage: 1.14 against 1.03 ms per re-solve)
+  const bool seq_ok = src != nullptr && nrhs == 1 && 3 * src->Wb == B && !cr.rsep && dev_switches().cr_seq &&
+                      (cr.nsb >= 4096 || dev_switches().cr_seq_m >= 2);
+  const int m0 = !seq_ok ? 0 : dev_switches().cr_seq_m >= 2 ? dev_switches().cr_seq_m : cr_seq_chunk(cr.nsb, B);
+  const CrPlan pl = cr_plan(cr, B, cr.np, nrhs, wstride, m0);
+  const bool seq0 = seq_ok && pl.n >= 2 && !pl.st[0].top && pl.st[0].M == m0 && cr_seq_lds_bytes<B>(m0) <= 64 * 1024;
+  if (seq_ok && !seq0 && dev_switches().cr_seq_m >= 2) return false;           // (a forced chunk size that cannot run)
   for (int t = 0; t < pl.n; ++t) {                        // every stage must fit its LDS budget, else the level-per-launch path
     const CrStage& g = pl.st[t];
+    if (t == 0 && seq0) { if ((g.M - 1) * B > 256) return false; continue; }
     if (g.M < 2 || g.M > (B == 3 ? 128 : 64) || (g.M & (g.M - 1)) != 0) return false;
     const int thr = cr_chunk_threads(g.M, B, t);
     const bool use_src = (src != nullptr && t == 0);
@@ -1333,6 +1843,10 @@ static bool cr_factor_fused(hipStream_t st, const CrView& cr, double* w, double*
     const bool use_src = (src != nullptr && t == 0);
     const size_t lds = cr_chunk_lds_bytes(g.nsl - 1, B, thr, nrhs) + (use_src ? cr_chunk_src_extra(g.nsl, B, thr, src->Wb, nrhs) : 0);
     CrSource none = {};
+    if (t == 0 && seq0) {
+      hipLaunchKernelGGL((k_cr_seq<B>), dim3(chunks > 0 ? chunks : 1), dim3(kCrSeqThreads), cr_seq_lds_bytes<B>(g.M), st, cr, g, *src, w);
+      continue;
+    }
     if (use_src && nrhs == 1 && !g.top && !g.has_prev && g.S == 1 && thr <= 512 && 3 * src->Wb == B && (g.M + 1) * B <= thr &&
         !(cr.rsep && t == pl.n - 1)) {
       if (cr.rsep) hipLaunchKernelGGL((k_cr_chunk<B, 1, true>), dim3(chunks > 0 ? chunks : 1), dim3(thr), lds, st, cr, g, *src, w, x);
@@ -1351,6 +1865,10 @@ static bool cr_factor_fused(hipStream_t st, const CrView& cr, double* w, double*
       int thr = (g.M - (g.top ? 0 : 1)) * B;
       thr = (thr + 63) & ~63;
       const int grid = (nrhs > 1) ? 8 * nrhs * ((chunks + 7) / 8) : chunks;
+      if (t == 0 && seq0) {
+        hipLaunchKernelGGL((k_cr_seq_back<B>), dim3(chunks), dim3(thr), sizeof(double) * (g.M + 1) * B, st, cr, g.M, w, x);
+        continue;
+      }
       if (cr.rsep)
         hipLaunchKernelGGL((k_cr_chunk_back<B, true>), dim3(grid), dim3(thr), sizeof(double) * (g.M + 1) * B, st, cr, g.S, g.M, g.top, w, x, wstride, chunks, nrhs);
       else
@@ -1449,6 +1967,13 @@ static void cr_solve_t(hipStream_t st, const CrView& cr, double* w, double* x, i
 }
 
 #ifdef HITL_CR_PROBE
+extern "C" void hitl_seq_probe_dump(unsigned long long* out, int n) {      // n * 4 words
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_seq_probe), sizeof(unsigned long long) * 4 * (size_t)(n < 4096 ? n : 4096));
+  unsigned long long h[16];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_seq_node_probe), sizeof(h)) != hipSuccess) return;
+  fprintf(stderr, "seq node probe (shader cycles): cut %llu, column load %llu, Gauss-Jordan %llu, stores + G^T w + G to LDS %llu, products %llu, puts %llu; whole step %llu\n",
+          h[1] - h[0], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[7] - h[6], h[8] - h[0]);
+}
 extern "C" void hitl_cr_probe_dump() {
   unsigned long long h[3 * 64];
   if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_cr_probe), sizeof(h)) != hipSuccess) return;

@@ -34,6 +34,9 @@ struct DevSwitches {
   // ---- test hooks ----
   bool cr_legacy = false;          // "cr_legacy": the level-per-launch cyclic reduction (the fallback of the fused stages)
   bool cr_unfused_build = false;   // "cr_unfused_build": k_build_system as its own launch in front of the generic first stage
+  bool cr_seq = true;              // "cr_seq" = 0: the first stage of the LM path's factor-solve as a cyclic-reduction stage (rounds 2-4)
+                                   // instead of the two-way sequential order (k_cr_seq, round 5)
+  int cr_seq_m = 0;                // "cr_seq_m": chunk size of that first stage (0 = the default)
   bool stf_addr64 = false;         // "stf_addr64": the 64-bit addressing instantiations of k_linearize_stf (arrays beyond 4 GB)
   bool device_lm = false;          // "device_lm": accept / reject / terminate decided on the device (k_lm_decide), iterations queued ahead.
                                    // Measured (round 3): 4-8 us per iteration SLOWER than the host-driven loop on every workload

@@ -574,6 +574,8 @@ extern "C" int hitl_test_set_switch(const char* name, long long value) {
   DevSwitches& d = g_test_hooks;
   if (k == "cr_legacy") d.cr_legacy = value != 0;
   else if (k == "cr_unfused_build") d.cr_unfused_build = value != 0;
+  else if (k == "cr_seq") d.cr_seq = value != 0;
+  else if (k == "cr_seq_m") d.cr_seq_m = (int)std::max(0ll, std::min(64ll, value));
   else if (k == "stf_addr64") d.stf_addr64 = value != 0;
   else if (k == "device_lm") d.device_lm = value != 0;
   else if (k == "lm_ahead") d.lm_ahead = (int)std::max(1ll, std::min(16ll, value));

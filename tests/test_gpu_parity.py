@@ -368,7 +368,7 @@ def test_device_driven_lm_loop_equals_the_host_driven_one(switches, shape, late)
 
 
 @pytest.mark.parametrize("shape", [(150, 64, 50, 3, 0, 3), (97, 48, 97, 2, 4, 2), (64, 40, 64, 1, 2, 4), (333, 32, 111, 2, 0, 3)])
-def test_first_stage_instantiation_equals_the_separate_build(switches, shape):
+def test_first_stage_forms_agree(switches, shape):
     """The first fused cyclic-reduction stage of the LM path cuts its tiles and right-hand side from the band rows itself (its own
     instantiation of k_cr_chunk: facts of that stage known at compile time, a register budget for four workgroups per CU).
     The test hook cr_unfused_build forms the same system with k_build_system and runs the generic instantiation: same arithmetic in the
@@ -383,18 +383,25 @@ def test_first_stage_instantiation_equals_the_separate_build(switches, shape):
     g.close()
     for mode in (0, 2):
         res = []
-        for unfused in (False, True):
-            switches(cr_unfused_build=1 if unfused else 0)
+        # (1) the cyclic-reduction first stage with its own instantiation, (2) the same stage behind k_build_system: same arithmetic in
+        # the same order, bit for bit; (3) round 5's default, the two-way SEQUENTIAL first stage (k_cr_seq), with chunk sizes that
+        # leave short, odd and single-node last chunks: the same eliminations in another order -- same LM path, rounding apart
+        for hooks in (dict(cr_seq=0), dict(cr_seq=0, cr_unfused_build=1), dict(), dict(cr_seq_m=5), dict(cr_seq_m=2), dict(cr_seq_m=7)):
+            switches(cr_seq=1, cr_seq_m=0, cr_unfused_build=0)
+            switches(**hooks)
             s = H.Solver()               # the switches are read at create
             prob.load(s, corr=corr)
             p, sm = s.solve(mode, prob.init)
             res.append((p, sm.termination, sm.iterations, sm.successful_steps, sm.final_cost, sm.final_trust_region_radius, sm.band_poses))
             s.close()
-        f, u = res
+        f, u = res[0], res[1]
         assert np.array_equal(f[0].view(np.uint32), u[0].view(np.uint32)), (mode, np.abs(f[0] - u[0]).max())
         assert f[1:] == u[1:], (mode, f[1:], u[1:])
         if mode == 2:
             assert f[6] == window
+        for q in res[2:]:
+            assert q[1:4] == f[1:4] and q[6] == f[6], (mode, q[1:], f[1:])
+            assert abs(q[4] - f[4]) <= 1e-9 * abs(f[4]) and np.abs(q[0] - f[0]).max() <= 2e-6
 
 
 def test_timing_levels_do_not_change_results(small_problem):

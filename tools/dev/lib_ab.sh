@@ -15,7 +15,7 @@ import csv, glob
 for f in glob.glob("$OUT/t/*/*kernel_stats.csv"):
     for r in csv.DictReader(open(f)):
         n = r["Name"]
-        if "k_cr_chunk" in n or "k_linearize_stf" in n or "k_assemble" in n or "k_spmv" in n:
+        if "k_cr_chunk" in n or "k_cr_seq" in n or "k_host_flag" in n or "k_linearize_stf" in n or "k_assemble" in n or "k_spmv" in n:
             print("   %-44s calls %5s avg %8.2f us" % (n.split("(")[0].replace("void hitl::","").replace("hitl::","")[:44], r["Calls"], float(r["AverageNs"]) / 1e3))
 PY
 done

@@ -4,6 +4,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import hitl_slam_amd as H
 from tools import hitl_synth as S
+from hitl_slam_amd.api import apply_test_switches_from_env
+apply_test_switches_from_env()          # HITL_TEST_SWITCHES="cr_seq=0": the library's test hooks, set by this script
 n, m = 50000, 400
 p = S.params(n, m, seed=20264102, poses_per_floor=200)
 gt, init, cov = S.poses(p)

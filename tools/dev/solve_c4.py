@@ -4,6 +4,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import hitl_slam_amd as H
 from tools import hitl_synth as S
+from hitl_slam_amd.api import apply_test_switches_from_env
+apply_test_switches_from_env()          # HITL_TEST_SWITCHES="cr_seq=0": the library's test hooks, set by this script
 n, m = 50000, 400
 p = S.params(n, m, seed=20264102, poses_per_floor=200)
 gt, init, cov = S.poses(p)
@@ -29,3 +31,25 @@ if os.environ.get("CR_PROBE"):          # development build with -DHITL_CR_PROBE
     from hitl_slam_amd.api import load_library
     load_library().hitl_cr_probe_dump()
 s.close()
+
+if os.environ.get("SEQ_PROBE"):         # development build with -DHITL_CR_PROBE only: the workgroup timeline of the LAST k_cr_seq launch
+    import ctypes as C
+    from hitl_slam_amd.api import load_library
+    nwg = 1042
+    buf = (C.c_ulonglong * (4 * nwg))()
+    load_library().hitl_seq_probe_dump(buf, nwg)
+    a = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 4).astype(np.int64)
+    t0 = a[:, 0].min()
+    st, pro, en = (a[:, 0] - t0) / 100.0, (a[:, 1] - a[:, 0]) / 100.0, (a[:, 2] - t0) / 100.0      # microseconds
+    print("k_cr_seq timeline (us): kernel span %.1f; starts: min %.1f median %.1f p90 %.1f max %.1f; staging median %.1f; lifetime median %.1f p10 %.1f p90 %.1f max %.1f"
+          % (en.max(), st.min(), np.median(st), np.percentile(st, 90), st.max(), np.median(pro), np.median(en - st), np.percentile(en - st, 10), np.percentile(en - st, 90), (en - st).max()))
+    print("start-time histogram (2 us bins):", np.histogram(st, bins=np.arange(0, st.max() + 2, 2))[0].tolist())
+    print("end-time histogram (2 us bins):", np.histogram(en, bins=np.arange(0, en.max() + 2, 2))[0].tolist())
+    hw = a[:, 3] & 0xffffffff
+    xcc = (a[:, 3] >> 32) & 0xf
+    cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 0x1; se = (hw >> 13) & 0x7
+    key = xcc * 1000 + se * 100 + sh * 10 + cu
+    u, cnt = np.unique(key, return_counts=True)
+    print("distinct (xcc, se, sh, cu):", len(u), "workgroups per CU: min %d max %d; histogram" % (cnt.min(), cnt.max()), np.bincount(cnt).tolist())
+    late = st > np.median(st) + 5
+    print("late starters:", int(late.sum()), "their lifetimes median %.1f" % (np.median((en - st)[late]) if late.any() else 0.0))
