@@ -60,4 +60,49 @@ __device__ __forceinline__ double block_max(double v, double* sm) {
   return sm[0];
 }
 
+// ===========================================================================================
+// The decision of one Levenberg-Marquardt iteration on the device: Ceres' trust-region rules as restated in SURVEY.md A.4 /
+// DESIGN.md section 2, the same statements in the same order as the host loop of lm_solve (hitl_lm.cpp), compiled without
+// contraction like that loop (1 - q*q*q must round the same way).  One thread.
+// ===========================================================================================
+__device__ __forceinline__ void lm_decide_step(LmDev& s, const LmOpts& o, double rr, double bb, double dt_rhs, double dt_q, double step2, double xn2,
+                                               double bad, double cand_cost, double cand_gmax) {
+#pragma clang fp contract(off)
+  ++s.iter;
+  const bool ok = (rr == rr) && !(rr > o.guard2 * bb);          // the factorisation did not break down
+  const double mcc = dt_rhs - 0.5 * dt_q;                        // model_cost_change; rhs = -S g
+  if (!ok || bad > 0.0 || !(mcc == mcc) || mcc < 0.0) {         // invalid step
+    ++s.unsuccessful;
+    if (++s.invalid_run >= 5) { s.term = HITL_FAILURE; s.done = 1; }
+    else s.radius *= 0.5;                                        // LevenbergMarquardtStrategy::StepIsInvalid
+  } else {
+    s.invalid_run = 0;
+    ++s.lin_calls;
+    const bool par_tol = sqrt(step2) <= o.parameter_tolerance * (sqrt(xn2) + o.parameter_tolerance);
+    const double cost_change = s.cost - cand_cost;
+    const bool fun_tol = fabs(cost_change) <= o.function_tolerance * s.cost;
+    if (!o.late && (par_tol || fun_tol)) { s.term = HITL_CONVERGENCE; s.done = 1; }
+    else {
+      const double rho = cost_change / mcc;
+      if (rho > o.min_relative_decrease) {
+        ++s.successful;
+        s.cur ^= 1;
+        s.cost = cand_cost; s.gmax = cand_gmax;
+        if (s.gmax <= o.gradient_tolerance) { s.term = HITL_CONVERGENCE; s.done = 1; }
+        else if (o.late && (par_tol || fun_tol)) { s.term = HITL_CONVERGENCE; s.done = 1; }
+        else {
+          const double q = 2.0 * rho - 1.0;
+          s.radius = fmin(o.max_radius, s.radius / fmax(1.0 / 3.0, 1.0 - q * q * q));
+          s.decrease_factor = 2.0;
+        }
+      } else {
+        ++s.unsuccessful;
+        s.radius /= s.decrease_factor; s.decrease_factor *= 2.0;
+        if (s.radius < o.min_radius) { s.term = HITL_CONVERGENCE; s.done = 1; }
+      }
+    }
+  }
+  if (!s.done && s.iter >= o.max_iter) { s.term = HITL_NO_CONVERGENCE; s.done = 1; }
+}
+
 }  // namespace hitl

@@ -167,8 +167,22 @@ size_t stf_pose_rec_bytes();
 void launch_build_stf_pose_recs(hipStream_t st, const MapView& map, const PairView& pr, void* recs);
 void launch_pack_obs(hipStream_t st, int64_t n, const float* px, const float* py, const float* nx, const float* ny,
                      float4* obs);
+// Device-driven LM loop: the decision of the iteration (lm_decide_step) is taken by the LAST workgroup of k_assemble to finish -- the
+// kernel that produces the last numbers the decision needs -- instead of by a launch of its own behind it.
+struct LmDecide {
+  LmDev* lm;                   // null: no decision (host-driven loop)
+  LmOpts o;
+  const double* step_partials; int nblk_step;      // band pass: 8 per workgroup (r.r, b.b, dt.rhs, dt.q, |step|^2, |x|^2, bad, -)
+  const double* lin_partials0; const double* lin_partials1; int nblk_lin;    // k_assemble's own (cost, max |g|), both buffers
+  unsigned* arrivals;          // workgroups of this launch that have stored their partials (reset by the last one)
+  double* progress;            // pinned host memory: [0] iterations completed (written last), [1] done, [2] termination, [3] cost, [4] radius
+  // host-driven loop (lm == null): the last workgroup stores flag_seq into *host_flag (pinned) once every workgroup's partials are out --
+  // what the one-thread kernel k_host_flag did behind k_assemble, without the launch (4 us per LM iteration)
+  double* host_flag; double flag_seq;
+};
 void launch_assemble(hipStream_t st, const MapView& map, const PairView& pr, const FactorView& fv,
-                     const double* x, const LinView& lin, const LmDev* lm = nullptr, const double* x_alt = nullptr, const LinView* lin_alt = nullptr);
+                     const double* x, const LinView& lin, const LmDev* lm = nullptr, const double* x_alt = nullptr, const LinView* lin_alt = nullptr,
+                     const LmDecide* decide = nullptr);
 inline int assemble_blocks(int n_poses) { return (n_poses + 63) / 64; }   // k_assemble: 4 lanes per pose, 256 threads
 void launch_jacobi_scale(hipStream_t st, int n_poses, int npad, int Wb, const double* Hband, int enable,
                          const unsigned char* fixed, double* scale);
@@ -237,9 +251,6 @@ void launch_spmv_residual_step_lm(hipStream_t st, int n_poses, int npad, const F
                                   double* x1, double* q, double* partials, double2* cs, const LmDev* lm);
 // the decision of one LM iteration (Ceres' trust-region rules) from the partial sums of the band pass and of
 // the candidate's linearisation; progress[0..7] (pinned host memory) = iterations completed, done, termination, cost, ...
-size_t lm_decide_lds_bytes(int nblk_step, int nblk_lin);   // dynamic LDS of k_lm_decide: the device-driven loop applies while it fits
-void launch_lm_decide(hipStream_t st, LmDev* lm, LmOpts o, const double* step_partials, int nblk_step, const double* lin_partials0,
-                      const double* lin_partials1, int nblk_lin, double* progress_pinned);
 void launch_pack_owned(hipStream_t st, int nhead, const double* head, const double* vec, int off, int cnt, int maxcnt, double* rec);
 void launch_pack_edges(hipStream_t st, int nhead, const double* head, const double* vec, int off, int cnt, int edge, int maxcnt, double* rec);
 void launch_scatter_idx(hipStream_t st, int cnt, const int* idx, const double* val, double* vec);

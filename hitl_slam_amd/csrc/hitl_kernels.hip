@@ -644,7 +644,7 @@ __device__ __forceinline__ double quad_sum(double v) {     // fixed order: (l0 +
 constexpr int kAsmBlock = 256;     // 64 poses per workgroup
 struct AsmLm { const LmDev* lm; const double* x_alt; LinView lin_alt; };
 __global__ __launch_bounds__(kAsmBlock) void k_assemble(MapView map, PairView pr, FactorView fv, const double* __restrict__ x,
-                                                         LinView lin, AsmLm lmsel) {
+                                                         LinView lin, AsmLm lmsel, LmDecide dec) {
   if (lmsel.lm != nullptr) {                    // device-driven LM loop: the candidate's buffers
     if (lmsel.lm->done) return;
     if ((lmsel.lm->cur ^ 1) != 0) { x = lmsel.x_alt; lin = lmsel.lin_alt; }
@@ -815,8 +815,76 @@ __global__ __launch_bounds__(kAsmBlock) void k_assemble(MapView map, PairView pr
   if (threadIdx.x == 0) {
     double cs = sm_c[0], gs = sm_g[0];
     for (int k = 1; k < kAsmBlock / WAVE; ++k) { cs += sm_c[k]; const double g1 = sm_g[k]; gs = (g1 > gs || g1 != g1) ? g1 : gs; }
-    lin.partials[2 * blockIdx.x] = cs;
-    lin.partials[2 * blockIdx.x + 1] = gs;
+    if (dec.lm == nullptr) {
+      lin.partials[2 * blockIdx.x] = cs;
+      lin.partials[2 * blockIdx.x + 1] = gs;
+      if (dec.host_flag != nullptr) {
+        // host-driven loop: the partials are in flight to pinned host memory; once they have been accepted this workgroup counts
+        // itself in, and the last one to do so raises the flag the host polls (same order on the link: partials, then flag)
+        __builtin_amdgcn_s_waitcnt(0);
+        if (__hip_atomic_fetch_add(dec.arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+          *dec.arrivals = 0u;
+          __threadfence_system();
+          *reinterpret_cast<volatile double*>(dec.host_flag) = dec.flag_seq;
+        }
+      }
+    } else {
+      // device-driven loop: the two numbers go out as device-scope stores (written through to where every XCD sees them) and have
+      // arrived there before this workgroup counts itself in -- NOT a release fence: at device scope that writes back the whole
+      // L2 slice, 14 MB of band blocks 782 times over (measured: +115 us per LM iteration)
+      __hip_atomic_store(&lin.partials[2 * blockIdx.x], cs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&lin.partials[2 * blockIdx.x + 1], gs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_s_waitcnt(0);
+    }
+  }
+  if (dec.lm == nullptr) return;
+  // ---- device-driven LM loop: the last workgroup to get here takes the iteration's decision (round 5; rounds 3-4: a launch of
+  //      its own, k_lm_decide, that cost what the host's turn-around did).  Nine sums over the per-workgroup partials (7 of the band
+  //      pass, cost and max |g| of this linearisation), each in the fixed order of ordered_sum32 (hitl_host.h): 32 lanes take the
+  //      terms b = lane, lane + 32, ... in ascending order, then the 32 lane sums are added from lane 0 up. ----
+  __shared__ int s_last;
+  __shared__ double s_part[9][32];
+  __shared__ double s_tot[9];
+  if (threadIdx.x == 0) s_last = (__hip_atomic_fetch_add(dec.arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1 : 0;
+  __syncthreads();
+  if (!s_last) return;
+  {
+    const int tid = threadIdx.x, j = tid & 31;
+    const double* lp = (lmsel.lm->cur ^ 1) ? dec.lin_partials1 : dec.lin_partials0;      // the candidate's linearisation = this launch's
+    for (int grp = tid >> 5; grp < 9; grp += kAsmBlock / 32) {
+      double acc = 0.0;
+      if (grp < 7) {
+#pragma unroll 8
+        for (int b = j; b < dec.nblk_step; b += 32) acc += dec.step_partials[8 * b + grp];
+      } else if (grp == 7) {
+#pragma unroll 8
+        for (int b = j; b < dec.nblk_lin; b += 32) acc += __hip_atomic_load(&lp[2 * b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+#pragma unroll 8
+        for (int b = j; b < dec.nblk_lin; b += 32) {
+          const double g = __hip_atomic_load(&lp[2 * b + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (g > acc || g != g) acc = g;
+        }
+      }
+      s_part[grp][j] = acc;
+    }
+    __syncthreads();
+    if (tid < 9) {
+      double t = 0.0;
+      if (tid != 8) { for (int q = 0; q < 32; ++q) t += s_part[tid][q]; }
+      else { for (int q = 0; q < 32; ++q) { const double g = s_part[8][q]; if (g > t || g != g) t = g; } }
+      s_tot[tid] = t;
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    LmDev s = *dec.lm;
+    lm_decide_step(s, dec.o, s_tot[0], s_tot[1], s_tot[2], s_tot[3], s_tot[4], s_tot[5], s_tot[6], s_tot[7], s_tot[8]);
+    *dec.lm = s;
+    *dec.arrivals = 0u;                                          // every workgroup of this launch has arrived: ready for the next one
+    volatile double* progress = dec.progress;
+    progress[1] = (double)s.done; progress[2] = (double)s.term; progress[3] = s.cost; progress[4] = s.radius;
+    __threadfence_system();
+    progress[0] = (double)s.iter;                                // last: the host polls this word
   }
 }
 
@@ -841,10 +909,13 @@ __global__ __launch_bounds__(128) void k_assemble_offband(FactorView fv, LinView
 }
 
 void launch_assemble(hipStream_t st, const MapView& map, const PairView& pr, const FactorView& fv, const double* x,
-                     const LinView& lin, const LmDev* lm, const double* x_alt, const LinView* lin_alt) {
+                     const LinView& lin, const LmDev* lm, const double* x_alt, const LinView* lin_alt, const LmDecide* decide) {
   const int n = map.n_poses;
   AsmLm lmsel = {lm, x_alt, lin_alt ? *lin_alt : lin};
-  hipLaunchKernelGGL(k_assemble, dim3(assemble_blocks(n)), dim3(kAsmBlock), 0, st, map, pr, fv, x, lin, lmsel);
+  LmDecide dec = {};
+  if (decide != nullptr && (lm != nullptr || (decide->lm == nullptr && decide->host_flag != nullptr))) dec = *decide;
+  if (fv.with_stf && fv.n_offband > 0) dec.host_flag = nullptr;   // (k_assemble_offband follows: the caller keeps its own flag)
+  hipLaunchKernelGGL(k_assemble, dim3(assemble_blocks(n)), dim3(kAsmBlock), 0, st, map, pr, fv, x, lin, lmsel, dec);
   if (fv.with_stf && fv.n_offband > 0)
     hipLaunchKernelGGL(k_assemble_offband, dim3((fv.n_offband + 127) / 128), dim3(128), 0, st, fv, lin);
 }

@@ -21,7 +21,8 @@ namespace hitl {
 // enqueue_linearize only queues the kernels and the copy of the per-workgroup partials (behind the step partials in
 // the pinned buffer); finish_linearize adds them up once the stream has been synchronised.
 static int enqueue_linearize(hitl_solver* s, const FactorView& fv, const double* xdev, int buf, bool direct = false, bool have_trig = false,
-                             bool device_only = false /* the partials stay in device memory (launch_sum_partials adds them up there) */) {
+                             bool device_only = false /* the partials stay in device memory (launch_sum_partials adds them up there) */,
+                             double flag_seq = 0.0 /* != 0 (with direct): k_assemble's last workgroup raises the host flag itself */) {
   hipStream_t st = s->stream;
   const MapView mv = s->map_view();
   const PairView pv = s->pair_view();
@@ -43,7 +44,12 @@ static int enqueue_linearize(hitl_solver* s, const FactorView& fv, const double*
                            nullptr, nullptr, nullptr, s->stf_pose_recs_of == s->corr_generation ? s->stf_pose_recs.p : nullptr);
   }
   if (s->lin_timed) HIP_TRY(hipEventRecord(s->ev1, st));
-  launch_assemble(st, mv, pv, fv, xdev, lv);
+  if (flag_seq != 0.0 && direct && !(fv.with_stf && fv.n_offband > 0)) {
+    LmDecide dec = {};
+    dec.arrivals = s->lm_arrivals.p; dec.host_flag = s->h_scalars + 15; dec.flag_seq = flag_seq;
+    launch_assemble(st, mv, pv, fv, xdev, lv, nullptr, nullptr, nullptr, &dec);
+  } else
+    launch_assemble(st, mv, pv, fv, xdev, lv);
   HIP_TRY(hipGetLastError());
   const int nblk = assemble_blocks(s->n);
   if (!direct && !device_only) HIP_TRY(hipMemcpyAsync(host, lv.partials, sizeof(double) * 2 * nblk, hipMemcpyDeviceToHost, st));
@@ -71,10 +77,15 @@ static int finish_linearize(hitl_solver* s, const FactorView& fv, LinResult* out
 // kernel behind the queued work stores a sequence number into pinned host memory and the host polls that word: ~0.25 ms per
 // re-solve cheaper than hipEventRecord + hipEventQuery (measured in round 2).  The kernels in front of it
 // have completed -- and their own stores to pinned memory (the partial sums) are visible -- before it starts.
+static int wait_host_flag(hitl_solver* s, double seq);
 static int spin_sync(hitl_solver* s) {
-  volatile double* flag = s->h_scalars + 15;
   const double seq = (double)(++s->sync_seq);
   launch_host_flag(s->stream, s->h_scalars + 15, seq);   // (hipStreamWriteValue64 instead of this one-thread kernel: measured, no difference)
+  return wait_host_flag(s, seq);
+}
+// the flag may also be raised by the last workgroup of k_assemble (LmDecide::host_flag): no launch of its own
+static int wait_host_flag(hitl_solver* s, double seq) {
+  volatile double* flag = s->h_scalars + 15;
   for (uint32_t spins = 1;; ++spins) {
     if (*flag == seq) { std::atomic_thread_fence(std::memory_order_acquire); return HITL_OK; }
     if ((spins & 0xfffffu) == 0) {                       // every million polls: is the stream still alive?
@@ -724,7 +735,6 @@ constexpr int kLmEventPairs = 32;
 
 static bool lm_device_loop_applies(hitl_solver* s, const FactorView& fv) {
   if (!dev_switches().device_lm || s->dist_mode() || fv.n_offband != 0 || s->opt.timing_level >= 2) return false;
-  if (lm_decide_lds_bytes(spmv_blocks(s->npad), assemble_blocks(s->n)) > (size_t)150 * 1024) return false;   // C5's 200 000 poses: 4 x the partials of C4 (46 KB)
   const LinView lv0 = s->lin_view(0), lv1 = s->lin_view(1);
   CrView cr = s->cr_view();
   cr.lm = s->lm_dev.p;
@@ -756,6 +766,7 @@ static int lm_device_loop(hitl_solver* s, const FactorView& fv, int cur, double 
   const CrSource src = {lv0.Hband, lv0.g, s->scale.p, s->fixed.p, 1.0, o.min_lm_diagonal, o.max_lm_diagonal, s->n, fv.band_poses, s->rhs.p,
                         nullptr, 0, s->lm_dev.p, lv1.Hband, lv1.g};
   const int nblk_step = spmv_blocks(s->npad), nblk_lin = assemble_blocks(s->n);
+  const LmDecide decide = {s->lm_dev.p, lo, s->step_partials.p, nblk_step, lv0.partials, lv1.partials, nblk_lin, s->lm_arrivals.p, s->h_scalars + kNumScalars};
   if (s->lm_events.empty() && o.timing_level >= 1) {
     s->lm_events.assign(2 * kLmEventPairs, nullptr);
     for (hipEvent_t& e : s->lm_events) if (hipEventCreate(&e) != hipSuccess) return fail(HITL_ERR_HIP, "hipEventCreate failed");
@@ -785,8 +796,7 @@ static int lm_device_loop(hitl_solver* s, const FactorView& fv, int cur, double 
                                s->lm_dev.p, xb[1], lv1.pairRJ, s->stf_pose_recs_of == s->corr_generation ? s->stf_pose_recs.p : nullptr);
       }
       if (timed) { HIP_TRY(hipEventRecord(s->lm_events[2 * pairs_used + 1], st)); pair_iter[pairs_used] = queued + 1; ++pairs_used; }
-      launch_assemble(st, mv, pv, fv, xb[0], lv0, s->lm_dev.p, xb[1], &lv1);
-      launch_lm_decide(st, s->lm_dev.p, lo, s->step_partials.p, nblk_step, lv0.partials, lv1.partials, nblk_lin, s->h_scalars + kNumScalars);
+      launch_assemble(st, mv, pv, fv, xb[0], lv0, s->lm_dev.p, xb[1], &lv1, &decide);      // its last workgroup takes the iteration's decision
       HIP_TRY(hipGetLastError());
       ++queued;
     }
@@ -832,6 +842,8 @@ int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float* poses
   if (dev_switches().timing) std::fprintf(stderr, "lm_solve: prepare (factor tables)   %.3f ms\n", now_ms() - t_start);
   hipStream_t st = s->stream;
   const int n = s->n, n3 = 3 * n;
+  TRY(s->lm_arrivals.resize(1));                           // arrival counter of k_assemble's last-workgroup duties: zero at the start of every solve
+  HIP_TRY(hipMemsetAsync(s->lm_arrivals.p, 0, sizeof(unsigned), st));
   hitl_summary S;
   std::memset(&S, 0, sizeof(S));
   {  // SetParams (JointOptimization.cpp:392-402): fp32 -> fp64, through a page-locked buffer the solver keeps (queued, not waited for)
@@ -894,9 +906,10 @@ int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float* poses
     if (fused) {
       { RoctxRange r("hitl:queue linear solve + step"); TRY(enqueue_linear_solve_banded(s, fv, cur, radius, xcur, xcand)); }
       if (time_solver) HIP_TRY(hipEventRecord(s->ev3, st));
+      const double seq = (double)(++s->sync_seq);
       { RoctxRange r("hitl:queue linearisation of the candidate");
-        TRY(enqueue_linearize(s, fv, xcand, cur ^ 1, /*direct=*/true, /*have_trig=*/true)); }   // partial sums are written to pinned host memory by the kernels
-      { RoctxRange r("hitl:wait for the device"); TRY(spin_sync(s)); }
+        TRY(enqueue_linearize(s, fv, xcand, cur ^ 1, /*direct=*/true, /*have_trig=*/true, false, seq)); }   // partial sums are written to pinned host memory by the kernels
+      { RoctxRange r("hitl:wait for the device"); TRY(wait_host_flag(s, seq)); }
       double rr, bb;
       TRY(finish_step_partials(s, &rr, &bb, &ss));
       const double guard = std::max(std::max(o.linear_solver_tolerance, 1e-15), 1e-9);

@@ -22,6 +22,7 @@ struct hitl_solver {
   bool lin_timed = false;       // the linearisation in flight is bracketed
   double* h_scalars = nullptr;  // pinned, kNumScalars + 8: [15] = sequence word of spin_sync, [kNumScalars ..] = progress record of the device-driven LM loop
   DevArray<LmDev> lm_dev;       // device-resident state of the LM loop (k_lm_decide)
+  DevArray<unsigned> lm_arrivals;             //   workgroups of the deciding launch that have stored their partials (k_assemble)
   std::vector<hipEvent_t> lm_events;   // pairs bracketing k_linearize_stf launches queued ahead (device-driven loop)
   int64_t sync_seq = 0;
   double* h_partials = nullptr; // pinned, h_partials_cap doubles

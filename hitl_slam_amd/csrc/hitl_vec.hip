@@ -257,13 +257,6 @@ void launch_spmv_residual_step_lm(hipStream_t st, int n_poses, int npad, const F
   else hipLaunchKernelGGL((k_spmv<3, 0>), dim3(spmv_blocks(npad)), dim3(128), 0, st, n_poses, npad, fv, lin0, scale, 1.0, min_diag, max_diag, v, q, aux);
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// The decision of one Levenberg-Marquardt iteration on the device (round 3; until round 2 the host took it after a
-// synchronisation, which left the GPU idle for ~40 us per iteration).  Ceres' trust-region rules as restated in SURVEY.md
-// A.4 / DESIGN.md section 2, the same statements in the same order as the host loop of lm_solve (which remains for the
-// submap and off-band paths, and is the default: the test hook device_lm selects this one).  The per-workgroup partial sums are added in index
-// order, one sequence per lane -- the same order the host used, so both loops take bit-identical decisions.
-// ---------------------------------------------------------------------------------------------------------------------
 // The scalars a submap rank contributes to the exchange that ends an LM iteration -- (dt.rhs, dt.q, |step|^2, |x|^2, bad,
 // cost, max |g| of the candidate) -- summed from the per-workgroup partials ON THE DEVICE, in the order of ordered_sum32 (the
 // host's), so that with the built-in RCCL transport the record can travel device -> device and the host waits once per
@@ -291,94 +284,6 @@ __global__ __launch_bounds__(512) void k_sum_partials(const double* __restrict__
 void launch_sum_partials(hipStream_t st, const double* step_partials, int nblk_step, const double* lin_partials, int nblk_lin, double* rec7) {
   hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(512), 0, st, step_partials, nblk_step, lin_partials, nblk_lin, rec7);
 }
-
-__global__ __launch_bounds__(1024) void k_lm_decide(LmDev* lm, LmOpts o, const double* __restrict__ sp, int nblk_step, const double* __restrict__ lp0,
-                                                    const double* __restrict__ lp1, int nblk_lin, volatile double* progress) {
-#pragma clang fp contract(off)      // the host loop is compiled without contraction: 1 - q*q*q must round like there
-  // Nine sums over the per-workgroup partials (7 of the band pass, cost and max |g| of the candidate's linearisation), each
-  // in the fixed order of ordered_sum32 (hitl_host.h; the host-driven loop adds them the same way): 32 lanes take the terms
-  // b = lane, lane + 32, ... in ascending order, then the 32 lane sums are added from lane 0 up.  Every partial -- and the
-  // loop state -- is requested in ONE round of loads by the whole workgroup (both linearisation buffers: which one is the
-  // candidate's is only known once the state has arrived) and staged through LDS.
-  extern __shared__ double buf[];                        // 8 nblk_step + 4 nblk_lin
-  __shared__ double part[9][32];
-  __shared__ double tot[9];
-  __shared__ LmDev s_state;
-  const int tid = threadIdx.x, nthr = blockDim.x, grp = tid >> 5, j = tid & 31;
-  const int n1 = 8 * nblk_step, n2 = 2 * nblk_lin;
-  for (int e = tid; e < n1; e += nthr) buf[e] = sp[e];
-  for (int e = tid; e < n2; e += nthr) { buf[n1 + e] = lp0[e]; buf[n1 + n2 + e] = lp1[e]; }
-  if (tid == 0) s_state = *lm;
-  __syncthreads();
-  if (s_state.done) return;
-  const double* lp = buf + n1 + ((s_state.cur ^ 1) ? n2 : 0);      // the candidate's linearisation
-  if (grp < 9) {
-    double acc = 0.0;
-    if (grp < 7) { for (int b = j; b < nblk_step; b += 32) acc += buf[8 * b + grp]; }
-    else if (grp == 7) { for (int b = j; b < nblk_lin; b += 32) acc += lp[2 * b]; }
-    else { for (int b = j; b < nblk_lin; b += 32) { const double g = lp[2 * b + 1]; if (g > acc || g != g) acc = g; } }
-    part[grp][j] = acc;
-  }
-  __syncthreads();
-  if (tid < 9) {
-    double t = 0.0;
-    if (tid != 8) { for (int q = 0; q < 32; ++q) t += part[tid][q]; }
-    else { for (int q = 0; q < 32; ++q) { const double g = part[8][q]; if (g > t || g != g) t = g; } }
-    tot[tid] = t;
-  }
-  __syncthreads();
-  if (tid != 0) return;
-  const double rr = tot[0], bb = tot[1], dt_rhs = tot[2], dt_q = tot[3], step2 = tot[4], xn2 = tot[5], bad = tot[6], cand_cost = tot[7], cand_gmax = tot[8];
-  LmDev s = s_state;
-  ++s.iter;
-  const bool ok = (rr == rr) && !(rr > o.guard2 * bb);          // the factorisation did not break down
-  const double mcc = dt_rhs - 0.5 * dt_q;                        // model_cost_change; rhs = -S g
-  if (!ok || bad > 0.0 || !(mcc == mcc) || mcc < 0.0) {         // invalid step
-    ++s.unsuccessful;
-    if (++s.invalid_run >= 5) { s.term = HITL_FAILURE; s.done = 1; }
-    else s.radius *= 0.5;                                        // LevenbergMarquardtStrategy::StepIsInvalid
-  } else {
-    s.invalid_run = 0;
-    ++s.lin_calls;
-    const bool par_tol = sqrt(step2) <= o.parameter_tolerance * (sqrt(xn2) + o.parameter_tolerance);
-    const double cost_change = s.cost - cand_cost;
-    const bool fun_tol = fabs(cost_change) <= o.function_tolerance * s.cost;
-    if (!o.late && (par_tol || fun_tol)) { s.term = HITL_CONVERGENCE; s.done = 1; }
-    else {
-      const double rho = cost_change / mcc;
-      if (rho > o.min_relative_decrease) {
-        ++s.successful;
-        s.cur ^= 1;
-        s.cost = cand_cost; s.gmax = cand_gmax;
-        if (s.gmax <= o.gradient_tolerance) { s.term = HITL_CONVERGENCE; s.done = 1; }
-        else if (o.late && (par_tol || fun_tol)) { s.term = HITL_CONVERGENCE; s.done = 1; }
-        else {
-          const double q = 2.0 * rho - 1.0;
-          s.radius = fmin(o.max_radius, s.radius / fmax(1.0 / 3.0, 1.0 - q * q * q));
-          s.decrease_factor = 2.0;
-        }
-      } else {
-        ++s.unsuccessful;
-        s.radius /= s.decrease_factor; s.decrease_factor *= 2.0;
-        if (s.radius < o.min_radius) { s.term = HITL_CONVERGENCE; s.done = 1; }
-      }
-    }
-  }
-  if (!s.done && s.iter >= o.max_iter) { s.term = HITL_NO_CONVERGENCE; s.done = 1; }
-  *lm = s;
-  progress[1] = (double)s.done; progress[2] = (double)s.term; progress[3] = s.cost; progress[4] = s.radius;
-  __threadfence_system();
-  progress[0] = (double)s.iter;                                  // last: the host polls this word
-}
-
-void launch_lm_decide(hipStream_t st, LmDev* lm, LmOpts o, const double* step_partials, int nblk_step, const double* lin_partials0,
-                      const double* lin_partials1, int nblk_lin, double* progress_pinned) {
-  const size_t lds = sizeof(double) * ((size_t)8 * nblk_step + (size_t)4 * nblk_lin);
-  static bool raised = false;
-  if (!raised) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lm_decide), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); raised = true; }
-  hipLaunchKernelGGL(k_lm_decide, dim3(1), dim3(1024), lds, st, lm, o, step_partials, nblk_step, lin_partials0, lin_partials1, nblk_lin, progress_pinned);
-}
-size_t lm_decide_lds_bytes(int nblk_step, int nblk_lin) { return sizeof(double) * ((size_t)8 * nblk_step + (size_t)4 * nblk_lin); }
 
 void launch_spmv_step(hipStream_t st, int n_poses, int npad, const FactorView& fv, const LinView& lin,
                       const double* scale, const double* dt, const double* rhs, const double* x, double* q, double* xc,

@@ -1,0 +1,35 @@
+"""Development helper: wall clock of C4 (or POSES=...) re-solves with the host-driven and the device-driven LM loop (test hook device_lm), modes A and C."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import hitl_slam_amd as H
+from tools import hitl_synth as S
+n, m = int(os.environ.get("POSES", 50000)), int(os.environ.get("OBS", 400))
+p = S.params(n, m, seed=20264102, poses_per_floor=200 if n >= 400 else n // 2)
+gt, init, cov = S.poses(p)
+off, px, py, nx, ny = S.scans(p)
+rows = S.constraints(p, gt, max(1, n // 1000), kind=4)
+corr = None
+res = {}
+for rep in range(2):
+  for tag, hooks in (("host", dict(device_lm=0)), ("device", dict(device_lm=1)), ("device ahead 1", dict(device_lm=1, lm_ahead=1)), ("device ahead 6", dict(device_lm=1, lm_ahead=6))):
+    H.set_test_switch(None)
+    for k, v in hooks.items():
+        H.set_test_switch(k, v)
+    s = H.Solver()
+    s.set_map(off, px, py, nx, ny, cov)
+    s.set_human_constraints(rows)
+    if corr is None:
+        s.find_correspondences(init, 3); corr = s.get_correspondences()
+    else:
+        s.set_correspondences(*corr)
+    out = []
+    for mode in (H.MODE_ODOM_HC, H.MODE_JOINT):
+        s.solve(mode, init)
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter(); po, sm = s.solve(mode, init); ts.append((time.perf_counter() - t0) * 1e3)
+        res.setdefault((tag, mode), []).append(min(ts))
+        out.append("mode %d: %.3f ms (%d it, cost %.15g, %.1f us/it)" % (mode, min(ts), sm.iterations, sm.final_cost, 1e3 * min(ts) / max(sm.iterations, 1)))
+    print("%-16s %s" % (tag, " | ".join(out)), flush=True)
+    s.close()
