@@ -671,6 +671,7 @@ class Solver(SolverBase):
 
     def find_correspondences(self, poses_xyt, window):
         pin = _as(poses_xyt, np.float32).reshape(-1)
+        assert pin.size == 3 * self.n_poses, "poses_xyt must hold every pose of the (global) map: the C ABI takes a bare pointer"
         self._check(self._fn("find_corr")(self._h, _ptr(pin, _f32p), int(window)), "find_corr")
 
 

@@ -2181,8 +2181,18 @@ __global__ void k_sep_build(CrView red, const double* __restrict__ rec_all, int 
 __global__ void k_sep_scatter(int B, const double* __restrict__ rec_all, int rec_len, const double* __restrict__ x2, SepGeom gm,
                               double* __restrict__ dt, double* __restrict__ scale) {
   const int BB = B * B, me = gm.rank, Wb = gm.Wb;
+  // A breakdown of the separator chain (or of a rank's Schur complement feeding it) shows as a non-finite entry SOMEWHERE in x2 --
+  // maybe only at another rank's separators.  Every rank solves the same chain: each plants a NaN in an owned row when any entry is
+  // not finite, so the step scalars of ALL ranks report the step as invalid (slot `bad`) and the LM loop raises the damping, as
+  // the interface-column form does when its dense solve fails
+  __shared__ int s_bad;
+  if (threadIdx.x == 0) s_bad = 0;
+  __syncthreads();
+  for (int t = threadIdx.x; t < 2 * gm.world * B; t += blockDim.x) if (!isfinite(x2[t])) s_bad = 1;
+  __syncthreads();
+  const double poison = s_bad ? __builtin_nan("") : 0.0;
   for (int t = threadIdx.x; t < B; t += blockDim.x) {
-    dt[3 * gm.own_lo + t] = x2[(size_t)(2 * me) * B + t];
+    dt[3 * gm.own_lo + t] = x2[(size_t)(2 * me) * B + t] + poison;
     dt[3 * gm.r_pose0 + t] = x2[(size_t)(2 * me + 1) * B + t];
   }
   for (int t = threadIdx.x; t < 3 * gm.halo_lo; t += blockDim.x) {          // the last halo_lo poses of the previous rank's R

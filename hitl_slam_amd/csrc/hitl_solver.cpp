@@ -502,6 +502,20 @@ int prepare(hitl_solver* s, int mode, const float* poses_ref, const float* poses
       CrSource probe = {};
       probe.Wb = Wb;
       double mine_s = (Wb == band_target && cr_sep_applies(s->sep_chain_view(), probe, s->wv.p, s->dt.p)) ? 1.0 : 0.0;
+      if (mine_s != 0.0) {
+        // the separator form's buffers are allocated BEFORE the ranks agree on it and a failure counts as "does not apply here":
+        // a rank that cannot allocate must not return alone while the others walk into the LM loop's collectives
+        auto alloc = [&]() -> int {
+          const size_t rl = (size_t)sep_rec_len(s->B), nn = (size_t)2 * s->world, bb2 = nn * s->B * s->B;
+          TRY(s->sep_rec.resize(rl)); TRY(s->sep_all.resize(rl * s->world));
+          TRY(s->sep_w2.resize(nn * s->B)); TRY(s->sep_x2.resize(nn * s->B));
+          TRY(s->sep_D.resize(bb2)); TRY(s->sep_L.resize(bb2)); TRY(s->sep_Dinv.resize(bb2)); TRY(s->sep_Gl.resize(bb2)); TRY(s->sep_Gr.resize(bb2));
+          const size_t np2 = (size_t)cr_contrib_slots((int)nn);
+          TRY(s->sep_P.resize(4 * np2 * s->B * s->B)); TRY(s->sep_Pw.resize(4 * np2 * s->B));
+          return HITL_OK;
+        };
+        if (alloc() != HITL_OK) { (void)hipGetLastError(); mine_s = 0.0; }
+      }
       std::vector<double> all_s((size_t)s->world);
       TRY(comm_allgather(s, &mine_s, all_s.data(), sizeof(mine_s)));
       s->dist_sep = true;
@@ -520,13 +534,7 @@ int prepare(hitl_solver* s, int mode, const float* poses_ref, const float* poses
       for (int p = 0; p < gm.halo_lo; ++p) for (int c = 0; c < 3; ++c) hidx.push_back(3 * (s->own_lo - gm.halo_lo + p) + c);
       for (int p = 0; p < gm.halo_hi; ++p) for (int c = 0; c < 3; ++c) hidx.push_back(3 * (s->own_hi + p) + c);
       s->n_halo = (int)hidx.size();
-      const size_t rl = (size_t)sep_rec_len(s->B), nn = (size_t)2 * s->world, bb2 = nn * s->B * s->B;
-      TRY(s->sep_rec.resize(rl)); TRY(s->sep_all.resize(rl * s->world));
-      TRY(s->sep_w2.resize(nn * s->B)); TRY(s->sep_x2.resize(nn * s->B));
-      TRY(s->sep_D.resize(bb2)); TRY(s->sep_L.resize(bb2)); TRY(s->sep_Dinv.resize(bb2)); TRY(s->sep_Gl.resize(bb2)); TRY(s->sep_Gr.resize(bb2));
-      const size_t np2 = (size_t)cr_contrib_slots((int)nn);
-      TRY(s->sep_P.resize(4 * np2 * s->B * s->B)); TRY(s->sep_Pw.resize(4 * np2 * s->B));
-      TRY(s->dt.zero(s->stream));          // rows outside the chain and the filled halo entries stay zero
+      TRY(s->dt.zero(s->stream));          // rows outside the chain and the filled halo entries stay zero (the separator buffers exist: allocated above)
     } else {
     if (s->rank > 0) for (int p = 0; p < Wi; ++p) for (int c = 0; c < 3; ++c) hidx.push_back(3 * (s->own_lo - Wi + p) + c);
     if (s->rank < s->world - 1) for (int p = 0; p < Wi; ++p) for (int c = 0; c < 3; ++c) hidx.push_back(3 * (s->own_hi + p) + c);
