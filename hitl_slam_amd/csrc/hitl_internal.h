@@ -45,6 +45,10 @@ struct DevSwitches {
   int kd_redo_cap = 1 << 18;       // "kd_redo_cap": entries of the redo list behind the fast attempt (shrunk to force the full-depth repeat)
   bool cand_tf_check = false;      // "cand_tf_check": the device's candidate transforms held to the host routine, bit for bit
   size_t cand_tile_bytes = (size_t)4 << 30;   // "cand_tile_bytes": candidate-table budget of the tiled search (shrunk to force several tiles)
+  // failure injection on ONE rank of a submap solve (tests/test_submap_gpu.py: every rank must come back with an error, none may
+  // be left waiting in a collective)
+  bool fail_prepare = false;       // "fail_prepare": the rank-local part of prepare() reports HITL_ERR_OUT_OF_MEMORY
+  int poison_step_from = 0;        // "poison_step_from" = k > 0: from LM iteration k on this rank reports its step as not finite
 };
 const DevSwitches& dev_switches();
 void read_dev_switches();          // hitl_solver_create only
@@ -164,6 +168,7 @@ void launch_linearize_stf(hipStream_t st, const MapView& map, const PairView& pr
                           const LmDev* lm = nullptr, const double* x_alt = nullptr, double* pairRJ_alt = nullptr,
                           const void* pose_recs = nullptr /* launch_build_stf_pose_recs: one stf_pose_rec_bytes() record per pose, or null */);
 size_t stf_pose_rec_bytes();
+
 void launch_build_stf_pose_recs(hipStream_t st, const MapView& map, const PairView& pr, void* recs);
 void launch_pack_obs(hipStream_t st, int64_t n, const float* px, const float* py, const float* nx, const float* ny,
                      float4* obs);

@@ -564,6 +564,7 @@ static int linear_solve_and_step_dist(hitl_solver* s, const FactorView& fv, int 
     TRY(spin_sync(s));                     // host vectors above stay alive until here
     StepScalars loc;
     TRY(finish_step_partials(s, nullptr, nullptr, &loc));
+    if (dev_switches().poison_step_from > 0 && s->lm_iter >= dev_switches().poison_step_from) loc.bad += 1.0;   // test hook: this rank's step "is not finite"
     if (spec) TRY(finish_linearize(s, fv, &lloc));
     double r2[7] = {loc.dt_rhs, loc.dt_q, loc.step2, loc.xn2, loc.bad, lloc.cost, lloc.gmax};
     TRY(comm_allgather(s, r2, all2.data(), sizeof(r2)));
@@ -894,6 +895,7 @@ int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float* poses
   while (!done) {
     if (iter >= o.max_num_iterations) { term = HITL_NO_CONVERGENCE; break; }
     ++iter;
+    s->lm_iter = iter;
     RoctxRange r_iter("hitl:lm iteration");
     int lin_iters = 0;
     bool ok = true;

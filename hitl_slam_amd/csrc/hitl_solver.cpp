@@ -346,6 +346,7 @@ int check_ready(hitl_solver* s, int mode) {
 // the rank-local part of prepare: everything that can fail before the ranks talk to each other
 static int prepare_local(hitl_solver* s, int mode, const float* poses_ref, const float* poses_global, int Wb) {
   HIP_TRY(hipSetDevice(s->device));
+  if (dev_switches().fail_prepare) return fail(HITL_ERR_OUT_OF_MEMORY, "prepare: failure injected by the test hook fail_prepare");
   TRY(ensure_empty_pair_tables(s));
   TRY(ensure_work(s, Wb));
   if (s->opt.stf_moments && mode != HITL_MODE_ODOM_HC && s->moments_of != s->corr_generation) {
@@ -591,6 +592,8 @@ extern "C" int hitl_test_set_switch(const char* name, long long value) {
   else if (k == "kd_redo_cap") d.kd_redo_cap = (int)std::max(1ll, std::min((long long)(1 << 18), value));
   else if (k == "cand_tf_check") d.cand_tf_check = value != 0;
   else if (k == "cand_tile_bytes") d.cand_tile_bytes = (size_t)std::max(1ll, value);
+  else if (k == "fail_prepare") d.fail_prepare = value != 0;
+  else if (k == "poison_step_from") d.poison_step_from = (int)std::max(0ll, value);
   else return -1;
   return 0;
 }

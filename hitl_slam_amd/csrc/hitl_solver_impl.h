@@ -25,6 +25,7 @@ struct hitl_solver {
   DevArray<unsigned> lm_arrivals;             //   workgroups of the deciding launch that have stored their partials (k_assemble)
   std::vector<hipEvent_t> lm_events;   // pairs bracketing k_linearize_stf launches queued ahead (device-driven loop)
   int64_t sync_seq = 0;
+  int lm_iter = 0;                 // LM iteration the host-driven loop is in (test hook poison_step_from)
   double* h_partials = nullptr; // pinned, h_partials_cap doubles
   size_t h_partials_cap = 0;
   DevArray<double> step_partials;   // spmv workgroups x 8

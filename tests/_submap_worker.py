@@ -42,6 +42,13 @@ def main():
     M = 48
     if os.environ.get("HITL_TEST_COLUMNS_RANK") == str(rank):       # ONE rank asks for the interface-column form: all must follow
         os.environ["HITL_DIST_COLUMNS"] = "1"
+    # failure injection on ONE rank (tests/test_submap_gpu.py::test_a_failure_on_one_rank_...): "hook=value" for the library's test
+    # hooks (hitl_test_set_switch; per process), or "nan_pose" = this rank hands in a NaN at one of its own poses
+    inject = os.environ.get("HITL_TEST_INJECT", "")
+    inject_here = inject and os.environ.get("HITL_TEST_INJECT_RANK") == str(rank)
+    if inject_here and "=" in inject:
+        k, _, v = inject.partition("=")
+        H.set_test_switch(k, int(v))
     opt = H.default_options()
     opt.rank, opt.world_size = rank, world
     opt.device = rank % max(torch.cuda.device_count(), 1)
@@ -64,12 +71,15 @@ def main():
     lens = corr[2][1:] - corr[2][:-1]
     if os.environ.get("HITL_TEST_EXPECT_FAIL"):
         # a solve every rank must refuse together (no rank may be left waiting in a collective)
+        pin = np.array(prob.init, np.float32)
+        if inject_here and inject == "nan_pose":
+            pin[(b + e) // 2, 0] = np.nan
+        status, err = 0, ""
         try:
-            s.solve(mode, prob.init)
-            err = ""
+            s.solve(mode, pin)
         except H.HitlError as ex:
-            err = str(ex)
-        json.dump(dict(rank=rank, error=err), open("%s.%d" % (out_path, rank), "w"))
+            status, err = ex.status, str(ex)
+        json.dump(dict(rank=rank, error=err, status=status), open("%s.%d" % (out_path, rank), "w"))
         s.close()
         dist.destroy_process_group()
         return

@@ -220,3 +220,29 @@ def test_separator_form_at_other_band_widths(tmp_path, world, window, nper, halo
         Sg = np.array(x["cov"])
         scale = np.abs(So[b:e]).max(axis=(1, 2))[:, None, None] + 1e-300
         assert (np.abs(Sg[b:e] - So[b:e]) / scale).max() < 1e-6
+
+
+@pytest.mark.parametrize("inject, mode, cuts", [("fail_prepare=1", 2, None), ("fail_prepare=1", 0, "0,39,81,120"), ("nan_pose", 2, None),
+                                                ("poison_step_from=2", 2, None), ("poison_step_from=1", 0, "0,39,81,120")])
+def test_a_failure_on_one_rank_fails_every_rank(tmp_path, inject, mode, cuts):
+    """one rank of a submap solve fails -- (a) in the rank-local part of prepare (an allocation failure, injected by
+    the library's test hook on rank 1 only), (b) inside the LM loop (rank 1 hands in a NaN at one of its own poses; rank 1's steps
+    stop being finite from some iteration on) -- and EVERY rank returns a non-zero status within the timeout: the verdicts travel
+    in prepare's exchange and in the scalars that end every LM iteration, so nobody is left waiting in a collective.  Two and three
+    ranks share the test box's GPU over gloo; a hung rank would run into the subprocess timeout."""
+    world = 3 if cuts else 2
+    out = str(tmp_path / "res")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", HITL_TEST_EXPECT_FAIL="1", HITL_TEST_INJECT=inject,
+               HITL_TEST_INJECT_RANK="1")
+    if cuts:
+        env["HITL_TEST_CUTS"] = cuts
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_submap_worker.py"), out, str(mode), "120"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = [json.load(open("%s.%d" % (out, k))) for k in range(world)]
+    assert all(x["status"] != 0 for x in res), res
+    if inject.startswith("fail_prepare"):
+        assert "injected" in res[1]["error"] and all("another rank failed" in res[k]["error"] for k in range(world) if k != 1), res
+    else:                                    # the LM loop ends with FAILURE on every rank alike (status 7 = HITL_ERR_SOLVER_FAILURE)
+        assert len({x["status"] for x in res}) == 1 and "FAILURE" in res[0]["error"], res
