@@ -719,10 +719,10 @@ __device__ unsigned long long g_cr_probe[3 * 64];
 // RS: the chain's last node is a separator (CrView::rsep), known at compile time: the plain instantiations keep the code -- and the
 // registers -- they had before submap ranks learnt the separator form (a runtime flag cost the first stage 3 % and the 3 x 3
 // tiles of the one-pose band 8 %: same-box A/B, tools/dev/lib_ab.sh).
-template <int B, int KIND, bool RS = false>
-__global__ __launch_bounds__((B >= 12 || KIND == 1) ? 512 : 1024) __attribute__((amdgpu_waves_per_eu((KIND == 1 && B == 9) ? HITL_CR_WAVES : 4)))
-void k_cr_chunk(CrView cr, CrStage sg_in, CrSource src, double* w, double* x) {
-  extern __shared__ double lds[];
+// (the body of a chunk stage as a device function: k_cr_chunk launches it one chunk per workgroup; k_cr_tail runs the last chunk stage,
+// the top and both back-substitutions in ONE launch)
+template <int B, int KIND, bool RS>
+__device__ __forceinline__ void cr_chunk_body(CrView cr, CrStage sg_in, CrSource src, double* w, double* x, double* lds, int chunk_, int tid_, int nthr_) {
   CrStage sg = sg_in;
   if (KIND == 1) { sg.top = 0; sg.has_prev = 0; sg.nrhs = 1; sg.nsl = sg.M + 1; sg.S = 1; }
   if (cr.lm != nullptr) {                                  // device-driven LM loop (uniform branch)
@@ -739,17 +739,17 @@ void k_cr_chunk(CrView cr, CrStage sg_in, CrSource src, double* w, double* x) {
   double* sL = sD + (size_t)nsl * BB;                     // nsl tiles: L_u (coupling u <-> u - s), later P_b of an eliminated u
   double* sG = sL + (size_t)nsl * BB;                     // per wave: Gl, Gr of the node it is eliminating (2 tiles)
   const int NR = sg.nrhs;                                 // right-hand sides; vector v of local node u lives at [(v * nsl + u) * B]
-  double* sW = sG + (size_t)(blockDim.x >> 6) * 2 * BB;   // NR x nsl vectors: right-hand sides
+  double* sW = sG + (size_t)(nthr_ >> 6) * 2 * BB;   // NR x nsl vectors: right-hand sides
   double* sCa = sW + (size_t)NR * nsl * B;                // NR x nsl vectors: Gl_u^T w_u (for a)
   double* sCb = sCa + (size_t)NR * nsl * B;               // NR x nsl vectors: Gr_u^T w_u (for b)
   double* accR = sCb + (size_t)NR * nsl * B;              // tile: contributions to local node 0
   double* accL = accR + BB;                               // tile: contributions to local node M
   double* accWR = accL + BB;                              // NR vectors
   double* accWL = accWR + (size_t)NR * B;                 // NR vectors
-  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int tid = tid_, nthr = nthr_;
   const int wave = tid >> 6, lane = tid & 63, NW = nthr >> 6;
   CR_PROBE(0);
-  const int64_t base = (int64_t)blockIdx.x * M;            // in stage nodes
+  const int64_t base = (int64_t)chunk_ * M;            // in stage nodes
   const int64_t nst = RS ? ((int64_t)cr.nsb - 2) / S + 2 : ((int64_t)cr.nsb + S - 1) / S;   // stage nodes alive: 0 .. nst-1 (cr_stage_nodes)
   // local slots that exist: u with base + u < nst
   const int u_last = (int)((nst - 1 - base < M) ? (nst - 1 - base) : M);     // >= 0
@@ -1030,10 +1030,10 @@ void k_cr_chunk(CrView cr, CrStage sg_in, CrSource src, double* w, double* x) {
     double* PRn = cr.P + (size_t)(sg.next_par * 2 + 1) * sg.np * BB;
     double* WLn = cr.Pw + (size_t)(sg.next_par * 2 + 0) * sg.np * B;
     double* WRn = cr.Pw + (size_t)(sg.next_par * 2 + 1) * sg.np * B;
-    const size_t c0 = (size_t)blockIdx.x, c1 = c0 + 1;
+    const size_t c0 = (size_t)chunk_, c1 = c0 + 1;
     for (int e = tid; e < BB; e += nthr) {
       PRn[c0 * BB + e] = accR[e];
-      if (blockIdx.x == 0) PLn[e] = 0.0;                                           // node 0 has no chunk on its left
+      if (chunk_ == 0) PLn[e] = 0.0;                                           // node 0 has no chunk on its left
       if (has_rb) { PLn[c1 * BB + e] = accL[e]; cr.L[(size_t)CR_ADDR(base + rbs) * BB + e] = sL[(size_t)rbs * BB + e]; }
       if (last_is_rb) PRn[c1 * BB + e] = 0.0;                                      // the last node has no chunk on its right
     }
@@ -1042,7 +1042,7 @@ void k_cr_chunk(CrView cr, CrStage sg_in, CrSource src, double* w, double* x) {
         const int rv = e2 / B, e = e2 % B;
         const size_t vo = pws * rv;
         WRn[vo + c0 * B + e] = accWR[e2];
-        if (blockIdx.x == 0) WLn[vo + e] = 0.0;
+        if (chunk_ == 0) WLn[vo + e] = 0.0;
         if (has_rb) WLn[vo + c1 * B + e] = accWL[e2];
         if (last_is_rb) WRn[vo + c1 * B + e] = 0.0;
       }
@@ -1081,6 +1081,14 @@ void k_cr_chunk(CrView cr, CrStage sg_in, CrSource src, double* w, double* x) {
   CR_PROBE(probe_slot++);
 }
 
+
+template <int B, int KIND, bool RS = false>
+__global__ __launch_bounds__((B >= 12 || KIND == 1) ? 512 : 1024) __attribute__((amdgpu_waves_per_eu((KIND == 1 && B == 9) ? HITL_CR_WAVES : 4)))
+void k_cr_chunk(CrView cr, CrStage sg_in, CrSource src, double* w, double* x) {
+  extern __shared__ double lds[];
+  cr_chunk_body<B, KIND, RS>(cr, sg_in, src, w, x, lds, (int)blockIdx.x, (int)threadIdx.x, (int)blockDim.x);
+}
+
 // Back-substitution of one stage: x is known at the chunk's two boundary nodes; thread (u, r) owns row r of interior
 // node u, fetches its three coefficient rows ONCE (all loads of the launch are in flight together), forms
 // v = (Dinv_u w_u)[r] and then only touches LDS: x_u[r] = v - Gl_u[r,:] x_{u-s} - Gr_u[r,:] x_{u+s}, level by level.
@@ -1088,15 +1096,13 @@ void k_cr_chunk(CrView cr, CrStage sg_in, CrSource src, double* w, double* x) {
 // workgroups of a chunk land on the SAME XCD one after the other (workgroups go to the 8 XCDs round-robin by index): the
 // chunk's 3 x 81 x (M - 1) coefficient doubles come from HBM once and from that XCD's L2 for the other right-hand sides,
 // instead of nrhs times from HBM (a (chunks, nrhs) grid puts the workgroups of a chunk ~1000 dispatches apart).
-template <int B, bool RS = false>
-__global__ __launch_bounds__(1024) void k_cr_chunk_back(CrView cr, int S, int M, int top, const double* __restrict__ w, double* __restrict__ x, size_t wstride,
-                                                        int chunks, int nrhs) {
-  if (cr.lm != nullptr && cr.lm->done) return;
-  extern __shared__ double sx[];                         // (M + 1) * B
-  const int tid = threadIdx.x;
-  int chunk = blockIdx.x, rv = 0;
+template <int B, bool RS>
+__device__ __forceinline__ void cr_chunk_back_body(CrView cr, int S, int M, int top, const double* __restrict__ w, double* __restrict__ x, size_t wstride,
+                                                   int chunks, int nrhs, double* sx, int block_, int tid_, int nthr_) {
+  const int tid = tid_;
+  int chunk = block_, rv = 0;
   if (nrhs > 1) {
-    const int xcd = blockIdx.x & 7, t = blockIdx.x >> 3;
+    const int xcd = block_ & 7, t = block_ >> 3;
     rv = t % nrhs;
     chunk = (t / nrhs) * 8 + xcd;
     if (chunk >= chunks) return;
@@ -1124,7 +1130,7 @@ __global__ __launch_bounds__(1024) void k_cr_chunk_back(CrView cr, int S, int M,
 #pragma unroll
     for (int c = 0; c < B; ++c) { v += Di[c] * wk[c]; gl[c] = Gl[c]; gr[c] = Gr[c]; }
   }
-  for (int e = tid; e < (M + 1) * B; e += blockDim.x) sx[e] = 0.0;
+  for (int e = tid; e < (M + 1) * B; e += nthr_) sx[e] = 0.0;
   __syncthreads();
   if (tid < 2 * B) {                                      // the two boundary nodes (known)
     const int ub = (tid < B) ? 0 : (RS ? u_last : M), rr = tid % B;
@@ -1147,6 +1153,90 @@ __global__ __launch_bounds__(1024) void k_cr_chunk_back(CrView cr, int S, int M,
       x[(size_t)((base + u) * S) * B + r] = acc;
     }
     __syncthreads();
+  }
+}
+
+
+template <int B, bool RS = false>
+__global__ __launch_bounds__(1024) void k_cr_chunk_back(CrView cr, int S, int M, int top, const double* __restrict__ w, double* __restrict__ x, size_t wstride,
+                                                        int chunks, int nrhs) {
+  if (cr.lm != nullptr && cr.lm->done) return;
+  extern __shared__ double sx[];                         // (M + 1) * B
+  cr_chunk_back_body<B, RS>(cr, S, M, top, w, x, wstride, chunks, nrhs, sx, (int)blockIdx.x, (int)threadIdx.x, (int)blockDim.x);
+}
+
+// ===========================================================================================
+// k_cr_tail (round 5): the LAST chunk stage, the top, the top's back-substitution and that stage's own back-substitution in ONE
+// launch.  The upper stages are chains of dependent latency on a handful of workgroups (C4: 33 chunks, then one workgroup, then the
+// same again backwards): as four launches they pay four launch boundaries (~4 us each in the kernel trace, whatever the work) for
+// ~60 us of work.  Here workgroups 0 .. C-1 run the chunk stage and announce themselves; workgroup C waits for all of them, runs the
+// top (forward, root, back-substitution: x at every node the chunk stage kept) and releases them; they then back-substitute their
+// interiors from the tiles they have just written.  All C + 1 workgroups are resident at once (one per compute unit; the host only
+// takes this path for C + 1 <= kCrTailMaxGroups), so the waits cannot deadlock; they are bounded anyway (a wait that runs out flags
+// the launch as failed -- ticket[2] -- instead of hanging the device).
+// Ordering: every thread's stores have reached the L2 (s_waitcnt) before the workgroup barrier; then ONE thread makes them visible
+// device-wide (release fence: one L2 write-back per workgroup, not per wave) and counts the workgroup in with a device-scope atomic.
+// The waiting side polls with device-scope loads, then ONE thread invalidates (acquire fence) before the workgroup proceeds.
+// Tickets: [0] arrivals, [1] released, [2] a wait ran out, [3] departures; the last chunk workgroup to leave clears them for the next
+// launch (launches of a stream do not overlap), so the host keeps no state and a launch skipped by lm->done leaves them untouched.
+// KIND2: 0 = the chunk stage folds a previous stage's contributions (C4: the stage above the first one); 1 = it IS the first stage and
+// cuts its tiles from the band rows (short chains -- C2, Figure-8-size maps: the whole linear solve is this one launch).
+// ===========================================================================================
+constexpr int kCrTailMaxGroups = 128;
+__device__ __forceinline__ bool cr_tail_wait(const unsigned* word, unsigned target) {
+  for (unsigned spins = 0; spins < (1u << 22); ++spins) {
+    if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
+    __builtin_amdgcn_s_sleep(4);
+  }
+  return false;
+}
+
+template <int B, int KIND2>
+__global__ __launch_bounds__(1024) void k_cr_tail(CrView cr, CrStage sg2, CrStage sgt, CrSource src, double* w, double* x, int chunks2, unsigned* ticket) {
+  if (cr.lm != nullptr && cr.lm->done) return;
+  extern __shared__ double lds[];
+  __shared__ int s_ok;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  if ((int)blockIdx.x < chunks2) {
+    cr_chunk_body<B, KIND2, false>(cr, sg2, src, w, x, lds, (int)blockIdx.x, tid, nthr);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __hip_atomic_fetch_add(&ticket[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_ok = cr_tail_wait(&ticket[1], 1u) ? 1 : 0;
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (s_ok) cr_chunk_back_body<B, false>(cr, sg2.S, sg2.M, 0, w, x, (size_t)0, chunks2, 1, lds, (int)blockIdx.x, tid, nthr);
+    if (tid == 0) {
+      if (!s_ok) __hip_atomic_store(&ticket[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__hip_atomic_fetch_add(&ticket[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)chunks2 - 1u) {     // the last one out
+        __hip_atomic_store(&ticket[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ticket[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ticket[3], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  } else {
+    if (tid == 0) {
+      s_ok = cr_tail_wait(&ticket[0], (unsigned)chunks2) ? 1 : 0;
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (s_ok) {
+      CrSource none = {};
+      cr_chunk_body<B, 0, false>(cr, sgt, none, w, x, lds, 0, tid, nthr);
+      __builtin_amdgcn_s_waitcnt(0);
+      __syncthreads();
+      cr_chunk_back_body<B, false>(cr, sgt.S, sgt.M, 1, w, x, (size_t)0, 1, 1, lds, 0, tid, nthr);
+      __builtin_amdgcn_s_waitcnt(0);
+      __syncthreads();
+    }
+    if (tid == 0) {
+      if (!s_ok) __hip_atomic_store(&ticket[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __hip_atomic_store(&ticket[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);         // (also after a failed wait: nobody is left waiting)
+    }
   }
 }
 
@@ -1835,7 +1925,44 @@ static bool cr_factor_fused(hipStream_t st, const CrView& cr, double* w, double*
     if (bthr > 1024) return false;                                           // never with M <= 64, B <= 12 (or M = 128, B = 3)
   }
   if (validate) return true;
+  // the last chunk stage + the top + both their back-substitutions as ONE launch (k_cr_tail)
+  const int t2 = pl.n - 2;
+  int tail_chunks = 0;
+  bool tail = phase == 3 && w != nullptr && x != nullptr && nrhs == 1 && !cr.rsep && pl.n >= 2 && B <= 9 && cr.ticket != nullptr && dev_switches().cr_tail &&
+              !(t2 == 0 && seq0);
+  if (tail) {
+    const CrStage& g2 = pl.st[t2];
+    tail_chunks = (int)((cr_stage_nodes(cr, g2.S) - 1 + g2.M - 1) / g2.M);
+    if (tail_chunks < 1 || tail_chunks + 1 > kCrTailMaxGroups || (g2.M + 1) * B > 1024) tail = false;
+  }
   for (int t = 0; t < pl.n && (phase & 1); ++t) {
+    if (tail && t >= t2) {
+      if (t > t2) continue;
+      const CrStage& g2 = pl.st[t2];
+      const CrStage& gt = pl.st[t2 + 1];
+      const bool use_src2 = (src != nullptr && t2 == 0);
+      const bool kind1 = use_src2 && !g2.has_prev && g2.S == 1 && 3 * src->Wb == B;
+      const int thr = 1024;
+      size_t lds = cr_chunk_lds_bytes(g2.nsl - 1, B, thr, 1) + (use_src2 ? cr_chunk_src_extra(g2.nsl, B, thr, src->Wb, 1) : 0);
+      lds = std::max(lds, cr_chunk_lds_bytes(gt.nsl - 1, B, thr, 1));
+      lds = std::max(lds, sizeof(double) * (size_t)(std::max(g2.M, gt.M) + 1) * B);
+      if (lds > 128 * 1024) { tail = false; }
+      else {
+        static bool raised_tail = false;
+        if (!raised_tail) {
+          raised_tail = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cr_tail<B, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess &&
+                        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cr_tail<B, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess;
+          if (!raised_tail) (void)hipGetLastError();
+        }
+        if (!raised_tail) tail = false;
+        else {
+          CrSource none2 = {};
+          if (kind1) hipLaunchKernelGGL((k_cr_tail<B, 1>), dim3(tail_chunks + 1), dim3(thr), lds, st, cr, g2, gt, *src, w, x, tail_chunks, cr.ticket);
+          else hipLaunchKernelGGL((k_cr_tail<B, 0>), dim3(tail_chunks + 1), dim3(thr), lds, st, cr, g2, gt, use_src2 ? *src : none2, w, x, tail_chunks, cr.ticket);
+          continue;
+        }
+      }
+    }
     const CrStage& g = pl.st[t];
     const int64_t alive = cr_stage_nodes(cr, g.S);
     const int chunks = g.top ? 1 : (int)((alive - 1 + g.M - 1) / g.M);       // chunks with at least one interior or boundary-M node
@@ -1858,6 +1985,7 @@ static bool cr_factor_fused(hipStream_t st, const CrView& cr, double* w, double*
   }
   if (w != nullptr && x != nullptr && (phase & 2)) {
     for (int t = pl.n - 1; t >= 0; --t) {
+      if (tail && t >= t2) continue;                       // k_cr_tail has back-substituted these two stages already
       const CrStage& g = pl.st[t];
       const int64_t alive = cr_stage_nodes(cr, g.S);
       if (alive <= 1) continue;

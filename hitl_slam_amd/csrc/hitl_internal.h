@@ -37,6 +37,8 @@ struct DevSwitches {
   bool cr_seq = true;              // "cr_seq" = 0: the first stage of the LM path's factor-solve as a cyclic-reduction stage (rounds 2-4)
                                    // instead of the two-way sequential order (k_cr_seq, round 5)
   int cr_seq_m = 0;                // "cr_seq_m": chunk size of that first stage (0 = the default)
+  bool cr_tail = true;             // "cr_tail" = 0: the last chunk stage, the top and their back-substitutions as four launches (rounds 2-4)
+                                   // instead of one (k_cr_tail, round 5)
   bool stf_addr64 = false;         // "stf_addr64": the 64-bit addressing instantiations of k_linearize_stf (arrays beyond 4 GB)
   bool device_lm = false;          // "device_lm": accept / reject / terminate decided on the device (k_lm_decide), iterations queued ahead.
                                    // Measured (round 3): 4-8 us per iteration SLOWER than the host-driven loop on every workload
@@ -147,6 +149,7 @@ struct CrView {             // block-tridiagonal system + cyclic-reduction facto
   // the Schur complement of everything between the two onto them (D, L, w of both nodes + the last stage's contribution slots 0 / 1).
   // It lives at its true index nsb - 1 and takes part in every stage as the node behind the last regular one (fused stages only).
   int rsep = 0;
+  unsigned* ticket = nullptr; // 4 words of device memory, zero between launches: k_cr_tail's arrivals / release / error / departures (null: no fused tail)
 };
 // stage nodes alive at stride S (the right separator counts as one), and where stage node sn lives in D / L / w / x
 __host__ __device__ inline int64_t cr_stage_nodes(const CrView& cr, int S) {

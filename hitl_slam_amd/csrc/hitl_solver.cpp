@@ -207,6 +207,7 @@ int ensure_work(hitl_solver* s, int Wb) {
     const size_t np = (size_t)cr_contrib_slots(s->nsb);
     s->cr_pw_rhs = s->dist_mode() ? 1 + 6 * Wb : 1;       // the submap solve pushes its interface columns through the factorisation
     TRY(s->crP.resize(4 * np * s->B * s->B)); TRY(s->crPw.resize((size_t)s->cr_pw_rhs * 4 * np * s->B));
+    if (s->cr_ticket.p == nullptr) { TRY(s->cr_ticket.resize(4)); TRY(s->cr_ticket.zero(s->stream)); }
   }
   s->wb_Wb = Wb; s->wb_n = n; s->wb_pairs = s->n_pairs; s->wb_offband = s->n_offband;
   return HITL_OK;
@@ -585,6 +586,7 @@ extern "C" int hitl_test_set_switch(const char* name, long long value) {
   else if (k == "cr_unfused_build") d.cr_unfused_build = value != 0;
   else if (k == "cr_seq") d.cr_seq = value != 0;
   else if (k == "cr_seq_m") d.cr_seq_m = (int)std::max(0ll, std::min(64ll, value));
+  else if (k == "cr_tail") d.cr_tail = value != 0;
   else if (k == "stf_addr64") d.stf_addr64 = value != 0;
   else if (k == "device_lm") d.device_lm = value != 0;
   else if (k == "lm_ahead") d.lm_ahead = (int)std::max(1ll, std::min(16ll, value));

@@ -119,6 +119,7 @@ struct hitl_solver {
   DevArray<uint16_t> d_cand_table;
   DevArray<float4> kd_pts;                     // opt-in (kd_tree_search): every scan in KD in-order layout
   DevArray<uint32_t> kd_meta;                  //   original index | split plane << 16
+  DevArray<unsigned> cr_ticket;                // k_cr_tail's four ticket words (zero between launches)
   double prepare_pcie_bytes = 0.0;             // host -> device bytes of the last prepare() (factor tables): hitl_summary.pcie_bytes
   int cu_count = 256;                          // compute units of the device
   DevArray<char> stf_pose_recs;                // per-pose descriptor records of the half-wave linearisation (k_linearize_stf_r)
@@ -183,6 +184,7 @@ struct hitl_solver {
     CrView c;
     c.nsb = nsb; c.B = B; c.D = crD.p; c.L = crL.p; c.Dinv = crDinv.p; c.Gl = crGl.p; c.Gr = crGr.p;
     c.P = crP.p; c.Pw = crPw.p; c.np = cr_contrib_slots(nsb); c.pw_rhs = cr_pw_rhs;
+    c.ticket = cr_ticket.p;
     return c;
   }
 };

@@ -11,8 +11,10 @@ off, px, py, nx, ny = S.scans(p)
 rows = S.constraints(p, gt, max(1, n // 1000), kind=4)
 corr = None
 res = {}
-for rep in range(2):
-  for tag, hooks in (("host", dict(device_lm=0)), ("device", dict(device_lm=1)), ("device ahead 1", dict(device_lm=1, lm_ahead=1)), ("device ahead 6", dict(device_lm=1, lm_ahead=6))):
+for rep in range(int(os.environ.get("REPS", 2))):
+  VARIANTS = {"lm": (("host", dict(device_lm=0)), ("device", dict(device_lm=1)), ("device ahead 1", dict(device_lm=1, lm_ahead=1)), ("device ahead 6", dict(device_lm=1, lm_ahead=6))),
+            "tail": (("tail 4 launches", dict(cr_tail=0)), ("tail fused", dict(cr_tail=1)), ("fused + device lm", dict(cr_tail=1, device_lm=1)), ("4 launches + device lm", dict(cr_tail=0, device_lm=1)))}
+for tag, hooks in VARIANTS[os.environ.get("AB", "lm")]:
     H.set_test_switch(None)
     for k, v in hooks.items():
         H.set_test_switch(k, v)
