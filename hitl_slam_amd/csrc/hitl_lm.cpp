@@ -976,7 +976,13 @@ int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float* poses
     TRY(s->h_x.resize(s->npad));
     double* hx = s->h_x.p;                                 // page-locked: a direct DMA instead of a copy through a bounce buffer
     HIP_TRY(hipMemcpyAsync(hx, xcur, sizeof(double) * n3, hipMemcpyDeviceToHost, st));
+    unsigned tick[4] = {0, 0, 0, 0};
+    if (s->cr_ticket.p != nullptr) HIP_TRY(hipMemcpyAsync(tick, s->cr_ticket.p, sizeof(tick), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    if (tick[2] != 0) {                                    // a wait inside k_cr_tail ran out (never seen): leave clean tickets behind and say so
+      (void)hipMemsetAsync(s->cr_ticket.p, 0, sizeof(tick), st);
+      return fail(HITL_ERR_HIP, "the fused tail of the cyclic reduction (k_cr_tail) gave up waiting for its workgroups");
+    }
     for (int i = 0; i < n; ++i) {
       poses_out[3 * i] = (float)hx[3 * i];
       poses_out[3 * i + 1] = (float)hx[3 * i + 1];
