@@ -119,6 +119,8 @@ struct hitl_solver {
   DevArray<uint16_t> d_cand_table;
   DevArray<float4> kd_pts;                     // opt-in (kd_tree_search): every scan in KD in-order layout
   DevArray<uint32_t> kd_meta;                  //   original index | split plane << 16
+  PinnedArray<char> h_stage[2];                // staged_d2h: two page-locked pieces for large copies into pageable memory
+  hipEvent_t ev_stage[2] = {nullptr, nullptr};
   DevArray<unsigned> cr_ticket;                // k_cr_tail's four ticket words (zero between launches)
   double prepare_pcie_bytes = 0.0;             // host -> device bytes of the last prepare() (factor tables): hitl_summary.pcie_bytes
   int cu_count = 256;                          // compute units of the device

@@ -29,6 +29,8 @@ hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = reinterpret
 hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = reinterpret_cast<hipEvent_t>(calloc(1, 8)); return hipSuccess; }
+hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void*) { memset(a, 0, sizeof(*a)); a->type = hipMemoryTypeUnregistered; return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t* e) { *e = reinterpret_cast<hipEvent_t>(calloc(1, 8)); return hipSuccess; }
 hipError_t hipEventDestroy(hipEvent_t e) { free(e); return hipSuccess; }
 hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }

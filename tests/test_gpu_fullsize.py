@@ -217,3 +217,25 @@ def test_fullsize_correction_cycle_matches_oracle(big):
     # Instead: the same call twice is bit-reproducible, and the moments form of the factors gives the same blocks
     assert np.array_equal(Sg, s.pose_covariances(H.MODE_JOINT, p1))
     o.close()
+
+
+def test_fullsize_display_clouds_pageable_pinned_and_oracle_agree(big):
+    """hitl_solver_transform_scans at 20 M observations: into pageable memory (round 5: 8 MB pieces through two page-locked staging
+    buffers, a few host threads copying piece k out while piece k + 1 arrives), into page-locked memory (one direct DMA) and the
+    oracle's loop: the same bits; the staged path is not slower than a plain copy would be (4 bytes x 2 x 20 M in well under 50 ms)."""
+    import time
+    from oracle import hitl_oracle as O
+    s = big["s"]
+    init = np.ascontiguousarray(big["init"], np.float32).reshape(-1, 3)
+    t0 = time.perf_counter()
+    wx, wy = s.transform_scans(init)                 # numpy (pageable) destinations: the staged path
+    dt = time.perf_counter() - t0
+    px_, py_, pinned = s.transform_scans_pinned(init)
+    assert np.array_equal(wx.view(np.uint32), px_.view(np.uint32)) and np.array_equal(wy.view(np.uint32), py_.view(np.uint32))
+    s.host_free(pinned)
+    o = O.OracleSolver()
+    o.set_map(*big["map"])
+    ox, oy = o.transform_scans(init)
+    o.close()
+    assert np.array_equal(wx.view(np.uint32), ox.view(np.uint32)) and np.array_equal(wy.view(np.uint32), oy.view(np.uint32))
+    assert dt < 0.05, dt
