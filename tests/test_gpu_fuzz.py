@@ -72,8 +72,12 @@ def test_solver_paths_agree_over_many_map_sizes(tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
+    # round 5: "fused" = the default plan (two-way sequential first stage on chains of >= 4096 super-blocks, the last chunk stage + the
+    # top + their back-substitutions in one launch); "seq5" forces the sequential stage with chunks of 5 on EVERY size (short, odd and
+    # single-node last chunks at both band widths); "plain" = neither (the stage kernels of rounds 2-4, one launch each)
     for tag, extra in (("fused", {}), ("legacy", {"HITL_TEST_SWITCHES": "cr_legacy=1"}), ("dist", {"HITL_FORCE_DIST": "1"}),
-                       ("distcols", {"HITL_FORCE_DIST": "1", "HITL_DIST_COLUMNS": "1"})):
+                       ("distcols", {"HITL_FORCE_DIST": "1", "HITL_DIST_COLUMNS": "1"}), ("seq5", {"HITL_TEST_SWITCHES": "cr_seq_m=5"}),
+                       ("plain", {"HITL_TEST_SWITCHES": "cr_seq=0,cr_tail=0"})):
         out = str(tmp_path / (tag + ".jsonl"))
         env = dict(os.environ, HITL_SWEEP_QUICK="1", **extra)
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "cr_size_sweep.py"), out], env=env, cwd=root, capture_output=True,
@@ -87,6 +91,11 @@ def test_solver_paths_agree_over_many_map_sizes(tmp_path):
         assert a["it"] == b["it"] == c["it"] == d["it"] and a["term"] == b["term"] == c["term"] == d["term"], (a, b, c, d)
         assert abs(a["cost"] - b["cost"]) <= 1e-9 * max(abs(b["cost"]), 1e-12) and abs(c["cost"] - b["cost"]) <= 1e-8 * max(abs(b["cost"]), 1e-12)
         assert abs(d["cost"] - b["cost"]) <= 1e-8 * max(abs(b["cost"]), 1e-12)
+    for tag in ("seq5", "plain"):
+        assert len(res[tag]) == len(res["legacy"])
+        for e, b in zip(res[tag], res["legacy"]):
+            assert "err" not in e and e["n"] == b["n"] and e["it"] == b["it"] and e["term"] == b["term"], (tag, e, b)
+            assert abs(e["cost"] - b["cost"]) <= 1e-9 * max(abs(b["cost"]), 1e-12), (tag, e, b)
 
 
 def test_solves_are_reproducible_run_to_run(tmp_path):

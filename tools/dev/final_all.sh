@@ -2,7 +2,7 @@
 # round-end artefacts in one call: GPU tests, the three bench lines, kernel trace + traffic counters, utilisation counters
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=gpurun_out/final_$TAG
 mkdir -p $OUT
 timeout 2400 python -m pytest tests -q -m gpu > $OUT/gputests.txt 2>&1
