@@ -1,6 +1,6 @@
 """The bench line contract (one JSON object: metric/value/unit/..., a `roofline` object -- `achieved` from the HBM bytes the
 kernel really moves, the SURVEY 8(d) algorithmic-byte figure beside it -- and a `cpu_baseline` object), checked on the
-committed lines of the last profiled run (profiles/r02_final_bench_*.json) and on
+committed lines of profiled runs (profiles/r02_final_bench_*.json, r05_final_bench_*.json) and on
 bench.py's own source: the product path may not fall back to the oracle, the oracle is only the cpu_baseline leg."""
 import json
 import os
@@ -9,7 +9,7 @@ import re
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LINES = [os.path.join(ROOT, "profiles", f) for f in ("r02_final_bench_c4.json", "r02_final_bench_c2.json")]
+LINES = [os.path.join(ROOT, "profiles", f) for f in ("r02_final_bench_c4.json", "r02_final_bench_c2.json", "r05_final_bench_c4.json", "r05_final_bench_c2.json")]
 
 
 @pytest.mark.parametrize("path", LINES, ids=[os.path.basename(p) for p in LINES])
