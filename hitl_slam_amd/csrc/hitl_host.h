@@ -125,7 +125,7 @@ struct SolverCtx {
 };
 int solver_ctx(hitl_solver* s, SolverCtx* out);
 
-// The fixed summation order of the per-workgroup partial sums, shared by the host-driven LM loop and k_lm_decide (so that
+// The fixed summation order of the per-workgroup partial sums, shared by the host-driven LM loop and the device-side decision in k_assemble (so that
 // both take bit-identical decisions): 32 accumulators take the terms b = lane, lane + 32, ... in ascending order, then the
 // 32 accumulators are added from lane 0 up.  v[b * stride] is term b.
 static inline double ordered_sum32(const double* v, int n, int stride) {

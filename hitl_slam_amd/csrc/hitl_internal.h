@@ -40,7 +40,7 @@ struct DevSwitches {
   bool cr_tail = true;             // "cr_tail" = 0: the last chunk stage, the top and their back-substitutions as four launches (rounds 2-4)
                                    // instead of one (k_cr_tail, round 5)
   bool stf_addr64 = false;         // "stf_addr64": the 64-bit addressing instantiations of k_linearize_stf (arrays beyond 4 GB)
-  bool device_lm = false;          // "device_lm": accept / reject / terminate decided on the device (k_lm_decide), iterations queued ahead.
+  bool device_lm = false;          // "device_lm": accept / reject / terminate decided on the device (the last workgroup of k_assemble), iterations queued ahead.
                                    // Measured (round 3): 4-8 us per iteration SLOWER than the host-driven loop on every workload
   int lm_ahead = 3;                // "lm_ahead": LM iterations the host queues ahead of the device-driven loop
   int kd_cap = 0;                  // "kd_cap": frame-stack entries per lane of k_match_kd_tgt's first attempt (0 = 5); 1 forces the redo walks
@@ -103,7 +103,7 @@ struct LinView {            // one linearisation (double buffered by the driver)
   double* partials;           // assemble workgroups x 2 : (cost, max |g|) per workgroup
 };
 
-// Device-resident state of the Levenberg-Marquardt loop (round 3: accept / reject / terminate are decided by k_lm_decide on
+// Device-resident state of the Levenberg-Marquardt loop (round 3: accept / reject / terminate are decided by lm_decide_step -- since round 5 run by the last workgroup of k_assemble -- on
 // the device; the host only queues iterations ahead and polls a pinned progress word).  Kernels of the chain take a pointer
 // to it: `done` makes the launches queued behind the terminating iteration return at once, `cur` selects which of the two
 // linearisation / state buffers is the current one, `radius` is the trust region the next step is solved with.

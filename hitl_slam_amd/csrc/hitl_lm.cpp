@@ -59,7 +59,7 @@ static int enqueue_linearize(hitl_solver* s, const FactorView& fv, const double*
 static int finish_linearize(hitl_solver* s, const FactorView& fv, LinResult* out) {
   const int nblk = assemble_blocks(s->n);
   const double* host = s->h_partials + (size_t)spmv_blocks(s->npad) * 8;
-  const double cost = ordered_sum32(host, nblk, 2);   // fixed order: bit-reproducible, and the order k_lm_decide uses
+  const double cost = ordered_sum32(host, nblk, 2);   // fixed order: bit-reproducible, and the order the device-side decision uses
   double gmax = 0.0;
   for (int b = 0; b < nblk; ++b) {
     const double g = host[2 * b + 1];
@@ -234,7 +234,7 @@ static int read_step_partials(hitl_solver* s, double* rr, double* bb, StepScalar
 static int finish_step_partials(hitl_solver* s, double* rr, double* bb, StepScalars* ss) {
   const int nblk = spmv_blocks(s->npad);
   double acc[7];
-  ordered_sum32_records<7>(s->h_partials, nblk, 8, acc);     // the order k_lm_decide uses (ordered_sum32 per sum), one pass over the records
+  ordered_sum32_records<7>(s->h_partials, nblk, 8, acc);     // the order the device-side decision uses (ordered_sum32 per sum), one pass over the records
   if (rr) *rr = acc[0];
   if (bb) *bb = acc[1];
   if (ss) { ss->dt_rhs = acc[2]; ss->dt_q = acc[3]; ss->step2 = acc[4]; ss->xn2 = acc[5]; ss->bad = acc[6]; }
@@ -720,17 +720,15 @@ static double now_ms() {
 // ---------------------------------------------------------------------------------------
 // The Levenberg-Marquardt loop with the decisions on the device (single GPU, every pose pair inside the band -- the path
 // the headline numbers run).  The host queues whole iterations -- banded solve on the CURRENT buffers with the CURRENT
-// trust region, band pass + candidate state, the candidate's linearisation, k_lm_decide -- up to DevSwitches::lm_ahead (3) iterations ahead
+// trust region, band pass + candidate state, the candidate's linearisation with the decision in its last workgroup -- up to DevSwitches::lm_ahead (3) iterations ahead
 // of the one the device has finished, and polls one pinned word.  No kernel argument depends on a decision: which buffers
 // are current, the radius, and whether the loop is over are read from LmDev on the device.  Launches queued behind the
 // terminating iteration return at once.  Same statements, same sums in the same order as the host loop below: identical
 // iteration sequences and bit-identical poses (tests/test_gpu_parity.py A/B).
-// OPT-IN (test hook device_lm).  Measured on MI355X (tools/dev/lm_ab.py, lm_ab2.py): the kernel trace of this loop has no gaps
-// between launches (the host-driven loop: ~40 us per iteration in the round-2 trace), yet its wall clock is 4-8 us per
-// iteration LONGER on every workload tried (C4 18.65 vs 18.15 ms, C2 1.20 vs 1.16 ms, moments mode 7.39 vs 7.15 ms,
-// mode A 5.13 vs 5.01 ms; queue depth 1..6 makes no difference): k_lm_decide (sums of ~4700 partials, a system-scope fence
-// for the progress word, one more launch boundary: 12 us) costs what the host's turn-around really cost -- most of those
-// 40 us were already hidden behind the first cyclic-reduction stage the host queues first.
+// OPT-IN (test hook device_lm).  Measured on MI355X: rounds 3-4 (a k_lm_decide launch per iteration: 12 us, later 10) 4-8 us per
+// iteration SLOWER than the host-driven loop on every workload; round 5 (the decision in k_assemble's last workgroup, no launch of its
+// own) 424 against 420 us at C4 and 93.5 against 95.1 us at C2 with the one-launch solve tail: every kernel of this loop starts with a
+// dependent scalar load of the loop state, which costs what the host's turn-around costs (profiles/r05_linear_solve.md).
 // ---------------------------------------------------------------------------------------
 constexpr int kLmEventPairs = 32;
 

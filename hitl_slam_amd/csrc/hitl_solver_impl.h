@@ -21,7 +21,7 @@ struct hitl_solver {
   int64_t lin_launches = 0;     // linearisations queued so far (every 4th is bracketed by events at timing_level 1)
   bool lin_timed = false;       // the linearisation in flight is bracketed
   double* h_scalars = nullptr;  // pinned, kNumScalars + 8: [15] = sequence word of spin_sync, [kNumScalars ..] = progress record of the device-driven LM loop
-  DevArray<LmDev> lm_dev;       // device-resident state of the LM loop (k_lm_decide)
+  DevArray<LmDev> lm_dev;       // device-resident state of the LM loop (lm_decide_step in k_assemble)
   DevArray<unsigned> lm_arrivals;             //   workgroups of the deciding launch that have stored their partials (k_assemble)
   std::vector<hipEvent_t> lm_events;   // pairs bracketing k_linearize_stf launches queued ahead (device-driven loop)
   int64_t sync_seq = 0;

@@ -339,7 +339,7 @@ def test_submap_solve_through_in_library_rccl_world1(columns):
 @pytest.mark.parametrize("late", [0, 1])
 @pytest.mark.parametrize("shape", [(60, 90, 30, 2, 4), (150, 64, 50, 3, 0), (40, 48, 40, 1, 2)])
 def test_device_driven_lm_loop_equals_the_host_driven_one(switches, shape, late):
-    """Round 3: accept / reject / terminate are decided on the device (k_lm_decide) and the host queues iterations ahead.  The
+    """Round 3: accept / reject / terminate are decided on the device (round 5: by the last workgroup of k_assemble) and the host queues iterations ahead.  The
     host-driven loop of rounds 1-2 remains the default (measured 4-8 us per iteration faster: the decision kernel costs what the
     hidden part of the host's turn-around did not; the test hook device_lm selects the device-driven loop): both take bit-identical
     decisions -- same poses to the last bit, same iteration / accepted / rejected counts, same costs, same
