@@ -1,7 +1,8 @@
 /*
  * hitl_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).  See hitl_oracle.h.
  *
- * PARITY UNPINNED (no reference tests/goldens exist; reference unbuildable here).
+ * PARITY UNPINNED (no reference tests/goldens exist; reference unbuildable here) -- except orc_angle_mod and the rotation of
+ * orc_odom_setup, held bit for bit to the reference's own shared/math/util.h compiled in place (oracle/_ref, tests/test_oracle_ref.py).
  *
  * What follows the reference, by section:
  *   jets            : forward-mode dual numbers = ceres::Jet<double,6> as used by
