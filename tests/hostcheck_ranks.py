@@ -159,6 +159,11 @@ CASES = [
     dict(name="three ranks, replicated scans, all pairs", world=3, n=48, m=10, window=0, cuts=[0, 16, 32, 48], halo=-1),
     dict(name="two ranks, moments mode, range call", world=2, n=40, m=16, window=1, cuts=[0, 19, 40], opts=dict(stf_moments=1), range_call=True),
     dict(name="two ranks, timing level 2", world=2, n=40, m=16, window=4, cuts=[0, 24, 40], opts=dict(timing_level=2)),
+    dict(name="four ranks (the C4 split of BASELINE configs[3])", world=4, n=120, m=10, window=3, cuts=[0, 30, 60, 90, 120]),
+    dict(name="eight ranks (the C5 split), uneven, one rank of 9 poses", world=8, n=200, m=8, window=3,
+         cuts=[0, 25, 50, 59, 90, 115, 140, 170, 200]),
+    dict(name="eight ranks, interface columns", world=8, n=200, m=8, window=2, cuts=[0, 25, 50, 75, 100, 125, 150, 175, 200],
+         env={"HITL_DIST_COLUMNS": "1"}, modes=(0, 2)),
     dict(name="two ranks, rank 1 fails in prepare", world=2, n=64, m=20, window=3, cuts=[0, 30, 64], inject_rank=1, inject=("fail_prepare", 1),
          expect_all_fail=True),
     dict(name="three ranks, rank 0 reports a bad step from iteration 2", world=3, n=90, m=12, window=2, cuts=[0, 20, 61, 90], inject_rank=0,
