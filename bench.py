@@ -70,6 +70,7 @@ def main():
                     help="N>1: strong (auto) = the SAME named map split into N pose-range submaps (BASELINE configs[3] / [4]); "
                          "weak = N x the workload's per-GPU poses.  N=1 is the named map on one GPU either way (labelled weak)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-copy-ceiling", action="store_true", help="skip the measured device-copy ceiling (SURVEY.md 8(d)) beside the 8 TB/s peak")
     ap.add_argument("--timing-level", type=int, default=1, help="hitl_options.timing_level: 1 = every 4th stf launch bracketed by "
                     "HIP events (default), 2 = all launches + linear-solver timing")
     ap.add_argument("--cut-align", type=int, default=12,
@@ -404,6 +405,34 @@ def main():
                         "queue, so this leg is slower than ms_per_step and is not part of `value`)"}
         except Exception as e:
             result["phase_breakdown_timing_level_2"] = {"failed": repr(e)}
+
+    # ---- measured device-copy ceiling beside the vendor peak; untimed side leg, never part of `value` or `frac` ----
+    if world == 1 and not args.no_copy_ceiling:
+        try:
+            n_words = 1 << 28                                     # 1 GiB of fp32: 1 GiB read + 1 GiB written per copy
+            a = torch.empty(n_words, dtype=torch.float32, device="cuda")
+            a.fill_(1.0)
+            b = torch.empty_like(a)
+            for _ in range(3):
+                b.copy_(a)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                b.copy_(a)
+            e1.record()
+            torch.cuda.synchronize()
+            copy_ms = e0.elapsed_time(e1) / 10.0
+            copy_gbs = 2.0 * n_words * 4 / (copy_ms * 1e-3) / 1e9
+            del a, b
+            torch.cuda.empty_cache()
+            result["roofline"]["measured_copy_ceiling"] = {
+                "GB/s": copy_gbs, "ms_per_copy": copy_ms, "bytes_per_copy": 2 * n_words * 4,
+                "achieved_over_ceiling": (achieved / copy_gbs) if copy_gbs > 0 else None,
+                "what": "torch device-to-device copy of 1 GiB (read + write counted), 10 repeats between two events on torch's stream, "
+                        "after the timed region; `frac` stays against the 8 TB/s vendor peak"}
+        except Exception as e:
+            result["roofline"]["measured_copy_ceiling"] = {"failed": repr(e)}
 
     # ---- one interactive correction cycle on the same resident map, reported alongside ----
     if world == 1:
