@@ -314,12 +314,14 @@ class SolverBase(object):
         return poses.reshape(-1, 3)
 
     def run_correction(self, ctype, selected_points_xy8, poses_xyt, cov9, constraint_groups, mode=abi.MODE_ODOM_HC,
-                       select_threshold=0.05, stf_window=3, find_corr_kwargs=None, reproject=False):
+                       select_threshold=0.05, stf_window=3, find_corr_kwargs=None, reproject=True):
         """One whole HitLSLAM::Run (HitLSLAM.cpp:380-480) on this backend.  constraint_groups is the session's list of
         row arrays (human_constraints_); returns dict(poses, cov9, constraint_groups, summary, status, ...).
-        reproject=True adds out["world"] = world_clouds(poses): the whole map's world-frame clouds copied to the host (8 bytes
-        per observation: 160 MB at 20 M observations, and as much page-locked memory held by this object) -- off by default,
-        callers that only want poses and covariances do not pay for it."""
+        reproject=True (the default: the reference's Run always ends with transformPointCloudsToWorldFrame, HitLSLAM.cpp:476-479)
+        adds out["world"] = world_clouds(poses, copy=False): VIEWS into the page-locked display buffers this object keeps (8 bytes
+        per observation of pinned memory, no second host copy) -- valid until the next run_correction / world_clouds / set_map /
+        close of this solver; a caller that keeps them longer copies them (np.array(...)).  reproject=False: poses and covariances
+        only, for callers that do not display the map."""
         poses = np.array(poses_xyt, np.float32).reshape(-1, 3)
         cov = np.array(cov9, np.float32).reshape(-1, 9)
         pts = np.array(selected_points_xy8, np.float32).reshape(-1)
@@ -349,7 +351,7 @@ class SolverBase(object):
         if reproject:
             # transformPointCloudsToWorldFrame at the end of HitLSLAM::Run (HitLSLAM.cpp:476): the clouds land in page-locked
             # buffers this object keeps (hitl_host_alloc, allocated on first use): 3 ms instead of 10 at 20 M observations
-            out["world"] = self.world_clouds(poses)
+            out["world"] = self.world_clouds(poses, copy=False)
         return out
 
     def world_clouds(self, poses_xyt, copy=True):

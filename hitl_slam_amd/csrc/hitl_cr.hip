@@ -1183,12 +1183,17 @@ __global__ __launch_bounds__(1024) void k_cr_chunk_back(CrView cr, int S, int M,
 // cuts its tiles from the band rows (short chains -- C2, Figure-8-size maps: the whole linear solve is this one launch).
 // ===========================================================================================
 constexpr int kCrTailMaxGroups = 128;
-__device__ __forceinline__ bool cr_tail_wait(const unsigned* word, unsigned target) {
-  for (unsigned spins = 0; spins < (1u << 22); ++spins) {
+__device__ __forceinline__ bool cr_tail_wait(const unsigned* word, unsigned target, unsigned max_spins) {
+  for (unsigned spins = 0; spins < max_spins; ++spins) {
     if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
     __builtin_amdgcn_s_sleep(4);
   }
   return false;
+}
+
+__device__ __forceinline__ void cr_tail_report(const CrView& cr, unsigned* ticket) {
+  __hip_atomic_store(&ticket[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (cr.fail_host != nullptr) __hip_atomic_store(cr.fail_host, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 template <int B, int KIND2>
@@ -1204,13 +1209,13 @@ __global__ __launch_bounds__(1024) void k_cr_tail(CrView cr, CrStage sg2, CrStag
     if (tid == 0) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       __hip_atomic_fetch_add(&ticket[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_ok = cr_tail_wait(&ticket[1], 1u) ? 1 : 0;
+      s_ok = cr_tail_wait(&ticket[1], 1u, cr.tail_spins) ? 1 : 0;
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
     if (s_ok) cr_chunk_back_body<B, false>(cr, sg2.S, sg2.M, 0, w, x, (size_t)0, chunks2, 1, lds, (int)blockIdx.x, tid, nthr);
     if (tid == 0) {
-      if (!s_ok) __hip_atomic_store(&ticket[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!s_ok) cr_tail_report(cr, ticket);
       if (__hip_atomic_fetch_add(&ticket[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)chunks2 - 1u) {     // the last one out
         __hip_atomic_store(&ticket[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&ticket[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1219,7 +1224,7 @@ __global__ __launch_bounds__(1024) void k_cr_tail(CrView cr, CrStage sg2, CrStag
     }
   } else {
     if (tid == 0) {
-      s_ok = cr_tail_wait(&ticket[0], (unsigned)chunks2) ? 1 : 0;
+      s_ok = cr_tail_wait(&ticket[0], (unsigned)chunks2, cr.tail_spins) ? 1 : 0;
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
@@ -1233,7 +1238,7 @@ __global__ __launch_bounds__(1024) void k_cr_tail(CrView cr, CrStage sg2, CrStag
       __syncthreads();
     }
     if (tid == 0) {
-      if (!s_ok) __hip_atomic_store(&ticket[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!s_ok) cr_tail_report(cr, ticket);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       __hip_atomic_store(&ticket[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);         // (also after a failed wait: nobody is left waiting)
     }
@@ -1540,15 +1545,17 @@ constexpr int kCrSeqThreads = 128;
 // fullest compute unit does: with 1042 chunks of 16 on 256 CUs, 18 CUs hold five workgroups and finish 10 us after the rest
 // (per-workgroup timeline, tools/dev/seq_probe.sh).  Chunks are therefore sized so that no CU holds more than four; short chains keep
 // chunks of 8 (fewer nodes in sequence per wave; the stages above are latency-bound either way).
-static int cr_seq_chunk(int nsb, int B) {
+static int cr_seq_chunk(int nsb, int B, int cus) {
   const int top = (B == 3 ? 128 : 40) - 1;                 // what the top stage takes in one workgroup (cr_plan)
-  int m = (nsb - 1 + 4 * 256 - 1) / (4 * 256);
+  if (cus < 1) cus = 256;
+  const int cap = std::min(24, 256 / B + 1);               // k_cr_seq_back: (M - 1) * B <= 256 threads
+  int m = (nsb - 1 + 4 * cus - 1) / (4 * cus);
   if (m < 8) {
     m = 8;
-    for (int k = 8; k <= 24; ++k)                            // short chains: the smallest chunk that hands the top stage everything at once
+    for (int k = 8; k <= cap; ++k)                           // short chains: the smallest chunk that hands the top stage everything at once
       if ((nsb + k - 1) / k <= top) { m = k; break; }
   }
-  return m > 24 ? 24 : m;
+  return m > cap ? cap : m;
 }
 template <int B>
 static size_t cr_seq_lds_bytes(int M) {
@@ -1909,7 +1916,7 @@ static bool cr_factor_fused(hipStream_t st, const CrView& cr, double* w, double*
   // eliminations in sequence cost more than the 4 levels of the cyclic-reduction stage: 1.14 against 1.03 ms per re-solve)
   const bool seq_ok = src != nullptr && nrhs == 1 && 3 * src->Wb == B && !cr.rsep && dev_switches().cr_seq &&
                       (cr.nsb >= 4096 || dev_switches().cr_seq_m >= 2);
-  const int m0 = !seq_ok ? 0 : dev_switches().cr_seq_m >= 2 ? dev_switches().cr_seq_m : cr_seq_chunk(cr.nsb, B);
+  const int m0 = !seq_ok ? 0 : dev_switches().cr_seq_m >= 2 ? dev_switches().cr_seq_m : cr_seq_chunk(cr.nsb, B, cr.cus);
   const CrPlan pl = cr_plan(cr, B, cr.np, nrhs, wstride, m0);
   const bool seq0 = seq_ok && pl.n >= 2 && !pl.st[0].top && pl.st[0].M == m0 && cr_seq_lds_bytes<B>(m0) <= 64 * 1024;
   if (seq_ok && !seq0 && dev_switches().cr_seq_m >= 2) return false;           // (a forced chunk size that cannot run)
@@ -1928,12 +1935,13 @@ static bool cr_factor_fused(hipStream_t st, const CrView& cr, double* w, double*
   // the last chunk stage + the top + both their back-substitutions as ONE launch (k_cr_tail)
   const int t2 = pl.n - 2;
   int tail_chunks = 0;
-  bool tail = phase == 3 && w != nullptr && x != nullptr && nrhs == 1 && !cr.rsep && pl.n >= 2 && B <= 9 && cr.ticket != nullptr && dev_switches().cr_tail &&
+  bool tail = phase == 3 && w != nullptr && x != nullptr && nrhs == 1 && !cr.rsep && pl.n >= 2 && B <= 9 && cr.ticket != nullptr && !cr.no_tail && dev_switches().cr_tail &&
               !(t2 == 0 && seq0);
   if (tail) {
     const CrStage& g2 = pl.st[t2];
     tail_chunks = (int)((cr_stage_nodes(cr, g2.S) - 1 + g2.M - 1) / g2.M);
-    if (tail_chunks < 1 || tail_chunks + 1 > kCrTailMaxGroups || (g2.M + 1) * B > 1024) tail = false;
+    // every workgroup of the launch must be resident at once: 1024 threads and up to 128 KB of LDS = one per compute unit
+    if (tail_chunks < 1 || tail_chunks + 1 > std::min(kCrTailMaxGroups, cr.cus) || (g2.M + 1) * B > 1024) tail = false;
   }
   for (int t = 0; t < pl.n && (phase & 1); ++t) {
     if (tail && t >= t2) {
@@ -1957,8 +1965,12 @@ static bool cr_factor_fused(hipStream_t st, const CrView& cr, double* w, double*
         if (!raised_tail) tail = false;
         else {
           CrSource none2 = {};
-          if (kind1) hipLaunchKernelGGL((k_cr_tail<B, 1>), dim3(tail_chunks + 1), dim3(thr), lds, st, cr, g2, gt, *src, w, x, tail_chunks, cr.ticket);
-          else hipLaunchKernelGGL((k_cr_tail<B, 0>), dim3(tail_chunks + 1), dim3(thr), lds, st, cr, g2, gt, use_src2 ? *src : none2, w, x, tail_chunks, cr.ticket);
+          CrView crt = cr;
+          const bool starve = dev_switches().cr_tail_starve;      // test hook: no top workgroup, a short wait -- the chunk workgroups give up
+          if (starve) crt.tail_spins = 1u << 10;
+          const int groups = tail_chunks + (starve ? 0 : 1);
+          if (kind1) hipLaunchKernelGGL((k_cr_tail<B, 1>), dim3(groups), dim3(thr), lds, st, crt, g2, gt, *src, w, x, tail_chunks, cr.ticket);
+          else hipLaunchKernelGGL((k_cr_tail<B, 0>), dim3(groups), dim3(thr), lds, st, crt, g2, gt, use_src2 ? *src : none2, w, x, tail_chunks, cr.ticket);
           continue;
         }
       }

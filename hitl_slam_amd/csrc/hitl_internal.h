@@ -47,6 +47,9 @@ struct DevSwitches {
   int kd_redo_cap = 1 << 18;       // "kd_redo_cap": entries of the redo list behind the fast attempt (shrunk to force the full-depth repeat)
   bool cand_tf_check = false;      // "cand_tf_check": the device's candidate transforms held to the host routine, bit for bit
   size_t cand_tile_bytes = (size_t)4 << 30;   // "cand_tile_bytes": candidate-table budget of the tiled search (shrunk to force several tiles)
+  bool cr_tail_starve = false;     // "cr_tail_starve": k_cr_tail is launched WITHOUT its top workgroup and with a short wait: what a device too busy to hold
+                                   // all its workgroups at once looks like (the host must notice and repeat that solve as separate launches)
+  int cu_count = 0;                // "cu_count" > 0: plan launches as if the device had this many compute units (a CU-masked or partitioned device)
   // failure injection on ONE rank of a submap solve (tests/test_submap_gpu.py: every rank must come back with an error, none may
   // be left waiting in a collective)
   bool fail_prepare = false;       // "fail_prepare": the rank-local part of prepare() reports HITL_ERR_OUT_OF_MEMORY
@@ -150,6 +153,14 @@ struct CrView {             // block-tridiagonal system + cyclic-reduction facto
   // It lives at its true index nsb - 1 and takes part in every stage as the node behind the last regular one (fused stages only).
   int rsep = 0;
   unsigned* ticket = nullptr; // 4 words of device memory, zero between launches: k_cr_tail's arrivals / release / error / departures (null: no fused tail)
+  // k_cr_tail's workgroups wait for each other: all of them must be resident at once.  The host takes that launch only for at most
+  // `cus` workgroups (one of 1024 threads per compute unit of THIS device: a CU-masked or partitioned device has fewer than 256) and
+  // not at all with no_tail; a wait that runs out anyway (a device shared with another busy process) is reported through fail_host
+  // (pinned host memory, system-scope store) so that the host can repeat that one solve as separate launches.
+  int cus = 256;
+  int no_tail = 0;
+  double* fail_host = nullptr;
+  unsigned tail_spins = 1u << 22;   // polls a waiting workgroup of k_cr_tail makes before it gives up (~1.5 us each)
 };
 // stage nodes alive at stride S (the right separator counts as one), and where stage node sn lives in D / L / w / x
 __host__ __device__ inline int64_t cr_stage_nodes(const CrView& cr, int S) {

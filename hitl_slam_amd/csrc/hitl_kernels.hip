@@ -815,18 +815,21 @@ __global__ __launch_bounds__(kAsmBlock) void k_assemble(MapView map, PairView pr
   if (threadIdx.x == 0) {
     double cs = sm_c[0], gs = sm_g[0];
     for (int k = 1; k < kAsmBlock / WAVE; ++k) { cs += sm_c[k]; const double g1 = sm_g[k]; gs = (g1 > gs || g1 != g1) ? g1 : gs; }
-    if (dec.lm == nullptr) {
+    if (dec.lm == nullptr && dec.host_flag == nullptr) {
       lin.partials[2 * blockIdx.x] = cs;
       lin.partials[2 * blockIdx.x + 1] = gs;
-      if (dec.host_flag != nullptr) {
-        // host-driven loop: the partials are in flight to pinned host memory; once they have been accepted this workgroup counts
-        // itself in, and the last one to do so raises the flag the host polls (same order on the link: partials, then flag)
-        __builtin_amdgcn_s_waitcnt(0);
-        if (__hip_atomic_fetch_add(dec.arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
-          *dec.arrivals = 0u;
-          __threadfence_system();
-          *reinterpret_cast<volatile double*>(dec.host_flag) = dec.flag_seq;
-        }
+    } else if (dec.lm == nullptr) {
+      // host-driven loop: the partials go to pinned host memory as SYSTEM-scope stores (written through every cache level on
+      // their way out: nothing of them may linger in this XCD's L2 when another XCD's workgroup raises the flag); once they have
+      // been accepted this workgroup counts itself in, and the last one to do so raises the flag the host polls (same order on
+      // the link: partials, then flag)
+      __hip_atomic_store(&lin.partials[2 * blockIdx.x], cs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&lin.partials[2 * blockIdx.x + 1], gs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __builtin_amdgcn_s_waitcnt(0);
+      if (__hip_atomic_fetch_add(dec.arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+        *dec.arrivals = 0u;
+        __threadfence_system();
+        __hip_atomic_store(dec.host_flag, dec.flag_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     } else {
       // device-driven loop: the two numbers go out as device-scope stores (written through to where every XCD sees them) and have

@@ -99,6 +99,18 @@ static int wait_host_flag(hitl_solver* s, double seq) {
   }
 }
 
+// k_cr_tail's workgroups wait for one another; a wait that ran out (its workgroups were not all resident: a device shared with
+// another busy process) is reported through a pinned word.  Called after a host synchronisation: true = the linear solve just
+// waited for is void; the fused tail is off for this solver from now on and the tickets are clean for whatever runs next.
+static bool take_cr_tail_failure(hitl_solver* s) {
+  volatile double* word = s->h_scalars + 14;
+  if (*word == 0.0) return false;
+  *word = 0.0;
+  s->cr_tail_off = true;
+  if (s->cr_ticket.p != nullptr) (void)hipMemsetAsync(s->cr_ticket.p, 0, sizeof(unsigned) * 4, s->stream);
+  return true;
+}
+
 int run_linearize(hitl_solver* s, const FactorView& fv, const double* xdev, int buf, LinResult* out) {
   TRY(enqueue_linearize(s, fv, xdev, buf));
   HIP_TRY(hipStreamSynchronize(s->stream));
@@ -910,6 +922,7 @@ int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float* poses
       { RoctxRange r("hitl:queue linearisation of the candidate");
         TRY(enqueue_linearize(s, fv, xcand, cur ^ 1, /*direct=*/true, /*have_trig=*/true, false, seq)); }   // partial sums are written to pinned host memory by the kernels
       { RoctxRange r("hitl:wait for the device"); TRY(wait_host_flag(s, seq)); }
+      if (take_cr_tail_failure(s)) { --iter; continue; }         // repeat this iteration's solve as separate launches (same radius)
       double rr, bb;
       TRY(finish_step_partials(s, &rr, &bb, &ss));
       const double guard = std::max(std::max(o.linear_solver_tolerance, 1e-15), 1e-9);
@@ -920,6 +933,7 @@ int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float* poses
       if (s->dist_mode()) { TRY(linear_solve_and_step_dist(s, fv, cur, radius, xcur, xcand, &lin_iters, &ok, &ss, &lr_spec)); have_spec = true; }
       else TRY(linear_solve_and_step(s, fv, cur, radius, xcur, xcand, &lin_iters, &ok, &ss));
       if (time_solver) { HIP_TRY(hipEventRecord(s->ev3, st)); HIP_TRY(hipEventSynchronize(s->ev3)); }
+      if (!s->dist_mode() && take_cr_tail_failure(s)) { --iter; continue; }
     }
     S.linear_iterations += lin_iters;
     if (time_solver) {

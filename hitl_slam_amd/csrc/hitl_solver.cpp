@@ -590,6 +590,8 @@ extern "C" int hitl_test_set_switch(const char* name, long long value) {
   else if (k == "cr_seq") d.cr_seq = value != 0;
   else if (k == "cr_seq_m") d.cr_seq_m = (int)std::max(0ll, std::min(64ll, value));
   else if (k == "cr_tail") d.cr_tail = value != 0;
+  else if (k == "cr_tail_starve") d.cr_tail_starve = value != 0;
+  else if (k == "cu_count") d.cu_count = (int)std::max(0ll, std::min(4096ll, value));
   else if (k == "stf_addr64") d.stf_addr64 = value != 0;
   else if (k == "device_lm") d.device_lm = value != 0;
   else if (k == "lm_ahead") d.lm_ahead = (int)std::max(1ll, std::min(16ll, value));
@@ -718,6 +720,7 @@ int hitl_solver_create(const hitl_options* opt, hitl_solver** out) {
   {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, o.device) == hipSuccess && cus > 0) s->cu_count = cus;
+    if (dev_switches().cu_count > 0) s->cu_count = dev_switches().cu_count;
   }
   s->rank = o.rank;
   s->world = o.world_size;

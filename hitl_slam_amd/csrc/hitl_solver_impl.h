@@ -20,7 +20,7 @@ struct hitl_solver {
   bool staging_queued = false;  // copies out of the pinned staging buffers (setup_factors, the start state) may still be in flight
   int64_t lin_launches = 0;     // linearisations queued so far (every 4th is bracketed by events at timing_level 1)
   bool lin_timed = false;       // the linearisation in flight is bracketed
-  double* h_scalars = nullptr;  // pinned, kNumScalars + 8: [15] = sequence word of spin_sync, [kNumScalars ..] = progress record of the device-driven LM loop
+  double* h_scalars = nullptr;  // pinned, kNumScalars + 8: [14] = k_cr_tail's failure word, [15] = sequence word of spin_sync, [kNumScalars ..] = progress record of the device-driven LM loop
   DevArray<LmDev> lm_dev;       // device-resident state of the LM loop (lm_decide_step in k_assemble)
   DevArray<unsigned> lm_arrivals;             //   workgroups of the deciding launch that have stored their partials (k_assemble)
   std::vector<hipEvent_t> lm_events;   // pairs bracketing k_linearize_stf launches queued ahead (device-driven loop)
@@ -124,6 +124,7 @@ struct hitl_solver {
   DevArray<unsigned> cr_ticket;                // k_cr_tail's four ticket words (zero between launches)
   double prepare_pcie_bytes = 0.0;             // host -> device bytes of the last prepare() (factor tables): hitl_summary.pcie_bytes
   int cu_count = 256;                          // compute units of the device
+  bool cr_tail_off = false;                    // a wait inside k_cr_tail once ran out on this device: separate launches from then on
   DevArray<char> stf_pose_recs;                // per-pose descriptor records of the half-wave linearisation (k_linearize_stf_r)
   int64_t stf_pose_recs_of = -1;               //   correspondence-set generation they belong to
   bool kd_full_depth = false;                  //   a walk on this map once needed more frames than the fast attempt provisions: full-depth stacks from then on
@@ -187,6 +188,7 @@ struct hitl_solver {
     c.nsb = nsb; c.B = B; c.D = crD.p; c.L = crL.p; c.Dinv = crDinv.p; c.Gl = crGl.p; c.Gr = crGr.p;
     c.P = crP.p; c.Pw = crPw.p; c.np = cr_contrib_slots(nsb); c.pw_rhs = cr_pw_rhs;
     c.ticket = cr_ticket.p;
+    c.cus = cu_count; c.no_tail = (cr_tail_off || dist_mode()) ? 1 : 0; c.fail_host = h_scalars ? h_scalars + 14 : nullptr;
     return c;
   }
 };

@@ -78,9 +78,9 @@ def test_full_cycle_parity_other_maps(seed):
     g, o = Solver(), O.OracleSolver()
     sc2.prob.load(g)
     sc2.prob.load(o)
-    rg = g.run_correction(4, sc2.selected, sc2.poses, sc2.cov, [], reproject=True)
-    ro = o.run_correction(4, sc2.selected, sc2.poses, sc2.cov, [])
-    assert rg["status"] == ro["status"] == "ok" and "world" not in ro          # re-projection is opt-in (160 MB at 20 M observations)
+    rg = g.run_correction(4, sc2.selected, sc2.poses, sc2.cov, [])            # the default: re-projection included, as in the reference's Run
+    ro = o.run_correction(4, sc2.selected, sc2.poses, sc2.cov, [], reproject=False)
+    assert rg["status"] == ro["status"] == "ok" and "world" not in ro and "world" in rg
     assert rg["order"]["bounds"] == ro["order"]["bounds"] and np.array_equal(rg["order"]["corrected"], ro["order"]["corrected"])
     d = rg["poses"].astype(np.float64) - ro["poses"]
     d[:, 2] = np.angle(np.exp(1j * d[:, 2]))
@@ -91,8 +91,8 @@ def test_full_cycle_parity_other_maps(seed):
     assert np.array_equal(rg["world"][0].view(np.uint32), wx.view(np.uint32)) and np.array_equal(rg["world"][1].view(np.uint32), wy.view(np.uint32))
     # a LARGER map loaded into the same solver: the page-locked buffers are sized by the map they were allocated for (ADVICE r4:
     # they used to be reused unconditionally -- a heap overflow); set_map drops them, and what world_clouds returned earlier are
-    # copies the caller owns (the views of copy=False die with the buffers)
-    old = rg["world"][0]
+    # copies the caller owns (the views of copy=False -- what run_correction hands out -- die with the buffers: copied here first)
+    old = np.array(rg["world"][0])
     from tests.conftest import Problem
     big = Problem(130, 128, seed=seed + 7, groups=0)
     big.load(g)

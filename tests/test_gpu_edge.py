@@ -294,6 +294,8 @@ _SWITCHES = [
     ({}, {"cr_legacy": 1}), ({}, {"cr_unfused_build": 1}), ({}, {"stf_addr64": 1}), ({}, {"device_lm": 1}), ({}, {"device_lm": 1, "lm_ahead": 1}),
     ({}, {"kd_cap": 1}), ({}, {"kd_cap": 2, "kd_redo_cap": 8}), ({}, {"cand_tf_check": 1}), ({}, {"cand_tile_bytes": 200000}),
     ({}, {"cr_tail": 0}), ({}, {"cr_seq": 0}), ({}, {"cr_seq": 0, "cr_tail": 0}), ({}, {"cr_seq_m": 4}), ({}, {"cr_seq_m": 9, "cr_tail": 0}), ({}, {"device_lm": 1, "cr_tail": 0, "cr_seq_m": 6}),
+    # the fused solve tail on a device that cannot hold all its workgroups at once: planned away (cu_count), or noticed and repeated (cr_tail_starve)
+    ({}, {"cu_count": 3}), ({}, {"cu_count": 32, "cr_seq_m": 5}), ({}, {"cr_tail_starve": 1}),
     # several at once: the switches nobody would combine on purpose
     ({"HITL_TIMING": "1", "HITL_ROCTX": "1"}, {"cr_unfused_build": 1, "kd_cap": 2, "cand_tile_bytes": 300000}),
     ({}, {"device_lm": 1, "stf_addr64": 1, "cand_tf_check": 1}),

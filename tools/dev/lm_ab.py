@@ -11,27 +11,33 @@ off, px, py, nx, ny = S.scans(p)
 rows = S.constraints(p, gt, max(1, n // 1000), kind=4)
 corr = None
 res = {}
-for rep in range(int(os.environ.get("REPS", 2))):
-  VARIANTS = {"lm": (("host", dict(device_lm=0)), ("device", dict(device_lm=1)), ("device ahead 1", dict(device_lm=1, lm_ahead=1)), ("device ahead 6", dict(device_lm=1, lm_ahead=6))),
+VARIANTS = {"lm": (("host", dict(device_lm=0)), ("device", dict(device_lm=1)), ("device ahead 1", dict(device_lm=1, lm_ahead=1)), ("device ahead 6", dict(device_lm=1, lm_ahead=6))),
             "tail": (("tail 4 launches", dict(cr_tail=0)), ("tail fused", dict(cr_tail=1)), ("fused + device lm", dict(cr_tail=1, device_lm=1)), ("4 launches + device lm", dict(cr_tail=0, device_lm=1)))}
-for tag, hooks in VARIANTS[os.environ.get("AB", "lm")]:
-    H.set_test_switch(None)
-    for k, v in hooks.items():
-        H.set_test_switch(k, v)
-    s = H.Solver()
-    s.set_map(off, px, py, nx, ny, cov)
-    s.set_human_constraints(rows)
-    if corr is None:
-        s.find_correspondences(init, 3); corr = s.get_correspondences()
-    else:
-        s.set_correspondences(*corr)
+its = {}
+for rep in range(max(1, int(os.environ.get("REPS", 2)))):
+    for tag, hooks in VARIANTS[os.environ.get("AB", "lm")]:
+        H.set_test_switch(None)
+        for k, v in hooks.items():
+            H.set_test_switch(k, v)
+        s = H.Solver()
+        s.set_map(off, px, py, nx, ny, cov)
+        s.set_human_constraints(rows)
+        if corr is None:
+            s.find_correspondences(init, 3); corr = s.get_correspondences()
+        else:
+            s.set_correspondences(*corr)
+        for mode in (H.MODE_ODOM_HC, H.MODE_JOINT):
+            s.solve(mode, init)
+            ts = []
+            for _ in range(5):
+                t0 = time.perf_counter(); po, sm = s.solve(mode, init); ts.append((time.perf_counter() - t0) * 1e3)
+            res.setdefault((tag, mode), []).append(min(ts))
+            its[(tag, mode)] = (sm.iterations, sm.final_cost)
+        s.close()
+# the minimum over the repetitions (variants interleaved: box drift hits all of them alike)
+for tag, _ in VARIANTS[os.environ.get("AB", "lm")]:
     out = []
     for mode in (H.MODE_ODOM_HC, H.MODE_JOINT):
-        s.solve(mode, init)
-        ts = []
-        for _ in range(5):
-            t0 = time.perf_counter(); po, sm = s.solve(mode, init); ts.append((time.perf_counter() - t0) * 1e3)
-        res.setdefault((tag, mode), []).append(min(ts))
-        out.append("mode %d: %.3f ms (%d it, cost %.15g, %.1f us/it)" % (mode, min(ts), sm.iterations, sm.final_cost, 1e3 * min(ts) / max(sm.iterations, 1)))
-    print("%-16s %s" % (tag, " | ".join(out)), flush=True)
-    s.close()
+        t, (it, cost) = min(res[(tag, mode)]), its[(tag, mode)]
+        out.append("mode %d: %.3f ms (%d it, cost %.15g, %.1f us/it)" % (mode, t, it, cost, 1e3 * t / max(it, 1)))
+    print("%-24s %s" % (tag, " | ".join(out)), flush=True)
