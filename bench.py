@@ -43,6 +43,7 @@ WORKLOADS = {
     "c5": dict(poses=200000, obs=512, groups=200, kind=0, window=3, weak_poses=25000, baseline="configs[4]",
                desc="synthetic campus-scale: 200k poses x 512 obs/pose, 200 mixed constraints, mode C"),
 }
+WORKLOAD_SEED = {"c2": 2, "c4": 4, "c5": 5}
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -53,6 +54,39 @@ def algorithmic_bytes_stf(n_obs, n_matches, n_poses, n_pairs):
     24 B per pose (fp64 state), and 112 B per directed pair (r[2] + J[2x6] written; the 3x3
     blocks of the survey's 72(N+P) term are produced from these by k_assemble)."""
     return 16 * n_obs + 24 * n_matches + 24 * n_poses + 112 * n_pairs
+
+
+def plan_partition(workload, world, scaling="strong", cut_align=12, poses=0, obs=0):
+    """The map and the pose-range submaps of a run (no GPU, no torch): what `--workload W --gpus N` solves.  Returns
+    dict(wl, named_poses, obs, ppf, n_global, cuts, seed); rank r owns global poses [cuts[r], cuts[r + 1]).
+    tests/test_gpu_splits_fullsize.py runs exactly this plan for BASELINE configs[3] (c4 on 4 ranks) and configs[4] (c5 on 8)."""
+    wl = dict(WORKLOADS[workload])
+    named_poses = wl["poses"]
+    if scaling == "weak" and world > 1:
+        wl["groups"] = max(1, int(round(wl["groups"] * wl["weak_poses"] / wl["poses"])))
+        wl["poses"] = wl["weak_poses"]                                              # per GPU
+    if poses:
+        wl["groups"] = max(1, int(round(wl["groups"] * poses / wl["poses"])))   # constraint density of the named workload
+        wl["poses"] = poses
+    if obs:
+        wl["obs"] = obs
+    ppf = 200 if wl["poses"] >= 400 else max(wl["poses"] // 2, 8)
+    if scaling == "strong" and world > 1:
+        # the SAME map on N GPUs (BASELINE configs[3]: 50k poses on 4; configs[4]: --workload c5 --poses 200000 on 8);
+        # cuts fall between floors where possible, so only an odometry edge straddles them
+        n_global = wl["poses"]
+        cuts = [0] + [int(round(r * n_global / world / ppf)) * ppf for r in range(1, world)] + [n_global]
+        if any(cuts[r + 1] - cuts[r] < 4 * wl["window"] + 2 for r in range(world)):
+            cuts = [r * n_global // world for r in range(world)] + [n_global]
+        # (the human constraints stay those of the whole map: every rank is handed all rows -- global pose ids -- and keeps the
+        # ones that constrain a pose it owns; anchors may lie on any rank, their targets come from the global start poses)
+    else:
+        n_global = wl["poses"] * world
+        cuts = [r * wl["poses"] for r in range(world + 1)]
+    if world > 1 and cut_align > 1 and min(cuts[r + 1] - cuts[r] for r in range(world)) >= 4 * cut_align:
+        cuts = [0] + [int(round(c / cut_align)) * cut_align for c in cuts[1:-1]] + [n_global]
+    seed = 20260102 + 1000 * WORKLOAD_SEED[workload]
+    return dict(wl=wl, named_poses=named_poses, obs=wl["obs"], ppf=ppf, n_global=n_global, cuts=cuts, seed=seed)
 
 
 def main():
@@ -132,34 +166,9 @@ def main():
     import hitl_slam_amd as H
     from tools import hitl_synth as S
 
-    wl = dict(WORKLOADS[args.workload])
-    named_poses = wl["poses"]
-    if args.scaling == "weak" and world > 1:
-        wl["groups"] = max(1, int(round(wl["groups"] * wl["weak_poses"] / wl["poses"])))
-        wl["poses"] = wl["weak_poses"]                                              # per GPU
-    if args.poses:
-        wl["groups"] = max(1, int(round(wl["groups"] * args.poses / wl["poses"])))   # constraint density of the named workload
-        wl["poses"] = args.poses
-    if args.obs:
-        wl["obs"] = args.obs
-    M = wl["obs"]
-    ppf = 200 if wl["poses"] >= 400 else max(wl["poses"] // 2, 8)
-    if args.scaling == "strong" and world > 1:
-        # the SAME map on N GPUs (BASELINE configs[3]: 50k poses on 4; configs[4]: --workload c5 --poses 200000 on 8);
-        # cuts fall between floors where possible, so only an odometry edge straddles them
-        n_global = wl["poses"]
-        cuts = [0] + [int(round(r * n_global / world / ppf)) * ppf for r in range(1, world)] + [n_global]
-        if any(cuts[r + 1] - cuts[r] < 4 * wl["window"] + 2 for r in range(world)):
-            cuts = [r * n_global // world for r in range(world)] + [n_global]
-        # (the human constraints stay those of the whole map: every rank is handed all rows -- global pose ids -- and keeps the
-        # ones that constrain a pose it owns; anchors may lie on any rank, their targets come from the global start poses)
-    else:
-        n_global = wl["poses"] * world
-        cuts = [r * wl["poses"] for r in range(world + 1)]
-    if world > 1 and args.cut_align > 1 and min(cuts[r + 1] - cuts[r] for r in range(world)) >= 4 * args.cut_align:
-        cuts = [0] + [int(round(c / args.cut_align)) * args.cut_align for c in cuts[1:-1]] + [n_global]
+    plan = plan_partition(args.workload, world, args.scaling, args.cut_align, args.poses, args.obs)
+    wl, named_poses, M, ppf, n_global, cuts, seed = (plan[k] for k in ("wl", "named_poses", "obs", "ppf", "n_global", "cuts", "seed"))
     n_local = cuts[rank + 1] - cuts[rank]
-    seed = 20260102 + 1000 * {"c2": 2, "c4": 4, "c5": 5}[args.workload]
 
     # ---- synthetic map: this rank's pose-range submap of the global trajectory ------------------
     t0 = time.time()

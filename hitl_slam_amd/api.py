@@ -444,9 +444,10 @@ class CommOps(C.Structure):
     _fields_ = [("allgather", ALLGATHER_FN), ("ctx", C.c_void_p)]
 
 
-def torch_allgather_ops(group=None, device=None):
+def torch_allgather_ops(group=None, device=None, counter=None):
     """hitl_comm_ops backed by torch.distributed (gloo on CPU tensors, or nccl == RCCL when
-    `device` is a cuda device).  Returns (CommOps, keepalive)."""
+    `device` is a cuda device).  Returns (CommOps, keepalive).  counter: a two-element list that receives
+    [exchanges, bytes sent] of this rank (tests: every rank of a solve must make the same number of exchanges)."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
@@ -459,6 +460,9 @@ def torch_allgather_ops(group=None, device=None):
             out = torch.empty(world * nbytes, dtype=torch.uint8, device=src.device)
             dist.all_gather_into_tensor(out, src, group=group)
             C.memmove(recv, out.cpu().numpy().ctypes.data, world * nbytes)
+            if counter is not None:
+                counter[0] += 1
+                counter[1] += int(nbytes)
             return 0
         except Exception as e:  # never let an exception cross the C boundary
             import sys
