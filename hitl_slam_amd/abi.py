@@ -119,7 +119,9 @@ class Summary(C.Structure):
         ("submap_linear_solver", C.c_double),
         ("hbm_bytes", C.c_double),
         ("pcie_bytes", C.c_double),
-        ("reserved", C.c_double * 3),
+        ("pcg_ms", C.c_double),
+        ("pcg_timed_calls", C.c_double),
+        ("pcg_timed_iterations", C.c_double),
     ]
 
     def as_dict(self):

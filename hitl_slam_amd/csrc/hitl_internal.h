@@ -47,6 +47,8 @@ struct DevSwitches {
   int kd_redo_cap = 1 << 18;       // "kd_redo_cap": entries of the redo list behind the fast attempt (shrunk to force the full-depth repeat)
   bool cand_tf_check = false;      // "cand_tf_check": the device's candidate transforms held to the host routine, bit for bit
   size_t cand_tile_bytes = (size_t)4 << 30;   // "cand_tile_bytes": candidate-table budget of the tiled search (shrunk to force several tiles)
+  bool pcg_fused = true;           // "pcg_fused" = 0: one launch group per CG iteration, the host looking every fourth (rounds 2-5) instead of one persistent launch per solve
+  bool pcg_starve = false;         // "pcg_starve": the persistent PCG launch is started WITHOUT its top workgroup and with short waits (see cr_tail_starve)
   bool cr_tail_starve = false;     // "cr_tail_starve": k_cr_tail is launched WITHOUT its top workgroup and with a short wait: what a device too busy to hold
                                    // all its workgroups at once looks like (the host must notice and repeat that solve as separate launches)
   int cu_count = 0;                // "cu_count" > 0: plan launches as if the device had this many compute units (a CU-masked or partitioned device)
@@ -294,6 +296,20 @@ void launch_pcg_update_xr(hipStream_t st, int n, const double* p, const double* 
 constexpr int kPcgFusedMax = 32768;
 void launch_pcg_dir(hipStream_t st, int n, const double* r, const double* z, double* p, double* s, bool first);          // r.z, p = z + beta p
 void launch_pcg_step(hipStream_t st, int n, const double* p, const double* q, double* x, double* r, double* s);          // p.q, x, r, r.r
+// The whole PCG solve as one persistent launch (hitl_pcg.hip): systems with pose pairs outside the band, one GPU, chains of at most
+// 64 chunks whose factor tiles fit LDS.  pcg_fused_plan: the launch geometry, or false (the launch-per-stage loop of hitl_lm.cpp runs).
+struct PcgPlan { int M, chunks, Tp, G; size_t lds_bytes, work_doubles; };
+bool pcg_fused_plan(int nsb, int B, int n_rows, int cus, PcgPlan* out);
+size_t pcg_fused_sync_words();
+// x: in x0 = M^-1 b, out the solution; r0 = b - A x0 with its (r.r, b.b) partials (launch_spmv_residual); work: PcgPlan::work_doubles
+// doubles of device memory, ZERO when allocated and never touched by anything else (hand-off granules tagged by launch_index, which
+// must grow by one per launch on that buffer, starting at 1); sync: pcg_fused_sync_words() words, zero when allocated;
+// result_pinned[4] (host memory): CG iterations, r.r, status (0 converged or iteration cap, 1 breakdown, 2 a wait between
+// workgroups ran out: the solve is void, 3 not finite), b.b
+bool launch_pcg_fused(hipStream_t st, const PcgPlan& pl, int n_poses, int npad, const FactorView& fv, const LinView& lin, const CrView& cr, const double* scale,
+                      double mu, double min_diag, double max_diag, double tol, int max_it, double* x, const double* r0, const double* partials0, int nblk0,
+                      double* work, unsigned* sync, uint64_t launch_index, double* result_pinned, unsigned spins, bool starve = false,
+                      unsigned long long* probe = nullptr /* HITL_TIMING: 16 x G timestamps of CG iteration 2 */);
 // y = alpha*x + beta*y
 void launch_axpby(hipStream_t st, int n, double alpha, const double* x, double beta, double* y);
 void launch_copy(hipStream_t st, int n, const double* src, double* dst);

@@ -343,6 +343,63 @@ static int enqueue_linear_solve_banded(hitl_solver* s, const FactorView& fv, int
   return HITL_OK;
 }
 
+// Pose pairs outside the band, one GPU, queue only (round 6): band factorisation + x0 = M^-1 b, the residual, the WHOLE preconditioned CG
+// as one persistent launch (hitl_pcg.hip: its scalars never leave the device, it stops by itself and leaves a four-double record in
+// pinned memory), then the trust-region bookkeeping and the candidate.  As in the banded case the caller queues the candidate's
+// linearisation right behind and waits ONCE per LM iteration (rounds 2-5: three waits + one per four CG iterations).
+static int enqueue_linear_solve_pcg(hitl_solver* s, const FactorView& fv, int buf, double mu, const double* xcur, double* xcand, const PcgPlan& pl, bool timed) {
+  hipStream_t st = s->stream;
+  const LinView lv = s->lin_view(buf);
+  const CrView cr = s->cr_view();
+  const double mind = s->opt.min_lm_diagonal, maxd = s->opt.max_lm_diagonal;
+  const int npad = s->npad;
+  const double tol = std::max(s->opt.linear_solver_tolerance, 1e-15);
+  if (s->pcg_work.n < pl.work_doubles) {                  // hand-off granules: zero once, tags only ever grow afterwards
+    TRY(s->pcg_work.resize(pl.work_doubles + pl.work_doubles / 4));
+    TRY(s->pcg_work.zero(st));
+  }
+  if (s->pcg_sync.p == nullptr) { TRY(s->pcg_sync.resize(pcg_fused_sync_words())); TRY(s->pcg_sync.zero(st)); }
+  launch_build_system(st, s->n, fv.band_poses, lv, s->scale.p, s->fixed.p, mu, mind, maxd, cr, s->rhs.p, s->wv.p);
+  launch_cr_factor_solve(st, cr, s->wv.p, s->dt.p);   // x0 = M^{-1} b
+  launch_spmv_residual(st, s->n, npad, fv, lv, s->scale.p, mu, mind, maxd, s->dt.p, s->rhs.p, s->rv.p, s->step_partials.p);
+  double* rec = s->h_scalars + 8;
+  rec[0] = 0.0; rec[1] = 0.0; rec[2] = -1.0; rec[3] = 0.0;      // status -1: nobody has reported (the previous launch has long finished: the host waited for it)
+  if (timed) HIP_TRY(hipEventRecord(s->ev4, st));
+  unsigned long long* probe = nullptr;
+  if (dev_switches().timing && s->pcg_launches == 0) {
+    TRY(s->pcg_probe.resize((size_t)pl.G * 16));
+    TRY(s->pcg_probe.zero(st));
+    probe = s->pcg_probe.p;
+  }
+  const bool starve = dev_switches().pcg_starve;                             // test hook: no top workgroup, short waits -- the chunk workgroups give up
+  const unsigned spins = starve ? 1u << 10 : 1u << 20;
+  if (!launch_pcg_fused(st, pl, s->n, npad, fv, lv, cr, s->scale.p, mu, mind, maxd, tol, (int)s->opt.max_linear_iterations, s->dt.p, s->rv.p, s->step_partials.p,
+                        spmv_blocks(npad), s->pcg_work.p, s->pcg_sync.p, ++s->pcg_launches, rec, spins, starve, probe))
+    return fail(HITL_ERR_HIP, "the persistent PCG kernel could not be launched");
+  if (probe != nullptr) {                                  // HITL_TIMING, first solve only: where one CG iteration's time goes, per role
+    std::vector<unsigned long long> h((size_t)pl.G * 16);
+    HIP_TRY(hipMemcpyAsync(h.data(), probe, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    auto us = [&](int wg, int a_, int b_) { return (h[(size_t)wg * 16 + b_] >= h[(size_t)wg * 16 + a_] && h[(size_t)wg * 16 + a_] != 0) ? (double)(h[(size_t)wg * 16 + b_] - h[(size_t)wg * 16 + a_]) * 0.01 : -1.0; };
+    const unsigned long long t00 = h[0];
+    auto at = [&](int wg, int slot) { return h[(size_t)wg * 16 + slot] ? ((double)h[(size_t)wg * 16 + slot] - (double)t00) * 0.01 : -1.0; };
+    std::fprintf(stderr, "k_pcg_fused probe (CG iteration 2; M %d, chunks %d, G %d), us relative to chunk 0's start of the iteration:\n", pl.M, pl.chunks, pl.G);
+    for (int wg : {0, pl.chunks / 2, pl.chunks - 1})
+      std::fprintf(stderr, "  chunk %3d: start %.2f | fwd done + ctr out %.2f | top's z taken %.2f | back + z out %.2f | r.r check %.2f | products out %.2f | w, delta taken %.2f | end %.2f  (iteration %.2f us)\n",
+                   wg, at(wg, 0), at(wg, 1), at(wg, 2), at(wg, 3), at(wg, 4), at(wg, 5), at(wg, 6), at(wg, 7), us(wg, 0, 7));
+    { const int wg = pl.G - 1;
+      std::fprintf(stderr, "  top      : start %.2f | ctr taken %.2f | solved %.2f | z out %.2f | r.r check %.2f | end %.2f\n", at(wg, 0), at(wg, 1), at(wg, 2), at(wg, 3), at(wg, 4), at(wg, 7)); }
+    for (int wg : {pl.chunks, (pl.chunks + pl.G - 1) / 2, pl.G - 2})
+      if (wg >= pl.chunks && wg < pl.G - 1)
+        std::fprintf(stderr, "  helper %3d: start %.2f | r.r check %.2f | products out %.2f | end %.2f\n", wg, at(wg, 0), at(wg, 4), at(wg, 5), at(wg, 7));
+    s->pcg_probe.release();
+  }
+  if (timed) HIP_TRY(hipEventRecord(s->ev5, st));
+  launch_spmv_step(st, s->n, npad, fv, lv, s->scale.p, s->dt.p, s->rhs.p, xcur, s->qv.p, xcand, s->h_partials, fv.with_stf ? s->pose_cs.p : nullptr);
+  HIP_TRY(hipGetLastError());
+  return HITL_OK;
+}
+
 // ---------------------------------------------------------------------------------------
 // distributed PCG pieces (submap ranks holding pose pairs outside the band)
 // ---------------------------------------------------------------------------------------
@@ -912,10 +969,37 @@ int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float* poses
     const bool time_solver = o.timing_level >= 2;
     if (time_solver) HIP_TRY(hipEventRecord(s->ev2, st));
     StepScalars ss;
-    const bool fused = (!s->dist_mode() && fv.n_offband == 0);   // one host synchronisation per LM iteration
+    bool fused = (!s->dist_mode() && fv.n_offband == 0);   // one host synchronisation per LM iteration
+    PcgPlan pcg_plan;
+    const bool fused_pcg = !fused && !s->dist_mode() && fv.n_offband > 0 && dev_switches().pcg_fused && !s->pcg_fused_off &&
+                           pcg_fused_plan(s->nsb, s->B, s->npad / 3, s->cu_count, &pcg_plan);
     LinResult lr_spec = {0.0, 0.0, 0.f, 0};
     bool have_spec = false;
-    if (fused) {
+    if (fused_pcg) {
+      const bool pcg_timed = o.timing_level >= 2 || (o.timing_level == 1 && (iter & 3) == 1);
+      { RoctxRange r("hitl:queue PCG solve + step"); TRY(enqueue_linear_solve_pcg(s, fv, cur, radius, xcur, xcand, pcg_plan, pcg_timed)); }
+      if (time_solver) HIP_TRY(hipEventRecord(s->ev3, st));
+      { RoctxRange r("hitl:queue linearisation of the candidate");
+        TRY(enqueue_linearize(s, fv, xcand, cur ^ 1, /*direct=*/true, /*have_trig=*/true)); }
+      { RoctxRange r("hitl:wait for the device"); TRY(spin_sync(s)); }
+      const double* rec = s->h_scalars + 8;
+      const double st_pcg = rec[2];
+      if (st_pcg == 2.0 || st_pcg < 0.0) {                        // a wait between the workgroups ran out (or nobody reported): this solve is void
+        s->pcg_fused_off = true;
+        (void)take_cr_tail_failure(s);
+        --iter; continue;                                         // the same iteration again, one launch group per CG iteration
+      }
+      if (take_cr_tail_failure(s)) { --iter; continue; }
+      if (st_pcg != 0.0) ok = false;                              // breakdown / not finite: an invalid step
+      lin_iters = 1 + (int)rec[0];
+      if (pcg_timed) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, s->ev4, s->ev5));
+        S.pcg_ms += ms; S.pcg_timed_calls += 1.0; S.pcg_timed_iterations += rec[0];
+      }
+      TRY(finish_step_partials(s, nullptr, nullptr, &ss));
+      fused = true;                                               // from here on: the banded flow (the candidate's linearisation is in pinned memory)
+    } else if (fused) {
       { RoctxRange r("hitl:queue linear solve + step"); TRY(enqueue_linear_solve_banded(s, fv, cur, radius, xcur, xcand)); }
       if (time_solver) HIP_TRY(hipEventRecord(s->ev3, st));
       const double seq = (double)(++s->sync_seq);

@@ -591,6 +591,8 @@ extern "C" int hitl_test_set_switch(const char* name, long long value) {
   else if (k == "cr_seq_m") d.cr_seq_m = (int)std::max(0ll, std::min(64ll, value));
   else if (k == "cr_tail") d.cr_tail = value != 0;
   else if (k == "cr_tail_starve") d.cr_tail_starve = value != 0;
+  else if (k == "pcg_fused") d.pcg_fused = value != 0;
+  else if (k == "pcg_starve") d.pcg_starve = value != 0;
   else if (k == "cu_count") d.cu_count = (int)std::max(0ll, std::min(4096ll, value));
   else if (k == "stf_addr64") d.stf_addr64 = value != 0;
   else if (k == "device_lm") d.device_lm = value != 0;
@@ -711,7 +713,7 @@ int hitl_solver_create(const hitl_options* opt, hitl_solver** out) {
   s->device = o.device;
   auto bail = [&](int code, const std::string& m) { hitl_solver_destroy(s); return fail(code, m); };
   if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) return bail(HITL_ERR_HIP, "hipStreamCreate failed");
-  for (hipEvent_t* e : {&s->ev0, &s->ev1, &s->ev2, &s->ev3})
+  for (hipEvent_t* e : {&s->ev0, &s->ev1, &s->ev2, &s->ev3, &s->ev4, &s->ev5})
     if (hipEventCreate(e) != hipSuccess) return bail(HITL_ERR_HIP, "hipEventCreate failed");
   if (hipHostMalloc((void**)&s->h_scalars, sizeof(double) * (kNumScalars + 8)) != hipSuccess) return bail(HITL_ERR_HIP, "hipHostMalloc failed");
   std::memset(s->h_scalars, 0, sizeof(double) * (kNumScalars + 8));
@@ -759,7 +761,7 @@ void hitl_solver_destroy(hitl_solver* s) {
   s->comm_send.release(); s->comm_recv.release(); s->fixed.release(); s->if_cols.release(); s->halo_idx.release();
   s->iface_dev.release(); s->rhsN.release(); s->zN.release(); s->coef_dev.release(); s->halo_val.release(); s->halo_sc.release();
   if (s->h_scalars) (void)hipHostFree(s->h_scalars);
-  for (hipEvent_t e : {s->ev0, s->ev1, s->ev2, s->ev3, s->ev_stage[0], s->ev_stage[1]}) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : {s->ev0, s->ev1, s->ev2, s->ev3, s->ev4, s->ev5, s->ev_stage[0], s->ev_stage[1]}) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : s->lm_events) if (e) (void)hipEventDestroy(e);
   s->lm_dev.release();
   if (s->stream) (void)hipStreamDestroy(s->stream);

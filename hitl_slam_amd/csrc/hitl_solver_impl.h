@@ -20,7 +20,7 @@ struct hitl_solver {
   bool staging_queued = false;  // copies out of the pinned staging buffers (setup_factors, the start state) may still be in flight
   int64_t lin_launches = 0;     // linearisations queued so far (every 4th is bracketed by events at timing_level 1)
   bool lin_timed = false;       // the linearisation in flight is bracketed
-  double* h_scalars = nullptr;  // pinned, kNumScalars + 8: [14] = k_cr_tail's failure word, [15] = sequence word of spin_sync, [kNumScalars ..] = progress record of the device-driven LM loop
+  double* h_scalars = nullptr;  // pinned, kNumScalars + 8: [8..11] = result record of the persistent PCG launch (or the scalars of the launch-per-stage loop), [14] = k_cr_tail's failure word, [15] = sequence word of spin_sync, [kNumScalars ..] = progress record of the device-driven LM loop
   DevArray<LmDev> lm_dev;       // device-resident state of the LM loop (lm_decide_step in k_assemble)
   DevArray<unsigned> lm_arrivals;             //   workgroups of the deciding launch that have stored their partials (k_assemble)
   std::vector<hipEvent_t> lm_events;   // pairs bracketing k_linearize_stf launches queued ahead (device-driven loop)
@@ -124,6 +124,12 @@ struct hitl_solver {
   DevArray<unsigned> cr_ticket;                // k_cr_tail's four ticket words (zero between launches)
   double prepare_pcie_bytes = 0.0;             // host -> device bytes of the last prepare() (factor tables): hitl_summary.pcie_bytes
   int cu_count = 256;                          // compute units of the device
+  bool pcg_fused_off = false;                  // a wait inside the persistent PCG launch once ran out on this device: the launch-per-stage loop from then on
+  DevArray<double> pcg_work;                   // k_pcg_fused: hand-off buffers (PcgPlan::work_doubles)
+  DevArray<unsigned> pcg_sync;                 //   its abort word
+  DevArray<unsigned long long> pcg_probe;      //   HITL_TIMING: phase timestamps of one CG iteration of the first launch
+  uint64_t pcg_launches = 0;                   //   launches so far on pcg_work (the epoch base of the granule tags)
+  hipEvent_t ev4 = nullptr, ev5 = nullptr;     //   brackets of that launch (hitl_summary.pcg_ms)
   bool cr_tail_off = false;                    // a wait inside k_cr_tail once ran out on this device: separate launches from then on
   DevArray<char> stf_pose_recs;                // per-pose descriptor records of the half-wave linearisation (k_linearize_stf_r)
   int64_t stf_pose_recs_of = -1;               //   correspondence-set generation they belong to

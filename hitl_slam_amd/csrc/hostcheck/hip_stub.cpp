@@ -73,6 +73,10 @@ bool match_kd_tgt_applies(int slots, int window, const MatchParams& mp) { return
 size_t stf_pose_rec_bytes() { return 128; }
 bool cr_build_factor_solve_is_fused(const CrView&, const CrSource&, double*, double*) { return true; }
 bool cr_sep_applies(const CrView& chain, const CrSource&, double*, double*) { return chain.rsep && chain.nsb >= 2; }
+bool pcg_fused_plan(int, int, int, int, PcgPlan*) { return false; }      // the stub device runs no kernels: the host keeps the launch-per-stage loop
+size_t pcg_fused_sync_words() { return 32; }
+bool launch_pcg_fused(hipStream_t, const PcgPlan&, int, int, const FactorView&, const LinView&, const CrView&, const double*, double, double, double, double, int,
+                      double*, const double*, const double*, int, double*, unsigned*, uint64_t, double*, unsigned, bool, unsigned long long*) { return false; }
 const char* kernels_build_info() { return "hostcheck stub (no device code)"; }
 }  // namespace hitl
 

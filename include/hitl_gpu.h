@@ -169,7 +169,12 @@ typedef struct hitl_summary {
    * hitl_solver_solve (poses in and out, factor tables, the per-iteration partial sums). */
   double hbm_bytes;
   double pcie_bytes;
-  double reserved[3];
+  /* the persistent PCG launch of systems with pose pairs outside the band (one launch per linear solve): device time of the
+   * pcg_timed_calls launches that were bracketed by events (hitl_options.timing_level: 1 = every fourth solve, 2 = all) and the CG
+   * iterations those launches ran -- pcg_ms / pcg_timed_iterations is the time of one CG iteration.  All 0 when no such launch ran. */
+  double pcg_ms;
+  double pcg_timed_calls;
+  double pcg_timed_iterations;
 } hitl_summary;
 
 typedef struct hitl_solver hitl_solver;   /* opaque; owns device memory */

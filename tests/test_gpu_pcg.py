@@ -1,0 +1,152 @@
+"""The sparse PCG solve (systems with pose pairs outside the band: the reference's all-pairs search on a map that revisits places,
+JointOptimization.cpp:561-642; solved by SPARSE_SCHUR at :145-162, 1208) -- since round 6 ONE persistent launch per linear solve
+(hitl_slam_amd/csrc/hitl_pcg.hip).  Held to the oracle's exact solve (a banded Cholesky over the whole pair bandwidth) on a Figure-8
+drive at a size the oracle finishes in seconds, to the launch-per-stage loop of rounds 2-5 (test hook pcg_fused = 0: the same LM
+path), over every band width and over chain lengths on both sides of the fused launch's limits, and with the failure path forced
+(pcg_starve: the launch runs without its top workgroup, the chunk workgroups give up, the host repeats that solve the old way)."""
+import numpy as np
+import pytest
+
+import figure8
+from conftest import Problem
+from hitl_slam_amd import abi
+from hitl_slam_amd.api import hc_rows
+
+pytestmark = pytest.mark.gpu
+
+
+def _pdiff(a, b):
+    d = np.asarray(a, np.float64) - np.asarray(b, np.float64)
+    d[:, 2] = np.angle(np.exp(1j * d[:, 2]))
+    return float(np.abs(d[:, :2]).max()), float(np.abs(d[:, 2]).max())
+
+
+def _fig8(n, m, laps):
+    d = figure8.make(n, m, seed=7, laps=laps)
+    rows = hc_rows(figure8.constraints(d["gt"], 5, 3))
+    return d, rows
+
+
+def _load(solver, d, rows):
+    solver.set_map(d["off"], d["px"], d["py"], d["nx"], d["ny"], d["cov"])
+    solver.set_human_constraints(rows)
+    return solver
+
+
+def test_figure8_all_pairs_mode_c_equals_the_oracles_exact_solve():
+    """BASELINE configs[2] at a size the oracle's dense factorisation finishes in seconds (400 poses x 120 points, two laps): the
+    same correspondence sets, the same LM path, poses within 1e-4 m / 1e-4 rad -- and the linear solves really ran as the one
+    persistent launch (hitl_summary.pcg_timed_calls)."""
+    import hitl_slam_amd as H
+    from oracle import hitl_oracle as O
+    d, rows = _fig8(400, 120, 2)
+    opt = H.default_options()
+    opt.timing_level = 2
+    g, o = _load(H.Solver(opt), d, rows), _load(O.OracleSolver(), d, rows)
+    g.find_correspondences(d["init"], 0)
+    o.find_correspondences(d["init"], 0, 1)
+    cg, co = g.get_correspondences(), o.get_correspondences()
+    for a, b in zip(cg, co):
+        assert np.array_equal(a, b)
+    assert np.abs(cg[0] - cg[1]).max() > 100                      # lap-to-lap revisits were matched: pose pairs far outside the band
+    pg, sg = g.solve(abi.MODE_JOINT, d["init"])
+    po, so = o.solve(abi.MODE_JOINT, d["init"])
+    assert sg.num_offband_pairs > 0 and sg.linear_iterations > 2 * sg.iterations
+    assert sg.pcg_timed_calls == sg.iterations and sg.pcg_timed_iterations == sg.linear_iterations - sg.iterations and sg.pcg_ms > 0
+    assert sg.termination == so.termination and sg.iterations == so.iterations
+    assert sg.successful_steps == so.successful_steps and sg.unsuccessful_steps == so.unsuccessful_steps
+    assert abs(sg.final_cost - so.final_cost) <= 1e-8 * so.final_cost
+    dxy, dth = _pdiff(pg, po)
+    assert dxy <= 1e-4 and dth <= 1e-4, (dxy, dth)
+    print("figure-8 400 x 120 all pairs: %d LM / %d CG iterations, %.1f us per CG iteration, cost %.12g (oracle %.12g), |dxy| %.2e |dth| %.2e"
+          % (sg.iterations, sg.linear_iterations - sg.iterations, 1e3 * sg.pcg_ms / max(sg.pcg_timed_iterations, 1), sg.final_cost, so.final_cost, dxy, dth))
+    g.close(); o.close()
+
+
+@pytest.mark.parametrize("band", [1, 2, 3, 4])
+@pytest.mark.parametrize("n,m,laps", [(64, 60, 2), (150, 90, 2), (333, 60, 3), (700, 48, 4)])
+def test_persistent_launch_walks_the_path_of_the_launch_per_stage_loop(switches, band, n, m, laps):
+    """Same map, same correspondences, same options: the persistent launch (Chronopoulos-Gear recurrence, workgroup roles) and the loop
+    of rounds 2-5 (textbook PCG, eight launches per iteration) solve every linear system to the same tolerance: the same LM iterations,
+    accepted steps and termination, final costs equal to 1e-9, poses to 1e-6.  Band widths 1-4 (super-blocks of 3, 6, 9 and 12), chains
+    from 16 to 700 nodes."""
+    import hitl_slam_amd as H
+    d, rows = _fig8(n, m, laps)
+    res = []
+    corr = None
+    for fused in (1, 0):
+        switches(pcg_fused=fused)
+        opt = H.default_options()
+        opt.max_band_poses = band
+        opt.timing_level = 2
+        g = _load(H.Solver(opt), d, rows)
+        if corr is None:
+            g.find_correspondences(d["init"], 0)
+            corr = g.get_correspondences()
+        else:
+            g.set_correspondences(*corr)
+        p, sm = g.solve(abi.MODE_JOINT, d["init"], allow_failure=True)
+        res.append((p, sm))
+        g.close()
+    (pf, sf), (pl, sl) = res
+    assert sf.num_offband_pairs == sl.num_offband_pairs > 0 and sf.band_poses == sl.band_poses <= band
+    assert sl.pcg_timed_calls == 0
+    # (chains shorter than four super-blocks keep the loop: nothing to spread over workgroups)
+    assert sf.pcg_timed_calls == (sf.iterations if (n + sf.band_poses - 1) // sf.band_poses >= 4 else 0)
+    assert (sf.termination, sf.iterations, sf.successful_steps, sf.unsuccessful_steps) == (sl.termination, sl.iterations, sl.successful_steps, sl.unsuccessful_steps)
+    assert abs(sf.final_cost - sl.final_cost) <= 1e-9 * sl.final_cost
+    dxy, dth = _pdiff(pf, pl)
+    assert dxy <= 1e-6 and dth <= 1e-6, (dxy, dth)
+
+
+def test_a_wait_that_runs_out_voids_the_solve_and_the_host_repeats_it(switches):
+    """pcg_starve: the launch starts without its top workgroup and with short waits -- what a device too busy to hold every workgroup at once
+    looks like.  The chunk workgroups give up, the record in pinned memory says so, the host repeats that LM iteration on the
+    launch-per-stage loop and stays there: the result is the loop's result, no error, no hang."""
+    import hitl_slam_amd as H
+    d, rows = _fig8(150, 90, 2)
+    out = []
+    corr = None
+    for hooks in (dict(pcg_fused=0), dict(pcg_starve=1)):
+        switches(**hooks)
+        opt = H.default_options()
+        opt.timing_level = 2
+        g = _load(H.Solver(opt), d, rows)
+        if corr is None:
+            g.find_correspondences(d["init"], 0)
+            corr = g.get_correspondences()
+        else:
+            g.set_correspondences(*corr)
+        out.append(g.solve(abi.MODE_JOINT, d["init"]))
+        # a second solve on the same solver: the persistent launch stays off (no second timeout)
+        out.append(g.solve(abi.MODE_JOINT, d["init"]))
+        g.close()
+        H.set_test_switch(None)
+    (p0, s0), (p0b, s0b), (p1, s1), (p1b, s1b) = out
+    assert s1.pcg_timed_calls == 0 and s1b.pcg_timed_calls == 0
+    for p, sm in ((p1, s1), (p1b, s1b)):
+        assert (sm.termination, sm.iterations, sm.successful_steps) == (s0.termination, s0.iterations, s0.successful_steps)
+        assert sm.final_cost == s0.final_cost and np.array_equal(p, p0)
+
+
+def test_corridor_all_pairs_dense_off_band_rows():
+    """One straight corridor searched all pairs: ~90 off-band blocks per pose (every pose sees most of the others), the densest rows the
+    product kernel meets; against the oracle."""
+    import hitl_slam_amd as H
+    from oracle import hitl_oracle as O
+    prob = Problem(240, 96, ppf=240, groups=2)
+    g, o = prob.load(H.Solver()), prob.load(O.OracleSolver())
+    g.find_correspondences(prob.init, 0)
+    o.find_correspondences(prob.init, 0, 1)
+    for a, b in zip(g.get_correspondences(), o.get_correspondences()):
+        assert np.array_equal(a, b)
+    pg, sg = g.solve(abi.MODE_JOINT, prob.init)
+    po, so = o.solve(abi.MODE_JOINT, prob.init)
+    print("corridor 240 x 96 all pairs: %d off-band block pairs (%.1f per pose), %d LM / %d CG iterations" % (
+        sg.num_offband_pairs, sg.num_offband_pairs / prob.n, sg.iterations, sg.linear_iterations - sg.iterations))
+    assert sg.num_offband_pairs > 2 * prob.n
+    assert sg.termination == so.termination and sg.iterations == so.iterations
+    assert abs(sg.final_cost - so.final_cost) <= 1e-8 * so.final_cost
+    dxy, dth = _pdiff(pg, po)
+    assert dxy <= 1e-4 and dth <= 1e-4
+    g.close(); o.close()
