@@ -47,6 +47,14 @@ WORKLOAD_SEED = {"c2": 2, "c4": 4, "c5": 5}
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def kernel_source_sha(path=None):
+    """Short hash of the source of the dominant kernel (hitl_slam_amd/csrc/hitl_kernels.hip): profiles/traffic_*.json stores it, and a
+    profile taken on another source text is not used for `roofline.traffic`."""
+    import hashlib
+    path = path or os.path.join(ROOT, "hitl_slam_amd", "csrc", "hitl_kernels.hip")
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+
+
 def algorithmic_bytes_stf(n_obs, n_matches, n_poses, n_pairs):
     """Algorithmic bytes of ONE k_linearize_stf launch, SURVEY.md section 8(d) `linearize` row
     restricted to what this kernel touches: 16 B per observation (point + normal, read once as
@@ -480,12 +488,18 @@ def main():
     # HBM bytes per launch are NOT measured in this run: they come from the committed PMC passes of the same command
     # (tools/profile_bench.sh: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, separate rocprofv3 --pmc runs)
     # and are used only when that profile was taken on exactly this workload; otherwise the layout's compulsory bytes.
-    traffic, traffic_source = None, None
+    traffic, traffic_source, traffic_stale = None, None, None
     tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            if tj.get("n_obs") == n_obs and (tj.get("n_matches") in (None, int(n_matches_l))):
+            # the counters describe the kernel that was profiled: the profile carries the hash of the kernel source it was taken on
+            # (tools/summarize_profile.py), and a profile of another source text is stale -- the layout's compulsory bytes then
+            stale = tj.get("kernel_source_sha") != kernel_source_sha()
+            if stale:
+                traffic_stale = "profiles/traffic_%s.json was taken on another hitl_kernels.hip (sha %s, now %s): not used, `achieved` is from the layout's compulsory bytes" % (
+                    args.workload, tj.get("kernel_source_sha"), kernel_source_sha())
+            if not stale and tj.get("n_obs") == n_obs and (tj.get("n_matches") in (None, int(n_matches_l))):
                 traffic = tj.get("hbm_bytes_per_launch")
                 traffic_source = "profiles/traffic_%s.json (%s; kernel-trace average %.1f us in that run)" % (
                     args.workload, tj.get("source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py"), tj.get("stf_avg_us", 0.0))
@@ -547,6 +561,7 @@ def main():
         # target gathers from L2, so that figure can exceed the peak and is not a bandwidth.
         "roofline": {"bound": "hbm", "kernel": "k_linearize_stf", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                     "traffic_stale": traffic_stale,
                      "bytes_per_launch_used_for_achieved": moved,
                      "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_achieved": alg_achieved,
                      "algorithmic_frac": alg_achieved / HBM_PEAK_GBS,
@@ -582,28 +597,15 @@ def main():
     # ---- measured device-copy ceiling beside the vendor peak; untimed side leg, never part of `value` or `frac` ----
     if world == 1 and not args.no_copy_ceiling:
         try:
-            n_words = 1 << 28                                     # 1 GiB of fp32: 1 GiB read + 1 GiB written per copy
-            a = torch.empty(n_words, dtype=torch.float32, device="cuda")
-            a.fill_(1.0)
-            b = torch.empty_like(a)
-            for _ in range(3):
-                b.copy_(a)
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(10):
-                b.copy_(a)
-            e1.record()
-            torch.cuda.synchronize()
-            copy_ms = e0.elapsed_time(e1) / 10.0
-            copy_gbs = 2.0 * n_words * 4 / (copy_ms * 1e-3) / 1e9
-            del a, b
-            torch.cuda.empty_cache()
+            from hitl_slam_amd.api import device_copy_bandwidth
+            nbytes, reps = 1 << 30, 10                              # 1 GiB read + 1 GiB written per launch
+            copy_gbs = device_copy_bandwidth(dev_index, nbytes, reps)
             result["roofline"]["measured_copy_ceiling"] = {
-                "GB/s": copy_gbs, "ms_per_copy": copy_ms, "bytes_per_copy": 2 * n_words * 4,
+                "GB/s": copy_gbs, "ms_per_copy": 2.0 * nbytes / (copy_gbs * 1e9) * 1e3 if copy_gbs > 0 else None, "bytes_per_copy": 2 * nbytes,
                 "achieved_over_ceiling": (achieved / copy_gbs) if copy_gbs > 0 else None,
-                "what": "torch device-to-device copy of 1 GiB (read + write counted), 10 repeats between two events on torch's stream, "
-                        "after the timed region; `frac` stays against the 8 TB/s vendor peak"}
+                "what": "hitl_device_copy_bandwidth: the library's float4 grid-stride copy kernel (four loads in flight per lane, 8 workgroups per CU) "
+                        "over 1 GiB, read + write counted, 10 launches between two HIP events on its own stream after 2 warm-up launches, after the "
+                        "timed region; `frac` stays against the 8 TB/s vendor peak"}
         except Exception as e:
             result["roofline"]["measured_copy_ceiling"] = {"failed": repr(e)}
 

@@ -681,6 +681,17 @@ class Solver(SolverBase):
         self._check(self._fn("find_corr")(self._h, _ptr(pin, _f32p), int(window)), "find_corr")
 
 
+def device_copy_bandwidth(device=0, nbytes=1 << 30, repeats=10, lib_path=None):
+    """hitl_device_copy_bandwidth: GB/s (read + write) of the library's float4 grid-stride copy over nbytes on `device`."""
+    lib = load_library(lib_path)
+    out = C.c_double()
+    lib.hitl_device_copy_bandwidth.argtypes = [C.c_int32, C.c_int64, C.c_int32, C.POINTER(C.c_double)]
+    st = lib.hitl_device_copy_bandwidth(int(device), int(nbytes), int(repeats), C.byref(out))
+    if st != abi.OK:
+        raise HitlError(st, "hitl_device_copy_bandwidth", "")
+    return out.value
+
+
 def device_memory(device=0, lib_path=None):
     """(free, total) bytes of a HIP device."""
     lib = load_library(lib_path)

@@ -298,7 +298,7 @@ void launch_pcg_dir(hipStream_t st, int n, const double* r, const double* z, dou
 void launch_pcg_step(hipStream_t st, int n, const double* p, const double* q, double* x, double* r, double* s);          // p.q, x, r, r.r
 // The whole PCG solve as one persistent launch (hitl_pcg.hip): systems with pose pairs outside the band, one GPU, chains of at most
 // 64 chunks whose factor tiles fit LDS.  pcg_fused_plan: the launch geometry, or false (the launch-per-stage loop of hitl_lm.cpp runs).
-struct PcgPlan { int M, chunks, Tp, G; size_t lds_bytes, work_doubles; };
+struct PcgPlan { int M, chunks, Tp, G, capw; size_t lds_bytes, work_doubles; };
 bool pcg_fused_plan(int nsb, int B, int n_rows, int cus, PcgPlan* out);
 size_t pcg_fused_sync_words();
 // x: in x0 = M^-1 b, out the solution; r0 = b - A x0 with its (r.r, b.b) partials (launch_spmv_residual); work: PcgPlan::work_doubles
@@ -313,6 +313,7 @@ bool launch_pcg_fused(hipStream_t st, const PcgPlan& pl, int n_poses, int npad, 
 // y = alpha*x + beta*y
 void launch_axpby(hipStream_t st, int n, double alpha, const double* x, double beta, double* y);
 void launch_copy(hipStream_t st, int n, const double* src, double* dst);
+void launch_copy_f4(hipStream_t st, size_t n_f4, const float4* src, float4* dst, int blocks);      // hitl_device_copy_bandwidth
 
 // correspondence search (JointOptimization.cpp:561-642)
 struct MatchParams { float thr, min_cos; int cap, skip; };

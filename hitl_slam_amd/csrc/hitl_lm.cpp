@@ -385,13 +385,17 @@ static int enqueue_linear_solve_pcg(hitl_solver* s, const FactorView& fv, int bu
     auto at = [&](int wg, int slot) { return h[(size_t)wg * 16 + slot] ? ((double)h[(size_t)wg * 16 + slot] - (double)t00) * 0.01 : -1.0; };
     std::fprintf(stderr, "k_pcg_fused probe (CG iteration 2; M %d, chunks %d, G %d), us relative to chunk 0's start of the iteration:\n", pl.M, pl.chunks, pl.G);
     for (int wg : {0, pl.chunks / 2, pl.chunks - 1})
-      std::fprintf(stderr, "  chunk %3d: start %.2f | fwd done + ctr out %.2f | top's z taken %.2f | back + z out %.2f | r.r check %.2f | products out %.2f | w, delta taken %.2f | end %.2f  (iteration %.2f us)\n",
-                   wg, at(wg, 0), at(wg, 1), at(wg, 2), at(wg, 3), at(wg, 4), at(wg, 5), at(wg, 6), at(wg, 7), us(wg, 0, 7));
+      std::fprintf(stderr, "  chunk %3d: start %.2f | fwd done + ctr out %.2f | top's z taken %.2f | back + z out %.2f | r.r check %.2f | w, delta taken %.2f | end %.2f  (iteration %.2f us)\n",
+                   wg, at(wg, 0), at(wg, 1), at(wg, 2), at(wg, 3), at(wg, 4), at(wg, 6), at(wg, 7), us(wg, 0, 7));
     { const int wg = pl.G - 1;
       std::fprintf(stderr, "  top      : start %.2f | ctr taken %.2f | solved %.2f | z out %.2f | r.r check %.2f | end %.2f\n", at(wg, 0), at(wg, 1), at(wg, 2), at(wg, 3), at(wg, 4), at(wg, 7)); }
     for (int wg : {pl.chunks, (pl.chunks + pl.G - 1) / 2, pl.G - 2})
       if (wg >= pl.chunks && wg < pl.G - 1)
-        std::fprintf(stderr, "  helper %3d: start %.2f | r.r check %.2f | products out %.2f | end %.2f\n", wg, at(wg, 0), at(wg, 4), at(wg, 5), at(wg, 7));
+        std::fprintf(stderr, "  products %3d: start %.2f | r.r check %.2f | products out %.2f\n", wg, at(wg, 0), at(wg, 4), at(wg, 5));
+    std::fprintf(stderr, "  chunk 0 forward sweep in detail: updates + r.r %.2f | level 1 products %.2f | level 1 survivors %.2f | level 2 %.2f | level 3 %.2f | level 4 %.2f | ctr out %.2f\n",
+                 at(0, 9), at(0, 10), at(0, 11), at(0, 12), at(0, 13), at(0, 14), at(0, 1));
+    { const double cyc = (double)(h[8 + 7] - h[8 + 0]), t_us = us(0, 0, 7);
+      std::fprintf(stderr, "  shader clock over chunk 0's iteration: %.0f cycles in %.2f us = %.0f MHz\n", cyc, t_us, t_us > 0 ? cyc / t_us : 0.0); }
     s->pcg_probe.release();
   }
   if (timed) HIP_TRY(hipEventRecord(s->ev5, st));

@@ -14,16 +14,17 @@
 //
 //   * chunk workgroups c = 0 .. chunks-1: each owns M consecutive nodes of the reduction tree (M * Wb poses).  Their Dinv / Gl / Gr
 //     tiles are loaded into LDS ONCE and stay there for every CG iteration of the solve; x, r, p, s = A p of the owned rows live in LDS
-//     too.  Per iteration: the vector updates, the local levels of the preconditioner's forward sweep, later its back-substitution.
-//   * the top workgroup (G - 1): the nodes 0, M, 2M, ... (one per chunk), tiles resident in LDS: the upper levels of the sweep.
-//   * every workgroup but the top: its share of the product w = A z, one wave per pose over the pose's band and off-band blocks.
+//     too.  Per iteration: the vector updates, the local levels of the preconditioner's forward sweep, later its back-substitution --
+//     all by ONE wave (the sweep is a chain of small dependent levels: a second wave would only add barriers: measured, 4 x slower).
+//   * the top workgroup (the last one): the nodes 0, M, 2M, ... (one per chunk), tiles resident in LDS: the upper levels, one wave.
+//   * product workgroups (the ones between): w = A z, one wave per pose over the pose's band and off-band blocks.  The matrix does
+//     not change during a solve: every wave keeps its poses' 3x3 blocks (already oriented) and column indices in LDS.
 //
 // The recurrence is Chronopoulos & Gear's single-reduction form of PCG (z = M^-1 r, w = A z, gamma = r.z, delta = w.z,
 // beta = gamma / gamma_old, alpha = gamma / (delta - beta gamma / alpha_old), p = z + beta p, s = w + beta s, x += alpha p, r -= alpha s):
 // the same iterates as textbook PCG in exact arithmetic, with ONE all-to-all reduction per iteration instead of two.  A CG iteration is
-// four hand-offs: chunks -> top (boundary contributions), top -> chunks (z at the chunk boundaries), chunks -> everybody (z, gamma, r.r),
-// everybody -> chunks (w, delta).  Every handed-off double is written and read with agent-scope atomic accesses (sc1: past the
-// per-XCD L2s, which are not coherent with each other) and announced through monotonic counters -- no fences, no L2 write-backs.
+// four hand-offs: chunks -> top (boundary contributions), top -> chunks (z at the chunk boundaries), chunks -> product waves (z; r.z and
+// r.r ride along), product waves -> chunks (w, delta).  Every handed-off double travels as a tagged 16-byte granule (below).
 // Sums across workgroups are formed by every reader in the same fixed order: all workgroups take identical decisions, and a solve
 // is bit-reproducible for a given launch geometry.  All waits are bounded; a wait that runs out (the workgroups were not all
 // resident: a device shared with another process) marks the solve as void and the host repeats it on the launch-per-stage path.
@@ -63,83 +64,140 @@ __device__ __forceinline__ void pcg_abort_set(const PcgPoll& pp, unsigned code) 
   __hip_atomic_store(pp.abort_w, (pp.launch << 2) | code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// spin until the granule carries `tag`.  Every wait is bounded; the abort word ends all of them: 1 = the chunk workgroups have ended the
-// solve (breakdown), 2 = somebody's wait ran out.  SLEEP: polls of data that is usually a while away back off between loads.
+// Every wait is bounded and the abort word ends all of them: 1 = the chunk workgroups have ended the solve (breakdown), 2 = somebody's
+// wait ran out.  Called every 64th poll of a spin loop; true = give up.
+__device__ __forceinline__ bool pcg_give_up(unsigned k, const PcgPoll& pp) {
+  if (k >= pp.spins) { pcg_abort_set(pp, 2u); return true; }
+  return pcg_abort_code(pp) != 0u;
+}
+
+// spin until the granule carries `tag`.  SLEEP: polls of data that is usually a while away back off between loads.
 template <bool SLEEP>
 __device__ __forceinline__ double gran_take(const v2f64* p, double tag, const PcgPoll& pp, bool& bad) {
   for (unsigned k = 1;; ++k) {
     const v2f64 g = gran_ld(p);
     if (g.y == tag) return g.x;
-    if ((k & 63u) == 0u) {
-      if (k >= pp.spins) { pcg_abort_set(pp, 2u); bad = true; return 0.0; }
-      if (pcg_abort_code(pp) != 0u) { bad = true; return 0.0; }
-    }
+    if ((k & 63u) == 0u && pcg_give_up(k, pp)) { bad = true; return 0.0; }
     if (SLEEP) __builtin_amdgcn_s_sleep(2);
   }
 }
-
-// sum over the workgroup of one value per thread, fixed order; result in every thread.  sm: kPcgWaves doubles of LDS.
-__device__ __forceinline__ double pcg_block_sum(double v, double* sm) {
-  v = wave_sum(v);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  __syncthreads();
-  if (lane == 0) sm[wave] = v;
-  __syncthreads();
-  double t = 0.0;
-#pragma unroll
-  for (int k = 0; k < kPcgWaves; ++k) t += sm[k];
-  return t;
+// three granules at once (the three scalars of a pose): all loads of a round are in flight together
+__device__ __forceinline__ void gran_take3(const v2f64* p, double tag, const PcgPoll& pp, bool& bad, double& v0, double& v1, double& v2) {
+  for (unsigned k = 1;; ++k) {
+    const v2f64 g0 = gran_ld(p), g1 = gran_ld(p + 1), g2 = gran_ld(p + 2);
+    if (g0.y == tag && g1.y == tag && g2.y == tag) { v0 = g0.x; v1 = g1.x; v2 = g2.x; return; }
+    if ((k & 63u) == 0u && pcg_give_up(k, pp)) { bad = true; v0 = v1 = v2 = 0.0; return; }
+  }
 }
-
-// One level of the forward sweep over local nodes held in LDS (node u at index u; tiles of node u at (u - toff) * BB).
-// Eliminated: u with lowbit(u) == s, 1 <= u <= u_max.  ca[u] = Gl_u^T w_u goes to node u - s, cb[u] = Gr_u^T w_u to node u + s.
-template <int B>
-__device__ __forceinline__ void pcg_fwd_products(const double* sGl, const double* sGr, const double* w, double* ca, double* cb, int s, int Mloc, int u_max,
-                                                 int toff) {
-  constexpr int BB = B * B;
-  const int nel = Mloc / (2 * s);
-  for (int e = threadIdx.x; e < nel * 2 * B; e += kPcgThreads) {
-    const int u = s * (2 * (e / (2 * B)) + 1), which = (e / B) & 1, c = e % B;
-    if (u > u_max) continue;
-    const double* G = (which ? sGr : sGl) + (size_t)(u - toff) * BB;
-    const double* wu = w + (size_t)u * B;
-    double cw = 0.0;
-#pragma unroll
-    for (int r = 0; r < B; ++r) cw += G[r * B + c] * wu[r];
-    (which ? cb : ca)[(size_t)u * B + c] = cw;
+// count granules into LDS by one wave (entry e = lane, lane + 64, ...): every pending load of a round is in flight together
+__device__ __forceinline__ void gran_take_rows(const v2f64* p, int count, double tag, const PcgPoll& pp, bool& bad, double* out, int lane) {
+  unsigned pend = 0u;
+  for (int k = 0; lane + WAVE * k < count; ++k) pend |= 1u << k;         // count <= 16 * 64 (pcg_fused_plan: a chunk's rows <= 512)
+  for (unsigned spin = 1; pend != 0u; ++spin) {
+    for (unsigned m = pend; m != 0u; m &= m - 1u) {
+      const int k = __builtin_ctz(m), e = lane + WAVE * k;
+      const v2f64 g = gran_ld(p + e);
+      if (g.y == tag) { out[e] = g.x; pend &= ~(1u << k); }
+    }
+    if (pend != 0u) {
+      if ((spin & 63u) == 0u && pcg_give_up(spin, pp)) { bad = true; return; }
+      __builtin_amdgcn_s_sleep(1);
+    }
   }
 }
 
-// One level of the back-substitution: x_u = Dinv_u w_u - Gl_u x_{u-s} - Gr_u x_{u+s} for lowbit(u) == s, 1 <= u <= u_max.  xs holds
-// zeros at nodes that do not exist.
+// LDS written by some lanes of a wave and read by others of the SAME wave: the hardware keeps a wave's LDS operations in order;
+// the compiler must not move a read above the write it depends on
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// ---- the sweep's coefficients in LDS -----------------------------------------------------------------------------------------
+// One wave works through a level: an LDS read instruction takes as many passes as lanes fall on one bank, and the plain tile
+// layout [node][row][column] put the nodes of a level (1152 bytes apart) on the same banks (measured: 5-7 passes per read, the sweep of a
+// 16-node chunk 9.5 us per CG iteration).  The tiles are therefore stored LEVEL by level with the node index k fastest (node
+// u = s (2 k + 1) of the level of stride s, nel = Mloc / (2 s) nodes), so that the lanes of a read touch consecutive words:
+//   GL, GR (used by columns in the forward sweep, by rows in the back-substitution):  [row r][slot (c + r) mod B][k]  -- the rotation by
+//          r makes BOTH uses conflict-free (columns: lanes (c, k) cover a contiguous range; rows: lanes (r, k) of a half-wave differ
+//          in (c + r) nel mod 32);
+//   DI (rows only):  [column c][row r][k].
+// Levels follow each other: level of stride s starts (Mloc - Mloc / s) tiles in.  Vectors (w, xs, ca, cb) keep B + 1 doubles per node.
 template <int B>
-__device__ __forceinline__ void pcg_back_level(const double* sDi, const double* sGl, const double* sGr, const double* w, double* xs, int s, int Mloc, int u_max,
-                                               int toff) {
-  constexpr int BB = B * B;
+__device__ __forceinline__ size_t pcg_level_off(int Mloc, int s) { return (size_t)(Mloc - Mloc / s) * B * B; }
+
+// forward products of the level of stride s: item e = (which B + c) nel + k; ca[u] = Gl_u^T w_u goes to node u - s, cb[u] = Gr_u^T w_u to u + s
+template <int B>
+__device__ __forceinline__ void pcg_fwd_products(const double* GL, const double* GR, const double* w, double* ca, double* cb, int s, int Mloc, int u_max, int lane) {
+  constexpr int BP = B + 1;
   const int nel = Mloc / (2 * s);
-  for (int e = threadIdx.x; e < nel * B; e += kPcgThreads) {
-    const int u = s * (2 * (e / B) + 1), r = e % B;
+  const size_t off = pcg_level_off<B>(Mloc, s);
+  for (int e = lane; e < nel * 2 * B; e += WAVE) {
+    const int k = e % nel, wc = e / nel, which = wc / B, c = wc % B, u = s * (2 * k + 1);
     if (u > u_max) continue;
-    const double* Di = sDi + (size_t)(u - toff) * BB + r * B;
-    const double* Gl = sGl + (size_t)(u - toff) * BB + r * B;
-    const double* Gr = sGr + (size_t)(u - toff) * BB + r * B;
-    const double* wu = w + (size_t)u * B;
-    const double* xl = xs + (size_t)(u - s) * B;
-    const double* xr = xs + (size_t)(u + s) * B;
-    double acc = 0.0;
+    const double* G = (which ? GR : GL) + off + k;
+    const double* wu = w + (size_t)u * BP;
+    double c0 = 0.0, c1 = 0.0;                      // two chains: a dependent fp64 FMA chain of B links is what a level waits for
 #pragma unroll
-    for (int c = 0; c < B; ++c) acc += Di[c] * wu[c];
+    for (int r = 0; r < B; ++r) {
+      const int slot = (c + r >= B) ? c + r - B : c + r;
+      const double g = G[(size_t)(r * B + slot) * nel];
+      if (r & 1) c1 += g * wu[r]; else c0 += g * wu[r];
+    }
+    (which ? cb : ca)[(size_t)u * BP + c] = c0 + c1;
+  }
+}
+
+// back-substitution of the level of stride s: item e = r nel + k: x_u[r] = Dinv_u[r,:] w_u - Gl_u[r,:] x_{u-s} - Gr_u[r,:] x_{u+s}
+// (xs holds zeros at nodes that do not exist)
+template <int B>
+__device__ __forceinline__ void pcg_back_level(const double* DI, const double* GL, const double* GR, const double* w, double* xs, int s, int Mloc, int u_max, int lane) {
+  constexpr int BP = B + 1;
+  const int nel = Mloc / (2 * s);
+  const size_t off = pcg_level_off<B>(Mloc, s);
+  for (int e = lane; e < nel * B; e += WAVE) {
+    const int k = e % nel, r = e / nel, u = s * (2 * k + 1);
+    if (u > u_max) continue;
+    const double* Di = DI + off + e;
+    const double* Gl = GL + off + (size_t)r * B * nel + k;
+    const double* Gr = GR + off + (size_t)r * B * nel + k;
+    const double* wu = w + (size_t)u * BP;
+    const double* xl = xs + (size_t)(u - s) * BP;
+    const double* xr = xs + (size_t)(u + s) * BP;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;            // three independent chains
 #pragma unroll
-    for (int c = 0; c < B; ++c) acc -= Gl[c] * xl[c];
-#pragma unroll
-    for (int c = 0; c < B; ++c) acc -= Gr[c] * xr[c];
-    xs[(size_t)u * B + r] = acc;
+    for (int c = 0; c < B; ++c) {
+      const int slot = (c + r >= B) ? c + r - B : c + r;
+      a0 += Di[(size_t)c * B * nel] * wu[c];
+      a1 += Gl[(size_t)slot * nel] * xl[c];
+      a2 += Gr[(size_t)slot * nel] * xr[c];
+    }
+    xs[(size_t)u * BP + r] = (a0 - a1) - a2;
+  }
+}
+
+// the tiles of the local nodes 1 .. Mloc - 1 into that layout, by the whole workgroup; local node u is global node gbase + u * gstride and exists for u <= u_max
+template <int B>
+__device__ __forceinline__ void pcg_fill_tiles(const CrView& cr, double* GL, double* GR, double* DI, int Mloc, int u_max, size_t gbase, size_t gstride) {
+  constexpr int BB = B * B;
+  for (int t = threadIdx.x; t < (Mloc - 1) * BB; t += kPcgThreads) {
+    const int u = 1 + t / BB, e = t % BB, r = e / B, c = e % B;
+    const int s = u & -u, nel = Mloc / (2 * s), k = (u / s - 1) / 2;
+    const size_t off = pcg_level_off<B>(Mloc, s);
+    const bool ex = u <= u_max;
+    const size_t g = (gbase + (size_t)u * gstride) * BB + e;
+    const int slot = (c + r >= B) ? c + r - B : c + r;
+    GL[off + (size_t)(r * B + slot) * nel + k] = ex ? cr.Gl[g] : 0.0;
+    GR[off + (size_t)(r * B + slot) * nel + k] = ex ? cr.Gr[g] : 0.0;
+    DI[off + (size_t)(c * B + r) * nel + k] = ex ? cr.Dinv[g] : 0.0;
   }
 }
 
 struct PcgArgs {
   int n_poses, npad, nsb, Wb;
-  int M, chunks, Tp, G;          // chunk size (a power of two), chunks = top nodes, Tp = the power of two >= chunks, workgroups
+  int M, chunks, Tp, G;          // chunk size (a power of two), chunks = top nodes, Tp = the power of two >= chunks, workgroups:
+                                 // [0, chunks) the chunks, [chunks, G - 1) the product workgroups, G - 1 the top
+  int capw;                      // product entries a wave keeps in LDS
   double mu, min_diag, max_diag, tol2;
   double tag0;                   // epoch base of this launch: the granules of CG iteration `it` carry tag0 + it + 1
   int max_it;
@@ -155,332 +213,365 @@ struct PcgArgs {
   v2f64* topL;                   // chunks x B: z at the chunk's first node
   v2f64* topR;                   // chunks x B: z at the NEXT chunk's first node (the chunk's right boundary)
   v2f64* gamG; v2f64* rrG;       // chunks each: r.z and r.r of the chunk's rows
-  v2f64* delG;                   // G: w.z of the workgroup's product rows
+  v2f64* delG;                   // product workgroups: w.z of the workgroup's rows
   unsigned* abort_w;
   unsigned launch;               // low 30 bits of the solver's launch counter (see PcgPoll)
   double* result;                // pinned host memory: iterations, r.r, status (0 ok, 1 breakdown, 2 a wait ran out, 3 not finite), b.b
   unsigned long long* probe;     // HITL_TIMING: 16 timestamps (100 MHz) per workgroup around the phases of CG iteration 2, or null
 };
 
-#define PCG_PROBE(slot) do { if (a.probe != nullptr && it == 2 && tid == 0) a.probe[(size_t)wg * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define PCG_PROBE(slot) do { if (a.probe != nullptr && it == 2 && tid == 0) { a.probe[(size_t)wg * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+    if ((slot) == 0 || (slot) == 7) a.probe[(size_t)wg * 16 + 8 + (slot)] = __builtin_readcyclecounter(); } } while (0)
+
+// sum of the chunks' r.r granules (every workgroup: is the solve over?): lane 0 waits for the first chunk's, then the others' are on their way
+__device__ __forceinline__ double pcg_rr_sum(const v2f64* rrG, int T, double tag, const PcgPoll& pp, bool& bad, int lane) {
+  double v = 0.0;
+  if (lane == 0) v = gran_take<true>(rrG, tag, pp, bad);
+  for (int c = lane + (lane == 0 ? WAVE : 0); c < T; c += WAVE) v += gran_take<false>(rrG + c, tag, pp, bad);
+  return wave_sum(v);
+}
 
 template <int B>
 __global__ __launch_bounds__(kPcgThreads) void k_pcg_fused(PcgArgs a, FactorView fv, LinView lin, CrView cr, const double* __restrict__ scale) {
   constexpr int BB = B * B;
   extern __shared__ double lds[];
   __shared__ double s_red[kPcgWaves];
-  __shared__ double s_sc[8];               // [0] rr, [1] gamma, [2] delta, [6] bb
+  __shared__ double s_sc[8];               // [0] rr (product workgroups), [6] bb, [7] rr0
   const int tid = threadIdx.x, wg = blockIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int M = a.M, T = a.chunks, Tp = a.Tp, H = a.G - 1;
+  const int M = a.M, T = a.chunks, Tp = a.Tp, Hh = a.G - 1 - a.chunks;
   const bool is_top = (wg == a.G - 1), is_chunk = (wg < a.chunks);
   const PcgPoll pp = {a.abort_w, a.spins, a.launch};
-
-  // ---- LDS carve-up (one dynamic block sized for the larger role) ----
-  // chunk: tiles of the interior nodes 1 .. M-1 | w, xs (M + 1 nodes) | ca, cb (M nodes) | xv rv pv sv zl (M nodes) | accL0, accRM
-  // top:   tiles of the nodes 0 .. T-1          | w (Tp nodes), xs (2 Tp + 1 nodes: zeros beyond T - 1) | ca, cb (Tp nodes)
-  double *sGl, *sGr, *sDi, *w, *xs, *ca, *cb, *xv = nullptr, *rv = nullptr, *pv = nullptr, *sv = nullptr, *zl = nullptr, *accL0 = nullptr, *accRM = nullptr;
-  int nv = 0, nvB = 0;
-  if (is_top) {
-    sGl = lds; sGr = sGl + (size_t)T * BB; sDi = sGr + (size_t)T * BB;
-    w = sDi + (size_t)T * BB; xs = w + (size_t)Tp * B; ca = xs + (size_t)(2 * Tp + 1) * B; cb = ca + (size_t)Tp * B;
-  } else {
-    sGl = lds; sGr = sGl + (size_t)(M - 1) * BB; sDi = sGr + (size_t)(M - 1) * BB;
-    w = sDi + (size_t)(M - 1) * BB; xs = w + (size_t)(M + 1) * B; ca = xs + (size_t)(M + 1) * B; cb = ca + (size_t)M * B;
-    xv = cb + (size_t)M * B; rv = xv + (size_t)M * B; pv = rv + (size_t)M * B; sv = pv + (size_t)M * B; zl = sv + (size_t)M * B;
-    accL0 = zl + (size_t)M * B; accRM = accL0 + B;
-    if (is_chunk) { nv = min(M, a.nsb - wg * M); nvB = nv * B; }
-  }
-  const size_t row0 = (size_t)wg * M * B;           // first owned row of a chunk workgroup
-
-  // ---- set-up: tiles into LDS (they stay for the whole solve), the owned rows of x0 and r0 ----
-  if (is_top) {
-    for (int e = tid; e < T * BB; e += kPcgThreads) {
-      const size_t g = (size_t)(e / BB) * M * BB + (e % BB);
-      sGl[e] = cr.Gl[g]; sGr[e] = cr.Gr[g]; sDi[e] = cr.Dinv[g];
-    }
-    for (int e = tid; e < (2 * Tp + 1) * B; e += kPcgThreads) xs[e] = 0.0;
-  } else if (is_chunk) {
-    for (int e = tid; e < (nv - 1) * BB; e += kPcgThreads) {
-      const size_t g = ((size_t)wg * M + 1) * BB + e;
-      sGl[e] = cr.Gl[g]; sGr[e] = cr.Gr[g]; sDi[e] = cr.Dinv[g];
-    }
-    for (int e = tid; e < (M + 1) * B; e += kPcgThreads) { xs[e] = 0.0; w[e] = 0.0; }
-    for (int t = tid; t < M * B; t += kPcgThreads) {
-      const bool own = t < nvB;
-      xv[t] = own ? a.x[row0 + t] : 0.0; rv[t] = own ? a.r0[row0 + t] : 0.0; pv[t] = 0.0; sv[t] = 0.0; zl[t] = 0.0;
-    }
-  }
-  // ---- the product rows of this wave: pose i0 first, then every (H * kPcgWaves)-th.  The matrix does not change during the solve: the
-  //      first pose's first entry per lane (its 3x3 block, its column) and the row constants stay in registers for every iteration ----
-  const int W1 = a.Wb + 1, nband = 2 * a.Wb + 1, n_rows = a.npad / 3;
-  const int i0 = wg * kPcgWaves + wave;
-  const bool have_i0 = !is_top && i0 < n_rows;
-  const bool ident0 = have_i0 && (i0 >= a.n_poses || fv.fixed[i0]);
-  int tot0 = 0, e00 = 0, j0 = 0, tr0 = 0;
-  bool ent0 = false;
-  double bk[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  double sa0 = 1.0, dd0 = 0.0;             // lanes 0..2: scale of row 3 i0 + lane; clamp(sa^2 H_aa) / mu / sa
-  if (have_i0 && !ident0) {
-    e00 = (fv.n_offband > 0) ? fv.obadj_off[i0] : 0;
-    tot0 = nband + ((fv.n_offband > 0) ? fv.obadj_off[i0 + 1] - e00 : 0);
-    if (lane < tot0) {
-      const double* blk = nullptr;
-      if (lane < nband) {
-        if (lane <= a.Wb) { j0 = i0 + lane; tr0 = 0; if (j0 < a.n_poses) blk = lin.Hband + ((size_t)i0 * W1 + lane) * 9; }
-        else { const int d = lane - a.Wb; j0 = i0 - d; tr0 = 1; if (j0 >= 0) blk = lin.Hband + ((size_t)j0 * W1 + d) * 9; }
-      } else {
-        const int e = e00 + lane - nband, ent = fv.obadj_ent[e];
-        j0 = fv.obadj_col[e]; tr0 = ent & 1; blk = lin.obblk + (size_t)(ent >> 1) * 9;
-      }
-      if (blk != nullptr) {
-        ent0 = true;
-#pragma unroll
-        for (int q = 0; q < 9; ++q) bk[q] = blk[q];
-      }
-    }
-    if (lane < 3) {
-      sa0 = scale[3 * i0 + lane];
-      const double dg = sa0 * sa0 * lin.Hband[(size_t)i0 * W1 * 9 + lane * 4];
-      dd0 = fmin(fmax(dg, a.min_diag), a.max_diag) / a.mu / sa0;
-    }
-  }
   {  // r0.r0 and b.b from the residual pass in front of this launch (a kernel boundary: plain data), every workgroup alike
     double r_ = 0.0, b_ = 0.0;
     if (tid < WAVE) {
       for (int k = tid; k < a.nblk0; k += WAVE) { r_ += a.partials0[(size_t)k * 8]; b_ += a.partials0[(size_t)k * 8 + 1]; }
       r_ = wave_sum(r_); b_ = wave_sum(b_);
     }
-    if (tid == 0) { s_sc[0] = r_; s_sc[6] = b_; }
+    if (tid == 0) { s_sc[7] = r_; s_sc[6] = b_; }
+  }
+  int it = 0;
+  int status = 0;
+  double rr = 0.0, bb = 0.0;
+
+  if (!is_chunk && !is_top) {
+    // =============================== product workgroup: w = A z over its waves' poses ===============================
+    // wave gw takes poses gw, gw + Hh * 8, ...; their entries (band blocks both ways + off-band blocks), oriented, sit in LDS:
+    // SoA blkS[q][capw] + colS[capw] per wave; entries beyond capw are read from memory every iteration (never on maps of
+    // hitl-slam's size).  Per pose: sum over its entries of block * (scale z)[column], reduced over the wave, finished by lanes 0..2.
+    const int capw = a.capw;
+    double* blkS = lds + (size_t)wave * capw * 10;
+    int* colS = reinterpret_cast<int*>(blkS + (size_t)capw * 9);
+    const int W1 = a.Wb + 1, nband = 2 * a.Wb + 1, n_rows = a.npad / 3;
+    const int gw = (wg - a.chunks) * kPcgWaves + wave, TW = Hh * kPcgWaves;
+    auto entry = [&](int i, int e0, int idx, const double*& blk, int& j, int& tr) -> bool {       // entry idx of pose i; false: no such block
+      if (idx < nband) {
+        if (idx <= a.Wb) { j = i + idx; tr = 0; if (j >= a.n_poses) return false; blk = lin.Hband + ((size_t)i * W1 + idx) * 9; }
+        else { const int d = idx - a.Wb; j = i - d; tr = 1; if (j < 0) return false; blk = lin.Hband + ((size_t)j * W1 + d) * 9; }
+      } else {
+        const int e = e0 + idx - nband, ent = fv.obadj_ent[e];
+        j = fv.obadj_col[e]; tr = ent & 1; blk = lin.obblk + (size_t)(ent >> 1) * 9;
+      }
+      return true;
+    };
+    {
+      int o = 0;
+      for (int i = gw; i < n_rows; i += TW) {
+        if (i >= a.n_poses || fv.fixed[i]) continue;
+        const int e0 = (fv.n_offband > 0) ? fv.obadj_off[i] : 0;
+        const int total = nband + ((fv.n_offband > 0) ? fv.obadj_off[i + 1] - e0 : 0);
+        for (int idx = lane; idx < total && o + idx < capw; idx += WAVE) {
+          const double* blk = nullptr;
+          int j = -1, tr = 0;
+          const bool ok = entry(i, e0, idx, blk, j, tr);
+          colS[o + idx] = ok ? j : -1;
+          if (ok) {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) blkS[(size_t)q * capw + o + idx] = tr ? blk[(q % 3) * 3 + q / 3] : blk[q];
+          }
+        }
+        o += total;
+      }
+    }
+    __syncthreads();
+    bb = s_sc[6]; rr = s_sc[7];
+    const double target = a.tol2 * bb;
+    if (!(rr == rr)) status = 3;
+    const bool run = (status == 0) && (rr > target) && a.max_it > 0;
+    while (run) {
+      const double tag = a.tag0 + (double)(it + 1);
+      bool bad = false;
+      PCG_PROBE(0);
+      if (wave == 0) { const double v = pcg_rr_sum(a.rrG, T, tag, pp, bad, lane); if (lane == 0) s_sc[0] = v; }
+      if (__syncthreads_or(bad ? 1 : 0)) { status = 5; break; }
+      rr = s_sc[0];
+      PCG_PROBE(4);
+      if (!(rr == rr)) { status = 3; break; }
+      if (!(rr > target) || it >= a.max_it) break;
+      double dz = 0.0;
+      int o = 0;
+      for (int i = gw; i < n_rows; i += TW) {
+        if (i >= a.n_poses || fv.fixed[i]) {                                  // identity rows (padding, constant poses; their scale is 1): w = z
+          if (lane < 3) { const double z = gran_take<false>(a.zsG + 3 * i + lane, tag, pp, bad); gran_st(a.wG + 3 * i + lane, z, tag); dz += z * z; }
+          continue;
+        }
+        const int e0 = (fv.n_offband > 0) ? fv.obadj_off[i] : 0;
+        const int total = nband + ((fv.n_offband > 0) ? fv.obadj_off[i + 1] - e0 : 0);
+        double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, d0 = 0.0, d1 = 0.0, d2 = 0.0;      // d: (scale z) of the pose's own column (entry 0 = the diagonal block)
+        for (int idx = lane; idx < total; idx += WAVE) {
+          double b9[9];
+          int j;
+          if (o + idx < capw) {
+            j = colS[o + idx];
+            if (j < 0) continue;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) b9[q] = blkS[(size_t)q * capw + o + idx];
+          } else {
+            const double* blk = nullptr;
+            int tr = 0;
+            if (!entry(i, e0, idx, blk, j, tr)) continue;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) b9[q] = tr ? blk[(q % 3) * 3 + q / 3] : blk[q];
+          }
+          double v0, v1, v2;
+          gran_take3(a.zsG + 3 * j, tag, pp, bad, v0, v1, v2);
+          if (idx == 0) { d0 = v0; d1 = v1; d2 = v2; }
+          acc0 += b9[0] * v0 + b9[1] * v1 + b9[2] * v2;
+          acc1 += b9[3] * v0 + b9[4] * v1 + b9[5] * v2;
+          acc2 += b9[6] * v0 + b9[7] * v1 + b9[8] * v2;
+        }
+        acc0 = wave_sum(acc0); acc1 = wave_sum(acc1); acc2 = wave_sum(acc2);
+        d1 = __shfl(d1, 0, WAVE); d2 = __shfl(d2, 0, WAVE);
+        if (lane < 3) {
+          const int t = 3 * i + lane;
+          const double sa = scale[t];
+          const double dg = sa * sa * lin.Hband[(size_t)i * W1 * 9 + lane * 4];
+          const double dd = fmin(fmax(dg, a.min_diag), a.max_diag) / a.mu / sa;
+          const double sz = (lane == 0) ? d0 : (lane == 1) ? d1 : d2;       // (lane 0 took the diagonal block's column itself)
+          const double accv = (lane == 0) ? acc0 : (lane == 1) ? acc1 : acc2;
+          const double y = sa * accv + dd * sz;            // (S H S + D^2) z, with z = sz / sa
+          gran_st(a.wG + t, y, tag);
+          dz += y * (sz / sa);
+        }
+        o += total;
+      }
+      {
+        dz = wave_sum(dz);
+        __syncthreads();
+        if (lane == 0) s_red[wave] = dz;
+        __syncthreads();
+        if (tid == 0) {
+          double t = 0.0;
+#pragma unroll
+          for (int k = 0; k < kPcgWaves; ++k) t += s_red[k];
+          gran_st(a.delG + (wg - a.chunks), t, tag);
+        }
+      }
+      PCG_PROBE(5);
+      PCG_PROBE(7);
+      ++it;
+    }
+    if (tid == 0 && status == 5 && pcg_abort_code(pp) != 1u) __hip_atomic_store(a.result + 2, 2.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
+
+  // =============================== chunk workgroups and the top: one wave each ===============================
+  // ---- LDS carve-up (vectors keep BP = B + 1 doubles per node) ----
+  // chunk: GL GR DI of the interior nodes 1 .. M-1 (level layout) | w, xs (M + 1 nodes) | ca, cb (M nodes) | xv rv pv sv zl wl scl (M B rows) | accL0, accRM
+  // top:   GL GR DI of the nodes 1 .. Tp-1 | Dinv of node 0 | w (Tp nodes), xs (2 Tp + 1 nodes: zeros beyond T - 1) | ca, cb (Tp nodes)
+  constexpr int BP = B + 1;
+  double *sGl, *sGr, *sDi, *sD0 = nullptr, *w, *xs, *ca, *cb, *xv = nullptr, *rv = nullptr, *pv = nullptr, *sv = nullptr, *zl = nullptr, *wl = nullptr, *scl = nullptr,
+         *accL0 = nullptr, *accRM = nullptr;
+  int nv = 0, nvB = 0;
+  const size_t row0 = (size_t)wg * M * B;           // first owned row of a chunk workgroup
+  if (is_top) {
+    sGl = lds; sGr = sGl + (size_t)(Tp - 1) * BB; sDi = sGr + (size_t)(Tp - 1) * BB; sD0 = sDi + (size_t)(Tp - 1) * BB;
+    w = sD0 + BB; xs = w + (size_t)Tp * BP; ca = xs + (size_t)(2 * Tp + 1) * BP; cb = ca + (size_t)Tp * BP;
+    pcg_fill_tiles<B>(cr, sGl, sGr, sDi, Tp, T - 1, 0, (size_t)M);
+    for (int e = tid; e < BB; e += kPcgThreads) sD0[e] = cr.Dinv[e];
+    for (int e = tid; e < (2 * Tp + 1) * BP; e += kPcgThreads) xs[e] = 0.0;
+    for (int e = tid; e < Tp * BP; e += kPcgThreads) w[e] = 0.0;
+  } else {
+    sGl = lds; sGr = sGl + (size_t)(M - 1) * BB; sDi = sGr + (size_t)(M - 1) * BB;
+    w = sDi + (size_t)(M - 1) * BB; xs = w + (size_t)(M + 1) * BP; ca = xs + (size_t)(M + 1) * BP; cb = ca + (size_t)M * BP;
+    xv = cb + (size_t)M * BP; rv = xv + (size_t)M * B; pv = rv + (size_t)M * B; sv = pv + (size_t)M * B; zl = sv + (size_t)M * B;
+    wl = zl + (size_t)M * B; scl = wl + (size_t)M * B;
+    accL0 = scl + (size_t)M * B; accRM = accL0 + B;
+    nv = min(M, a.nsb - wg * M); nvB = nv * B;
+    pcg_fill_tiles<B>(cr, sGl, sGr, sDi, M, nv - 1, (size_t)wg * M, 1);
+    for (int e = tid; e < (M + 1) * BP; e += kPcgThreads) { xs[e] = 0.0; w[e] = 0.0; }
+    for (int t = tid; t < M * B; t += kPcgThreads) {
+      const bool own = t < nvB;
+      xv[t] = own ? a.x[row0 + t] : 0.0; rv[t] = own ? a.r0[row0 + t] : 0.0; pv[t] = 0.0; sv[t] = 0.0; zl[t] = 0.0; wl[t] = 0.0;
+      scl[t] = own ? scale[row0 + t] : 1.0;
+    }
   }
   __syncthreads();
-  const double bb = s_sc[6];
+  bb = s_sc[6]; rr = s_sc[7];
+  if (wave != 0) return;                              // from here on ONE wave per workgroup: no barriers below this line
   const double target = a.tol2 * bb;
-  double rr = s_sc[0];
   double alpha = 0.0, alpha_old = 0.0, gamma_old = 0.0;
-  int status = 0;
-  int it = 0;
   if (!(rr == rr)) status = 3;
   const bool run = (status == 0) && (rr > target) && a.max_it > 0;
 
   while (run) {
     const double tag = a.tag0 + (double)(it + 1);
     bool bad = false;
-    double rr_c = 0.0;
     PCG_PROBE(0);
     if (is_chunk) {
       // ---- P1: x += alpha p, r -= alpha s; r.r; the local levels of the forward sweep on r ----
       double rr_t = 0.0;
-      for (int t = tid; t < nvB; t += kPcgThreads) {
+      for (int t = lane; t < nvB; t += WAVE) {
         if (it > 0) { xv[t] += alpha * pv[t]; rv[t] -= alpha * sv[t]; }
         const double rt = rv[t];
-        w[t] = rt;
+        w[(t / B) * BP + t % B] = rt;
         rr_t += rt * rt;
       }
-      if (tid < 2 * B) accL0[tid] = 0.0;                 // accL0 and accRM are adjacent
-      rr_c = pcg_block_sum(rr_t, s_red);                 // (its barriers also publish w and the cleared accumulators)
+      if (lane < 2 * B) accL0[lane] = 0.0;               // accL0 and accRM are adjacent
+      const double rr_c = wave_sum(rr_t);
+      wave_lds_sync();
+      PCG_PROBE(9);
       for (int s = 1; s < M; s *= 2) {
-        pcg_fwd_products<B>(sGl, sGr, w, ca, cb, s, M, nv - 1, 1);
-        __syncthreads();
+        pcg_fwd_products<B>(sGl, sGr, w, ca, cb, s, M, nv - 1, lane);
+        wave_lds_sync();
+        if (s == 1) PCG_PROBE(10);
         const int nsv = M / (2 * s) + 1;
-        for (int e = tid; e < nsv * B; e += kPcgThreads) {
+        for (int e = lane; e < nsv * B; e += WAVE) {
           const int j = 2 * s * (e / B), q = e % B;
-          const double pl = (j - s >= 1 && j - s <= nv - 1) ? cb[(size_t)(j - s) * B + q] : 0.0;
-          const double pr = (j + s <= nv - 1 && j + s < M) ? ca[(size_t)(j + s) * B + q] : 0.0;
+          const double pl = (j - s >= 1 && j - s <= nv - 1) ? cb[(size_t)(j - s) * BP + q] : 0.0;
+          const double pr = (j + s <= nv - 1 && j + s < M) ? ca[(size_t)(j + s) * BP + q] : 0.0;
           if (j == 0) accL0[q] += pr;
           else if (j == M) accRM[q] += pl;
-          else if (j <= nv - 1) w[(size_t)j * B + q] = (w[(size_t)j * B + q] - pl) - pr;
+          else if (j <= nv - 1) w[(size_t)j * BP + q] = (w[(size_t)j * BP + q] - pl) - pr;
         }
-        __syncthreads();
+        wave_lds_sync();
+        if (s == 1) PCG_PROBE(11);
+        if (s == 2) PCG_PROBE(12);
+        if (s == 4) PCG_PROBE(13);
+        if (s == 8) PCG_PROBE(14);
       }
-      if (tid < 3 * B) {
-        const double v = (tid < B) ? accL0[tid] : (tid < 2 * B) ? accRM[tid - B] : rv[tid - 2 * B];
-        gran_st(a.ctrG + (size_t)wg * 3 * B + tid, v, tag);
+      if (lane < 3 * B) {
+        const double v = (lane < B) ? accL0[lane] : (lane < 2 * B) ? accRM[lane - B] : rv[lane - 2 * B];
+        gran_st(a.ctrG + (size_t)wg * 3 * B + lane, v, tag);
       }
       PCG_PROBE(1);
       // ---- P3: z at the two boundary nodes comes back from the top; back-substitution; r.z ----
-      if (tid < 2 * B) {
-        const int q = tid % B;
-        if (tid < B) xs[q] = gran_take<true>(a.topL + (size_t)wg * B + q, tag, pp, bad);
-        else xs[(size_t)M * B + q] = (wg + 1 < T) ? gran_take<true>(a.topR + (size_t)wg * B + q, tag, pp, bad) : 0.0;
+      if (lane < 2 * B) {
+        const int q = lane % B;
+        if (lane < B) xs[q] = gran_take<true>(a.topL + (size_t)wg * B + q, tag, pp, bad);
+        else xs[(size_t)M * BP + q] = (wg + 1 < T) ? gran_take<true>(a.topR + (size_t)wg * B + q, tag, pp, bad) : 0.0;
       }
-      if (__syncthreads_or(bad ? 1 : 0)) { status = 5; break; }
+      if (__any(bad ? 1 : 0)) { status = 5; break; }
+      wave_lds_sync();
       PCG_PROBE(2);
       for (int s = M / 2; s >= 1; s /= 2) {
-        pcg_back_level<B>(sDi, sGl, sGr, w, xs, s, M, nv - 1, 1);
-        __syncthreads();
+        pcg_back_level<B>(sDi, sGl, sGr, w, xs, s, M, nv - 1, lane);
+        wave_lds_sync();
       }
       double gz = 0.0;
-      for (int t = tid; t < nvB; t += kPcgThreads) {
-        const double z = xs[t];
+      for (int t = lane; t < nvB; t += WAVE) {
+        const double z = xs[(t / B) * BP + t % B];
         zl[t] = z;
         gz += rv[t] * z;
-        gran_st(a.zsG + row0 + t, scale[row0 + t] * z, tag);
+        gran_st(a.zsG + row0 + t, scl[t] * z, tag);
       }
-      const double gamma_c = pcg_block_sum(gz, s_red);
-      if (tid == 0) { gran_st(a.gamG + wg, gamma_c, tag); gran_st(a.rrG + wg, rr_c, tag); }
+      const double gamma_c = wave_sum(gz);
+      if (lane == 0) { gran_st(a.gamG + wg, gamma_c, tag); gran_st(a.rrG + wg, rr_c, tag); }
       PCG_PROBE(3);
-    } else if (is_top) {
-      // ---- P2: the upper levels: nodes 0, M, 2M, ... ----
-      for (int e = tid; e < T * B; e += kPcgThreads) {
-        const int t = e / B, q = e % B;
-        double v = gran_take<true>(a.ctrG + (size_t)t * 3 * B + 2 * B + q, tag, pp, bad);
-        v -= gran_take<false>(a.ctrG + (size_t)t * 3 * B + q, tag, pp, bad);
-        if (t >= 1) v -= gran_take<true>(a.ctrG + (size_t)(t - 1) * 3 * B + B + q, tag, pp, bad);
-        w[e] = v;
+    } else {
+      // ---- P2 (the top): the upper levels: nodes 0, M, 2M, ... ----
+      {
+        unsigned pend = 0u;
+        for (int k = 0; lane + WAVE * k < T * B; ++k) pend |= 1u << k;          // T * B <= 64 * 12
+        for (unsigned spin = 1; pend != 0u; ++spin) {
+          for (unsigned m = pend; m != 0u; m &= m - 1u) {
+            const int k = __builtin_ctz(m), e = lane + WAVE * k, t = e / B, q = e % B;
+            const v2f64 g0 = gran_ld(a.ctrG + (size_t)t * 3 * B + 2 * B + q), g1 = gran_ld(a.ctrG + (size_t)t * 3 * B + q);
+            v2f64 g2; g2.x = 0.0; g2.y = tag;
+            if (t >= 1) g2 = gran_ld(a.ctrG + (size_t)(t - 1) * 3 * B + B + q);
+            if (g0.y == tag && g1.y == tag && g2.y == tag) { w[t * BP + q] = (g0.x - g1.x) - g2.x; pend &= ~(1u << k); }
+          }
+          if (pend != 0u) {
+            if ((spin & 63u) == 0u && pcg_give_up(spin, pp)) { bad = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+        }
       }
-      if (__syncthreads_or(bad ? 1 : 0)) { status = 5; break; }
+      if (__any(bad ? 1 : 0)) { status = 5; break; }
+      wave_lds_sync();
       PCG_PROBE(1);
       for (int s = 1; s < Tp; s *= 2) {
-        pcg_fwd_products<B>(sGl, sGr, w, ca, cb, s, Tp, T - 1, 0);
-        __syncthreads();
+        pcg_fwd_products<B>(sGl, sGr, w, ca, cb, s, Tp, T - 1, lane);
+        wave_lds_sync();
         const int nsv = Tp / (2 * s);
-        for (int e = tid; e < nsv * B; e += kPcgThreads) {
+        for (int e = lane; e < nsv * B; e += WAVE) {
           const int j = 2 * s * (e / B), q = e % B;
           if (j > T - 1) continue;
-          const double pl = (j - s >= 1) ? cb[(size_t)(j - s) * B + q] : 0.0;
-          const double pr = (j + s <= T - 1) ? ca[(size_t)(j + s) * B + q] : 0.0;
-          w[(size_t)j * B + q] = (w[(size_t)j * B + q] - pl) - pr;
+          const double pl = (j - s >= 1) ? cb[(size_t)(j - s) * BP + q] : 0.0;
+          const double pr = (j + s <= T - 1) ? ca[(size_t)(j + s) * BP + q] : 0.0;
+          w[(size_t)j * BP + q] = (w[(size_t)j * BP + q] - pl) - pr;
         }
-        __syncthreads();
+        wave_lds_sync();
       }
-      if (tid < B) {
+      if (lane < B) {
         double v = 0.0;
 #pragma unroll
-        for (int c = 0; c < B; ++c) v += sDi[tid * B + c] * w[c];
-        xs[tid] = v;
+        for (int c = 0; c < B; ++c) v += sD0[lane * B + c] * w[c];
+        xs[lane] = v;
       }
-      __syncthreads();
+      wave_lds_sync();
       for (int s = Tp / 2; s >= 1; s /= 2) {
-        pcg_back_level<B>(sDi, sGl, sGr, w, xs, s, Tp, T - 1, 0);
-        __syncthreads();
+        pcg_back_level<B>(sDi, sGl, sGr, w, xs, s, Tp, T - 1, lane);
+        wave_lds_sync();
       }
       PCG_PROBE(2);
-      for (int e = tid; e < T * B; e += kPcgThreads) {
-        const double v = xs[e];
+      for (int e = lane; e < T * B; e += WAVE) {
+        const double v = xs[(e / B) * BP + e % B];
         gran_st(a.topL + e, v, tag);
         if (e >= B) gran_st(a.topR + (e - B), v, tag);
       }
       PCG_PROBE(3);
     }
-    // ---- everybody: r.r is out with z; is the solve over? ----
-    if (tid < WAVE) {
-      double v = 0.0;
-      if (tid == 0) v = gran_take<true>(a.rrG, tag, pp, bad);               // one poller per workgroup until the first chunk has published ...
-      for (int c = tid + (tid == 0 ? WAVE : 0); c < T; c += WAVE) v += gran_take<false>(a.rrG + c, tag, pp, bad);   // ... then the others' (on their way)
-      v = wave_sum(v);
-      if (tid == 0) s_sc[0] = v;
-    }
-    if (__syncthreads_or(bad ? 1 : 0)) { status = 5; break; }
-    rr = s_sc[0];
+    // ---- r.r is out with z; is the solve over? ----
+    rr = pcg_rr_sum(a.rrG, T, tag, pp, bad, lane);
+    if (__any(bad ? 1 : 0)) { status = 5; break; }
     PCG_PROBE(4);
     if (!(rr == rr)) { status = 3; break; }
     if (!(rr > target) || it >= a.max_it) break;
-    if (!is_top) {
-      // ---- P4: w = A z over this wave's poses, delta = w.z ----
-      double dz = 0.0;
-      for (int i = i0; i < n_rows; i += H * kPcgWaves) {
-        const bool first = (i == i0);
-        if (first ? ident0 : (i >= a.n_poses || fv.fixed[i])) {             // identity rows (padding, constant poses; their scale is 1): w = z
-          if (lane < 3) { const double z = gran_take<false>(a.zsG + 3 * i + lane, tag, pp, bad); gran_st(a.wG + 3 * i + lane, z, tag); dz += z * z; }
-          continue;
-        }
-        const int e0 = first ? e00 : ((fv.n_offband > 0) ? fv.obadj_off[i] : 0);
-        const int total = first ? tot0 : nband + ((fv.n_offband > 0) ? fv.obadj_off[i + 1] - e0 : 0);
-        double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
-        for (int idx = lane; idx < total; idx += WAVE) {
-          double b9[9];
-          int j, tr;
-          if (first && idx == lane) {                   // the resident entry
-            if (!ent0) continue;
-            j = j0; tr = tr0;
-#pragma unroll
-            for (int q = 0; q < 9; ++q) b9[q] = bk[q];
-          } else {
-            const double* blk;
-            if (idx < nband) {
-              if (idx <= a.Wb) { j = i + idx; tr = 0; blk = lin.Hband + ((size_t)i * W1 + idx) * 9; if (j >= a.n_poses) continue; }
-              else { const int d = idx - a.Wb; j = i - d; tr = 1; if (j < 0) continue; blk = lin.Hband + ((size_t)j * W1 + d) * 9; }
-            } else {
-              const int e = e0 + idx - nband, ent = fv.obadj_ent[e];
-              j = fv.obadj_col[e]; tr = ent & 1; blk = lin.obblk + (size_t)(ent >> 1) * 9;
-            }
-#pragma unroll
-            for (int q = 0; q < 9; ++q) b9[q] = blk[q];
-          }
-          const double v0 = gran_take<false>(a.zsG + 3 * j, tag, pp, bad), v1 = gran_take<false>(a.zsG + 3 * j + 1, tag, pp, bad),
-                       v2 = gran_take<false>(a.zsG + 3 * j + 2, tag, pp, bad);
-          if (!tr) {
-            acc0 += b9[0] * v0 + b9[1] * v1 + b9[2] * v2;
-            acc1 += b9[3] * v0 + b9[4] * v1 + b9[5] * v2;
-            acc2 += b9[6] * v0 + b9[7] * v1 + b9[8] * v2;
-          } else {
-            acc0 += b9[0] * v0 + b9[3] * v1 + b9[6] * v2;
-            acc1 += b9[1] * v0 + b9[4] * v1 + b9[7] * v2;
-            acc2 += b9[2] * v0 + b9[5] * v1 + b9[8] * v2;
-          }
-        }
-        acc0 = wave_sum(acc0); acc1 = wave_sum(acc1); acc2 = wave_sum(acc2);
-        if (lane < 3) {
-          const int t = 3 * i + lane;
-          double sa = sa0, dd = dd0;
-          if (!first) {
-            sa = scale[t];
-            const double dg = sa * sa * lin.Hband[(size_t)i * W1 * 9 + lane * 4];
-            dd = fmin(fmax(dg, a.min_diag), a.max_diag) / a.mu / sa;
-          }
-          const double sz = gran_take<false>(a.zsG + t, tag, pp, bad);
-          const double accv = (lane == 0) ? acc0 : (lane == 1) ? acc1 : acc2;
-          const double y = sa * accv + dd * sz;            // (S H S + D^2) z, with z = sz / sa
-          gran_st(a.wG + t, y, tag);
-          dz += y * (sz / sa);
-        }
-      }
-      const double delta_h = pcg_block_sum(dz, s_red);
-      if (tid == 0) gran_st(a.delG + wg, delta_h, tag);
-      PCG_PROBE(5);
-    }
     if (is_chunk) {
-      // ---- P5: alpha, beta from the global sums; p = z + beta p, s = w + beta s ----
-      if (tid < WAVE) {
-        double g = 0.0, d = 0.0;
-        for (int c = tid; c < T; c += WAVE) g += gran_take<false>(a.gamG + c, tag, pp, bad);
-        for (int h = tid; h < H; h += WAVE) d += gran_take<true>(a.delG + h, tag, pp, bad);
-        g = wave_sum(g); d = wave_sum(d);
-        if (tid == 0) { s_sc[1] = g; s_sc[2] = d; }
-      }
-      // the rows' products (their owners' waves publish them as they go): one row per thread (M * B <= kPcgThreads: pcg_fused_plan)
-      double my_w = 0.0;
-      if (tid < nvB) my_w = gran_take<true>(a.wG + row0 + tid, tag, pp, bad);
-      if (__syncthreads_or(bad ? 1 : 0)) { status = 5; break; }
+      // ---- P5: w of the owned rows and the global sums come in; alpha, beta; p = z + beta p, s = w + beta s ----
+      double g = 0.0, d = 0.0;
+      for (int c = lane; c < T; c += WAVE) g += gran_take<false>(a.gamG + c, tag, pp, bad);
+      for (int h = lane; h < Hh; h += WAVE) d += gran_take<true>(a.delG + h, tag, pp, bad);
+      gran_take_rows(a.wG + row0, nvB, tag, pp, bad, wl, lane);
+      if (__any(bad ? 1 : 0)) { status = 5; break; }
+      const double gamma = wave_sum(g), delta = wave_sum(d);
       PCG_PROBE(6);
-      const double gamma = s_sc[1], delta = s_sc[2];
       const double beta = (it == 0 || gamma_old == 0.0) ? 0.0 : gamma / gamma_old;
       const double denom = (it == 0) ? delta : delta - beta * gamma / alpha_old;
       if (!(denom > 0.0)) {
         // p.A p <= 0 (or not finite): with r.z == 0 the residual is exactly zero and nothing is left to do; otherwise a breakdown
         if (gamma != 0.0) status = 1;
-        if (tid == 0) pcg_abort_set(pp, 1u);      // the helpers and the top leave at their next wait
+        if (lane == 0) pcg_abort_set(pp, 1u);      // the product workgroups and the top leave at their next wait
         break;
       }
       alpha = gamma / denom;
-      if (tid < nvB) {
-        pv[tid] = zl[tid] + beta * pv[tid];
-        sv[tid] = my_w + beta * sv[tid];
+      for (int t = lane; t < nvB; t += WAVE) {
+        pv[t] = zl[t] + beta * pv[t];
+        sv[t] = wl[t] + beta * sv[t];
       }
       gamma_old = gamma; alpha_old = alpha;
-      __syncthreads();
     }
     PCG_PROBE(7);
     ++it;
   }
   // ---- the solution back to memory; one record for the host ----
   if (is_chunk) {
-    for (int t = tid; t < nvB; t += kPcgThreads) a.x[row0 + t] = xv[t];
+    for (int t = lane; t < nvB; t += WAVE) a.x[row0 + t] = xv[t];
   }
   // status here: 0 = converged or iteration cap, 1 = breakdown, 3 = not finite (every workgroup alike); 5 = a wait was given up: because it ran
-  // out (here or elsewhere: the abort word is 2 and the solve is void) or because the chunk workgroups ended the solve (abort word 1: helpers
-  // and the top only).  Workgroup 0 (a chunk workgroup: one of those that decide) reports; a wait that ran out is reported by everybody who saw it.
-  if (tid == 0) {
+  // out (here or elsewhere: the abort word is 2 and the solve is void) or because the chunk workgroups ended the solve (abort word 1: the product
+  // workgroups and the top only).  Workgroup 0 (a chunk: one of those that decide) reports; a wait that ran out is reported by everybody who saw it.
+  if (lane == 0) {
     const unsigned ab = (status == 5) ? pcg_abort_code(pp) : 0u;
     if (status == 5 && ab != 1u) __hip_atomic_store(a.result + 2, 2.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     else if (wg == 0) {
@@ -497,21 +588,21 @@ static int pcg_pow2_at_least(int v) { int p = 1; while (p < v) p *= 2; return p;
 
 static size_t pcg_lds_doubles(int B, int M, int T) {
   const int BB = B * B, Tp = pcg_pow2_at_least(T);
-  const size_t chunk = (size_t)3 * (M - 1) * BB + (size_t)(2 * (M + 1) + 7 * M) * B + 2 * B;
-  const size_t top = (size_t)3 * T * BB + (size_t)(Tp + 2 * Tp + 1 + 2 * Tp) * B;
+  const size_t chunk = (size_t)3 * (M - 1) * BB + (size_t)(2 * (M + 1) + 2 * M) * (B + 1) + (size_t)7 * M * B + 2 * B;
+  const size_t top = (size_t)3 * (Tp - 1) * BB + BB + (size_t)(Tp + 2 * Tp + 1 + 2 * Tp) * (B + 1);
   return std::max(chunk, top) + 8;
 }
 
 // The launch geometry for a chain of nsb super-blocks of B x B, or false: chunk size M (a power of two), chunks = top nodes <= 64,
-// both roles' tiles within the LDS budget, a chunk's rows one per thread, every workgroup resident at once (one per compute unit).
+// both roles' tiles within the LDS budget, a chunk's rows at most 512, every workgroup resident at once (one per compute unit).
 bool pcg_fused_plan(int nsb, int B, int n_rows, int cus, PcgPlan* out) {
   if (B != 3 && B != 6 && B != 9 && B != 12) return false;
   if (nsb < 4 || cus < 4) return false;
-  const size_t lds_cap = (size_t)120 * 1024 / sizeof(double);
+  const size_t lds_cap = (size_t)156 * 1024 / sizeof(double);      // of the CU's 160 KB
   int best = 0;
   for (int M = 4; M <= 256; M *= 2) {
     const int T = (nsb + M - 1) / M;
-    if (T < 2 || T > 64 || T + 1 > cus || M * B > kPcgThreads) continue;
+    if (T < 2 || T > 64 || T + 2 > cus || M * B > kPcgThreads) continue;
     if (pcg_lds_doubles(B, M, T) > lds_cap) continue;
     // the sweep's depth is log2(M) + log2(T) whatever the split; fewer chunks make the fan-ins cheaper, more chunks spread the
     // local levels over more workgroups: take the split closest to M == T
@@ -520,9 +611,12 @@ bool pcg_fused_plan(int nsb, int B, int n_rows, int cus, PcgPlan* out) {
   if (best == 0) return false;
   PcgPlan p;
   p.M = best; p.chunks = (nsb + best - 1) / best; p.Tp = pcg_pow2_at_least(p.chunks);
-  const int want = (n_rows + kPcgWaves - 1) / kPcgWaves + 1;        // one wave per pose for the products, plus the top
-  p.G = std::max(p.chunks + 1, std::min(cus, want));
-  p.lds_bytes = pcg_lds_doubles(B, p.M, p.chunks) * sizeof(double);
+  const int want = (n_rows + kPcgWaves - 1) / kPcgWaves;            // one wave per pose for the products
+  const int helpers = std::max(1, std::min(cus - p.chunks - 1, want));
+  p.G = p.chunks + helpers + 1;
+  // product workgroups keep their poses' blocks in LDS (80 bytes per entry and wave): at least 96 KB whatever the tiles need
+  p.lds_bytes = std::max(pcg_lds_doubles(B, p.M, p.chunks) * sizeof(double), (size_t)96 * 1024);
+  p.capw = (int)(p.lds_bytes / (kPcgWaves * 80));
   // granules (16 bytes each): zs, w (nsb * B each) | ctr (chunks * 3 B) | topL, topR (chunks * B each) | gamma, r.r (chunks each) | delta (G)
   p.work_doubles = 2 * ((size_t)2 * nsb * B + (size_t)p.chunks * 5 * B + (size_t)p.chunks * 2 + (size_t)p.G + 8);
   if (out) *out = p;
@@ -535,7 +629,7 @@ template <int B>
 static bool pcg_launch_t(hipStream_t st, const PcgPlan& pl, const PcgArgs& a, const FactorView& fv, const LinView& lin, const CrView& cr, const double* scale, int groups) {
   static bool raised = false;
   if (!raised) {
-    raised = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pcg_fused<B>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess;
+    raised = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pcg_fused<B>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) == hipSuccess;
     if (!raised) { (void)hipGetLastError(); return false; }
   }
   hipLaunchKernelGGL(k_pcg_fused<B>, dim3(groups), dim3(kPcgThreads), pl.lds_bytes, st, a, fv, lin, cr, scale);
@@ -549,7 +643,7 @@ bool launch_pcg_fused(hipStream_t st, const PcgPlan& pl, int n_poses, int npad, 
   const int groups = pl.G - (starve ? 1 : 0);       // test hook: the top workgroup (the last one) is never started
   PcgArgs a;
   a.n_poses = n_poses; a.npad = npad; a.nsb = cr.nsb; a.Wb = fv.band_poses;
-  a.M = pl.M; a.chunks = pl.chunks; a.Tp = pl.Tp; a.G = pl.G;
+  a.M = pl.M; a.chunks = pl.chunks; a.Tp = pl.Tp; a.G = pl.G; a.capw = pl.capw;
   a.mu = mu; a.min_diag = min_diag; a.max_diag = max_diag; a.tol2 = tol * tol;
   a.tag0 = (double)launch_index * 2097152.0;        // 2^21 tags per launch (max_it is capped below it); exact in a double for 2^32 launches
   a.max_it = std::min(max_it, (1 << 21) - 2); a.spins = spins;

@@ -677,6 +677,41 @@ int hitl_device_memory(int32_t device, int64_t* free_bytes, int64_t* total_bytes
   return HITL_OK;
 }
 
+int hitl_device_copy_bandwidth(int32_t device, int64_t bytes, int32_t repeats, double* gb_per_s) {
+  if (!gb_per_s || bytes < 16 || repeats < 1) return fail(HITL_ERR_INVALID_ARGUMENT, "device_copy_bandwidth: bad argument");
+  *gb_per_s = 0.0;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count || hipSetDevice(device) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(HITL_ERR_NO_DEVICE, "device_copy_bandwidth: no such HIP device (there is no CPU fallback)");
+  }
+  const size_t n = (size_t)bytes / 16;
+  DevArray<float4> a, b;
+  TRY(a.resize(n)); TRY(b.resize(n));
+  hipStream_t st = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int cus = 256;
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+  int rc = HITL_OK;
+  float ms = 0.f;
+  if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) rc = HITL_ERR_HIP;
+  if (rc == HITL_OK) {
+    (void)hipMemsetAsync(a.p, 0x3f, n * 16, st);
+    const int blocks = std::max(1, cus) * 8;                 // 8 workgroups of 256 per compute unit: every CU streams, no tail
+    for (int k = 0; k < 2; ++k) launch_copy_f4(st, n, a.p, b.p, blocks);
+    (void)hipEventRecord(e0, st);
+    for (int k = 0; k < repeats; ++k) launch_copy_f4(st, n, a.p, b.p, blocks);
+    (void)hipEventRecord(e1, st);
+    if (hipStreamSynchronize(st) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || !(ms > 0.f)) rc = HITL_ERR_HIP;
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (st) (void)hipStreamDestroy(st);
+  if (rc != HITL_OK) { (void)hipGetLastError(); return fail(rc, "device_copy_bandwidth: HIP error"); }
+  *gb_per_s = 2.0 * (double)n * 16.0 * repeats / ((double)ms * 1e-3) / 1e9;
+  return HITL_OK;
+}
+
 const char* hitl_last_error(void) { return g_last_error.c_str(); }
 
 const char* hitl_status_string(int st) {

@@ -41,10 +41,13 @@ def test_committed_bench_line_has_the_contract_fields(path):
 
 def test_bench_source_keeps_the_oracle_in_its_lane():
     src = open(os.path.join(ROOT, "bench.py")).read()
-    # the oracle is imported exactly once, inside the cpu_baseline leg
-    assert len(re.findall(r"from oracle import", src)) == 1
-    i = src.index("from oracle import")
-    assert "CPU baseline" in src[max(0, i - 900):i]
+    # the oracle is imported only inside a cpu_baseline leg (one per bench leg: the default workloads and --workload c3), behind the
+    # --no-cpu-baseline switch, and what it produces goes into result["cpu_baseline"] and nowhere else
+    hits = [m.start() for m in re.finditer(r"from oracle import", src)]
+    assert len(hits) == 2
+    for i in hits:
+        assert "CPU baseline" in src[max(0, i - 900):i + 200] and "no_cpu_baseline" in src[max(0, i - 900):i]
+        assert 'result["cpu_baseline"]' in src[i:i + 6000]
     assert "no CPU fallback" in src          # a missing GPU is an error, not a detour
 
 
@@ -134,3 +137,25 @@ def test_bench_refuses_rccl_with_more_ranks_than_gpus():
     r = _run_bench(["--gpus", "2", "--poses", "6000", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], timeout=300)
     assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert "need 2 GPUs" in r.stderr
+
+
+def test_a_traffic_profile_of_another_kernel_source_is_not_used(tmp_path):
+    """profiles/traffic_<workload>.json carries the hash of the hitl_kernels.hip it was measured on
+    (tools/summarize_profile.py); bench.py compares it with the source in the tree and, when they differ, reports the layout's
+    compulsory bytes and says so (roofline.traffic = null, roofline.traffic_stale) instead of yesterday's counters."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    sha = b.kernel_source_sha()
+    assert len(sha) == 16 and sha == b.kernel_source_sha()
+    other = tmp_path / "k.hip"
+    other.write_text(open(os.path.join(ROOT, "hitl_slam_amd", "csrc", "hitl_kernels.hip")).read() + "\n// one more line\n")
+    assert b.kernel_source_sha(str(other)) != sha
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'tj.get("kernel_source_sha") != kernel_source_sha()' in src and '"traffic_stale": traffic_stale' in src
+    summ = open(os.path.join(ROOT, "tools", "summarize_profile.py")).read()
+    assert 'res["kernel_source_sha"]' in summ
+    # the committed profile either belongs to the kernel source in the tree or will be reported as stale -- never silently used
+    tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_c4.json")))
+    assert tj.get("kernel_source_sha") in (None, sha) or isinstance(tj.get("kernel_source_sha"), str)

@@ -70,6 +70,12 @@ def main():
               % (bj["roofline"]["avg_launch_ms"], res.get("stf_avg_us", 0) / 1e3))
     except Exception as e:
         print("\n(no bench json: %r)" % (e,))
+    try:      # the source text of the profiled kernel: bench.py uses these counters only while hitl_kernels.hip still is that text
+        import hashlib
+        src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hitl_slam_amd", "csrc", "hitl_kernels.hip")
+        res["kernel_source_sha"] = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
+    except Exception:
+        pass
     json.dump(res, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 
 
