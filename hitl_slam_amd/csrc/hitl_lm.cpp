@@ -392,8 +392,8 @@ static int enqueue_linear_solve_pcg(hitl_solver* s, const FactorView& fv, int bu
     for (int wg : {pl.chunks, (pl.chunks + pl.G - 1) / 2, pl.G - 2})
       if (wg >= pl.chunks && wg < pl.G - 1)
         std::fprintf(stderr, "  products %3d: start %.2f | r.r check %.2f | products out %.2f\n", wg, at(wg, 0), at(wg, 4), at(wg, 5));
-    std::fprintf(stderr, "  chunk 0 forward sweep in detail: updates + r.r %.2f | level 1 products %.2f | level 1 survivors %.2f | level 2 %.2f | level 3 %.2f | level 4 %.2f | ctr out %.2f\n",
-                 at(0, 9), at(0, 10), at(0, 11), at(0, 12), at(0, 13), at(0, 14), at(0, 1));
+    std::fprintf(stderr, "  chunk 0 in detail: updates + r.r done %.2f | forward levels done %.2f | ctr out %.2f ... z taken %.2f | back levels done %.2f | z, r.z, r.r out %.2f\n",
+                 at(0, 9), at(0, 10), at(0, 1), at(0, 2), at(0, 11), at(0, 3));
     { const double cyc = (double)(h[8 + 7] - h[8 + 0]), t_us = us(0, 0, 7);
       std::fprintf(stderr, "  shader clock over chunk 0's iteration: %.0f cycles in %.2f us = %.0f MHz\n", cyc, t_us, t_us > 0 ? cyc / t_us : 0.0); }
     s->pcg_probe.release();

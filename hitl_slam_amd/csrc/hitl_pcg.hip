@@ -12,13 +12,22 @@
 // same factor tiles) and the host looked at r.r every fourth iteration.  Here the whole solve is one launch of G <= #CU workgroups
 // with fixed roles that hand small vectors to each other through device memory:
 //
-//   * chunk workgroups c = 0 .. chunks-1: each owns M consecutive nodes of the reduction tree (M * Wb poses).  Their Dinv / Gl / Gr
-//     tiles are loaded into LDS ONCE and stay there for every CG iteration of the solve; x, r, p, s = A p of the owned rows live in LDS
-//     too.  Per iteration: the vector updates, the local levels of the preconditioner's forward sweep, later its back-substitution --
-//     all by ONE wave (the sweep is a chain of small dependent levels: a second wave would only add barriers: measured, 4 x slower).
-//   * the top workgroup (the last one): the nodes 0, M, 2M, ... (one per chunk), tiles resident in LDS: the upper levels, one wave.
+//   * chunk workgroups c = 0 .. chunks-1: each owns M consecutive nodes of the reduction tree (M * Wb poses).  Every thread keeps the
+//     coefficients of a few fixed items of the preconditioner's sweep in REGISTERS for the whole solve (hitl_pcg_sweep.h) and -- one row
+//     per thread -- x, r, p, s = A p of the owned rows; only the sweep's small vectors go through LDS.  Per iteration: the vector updates,
+//     the local levels of the forward sweep, later the back-substitution.
+//   * the top workgroup (the last one): the nodes 0, M, 2M, ... (one per chunk): the upper levels of the sweep, same engine.
 //   * product workgroups (the ones between): w = A z, one wave per pose over the pose's band and off-band blocks.  The matrix does
-//     not change during a solve: every wave keeps its poses' 3x3 blocks (already oriented) and column indices in LDS.
+//     not change during a solve: a workgroup keeps its poses' 3x3 blocks (already oriented) and column indices in LDS; consecutive
+//     poses go to different workgroups (a map's first poses can have ten times the off-band partners of the others).
+//
+// Where a CG iteration's time goes (in-kernel probe, HITL_TIMING=1; 1 000-pose Figure-8 map, 16 chunks of 16 nodes, 125 product
+// workgroups; profiles/r06_pcg.md): chunk forward sweep 3.4 us, hand-off 1.8, top 4.3 + 1.0, hand-off 0.7, chunk back-substitution +
+// publishing z 3.7, products 1.6 after z, their hand-off back 3.5 (192 rows from 64 producers per chunk: the last one counts) -- ~20 us,
+// against ~58 us for the eight launches.  What did NOT help, each measured: the sweep's tiles in LDS (plain layout: 5-7 bank passes per
+// read; conflict-free level-major layout: its address arithmetic cost the same), one wave per chunk without barriers, a "lazy" forward
+// sweep (every product lane re-reading 2 l + 1 vectors), several loads in flight per watcher (more polling traffic slowed every
+// hand-off), one watcher per workgroup in front of the gathers (a second memory round trip).
 //
 // The recurrence is Chronopoulos & Gear's single-reduction form of PCG (z = M^-1 r, w = A z, gamma = r.z, delta = w.z,
 // beta = gamma / gamma_old, alpha = gamma / (delta - beta gamma / alpha_old), p = z + beta p, s = w + beta s, x += alpha p, r -= alpha s):
@@ -34,11 +43,9 @@
 #include <algorithm>
 
 #include "hitl_device.h"
+#include "hitl_pcg_sweep.h"
 
 namespace hitl {
-
-constexpr int kPcgThreads = 512;
-constexpr int kPcgWaves = kPcgThreads / WAVE;
 
 // ---- hand-off granules ------------------------------------------------------------------------------------------------------
 // Every double that crosses from one workgroup to another travels as a 16-byte granule {value, tag}: ONE 16-byte store, ONE 16-byte
@@ -106,6 +113,31 @@ __device__ __forceinline__ void gran_take_rows(const v2f64* p, int count, double
   }
 }
 
+// sum over the wave by DPP (quad permutes, row mirrors, row broadcasts: ALU moves, no LDS crossbar as in __shfl_xor), the same in
+// every lane.  A fixed order of additions, not the butterfly's: used inside this file only.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_get(double v) {      // the DPP source lane's value; 0 where the row is masked or there is no source
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+  v += dpp_get<0xB1, 0xf>(v);       // quad_perm [1,0,3,2]
+  v += dpp_get<0x4E, 0xf>(v);       // quad_perm [2,3,0,1]
+  v += dpp_get<0x141, 0xf>(v);      // row_half_mirror: the other quad pair of the 8
+  v += dpp_get<0x140, 0xf>(v);      // row_mirror: the other half of the row of 16 -- every lane of a row now holds the row's sum
+  v += dpp_get<0x142, 0xa>(v);      // row_bcast:15 into rows 1 and 3
+  v += dpp_get<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+  return readlane_f64(v, 63);
+}
+
+// has any thread of the workgroup given a wait up?  (s_bad: LDS, zero at the start, only ever set)
+__device__ __forceinline__ bool pcg_any_bad(bool bad, int* s_bad) {
+  if (bad) *s_bad = 1;
+  lds_barrier();
+  return *s_bad != 0;
+}
+
 // LDS written by some lanes of a wave and read by others of the SAME wave: the hardware keeps a wave's LDS operations in order;
 // the compiler must not move a read above the write it depends on
 __device__ __forceinline__ void wave_lds_sync() {
@@ -113,91 +145,11 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
-// ---- the sweep's coefficients in LDS -----------------------------------------------------------------------------------------
-// One wave works through a level: an LDS read instruction takes as many passes as lanes fall on one bank, and the plain tile
-// layout [node][row][column] put the nodes of a level (1152 bytes apart) on the same banks (measured: 5-7 passes per read, the sweep of a
-// 16-node chunk 9.5 us per CG iteration).  The tiles are therefore stored LEVEL by level with the node index k fastest (node
-// u = s (2 k + 1) of the level of stride s, nel = Mloc / (2 s) nodes), so that the lanes of a read touch consecutive words:
-//   GL, GR (used by columns in the forward sweep, by rows in the back-substitution):  [row r][slot (c + r) mod B][k]  -- the rotation by
-//          r makes BOTH uses conflict-free (columns: lanes (c, k) cover a contiguous range; rows: lanes (r, k) of a half-wave differ
-//          in (c + r) nel mod 32);
-//   DI (rows only):  [column c][row r][k].
-// Levels follow each other: level of stride s starts (Mloc - Mloc / s) tiles in.  Vectors (w, xs, ca, cb) keep B + 1 doubles per node.
-template <int B>
-__device__ __forceinline__ size_t pcg_level_off(int Mloc, int s) { return (size_t)(Mloc - Mloc / s) * B * B; }
-
-// forward products of the level of stride s: item e = (which B + c) nel + k; ca[u] = Gl_u^T w_u goes to node u - s, cb[u] = Gr_u^T w_u to u + s
-template <int B>
-__device__ __forceinline__ void pcg_fwd_products(const double* GL, const double* GR, const double* w, double* ca, double* cb, int s, int Mloc, int u_max, int lane) {
-  constexpr int BP = B + 1;
-  const int nel = Mloc / (2 * s);
-  const size_t off = pcg_level_off<B>(Mloc, s);
-  for (int e = lane; e < nel * 2 * B; e += WAVE) {
-    const int k = e % nel, wc = e / nel, which = wc / B, c = wc % B, u = s * (2 * k + 1);
-    if (u > u_max) continue;
-    const double* G = (which ? GR : GL) + off + k;
-    const double* wu = w + (size_t)u * BP;
-    double c0 = 0.0, c1 = 0.0;                      // two chains: a dependent fp64 FMA chain of B links is what a level waits for
-#pragma unroll
-    for (int r = 0; r < B; ++r) {
-      const int slot = (c + r >= B) ? c + r - B : c + r;
-      const double g = G[(size_t)(r * B + slot) * nel];
-      if (r & 1) c1 += g * wu[r]; else c0 += g * wu[r];
-    }
-    (which ? cb : ca)[(size_t)u * BP + c] = c0 + c1;
-  }
-}
-
-// back-substitution of the level of stride s: item e = r nel + k: x_u[r] = Dinv_u[r,:] w_u - Gl_u[r,:] x_{u-s} - Gr_u[r,:] x_{u+s}
-// (xs holds zeros at nodes that do not exist)
-template <int B>
-__device__ __forceinline__ void pcg_back_level(const double* DI, const double* GL, const double* GR, const double* w, double* xs, int s, int Mloc, int u_max, int lane) {
-  constexpr int BP = B + 1;
-  const int nel = Mloc / (2 * s);
-  const size_t off = pcg_level_off<B>(Mloc, s);
-  for (int e = lane; e < nel * B; e += WAVE) {
-    const int k = e % nel, r = e / nel, u = s * (2 * k + 1);
-    if (u > u_max) continue;
-    const double* Di = DI + off + e;
-    const double* Gl = GL + off + (size_t)r * B * nel + k;
-    const double* Gr = GR + off + (size_t)r * B * nel + k;
-    const double* wu = w + (size_t)u * BP;
-    const double* xl = xs + (size_t)(u - s) * BP;
-    const double* xr = xs + (size_t)(u + s) * BP;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0;            // three independent chains
-#pragma unroll
-    for (int c = 0; c < B; ++c) {
-      const int slot = (c + r >= B) ? c + r - B : c + r;
-      a0 += Di[(size_t)c * B * nel] * wu[c];
-      a1 += Gl[(size_t)slot * nel] * xl[c];
-      a2 += Gr[(size_t)slot * nel] * xr[c];
-    }
-    xs[(size_t)u * BP + r] = (a0 - a1) - a2;
-  }
-}
-
-// the tiles of the local nodes 1 .. Mloc - 1 into that layout, by the whole workgroup; local node u is global node gbase + u * gstride and exists for u <= u_max
-template <int B>
-__device__ __forceinline__ void pcg_fill_tiles(const CrView& cr, double* GL, double* GR, double* DI, int Mloc, int u_max, size_t gbase, size_t gstride) {
-  constexpr int BB = B * B;
-  for (int t = threadIdx.x; t < (Mloc - 1) * BB; t += kPcgThreads) {
-    const int u = 1 + t / BB, e = t % BB, r = e / B, c = e % B;
-    const int s = u & -u, nel = Mloc / (2 * s), k = (u / s - 1) / 2;
-    const size_t off = pcg_level_off<B>(Mloc, s);
-    const bool ex = u <= u_max;
-    const size_t g = (gbase + (size_t)u * gstride) * BB + e;
-    const int slot = (c + r >= B) ? c + r - B : c + r;
-    GL[off + (size_t)(r * B + slot) * nel + k] = ex ? cr.Gl[g] : 0.0;
-    GR[off + (size_t)(r * B + slot) * nel + k] = ex ? cr.Gr[g] : 0.0;
-    DI[off + (size_t)(c * B + r) * nel + k] = ex ? cr.Dinv[g] : 0.0;
-  }
-}
-
 struct PcgArgs {
   int n_poses, npad, nsb, Wb;
   int M, chunks, Tp, G;          // chunk size (a power of two), chunks = top nodes, Tp = the power of two >= chunks, workgroups:
                                  // [0, chunks) the chunks, [chunks, G - 1) the product workgroups, G - 1 the top
-  int capw;                      // product entries a wave keeps in LDS
+  int capw;                      // product entries a workgroup keeps in LDS (a pool shared by its waves)
   double mu, min_diag, max_diag, tol2;
   double tag0;                   // epoch base of this launch: the granules of CG iteration `it` carry tag0 + it + 1
   int max_it;
@@ -228,15 +180,16 @@ __device__ __forceinline__ double pcg_rr_sum(const v2f64* rrG, int T, double tag
   double v = 0.0;
   if (lane == 0) v = gran_take<true>(rrG, tag, pp, bad);
   for (int c = lane + (lane == 0 ? WAVE : 0); c < T; c += WAVE) v += gran_take<false>(rrG + c, tag, pp, bad);
-  return wave_sum(v);
+  return wave_sum_dpp(v);
 }
 
-template <int B>
+template <int B, int NS>
 __global__ __launch_bounds__(kPcgThreads) void k_pcg_fused(PcgArgs a, FactorView fv, LinView lin, CrView cr, const double* __restrict__ scale) {
   constexpr int BB = B * B;
   extern __shared__ double lds[];
-  __shared__ double s_red[kPcgWaves];
-  __shared__ double s_sc[8];               // [0] rr (product workgroups), [6] bb, [7] rr0
+  __shared__ int s_bad;
+  __shared__ double s_red[2 * kPcgWaves];
+  __shared__ double s_sc[8];               // [0] rr, [1] gamma, [2] delta, [6] bb, [7] rr0
   const int tid = threadIdx.x, wg = blockIdx.x, wave = tid >> 6, lane = tid & 63;
   const int M = a.M, T = a.chunks, Tp = a.Tp, Hh = a.G - 1 - a.chunks;
   const bool is_top = (wg == a.G - 1), is_chunk = (wg < a.chunks);
@@ -247,7 +200,7 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg_fused(PcgArgs a, FactorView
       for (int k = tid; k < a.nblk0; k += WAVE) { r_ += a.partials0[(size_t)k * 8]; b_ += a.partials0[(size_t)k * 8 + 1]; }
       r_ = wave_sum(r_); b_ = wave_sum(b_);
     }
-    if (tid == 0) { s_sc[7] = r_; s_sc[6] = b_; }
+    if (tid == 0) { s_sc[7] = r_; s_sc[6] = b_; s_bad = 0; }
   }
   int it = 0;
   int status = 0;
@@ -255,14 +208,17 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg_fused(PcgArgs a, FactorView
 
   if (!is_chunk && !is_top) {
     // =============================== product workgroup: w = A z over its waves' poses ===============================
-    // wave gw takes poses gw, gw + Hh * 8, ...; their entries (band blocks both ways + off-band blocks), oriented, sit in LDS:
-    // SoA blkS[q][capw] + colS[capw] per wave; entries beyond capw are read from memory every iteration (never on maps of
-    // hitl-slam's size).  Per pose: sum over its entries of block * (scale z)[column], reduced over the wave, finished by lanes 0..2.
+    // A wave's poses' entries (band blocks both ways + off-band blocks), oriented, sit in LDS: SoA blkS[q][capw] + colS[capw]; entries
+    // beyond the pool are read from memory every iteration (never on maps of hitl-slam's size).  Per pose: sum over its entries of
+    // block * (scale z)[column], reduced over the wave, finished by lanes 0..2.
+    // (capw: the WORKGROUP's pool of LDS entries, shared by its waves in proportion to what their poses need: a map's first poses can
+    // have ten times the off-band partners of the others)
     const int capw = a.capw;
-    double* blkS = lds + (size_t)wave * capw * 10;
+    double* blkS = lds;
     int* colS = reinterpret_cast<int*>(blkS + (size_t)capw * 9);
     const int W1 = a.Wb + 1, nband = 2 * a.Wb + 1, n_rows = a.npad / 3;
-    const int gw = (wg - a.chunks) * kPcgWaves + wave, TW = Hh * kPcgWaves;
+    // wave `wave` of product workgroup h takes poses wave * Hh + h, + Hh * 8, ...: CONSECUTIVE poses go to different workgroups
+    const int gw = wave * Hh + (wg - a.chunks), TW = Hh * kPcgWaves;
     auto entry = [&](int i, int e0, int idx, const double*& blk, int& j, int& tr) -> bool {       // entry idx of pose i; false: no such block
       if (idx < nband) {
         if (idx <= a.Wb) { j = i + idx; tr = 0; if (j >= a.n_poses) return false; blk = lin.Hband + ((size_t)i * W1 + idx) * 9; }
@@ -273,8 +229,18 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg_fused(PcgArgs a, FactorView
       }
       return true;
     };
+    int o_wave = 0;                                     // this wave's first entry in the pool
     {
-      int o = 0;
+      int cnt = 0;
+      for (int i = gw; i < n_rows; i += TW) {
+        if (i >= a.n_poses || fv.fixed[i]) continue;
+        cnt += nband + ((fv.n_offband > 0) ? fv.obadj_off[i + 1] - fv.obadj_off[i] : 0);
+      }
+      if (lane == 0) s_red[wave] = (double)cnt;
+      lds_barrier();
+      for (int k = 0; k < wave; ++k) o_wave += (int)s_red[k];
+      lds_barrier();
+      int o = o_wave;
       for (int i = gw; i < n_rows; i += TW) {
         if (i >= a.n_poses || fv.fixed[i]) continue;
         const int e0 = (fv.n_offband > 0) ? fv.obadj_off[i] : 0;
@@ -292,7 +258,7 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg_fused(PcgArgs a, FactorView
         o += total;
       }
     }
-    __syncthreads();
+    lds_barrier();
     bb = s_sc[6]; rr = s_sc[7];
     const double target = a.tol2 * bb;
     if (!(rr == rr)) status = 3;
@@ -301,14 +267,11 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg_fused(PcgArgs a, FactorView
       const double tag = a.tag0 + (double)(it + 1);
       bool bad = false;
       PCG_PROBE(0);
-      if (wave == 0) { const double v = pcg_rr_sum(a.rrG, T, tag, pp, bad, lane); if (lane == 0) s_sc[0] = v; }
-      if (__syncthreads_or(bad ? 1 : 0)) { status = 5; break; }
-      rr = s_sc[0];
-      PCG_PROBE(4);
-      if (!(rr == rr)) { status = 3; break; }
-      if (!(rr > target) || it >= a.max_it) break;
+      // The products come FIRST, the question "is the solve over?" after them: z arrives tagged, so a wave starts on it the moment it is
+      // there, and r.r (published right behind z) is looked at while the chunk workgroups take w in.  When the solve IS over the last
+      // products were for nothing (nobody takes them).
       double dz = 0.0;
-      int o = 0;
+      int o = o_wave;
       for (int i = gw; i < n_rows; i += TW) {
         if (i >= a.n_poses || fv.fixed[i]) {                                  // identity rows (padding, constant poses; their scale is 1): w = z
           if (lane < 3) { const double z = gran_take<false>(a.zsG + 3 * i + lane, tag, pp, bad); gran_st(a.wG + 3 * i + lane, z, tag); dz += z * z; }
@@ -316,36 +279,55 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg_fused(PcgArgs a, FactorView
         }
         const int e0 = (fv.n_offband > 0) ? fv.obadj_off[i] : 0;
         const int total = nband + ((fv.n_offband > 0) ? fv.obadj_off[i + 1] - e0 : 0);
-        double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, d0 = 0.0, d1 = 0.0, d2 = 0.0;      // d: (scale z) of the pose's own column (entry 0 = the diagonal block)
-        for (int idx = lane; idx < total; idx += WAVE) {
-          double b9[9];
-          int j;
-          if (o + idx < capw) {
-            j = colS[o + idx];
-            if (j < 0) continue;
-#pragma unroll
-            for (int q = 0; q < 9; ++q) b9[q] = blkS[(size_t)q * capw + o + idx];
-          } else {
-            const double* blk = nullptr;
-            int tr = 0;
-            if (!entry(i, e0, idx, blk, j, tr)) continue;
-#pragma unroll
-            for (int q = 0; q < 9; ++q) b9[q] = tr ? blk[(q % 3) * 3 + q / 3] : blk[q];
-          }
-          double v0, v1, v2;
-          gran_take3(a.zsG + 3 * j, tag, pp, bad, v0, v1, v2);
-          if (idx == 0) { d0 = v0; d1 = v1; d2 = v2; }
-          acc0 += b9[0] * v0 + b9[1] * v1 + b9[2] * v2;
-          acc1 += b9[3] * v0 + b9[4] * v1 + b9[5] * v2;
-          acc2 += b9[6] * v0 + b9[7] * v1 + b9[8] * v2;
+        // the row's constants (lanes 0..2), asked for before the gather so that their latency hides under it
+        double sa = 1.0, dd = 0.0;
+        if (lane < 3) {
+          sa = scale[3 * i + lane];
+          const double dg = sa * sa * lin.Hband[(size_t)i * W1 * 9 + lane * 4];
+          dd = fmin(fmax(dg, a.min_diag), a.max_diag) / a.mu / sa;
         }
-        acc0 = wave_sum(acc0); acc1 = wave_sum(acc1); acc2 = wave_sum(acc2);
-        d1 = __shfl(d1, 0, WAVE); d2 = __shfl(d2, 0, WAVE);
+        double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, d0 = 0.0, d1 = 0.0, d2 = 0.0;      // d: (scale z) of the pose's own column (entry 0 = the diagonal block)
+        for (int base = 0; base < total; base += 5 * WAVE) {
+          // up to five entries per lane and round: every granule load of the round is in flight before the first tag is looked at
+          int jj[5];
+          v2f64 g[5][3];
+#pragma unroll
+          for (int k = 0; k < 5; ++k) {
+            const int idx = base + lane + WAVE * k;
+            jj[k] = -1;
+            if (idx < total) {
+              if (o + idx < capw) jj[k] = colS[o + idx];
+              else { const double* blk = nullptr; int tr = 0, j = -1; if (entry(i, e0, idx, blk, j, tr)) jj[k] = j; }
+            }
+            if (jj[k] >= 0) { g[k][0] = gran_ld(a.zsG + 3 * jj[k]); g[k][1] = gran_ld(a.zsG + 3 * jj[k] + 1); g[k][2] = gran_ld(a.zsG + 3 * jj[k] + 2); }
+          }
+#pragma unroll
+          for (int k = 0; k < 5; ++k) {
+            if (jj[k] < 0) continue;
+            const int idx = base + lane + WAVE * k;
+            double v0 = g[k][0].x, v1 = g[k][1].x, v2 = g[k][2].x;
+            if (!(g[k][0].y == tag && g[k][1].y == tag && g[k][2].y == tag)) gran_take3(a.zsG + 3 * jj[k], tag, pp, bad, v0, v1, v2);
+            double b9[9];
+            if (o + idx < capw) {
+#pragma unroll
+              for (int q = 0; q < 9; ++q) b9[q] = blkS[(size_t)q * capw + o + idx];
+            } else {
+              const double* blk = nullptr;
+              int tr = 0, j = -1;
+              (void)entry(i, e0, idx, blk, j, tr);
+#pragma unroll
+              for (int q = 0; q < 9; ++q) b9[q] = tr ? blk[(q % 3) * 3 + q / 3] : blk[q];
+            }
+            if (idx == 0) { d0 = v0; d1 = v1; d2 = v2; }
+            acc0 += b9[0] * v0 + b9[1] * v1 + b9[2] * v2;
+            acc1 += b9[3] * v0 + b9[4] * v1 + b9[5] * v2;
+            acc2 += b9[6] * v0 + b9[7] * v1 + b9[8] * v2;
+          }
+        }
+        acc0 = wave_sum_dpp(acc0); acc1 = wave_sum_dpp(acc1); acc2 = wave_sum_dpp(acc2);
+        d1 = readlane_f64(d1, 0); d2 = readlane_f64(d2, 0);
         if (lane < 3) {
           const int t = 3 * i + lane;
-          const double sa = scale[t];
-          const double dg = sa * sa * lin.Hband[(size_t)i * W1 * 9 + lane * 4];
-          const double dd = fmin(fmax(dg, a.min_diag), a.max_diag) / a.mu / sa;
           const double sz = (lane == 0) ? d0 : (lane == 1) ? d1 : d2;       // (lane 0 took the diagonal block's column itself)
           const double accv = (lane == 0) ? acc0 : (lane == 1) ? acc1 : acc2;
           const double y = sa * accv + dd * sz;            // (S H S + D^2) z, with z = sz / sa
@@ -355,10 +337,9 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg_fused(PcgArgs a, FactorView
         o += total;
       }
       {
-        dz = wave_sum(dz);
-        __syncthreads();
+        dz = wave_sum_dpp(dz);
         if (lane == 0) s_red[wave] = dz;
-        __syncthreads();
+        lds_barrier();
         if (tid == 0) {
           double t = 0.0;
 #pragma unroll
@@ -367,6 +348,12 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg_fused(PcgArgs a, FactorView
         }
       }
       PCG_PROBE(5);
+      if (wave == 0) { const double v = pcg_rr_sum(a.rrG, T, tag, pp, bad, lane); if (lane == 0) s_sc[0] = v; }
+      if (pcg_any_bad(bad, &s_bad)) { status = 5; break; }
+      rr = s_sc[0];
+      PCG_PROBE(4);
+      if (!(rr == rr)) { status = 3; break; }
+      if (!(rr > target) || it >= a.max_it) break;
       PCG_PROBE(7);
       ++it;
     }
@@ -374,40 +361,33 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg_fused(PcgArgs a, FactorView
     return;
   }
 
-  // =============================== chunk workgroups and the top: one wave each ===============================
-  // ---- LDS carve-up (vectors keep BP = B + 1 doubles per node) ----
-  // chunk: GL GR DI of the interior nodes 1 .. M-1 (level layout) | w, xs (M + 1 nodes) | ca, cb (M nodes) | xv rv pv sv zl wl scl (M B rows) | accL0, accRM
-  // top:   GL GR DI of the nodes 1 .. Tp-1 | Dinv of node 0 | w (Tp nodes), xs (2 Tp + 1 nodes: zeros beyond T - 1) | ca, cb (Tp nodes)
+  // =============================== chunk workgroups and the top ===============================
+  // Small vectors in LDS, B + 1 doubles per node: w0 (the sweep's right-hand side, updated in place), xs (the solution; zeros at nodes that
+  // do not exist), ca / cb (what an eliminated node hands to its left / right neighbour); the top also keeps Dinv of node 0.  Everything
+  // else lives in registers.
   constexpr int BP = B + 1;
-  double *sGl, *sGr, *sDi, *sD0 = nullptr, *w, *xs, *ca, *cb, *xv = nullptr, *rv = nullptr, *pv = nullptr, *sv = nullptr, *zl = nullptr, *wl = nullptr, *scl = nullptr,
-         *accL0 = nullptr, *accRM = nullptr;
-  int nv = 0, nvB = 0;
-  const size_t row0 = (size_t)wg * M * B;           // first owned row of a chunk workgroup
-  if (is_top) {
-    sGl = lds; sGr = sGl + (size_t)(Tp - 1) * BB; sDi = sGr + (size_t)(Tp - 1) * BB; sD0 = sDi + (size_t)(Tp - 1) * BB;
-    w = sD0 + BB; xs = w + (size_t)Tp * BP; ca = xs + (size_t)(2 * Tp + 1) * BP; cb = ca + (size_t)Tp * BP;
-    pcg_fill_tiles<B>(cr, sGl, sGr, sDi, Tp, T - 1, 0, (size_t)M);
-    for (int e = tid; e < BB; e += kPcgThreads) sD0[e] = cr.Dinv[e];
-    for (int e = tid; e < (2 * Tp + 1) * BP; e += kPcgThreads) xs[e] = 0.0;
-    for (int e = tid; e < Tp * BP; e += kPcgThreads) w[e] = 0.0;
-  } else {
-    sGl = lds; sGr = sGl + (size_t)(M - 1) * BB; sDi = sGr + (size_t)(M - 1) * BB;
-    w = sDi + (size_t)(M - 1) * BB; xs = w + (size_t)(M + 1) * BP; ca = xs + (size_t)(M + 1) * BP; cb = ca + (size_t)M * BP;
-    xv = cb + (size_t)M * BP; rv = xv + (size_t)M * B; pv = rv + (size_t)M * B; sv = pv + (size_t)M * B; zl = sv + (size_t)M * B;
-    wl = zl + (size_t)M * B; scl = wl + (size_t)M * B;
-    accL0 = scl + (size_t)M * B; accRM = accL0 + B;
-    nv = min(M, a.nsb - wg * M); nvB = nv * B;
-    pcg_fill_tiles<B>(cr, sGl, sGr, sDi, M, nv - 1, (size_t)wg * M, 1);
-    for (int e = tid; e < (M + 1) * BP; e += kPcgThreads) { xs[e] = 0.0; w[e] = 0.0; }
-    for (int t = tid; t < M * B; t += kPcgThreads) {
-      const bool own = t < nvB;
-      xv[t] = own ? a.x[row0 + t] : 0.0; rv[t] = own ? a.r0[row0 + t] : 0.0; pv[t] = 0.0; sv[t] = 0.0; zl[t] = 0.0; wl[t] = 0.0;
-      scl[t] = own ? scale[row0 + t] : 1.0;
-    }
-  }
-  __syncthreads();
+  const int Mloc = is_top ? Tp : M;
+  double* w0 = lds;
+  double* xs = w0 + (size_t)(Mloc + 1) * BP;
+  double* ca = xs + (size_t)(Mloc + 1) * BP;
+  double* cb = ca + (size_t)(Mloc + 1) * BP;
+  double* acc0 = cb + (size_t)(Mloc + 1) * BP;          // chunk: what the interior hands to its first node ...
+  double* accM = acc0 + B;                              // ... and to the next chunk's first node
+  double* sD0 = accM + B;                               // top only: BB doubles
+  const int nv = is_top ? 0 : min(M, a.nsb - wg * M), nvB = nv * B;       // chunk: owned nodes / rows (row t in thread t)
+  const size_t row0 = (size_t)wg * M * B;
+  PcgItems<B, NS> items;
+  if (is_top) pcg_items_init<B, NS>(items, cr, Tp, T - 1, 0, (size_t)M);
+  else pcg_items_init<B, NS>(items, cr, M, nv - 1, (size_t)wg * M, 1);
+  for (int e = tid; e < 4 * (Mloc + 1) * BP + 2 * B; e += kPcgThreads) w0[e] = 0.0;
+  if (is_top) for (int e = tid; e < BB; e += kPcgThreads) sD0[e] = cr.Dinv[e];
+  // the owned row of a chunk thread: x, r, p, s = A p, z, scale
+  const bool own = is_chunk && tid < nvB;
+  double xr = own ? a.x[row0 + tid] : 0.0, rr_ = own ? a.r0[row0 + tid] : 0.0, pr = 0.0, sr = 0.0, zr = 0.0;
+  const double scr = own ? scale[row0 + tid] : 1.0;
+  const int own_slot = (tid / B) * BP + tid % B;
+  lds_barrier();
   bb = s_sc[6]; rr = s_sc[7];
-  if (wave != 0) return;                              // from here on ONE wave per workgroup: no barriers below this line
   const double target = a.tol2 * bb;
   double alpha = 0.0, alpha_old = 0.0, gamma_old = 0.0;
   if (!(rr == rr)) status = 3;
@@ -419,76 +399,72 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg_fused(PcgArgs a, FactorView
     PCG_PROBE(0);
     if (is_chunk) {
       // ---- P1: x += alpha p, r -= alpha s; r.r; the local levels of the forward sweep on r ----
-      double rr_t = 0.0;
-      for (int t = lane; t < nvB; t += WAVE) {
-        if (it > 0) { xv[t] += alpha * pv[t]; rv[t] -= alpha * sv[t]; }
-        const double rt = rv[t];
-        w[(t / B) * BP + t % B] = rt;
-        rr_t += rt * rt;
+      double rsq = 0.0;
+      if (own) {
+        if (it > 0) { xr += alpha * pr; rr_ -= alpha * sr; }
+        w0[own_slot] = rr_;
+        rsq = rr_ * rr_;
       }
-      if (lane < 2 * B) accL0[lane] = 0.0;               // accL0 and accRM are adjacent
-      const double rr_c = wave_sum(rr_t);
-      wave_lds_sync();
+      rsq = wave_sum_dpp(rsq);
+      if (lane == 0) s_red[wave] = rsq;
+      lds_barrier();
       PCG_PROBE(9);
       for (int s = 1; s < M; s *= 2) {
-        pcg_fwd_products<B>(sGl, sGr, w, ca, cb, s, M, nv - 1, lane);
-        wave_lds_sync();
-        if (s == 1) PCG_PROBE(10);
-        const int nsv = M / (2 * s) + 1;
-        for (int e = lane; e < nsv * B; e += WAVE) {
-          const int j = 2 * s * (e / B), q = e % B;
-          const double pl = (j - s >= 1 && j - s <= nv - 1) ? cb[(size_t)(j - s) * BP + q] : 0.0;
-          const double pr = (j + s <= nv - 1 && j + s < M) ? ca[(size_t)(j + s) * BP + q] : 0.0;
-          if (j == 0) accL0[q] += pr;
-          else if (j == M) accRM[q] += pl;
-          else if (j <= nv - 1) w[(size_t)j * BP + q] = (w[(size_t)j * BP + q] - pl) - pr;
-        }
-        wave_lds_sync();
-        if (s == 1) PCG_PROBE(11);
-        if (s == 2) PCG_PROBE(12);
-        if (s == 4) PCG_PROBE(13);
-        if (s == 8) PCG_PROBE(14);
+        pcg_fwd_products<B, NS>(items, s, w0, ca, cb);
+        lds_barrier();
+        pcg_fwd_survivors<B>(s, M, nv - 1, w0, ca, cb, acc0, accM);
+        lds_barrier();
       }
-      if (lane < 3 * B) {
-        const double v = (lane < B) ? accL0[lane] : (lane < 2 * B) ? accRM[lane - B] : rv[lane - 2 * B];
-        gran_st(a.ctrG + (size_t)wg * 3 * B + lane, v, tag);
+      PCG_PROBE(10);
+      if (tid < 3 * B) {                                 // what the chunk's interior hands to its two boundary nodes, and r at its first node
+        const int q = tid % B;
+        double v;
+        if (tid < 2 * B) { v = acc0[tid]; acc0[tid] = 0.0; }          // (acc0 and accM are adjacent; cleared for the next iteration)
+        else v = w0[q];
+        gran_st(a.ctrG + (size_t)wg * 3 * B + tid, v, tag);
       }
       PCG_PROBE(1);
       // ---- P3: z at the two boundary nodes comes back from the top; back-substitution; r.z ----
-      if (lane < 2 * B) {
-        const int q = lane % B;
-        if (lane < B) xs[q] = gran_take<true>(a.topL + (size_t)wg * B + q, tag, pp, bad);
-        else xs[(size_t)M * BP + q] = (wg + 1 < T) ? gran_take<true>(a.topR + (size_t)wg * B + q, tag, pp, bad) : 0.0;
+      if (tid < 2 * B) {
+        const int q = tid % B;
+        if (tid < B) xs[q] = gran_take<true>(a.topL + (size_t)wg * B + q, tag, pp, bad);
+        else xs[M * BP + q] = (wg + 1 < T) ? gran_take<true>(a.topR + (size_t)wg * B + q, tag, pp, bad) : 0.0;
       }
-      if (__any(bad ? 1 : 0)) { status = 5; break; }
-      wave_lds_sync();
+      if (pcg_any_bad(bad, &s_bad)) { status = 5; break; }
       PCG_PROBE(2);
       for (int s = M / 2; s >= 1; s /= 2) {
-        pcg_back_level<B>(sDi, sGl, sGr, w, xs, s, M, nv - 1, lane);
-        wave_lds_sync();
+        pcg_back_level<B, NS>(items, s, w0, xs);
+        lds_barrier();
       }
+      PCG_PROBE(11);
       double gz = 0.0;
-      for (int t = lane; t < nvB; t += WAVE) {
-        const double z = xs[(t / B) * BP + t % B];
-        zl[t] = z;
-        gz += rv[t] * z;
-        gran_st(a.zsG + row0 + t, scl[t] * z, tag);
+      if (own) {
+        zr = xs[own_slot];
+        gz = rr_ * zr;
+        gran_st(a.zsG + row0 + tid, scr * zr, tag);
       }
-      const double gamma_c = wave_sum(gz);
-      if (lane == 0) { gran_st(a.gamG + wg, gamma_c, tag); gran_st(a.rrG + wg, rr_c, tag); }
+      gz = wave_sum_dpp(gz);
+      if (lane == 0) s_red[kPcgWaves + wave] = gz;
+      lds_barrier();
+      if (tid == 0) {
+        double rr_c = 0.0, gamma_c = 0.0;
+#pragma unroll
+        for (int k = 0; k < kPcgWaves; ++k) { rr_c += s_red[k]; gamma_c += s_red[kPcgWaves + k]; }
+        gran_st(a.gamG + wg, gamma_c, tag); gran_st(a.rrG + wg, rr_c, tag);
+      }
       PCG_PROBE(3);
     } else {
       // ---- P2 (the top): the upper levels: nodes 0, M, 2M, ... ----
       {
         unsigned pend = 0u;
-        for (int k = 0; lane + WAVE * k < T * B; ++k) pend |= 1u << k;          // T * B <= 64 * 12
+        for (int k = 0; tid + kPcgThreads * k < T * B; ++k) pend |= 1u << k;          // T * B <= 64 * 12: at most two per thread
         for (unsigned spin = 1; pend != 0u; ++spin) {
           for (unsigned m = pend; m != 0u; m &= m - 1u) {
-            const int k = __builtin_ctz(m), e = lane + WAVE * k, t = e / B, q = e % B;
+            const int k = __builtin_ctz(m), e = tid + kPcgThreads * k, t = e / B, q = e % B;
             const v2f64 g0 = gran_ld(a.ctrG + (size_t)t * 3 * B + 2 * B + q), g1 = gran_ld(a.ctrG + (size_t)t * 3 * B + q);
             v2f64 g2; g2.x = 0.0; g2.y = tag;
             if (t >= 1) g2 = gran_ld(a.ctrG + (size_t)(t - 1) * 3 * B + B + q);
-            if (g0.y == tag && g1.y == tag && g2.y == tag) { w[t * BP + q] = (g0.x - g1.x) - g2.x; pend &= ~(1u << k); }
+            if (g0.y == tag && g1.y == tag && g2.y == tag) { w0[t * BP + q] = (g0.x - g1.x) - g2.x; pend &= ~(1u << k); }
           }
           if (pend != 0u) {
             if ((spin & 63u) == 0u && pcg_give_up(spin, pp)) { bad = true; break; }
@@ -496,35 +472,27 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg_fused(PcgArgs a, FactorView
           }
         }
       }
-      if (__any(bad ? 1 : 0)) { status = 5; break; }
-      wave_lds_sync();
+      if (pcg_any_bad(bad, &s_bad)) { status = 5; break; }
       PCG_PROBE(1);
       for (int s = 1; s < Tp; s *= 2) {
-        pcg_fwd_products<B>(sGl, sGr, w, ca, cb, s, Tp, T - 1, lane);
-        wave_lds_sync();
-        const int nsv = Tp / (2 * s);
-        for (int e = lane; e < nsv * B; e += WAVE) {
-          const int j = 2 * s * (e / B), q = e % B;
-          if (j > T - 1) continue;
-          const double pl = (j - s >= 1) ? cb[(size_t)(j - s) * BP + q] : 0.0;
-          const double pr = (j + s <= T - 1) ? ca[(size_t)(j + s) * BP + q] : 0.0;
-          w[(size_t)j * BP + q] = (w[(size_t)j * BP + q] - pl) - pr;
-        }
-        wave_lds_sync();
+        pcg_fwd_products<B, NS>(items, s, w0, ca, cb);
+        lds_barrier();
+        pcg_fwd_survivors<B>(s, Tp, T - 1, w0, ca, cb, nullptr, nullptr);
+        lds_barrier();
       }
-      if (lane < B) {
+      if (tid < B) {                                     // the root: x_0 = Dinv_0 w_0
         double v = 0.0;
 #pragma unroll
-        for (int c = 0; c < B; ++c) v += sD0[lane * B + c] * w[c];
-        xs[lane] = v;
+        for (int c = 0; c < B; ++c) v += sD0[tid * B + c] * w0[c];
+        xs[tid] = v;
       }
-      wave_lds_sync();
+      lds_barrier();
       for (int s = Tp / 2; s >= 1; s /= 2) {
-        pcg_back_level<B>(sDi, sGl, sGr, w, xs, s, Tp, T - 1, lane);
-        wave_lds_sync();
+        pcg_back_level<B, NS>(items, s, w0, xs);
+        lds_barrier();
       }
       PCG_PROBE(2);
-      for (int e = lane; e < T * B; e += WAVE) {
+      for (int e = tid; e < T * B; e += kPcgThreads) {
         const double v = xs[(e / B) * BP + e % B];
         gran_st(a.topL + e, v, tag);
         if (e >= B) gran_st(a.topR + (e - B), v, tag);
@@ -532,46 +500,59 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg_fused(PcgArgs a, FactorView
       PCG_PROBE(3);
     }
     // ---- r.r is out with z; is the solve over? ----
-    rr = pcg_rr_sum(a.rrG, T, tag, pp, bad, lane);
-    if (__any(bad ? 1 : 0)) { status = 5; break; }
+    if (wave == 0) { const double v = pcg_rr_sum(a.rrG, T, tag, pp, bad, lane); if (lane == 0) s_sc[0] = v; }
+    if (pcg_any_bad(bad, &s_bad)) { status = 5; break; }
+    rr = s_sc[0];
     PCG_PROBE(4);
     if (!(rr == rr)) { status = 3; break; }
     if (!(rr > target) || it >= a.max_it) break;
     if (is_chunk) {
       // ---- P5: w of the owned rows and the global sums come in; alpha, beta; p = z + beta p, s = w + beta s ----
-      double g = 0.0, d = 0.0;
-      for (int c = lane; c < T; c += WAVE) g += gran_take<false>(a.gamG + c, tag, pp, bad);
-      for (int h = lane; h < Hh; h += WAVE) d += gran_take<true>(a.delG + h, tag, pp, bad);
-      gran_take_rows(a.wG + row0, nvB, tag, pp, bad, wl, lane);
-      if (__any(bad ? 1 : 0)) { status = 5; break; }
-      const double gamma = wave_sum(g), delta = wave_sum(d);
+      if (wave == 0) {
+        double g = 0.0, d = 0.0;
+        for (int c = lane; c < T; c += WAVE) g += gran_take<false>(a.gamG + c, tag, pp, bad);
+        {                                                // the product workgroups' w.z: every pending load of a round in flight together
+          unsigned pend = 0u;
+          for (int k = 0; lane + WAVE * k < Hh; ++k) pend |= 1u << k;
+          for (unsigned spin = 1; pend != 0u; ++spin) {
+            for (unsigned m = pend; m != 0u; m &= m - 1u) {
+              const int k = __builtin_ctz(m);
+              const v2f64 gq = gran_ld(a.delG + lane + WAVE * k);
+              if (gq.y == tag) { d += gq.x; pend &= ~(1u << k); }
+            }
+            if (pend != 0u && (spin & 63u) == 0u && pcg_give_up(spin, pp)) { bad = true; break; }
+          }
+        }
+        g = wave_sum_dpp(g); d = wave_sum_dpp(d);
+        if (lane == 0) { s_sc[1] = g; s_sc[2] = d; }
+      }
+      double wr = 0.0;
+      if (own) wr = gran_take<true>(a.wG + row0 + tid, tag, pp, bad);
+      if (pcg_any_bad(bad, &s_bad)) { status = 5; break; }
+      const double gamma = s_sc[1], delta = s_sc[2];
       PCG_PROBE(6);
       const double beta = (it == 0 || gamma_old == 0.0) ? 0.0 : gamma / gamma_old;
       const double denom = (it == 0) ? delta : delta - beta * gamma / alpha_old;
       if (!(denom > 0.0)) {
         // p.A p <= 0 (or not finite): with r.z == 0 the residual is exactly zero and nothing is left to do; otherwise a breakdown
         if (gamma != 0.0) status = 1;
-        if (lane == 0) pcg_abort_set(pp, 1u);      // the product workgroups and the top leave at their next wait
+        if (tid == 0) pcg_abort_set(pp, 1u);       // the product workgroups and the top leave at their next wait
         break;
       }
       alpha = gamma / denom;
-      for (int t = lane; t < nvB; t += WAVE) {
-        pv[t] = zl[t] + beta * pv[t];
-        sv[t] = wl[t] + beta * sv[t];
-      }
+      pr = zr + beta * pr;
+      sr = wr + beta * sr;
       gamma_old = gamma; alpha_old = alpha;
     }
     PCG_PROBE(7);
     ++it;
   }
   // ---- the solution back to memory; one record for the host ----
-  if (is_chunk) {
-    for (int t = lane; t < nvB; t += WAVE) a.x[row0 + t] = xv[t];
-  }
+  if (own) a.x[row0 + tid] = xr;
   // status here: 0 = converged or iteration cap, 1 = breakdown, 3 = not finite (every workgroup alike); 5 = a wait was given up: because it ran
   // out (here or elsewhere: the abort word is 2 and the solve is void) or because the chunk workgroups ended the solve (abort word 1: the product
   // workgroups and the top only).  Workgroup 0 (a chunk: one of those that decide) reports; a wait that ran out is reported by everybody who saw it.
-  if (lane == 0) {
+  if (tid == 0) {
     const unsigned ab = (status == 5) ? pcg_abort_code(pp) : 0u;
     if (status == 5 && ab != 1u) __hip_atomic_store(a.result + 2, 2.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     else if (wg == 0) {
@@ -587,10 +568,8 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg_fused(PcgArgs a, FactorView
 static int pcg_pow2_at_least(int v) { int p = 1; while (p < v) p *= 2; return p; }
 
 static size_t pcg_lds_doubles(int B, int M, int T) {
-  const int BB = B * B, Tp = pcg_pow2_at_least(T);
-  const size_t chunk = (size_t)3 * (M - 1) * BB + (size_t)(2 * (M + 1) + 2 * M) * (B + 1) + (size_t)7 * M * B + 2 * B;
-  const size_t top = (size_t)3 * (Tp - 1) * BB + BB + (size_t)(Tp + 2 * Tp + 1 + 2 * Tp) * (B + 1);
-  return std::max(chunk, top) + 8;
+  const int Tp = pcg_pow2_at_least(T), Mloc = std::max(M, Tp);
+  return (size_t)4 * (Mloc + 1) * (B + 1) + 2 * (size_t)B + (size_t)B * B + 8;            // the sweep's vectors (+ Dinv of node 0 in the top)
 }
 
 // The launch geometry for a chain of nsb super-blocks of B x B, or false: chunk size M (a power of two), chunks = top nodes <= 64,
@@ -602,7 +581,9 @@ bool pcg_fused_plan(int nsb, int B, int n_rows, int cus, PcgPlan* out) {
   int best = 0;
   for (int M = 4; M <= 256; M *= 2) {
     const int T = (nsb + M - 1) / M;
+    // every item of a sweep has a slot: 6 B (nodes - 1) items over 512 threads x 5 slots (the top has Tp nodes); a chunk's rows one per thread
     if (T < 2 || T > 64 || T + 2 > cus || M * B > kPcgThreads) continue;
+    if (6 * B * (M - 1) + 4 > kPcgThreads * kPcgSlotsMax || 6 * B * (pcg_pow2_at_least(T) - 1) + 4 > kPcgThreads * kPcgSlotsMax) continue;
     if (pcg_lds_doubles(B, M, T) > lds_cap) continue;
     // the sweep's depth is log2(M) + log2(T) whatever the split; fewer chunks make the fan-ins cheaper, more chunks spread the
     // local levels over more workgroups: take the split closest to M == T
@@ -616,7 +597,7 @@ bool pcg_fused_plan(int nsb, int B, int n_rows, int cus, PcgPlan* out) {
   p.G = p.chunks + helpers + 1;
   // product workgroups keep their poses' blocks in LDS (80 bytes per entry and wave): at least 96 KB whatever the tiles need
   p.lds_bytes = std::max(pcg_lds_doubles(B, p.M, p.chunks) * sizeof(double), (size_t)96 * 1024);
-  p.capw = (int)(p.lds_bytes / (kPcgWaves * 80));
+  p.capw = (int)((p.lds_bytes - 64) / 76);                           // the workgroup's pool: 9 doubles + 1 int per entry
   // granules (16 bytes each): zs, w (nsb * B each) | ctr (chunks * 3 B) | topL, topR (chunks * B each) | gamma, r.r (chunks each) | delta (G)
   p.work_doubles = 2 * ((size_t)2 * nsb * B + (size_t)p.chunks * 5 * B + (size_t)p.chunks * 2 + (size_t)p.G + 8);
   if (out) *out = p;
@@ -625,15 +606,21 @@ bool pcg_fused_plan(int nsb, int B, int n_rows, int cus, PcgPlan* out) {
 
 size_t pcg_fused_sync_words() { return 32; }
 
-template <int B>
-static bool pcg_launch_t(hipStream_t st, const PcgPlan& pl, const PcgArgs& a, const FactorView& fv, const LinView& lin, const CrView& cr, const double* scale, int groups) {
+template <int B, int NS>
+static bool pcg_launch_tn(hipStream_t st, const PcgPlan& pl, const PcgArgs& a, const FactorView& fv, const LinView& lin, const CrView& cr, const double* scale, int groups) {
   static bool raised = false;
   if (!raised) {
-    raised = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pcg_fused<B>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) == hipSuccess;
+    raised = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pcg_fused<B, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) == hipSuccess;
     if (!raised) { (void)hipGetLastError(); return false; }
   }
-  hipLaunchKernelGGL(k_pcg_fused<B>, dim3(groups), dim3(kPcgThreads), pl.lds_bytes, st, a, fv, lin, cr, scale);
+  hipLaunchKernelGGL((k_pcg_fused<B, NS>), dim3(groups), dim3(kPcgThreads), pl.lds_bytes, st, a, fv, lin, cr, scale);
   return true;
+}
+template <int B>
+static bool pcg_launch_t(hipStream_t st, const PcgPlan& pl, const PcgArgs& a, const FactorView& fv, const LinView& lin, const CrView& cr, const double* scale, int groups) {
+  const int nodes = std::max(pl.M, pl.Tp);
+  if (6 * B * (nodes - 1) + 4 <= kPcgThreads * 3) return pcg_launch_tn<B, 3>(st, pl, a, fv, lin, cr, scale, groups);
+  return pcg_launch_tn<B, kPcgSlotsMax>(st, pl, a, fv, lin, cr, scale, groups);
 }
 
 bool launch_pcg_fused(hipStream_t st, const PcgPlan& pl, int n_poses, int npad, const FactorView& fv, const LinView& lin, const CrView& cr, const double* scale,

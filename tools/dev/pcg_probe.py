@@ -21,3 +21,13 @@ for k in range(2):
 cg = sm.linear_iterations - sm.iterations
 print("re-solve: %d LM, %d CG iterations, %.2f us per CG iteration, linear solver %.3f ms per LM iteration, total %.2f ms" % (
     sm.iterations, cg, 1e3 * sm.pcg_ms / max(sm.pcg_timed_iterations, 1), sm.linear_solver_ms / sm.iterations, sm.total_ms))
+ps, pt = s.get_correspondences()[:2]
+far = np.abs(ps.astype(np.int64) - pt) > sm.band_poses
+deg = np.zeros(n, np.int64)
+und = set()
+for a_, b_ in zip(ps[far], pt[far]):
+    und.add((min(a_, b_), max(a_, b_)))
+for a_, b_ in und:
+    deg[a_] += 1; deg[b_] += 1
+print("off-band partners per pose: mean %.1f, max %d (pose %d), first 16 poses: %s; poses with more than 55: %d" % (
+    deg.mean(), deg.max(), int(deg.argmax()), deg[:16].tolist(), int((deg > 55).sum())))
