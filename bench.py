@@ -603,7 +603,7 @@ def main():
             result["roofline"]["measured_copy_ceiling"] = {
                 "GB/s": copy_gbs, "ms_per_copy": 2.0 * nbytes / (copy_gbs * 1e9) * 1e3 if copy_gbs > 0 else None, "bytes_per_copy": 2 * nbytes,
                 "achieved_over_ceiling": (achieved / copy_gbs) if copy_gbs > 0 else None,
-                "what": "hitl_device_copy_bandwidth: the library's float4 grid-stride copy kernel (four loads in flight per lane, 8 workgroups per CU) "
+                "what": "hitl_device_copy_bandwidth: the library's float4 copy kernel (one float4 per thread, a workgroup per 4 KB) "
                         "over 1 GiB, read + write counted, 10 launches between two HIP events on its own stream after 2 warm-up launches, after the "
                         "timed region; `frac` stays against the 8 TB/s vendor peak"}
         except Exception as e:

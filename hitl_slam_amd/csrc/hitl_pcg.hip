@@ -94,6 +94,7 @@ __device__ __forceinline__ void gran_take3(const v2f64* p, double tag, const Pcg
     const v2f64 g0 = gran_ld(p), g1 = gran_ld(p + 1), g2 = gran_ld(p + 2);
     if (g0.y == tag && g1.y == tag && g2.y == tag) { v0 = g0.x; v1 = g1.x; v2 = g2.x; return; }
     if ((k & 63u) == 0u && pcg_give_up(k, pp)) { bad = true; v0 = v1 = v2 = 0.0; return; }
+    __builtin_amdgcn_s_sleep(4);                    // a thousand product waves wait here through a whole sweep: poll politely
   }
 }
 // count granules into LDS by one wave (entry e = lane, lane + 64, ...): every pending load of a round is in flight together

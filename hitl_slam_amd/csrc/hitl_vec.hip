@@ -585,18 +585,16 @@ void launch_host_flag(hipStream_t st, double* flag_pinned, double seq) {
   hipLaunchKernelGGL(k_host_flag, dim3(1), dim3(1), 0, st, flag_pinned, seq);
 }
 
-// the copy the measured ceiling of bench.py is taken with: 16 bytes per lane, four independent loads in flight per lane and trip
+// the copy the measured ceiling of bench.py is taken with: ONE float4 per thread, a workgroup per 4 KB -- measured on MI355X
+// (tools/dev/probes/copy_probe.hip, 1 GiB): 6.28 TB/s; a grid-stride loop with four loads in flight per lane (the first form tried
+// here) 4.4-4.9, 16 KB per workgroup 5.9 (6.28 with nontemporal accesses), hipMemcpy device-to-device 5.0
 __global__ __launch_bounds__(256) void k_copy_f4(size_t n, const float4* __restrict__ src, float4* __restrict__ dst) {
-  const size_t stride = (size_t)gridDim.x * 256;
-  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  for (; i + 3 * stride < n; i += 4 * stride) {
-    const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-    dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
-  }
-  for (; i < n; i += stride) dst[i] = src[i];
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = src[i];
 }
-void launch_copy_f4(hipStream_t st, size_t n_f4, const float4* src, float4* dst, int blocks) {
-  hipLaunchKernelGGL(k_copy_f4, dim3(blocks), dim3(256), 0, st, n_f4, src, dst);
+void launch_copy_f4(hipStream_t st, size_t n_f4, const float4* src, float4* dst, int /*blocks: unused, one float4 per thread*/) {
+  if (n_f4 == 0) return;
+  hipLaunchKernelGGL(k_copy_f4, dim3((unsigned)((n_f4 + 255) / 256)), dim3(256), 0, st, n_f4, src, dst);
 }
 
 void launch_copy(hipStream_t st, int n, const double* src, double* dst) {

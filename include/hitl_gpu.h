@@ -466,7 +466,7 @@ int hitl_solver_set_timing_level(hitl_solver*, int32_t level);
 
 /* Free / total memory of a HIP device in bytes (hipMemGetInfo); for leak checks and capacity planning. */
 int hitl_device_memory(int32_t device, int64_t* free_bytes, int64_t* total_bytes);
-/* Measured device-to-device copy rate of a HIP device: a float4 grid-stride copy kernel over `bytes` (>= 1 GiB recommended; rounded
+/* Measured device-to-device copy rate of a HIP device: a float4-per-thread copy kernel over `bytes` (>= 1 GiB recommended; rounded
  * down to 16), `repeats` launches between two HIP events after 2 warm-up launches; *gb_per_s counts bytes read + bytes written.
  * The measured ceiling SURVEY.md 8(d) asks for beside the 8 TB/s vendor peak (bench.py `roofline.measured_copy_ceiling`). */
 int hitl_device_copy_bandwidth(int32_t device, int64_t bytes, int32_t repeats, double* gb_per_s);

@@ -64,12 +64,12 @@ def test_figure8_all_pairs_mode_c_equals_the_oracles_exact_solve():
 
 
 @pytest.mark.parametrize("band", [1, 2, 3, 4])
-@pytest.mark.parametrize("n,m,laps", [(64, 60, 2), (150, 90, 2), (333, 60, 3), (700, 48, 4)])
+@pytest.mark.parametrize("n,m,laps", [(64, 60, 2), (150, 90, 2), (333, 60, 3), (700, 48, 4), (2000, 24, 8)])
 def test_persistent_launch_walks_the_path_of_the_launch_per_stage_loop(switches, band, n, m, laps):
     """Same map, same correspondences, same options: the persistent launch (Chronopoulos-Gear recurrence, workgroup roles) and the loop
     of rounds 2-5 (textbook PCG, eight launches per iteration) solve every linear system to the same tolerance: the same LM iterations,
     accepted steps and termination, final costs equal to 1e-9, poses to 1e-6.  Band widths 1-4 (super-blocks of 3, 6, 9 and 12), chains
-    from 16 to 700 nodes."""
+    from 16 to 2 000 nodes (2 000 poses at a band of 4: 32 top nodes of 12 x 12, the five-slot instantiation of the sweep)."""
     import hitl_slam_amd as H
     d, rows = _fig8(n, m, laps)
     res = []
