@@ -299,6 +299,8 @@ void launch_pcg_step(hipStream_t st, int n, const double* p, const double* q, do
 // The whole PCG solve as one persistent launch (hitl_pcg.hip): systems with pose pairs outside the band, one GPU, chains of at most
 // 64 chunks whose factor tiles fit LDS.  pcg_fused_plan: the launch geometry, or false (the launch-per-stage loop of hitl_lm.cpp runs).
 struct PcgPlan { int M, chunks, Tp, G, capw; size_t lds_bytes, work_doubles; };
+constexpr int kPcgMaxParts = 8;            // a pose's product is cut into at most this many items ...
+constexpr int kPcgPartEntries = 128;       // ... of this many entries (the last one takes the rest)
 bool pcg_fused_plan(int nsb, int B, int n_rows, int cus, PcgPlan* out);
 size_t pcg_fused_sync_words();
 // x: in x0 = M^-1 b, out the solution; r0 = b - A x0 with its (r.r, b.b) partials (launch_spmv_residual); work: PcgPlan::work_doubles
@@ -308,6 +310,8 @@ size_t pcg_fused_sync_words();
 // workgroups ran out: the solve is void, 3 not finite), b.b
 bool launch_pcg_fused(hipStream_t st, const PcgPlan& pl, int n_poses, int npad, const FactorView& fv, const LinView& lin, const CrView& cr, const double* scale,
                       double mu, double min_diag, double max_diag, double tol, int max_it, double* x, const double* r0, const double* partials0, int nblk0,
+                      const int* items /* (pose, first entry, entries, part) x n_items: the products cut into parts of <= 64 entries */, int n_items,
+                      const unsigned char* parts /* per pose row */,
                       double* work, unsigned* sync, uint64_t launch_index, double* result_pinned, unsigned spins, bool starve = false,
                       unsigned long long* probe = nullptr /* HITL_TIMING: 16 x G timestamps of CG iteration 2 */);
 // y = alpha*x + beta*y

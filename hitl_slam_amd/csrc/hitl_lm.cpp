@@ -343,6 +343,38 @@ static int enqueue_linear_solve_banded(hitl_solver* s, const FactorView& fv, int
   return HITL_OK;
 }
 
+// Product items of the persistent PCG launch, once per correspondence set and pose band: a pose's entries (2 Wb + 1 band blocks, then
+// its off-band partners) in parts of at most kPcgPartEntries = 128 (two gathers per lane) so that a pose with hundreds of partners (a
+// map's hub: 270 at c3, against 32 on average) is spread over several workgroups instead of holding one wave, and every chunk that
+// waits for it, 2.5 us longer than the others (measured; parts of 64 doubled the items of a map with 60 partners per pose and cost
+// more than they saved there).
+static int pcg_prepare_items(hitl_solver* s, const FactorView& fv) {
+  hipStream_t st = s->stream;
+  const int npad = s->npad;
+  if (s->pcg_items_of != s->corr_generation || s->pcg_items_wb != fv.band_poses) {
+    const int n_rows = npad / 3, nband = 2 * fv.band_poses + 1;
+    std::vector<int> items;
+    std::vector<unsigned char> parts((size_t)n_rows, 1);
+    items.reserve((size_t)4 * (n_rows + 64));
+    for (int i = 0; i < n_rows; ++i) {
+      const int deg = (i < s->n && (int)s->h_obadj_off.size() == s->n + 1) ? s->h_obadj_off[i + 1] - s->h_obadj_off[i] : 0;
+      const int total = nband + deg;
+      const int np = std::min(kPcgMaxParts, (total + kPcgPartEntries - 1) / kPcgPartEntries);
+      parts[i] = (unsigned char)np;
+      for (int q = 0; q < np; ++q) {
+        const int first = q * kPcgPartEntries, cnt = (q == np - 1) ? total - first : kPcgPartEntries;
+        items.push_back(i); items.push_back(first); items.push_back(cnt); items.push_back(q);
+      }
+    }
+    s->pcg_n_items = (int)(items.size() / 4);
+    TRY(s->pcg_items.upload(items, st));
+    TRY(s->pcg_parts.upload(parts, st));
+    HIP_TRY(hipStreamSynchronize(st));                     // (the host vectors go out of scope; once per correspondence set)
+    s->pcg_items_of = s->corr_generation; s->pcg_items_wb = fv.band_poses;
+  }
+  return HITL_OK;
+}
+
 // Pose pairs outside the band, one GPU, queue only (round 6): band factorisation + x0 = M^-1 b, the residual, the WHOLE preconditioned CG
 // as one persistent launch (hitl_pcg.hip: its scalars never leave the device, it stops by itself and leaves a four-double record in
 // pinned memory), then the trust-region bookkeeping and the candidate.  As in the banded case the caller queues the candidate's
@@ -374,7 +406,7 @@ static int enqueue_linear_solve_pcg(hitl_solver* s, const FactorView& fv, int bu
   const bool starve = dev_switches().pcg_starve;                             // test hook: no top workgroup, short waits -- the chunk workgroups give up
   const unsigned spins = starve ? 1u << 10 : 1u << 20;
   if (!launch_pcg_fused(st, pl, s->n, npad, fv, lv, cr, s->scale.p, mu, mind, maxd, tol, (int)s->opt.max_linear_iterations, s->dt.p, s->rv.p, s->step_partials.p,
-                        spmv_blocks(npad), s->pcg_work.p, s->pcg_sync.p, ++s->pcg_launches, rec, spins, starve, probe))
+                        spmv_blocks(npad), s->pcg_items.p, s->pcg_n_items, s->pcg_parts.p, s->pcg_work.p, s->pcg_sync.p, ++s->pcg_launches, rec, spins, starve, probe))
     return fail(HITL_ERR_HIP, "the persistent PCG kernel could not be launched");
   if (probe != nullptr) {                                  // HITL_TIMING, first solve only: where one CG iteration's time goes, per role
     std::vector<unsigned long long> h((size_t)pl.G * 16);
@@ -394,6 +426,9 @@ static int enqueue_linear_solve_pcg(hitl_solver* s, const FactorView& fv, int bu
         std::fprintf(stderr, "  products %3d: start %.2f | r.r check %.2f | products out %.2f\n", wg, at(wg, 0), at(wg, 4), at(wg, 5));
     std::fprintf(stderr, "  chunk 0 in detail: updates + r.r done %.2f | forward levels done %.2f | ctr out %.2f ... z taken %.2f | back levels done %.2f | z, r.z, r.r out %.2f\n",
                  at(0, 9), at(0, 10), at(0, 1), at(0, 2), at(0, 11), at(0, 3));
+    { double worst = -1e9, best = 1e9; int wwg = -1;
+      for (int wg = pl.chunks; wg < pl.G - 1; ++wg) { const double t = at(wg, 5); if (t > worst) { worst = t; wwg = wg; } if (t < best) best = t; }
+      std::fprintf(stderr, "  products out over all %d product workgroups: first %.2f, last %.2f (workgroup %d)\n", pl.G - 1 - pl.chunks, best, worst, wwg); }
     { const double cyc = (double)(h[8 + 7] - h[8 + 0]), t_us = us(0, 0, 7);
       std::fprintf(stderr, "  shader clock over chunk 0's iteration: %.0f cycles in %.2f us = %.0f MHz\n", cyc, t_us, t_us > 0 ? cyc / t_us : 0.0); }
     s->pcg_probe.release();
@@ -975,8 +1010,11 @@ int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float* poses
     StepScalars ss;
     bool fused = (!s->dist_mode() && fv.n_offband == 0);   // one host synchronisation per LM iteration
     PcgPlan pcg_plan;
-    const bool fused_pcg = !fused && !s->dist_mode() && fv.n_offband > 0 && dev_switches().pcg_fused && !s->pcg_fused_off &&
-                           pcg_fused_plan(s->nsb, s->B, s->npad / 3, s->cu_count, &pcg_plan);
+    bool fused_pcg = !fused && !s->dist_mode() && fv.n_offband > 0 && dev_switches().pcg_fused && !s->pcg_fused_off;
+    if (fused_pcg) {
+      TRY(pcg_prepare_items(s, fv));
+      fused_pcg = pcg_fused_plan(s->nsb, s->B, std::max(s->npad / 3, s->pcg_n_items), s->cu_count, &pcg_plan);     // one product wave per item where the device has them
+    }
     LinResult lr_spec = {0.0, 0.0, 0.f, 0};
     bool have_spec = false;
     if (fused_pcg) {
@@ -988,6 +1026,9 @@ int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float* poses
       { RoctxRange r("hitl:wait for the device"); TRY(spin_sync(s)); }
       const double* rec = s->h_scalars + 8;
       const double st_pcg = rec[2];
+      if (dev_switches().timing && st_pcg != 0.0)
+        std::fprintf(stderr, "k_pcg_fused: status %.0f after %.0f iterations, r.r (status 2: workgroup * 1000 + thread + wait site / 100 of the wait that ran out) %.4f, b.b %.3g (M %d, chunks %d, G %d, items %d)\n", st_pcg, rec[0], rec[1], rec[3], pcg_plan.M,
+                     pcg_plan.chunks, pcg_plan.G, s->pcg_n_items);
       if (st_pcg == 2.0 || st_pcg < 0.0) {                        // a wait between the workgroups ran out (or nobody reported): this solve is void
         s->pcg_fused_off = true;
         (void)take_cr_tail_failure(s);

@@ -62,7 +62,16 @@ __device__ __forceinline__ void gran_st(v2f64* p, double v, double tag) {
   *(volatile gv2f64*)p = g;
 }
 
-struct PcgPoll { unsigned* abort_w; unsigned spins; unsigned launch; };   // abort word = launch << 2 | code: a word left by an earlier launch means nothing
+// A reader waits for EXACTLY the tag of its iteration, so no producer may publish iteration it + 1 into a granule before every reader
+// of iteration it has taken it.  That holds by data dependence, not by timing: a chunk hands its boundary record over (it + 1) only after
+// it has taken the top's z (it), which the top published after reading every record (it); the top publishes (it + 1) after every
+// chunk's record (it + 1), i.e. after they took its z (it); a chunk publishes z (it + 1) after it has taken every product workgroup's
+// w.z (it), each published after ALL that workgroup's gathers (it); a product item publishes w (it + 1) only after it has taken z (it + 1)
+// of its OWN pose (every item does, also the ones that do not need the value), which that pose's chunk published after taking w (it).
+// The one value without such a chain is r.r (read by the product workgroups AFTER they have published w.z): it alternates between two
+// buffers, and the buffer of iteration it is rewritten at it + 2, which needs the product workgroups' w.z (it + 1), published after
+// their look at r.r (it).
+struct PcgPoll { unsigned* abort_w; unsigned spins; unsigned launch; double* dbg; };      // dbg (pinned): workgroup * 1000 + thread + site / 100 of a wait that ran out   // abort word = launch << 2 | code: a word left by an earlier launch means nothing
 __device__ __forceinline__ unsigned pcg_abort_code(const PcgPoll& pp) {
   const unsigned v = __hip_atomic_load(pp.abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return ((v >> 2) == pp.launch) ? (v & 3u) : 0u;
@@ -73,8 +82,12 @@ __device__ __forceinline__ void pcg_abort_set(const PcgPoll& pp, unsigned code) 
 
 // Every wait is bounded and the abort word ends all of them: 1 = the chunk workgroups have ended the solve (breakdown), 2 = somebody's
 // wait ran out.  Called every 64th poll of a spin loop; true = give up.
-__device__ __forceinline__ bool pcg_give_up(unsigned k, const PcgPoll& pp) {
-  if (k >= pp.spins) { pcg_abort_set(pp, 2u); return true; }
+__device__ __forceinline__ bool pcg_give_up(unsigned k, const PcgPoll& pp, int site) {
+  if (k >= pp.spins) {
+    pcg_abort_set(pp, 2u);
+    if (pp.dbg != nullptr) __hip_atomic_store(pp.dbg, 1000.0 * (double)blockIdx.x + (double)threadIdx.x + 0.01 * (double)site, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return true;
+  }
   return pcg_abort_code(pp) != 0u;
 }
 
@@ -84,7 +97,7 @@ __device__ __forceinline__ double gran_take(const v2f64* p, double tag, const Pc
   for (unsigned k = 1;; ++k) {
     const v2f64 g = gran_ld(p);
     if (g.y == tag) return g.x;
-    if ((k & 63u) == 0u && pcg_give_up(k, pp)) { bad = true; return 0.0; }
+    if ((k & 63u) == 0u && pcg_give_up(k, pp, 1)) { bad = true; return 0.0; }
     if (SLEEP) __builtin_amdgcn_s_sleep(2);
   }
 }
@@ -93,7 +106,7 @@ __device__ __forceinline__ void gran_take3(const v2f64* p, double tag, const Pcg
   for (unsigned k = 1;; ++k) {
     const v2f64 g0 = gran_ld(p), g1 = gran_ld(p + 1), g2 = gran_ld(p + 2);
     if (g0.y == tag && g1.y == tag && g2.y == tag) { v0 = g0.x; v1 = g1.x; v2 = g2.x; return; }
-    if ((k & 63u) == 0u && pcg_give_up(k, pp)) { bad = true; v0 = v1 = v2 = 0.0; return; }
+    if ((k & 63u) == 0u && pcg_give_up(k, pp, 2)) { bad = true; v0 = v1 = v2 = 0.0; return; }
     __builtin_amdgcn_s_sleep(4);                    // a thousand product waves wait here through a whole sweep: poll politely
   }
 }
@@ -108,7 +121,7 @@ __device__ __forceinline__ void gran_take_rows(const v2f64* p, int count, double
       if (g.y == tag) { out[e] = g.x; pend &= ~(1u << k); }
     }
     if (pend != 0u) {
-      if ((spin & 63u) == 0u && pcg_give_up(spin, pp)) { bad = true; return; }
+      if ((spin & 63u) == 0u && pcg_give_up(spin, pp, 3)) { bad = true; return; }
       __builtin_amdgcn_s_sleep(1);
     }
   }
@@ -146,6 +159,15 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// Granules written by DIFFERENT workgroups never share a 128-byte line (write-through partial writes from several CUs to one line
+// serialise at the memory side: the products' w took 2.8-3.5 us to reach the chunks while the coalesced records took 0.7-1.8):
+//   w: the three rows of one PART of a pose's product (hitl_lm.cpp cuts a pose's entries into parts of 128) in a 64-byte slot of their own;
+//   per-workgroup scalars (r.z and r.r of a chunk, w.z of a product workgroup): one 128-byte slot each (8 granules);
+//   a chunk's boundary record: its 3 B granules rounded up to whole lines.
+__host__ __device__ inline size_t pcg_w_slot(size_t pose, int part, int comp) { return ((pose * kPcgMaxParts + part) * 4) + comp; }
+constexpr int kPcgLine = 8;                       // granules per 128-byte line
+__host__ __device__ inline int pcg_ctr_stride(int B) { return ((3 * B + kPcgLine - 1) / kPcgLine) * kPcgLine; }
+
 struct PcgArgs {
   int n_poses, npad, nsb, Wb;
   int M, chunks, Tp, G;          // chunk size (a power of two), chunks = top nodes, Tp = the power of two >= chunks, workgroups:
@@ -161,11 +183,14 @@ struct PcgArgs {
   int nblk0;
   // granule arrays (device memory, zero when allocated)
   v2f64* zsG;                    // npad: scale * z, gathered by the products
-  v2f64* wG;                     // npad: w = A z, taken by the rows' chunk workgroups
+  const int* items;              // the products cut into items: (pose, first entry, entries, part) x n_items
+  int n_items;
+  const unsigned char* parts;    // parts of every pose row
+  v2f64* wG;                     // (npad / 3) x kPcgMaxParts x 4: the parts of w = A z, summed by the rows' chunk workgroups
   v2f64* ctrG;                   // chunks x 3 B: contribution to the chunk's own first node | to the next chunk's first node | r at the first node
   v2f64* topL;                   // chunks x B: z at the chunk's first node
   v2f64* topR;                   // chunks x B: z at the NEXT chunk's first node (the chunk's right boundary)
-  v2f64* gamG; v2f64* rrG;       // chunks each: r.z and r.r of the chunk's rows
+  v2f64* gamG; v2f64* rrG;       // r.z (chunks lines) and r.r (2 x chunks lines: two buffers taken in turn) of the chunks' rows
   v2f64* delG;                   // product workgroups: w.z of the workgroup's rows
   unsigned* abort_w;
   unsigned launch;               // low 30 bits of the solver's launch counter (see PcgPoll)
@@ -180,7 +205,7 @@ struct PcgArgs {
 __device__ __forceinline__ double pcg_rr_sum(const v2f64* rrG, int T, double tag, const PcgPoll& pp, bool& bad, int lane) {
   double v = 0.0;
   if (lane == 0) v = gran_take<true>(rrG, tag, pp, bad);
-  for (int c = lane + (lane == 0 ? WAVE : 0); c < T; c += WAVE) v += gran_take<false>(rrG + c, tag, pp, bad);
+  for (int c = lane + (lane == 0 ? WAVE : 0); c < T; c += WAVE) v += gran_take<false>(rrG + (size_t)c * kPcgLine, tag, pp, bad);
   return wave_sum_dpp(v);
 }
 
@@ -194,7 +219,7 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg_fused(PcgArgs a, FactorView
   const int tid = threadIdx.x, wg = blockIdx.x, wave = tid >> 6, lane = tid & 63;
   const int M = a.M, T = a.chunks, Tp = a.Tp, Hh = a.G - 1 - a.chunks;
   const bool is_top = (wg == a.G - 1), is_chunk = (wg < a.chunks);
-  const PcgPoll pp = {a.abort_w, a.spins, a.launch};
+  const PcgPoll pp = {a.abort_w, a.spins, a.launch, a.result + 1};
   {  // r0.r0 and b.b from the residual pass in front of this launch (a kernel boundary: plain data), every workgroup alike
     double r_ = 0.0, b_ = 0.0;
     if (tid < WAVE) {
@@ -217,7 +242,7 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg_fused(PcgArgs a, FactorView
     const int capw = a.capw;
     double* blkS = lds;
     int* colS = reinterpret_cast<int*>(blkS + (size_t)capw * 9);
-    const int W1 = a.Wb + 1, nband = 2 * a.Wb + 1, n_rows = a.npad / 3;
+    const int W1 = a.Wb + 1, nband = 2 * a.Wb + 1;
     // wave `wave` of product workgroup h takes poses wave * Hh + h, + Hh * 8, ...: CONSECUTIVE poses go to different workgroups
     const int gw = wave * Hh + (wg - a.chunks), TW = Hh * kPcgWaves;
     auto entry = [&](int i, int e0, int idx, const double*& blk, int& j, int& tr) -> bool {       // entry idx of pose i; false: no such block
@@ -230,33 +255,37 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg_fused(PcgArgs a, FactorView
       }
       return true;
     };
+    // The products are cut into ITEMS on the host (hitl_lm.cpp): (pose, first entry, entries <= 128 except a last part, part number); item t
+    // goes to wave (t mod Hh * 8): wave `wave` of product workgroup h takes items wave * Hh + h, + Hh * 8, ... -- consecutive items (the
+    // parts of one pose, neighbouring poses) go to DIFFERENT workgroups.
     int o_wave = 0;                                     // this wave's first entry in the pool
     {
       int cnt = 0;
-      for (int i = gw; i < n_rows; i += TW) {
+      for (int t = gw; t < a.n_items; t += TW) {
+        const int i = a.items[4 * t];
         if (i >= a.n_poses || fv.fixed[i]) continue;
-        cnt += nband + ((fv.n_offband > 0) ? fv.obadj_off[i + 1] - fv.obadj_off[i] : 0);
+        cnt += a.items[4 * t + 2];
       }
       if (lane == 0) s_red[wave] = (double)cnt;
       lds_barrier();
       for (int k = 0; k < wave; ++k) o_wave += (int)s_red[k];
       lds_barrier();
       int o = o_wave;
-      for (int i = gw; i < n_rows; i += TW) {
+      for (int t = gw; t < a.n_items; t += TW) {
+        const int i = a.items[4 * t], first = a.items[4 * t + 1], cnt_t = a.items[4 * t + 2];
         if (i >= a.n_poses || fv.fixed[i]) continue;
         const int e0 = (fv.n_offband > 0) ? fv.obadj_off[i] : 0;
-        const int total = nband + ((fv.n_offband > 0) ? fv.obadj_off[i + 1] - e0 : 0);
-        for (int idx = lane; idx < total && o + idx < capw; idx += WAVE) {
+        for (int q = lane; q < cnt_t && o + q < capw; q += WAVE) {
           const double* blk = nullptr;
           int j = -1, tr = 0;
-          const bool ok = entry(i, e0, idx, blk, j, tr);
-          colS[o + idx] = ok ? j : -1;
+          const bool ok = entry(i, e0, first + q, blk, j, tr);
+          colS[o + q] = ok ? j : -1;
           if (ok) {
 #pragma unroll
-            for (int q = 0; q < 9; ++q) blkS[(size_t)q * capw + o + idx] = tr ? blk[(q % 3) * 3 + q / 3] : blk[q];
+            for (int c = 0; c < 9; ++c) blkS[(size_t)c * capw + o + q] = tr ? blk[(c % 3) * 3 + c / 3] : blk[c];
           }
         }
-        o += total;
+        o += cnt_t;
       }
     }
     lds_barrier();
@@ -273,69 +302,96 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg_fused(PcgArgs a, FactorView
       // products were for nothing (nobody takes them).
       double dz = 0.0;
       int o = o_wave;
-      for (int i = gw; i < n_rows; i += TW) {
+      for (int t = gw; t < a.n_items; t += TW) {
+        const int i = a.items[4 * t], first = a.items[4 * t + 1], cnt_t = a.items[4 * t + 2], part = a.items[4 * t + 3];
         if (i >= a.n_poses || fv.fixed[i]) {                                  // identity rows (padding, constant poses; their scale is 1): w = z
-          if (lane < 3) { const double z = gran_take<false>(a.zsG + 3 * i + lane, tag, pp, bad); gran_st(a.wG + 3 * i + lane, z, tag); dz += z * z; }
+          // (the host cuts items by the entry count alone: a constant pose with many partners has several; part 0 carries z, the others 0)
+          if (lane < 3) {
+            // EVERY item waits for z of its own pose before it publishes (here too, where the value is not needed): the row's chunk
+            // publishes that z only after it has taken the previous iteration's w in -- a product that ran ahead would overwrite a
+            // granule whose tag its reader is still waiting for
+            const double zt = gran_take<false>(a.zsG + 3 * i + lane, tag, pp, bad);
+            const double z = (part == 0) ? zt : 0.0;
+            gran_st(a.wG + pcg_w_slot(i, part, lane), z, tag);
+            dz += z * z;
+          }
           continue;
         }
         const int e0 = (fv.n_offband > 0) ? fv.obadj_off[i] : 0;
-        const int total = nband + ((fv.n_offband > 0) ? fv.obadj_off[i + 1] - e0 : 0);
         // the row's constants (lanes 0..2), asked for before the gather so that their latency hides under it
         double sa = 1.0, dd = 0.0;
         if (lane < 3) {
           sa = scale[3 * i + lane];
           const double dg = sa * sa * lin.Hband[(size_t)i * W1 * 9 + lane * 4];
-          dd = fmin(fmax(dg, a.min_diag), a.max_diag) / a.mu / sa;
+          dd = (part == 0) ? fmin(fmax(dg, a.min_diag), a.max_diag) / a.mu / sa : 0.0;       // the LM diagonal rides with the part that holds the diagonal block
         }
-        double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, d0 = 0.0, d1 = 0.0, d2 = 0.0;      // d: (scale z) of the pose's own column (entry 0 = the diagonal block)
-        for (int base = 0; base < total; base += 5 * WAVE) {
-          // up to five entries per lane and round: every granule load of the round is in flight before the first tag is looked at
+        double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, d0 = 0.0, d1 = 0.0, d2 = 0.0;      // d: (scale z) of the pose's own column
+        if (part != 0 && lane < 3) {                    // parts without the diagonal block ask for the own column too (for w.z)
+          const double v = gran_take<false>(a.zsG + 3 * i + lane, tag, pp, bad);
+          d0 = v;
+        }
+        for (int base = 0; base < cnt_t; base += 5 * WAVE) {
+          // up to five entries per lane and round (an item has 128 entries at most, except the last part of a pose with more than 1024):
+          // every granule load of a round is in flight before the first tag is looked at; entries whose z has not arrived are asked for
+          // again TOGETHER
           int jj[5];
           v2f64 g[5][3];
 #pragma unroll
           for (int k = 0; k < 5; ++k) {
-            const int idx = base + lane + WAVE * k;
+            const int q = base + lane + WAVE * k;
             jj[k] = -1;
-            if (idx < total) {
-              if (o + idx < capw) jj[k] = colS[o + idx];
-              else { const double* blk = nullptr; int tr = 0, j = -1; if (entry(i, e0, idx, blk, j, tr)) jj[k] = j; }
+            if (q < cnt_t) {
+              if (o + q < capw) jj[k] = colS[o + q];
+              else { const double* blk = nullptr; int tr = 0, j = -1; if (entry(i, e0, first + q, blk, j, tr)) jj[k] = j; }
             }
-            if (jj[k] >= 0) { g[k][0] = gran_ld(a.zsG + 3 * jj[k]); g[k][1] = gran_ld(a.zsG + 3 * jj[k] + 1); g[k][2] = gran_ld(a.zsG + 3 * jj[k] + 2); }
+          }
+          for (unsigned spin = 1;; ++spin) {
+            bool all = true;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+              if (jj[k] < 0) continue;
+              if (spin > 1 && g[k][0].y == tag && g[k][1].y == tag && g[k][2].y == tag) continue;
+              g[k][0] = gran_ld(a.zsG + 3 * jj[k]); g[k][1] = gran_ld(a.zsG + 3 * jj[k] + 1); g[k][2] = gran_ld(a.zsG + 3 * jj[k] + 2);
+            }
+#pragma unroll
+            for (int k = 0; k < 5; ++k)
+              if (jj[k] >= 0 && !(g[k][0].y == tag && g[k][1].y == tag && g[k][2].y == tag)) all = false;
+            if (all) break;
+            if ((spin & 63u) == 0u && pcg_give_up(spin, pp, 4)) { bad = true; break; }
+            __builtin_amdgcn_s_sleep(4);
           }
 #pragma unroll
           for (int k = 0; k < 5; ++k) {
             if (jj[k] < 0) continue;
-            const int idx = base + lane + WAVE * k;
-            double v0 = g[k][0].x, v1 = g[k][1].x, v2 = g[k][2].x;
-            if (!(g[k][0].y == tag && g[k][1].y == tag && g[k][2].y == tag)) gran_take3(a.zsG + 3 * jj[k], tag, pp, bad, v0, v1, v2);
+            const int q = base + lane + WAVE * k;
+            const double v0 = g[k][0].x, v1 = g[k][1].x, v2 = g[k][2].x;
             double b9[9];
-            if (o + idx < capw) {
+            if (o + q < capw) {
 #pragma unroll
-              for (int q = 0; q < 9; ++q) b9[q] = blkS[(size_t)q * capw + o + idx];
+              for (int c = 0; c < 9; ++c) b9[c] = blkS[(size_t)c * capw + o + q];
             } else {
               const double* blk = nullptr;
               int tr = 0, j = -1;
-              (void)entry(i, e0, idx, blk, j, tr);
+              (void)entry(i, e0, first + q, blk, j, tr);
 #pragma unroll
-              for (int q = 0; q < 9; ++q) b9[q] = tr ? blk[(q % 3) * 3 + q / 3] : blk[q];
+              for (int c = 0; c < 9; ++c) b9[c] = tr ? blk[(c % 3) * 3 + c / 3] : blk[c];
             }
-            if (idx == 0) { d0 = v0; d1 = v1; d2 = v2; }
+            if (first + q == 0) { d0 = v0; d1 = v1; d2 = v2; }
             acc0 += b9[0] * v0 + b9[1] * v1 + b9[2] * v2;
             acc1 += b9[3] * v0 + b9[4] * v1 + b9[5] * v2;
             acc2 += b9[6] * v0 + b9[7] * v1 + b9[8] * v2;
           }
         }
         acc0 = wave_sum_dpp(acc0); acc1 = wave_sum_dpp(acc1); acc2 = wave_sum_dpp(acc2);
-        d1 = readlane_f64(d1, 0); d2 = readlane_f64(d2, 0);
+        if (part == 0) { d1 = readlane_f64(d1, 0); d2 = readlane_f64(d2, 0); }
         if (lane < 3) {
-          const int t = 3 * i + lane;
-          const double sz = (lane == 0) ? d0 : (lane == 1) ? d1 : d2;       // (lane 0 took the diagonal block's column itself)
+          const double sz = (part != 0 || lane == 0) ? d0 : (lane == 1) ? d1 : d2;       // part 0: lane 0 took the diagonal block's column itself
           const double accv = (lane == 0) ? acc0 : (lane == 1) ? acc1 : acc2;
-          const double y = sa * accv + dd * sz;            // (S H S + D^2) z, with z = sz / sa
-          gran_st(a.wG + t, y, tag);
+          const double y = sa * accv + dd * sz;            // this part of (S H S + D^2) z, with z = sz / sa
+          gran_st(a.wG + pcg_w_slot(i, part, lane), y, tag);
           dz += y * (sz / sa);
         }
-        o += total;
+        o += cnt_t;
       }
       {
         dz = wave_sum_dpp(dz);
@@ -345,11 +401,11 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg_fused(PcgArgs a, FactorView
           double t = 0.0;
 #pragma unroll
           for (int k = 0; k < kPcgWaves; ++k) t += s_red[k];
-          gran_st(a.delG + (wg - a.chunks), t, tag);
+          gran_st(a.delG + (size_t)(wg - a.chunks) * kPcgLine, t, tag);
         }
       }
       PCG_PROBE(5);
-      if (wave == 0) { const double v = pcg_rr_sum(a.rrG, T, tag, pp, bad, lane); if (lane == 0) s_sc[0] = v; }
+      if (wave == 0) { const double v = pcg_rr_sum(a.rrG + (size_t)(it & 1) * T * kPcgLine, T, tag, pp, bad, lane); if (lane == 0) s_sc[0] = v; }
       if (pcg_any_bad(bad, &s_bad)) { status = 5; break; }
       rr = s_sc[0];
       PCG_PROBE(4);
@@ -387,6 +443,7 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg_fused(PcgArgs a, FactorView
   double xr = own ? a.x[row0 + tid] : 0.0, rr_ = own ? a.r0[row0 + tid] : 0.0, pr = 0.0, sr = 0.0, zr = 0.0;
   const double scr = own ? scale[row0 + tid] : 1.0;
   const int own_slot = (tid / B) * BP + tid % B;
+  const int own_parts = own ? (int)a.parts[(row0 + tid) / 3] : 0;
   lds_barrier();
   bb = s_sc[6]; rr = s_sc[7];
   const double target = a.tol2 * bb;
@@ -422,7 +479,7 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg_fused(PcgArgs a, FactorView
         double v;
         if (tid < 2 * B) { v = acc0[tid]; acc0[tid] = 0.0; }          // (acc0 and accM are adjacent; cleared for the next iteration)
         else v = w0[q];
-        gran_st(a.ctrG + (size_t)wg * 3 * B + tid, v, tag);
+        gran_st(a.ctrG + (size_t)wg * pcg_ctr_stride(B) + tid, v, tag);
       }
       PCG_PROBE(1);
       // ---- P3: z at the two boundary nodes comes back from the top; back-substitution; r.z ----
@@ -451,7 +508,8 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg_fused(PcgArgs a, FactorView
         double rr_c = 0.0, gamma_c = 0.0;
 #pragma unroll
         for (int k = 0; k < kPcgWaves; ++k) { rr_c += s_red[k]; gamma_c += s_red[kPcgWaves + k]; }
-        gran_st(a.gamG + wg, gamma_c, tag); gran_st(a.rrG + wg, rr_c, tag);
+        gran_st(a.gamG + (size_t)wg * kPcgLine, gamma_c, tag);
+        gran_st(a.rrG + ((size_t)(it & 1) * T + wg) * kPcgLine, rr_c, tag);
       }
       PCG_PROBE(3);
     } else {
@@ -462,13 +520,13 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg_fused(PcgArgs a, FactorView
         for (unsigned spin = 1; pend != 0u; ++spin) {
           for (unsigned m = pend; m != 0u; m &= m - 1u) {
             const int k = __builtin_ctz(m), e = tid + kPcgThreads * k, t = e / B, q = e % B;
-            const v2f64 g0 = gran_ld(a.ctrG + (size_t)t * 3 * B + 2 * B + q), g1 = gran_ld(a.ctrG + (size_t)t * 3 * B + q);
+            const v2f64 g0 = gran_ld(a.ctrG + (size_t)t * pcg_ctr_stride(B) + 2 * B + q), g1 = gran_ld(a.ctrG + (size_t)t * pcg_ctr_stride(B) + q);
             v2f64 g2; g2.x = 0.0; g2.y = tag;
-            if (t >= 1) g2 = gran_ld(a.ctrG + (size_t)(t - 1) * 3 * B + B + q);
+            if (t >= 1) g2 = gran_ld(a.ctrG + (size_t)(t - 1) * pcg_ctr_stride(B) + B + q);
             if (g0.y == tag && g1.y == tag && g2.y == tag) { w0[t * BP + q] = (g0.x - g1.x) - g2.x; pend &= ~(1u << k); }
           }
           if (pend != 0u) {
-            if ((spin & 63u) == 0u && pcg_give_up(spin, pp)) { bad = true; break; }
+            if ((spin & 63u) == 0u && pcg_give_up(spin, pp, 5)) { bad = true; break; }
             __builtin_amdgcn_s_sleep(1);
           }
         }
@@ -501,7 +559,7 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg_fused(PcgArgs a, FactorView
       PCG_PROBE(3);
     }
     // ---- r.r is out with z; is the solve over? ----
-    if (wave == 0) { const double v = pcg_rr_sum(a.rrG, T, tag, pp, bad, lane); if (lane == 0) s_sc[0] = v; }
+    if (wave == 0) { const double v = pcg_rr_sum(a.rrG + (size_t)(it & 1) * T * kPcgLine, T, tag, pp, bad, lane); if (lane == 0) s_sc[0] = v; }
     if (pcg_any_bad(bad, &s_bad)) { status = 5; break; }
     rr = s_sc[0];
     PCG_PROBE(4);
@@ -511,24 +569,43 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg_fused(PcgArgs a, FactorView
       // ---- P5: w of the owned rows and the global sums come in; alpha, beta; p = z + beta p, s = w + beta s ----
       if (wave == 0) {
         double g = 0.0, d = 0.0;
-        for (int c = lane; c < T; c += WAVE) g += gran_take<false>(a.gamG + c, tag, pp, bad);
+        for (int c = lane; c < T; c += WAVE) g += gran_take<false>(a.gamG + (size_t)c * kPcgLine, tag, pp, bad);
         {                                                // the product workgroups' w.z: every pending load of a round in flight together
           unsigned pend = 0u;
           for (int k = 0; lane + WAVE * k < Hh; ++k) pend |= 1u << k;
           for (unsigned spin = 1; pend != 0u; ++spin) {
             for (unsigned m = pend; m != 0u; m &= m - 1u) {
               const int k = __builtin_ctz(m);
-              const v2f64 gq = gran_ld(a.delG + lane + WAVE * k);
+              const v2f64 gq = gran_ld(a.delG + (size_t)(lane + WAVE * k) * kPcgLine);
               if (gq.y == tag) { d += gq.x; pend &= ~(1u << k); }
             }
-            if (pend != 0u && (spin & 63u) == 0u && pcg_give_up(spin, pp)) { bad = true; break; }
+            if (pend != 0u && (spin & 63u) == 0u && pcg_give_up(spin, pp, 6)) { bad = true; break; }
           }
         }
         g = wave_sum_dpp(g); d = wave_sum_dpp(d);
         if (lane == 0) { s_sc[1] = g; s_sc[2] = d; }
       }
       double wr = 0.0;
-      if (own) wr = gran_take<true>(a.wG + row0 + tid, tag, pp, bad);
+      if (own) {                                       // the row's product arrives in own_parts parts: every pending load of a round in flight together
+        const size_t pose = (row0 + tid) / 3;
+        const int comp = (int)((row0 + tid) % 3);
+        double pv_[kPcgMaxParts];
+        unsigned pend = (1u << own_parts) - 1u;
+        for (unsigned spin = 1; pend != 0u; ++spin) {
+#pragma unroll
+          for (int q = 0; q < kPcgMaxParts; ++q) {
+            if (!(pend & (1u << q))) continue;
+            const v2f64 gq = gran_ld(a.wG + pcg_w_slot(pose, q, comp));
+            if (gq.y == tag) { pv_[q] = gq.x; pend &= ~(1u << q); }
+          }
+          if (pend != 0u) {
+            if ((spin & 63u) == 0u && pcg_give_up(spin, pp, 7)) { bad = true; break; }
+            __builtin_amdgcn_s_sleep(2);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < kPcgMaxParts; ++q) if (q < own_parts) wr += pv_[q];          // part order: the same sum on every run
+      }
       if (pcg_any_bad(bad, &s_bad)) { status = 5; break; }
       const double gamma = s_sc[1], delta = s_sc[2];
       PCG_PROBE(6);
@@ -600,7 +677,8 @@ bool pcg_fused_plan(int nsb, int B, int n_rows, int cus, PcgPlan* out) {
   p.lds_bytes = std::max(pcg_lds_doubles(B, p.M, p.chunks) * sizeof(double), (size_t)96 * 1024);
   p.capw = (int)((p.lds_bytes - 64) / 76);                           // the workgroup's pool: 9 doubles + 1 int per entry
   // granules (16 bytes each): zs, w (nsb * B each) | ctr (chunks * 3 B) | topL, topR (chunks * B each) | gamma, r.r (chunks each) | delta (G)
-  p.work_doubles = 2 * ((size_t)2 * nsb * B + (size_t)p.chunks * 5 * B + (size_t)p.chunks * 2 + (size_t)p.G + 8);
+  p.work_doubles = 2 * ((size_t)nsb * B + pcg_w_slot((size_t)(nsb * B + 2) / 3, 0, 0) + 8 + 8 + (size_t)p.chunks * pcg_ctr_stride(B) + 2 * ((size_t)p.chunks * B + kPcgLine) +
+                        (size_t)(3 * p.chunks + p.G) * kPcgLine + 16);
   if (out) *out = p;
   return true;
 }
@@ -626,6 +704,7 @@ static bool pcg_launch_t(hipStream_t st, const PcgPlan& pl, const PcgArgs& a, co
 
 bool launch_pcg_fused(hipStream_t st, const PcgPlan& pl, int n_poses, int npad, const FactorView& fv, const LinView& lin, const CrView& cr, const double* scale,
                       double mu, double min_diag, double max_diag, double tol, int max_it, double* x, const double* r0, const double* partials0, int nblk0,
+                      const int* items, int n_items, const unsigned char* parts,
                       double* work, unsigned* sync, uint64_t launch_index, double* result_pinned, unsigned spins, bool starve, unsigned long long* probe) {
   const int B = cr.B;
   const int groups = pl.G - (starve ? 1 : 0);       // test hook: the top workgroup (the last one) is never started
@@ -636,14 +715,16 @@ bool launch_pcg_fused(hipStream_t st, const PcgPlan& pl, int n_poses, int npad, 
   a.tag0 = (double)launch_index * 2097152.0;        // 2^21 tags per launch (max_it is capped below it); exact in a double for 2^32 launches
   a.max_it = std::min(max_it, (1 << 21) - 2); a.spins = spins;
   a.x = x; a.r0 = r0; a.partials0 = partials0; a.nblk0 = nblk0;
+  a.items = items; a.n_items = n_items; a.parts = parts;
   v2f64* g = reinterpret_cast<v2f64*>(work);
   a.zsG = g; g += (size_t)cr.nsb * B;
-  a.wG = g; g += (size_t)cr.nsb * B;
-  a.ctrG = g; g += (size_t)pl.chunks * 3 * B;
-  a.topL = g; g += (size_t)pl.chunks * B;
-  a.topR = g; g += (size_t)pl.chunks * B;
-  a.gamG = g; g += pl.chunks;
-  a.rrG = g; g += pl.chunks;
+  a.wG = g; g += pcg_w_slot((size_t)(cr.nsb * B + 2) / 3, 0, 0) + 8;
+  g = reinterpret_cast<v2f64*>(((uintptr_t)g + 127) & ~(uintptr_t)127);       // whole lines from here on
+  a.ctrG = g; g += (size_t)pl.chunks * pcg_ctr_stride(B);
+  a.topL = g; g += (((size_t)pl.chunks * B + kPcgLine - 1) / kPcgLine) * kPcgLine;
+  a.topR = g; g += (((size_t)pl.chunks * B + kPcgLine - 1) / kPcgLine) * kPcgLine;
+  a.gamG = g; g += (size_t)pl.chunks * kPcgLine;
+  a.rrG = g; g += (size_t)2 * pl.chunks * kPcgLine;
   a.delG = g;
   a.abort_w = sync; a.launch = (unsigned)(launch_index & 0x3fffffffu);
   a.result = result_pinned; a.probe = probe;

@@ -142,6 +142,7 @@ int build_pair_structures(hitl_solver* s) {
     obadj_col[fill2[ob_hi[e]]] = ob_lo[e]; obadj_ent[fill2[ob_hi[e]]++] = 2 * e + 1;
   }
   s->n_offband = E;
+  s->h_obadj_off = obadj_off;                  // kept on the host: the persistent PCG launch's product items are cut from it
   hipStream_t st = s->stream;
   TRY(s->pose_pair_off.upload(ppo, st));
   TRY(s->inc_off.upload(inc_off, st));

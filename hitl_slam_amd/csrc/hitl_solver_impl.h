@@ -128,6 +128,12 @@ struct hitl_solver {
   DevArray<double> pcg_work;                   // k_pcg_fused: hand-off buffers (PcgPlan::work_doubles)
   DevArray<unsigned> pcg_sync;                 //   its abort word
   DevArray<unsigned long long> pcg_probe;      //   HITL_TIMING: phase timestamps of one CG iteration of the first launch
+  std::vector<int> h_obadj_off;                //   host copy of the off-band adjacency offsets (n + 1)
+  DevArray<int> pcg_items;                     //   product items: (pose, first entry, entries, part) x n_items
+  DevArray<unsigned char> pcg_parts;           //   parts per pose row (npad / 3)
+  int pcg_n_items = 0;
+  int64_t pcg_items_of = -1;                   //   correspondence-set generation ...
+  int pcg_items_wb = 0;                        //   ... and pose band the items were cut for
   uint64_t pcg_launches = 0;                   //   launches so far on pcg_work (the epoch base of the granule tags)
   hipEvent_t ev4 = nullptr, ev5 = nullptr;     //   brackets of that launch (hitl_summary.pcg_ms)
   bool cr_tail_off = false;                    // a wait inside k_cr_tail once ran out on this device: separate launches from then on
