@@ -122,12 +122,15 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
   const size_t per_pose = (size_t)slots * s->max_scan * sizeof(uint16_t);
   const int tile = device_tables ? n : (int)std::min<size_t>((size_t)n, std::max<size_t>(1, tile_budget / std::max<size_t>(per_pose, 1)));
   // scratch kept in the solver between calls (no 10 MB allocate-and-clear per search)
-  std::vector<int>& cand_tgt = s->h_cand_tgt;
-  std::vector<float>& cand_tf = s->h_cand_tf;
+#define TRYP(expr) do { const int rc_ = (expr); if (rc_ != HITL_OK) return rc_; } while (0)
   std::vector<float>& cs = s->h_cand_cs;
-  if (cand_tgt.size() != (size_t)tile * slots) cand_tgt.resize((size_t)tile * slots);
-  if (cand_tf.size() != (size_t)tile * slots * 8) cand_tf.resize((size_t)tile * slots * 8);
   if (cs.size() != (size_t)2 * n) cs.resize((size_t)2 * n);
+  // the j of candidate (i, slot): the slot-th pose of [i - window, i + window] without i (k_cand_tf forms the same list on the device)
+  auto cand_target = [&](int64_t i, int slot) -> int {
+    int64_t j = std::max<int64_t>(0, i - window) + slot;
+    if (j >= i) ++j;
+    return j <= std::min<int64_t>(n - 1, i + window) ? (int)j : -1;
+  };
   // candidate transforms: fp32 host libm (bit-identical to the CPU restatement), spread over a few threads
   // a handful of threads: spawning 32 cost more than the trigonometry (hardware_concurrency() also counts CPUs a container's
   // quota does not grant)
@@ -168,14 +171,14 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
     }
   };
   if (!device_tables) { run(0, n, pose_trig); mark("pose trigonometry"); }      // (one tile: the trigonometry shares a team with the candidates below)
-  // candidates of the source poses [i0, i1) into cand_tgt / cand_tf (indexed from i0)
-  // A windowed search over the whole map on one tile forms the transforms themselves on the device (k_cand_tf: the same
-  // operations in the same order) and keeps on the host only what needs the C library: the (cos, sin) of every pose and of
-  // every candidate's angle difference.  2 floats per candidate instead of 8 to compute, store and upload.
-  const bool tf_on_device = device_tables;
-  std::vector<float>& cand_trig = s->h_cand_trig;
-  if (tf_on_device && cand_trig.size() != (size_t)n * slots * 2) cand_trig.resize((size_t)n * slots * 2);
-  auto fill_candidates = [&](int64_t i0, int64_t i1, bool with_pose_trig = false, bool trig_only = false) {
+  // candidates of the source poses [i0, i1): the transforms themselves are formed on the device (k_cand_tf: the host routine's
+  // operations in the same order); the host keeps what needs the C library: the (cos, sin) of every pose and of every candidate's
+  // angle difference -- 2 floats per candidate (indexed from i0) to compute, store and upload, from page-locked memory (round 6: the
+  // all-pairs search of a 1 000-pose map uploaded 36 MB of ready-made transforms and target lists from pageable memory per search --
+  // more time than its kernels).
+  TRYP(s->hp_cand_trig.resize((size_t)tile * slots * 2));
+  float* cand_trig = s->hp_cand_trig.p;
+  auto fill_candidates = [&](int64_t i0, int64_t i1, bool with_pose_trig = false) {
     const bool paired = libm_ok && i0 == 0 && i1 == n;        // the mirror of a candidate lies in the same tile only when there is one tile
     run_phases(i0, i1, with_pose_trig ? 2 : 1, [&](int ph, int64_t a, int64_t b) {
       if (with_pose_trig && ph == 0) { pose_trig(a, b); return; }
@@ -184,44 +187,27 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
         const int64_t j0 = std::max<int64_t>(0, i - window), j1 = std::min<int64_t>(n - 1, i + window);
         for (int64_t j = j0; j <= j1; ++j) {
           if (j == i) continue;
-          cand_tgt[(size_t)(i - i0) * slots + slot] = (int)j;
-          if (trig_only) {                    // (i0 == 0: one tile)
-            float* tr = &cand_trig[((size_t)i * slots + slot) * 2];
-            if (!paired) {
-              const float dth = (float)((double)poses[3 * j + 2] - (double)poses[3 * i + 2]);
-              tr[0] = cosf(dth); tr[1] = sinf(dth);
-            } else if (j > i) {               // one sincosf for the candidate and its mirror (see below)
-              const float dth = (float)((double)poses[3 * j + 2] - (double)poses[3 * i + 2]);
-              float sn, cn;
-              sincosf(dth, &sn, &cn);
-              tr[0] = cn; tr[1] = sn;
-              const int64_t jj0 = std::max<int64_t>(0, j - window);
-              float* tm = &cand_trig[((size_t)j * slots + (size_t)(i - jj0)) * 2];
-              tm[0] = cn; tm[1] = -sn;
-            }
-            ++slot;
-            continue;
-          }
-          float* t = &cand_tf[((size_t)(i - i0) * slots + slot) * 8];
-          make_rel_tf(poses + 3 * i, poses + 3 * j, &cs[2 * i], &cs[2 * j], t, !paired);
-          if (paired && j > i) {
+          float* tr = &cand_trig[((size_t)(i - i0) * slots + slot) * 2];
+          if (!paired) {
+            const float dth = (float)((double)poses[3 * j + 2] - (double)poses[3 * i + 2]);
+            tr[0] = cosf(dth); tr[1] = sinf(dth);
+          } else if (j > i) {
             // one sincosf serves the candidate (i -> j) and its mirror (j -> i): the angle of the mirror is the exact
             // negative (fp64 difference, symmetric rounding to fp32), so its cosine is the same float and its sine the negated one
             const float dth = (float)((double)poses[3 * j + 2] - (double)poses[3 * i + 2]);
             float sn, cn;
             sincosf(dth, &sn, &cn);
-            t[6] = cn; t[7] = sn;
+            tr[0] = cn; tr[1] = sn;
             const int64_t jj0 = std::max<int64_t>(0, j - window);
-            float* tm = &cand_tf[((size_t)j * slots + (size_t)(i - jj0)) * 8];   // slot of i in j's list (i < j)
-            tm[6] = cn; tm[7] = -sn;
+            float* tm = &cand_trig[((size_t)j * slots + (size_t)(i - jj0)) * 2];   // slot of i in j's list (i < j)
+            tm[0] = cn; tm[1] = -sn;
           }
           ++slot;
         }
-        for (; slot < slots; ++slot) cand_tgt[(size_t)(i - i0) * slots + slot] = -1;     // unused slots of poses near the ends
       }
     });
   };
-  if (device_tables) fill_candidates(0, n, /*with_pose_trig=*/true, /*trig_only=*/tf_on_device);
+  if (device_tables) fill_candidates(0, n, /*with_pose_trig=*/true);
   mark("candidate transforms");
   hipStream_t st = s->stream;
   DevArray<int>&d_tgt = s->d_cand_tgt, &d_counts = s->d_cand_counts, &d_kept = s->d_cand_kept;   // device scratch, kept too
@@ -237,33 +223,34 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
   }
   // one tile of source poses [i0, i0 + cnt): upload its candidates, match
   auto match_tile = [&](int i0, int cnt) -> int {
-    if (!(tf_on_device && kd_tgt)) TRYC(d_tgt.upload(cand_tgt.data(), (size_t)cnt * slots, st));     // (the target-major kernel derives its candidates from the window)
-    if (tf_on_device) {
+    if (i0 == 0) {
       TRYC(s->d_cand_poses.upload(poses, (size_t)3 * n, st));
       TRYC(s->d_cand_cs.upload(cs.data(), (size_t)2 * n, st));
-      TRYC(s->d_cand_trig.upload(cand_trig.data(), (size_t)n * slots * 2, st));
-      TRYC(d_tf.resize((size_t)n * slots * 8));
-      launch_cand_tf(st, n, slots, (int)window, s->d_cand_poses.p, s->d_cand_cs.p, s->d_cand_trig.p, d_tf.p);
-      if (dev_switches().cand_tf_check) {
-        // development / tests: every candidate through the host routine as well, bit for bit
-        std::vector<float> dev((size_t)n * slots * 8), host(8);
-        if (hipMemcpyAsync(dev.data(), d_tf.p, dev.size() * sizeof(float), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
-          return fail(HITL_ERR_HIP, "find_correspondences: reading the candidate transforms back failed");
-        for (int64_t i = 0; i < n; ++i) {
-          int slot = 0;
-          const int64_t j0 = std::max<int64_t>(0, i - window), j1 = std::min<int64_t>(n - 1, i + window);
-          for (int64_t j = j0; j <= j1; ++j) {
-            if (j == i) continue;
-            make_rel_tf(poses + 3 * i, poses + 3 * j, &cs[2 * i], &cs[2 * j], host.data(), true);
-            if (std::memcmp(host.data(), &dev[((size_t)i * slots + slot) * 8], 8 * sizeof(float)) != 0)
-              return fail(HITL_ERR_SOLVER_FAILURE, "cand_tf_check: the device's transform of candidate (" + std::to_string(i) + ", " + std::to_string(j) +
-                                                   ") differs from the host's");
-            ++slot;
-          }
+    }
+    TRYC(s->d_cand_trig.upload(cand_trig, (size_t)cnt * slots * 2, st));
+    TRYC(d_tf.resize((size_t)cnt * slots * 8));
+    TRYC(d_tgt.resize((size_t)cnt * slots));
+    launch_cand_tf(st, n, slots, (int)window, i0, cnt, s->d_cand_poses.p, s->d_cand_cs.p, s->d_cand_trig.p, d_tf.p, d_tgt.p);
+    if (dev_switches().cand_tf_check) {
+      // development / tests: every candidate through the host routine as well, bit for bit
+      std::vector<float> dev((size_t)cnt * slots * 8), host(8);
+      std::vector<int> dev_tgt((size_t)cnt * slots);
+      if (hipMemcpyAsync(dev.data(), d_tf.p, dev.size() * sizeof(float), hipMemcpyDeviceToHost, st) != hipSuccess ||
+          hipMemcpyAsync(dev_tgt.data(), d_tgt.p, dev_tgt.size() * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+        return fail(HITL_ERR_HIP, "find_correspondences: reading the candidate transforms back failed");
+      for (int64_t i = i0; i < i0 + cnt; ++i)
+        for (int slot = 0; slot < slots; ++slot) {
+          const int j = cand_target(i, slot);
+          const size_t c = (size_t)(i - i0) * slots + slot;
+          if (dev_tgt[c] != j)
+            return fail(HITL_ERR_SOLVER_FAILURE, "cand_tf_check: the device's target of candidate (" + std::to_string(i) + ", slot " + std::to_string(slot) + ") differs from the host's");
+          if (j < 0) continue;
+          make_rel_tf(poses + 3 * i, poses + 3 * j, &cs[2 * i], &cs[2 * j], host.data(), true);
+          if (std::memcmp(host.data(), &dev[c * 8], 8 * sizeof(float)) != 0)
+            return fail(HITL_ERR_SOLVER_FAILURE, "cand_tf_check: the device's transform of candidate (" + std::to_string(i) + ", " + std::to_string(j) +
+                                                 ") differs from the host's");
         }
-      }
-    } else
-    TRYC(d_tf.upload(cand_tf.data(), (size_t)cnt * slots * 8, st));
+    }
     TRYC(d_counts.resize((size_t)cnt * slots));
     TRYC(d_counts.zero(st));
     TRYC(d_table.resize((size_t)cnt * slots * s->max_scan));
@@ -275,7 +262,29 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
       if (hipMemsetAsync(s->d_kd_ovf.p, 0, sizeof(int), st) != hipSuccess) return fail(HITL_ERR_HIP, "find_correspondences: clearing the redo counter failed");
       launch_match_kd_tgt(st, mv, s->max_scan, slots, (int)window, d_tf.p, mp, s->kd_pts.p, s->kd_meta.p, d_table.p, d_counts.p,
                           s->d_kd_ovf.p, s->d_kd_ovf.p + 1, dev_switches().kd_redo_cap, s->kd_full_depth);
-    } else if (kd) launch_match_kd(st, mv, s->max_scan, slots, d_tgt.p, d_tf.p, mp, s->kd_pts.p, s->kd_meta.p, d_table.p, d_counts.p, i0, cnt);
+    } else if (kd) {
+      const uint32_t* grid = nullptr;
+      if (dev_switches().kd_grid) {                 // the occupancy grids of the scans: once per map, on the first search that takes this kernel
+        if (!s->kd_grid_built || s->kd_grid_thr != mp.thr) {       // (the cell size follows the threshold: a changed option rebuilds)
+          TRYC(s->kd_grid.resize((size_t)std::max(n, 1) * kd_grid_words()));
+          launch_kd_grid(st, mv, mp.thr, s->kd_pts.p, s->kd_grid.p);
+          s->kd_grid_built = true; s->kd_grid_thr = mp.thr;
+        }
+        grid = s->kd_grid.p;
+      }
+      unsigned long long* stats = nullptr;
+      if (timing) {                                 // HITL_TIMING: how many pairs each stage of the kernel let through
+        TRYC(s->d_kd_stats.resize(3)); TRYC(s->d_kd_stats.zero(st));
+        stats = s->d_kd_stats.p;
+      }
+      launch_match_kd(st, mv, s->max_scan, slots, d_tgt.p, d_tf.p, mp, s->kd_pts.p, s->kd_meta.p, grid, d_table.p, d_counts.p, i0, cnt, stats);
+      if (timing) {
+        unsigned long long h[3] = {0, 0, 0};
+        if (hipMemcpyAsync(h, stats, sizeof(h), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess)
+          std::fprintf(stderr, "find_correspondences:   k_match_kd, poses [%d, %d): %lld candidate pairs, %llu past the box test, %llu staged a tree, %llu walks\n",
+                       i0, i0 + cnt, (long long)cnt * slots, h[0], h[1], h[2]);
+      }
+    }
     else launch_match(st, mv, s->max_scan, slots, d_tgt.p, d_tf.p, mp, d_table.p, d_counts.p, i0, cnt);
     if (hipGetLastError() != hipSuccess) return fail(HITL_ERR_HIP, "find_correspondences: the match kernel could not be launched");
     return HITL_OK;
@@ -344,24 +353,36 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
   }
   // general path (windows wider than the band): tile by tile -- match, fetch the counts, keep pairs with more than
   // kMinInterPoseCorrespondence matches (:632-634) in pose order (:636-641), compact the tile's rows behind what is there
-  std::vector<int> counts, kept;
+  std::vector<int> kept;
+  TRYC(s->hp_cand_counts.resize((size_t)tile * slots));
+  const int* counts = s->hp_cand_counts.p;                    // page-locked: the tile's counts arrive by DMA
   std::vector<int64_t> tile_off;
   s->adj_window = 0; s->adj_slots = 0; s->h_adj.clear();
   s->h_pair_src.clear(); s->h_pair_tgt.clear(); s->h_match_off.assign(1, 0);
   int64_t written = 0;                                   // matches compacted so far
+  double t_sub[4] = {0, 0, 0, 0};                        // HITL_TIMING: candidates on the host / uploads + match kernel / the host's filter / k_compact
+  auto sub = [&](int k, std::chrono::steady_clock::time_point& t0) {
+    if (!timing) return;
+    const auto t = std::chrono::steady_clock::now();
+    t_sub[k] += std::chrono::duration<double, std::milli>(t - t0).count();
+    t0 = t;
+  };
   for (int i0 = 0; i0 < n; i0 += tile) {
     const int cnt = std::min(tile, n - i0);
+    auto t_s = std::chrono::steady_clock::now();
     fill_candidates(i0, i0 + cnt);
+    sub(0, t_s);
     TRYC(match_tile(i0, cnt));
-    counts.resize((size_t)cnt * slots);
-    if (hipMemcpyAsync(counts.data(), d_counts.p, counts.size() * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+    if (hipMemcpyAsync(s->hp_cand_counts.p, d_counts.p, (size_t)cnt * slots * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess)
       return fail(HITL_ERR_HIP, std::string("match kernel: ") + hipGetErrorString(hipGetLastError()));
+    sub(1, t_s);
     kept.clear(); tile_off.clear();
     for (int il = 0; il < cnt; ++il)
       for (int sl = 0; sl < slots; ++sl) {
         const size_t c = (size_t)il * slots + sl;
-        const int i = i0 + il, jt = cand_tgt[c];
+        if (counts[c] <= 0 && s->opt.min_inter_pose_correspondence >= 0) continue;      // (neither an information-matrix mark nor a pair)
+        const int i = i0 + il, jt = cand_target(i, sl);
         if (jt >= 0 && counts[c] > 0) s->h_adj.emplace_back(std::min(i, jt), std::max(i, jt));        // info_mat_ marks per accepted match (:624-625)
         const bool relevant = (i >= s->own_lo && i < s->own_hi) || (jt >= s->own_lo && jt < s->own_hi);   // halo-halo pairs belong to other ranks
         if (jt >= 0 && relevant && counts[c] > s->opt.min_inter_pose_correspondence) {
@@ -381,6 +402,7 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
       std::swap(bigger.p, s->matches.p); std::swap(bigger.cap, s->matches.cap); std::swap(bigger.n, s->matches.n);
     }
     s->matches.n = (size_t)need;
+    sub(2, t_s);
     if (!kept.empty()) {
       TRYC(d_kept.upload(kept, st));
       TRYC(s->match_off.upload(tile_off, st));           // this tile's write offsets (the full list goes up after the loop)
@@ -388,7 +410,10 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
       if (hipStreamSynchronize(st) != hipSuccess) return fail(HITL_ERR_HIP, "compact kernel failed");
     }
     written = s->h_match_off.back();
+    sub(3, t_s);
   }
+  if (timing) std::fprintf(stderr, "find_correspondences:   tiles of %d poses: candidates %.3f, uploads + match kernel %.3f, filter %.3f, compact %.3f ms\n",
+                           tile, t_sub[0], t_sub[1], t_sub[2], t_sub[3]);
   mark("match + filter + compact (tiles)");
   s->n_pairs = (int)s->h_pair_src.size();
   s->n_matches = s->h_match_off.back();
@@ -402,6 +427,7 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
   if (hipStreamSynchronize(st) != hipSuccess) { return fail(HITL_ERR_HIP, "find_correspondences: uploads failed"); }
   mark("uploads");
 #undef TRYC
+#undef TRYP
   rc = build_pair_structures(s);
   mark("pair structures");
   return rc;

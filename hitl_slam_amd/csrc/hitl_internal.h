@@ -47,6 +47,7 @@ struct DevSwitches {
   int kd_redo_cap = 1 << 18;       // "kd_redo_cap": entries of the redo list behind the fast attempt (shrunk to force the full-depth repeat)
   bool cand_tf_check = false;      // "cand_tf_check": the device's candidate transforms held to the host routine, bit for bit
   size_t cand_tile_bytes = (size_t)4 << 30;   // "cand_tile_bytes": candidate-table budget of the tiled search (shrunk to force several tiles)
+  bool kd_grid = true;             // "kd_grid" = 0: the source-major tree search walks every query (rounds 3-5) instead of skipping those an occupancy grid rules out
   bool pcg_fused = true;           // "pcg_fused" = 0: one launch group per CG iteration, the host looking every fourth (rounds 2-5) instead of one persistent launch per solve
   bool pcg_starve = false;         // "pcg_starve": the persistent PCG launch is started WITHOUT its top workgroup and with short waits (see cr_tail_starve)
   bool cr_tail_starve = false;     // "cr_tail_starve": k_cr_tail is launched WITHOUT its top workgroup and with a short wait: what a device too busy to hold
@@ -330,14 +331,19 @@ size_t kd_build_lds_bytes(int max_scan);
 size_t match_kd_lds_bytes(int max_scan);
 size_t match_kd_tgt_lds_bytes(int max_scan, int block, bool full_depth);
 void launch_kd_build(hipStream_t st, const MapView& map, int max_scan, float4* kd_pts, uint32_t* kd_meta);
+// occupancy grid per scan (kd_grid_words() words each): lets the source-major search skip the walks that cannot find anything (exactly: hitl_match.hip)
+size_t kd_grid_words();
+void launch_kd_grid(hipStream_t st, const MapView& map, float thr, const float4* kd_pts, uint32_t* grid);
 void launch_match_kd(hipStream_t st, const MapView& map, int max_scan, int slots, const int* cand_tgt, const float* cand_tf, MatchParams mp,
-                     const float4* kd_pts, const uint32_t* kd_meta, uint16_t* table, int* counts, int i0 = 0, int n_tile = -1);
+                     const float4* kd_pts, const uint32_t* kd_meta, const uint32_t* kd_grid /* or null */, uint16_t* table, int* counts, int i0 = 0, int n_tile = -1,
+                     unsigned long long* stats = nullptr /* HITL_TIMING: 3 counters (pairs past the box test, pairs that staged a tree, walks) */);
 // target-major form of the same search (one workgroup per target tree, one queue of all its queries): whole map, windowed
 // candidates, slots <= cap (the per-point cap cannot bind); workgroups of 256 threads (128 / 64 where a long scan's tree
 // would not leave room for the frame stacks), a wave refills from the queue when 16 of its lanes are idle
 bool match_kd_tgt_applies(int slots, int window, const MatchParams& mp);
 // candidate transforms of a windowed search over the whole map on the device; trig = (cos, sin) of theta_j - theta_i per candidate (host libm)
-void launch_cand_tf(hipStream_t st, int n, int slots, int window, const float* poses, const float* cs, const float* trig, float* cand_tf);
+void launch_cand_tf(hipStream_t st, int n, int slots, int window, int i0, int cnt, const float* poses, const float* cs, const float* trig /* from i0 */,
+                    float* cand_tf /* from i0 */, int* cand_tgt /* from i0; -1 = none */);
 void launch_match_kd_tgt(hipStream_t st, const MapView& map, int max_scan, int slots, int window, const float* cand_tf, MatchParams mp,
                          const float4* kd_pts, const uint32_t* kd_meta, uint16_t* table, int* counts,
                          int* redo_count /* walks that needed more frames than the launch provisioned ... */, int* redo_list /* ... (candidate, point) each,

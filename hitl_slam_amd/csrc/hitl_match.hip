@@ -440,19 +440,124 @@ __global__ __launch_bounds__(64) void k_match_kd_redo(MapView map, int max_scan,
   }
 }
 
+// ===========================================================================================
+// Occupancy grid of a scan (round 6): the all-pairs search asks a target's tree about EVERY point of EVERY other scan -- 360 M walks on a
+// 1 000-pose map, of which 0.6 % end in a match.  FindNearestPointNormal (kdtree.cpp:141-197) can only return a node that lies within
+// `threshold` of the query in the plane (kdtree.cpp:147: the gate in front of every score), so a query with NO scan point within the
+// threshold has no match whatever the walk does.  The grid answers that conservatively in one bit test: cells of at least 1.25 x the
+// threshold over the scan's bounding box (two cells of margin), a cell's bit set when the cell or one of its eight neighbours holds
+// a point.  Two points closer than the threshold lie in the same or in neighbouring cells (their cell coordinates differ by less than
+// 0.8 + rounding), so a query whose cell bit is clear -- or that falls outside the grid -- skips its walk: the result (no match, the
+// per-point counter untouched) is exactly the walk's.
+// Layout per pose: kKdGridWords words: [0] x0, [1] y0, [2] 1 / cell (floats), [3] nx, [4] ny, [8 ...] the bits, row-major.
+// nx = 0: the scan has no point that could match (empty, or NaN coordinates only); nx = -1: points, but no grid (all queries walk).
+// ===========================================================================================
+constexpr int kKdGridBits = 32768;
+constexpr int kKdGridWords = 8 + kKdGridBits / 32;
+size_t kd_grid_words() { return kKdGridWords; }
+
+__global__ __launch_bounds__(256) void k_kd_grid(MapView map, float thr, const float4* __restrict__ kd_pts, uint32_t* __restrict__ grid) {
+  __shared__ uint32_t bits[kKdGridBits / 32];
+  __shared__ float s_min[2][4], s_max[2][4];
+  __shared__ float s_hdr[3];
+  __shared__ int s_dim[2];
+  const int j = blockIdx.x, tid = threadIdx.x;
+  const int64_t oj = map.obs_off[j];
+  const int mj = (int)(map.obs_off[j + 1] - oj);
+  uint32_t* out = grid + (size_t)j * kKdGridWords;
+  for (int t = tid; t < kKdGridBits / 32; t += 256) bits[t] = 0u;
+  float mnx = 3.0e38f, mny = 3.0e38f, mxx = -3.0e38f, mxy = -3.0e38f;
+  for (int t = tid; t < mj; t += 256) {
+    const float4 g = kd_pts[oj + t];
+    if (g.x == g.x && g.y == g.y) { mnx = fminf(mnx, g.x); mny = fminf(mny, g.y); mxx = fmaxf(mxx, g.x); mxy = fmaxf(mxy, g.y); }
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    mnx = fminf(mnx, __shfl_xor(mnx, m, 64)); mny = fminf(mny, __shfl_xor(mny, m, 64));
+    mxx = fmaxf(mxx, __shfl_xor(mxx, m, 64)); mxy = fmaxf(mxy, __shfl_xor(mxy, m, 64));
+  }
+  if ((tid & 63) == 0) { s_min[0][tid >> 6] = mnx; s_min[1][tid >> 6] = mny; s_max[0][tid >> 6] = mxx; s_max[1][tid >> 6] = mxy; }
+  __syncthreads();
+  if (tid == 0) {
+    float ax = s_min[0][0], ay = s_min[1][0], bx = s_max[0][0], by = s_max[1][0];
+    for (int k = 1; k < 4; ++k) { ax = fminf(ax, s_min[0][k]); ay = fminf(ay, s_min[1][k]); bx = fmaxf(bx, s_max[0][k]); by = fmaxf(by, s_max[1][k]); }
+    int nx = 0, ny = 0;
+    float cell = 1.25f * thr, x0 = 0.0f, y0 = 0.0f, inv = 0.0f;
+    const bool any = mj > 0 && ax <= bx && ay <= by;              // a point without NaN coordinates exists
+    if (any && cell > 0.0f && bx - ax < 1.0e30f && by - ay < 1.0e30f) {
+      for (int it = 0; it < 64; ++it) {
+        inv = 1.0f / cell;
+        x0 = ax - 2.0f * cell; y0 = ay - 2.0f * cell;
+        const float fx = floorf((bx - x0) * inv), fy = floorf((by - y0) * inv);
+        if (fx < 30000.0f && fy < 30000.0f) {
+          nx = (int)fx + 3; ny = (int)fy + 3;
+          if ((long long)nx * ny <= kKdGridBits) break;
+        }
+        nx = ny = 0;
+        cell *= 1.5f;                                  // a long-range scan: coarser cells (still >= 1.25 thr: still conservative)
+      }
+    }
+    if (any && nx == 0) nx = ny = -1;                  // points, but no grid over them (infinite coordinates, a zero threshold): every query of this target walks
+    s_hdr[0] = x0; s_hdr[1] = y0; s_hdr[2] = inv; s_dim[0] = nx; s_dim[1] = ny;
+  }
+  __syncthreads();
+  const float x0 = s_hdr[0], y0 = s_hdr[1], inv = s_hdr[2];
+  const int nx = s_dim[0], ny = s_dim[1];
+  if (nx > 0) {
+    for (int t = tid; t < mj; t += 256) {
+      const float4 g = kd_pts[oj + t];
+      if (!(g.x == g.x && g.y == g.y)) continue;
+      const int ix = (int)floorf((g.x - x0) * inv), iy = (int)floorf((g.y - y0) * inv);
+      for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int cx = ix + dx, cy = iy + dy;
+          if (cx >= 0 && cx < nx && cy >= 0 && cy < ny) { const int b = cy * nx + cx; atomicOr(&bits[b >> 5], 1u << (b & 31)); }
+        }
+    }
+  }
+  __syncthreads();
+  if (tid < 8) {
+    uint32_t v = 0u;
+    if (tid == 0) v = __float_as_uint(x0); else if (tid == 1) v = __float_as_uint(y0); else if (tid == 2) v = __float_as_uint(inv);
+    else if (tid == 3) v = (uint32_t)nx; else if (tid == 4) v = (uint32_t)ny;
+    out[tid] = v;
+  }
+  for (int t = tid; t < kKdGridBits / 32; t += 256) out[8 + t] = bits[t];
+}
+
+void launch_kd_grid(hipStream_t st, const MapView& map, float thr, const float4* kd_pts, uint32_t* grid) {
+  if (map.n_poses <= 0) return;
+  hipLaunchKernelGGL(k_kd_grid, dim3(map.n_poses), dim3(256), 0, st, map, thr, kd_pts, grid);
+}
+
 // source-major form (any number of slots, tiles of source poses): targets in ascending order, the per-point counters of
-// JointOptimization.cpp:596-599 in LDS, one query per thread and round.
+// JointOptimization.cpp:596-599 in LDS.  Round 6: three stages per (source, target) pair, each cheaper than the next and each
+// deciding whether the next one runs at all --
+//   0. (uniform) the source scan's bounding box, carried into the target's frame, against the extent of the target's grid: poses
+//      that look at different places are done after ~30 scalar-ish instructions;
+//   1. every query against the grid's bits, read through the caches (a grid is 0.1-4 KB, the 1 000 grids of a map stay in L2):
+//      no LDS staging, ONE barrier (the workgroup-wide OR).  No bit set anywhere: the pair has no match, its count stays at the
+//      zero the driver cleared it to, and its row of the candidate table is never written (k_compact only reads rows of kept pairs);
+//   2. only now the target's tree comes into LDS (8.6 KB for 360 points: staging it for each of the 10^6 pairs of a 1 000-pose map
+//      WAS the search's time: 8.6 GB through L2), the surviving queries are compacted into a list so that the walks fill whole
+//      waves, and walk.
+// Without grids (test hook kd_grid = 0) stages 0 and 1 pass everything: rounds 3-5's search.
 __global__ __launch_bounds__(kMatchBlock) void k_match_kd(MapView map, int chunk, int max_scan, int slots, int depth,
                                                            const int* __restrict__ cand_tgt, const float* __restrict__ cand_tf, MatchParams mp,
                                                            const float4* __restrict__ kd_pts, const uint32_t* __restrict__ kd_meta,
-                                                           uint16_t* __restrict__ table, int* __restrict__ counts, int i0, int n_tile) {
+                                                           const uint32_t* __restrict__ kd_grid /* k_kd_grid, or null: every query walks */,
+                                                           uint16_t* __restrict__ table, int* __restrict__ counts, int i0, int n_tile,
+                                                           unsigned long long* __restrict__ stats /* HITL_TIMING: pairs past stage 0, past stage 1, walks; or null */) {
   extern __shared__ float4 s_tgt[];                 // [max_scan] target tree points (in-order layout)
   uint32_t* s_meta = (uint32_t*)(s_tgt + max_scan); // [max_scan] original index | split << 16
   int* s_cnt = (int*)(s_meta + max_scan);           // [max_scan] accepted matches per source point
   float* st_inc = (float*)(s_cnt + max_scan);       // [depth + 1][kMatchBlock] frame stack of kd_step below its register-resident top (+ a dump entry)
   uint32_t* st_seg = (uint32_t*)(st_inc + (size_t)(depth + 1) * kMatchBlock);
   uint32_t* st_oc = st_seg + (size_t)(depth + 1) * kMatchBlock;
-  __shared__ int s_pair_count;
+  unsigned long long n_st0 = 0, n_st1 = 0, n_walk = 0;
+  uint16_t* s_list = (uint16_t*)(st_oc + (size_t)(depth + 1) * kMatchBlock);      // [max_scan] the queries that walk
+  __shared__ int s_pair_count, s_npass;
+  __shared__ float s_box[4][kMatchBlock / 64];
   const int b = blockIdx.x;
   const int idx = b >> 3;
   const int il = (b & 7) * chunk + idx;
@@ -461,60 +566,128 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_kd(MapView map, int chunk
   const int64_t oi = map.obs_off[i];
   const int mi = (int)(map.obs_off[i + 1] - oi);
   for (int k = threadIdx.x; k < mi; k += kMatchBlock) s_cnt[k] = 0;
+  if (threadIdx.x == 0) { s_pair_count = 0; s_npass = 0; }
+  // stage 0's box of the source scan (its own frame; NaN points stay out: they match nothing)
+  float bx0 = 3.0e38f, by0 = 3.0e38f, bx1 = -3.0e38f, by1 = -3.0e38f;
+  for (int k = threadIdx.x; k < mi; k += kMatchBlock) {
+    const float4 a = map.obs[oi + k];
+    if (a.x == a.x && a.y == a.y) { bx0 = fminf(bx0, a.x); by0 = fminf(by0, a.y); bx1 = fmaxf(bx1, a.x); by1 = fmaxf(by1, a.y); }
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    bx0 = fminf(bx0, __shfl_xor(bx0, m, 64)); by0 = fminf(by0, __shfl_xor(by0, m, 64));
+    bx1 = fmaxf(bx1, __shfl_xor(bx1, m, 64)); by1 = fmaxf(by1, __shfl_xor(by1, m, 64));
+  }
+  if ((threadIdx.x & 63) == 0) { const int wv = threadIdx.x >> 6; s_box[0][wv] = bx0; s_box[1][wv] = by0; s_box[2][wv] = bx1; s_box[3][wv] = by1; }
+  __syncthreads();
+  bx0 = s_box[0][0]; by0 = s_box[1][0]; bx1 = s_box[2][0]; by1 = s_box[3][0];
+#pragma unroll
+  for (int wv = 1; wv < kMatchBlock / 64; ++wv) { bx0 = fminf(bx0, s_box[0][wv]); by0 = fminf(by0, s_box[1][wv]); bx1 = fmaxf(bx1, s_box[2][wv]); by1 = fmaxf(by1, s_box[3][wv]); }
+  const bool box_ok = bx0 <= bx1 && by0 <= by1 && bx1 - bx0 < 1.0e30f && by1 - by0 < 1.0e30f;      // (false: no usable box -- stage 0 passes everything)
   const float thr = mp.thr, thr2 = mp.thr * mp.thr;
   for (int slot = 0; slot < slots; ++slot) {
     const int j = cand_tgt[(size_t)il * slots + slot];
     if (j < 0) continue;                            // block-uniform
     const int64_t oj = map.obs_off[j];
     const int mj = (int)(map.obs_off[j + 1] - oj);
-    __syncthreads();
-    if (threadIdx.x == 0) s_pair_count = 0;
-    for (int t = threadIdx.x; t < mj; t += kMatchBlock) { s_tgt[t] = kd_pts[oj + t]; s_meta[t] = kd_meta[oj + t]; }
-    __syncthreads();
+    if (mj <= 0) continue;                          // an empty scan: nothing to find (count stays 0)
     const float* tf = cand_tf + ((size_t)il * slots + slot) * 8;
     const float m00 = tf[0], m01 = tf[1], m10 = tf[2], m11 = tf[3], tx = tf[4], ty = tf[5], cr = tf[6], sr = tf[7];
-    uint16_t* row = table + ((size_t)il * slots + slot) * max_scan;
-    int local = 0;
-    for (int k = threadIdx.x; k < mi; k += kMatchBlock) {
-      uint16_t res = 0xFFFFu;
-      if ((k % mp.skip) == 0 && s_cnt[k] < mp.cap && mj > 0) {
-        const float4 a = map.obs[oi + k];
-        const float ax = a.x, ay = a.y;
-        const float qx = (m00 * ax + m01 * ay) + tx;
-        const float qy = (m10 * ax + m11 * ay) + ty;
-        KdWalk w;
-        w.ovf = 0; w.t_inc = 0.0f; w.t_seg = 0u; w.t_oc = 0u;
-        kd_begin(w, qx, qy, mj);
-        while (w.mode != 2) kd_step(w, s_tgt, s_meta, thr, thr2, st_inc + threadIdx.x, st_seg + threadIdx.x, st_oc + threadIdx.x, kMatchBlock, depth);
-        if (w.ret_c >= 0 && w.ret_d < thr) {
-          const float anx = a.z, any = a.w;
-          const float nqx = cr * anx - sr * any, nqy = sr * anx + cr * any;
-          const float4 g = s_tgt[w.ret_c];
-          const float cosang = g.z * nqx + g.w * nqy;
-          if (cosang > mp.min_cos) { res = (uint16_t)(s_meta[w.ret_c] & 0xffffu); s_cnt[k] += 1; ++local; }
+    const uint32_t* gj = nullptr;
+    float gx0 = 0.0f, gy0 = 0.0f, ginv = 0.0f;
+    int gnx = 0, gny = 0;
+    if (kd_grid != nullptr) {
+      gj = kd_grid + (size_t)j * kKdGridWords;
+      gx0 = __uint_as_float(gj[0]); gy0 = __uint_as_float(gj[1]); ginv = __uint_as_float(gj[2]); gnx = (int)gj[3]; gny = (int)gj[4];
+      if (gnx == 0) continue;                       // the target has no point without NaN coordinates: no query can pass the gate (kdtree.cpp:147)
+      if (gnx < 0) gj = nullptr;                    // no grid could be laid over this target (k_kd_grid): all its queries walk
+      else if (box_ok) {
+        // stage 0: the four corners of the source's box in the target's frame; one cell of slack on every side (the grid itself keeps
+        // two cells = 2.5 thresholds around the target's points, a match needs less than one threshold: 1.5 thresholds minus this cell
+        // of slack remain for fp32 rounding of the corners against the queries -- metres against micrometres)
+        const float c0x = (m00 * bx0 + m01 * by0) + tx, c0y = (m10 * bx0 + m11 * by0) + ty;
+        const float c1x = (m00 * bx1 + m01 * by0) + tx, c1y = (m10 * bx1 + m11 * by0) + ty;
+        const float c2x = (m00 * bx0 + m01 * by1) + tx, c2y = (m10 * bx0 + m11 * by1) + ty;
+        const float c3x = (m00 * bx1 + m01 * by1) + tx, c3y = (m10 * bx1 + m11 * by1) + ty;
+        const float lo_x = (fminf(fminf(c0x, c1x), fminf(c2x, c3x)) - gx0) * ginv, hi_x = (fmaxf(fmaxf(c0x, c1x), fmaxf(c2x, c3x)) - gx0) * ginv;
+        const float lo_y = (fminf(fminf(c0y, c1y), fminf(c2y, c3y)) - gy0) * ginv, hi_y = (fmaxf(fmaxf(c0y, c1y), fmaxf(c2y, c3y)) - gy0) * ginv;
+        if (hi_x < -1.0f || lo_x > (float)gnx + 1.0f || hi_y < -1.0f || lo_y > (float)gny + 1.0f) continue;
+      }
+    }
+    // stage 1: which of this thread's queries may find anything (bit p: the query k = threadIdx.x + p * kMatchBlock; scans of up to 32 x 256 points -- the
+    // tree kernels' LDS budget ends at ~5 900)
+    uint32_t mask = 0u;
+    ++n_st0;
+    {
+      int p = 0;
+      for (int k = threadIdx.x; k < mi; k += kMatchBlock, ++p) {
+        bool ok = (k % mp.skip) == 0 && s_cnt[k] < mp.cap;
+        if (ok && gj != nullptr) {
+          const float4 a = map.obs[oi + k];
+          const float qx = (m00 * a.x + m01 * a.y) + tx, qy = (m10 * a.x + m11 * a.y) + ty;
+          const float fx = floorf((qx - gx0) * ginv), fy = floorf((qy - gy0) * ginv);
+          ok = fx >= 0.0f && fx < (float)gnx && fy >= 0.0f && fy < (float)gny;        // (NaN coordinates: false, as every gate of the walk would be)
+          if (ok) { const int bit = (int)fy * gnx + (int)fx; ok = (gj[8 + (bit >> 5)] >> (bit & 31)) & 1u; }
         }
+        mask |= ok ? (1u << p) : 0u;
+      }
+    }
+    if (!__syncthreads_or(mask != 0u)) continue;    // no query has a point of the target within the threshold: FindNearestPointNormal would return "none" 360 times
+    // stage 2: the tree into LDS, the surviving queries into a list, rows of the others closed
+    for (int t = threadIdx.x; t < mj; t += kMatchBlock) { s_tgt[t] = kd_pts[oj + t]; s_meta[t] = kd_meta[oj + t]; }
+    uint16_t* row = table + ((size_t)il * slots + slot) * max_scan;
+    {
+      int p = 0;
+      for (int k = threadIdx.x; k < mi; k += kMatchBlock, ++p) {
+        if ((mask >> p) & 1u) s_list[atomicAdd(&s_npass, 1)] = (uint16_t)k;      // (any order: every query's result depends on k alone)
+        else row[k] = 0xFFFFu;
+      }
+    }
+    __syncthreads();
+    const int np = s_npass;
+    ++n_st1; n_walk += (unsigned)np;
+    int local = 0;
+    for (int e = threadIdx.x; e < np; e += kMatchBlock) {
+      const int k = s_list[e];
+      uint16_t res = 0xFFFFu;
+      const float4 a = map.obs[oi + k];
+      const float ax = a.x, ay = a.y;
+      const float qx = (m00 * ax + m01 * ay) + tx;
+      const float qy = (m10 * ax + m11 * ay) + ty;
+      KdWalk w;
+      w.ovf = 0; w.t_inc = 0.0f; w.t_seg = 0u; w.t_oc = 0u;
+      kd_begin(w, qx, qy, mj);
+      while (w.mode != 2) kd_step(w, s_tgt, s_meta, thr, thr2, st_inc + threadIdx.x, st_seg + threadIdx.x, st_oc + threadIdx.x, kMatchBlock, depth);
+      if (w.ret_c >= 0 && w.ret_d < thr) {
+        const float anx = a.z, any = a.w;
+        const float nqx = cr * anx - sr * any, nqy = sr * anx + cr * any;
+        const float4 g = s_tgt[w.ret_c];
+        const float cosang = g.z * nqx + g.w * nqy;
+        if (cosang > mp.min_cos) { res = (uint16_t)(s_meta[w.ret_c] & 0xffffu); s_cnt[k] += 1; ++local; }
       }
       row[k] = res;
     }
     if (local) atomicAdd(&s_pair_count, local);
     __syncthreads();
-    if (threadIdx.x == 0) counts[(size_t)il * slots + slot] = s_pair_count;
+    if (threadIdx.x == 0) { counts[(size_t)il * slots + slot] = s_pair_count; s_pair_count = 0; s_npass = 0; }      // (both untouched by the others until the next pair's OR barrier)
   }
+  if (stats != nullptr && threadIdx.x == 0) { atomicAdd(stats, n_st0); atomicAdd(stats + 1, n_st1); atomicAdd(stats + 2, n_walk); }
 }
 
 
 size_t match_kd_lds_bytes(int max_scan) {
-  return (size_t)std::max(max_scan, 1) * (sizeof(float4) + 2 * sizeof(int)) + (size_t)(kd_depth(max_scan) + 1) * kMatchBlock * 12;
+  return (size_t)std::max(max_scan, 1) * (sizeof(float4) + 2 * sizeof(int)) + (size_t)(kd_depth(max_scan) + 1) * kMatchBlock * 12 + (((size_t)std::max(max_scan, 1) * 2 + 15) & ~(size_t)15);
 }
 
 void launch_match_kd(hipStream_t st, const MapView& map, int max_scan, int slots, const int* cand_tgt, const float* cand_tf, MatchParams mp,
-                     const float4* kd_pts, const uint32_t* kd_meta, uint16_t* table, int* counts, int i0, int n_tile) {
+                     const float4* kd_pts, const uint32_t* kd_meta, const uint32_t* kd_grid, uint16_t* table, int* counts, int i0, int n_tile,
+                     unsigned long long* stats) {
   if (n_tile < 0) n_tile = map.n_poses - i0;
   const int chunk = (n_tile + 7) / 8;
   const size_t lds = match_kd_lds_bytes(max_scan);
   if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_match_kd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k_match_kd, dim3(8 * chunk), dim3(kMatchBlock), lds, st, map, chunk, max_scan, slots, kd_depth(max_scan), cand_tgt, cand_tf,
-                     mp, kd_pts, kd_meta, table, counts, i0, n_tile);
+                     mp, kd_pts, kd_meta, kd_grid, table, counts, i0, n_tile, stats);
 }
 
 // Candidate transforms of a windowed search on the device (round 4): RelativePoseTransform (JointOptimization.cpp:296-305) in
@@ -523,11 +696,11 @@ void launch_match_kd(hipStream_t st, const MapView& map, int max_scan, int slots
 // (cos, sin) of the angle difference, which stay with the host's libm (the only part whose bits a GPU cannot be trusted to
 // reproduce).  One thread per candidate (i, slot): j = slot-th pose of [i - window, i + window] without i; slots past the end
 // of the list get zeros.  The test hook cand_tf_check holds every launch to the host routine, bit for bit.
-__global__ void k_cand_tf(int n, int slots, int window, const float* __restrict__ poses, const float* __restrict__ cs,
-                          const float* __restrict__ trig, float* __restrict__ cand_tf) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= n * slots) return;
-  const int i = c / slots, slot = c % slots;
+__global__ void k_cand_tf(int n, int slots, int window, int i0, int cnt, const float* __restrict__ poses, const float* __restrict__ cs,
+                          const float* __restrict__ trig, float* __restrict__ cand_tf, int* __restrict__ cand_tgt) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= (int64_t)cnt * slots) return;
+  const int i = i0 + (int)(c / slots), slot = (int)(c % slots);
   const int j0 = max(0, i - window), j1 = min(n - 1, i + window);
   int j = j0 + slot;
   if (j >= i) ++j;
@@ -535,8 +708,10 @@ __global__ void k_cand_tf(int n, int slots, int window, const float* __restrict_
   if (j > j1) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) t[k] = 0.0f;
+    cand_tgt[c] = -1;
     return;
   }
+  cand_tgt[c] = j;
   const float* pi = poses + 3 * (size_t)i;
   const float* pj = poses + 3 * (size_t)j;
   const float ci = cs[2 * i], si = cs[2 * i + 1], cj = cs[2 * j], sj = cs[2 * j + 1];
@@ -552,10 +727,11 @@ __global__ void k_cand_tf(int n, int slots, int window, const float* __restrict_
   t[6] = trig[2 * (size_t)c]; t[7] = trig[2 * (size_t)c + 1];
 }
 
-void launch_cand_tf(hipStream_t st, int n, int slots, int window, const float* poses, const float* cs, const float* trig, float* cand_tf) {
-  const int tot = n * slots;
+void launch_cand_tf(hipStream_t st, int n, int slots, int window, int i0, int cnt, const float* poses, const float* cs, const float* trig, float* cand_tf,
+                    int* cand_tgt) {
+  const int64_t tot = (int64_t)cnt * slots;
   if (tot <= 0) return;
-  hipLaunchKernelGGL(k_cand_tf, dim3((tot + 255) / 256), dim3(256), 0, st, n, slots, window, poses, cs, trig, cand_tf);
+  hipLaunchKernelGGL(k_cand_tf, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, n, slots, window, i0, cnt, poses, cs, trig, cand_tf, cand_tgt);
 }
 
 // target-major search over the whole map (a windowed search inside the band whose slots cannot reach the per-point cap)

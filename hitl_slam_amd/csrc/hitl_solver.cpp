@@ -593,6 +593,7 @@ extern "C" int hitl_test_set_switch(const char* name, long long value) {
   else if (k == "cr_tail") d.cr_tail = value != 0;
   else if (k == "cr_tail_starve") d.cr_tail_starve = value != 0;
   else if (k == "pcg_fused") d.pcg_fused = value != 0;
+  else if (k == "kd_grid") d.kd_grid = value != 0;
   else if (k == "pcg_starve") d.pcg_starve = value != 0;
   else if (k == "cu_count") d.cu_count = (int)std::max(0ll, std::min(4096ll, value));
   else if (k == "stf_addr64") d.stf_addr64 = value != 0;
@@ -934,7 +935,7 @@ int hitl_solver_set_map(hitl_solver* s, int64_t n_poses, const int64_t* obs_offs
   if (cov9) TRY(s->cov9.upload(cov9, (size_t)n_poses * 9, st));   // carried like covariances_; no live factor reads it
   HIP_TRY(hipStreamSynchronize(st));
   // a new map invalidates correspondences, human rows and the KD-trees
-  s->kd_built = false; s->kd_full_depth = false;
+  s->kd_built = false; s->kd_grid_built = false; s->kd_full_depth = false;
   s->adj_window = 0; s->adj_slots = 0; s->h_adj.clear();      // info_mat: no search on this map yet
   s->n_pairs = 0; s->n_matches = 0; s->pose_pair_off.n = 0;
   s->h_hc.clear();

@@ -106,8 +106,9 @@ struct hitl_solver {
   // derived
   int band_pairs_Wb = 1;                       // Wb implied by the pair set
   // scratch of the correspondence search, kept between calls
-  std::vector<int> h_cand_tgt;
-  std::vector<float> h_cand_tf, h_cand_cs;
+  std::vector<float> h_cand_cs;
+  PinnedArray<float> hp_cand_trig;             // (cos, sin) of every candidate's angle difference: the upload of a search tile
+  PinnedArray<int> hp_cand_counts;             // matches per candidate of a tile of the general (wider than the band) search
   DevArray<int> d_cand_tgt, d_cand_counts, d_cand_kept;
   DevArray<int> d_pose_maxd;                   // device-built pair tables (windowed search inside the band): per-pose scratch
   DevArray<int64_t> d_pose_match_off, d_pair_totals;
@@ -115,7 +116,6 @@ struct hitl_solver {
   bool obadj_nonzero = true;                   // the off-band adjacency on the device is not known to be the empty one
   DevArray<float> d_cand_tf;
   DevArray<float> d_cand_trig, d_cand_poses, d_cand_cs;      // device-side candidate transforms: (cos, sin) per candidate, poses, (cos, sin) per pose
-  std::vector<float> h_cand_trig;
   DevArray<uint16_t> d_cand_table;
   DevArray<float4> kd_pts;                     // opt-in (kd_tree_search): every scan in KD in-order layout
   DevArray<uint32_t> kd_meta;                  //   original index | split plane << 16
@@ -142,6 +142,10 @@ struct hitl_solver {
   bool kd_full_depth = false;                  //   a walk on this map once needed more frames than the fast attempt provisions: full-depth stacks from then on
   DevArray<int> d_kd_ovf;                      //   k_match_kd_tgt: [0] = walks that overflowed the fast frame stack, [1 ..] = their (candidate, point) list
   bool kd_built = false;                       //   trees belong to the resident map
+  DevArray<uint32_t> kd_grid;                  //   occupancy grid of every scan (source-major search only: built on its first use per map)
+  bool kd_grid_built = false;
+  DevArray<unsigned long long> d_kd_stats;     //   HITL_TIMING: stage counters of k_match_kd
+  float kd_grid_thr = 0.0f;                    //   the point-match threshold the grids were laid out for
   DevArray<float> world_xy;                    // hitl_solver_transform_scans*: world x of every observation, then world y
   DevArray<float> pose_rt;                     // solver_pose_rt: (cos, sin, x, y) per resident pose ...
   std::vector<float> pose_rt_of;               // ... of these poses (n * 3)

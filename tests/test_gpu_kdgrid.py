@@ -1,0 +1,109 @@
+"""The occupancy grids in front of the source-major tree search (round 6, hitl_slam_amd/csrc/hitl_match.hip: k_kd_grid + the bit test
+in k_match_kd): a query with no scan point of the target within the point-match threshold skips its KD walk.  The reference's walk
+(kdtree.cpp:141-197) only ever returns a node inside that gate (:147), so the skip may not change ONE correspondence: held here to
+the walk-everything kernel of rounds 3-5 (test hook kd_grid = 0) bit for bit -- pairs, match offsets, both index lists -- on maps
+that revisit places, at BASELINE configs[2]'s size, over thresholds from 2 cm to 5 m (cells from the finest to coarser than the
+room), on scans far from their pose's origin (cells coarsened until the grid fits its 32 768 bits), on scans with NaN points and
+scans with no points, and to the oracle's walk."""
+import numpy as np
+import pytest
+
+import figure8
+from conftest import Problem
+
+pytestmark = pytest.mark.gpu
+
+
+def _search(H, switches, grid, opt, load, init, window=0):
+    switches(kd_grid=grid)
+    s = H.Solver(opt)
+    load(s)
+    s.find_correspondences(init, window)
+    c = s.get_correspondences()
+    s.close()
+    return c
+
+
+def _same(a, b):
+    assert len(a) == len(b)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
+def _fig8_loader(d):
+    def load(s):
+        s.set_map(d["off"], d["px"], d["py"], d["nx"], d["ny"], d["cov"])
+    return load
+
+
+@pytest.mark.parametrize("thr", [0.02, 0.15, 0.6, 5.0])
+def test_grid_skips_change_no_correspondence_figure8(switches, thr):
+    import hitl_slam_amd as H
+    d = figure8.make(300, 180, seed=11, laps=3)
+    opt = H.default_options()
+    opt.point_match_threshold = thr
+    a = _search(H, switches, 1, opt, _fig8_loader(d), d["init"])
+    b = _search(H, switches, 0, opt, _fig8_loader(d), d["init"])
+    _same(a, b)
+    print("figure-8 300 x 180 all pairs, threshold %.2f: %d pairs, %d matches" % (thr, len(a[0]), len(a[3])))
+    assert len(a[3]) > 0
+
+
+def test_grid_skips_at_configs2_size_and_against_the_oracle(switches):
+    """1 000 x 360 (bench.py --workload c3's map): grid against no grid; 400 x 120: against the oracle's walk."""
+    import hitl_slam_amd as H
+    from oracle import hitl_oracle as O
+    d = figure8.make(1000, 360, seed=7, laps=4)
+    opt = H.default_options()
+    a = _search(H, switches, 1, opt, _fig8_loader(d), d["init"])
+    b = _search(H, switches, 0, opt, _fig8_loader(d), d["init"])
+    _same(a, b)
+    assert len(a[3]) > 1000000
+    d = figure8.make(400, 120, seed=7, laps=2)
+    a = _search(H, switches, 1, opt, _fig8_loader(d), d["init"])
+    o = O.OracleSolver()
+    _fig8_loader(d)(o)
+    o.find_correspondences(d["init"], 0, 1)
+    _same(a, o.get_correspondences())
+    o.close()
+
+
+def test_grid_far_scans_nan_points_and_empty_scans(switches):
+    """Scans whose points lie hundreds of metres from the pose (a grid of 0.19 m cells would need millions of bits: coarser cells),
+    a few NaN points, two poses without any point: the same sets with and without the grid."""
+    import hitl_slam_amd as H
+    prob = Problem(96, 64, ppf=96, groups=0)
+    rng = np.random.default_rng(5)
+    off = np.asarray(prob.off).copy()
+    px, py = np.asarray(prob.px, np.float32).copy(), np.asarray(prob.py, np.float32).copy()
+    nx, ny = np.asarray(prob.nx, np.float32).copy(), np.asarray(prob.ny, np.float32).copy()
+    # every fourth scan: one outlier return 300-900 m away (a window, a mirror): the scan's bounding box explodes
+    for i in range(0, prob.n, 4):
+        k = off[i] + int(rng.integers(0, off[i + 1] - off[i]))
+        px[k] = np.float32(rng.uniform(300, 900)); py[k] = np.float32(-rng.uniform(300, 900))
+    # NaN returns
+    for k in rng.integers(0, len(px), 40):
+        px[k] = np.float32(np.nan)
+    # an infinite return in two scans (no grid can be laid over those: all their queries walk)
+    for i in (21, 70):
+        px[off[i] + 3] = np.float32(np.inf)
+    # two scans without points
+    keep = np.ones(len(px), bool)
+    cnt = np.diff(off).copy()
+    for i in (10, 57):
+        keep[off[i]:off[i + 1]] = False
+        cnt[i] = 0
+    off2 = np.concatenate([[0], np.cumsum(cnt)]).astype(off.dtype)
+    px, py, nx, ny = px[keep], py[keep], nx[keep], ny[keep]
+
+    def load(s):
+        s.set_map(off2, px, py, nx, ny, prob.cov)
+    opt = H.default_options()
+    a = _search(H, switches, 1, opt, load, prob.init)
+    b = _search(H, switches, 0, opt, load, prob.init)
+    _same(a, b)
+    assert len(a[3]) > 0
+    # the banded (target-major) search does not use the grids: untouched by the switch
+    a = _search(H, switches, 1, opt, load, prob.init, window=3)
+    b = _search(H, switches, 0, opt, load, prob.init, window=3)
+    _same(a, b)
