@@ -554,7 +554,7 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_kd(MapView map, int chunk
   float* st_inc = (float*)(s_cnt + max_scan);       // [depth + 1][kMatchBlock] frame stack of kd_step below its register-resident top (+ a dump entry)
   uint32_t* st_seg = (uint32_t*)(st_inc + (size_t)(depth + 1) * kMatchBlock);
   uint32_t* st_oc = st_seg + (size_t)(depth + 1) * kMatchBlock;
-  unsigned long long n_st0 = 0, n_st1 = 0, n_walk = 0;
+  unsigned long long n_st0 = 0, n_st1 = 0, n_walk = 0, t_st1 = 0, t_st2 = 0;       // (t_*: ticks of the 100 MHz clock)
   uint16_t* s_list = (uint16_t*)(st_oc + (size_t)(depth + 1) * kMatchBlock);      // [max_scan] the queries that walk
   __shared__ int s_pair_count, s_npass;
   __shared__ float s_box[4][kMatchBlock / 64];
@@ -618,6 +618,7 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_kd(MapView map, int chunk
     // tree kernels' LDS budget ends at ~5 900)
     uint32_t mask = 0u;
     ++n_st0;
+    const unsigned long long t_a = stats != nullptr ? wall_clock64() : 0ull;
     {
       int p = 0;
       for (int k = threadIdx.x; k < mi; k += kMatchBlock, ++p) {
@@ -632,7 +633,10 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_kd(MapView map, int chunk
         mask |= ok ? (1u << p) : 0u;
       }
     }
-    if (!__syncthreads_or(mask != 0u)) continue;    // no query has a point of the target within the threshold: FindNearestPointNormal would return "none" 360 times
+    const bool any_q = __syncthreads_or(mask != 0u);
+    const unsigned long long t_b = stats != nullptr ? wall_clock64() : 0ull;
+    t_st1 += t_b - t_a;
+    if (!any_q) continue;                           // no query has a point of the target within the threshold: FindNearestPointNormal would return "none" 360 times
     // stage 2: the tree into LDS, the surviving queries into a list, rows of the others closed
     for (int t = threadIdx.x; t < mj; t += kMatchBlock) { s_tgt[t] = kd_pts[oj + t]; s_meta[t] = kd_meta[oj + t]; }
     uint16_t* row = table + ((size_t)il * slots + slot) * max_scan;
@@ -670,8 +674,12 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_kd(MapView map, int chunk
     if (local) atomicAdd(&s_pair_count, local);
     __syncthreads();
     if (threadIdx.x == 0) { counts[(size_t)il * slots + slot] = s_pair_count; s_pair_count = 0; s_npass = 0; }      // (both untouched by the others until the next pair's OR barrier)
+    if (stats != nullptr) t_st2 += wall_clock64() - t_b;
   }
-  if (stats != nullptr && threadIdx.x == 0) { atomicAdd(stats, n_st0); atomicAdd(stats + 1, n_st1); atomicAdd(stats + 2, n_walk); }
+  if (stats != nullptr && threadIdx.x == 0) {
+    atomicAdd(stats, n_st0); atomicAdd(stats + 1, n_st1); atomicAdd(stats + 2, n_walk);
+    atomicAdd(stats + 3, t_st1); atomicAdd(stats + 4, t_st2); atomicMax(stats + 5, t_st1 + t_st2);
+  }
 }
 
 
