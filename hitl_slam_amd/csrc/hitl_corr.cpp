@@ -274,7 +274,7 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
       }
       unsigned long long* stats = nullptr;
       if (timing) {                                 // HITL_TIMING: how many pairs each stage of the kernel let through
-        TRYC(s->d_kd_stats.resize(6)); TRYC(s->d_kd_stats.zero(st));
+        TRYC(s->d_kd_stats.resize(6 + (size_t)cnt)); TRYC(s->d_kd_stats.zero(st));
         stats = s->d_kd_stats.p;
       }
       launch_match_kd(st, mv, s->max_scan, slots, d_tgt.p, d_tf.p, mp, s->kd_pts.p, s->kd_meta.p, grid, d_table.p, d_counts.p, i0, cnt, stats);
@@ -284,6 +284,11 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
           std::fprintf(stderr, "find_correspondences:   k_match_kd, poses [%d, %d): %lld candidate pairs, %llu past the box test, %llu staged a tree, %llu walks; "
                        "per workgroup: bit tests %.3f ms, staging + walks %.3f ms (the slowest workgroup: %.3f ms)\n",
                        i0, i0 + cnt, (long long)cnt * slots, h[0], h[1], h[2], 1e-5 * (double)h[3] / std::max(cnt, 1), 1e-5 * (double)h[4] / std::max(cnt, 1), 1e-5 * (double)h[5]);
+        if (std::getenv("HITL_KD_PER_POSE") != nullptr) {       // development: the time of every source pose's workgroup (k_match_kd_spec only)
+          std::vector<unsigned long long> per((size_t)cnt);
+          if (hipMemcpy(per.data(), stats + 6, per.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess)
+            for (int q = 0; q < cnt; ++q) std::fprintf(stderr, "kd_per_pose %d %.3f\n", i0 + q, 1e-5 * (double)per[(size_t)q]);
+        }
       }
     }
     else launch_match(st, mv, s->max_scan, slots, d_tgt.p, d_tf.p, mp, d_table.p, d_counts.p, i0, cnt);

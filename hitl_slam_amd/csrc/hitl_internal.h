@@ -47,6 +47,8 @@ struct DevSwitches {
   int kd_redo_cap = 1 << 18;       // "kd_redo_cap": entries of the redo list behind the fast attempt (shrunk to force the full-depth repeat)
   bool cand_tf_check = false;      // "cand_tf_check": the device's candidate transforms held to the host routine, bit for bit
   size_t cand_tile_bytes = (size_t)4 << 30;   // "cand_tile_bytes": candidate-table budget of the tiled search (shrunk to force several tiles)
+  bool stf_lds_targets = false;    // "stf_lds_targets": k_linearize_stf_r reads its targets from LDS (the source scan's fp32 copy) -- WRONG results, a timing experiment
+  int kd_spec = 4;                 // "kd_spec": targets in flight per workgroup of the source-major tree search (4, 2; 0 or 1: one at a time, rounds 3-5's order)
   bool kd_grid = true;             // "kd_grid" = 0: the source-major tree search walks every query (rounds 3-5) instead of skipping those an occupancy grid rules out
   bool pcg_fused = true;           // "pcg_fused" = 0: one launch group per CG iteration, the host looking every fourth (rounds 2-5) instead of one persistent launch per solve
   bool pcg_starve = false;         // "pcg_starve": the persistent PCG launch is started WITHOUT its top workgroup and with short waits (see cr_tail_starve)

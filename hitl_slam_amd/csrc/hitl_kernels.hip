@@ -332,7 +332,10 @@ void launch_build_stf_pose_recs(hipStream_t st, const MapView& map, const PairVi
 }
 size_t stf_pose_rec_bytes() { return sizeof(StfPoseRec); }
 
-template <int MINB>
+// ABL = 1 (test hook stf_lds_targets; WRONG NUMBERS ON PURPOSE, a timing experiment: profiles/r06_stf_counters.md): every target point is
+// read from an fp32 copy of the SOURCE scan in LDS (one ds_read_b128 at the target's index) instead of the 16-byte L1 gather -- what a
+// kernel with its target scans resident in LDS would issue per match, without any of the staging such a kernel has to pay for.
+template <int MINB, int ABL = 0>
 __global__ __launch_bounds__(kStfBlock, MINB) void k_linearize_stf_r(MapView map, PairView pr, const StfPoseRec* __restrict__ recs, int chunk,
                                                                      const double* __restrict__ x, const double2* __restrict__ cs, double kf,
                                                                      double* __restrict__ pairRJ, StfLm lmsel) {
@@ -354,6 +357,7 @@ __global__ __launch_bounds__(kStfBlock, MINB) void k_linearize_stf_r(MapView map
   const int mi = rec->mi;
   const int64_t oi = rec->src_off;
   double2* s_scanN = s_scan8 + mi;
+  float4* s_scanF = reinterpret_cast<float4*>(s_scanN + mi);           // ABL only
   const float4* __restrict__ src_g = map.obs + oi;
   const int lane = threadIdx.x & 63;
   const int sub = threadIdx.x / kStfSub;        // pair slot of this half-wave within the workgroup
@@ -374,13 +378,15 @@ __global__ __launch_bounds__(kStfBlock, MINB) void k_linearize_stf_r(MapView map
     const float4 o = src_g[k];
     s_scan8[k] = make_double2((double)o.x, (double)o.y);
     s_scanN[k] = make_double2((double)o.z, (double)o.w);
+    if (ABL) s_scanF[k] = o;
   }
   const double xi = uniform_f64(x[3 * i]), yi = uniform_f64(x[3 * i + 1]);
   const double2 cs0 = cs[i];
   const double c0 = uniform_f64(cs0.x), s0 = uniform_f64(cs0.y);
   bool staged = false;
   for (int pb = p_begin;;) {                            // workgroup-uniform trip count
-#define HITL_RTGT(u) (*reinterpret_cast<const float4*>(obs_b + (tgt_b + (__builtin_amdgcn_ubfe((u), 16, 16) << 4))))
+#define HITL_RTGT(u) (ABL ? s_scanF[min((int)__builtin_amdgcn_ubfe((u), 16, 16), mi - 1)] \
+                          : *reinterpret_cast<const float4*>(obs_b + (tgt_b + (__builtin_amdgcn_ubfe((u), 16, 16) << 4))))
     const double xj = x[3 * j], yj = x[3 * j + 1];
     const double2 cs1 = cs[j];
     uint32_t mo = (m_begin32 + (uint32_t)hl) << 2;
@@ -574,6 +580,11 @@ void launch_linearize_stf(hipStream_t st, const MapView& map, const PairView& pr
   const double kf = (double)corr / (double)std_dev;                       // k = corr / sigma, divided here once
   const dim3 grid(8 * chunk), block(kStfBlock);
   const int src = ((size_t)cap * 32 <= 64 * 1024) ? 2 : ((size_t)cap * 16 <= 64 * 1024) ? 1 : 0;
+  if (src == 2 && off32 && pose_recs != nullptr && dev_switches().stf_lds_targets && (size_t)cap * 48 <= 64 * 1024) {      // timing experiment (see the kernel)
+    hipLaunchKernelGGL((k_linearize_stf_r<7, 1>), grid, block, (size_t)cap * 48, st, map, pr, reinterpret_cast<const StfPoseRec*>(pose_recs), chunk, x, cs, kf,
+                       pairRJ, lmsel);
+    return;
+  }
   if (src == 2 && off32 && pose_recs != nullptr) {      // the shipped kernel: half-waves behind a per-pose descriptor record
     hipLaunchKernelGGL((k_linearize_stf_r<7>), grid, block, (size_t)cap * 32, st, map, pr, reinterpret_cast<const StfPoseRec*>(pose_recs), chunk, x, cs, kf,
                        pairRJ, lmsel);

@@ -683,6 +683,220 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_kd(MapView map, int chunk
 }
 
 
+// The same search, G targets at a time (round 6).  k_match_kd's time on a map that revisits places is the time of its SLOWEST
+// workgroup: a source pose whose points keep finding neighbours but rarely a match (the per-point cap of JointOptimization.cpp:596-599
+// never closes them) stages a tree and walks for every one of its 999 targets, ~13 us of dependent latency each, one wave busy.
+// The cap is the only thing that orders a source point's targets -- whether point k is ASKED about target j depends on its accepted
+// matches with earlier targets; what the walk RETURNS does not.  So: the next G targets are examined together against the counters
+// as they stand (a superset of the queries the sequential order would make: counters only grow), wave g stages target g's tree and
+// walks its list, and then every point's results are committed in ascending target order by the thread that owns the point --
+// accepted while the counter is below the cap, dropped (0xFFFF, not counted) after.  Identical rows, counts and counters; G trees
+// and G walks in flight per workgroup, and the G bit tests of stage 1 overlap their memory latency.
+template <int G>
+__global__ __launch_bounds__(64 * G) void k_match_kd_spec(MapView map, int chunk, int max_scan, int slots, int depth,
+                                                           const int* __restrict__ cand_tgt, const float* __restrict__ cand_tf, MatchParams mp,
+                                                           const float4* __restrict__ kd_pts, const uint32_t* __restrict__ kd_meta,
+                                                           const uint32_t* __restrict__ kd_grid, uint16_t* __restrict__ table, int* __restrict__ counts,
+                                                           int i0, int n_tile, unsigned long long* __restrict__ stats) {
+  constexpr int BLOCK = 64 * G;
+  extern __shared__ float4 s_tgt[];                               // [G][max_scan] target trees (in-order layout)
+  uint32_t* s_meta = (uint32_t*)(s_tgt + (size_t)G * max_scan);   // [G][max_scan]
+  int* s_cnt = (int*)(s_meta + (size_t)G * max_scan);             // [max_scan] accepted matches per source point
+  float* st_inc = (float*)(s_cnt + max_scan);                     // [depth + 1][BLOCK] frame stacks (see k_match_kd)
+  uint32_t* st_seg = (uint32_t*)(st_inc + (size_t)(depth + 1) * BLOCK);
+  uint32_t* st_oc = st_seg + (size_t)(depth + 1) * BLOCK;
+  uint16_t* s_list = (uint16_t*)(st_oc + (size_t)(depth + 1) * BLOCK);      // [G][max_scan] the queries that walk
+  uint16_t* s_res = s_list + (size_t)G * max_scan;                          // [G][max_scan] what the walks returned, by source point
+  __shared__ int s_np[2][G], s_pc[2][G];
+  __shared__ unsigned s_any[2];
+  __shared__ float s_box[4][G];
+  unsigned long long n_st0 = 0, n_st1 = 0, n_walk = 0, t_st1 = 0, t_st2 = 0;
+  const int b = blockIdx.x;
+  const int idx = b >> 3;
+  const int il = (b & 7) * chunk + idx;
+  if (idx >= chunk || il >= n_tile) return;
+  const int i = i0 + il;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t oi = map.obs_off[i];
+  const int mi = (int)(map.obs_off[i + 1] - oi);
+  for (int k = tid; k < mi; k += BLOCK) s_cnt[k] = 0;
+  if (tid < G) { s_np[0][tid] = 0; s_np[1][tid] = 0; s_pc[0][tid] = 0; s_pc[1][tid] = 0; }
+  if (tid < 2) s_any[tid] = 0u;
+  float bx0 = 3.0e38f, by0 = 3.0e38f, bx1 = -3.0e38f, by1 = -3.0e38f;
+  for (int k = tid; k < mi; k += BLOCK) {
+    const float4 a = map.obs[oi + k];
+    if (a.x == a.x && a.y == a.y) { bx0 = fminf(bx0, a.x); by0 = fminf(by0, a.y); bx1 = fmaxf(bx1, a.x); by1 = fmaxf(by1, a.y); }
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    bx0 = fminf(bx0, __shfl_xor(bx0, m, 64)); by0 = fminf(by0, __shfl_xor(by0, m, 64));
+    bx1 = fmaxf(bx1, __shfl_xor(bx1, m, 64)); by1 = fmaxf(by1, __shfl_xor(by1, m, 64));
+  }
+  if (lane == 0) { s_box[0][wave] = bx0; s_box[1][wave] = by0; s_box[2][wave] = bx1; s_box[3][wave] = by1; }
+  __syncthreads();
+  bx0 = s_box[0][0]; by0 = s_box[1][0]; bx1 = s_box[2][0]; by1 = s_box[3][0];
+#pragma unroll
+  for (int wv = 1; wv < G; ++wv) { bx0 = fminf(bx0, s_box[0][wv]); by0 = fminf(by0, s_box[1][wv]); bx1 = fmaxf(bx1, s_box[2][wv]); by1 = fmaxf(by1, s_box[3][wv]); }
+  const bool box_ok = bx0 <= bx1 && by0 <= by1 && bx1 - bx0 < 1.0e30f && by1 - by0 < 1.0e30f;
+  const float thr = mp.thr, thr2 = mp.thr * mp.thr;
+  int par = 0;
+  for (int slot0 = 0; slot0 < slots; slot0 += G) {
+    const unsigned long long t_a = stats != nullptr ? wall_clock64() : 0ull;
+    // ---- per target of the group (all uniform): candidate, transform, grid header, stage 0 ----
+    int tj[G], tmj[G], gnx[G], gny[G];
+    int64_t toj[G];
+    float tf[G][8], gx0[G], gy0[G], ginv[G];
+    const uint32_t* gptr[G];
+    bool live[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int slot = slot0 + g;
+      tj[g] = slot < slots ? cand_tgt[(size_t)il * slots + slot] : -1;
+      live[g] = tj[g] >= 0;
+      const int jj = live[g] ? tj[g] : 0;
+      toj[g] = map.obs_off[jj];
+      tmj[g] = (int)(map.obs_off[jj + 1] - toj[g]);
+      live[g] = live[g] && tmj[g] > 0;
+      const float* t = cand_tf + ((size_t)il * slots + (live[g] ? slot : 0)) * 8;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) tf[g][q] = t[q];
+      gptr[g] = nullptr; gx0[g] = 0.0f; gy0[g] = 0.0f; ginv[g] = 0.0f; gnx[g] = 0; gny[g] = 0;
+      if (kd_grid != nullptr) {
+        const uint32_t* gj = kd_grid + (size_t)jj * kKdGridWords;
+        gx0[g] = __uint_as_float(gj[0]); gy0[g] = __uint_as_float(gj[1]); ginv[g] = __uint_as_float(gj[2]); gnx[g] = (int)gj[3]; gny[g] = (int)gj[4];
+        if (gnx[g] == 0) live[g] = false;               // no point that could match
+        else if (gnx[g] > 0) {
+          gptr[g] = gj;
+          if (box_ok) {                                 // stage 0 (see k_match_kd)
+            const float m00 = tf[g][0], m01 = tf[g][1], m10 = tf[g][2], m11 = tf[g][3], tx = tf[g][4], ty = tf[g][5];
+            const float c0x = (m00 * bx0 + m01 * by0) + tx, c0y = (m10 * bx0 + m11 * by0) + ty;
+            const float c1x = (m00 * bx1 + m01 * by0) + tx, c1y = (m10 * bx1 + m11 * by0) + ty;
+            const float c2x = (m00 * bx0 + m01 * by1) + tx, c2y = (m10 * bx0 + m11 * by1) + ty;
+            const float c3x = (m00 * bx1 + m01 * by1) + tx, c3y = (m10 * bx1 + m11 * by1) + ty;
+            const float lo_x = (fminf(fminf(c0x, c1x), fminf(c2x, c3x)) - gx0[g]) * ginv[g], hi_x = (fmaxf(fmaxf(c0x, c1x), fmaxf(c2x, c3x)) - gx0[g]) * ginv[g];
+            const float lo_y = (fminf(fminf(c0y, c1y), fminf(c2y, c3y)) - gy0[g]) * ginv[g], hi_y = (fmaxf(fmaxf(c0y, c1y), fmaxf(c2y, c3y)) - gy0[g]) * ginv[g];
+            if (hi_x < -1.0f || lo_x > (float)gnx[g] + 1.0f || hi_y < -1.0f || lo_y > (float)gny[g] + 1.0f) live[g] = false;
+          }
+        }
+      }
+      n_st0 += live[g] ? 1u : 0u;
+    }
+    // ---- stage 1: this thread's queries against the G grids (bit p of mask[g]: the query k = tid + p * BLOCK) ----
+    uint32_t mask[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) mask[g] = 0u;
+    {
+      int p = 0;
+      for (int k = tid; k < mi; k += BLOCK, ++p) {
+        if (!((k % mp.skip) == 0 && s_cnt[k] < mp.cap)) continue;
+        const float4 a = map.obs[oi + k];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          bool ok = live[g];
+          if (ok && gptr[g] != nullptr) {
+            const float qx = (tf[g][0] * a.x + tf[g][1] * a.y) + tf[g][4], qy = (tf[g][2] * a.x + tf[g][3] * a.y) + tf[g][5];
+            const float fx = floorf((qx - gx0[g]) * ginv[g]), fy = floorf((qy - gy0[g]) * ginv[g]);
+            ok = fx >= 0.0f && fx < (float)gnx[g] && fy >= 0.0f && fy < (float)gny[g];
+            if (ok) { const int bit = (int)fy * gnx[g] + (int)fx; ok = (gptr[g][8 + (bit >> 5)] >> (bit & 31)) & 1u; }
+          }
+          mask[g] |= ok ? (1u << p) : 0u;
+        }
+      }
+    }
+    unsigned wbits = 0u;
+#pragma unroll
+    for (int g = 0; g < G; ++g) wbits |= (__ballot(mask[g] != 0u) != 0ull) ? (1u << g) : 0u;
+    if (lane == 0 && wbits != 0u) atomicOr(&s_any[par], wbits);
+    __syncthreads();
+    const unsigned anyb = s_any[par];
+    const unsigned long long t_b = stats != nullptr ? wall_clock64() : 0ull;
+    t_st1 += t_b - t_a;
+    if (anyb == 0u) continue;                       // none of the G targets has a point near any query still open (nothing of [par] was touched)
+    if (tid == 0) s_any[par ^ 1] = 0u;              // the other set: last read before this group's barrier, next written after the barrier below
+    if (tid < G) { s_np[par ^ 1][tid] = 0; s_pc[par ^ 1][tid] = 0; }
+    // ---- stage 2a: lists, result rows opened, wave g stages tree g ----
+    {
+      int p = 0;
+      for (int k = tid; k < mi; k += BLOCK, ++p) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          if (!((anyb >> g) & 1u)) continue;
+          s_res[(size_t)g * max_scan + k] = 0xFFFFu;
+          if ((mask[g] >> p) & 1u) s_list[(size_t)g * max_scan + atomicAdd(&s_np[par][g], 1)] = (uint16_t)k;
+        }
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      if (wave == g && ((anyb >> g) & 1u))
+        for (int t = lane; t < tmj[g]; t += 64) { s_tgt[(size_t)g * max_scan + t] = kd_pts[toj[g] + t]; s_meta[(size_t)g * max_scan + t] = kd_meta[toj[g] + t]; }
+    }
+    __syncthreads();
+    // ---- stage 2b: wave g walks list g in tree g (no counter is read or written here) ----
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      if (wave != g || !((anyb >> g) & 1u)) continue;
+      const int np = s_np[par][g];
+      const float4* tg = s_tgt + (size_t)g * max_scan;
+      const uint32_t* tm = s_meta + (size_t)g * max_scan;
+      ++n_st1; n_walk += (unsigned)np;
+      for (int e = lane; e < np; e += 64) {
+        const int k = s_list[(size_t)g * max_scan + e];
+        const float4 a = map.obs[oi + k];
+        const float qx = (tf[g][0] * a.x + tf[g][1] * a.y) + tf[g][4];
+        const float qy = (tf[g][2] * a.x + tf[g][3] * a.y) + tf[g][5];
+        KdWalk w;
+        w.ovf = 0; w.t_inc = 0.0f; w.t_seg = 0u; w.t_oc = 0u;
+        kd_begin(w, qx, qy, tmj[g]);
+        while (w.mode != 2) kd_step(w, tg, tm, thr, thr2, st_inc + tid, st_seg + tid, st_oc + tid, BLOCK, depth);
+        if (w.ret_c >= 0 && w.ret_d < thr) {
+          const float cr = tf[g][6], sr = tf[g][7];
+          const float nqx = cr * a.z - sr * a.w, nqy = sr * a.z + cr * a.w;
+          const float4 gp = tg[w.ret_c];
+          const float cosang = gp.z * nqx + gp.w * nqy;
+          if (cosang > mp.min_cos) s_res[(size_t)g * max_scan + k] = (uint16_t)(tm[w.ret_c] & 0xffffu);
+        }
+      }
+    }
+    __syncthreads();
+    // ---- stage 2c: commit in ascending target order, by the owner of each point: JointOptimization.cpp:596-599's counter ----
+    int local[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) local[g] = 0;
+    for (int k = tid; k < mi; k += BLOCK) {
+      int c = s_cnt[k];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        if (!((anyb >> g) & 1u)) continue;
+        uint16_t r = s_res[(size_t)g * max_scan + k];
+        if (r != 0xFFFFu) {
+          if (c < mp.cap) { ++c; ++local[g]; }
+          else r = 0xFFFFu;                         // the sequential order would not have asked
+        }
+        table[((size_t)il * slots + slot0 + g) * max_scan + k] = r;
+      }
+      s_cnt[k] = c;
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) if (local[g]) atomicAdd(&s_pc[par][g], local[g]);
+    __syncthreads();
+    if (tid < G && ((anyb >> tid) & 1u)) counts[(size_t)il * slots + slot0 + tid] = s_pc[par][tid];
+    par ^= 1;
+    if (stats != nullptr) t_st2 += wall_clock64() - t_b;
+  }
+  if (stats != nullptr && lane == 0) {
+    atomicAdd(stats + 1, n_st1); atomicAdd(stats + 2, n_walk);
+    if (tid == 0) { atomicAdd(stats, n_st0); atomicAdd(stats + 3, t_st1); atomicAdd(stats + 4, t_st2); atomicMax(stats + 5, t_st1 + t_st2); stats[6 + il] = t_st1 + t_st2; }
+  }
+}
+
+template <int G>
+static size_t match_kd_spec_lds_bytes(int max_scan) {
+  const size_t ms = (size_t)std::max(max_scan, 1);
+  return (size_t)G * ms * (sizeof(float4) + sizeof(uint32_t)) + ms * sizeof(int) + (size_t)(kd_depth(max_scan) + 1) * 64 * G * 12 +
+         (((size_t)2 * G * ms * sizeof(uint16_t) + 15) & ~(size_t)15);
+}
+
 size_t match_kd_lds_bytes(int max_scan) {
   return (size_t)std::max(max_scan, 1) * (sizeof(float4) + 2 * sizeof(int)) + (size_t)(kd_depth(max_scan) + 1) * kMatchBlock * 12 + (((size_t)std::max(max_scan, 1) * 2 + 15) & ~(size_t)15);
 }
@@ -692,6 +906,23 @@ void launch_match_kd(hipStream_t st, const MapView& map, int max_scan, int slots
                      unsigned long long* stats) {
   if (n_tile < 0) n_tile = map.n_poses - i0;
   const int chunk = (n_tile + 7) / 8;
+  // G targets in flight per workgroup while two workgroups still fit a CU's LDS (scans of up to ~470 points: four; ~900: two); longer scans: one
+  const int want = dev_switches().kd_spec;
+  const size_t budget = 80 * 1024;
+  if (want >= 4 && match_kd_spec_lds_bytes<4>(max_scan) <= budget) {
+    const size_t l4 = match_kd_spec_lds_bytes<4>(max_scan);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_match_kd_spec<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l4);
+    hipLaunchKernelGGL(k_match_kd_spec<4>, dim3(8 * chunk), dim3(256), l4, st, map, chunk, max_scan, slots, kd_depth(max_scan), cand_tgt, cand_tf,
+                       mp, kd_pts, kd_meta, kd_grid, table, counts, i0, n_tile, stats);
+    return;
+  }
+  if (want >= 2 && match_kd_spec_lds_bytes<2>(max_scan) <= budget) {
+    const size_t l2 = match_kd_spec_lds_bytes<2>(max_scan);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_match_kd_spec<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+    hipLaunchKernelGGL(k_match_kd_spec<2>, dim3(8 * chunk), dim3(128), l2, st, map, chunk, max_scan, slots, kd_depth(max_scan), cand_tgt, cand_tf,
+                       mp, kd_pts, kd_meta, kd_grid, table, counts, i0, n_tile, stats);
+    return;
+  }
   const size_t lds = match_kd_lds_bytes(max_scan);
   if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_match_kd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k_match_kd, dim3(8 * chunk), dim3(kMatchBlock), lds, st, map, chunk, max_scan, slots, kd_depth(max_scan), cand_tgt, cand_tf,

@@ -4,7 +4,11 @@ in k_match_kd): a query with no scan point of the target within the point-match 
 the walk-everything kernel of rounds 3-5 (test hook kd_grid = 0) bit for bit -- pairs, match offsets, both index lists -- on maps
 that revisit places, at BASELINE configs[2]'s size, over thresholds from 2 cm to 5 m (cells from the finest to coarser than the
 room), on scans far from their pose's origin (cells coarsened until the grid fits its 32 768 bits), on scans with NaN points and
-scans with no points, and to the oracle's walk."""
+scans with no points, and to the oracle's walk.
+The same kernel takes G = 4 (or 2) targets per workgroup at a time (k_match_kd_spec: walks first, the per-point cap of
+JointOptimization.cpp:596-599 applied afterwards in target order); test hook kd_spec = 0 is the one-target-at-a-time order of rounds
+3-5, and every comparison below is made against it as well -- including a cap of 1 and 2 matches per point (the cap closes points
+inside a group) and several tiles of source poses."""
 import numpy as np
 import pytest
 
@@ -14,8 +18,8 @@ from conftest import Problem
 pytestmark = pytest.mark.gpu
 
 
-def _search(H, switches, grid, opt, load, init, window=0):
-    switches(kd_grid=grid)
+def _search(H, switches, grid, opt, load, init, window=0, spec=4, **more):
+    switches(kd_grid=grid, kd_spec=spec, **more)
     s = H.Solver(opt)
     load(s)
     s.find_correspondences(init, window)
@@ -43,10 +47,27 @@ def test_grid_skips_change_no_correspondence_figure8(switches, thr):
     opt = H.default_options()
     opt.point_match_threshold = thr
     a = _search(H, switches, 1, opt, _fig8_loader(d), d["init"])
-    b = _search(H, switches, 0, opt, _fig8_loader(d), d["init"])
+    b = _search(H, switches, 0, opt, _fig8_loader(d), d["init"], spec=0)
     _same(a, b)
+    _same(_search(H, switches, 0, opt, _fig8_loader(d), d["init"], spec=4), b)
+    _same(_search(H, switches, 1, opt, _fig8_loader(d), d["init"], spec=2), b)
     print("figure-8 300 x 180 all pairs, threshold %.2f: %d pairs, %d matches" % (thr, len(a[0]), len(a[3])))
     assert len(a[3]) > 0
+
+
+@pytest.mark.parametrize("cap,skip", [(1, 1), (2, 1), (3, 2), (1000, 1)])
+def test_groups_of_targets_commit_in_the_sequential_order(switches, cap, skip):
+    """The per-point cap at 1, 2, 3 (every group of four targets closes points half-way) and out of reach; every second reading
+    skipped; one tile and several (cand_tile_bytes: the table budget of a tile): G = 4 and G = 2 against one target at a time."""
+    import hitl_slam_amd as H
+    d = figure8.make(230, 150, seed=3, laps=3)
+    opt = H.default_options()
+    opt.max_correspondences_per_point = cap
+    opt.num_skip_readings = skip
+    ref = _search(H, switches, 0, opt, _fig8_loader(d), d["init"], spec=0)
+    assert len(ref[3]) > 0
+    for spec, more in ((4, {}), (2, {}), (4, {"cand_tile_bytes": 229 * 150 * 2 * 37})):
+        _same(_search(H, switches, 1, opt, _fig8_loader(d), d["init"], spec=spec, **more), ref)
 
 
 def test_grid_skips_at_configs2_size_and_against_the_oracle(switches):
@@ -56,7 +77,7 @@ def test_grid_skips_at_configs2_size_and_against_the_oracle(switches):
     d = figure8.make(1000, 360, seed=7, laps=4)
     opt = H.default_options()
     a = _search(H, switches, 1, opt, _fig8_loader(d), d["init"])
-    b = _search(H, switches, 0, opt, _fig8_loader(d), d["init"])
+    b = _search(H, switches, 0, opt, _fig8_loader(d), d["init"], spec=0)
     _same(a, b)
     assert len(a[3]) > 1000000
     d = figure8.make(400, 120, seed=7, laps=2)
@@ -100,8 +121,9 @@ def test_grid_far_scans_nan_points_and_empty_scans(switches):
         s.set_map(off2, px, py, nx, ny, prob.cov)
     opt = H.default_options()
     a = _search(H, switches, 1, opt, load, prob.init)
-    b = _search(H, switches, 0, opt, load, prob.init)
+    b = _search(H, switches, 0, opt, load, prob.init, spec=0)
     _same(a, b)
+    _same(_search(H, switches, 1, opt, load, prob.init, spec=2), b)
     assert len(a[3]) > 0
     # the banded (target-major) search does not use the grids: untouched by the switch
     a = _search(H, switches, 1, opt, load, prob.init, window=3)

@@ -15,8 +15,9 @@ import hitl_slam_amd as H  # noqa: E402
 n, m, laps, reps = ([int(x) for x in sys.argv[1:5]] + [1000, 360, 4, 5][len(sys.argv) - 1:])[:4]
 d = figure8.make(n, m, seed=7, laps=laps)
 out = {}
-for grid in (1, 0, 1, 0):
+for grid, spec in ((1, 4), (1, 2), (1, 0), (0, 4), (0, 0)):
     H.set_test_switch("kd_grid", grid)
+    H.set_test_switch("kd_spec", spec)
     s = H.Solver(H.default_options())
     s.set_map(d["off"], d["px"], d["py"], d["nx"], d["ny"], d["cov"])
     ts = []
@@ -26,9 +27,8 @@ for grid in (1, 0, 1, 0):
         ts.append(1e3 * (time.perf_counter() - t0))
     c = s.get_correspondences()
     s.close()
-    print("kd_grid=%d: first call %.2f ms, then median %.2f ms (min %.2f); %d pairs, %d matches" % (grid, ts[0], float(np.median(ts[1:])), min(ts[1:]), len(c[0]), len(c[3])))
-    if grid in out:
-        assert all(np.array_equal(a, b) for a, b in zip(out[grid], c))
-    out[grid] = c
-assert all(np.array_equal(a, b) for a, b in zip(out[0], out[1])), "index sets differ"
+    print("kd_grid=%d kd_spec=%d: first call %.2f ms, then median %.2f ms (min %.2f); %d pairs, %d matches" % (grid, spec, ts[0], float(np.median(ts[1:])), min(ts[1:]), len(c[0]), len(c[3])))
+    if out:
+        assert all(np.array_equal(a, b) for a, b in zip(out[0], c)), "index sets differ"
+    out[0] = c
 print("index sets identical")
