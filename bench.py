@@ -105,6 +105,15 @@ C3 = dict(poses=1000, obs=360, laps=4, n_loop=5, n_colinear=3, baseline="configs
                "3 colinear (type 4) groups, the reference's all-pairs correspondence search (window 0), mode C")
 
 
+def pcg_source_sha():
+    """Short hash of the persistent PCG kernel's source (hitl_pcg.hip + hitl_pcg_sweep.h): profiles/traffic_c3.json stores it."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("hitl_pcg.hip", "hitl_pcg_sweep.h"):
+        h.update(open(os.path.join(ROOT, "hitl_slam_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def algorithmic_bytes_cg_iteration(n_poses, n_pairs_undirected):
     """SURVEY.md section 8(d), per CG iteration: 72 (N + P) bytes of 3x3 fp64 blocks (P = block pairs of the reduced Hessian, each
     read once per product) + 192 N bytes of vectors (x, r, p, q, z read and written)."""
@@ -175,6 +184,18 @@ def run_c3(args):
         us_per_cg = sm2.linear_solver_ms * 1e3 / max(int(sm2.linear_iterations), 1)
         kernel, avg_launch_ms, units = "PCG launch group (preconditioner stages + k_pcg_dir + k_spmv_offband + k_spmv + k_pcg_step)", us_per_cg * 1e-3, 1.0
     achieved = alg / (us_per_cg * 1e-6) / 1e9
+    # HBM-side bytes of the persistent launch from the committed counter passes (tools/summarize_pcg_profile.py), while hitl_pcg.hip still is the profiled text
+    traffic = traffic_source = traffic_stale = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_c3.json")))
+        sha = pcg_source_sha()
+        if kernel == "k_pcg_fused" and tj.get("n_matches") == int(n_matches) and tj.get("kernel_source_sha") == sha:
+            traffic = tj["hbm_bytes_per_launch"] / max(units, 1e-9)                  # per CG iteration, like `achieved`
+            traffic_source = "profiles/traffic_c3.json (%s): %.1f MB per launch of %.1f CG iterations" % (tj.get("source", "?"), tj["hbm_bytes_per_launch"] / 1e6, units)
+        elif kernel == "k_pcg_fused":
+            traffic_stale = "profiles/traffic_c3.json was taken on another hitl_pcg.hip / workload (sha %s, now %s): not used" % (tj.get("kernel_source_sha"), sha)
+    except (OSError, ValueError, KeyError):
+        pass
     d_gt = out.astype(np.float64) - d["gt"]
     result = {
         "metric": "full batch re-solve throughput (observation rows x Gauss-Newton/LM iterations per second); "
@@ -191,7 +212,7 @@ def run_c3(args):
         "correspondence_search_ms": match_ms, "correspondence_search_first_call_ms": match_first_ms,
         "max_abs_xy_vs_ground_truth_m": float(np.abs(d_gt[:, :2]).max()),
         "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "traffic_source": None,
+                     "traffic": traffic, "traffic_source": traffic_source, "traffic_stale": traffic_stale,
                      "algorithmic_bytes_per_cg_iteration": alg, "us_per_cg_iteration": us_per_cg, "cg_iterations_per_launch": units,
                      "avg_launch_ms": avg_launch_ms, "launches_bracketed_by_hip_events": pcg_launches or int(sm2.iterations),
                      "linear_solver_ms_per_lm_iteration": sm2.linear_solver_ms / max(int(sm2.iterations), 1),

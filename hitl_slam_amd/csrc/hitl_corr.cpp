@@ -286,7 +286,7 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
                        i0, i0 + cnt, (long long)cnt * slots, h[0], h[1], h[2], 1e-5 * (double)h[3] / std::max(cnt, 1), 1e-5 * (double)h[4] / std::max(cnt, 1), 1e-5 * (double)h[5]);
         if (std::getenv("HITL_KD_PER_POSE") != nullptr) {       // development: the time of every source pose's workgroup (k_match_kd_spec only)
           std::vector<unsigned long long> per((size_t)cnt);
-          if (hipMemcpy(per.data(), stats + 6, per.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess)
+          if (hipMemcpyAsync(per.data(), stats + 6, per.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess)
             for (int q = 0; q < cnt; ++q) std::fprintf(stderr, "kd_per_pose %d %.3f\n", i0 + q, 1e-5 * (double)per[(size_t)q]);
         }
       }
