@@ -129,3 +129,22 @@ def test_grid_far_scans_nan_points_and_empty_scans(switches):
     a = _search(H, switches, 1, opt, load, prob.init, window=3)
     b = _search(H, switches, 0, opt, load, prob.init, window=3)
     _same(a, b)
+
+
+@pytest.mark.parametrize("n,m", [(120, 600), (60, 1200)])
+def test_long_scans_take_fewer_targets_at_a_time(switches, n, m):
+    """Scans of 600 points: two targets per workgroup at a time (four trees would not leave room for two workgroups per CU); 1 200
+    points: one (the rounds-3-5 order) -- picked by the launcher from the LDS budget, not by a switch; against the forced
+    one-at-a-time kernel without grids and against the oracle's walk."""
+    import hitl_slam_amd as H
+    from oracle import hitl_oracle as O
+    d = figure8.make(n, m, seed=5, laps=2)
+    opt = H.default_options()
+    a = _search(H, switches, 1, opt, _fig8_loader(d), d["init"])
+    _same(a, _search(H, switches, 0, opt, _fig8_loader(d), d["init"], spec=0))
+    o = O.OracleSolver()
+    _fig8_loader(d)(o)
+    o.find_correspondences(d["init"], 0, 1)
+    _same(a, o.get_correspondences())
+    o.close()
+    assert len(a[3]) > 0
