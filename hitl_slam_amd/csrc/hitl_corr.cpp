@@ -277,7 +277,28 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
         TRYC(s->d_kd_stats.resize(6 + (size_t)cnt)); TRYC(s->d_kd_stats.zero(st));
         stats = s->d_kd_stats.p;
       }
-      launch_match_kd(st, mv, s->max_scan, slots, d_tgt.p, d_tf.p, mp, s->kd_pts.p, s->kd_meta.p, grid, d_table.p, d_counts.p, i0, cnt, stats);
+      // one tile = the whole map: the workgroups of the poses that took longest in the previous search of this map start first
+      // (test hook kd_order = 0: the plain mapping); what each took this time is kept for the next search
+      const int* order = nullptr;
+      unsigned* cost = nullptr;
+      if (i0 == 0 && cnt == n && dev_switches().kd_order) {
+        if (s->kd_cost_valid && s->h_kd_cost.size() == (size_t)n) {
+          std::vector<int>& ord = s->h_kd_order;
+          ord.resize((size_t)n);
+          std::iota(ord.begin(), ord.end(), 0);
+          const unsigned* c = s->h_kd_cost.data();
+          std::stable_sort(ord.begin(), ord.end(), [c](int a, int b) { return c[a] > c[b]; });
+          TRYC(s->d_kd_order.upload(ord, st));
+          order = s->d_kd_order.p;
+        }
+        TRYC(s->d_kd_cost.resize((size_t)n)); TRYC(s->d_kd_cost.zero(st));
+        cost = s->d_kd_cost.p;
+      }
+      launch_match_kd(st, mv, s->max_scan, slots, d_tgt.p, d_tf.p, mp, s->kd_pts.p, s->kd_meta.p, grid, d_table.p, d_counts.p, i0, cnt, stats, order, cost);
+      if (cost != nullptr) {                      // (arrives with the counts: the tile loop synchronises right after)
+        s->h_kd_cost.resize((size_t)n);
+        s->kd_cost_valid = hipMemcpyAsync(s->h_kd_cost.data(), cost, sizeof(unsigned) * (size_t)n, hipMemcpyDeviceToHost, st) == hipSuccess;
+      }
       if (timing) {
         unsigned long long h[6] = {0, 0, 0, 0, 0, 0};
         if (hipMemcpyAsync(h, stats, sizeof(h), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess)

@@ -697,7 +697,9 @@ __global__ __launch_bounds__(64 * G) void k_match_kd_spec(MapView map, int chunk
                                                            const int* __restrict__ cand_tgt, const float* __restrict__ cand_tf, MatchParams mp,
                                                            const float4* __restrict__ kd_pts, const uint32_t* __restrict__ kd_meta,
                                                            const uint32_t* __restrict__ kd_grid, uint16_t* __restrict__ table, int* __restrict__ counts,
-                                                           int i0, int n_tile, unsigned long long* __restrict__ stats) {
+                                                           int i0, int n_tile, unsigned long long* __restrict__ stats,
+                                                           const int* __restrict__ order /* workgroup -> source pose of the tile, or null */,
+                                                           unsigned* __restrict__ cost /* [n_tile] ticks this pose's workgroup took, or null */) {
   constexpr int BLOCK = 64 * G;
   extern __shared__ float4 s_tgt[];                               // [G][max_scan] target trees (in-order layout)
   uint32_t* s_meta = (uint32_t*)(s_tgt + (size_t)G * max_scan);   // [G][max_scan]
@@ -713,8 +715,11 @@ __global__ __launch_bounds__(64 * G) void k_match_kd_spec(MapView map, int chunk
   unsigned long long n_st0 = 0, n_st1 = 0, n_walk = 0, t_st1 = 0, t_st2 = 0;
   const int b = blockIdx.x;
   const int idx = b >> 3;
-  const int il = (b & 7) * chunk + idx;
-  if (idx >= chunk || il >= n_tile) return;
+  // The kernel ends with its slowest workgroup, and two workgroups per CU mean two rounds on a map of 1 000 poses: with an order
+  // (the poses sorted by what their workgroups took in the previous search of this map) the long ones start first
+  const int il = order != nullptr ? (b < n_tile ? order[b] : n_tile) : (b & 7) * chunk + idx;
+  if ((order == nullptr && idx >= chunk) || il >= n_tile) return;
+  const unsigned long long t_begin = cost != nullptr ? wall_clock64() : 0ull;
   const int i = i0 + il;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t oi = map.obs_off[i];
@@ -884,6 +889,7 @@ __global__ __launch_bounds__(64 * G) void k_match_kd_spec(MapView map, int chunk
     par ^= 1;
     if (stats != nullptr) t_st2 += wall_clock64() - t_b;
   }
+  if (cost != nullptr && tid == 0) cost[il] = (unsigned)(wall_clock64() - t_begin);
   if (stats != nullptr && lane == 0) {
     atomicAdd(stats + 1, n_st1); atomicAdd(stats + 2, n_walk);
     if (tid == 0) { atomicAdd(stats, n_st0); atomicAdd(stats + 3, t_st1); atomicAdd(stats + 4, t_st2); atomicMax(stats + 5, t_st1 + t_st2); stats[6 + il] = t_st1 + t_st2; }
@@ -903,7 +909,7 @@ size_t match_kd_lds_bytes(int max_scan) {
 
 void launch_match_kd(hipStream_t st, const MapView& map, int max_scan, int slots, const int* cand_tgt, const float* cand_tf, MatchParams mp,
                      const float4* kd_pts, const uint32_t* kd_meta, const uint32_t* kd_grid, uint16_t* table, int* counts, int i0, int n_tile,
-                     unsigned long long* stats) {
+                     unsigned long long* stats, const int* order, unsigned* cost) {
   if (n_tile < 0) n_tile = map.n_poses - i0;
   const int chunk = (n_tile + 7) / 8;
   // G targets in flight per workgroup while two workgroups still fit a CU's LDS (scans of up to ~470 points: four; ~900: two); longer scans: one
@@ -913,14 +919,14 @@ void launch_match_kd(hipStream_t st, const MapView& map, int max_scan, int slots
     const size_t l4 = match_kd_spec_lds_bytes<4>(max_scan);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_match_kd_spec<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l4);
     hipLaunchKernelGGL(k_match_kd_spec<4>, dim3(8 * chunk), dim3(256), l4, st, map, chunk, max_scan, slots, kd_depth(max_scan), cand_tgt, cand_tf,
-                       mp, kd_pts, kd_meta, kd_grid, table, counts, i0, n_tile, stats);
+                       mp, kd_pts, kd_meta, kd_grid, table, counts, i0, n_tile, stats, order, cost);
     return;
   }
   if (want >= 2 && match_kd_spec_lds_bytes<2>(max_scan) <= budget) {
     const size_t l2 = match_kd_spec_lds_bytes<2>(max_scan);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_match_kd_spec<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
     hipLaunchKernelGGL(k_match_kd_spec<2>, dim3(8 * chunk), dim3(128), l2, st, map, chunk, max_scan, slots, kd_depth(max_scan), cand_tgt, cand_tf,
-                       mp, kd_pts, kd_meta, kd_grid, table, counts, i0, n_tile, stats);
+                       mp, kd_pts, kd_meta, kd_grid, table, counts, i0, n_tile, stats, order, cost);
     return;
   }
   const size_t lds = match_kd_lds_bytes(max_scan);

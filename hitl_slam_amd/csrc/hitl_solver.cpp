@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <unordered_map>
 #include <numeric>
 #include <thread>
 
@@ -102,7 +103,8 @@ int build_pair_structures(hitl_solver* s) {
   for (int i = 0; i < n; ++i) { ppo[i + 1] += ppo[i]; inc_off[i + 1] += inc_off[i]; }
   std::vector<int> inc_ent(std::max(2 * P, 1)), fill(inc_off.begin(), inc_off.end() - 1);
   std::vector<int> band_pair((size_t)n * Wb * 2, -1);
-  std::map<std::pair<int, int>, int> ob_index;
+  std::unordered_map<int64_t, int> ob_index;                // (lo, hi) -> entry, entries numbered in the order the pairs arrive
+  ob_index.reserve((size_t)std::min(P, 1 << 15));
   std::vector<int> ob_lo, ob_hi, ob_fwd, ob_rev;
   for (int p = 0; p < P; ++p) {
     const int a = s->h_pair_src[p], b = s->h_pair_tgt[p];
@@ -114,7 +116,7 @@ int build_pair_structures(hitl_solver* s) {
       if (slot >= 0) return fail(HITL_ERR_INVALID_ARGUMENT, "duplicate directed pose pair in the correspondence set");
       slot = p;
     } else {
-      auto key = std::make_pair(lo, hi);
+      const int64_t key = (int64_t)lo * n + hi;
       auto it = ob_index.find(key);
       int e;
       if (it == ob_index.end()) {
@@ -595,6 +597,7 @@ extern "C" int hitl_test_set_switch(const char* name, long long value) {
   else if (k == "pcg_fused") d.pcg_fused = value != 0;
   else if (k == "kd_grid") d.kd_grid = value != 0;
   else if (k == "kd_spec") d.kd_spec = (int)value;
+  else if (k == "kd_order") d.kd_order = value != 0;
   else if (k == "stf_lds_targets") d.stf_lds_targets = value != 0;
   else if (k == "pcg_starve") d.pcg_starve = value != 0;
   else if (k == "cu_count") d.cu_count = (int)std::max(0ll, std::min(4096ll, value));
@@ -937,7 +940,7 @@ int hitl_solver_set_map(hitl_solver* s, int64_t n_poses, const int64_t* obs_offs
   if (cov9) TRY(s->cov9.upload(cov9, (size_t)n_poses * 9, st));   // carried like covariances_; no live factor reads it
   HIP_TRY(hipStreamSynchronize(st));
   // a new map invalidates correspondences, human rows and the KD-trees
-  s->kd_built = false; s->kd_grid_built = false; s->kd_full_depth = false;
+  s->kd_built = false; s->kd_grid_built = false; s->kd_full_depth = false; s->kd_cost_valid = false;
   s->adj_window = 0; s->adj_slots = 0; s->h_adj.clear();      // info_mat: no search on this map yet
   s->n_pairs = 0; s->n_matches = 0; s->pose_pair_off.n = 0;
   s->h_hc.clear();

@@ -144,6 +144,11 @@ struct hitl_solver {
   bool kd_built = false;                       //   trees belong to the resident map
   DevArray<uint32_t> kd_grid;                  //   occupancy grid of every scan (source-major search only: built on its first use per map)
   bool kd_grid_built = false;
+  DevArray<int> d_kd_order;                    //   source-major search, one tile: workgroup -> pose, longest first by the previous search of this map
+  DevArray<unsigned> d_kd_cost;                //   ... and what each pose's workgroup took this time
+  std::vector<int> h_kd_order;
+  std::vector<unsigned> h_kd_cost;
+  bool kd_cost_valid = false;
   DevArray<unsigned long long> d_kd_stats;     //   HITL_TIMING: stage counters of k_match_kd
   float kd_grid_thr = 0.0f;                    //   the point-match threshold the grids were laid out for
   DevArray<float> world_xy;                    // hitl_solver_transform_scans*: world x of every observation, then world y

@@ -148,3 +148,29 @@ def test_long_scans_take_fewer_targets_at_a_time(switches, n, m):
     _same(a, o.get_correspondences())
     o.close()
     assert len(a[3]) > 0
+
+
+def test_repeated_searches_start_the_long_workgroups_first(switches):
+    """From the second search of a map on, the source-major kernel starts the workgroups of the poses that took longest last time
+    first (its end is its slowest workgroup's): the mapping of workgroups to poses changes, the result may not -- three searches in a
+    row (moved poses in between), against a solver that never reorders (test hook kd_order = 0)."""
+    import hitl_slam_amd as H
+    d = figure8.make(260, 140, seed=9, laps=3)
+    opt = H.default_options()
+    res = {}
+    for order in (1, 0):
+        switches(kd_order=order)
+        s = H.Solver(opt)
+        _fig8_loader(d)(s)
+        out = []
+        for k in range(3):
+            poses = d["init"].copy()
+            poses[::3, 0] += np.float32(0.02 * k)                  # (every third pose moves: relative poses change)
+            poses[1::5, 2] += np.float32(0.01 * k)
+            s.find_correspondences(poses, 0)
+            out.append(s.get_correspondences())
+        s.close()
+        res[order] = out
+    for a, b in zip(res[1], res[0]):
+        _same(a, b)
+    assert not np.array_equal(res[1][0][3], res[1][2][3])          # (the moved poses did change the sets: the three searches are three problems)
