@@ -743,6 +743,7 @@ int hitl_solver_create(const hitl_options* opt, hitl_solver** out) {
   if (opt) o = *opt; else hitl_options_default(&o);
   if (o.abi_version != HITL_ABI_VERSION) return fail(HITL_ERR_INVALID_ARGUMENT, "hitl_options.abi_version mismatch");
   read_dev_switches();
+  (void)hitl_libm_sincos_exact();      // the search's once-per-process self-check of the C library (5-9 ms: a million sinf / cosf / sincosf calls) belongs here, not in the first search a user waits for
   if (o.world_size < 1 || o.rank < 0 || o.rank >= o.world_size) return fail(HITL_ERR_INVALID_ARGUMENT, "bad rank/world_size");
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
