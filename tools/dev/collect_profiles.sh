@@ -5,11 +5,11 @@ TAG=${1:-r06}
 cd "$(dirname "$0")/../.." || exit 1
 P=gpurun_out/prof_$TAG; P3=gpurun_out/prof_${TAG}c3; C=gpurun_out/pmc_$TAG; F=gpurun_out/final_$TAG
 cp $P/summary.md profiles/${TAG}_bench_c4_summary.md
-cp "$(ls $P/trace/*/*kernel_stats.csv | head -1)" profiles/${TAG}_bench_c4_kernel_stats.csv
+cp "$(ls -t $P/trace/*/*kernel_stats.csv | head -1)" profiles/${TAG}_bench_c4_kernel_stats.csv
 cp $C/summary.md profiles/${TAG}_pmc_c4.md
 if [ -d $P3 ]; then
   cp $P3/summary.md profiles/${TAG}_bench_c3_summary.md
-  cp "$(ls $P3/trace/*/*kernel_stats.csv | head -1)" profiles/${TAG}_bench_c3_kernel_stats.csv
+  cp "$(ls -t $P3/trace/*/*kernel_stats.csv | head -1)" profiles/${TAG}_bench_c3_kernel_stats.csv
   cp $P3/traffic_c3.json profiles/traffic_c3.json
   cat $F/traffic_c3.log >> profiles/${TAG}_bench_c3_summary.md
 fi
