@@ -1,6 +1,6 @@
 """The bench line contract (one JSON object: metric/value/unit/..., a `roofline` object -- `achieved` from the HBM bytes the
 kernel really moves, the SURVEY 8(d) algorithmic-byte figure beside it -- and a `cpu_baseline` object), checked on the
-committed lines of profiled runs (profiles/r02_final_bench_*.json, r05_final_bench_*.json) and on
+committed lines of profiled runs (profiles/r02_final_bench_*.json, r05_final_bench_*.json, r06_final_bench_*.json) and on
 bench.py's own source: the product path may not fall back to the oracle, the oracle is only the cpu_baseline leg."""
 import json
 import os
@@ -9,7 +9,8 @@ import re
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LINES = [os.path.join(ROOT, "profiles", f) for f in ("r02_final_bench_c4.json", "r02_final_bench_c2.json", "r05_final_bench_c4.json", "r05_final_bench_c2.json")]
+LINES = [os.path.join(ROOT, "profiles", f) for f in ("r02_final_bench_c4.json", "r02_final_bench_c2.json", "r05_final_bench_c4.json", "r05_final_bench_c2.json",
+                                                    "r06_final_bench_c4.json", "r06_final_bench_c2.json")]
 
 
 @pytest.mark.parametrize("path", LINES, ids=[os.path.basename(p) for p in LINES])
@@ -37,6 +38,29 @@ def test_committed_bench_line_has_the_contract_fields(path):
     assert cb["kind"] in ("port", "reference") and cb["unit"] == r["unit"] and cb["cores"] >= 1
     assert "extrapolated" not in json.dumps(cb) and cb["lm_iterations"] == cb["lm_iterations_gpu"] == r["lm_iterations_per_resolve"]
     assert cb["cores"] == cb["host"]["threads_used"] <= cb["host"]["affinity"]
+
+
+def test_committed_c3_line_has_the_contract_fields():
+    """`bench.py --workload c3` (BASELINE configs[2]: the PCG path): the same contract; `roofline` is the persistent PCG launch, per CG
+    iteration -- `achieved` = SURVEY 8(d)'s algorithmic bytes of one CG iteration / its measured time, `traffic` = the HBM-side
+    bytes of the counter passes per CG iteration; `cpu_baseline` is a bounded sample (the first LM iterations of the same re-solve)."""
+    r = json.load(open(os.path.join(ROOT, "profiles", "r06_final_bench_c3.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in r, k
+    assert r["higher_is_better"] is True and r["vs_baseline"] is None and r["dtype"] == "f64" and r["n_gpus"] == 1
+    assert "configs[2]" in r["config"]["workload"] and "model" not in r["config"] and r["config"]["window"] == 0
+    rf = r["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and rf["kernel"] == "k_pcg_fused"
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0 < rf["frac"] < 1
+    assert abs(rf["achieved"] - rf["algorithmic_bytes_per_cg_iteration"] / (rf["us_per_cg_iteration"] * 1e-6) / 1e9) < 1e-6 * rf["achieved"]
+    assert abs(rf["us_per_cg_iteration"] * rf["cg_iterations_per_launch"] - 1e3 * rf["avg_launch_ms"]) < 1e-6 * 1e3 * rf["avg_launch_ms"]
+    assert rf["traffic"] is not None and rf["traffic_source"] and rf["traffic"] > 0.5 * rf["algorithmic_bytes_per_cg_iteration"]
+    assert r["cg_iterations_per_resolve"] > 5 * r["lm_iterations_per_resolve"]          # the PCG really iterates on this workload
+    cb = r["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cb, k
+    assert cb["kind"] == "port" and cb["unit"] == r["unit"] and cb["cores"] >= 1 and cb["whole_resolve"] is False and cb["lm_iterations"] <= r["lm_iterations_per_resolve"]
 
 
 def test_bench_source_keeps_the_oracle_in_its_lane():
