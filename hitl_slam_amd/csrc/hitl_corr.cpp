@@ -277,24 +277,49 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
         TRYC(s->d_kd_stats.resize(6 + (size_t)cnt)); TRYC(s->d_kd_stats.zero(st));
         stats = s->d_kd_stats.p;
       }
-      // one tile = the whole map: the workgroups of the poses that took longest in the previous search of this map start first
-      // (test hook kd_order = 0: the plain mapping); what each took this time is kept for the next search
+      // one tile = the whole map: the workgroups of the poses that took longest in the previous search of this map start first, and a
+      // pose that took much longer than the average is served by several workgroups, each with every `parts`-th point (exact: see the
+      // kernel).  Test hooks: kd_order = 0: the plain mapping; kd_split = 0: whole poses only.  What each pose took this time is kept
+      // for the next search.
       const int* order = nullptr;
       unsigned* cost = nullptr;
-      if (i0 == 0 && cnt == n && dev_switches().kd_order) {
+      int n_wg = 0;
+      if (i0 == 0 && cnt == n && n < (1 << 20) && dev_switches().kd_order && match_kd_takes_order(s->max_scan)) {
         if (s->kd_cost_valid && s->h_kd_cost.size() == (size_t)n) {
-          std::vector<int>& ord = s->h_kd_order;
-          ord.resize((size_t)n);
-          std::iota(ord.begin(), ord.end(), 0);
           const unsigned* c = s->h_kd_cost.data();
-          std::stable_sort(ord.begin(), ord.end(), [c](int a, int b) { return c[a] > c[b]; });
+          double mean = 0.0;
+          for (int q = 0; q < n; ++q) mean += (double)c[q];
+          mean /= std::max(n, 1);
+          std::vector<std::pair<double, int>> ent;            // (estimated time of the workgroup, its order entry)
+          ent.reserve((size_t)n + 64);
+          int n_split = 0;
+          for (int q = 0; q < n; ++q) {
+            int parts = 1;
+            const int ks = dev_switches().kd_split;
+            if (ks == 1 && mean > 0.0) parts = std::min(4, std::max(1, (int)std::ceil((double)c[q] / (1.6 * mean))));
+            if (parts > 1 && n_split >= 256) parts = 1;      // (a map where "much longer than the average" is common has no stragglers to split)
+            if (ks >= 2) parts = std::min(ks, 4);             // tests: every pose in parts
+            static const double share[5] = {1.0, 1.0, 1.0 / 1.75, 1.0 / 2.5, 1.0 / 3.0};      // the inverse of the kernel's estimate
+            if (parts > 1) {
+              ++n_split;
+              // the rows of a split pose start as "no match": a part that stages no tree for a pair leaves its entries alone
+              if (hipMemsetAsync(d_table.p + (size_t)q * slots * s->max_scan, 0xFF, sizeof(uint16_t) * (size_t)slots * s->max_scan, st) != hipSuccess)
+                return fail(HITL_ERR_HIP, "find_correspondences: clearing a split pose's rows failed");
+            }
+            for (int pt = 0; pt < parts; ++pt) ent.emplace_back((double)c[q] * share[parts], q | (pt << 20) | (parts << 24));
+          }
+          std::stable_sort(ent.begin(), ent.end(), [](const std::pair<double, int>& x, const std::pair<double, int>& y) { return x.first > y.first; });
+          std::vector<int>& ord = s->h_kd_order;
+          ord.resize(ent.size());
+          for (size_t q = 0; q < ent.size(); ++q) ord[q] = ent[q].second;
           TRYC(s->d_kd_order.upload(ord, st));
           order = s->d_kd_order.p;
+          n_wg = (int)ord.size();
         }
         TRYC(s->d_kd_cost.resize((size_t)n)); TRYC(s->d_kd_cost.zero(st));
         cost = s->d_kd_cost.p;
       }
-      launch_match_kd(st, mv, s->max_scan, slots, d_tgt.p, d_tf.p, mp, s->kd_pts.p, s->kd_meta.p, grid, d_table.p, d_counts.p, i0, cnt, stats, order, cost);
+      launch_match_kd(st, mv, s->max_scan, slots, d_tgt.p, d_tf.p, mp, s->kd_pts.p, s->kd_meta.p, grid, d_table.p, d_counts.p, i0, cnt, stats, order, n_wg, cost);
       if (cost != nullptr) {                      // (arrives with the counts: the tile loop synchronises right after)
         s->h_kd_cost.resize((size_t)n);
         s->kd_cost_valid = hipMemcpyAsync(s->h_kd_cost.data(), cost, sizeof(unsigned) * (size_t)n, hipMemcpyDeviceToHost, st) == hipSuccess;

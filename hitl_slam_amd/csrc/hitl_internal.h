@@ -48,6 +48,7 @@ struct DevSwitches {
   bool cand_tf_check = false;      // "cand_tf_check": the device's candidate transforms held to the host routine, bit for bit
   size_t cand_tile_bytes = (size_t)4 << 30;   // "cand_tile_bytes": candidate-table budget of the tiled search (shrunk to force several tiles)
   bool stf_lds_targets = false;    // "stf_lds_targets": k_linearize_stf_r reads its targets from LDS (the source scan's fp32 copy) -- WRONG results, a timing experiment
+  int kd_split = 1;                // "kd_split" = 0: ... and never serves one pose by several workgroups; 2-4: EVERY pose by that many (tests)
   bool kd_order = true;            // "kd_order" = 0: the source-major search maps workgroups to poses the plain way on every call
   int kd_spec = 4;                 // "kd_spec": targets in flight per workgroup of the source-major tree search (4, 2; 0 or 1: one at a time, rounds 3-5's order)
   bool kd_grid = true;             // "kd_grid" = 0: the source-major tree search walks every query (rounds 3-5) instead of skipping those an occupancy grid rules out
@@ -340,8 +341,10 @@ void launch_kd_grid(hipStream_t st, const MapView& map, float thr, const float4*
 void launch_match_kd(hipStream_t st, const MapView& map, int max_scan, int slots, const int* cand_tgt, const float* cand_tf, MatchParams mp,
                      const float4* kd_pts, const uint32_t* kd_meta, const uint32_t* kd_grid /* or null */, uint16_t* table, int* counts, int i0 = 0, int n_tile = -1,
                      unsigned long long* stats = nullptr /* HITL_TIMING: 3 counters (pairs past the box test, pairs that staged a tree, walks) */,
-                     const int* order = nullptr /* n_tile: workgroup -> source pose of the tile (k_match_kd_spec only) */,
-                     unsigned* cost = nullptr /* n_tile: out, what each pose's workgroup took (k_match_kd_spec only) */);
+                     const int* order = nullptr /* n_wg entries: workgroup -> pose of the tile | part << 20 | parts << 24 (k_match_kd_spec only) */,
+                     int n_wg = 0,
+                     unsigned* cost = nullptr /* n_tile, zeroed: out, what each pose's workgroup(s) took (k_match_kd_spec only) */);
+bool match_kd_takes_order(int max_scan);      // the launcher would pick k_match_kd_spec for scans of this length
 // target-major form of the same search (one workgroup per target tree, one queue of all its queries): whole map, windowed
 // candidates, slots <= cap (the per-point cap cannot bind); workgroups of 256 threads (128 / 64 where a long scan's tree
 // would not leave room for the frame stacks), a wave refills from the queue when 16 of its lanes are idle

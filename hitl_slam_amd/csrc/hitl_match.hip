@@ -698,8 +698,9 @@ __global__ __launch_bounds__(64 * G) void k_match_kd_spec(MapView map, int chunk
                                                            const float4* __restrict__ kd_pts, const uint32_t* __restrict__ kd_meta,
                                                            const uint32_t* __restrict__ kd_grid, uint16_t* __restrict__ table, int* __restrict__ counts,
                                                            int i0, int n_tile, unsigned long long* __restrict__ stats,
-                                                           const int* __restrict__ order /* workgroup -> source pose of the tile, or null */,
-                                                           unsigned* __restrict__ cost /* [n_tile] ticks this pose's workgroup took, or null */) {
+                                                           const int* __restrict__ order /* workgroup -> pose of the tile | part << 20 | parts << 24, or null */,
+                                                           int n_wg /* entries of order */,
+                                                           unsigned* __restrict__ cost /* [n_tile] ticks this pose's workgroup took (zeroed by the driver), or null */) {
   constexpr int BLOCK = 64 * G;
   extern __shared__ float4 s_tgt[];                               // [G][max_scan] target trees (in-order layout)
   uint32_t* s_meta = (uint32_t*)(s_tgt + (size_t)G * max_scan);   // [G][max_scan]
@@ -717,18 +718,27 @@ __global__ __launch_bounds__(64 * G) void k_match_kd_spec(MapView map, int chunk
   const int idx = b >> 3;
   // The kernel ends with its slowest workgroup, and two workgroups per CU mean two rounds on a map of 1 000 poses: with an order
   // (the poses sorted by what their workgroups took in the previous search of this map) the long ones start first
-  const int il = order != nullptr ? (b < n_tile ? order[b] : n_tile) : (b & 7) * chunk + idx;
+  // An order entry is pose | part << 20 | parts << 24: a pose whose workgroup took much longer than the others' last time is served by
+  // `parts` workgroups, each with the points k = part (mod parts) -- exact, because the cap counts per POINT: a point's targets are
+  // ordered, the points of a scan are independent of each other.  The parts add their counts of a pair (atomics on the zeroed
+  // counts) and write their own points' entries of its row (the driver pre-fills the rows of split poses with 0xFFFF: a part that
+  // stages no tree for a pair leaves its entries alone).
+  const int code = order != nullptr ? (b < n_wg ? order[b] : -1) : 0;
+  const int il = order != nullptr ? (code < 0 ? n_tile : (code & 0xFFFFF)) : (b & 7) * chunk + idx;
+  const int part = order != nullptr && code >= 0 ? ((code >> 20) & 15) : 0;
+  const int parts = order != nullptr && code >= 0 && ((code >> 24) & 15) > 1 ? ((code >> 24) & 15) : 1;
   if ((order == nullptr && idx >= chunk) || il >= n_tile) return;
+  const int k0 = part + parts * (int)threadIdx.x, kstep = parts * BLOCK;          // this thread's points: k0, k0 + kstep, ...
   const unsigned long long t_begin = cost != nullptr ? wall_clock64() : 0ull;
   const int i = i0 + il;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t oi = map.obs_off[i];
   const int mi = (int)(map.obs_off[i + 1] - oi);
-  for (int k = tid; k < mi; k += BLOCK) s_cnt[k] = 0;
+  for (int k = k0; k < mi; k += kstep) s_cnt[k] = 0;
   if (tid < G) { s_np[0][tid] = 0; s_np[1][tid] = 0; s_pc[0][tid] = 0; s_pc[1][tid] = 0; }
   if (tid < 2) s_any[tid] = 0u;
   float bx0 = 3.0e38f, by0 = 3.0e38f, bx1 = -3.0e38f, by1 = -3.0e38f;
-  for (int k = tid; k < mi; k += BLOCK) {
+  for (int k = k0; k < mi; k += kstep) {
     const float4 a = map.obs[oi + k];
     if (a.x == a.x && a.y == a.y) { bx0 = fminf(bx0, a.x); by0 = fminf(by0, a.y); bx1 = fmaxf(bx1, a.x); by1 = fmaxf(by1, a.y); }
   }
@@ -792,7 +802,7 @@ __global__ __launch_bounds__(64 * G) void k_match_kd_spec(MapView map, int chunk
     for (int g = 0; g < G; ++g) mask[g] = 0u;
     {
       int p = 0;
-      for (int k = tid; k < mi; k += BLOCK, ++p) {
+      for (int k = k0; k < mi; k += kstep, ++p) {
         if (!((k % mp.skip) == 0 && s_cnt[k] < mp.cap)) continue;
         const float4 a = map.obs[oi + k];
 #pragma unroll
@@ -822,7 +832,7 @@ __global__ __launch_bounds__(64 * G) void k_match_kd_spec(MapView map, int chunk
     // ---- stage 2a: lists, result rows opened, wave g stages tree g ----
     {
       int p = 0;
-      for (int k = tid; k < mi; k += BLOCK, ++p) {
+      for (int k = k0; k < mi; k += kstep, ++p) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
           if (!((anyb >> g) & 1u)) continue;
@@ -868,7 +878,7 @@ __global__ __launch_bounds__(64 * G) void k_match_kd_spec(MapView map, int chunk
     int local[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) local[g] = 0;
-    for (int k = tid; k < mi; k += BLOCK) {
+    for (int k = k0; k < mi; k += kstep) {
       int c = s_cnt[k];
 #pragma unroll
       for (int g = 0; g < G; ++g) {
@@ -885,14 +895,20 @@ __global__ __launch_bounds__(64 * G) void k_match_kd_spec(MapView map, int chunk
 #pragma unroll
     for (int g = 0; g < G; ++g) if (local[g]) atomicAdd(&s_pc[par][g], local[g]);
     __syncthreads();
-    if (tid < G && ((anyb >> tid) & 1u)) counts[(size_t)il * slots + slot0 + tid] = s_pc[par][tid];
+    if (tid < G && ((anyb >> tid) & 1u)) {
+      if (parts > 1) { if (s_pc[par][tid]) atomicAdd(&counts[(size_t)il * slots + slot0 + tid], s_pc[par][tid]); }
+      else counts[(size_t)il * slots + slot0 + tid] = s_pc[par][tid];
+    }
     par ^= 1;
     if (stats != nullptr) t_st2 += wall_clock64() - t_b;
   }
-  if (cost != nullptr && tid == 0) cost[il] = (unsigned)(wall_clock64() - t_begin);
+  if (cost != nullptr && tid == 0) {              // what the WHOLE pose would take, roughly: a part's time does not fall in proportion (per-target latency stays)
+    const unsigned t = (unsigned)(wall_clock64() - t_begin);
+    atomicMax(&cost[il], parts == 1 ? t : (parts == 2 ? t + (t >> 1) + (t >> 2) : (parts == 3 ? 2 * t + (t >> 1) : 3 * t)));
+  }
   if (stats != nullptr && lane == 0) {
     atomicAdd(stats + 1, n_st1); atomicAdd(stats + 2, n_walk);
-    if (tid == 0) { atomicAdd(stats, n_st0); atomicAdd(stats + 3, t_st1); atomicAdd(stats + 4, t_st2); atomicMax(stats + 5, t_st1 + t_st2); stats[6 + il] = t_st1 + t_st2; }
+    if (tid == 0) { atomicAdd(stats, n_st0); atomicAdd(stats + 3, t_st1); atomicAdd(stats + 4, t_st2); atomicMax(stats + 5, t_st1 + t_st2); atomicMax(stats + 6 + il, t_st1 + t_st2); }
   }
 }
 
@@ -907,26 +923,29 @@ size_t match_kd_lds_bytes(int max_scan) {
   return (size_t)std::max(max_scan, 1) * (sizeof(float4) + 2 * sizeof(int)) + (size_t)(kd_depth(max_scan) + 1) * kMatchBlock * 12 + (((size_t)std::max(max_scan, 1) * 2 + 15) & ~(size_t)15);
 }
 
+bool match_kd_takes_order(int max_scan) { return dev_switches().kd_spec >= 2 && match_kd_spec_lds_bytes<2>(max_scan) <= (size_t)80 * 1024; }
+
 void launch_match_kd(hipStream_t st, const MapView& map, int max_scan, int slots, const int* cand_tgt, const float* cand_tf, MatchParams mp,
                      const float4* kd_pts, const uint32_t* kd_meta, const uint32_t* kd_grid, uint16_t* table, int* counts, int i0, int n_tile,
-                     unsigned long long* stats, const int* order, unsigned* cost) {
+                     unsigned long long* stats, const int* order, int n_wg, unsigned* cost) {
   if (n_tile < 0) n_tile = map.n_poses - i0;
   const int chunk = (n_tile + 7) / 8;
+  const unsigned grid = order != nullptr ? (unsigned)n_wg : (unsigned)(8 * chunk);
   // G targets in flight per workgroup while two workgroups still fit a CU's LDS (scans of up to ~470 points: four; ~900: two); longer scans: one
   const int want = dev_switches().kd_spec;
   const size_t budget = 80 * 1024;
   if (want >= 4 && match_kd_spec_lds_bytes<4>(max_scan) <= budget) {
     const size_t l4 = match_kd_spec_lds_bytes<4>(max_scan);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_match_kd_spec<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l4);
-    hipLaunchKernelGGL(k_match_kd_spec<4>, dim3(8 * chunk), dim3(256), l4, st, map, chunk, max_scan, slots, kd_depth(max_scan), cand_tgt, cand_tf,
-                       mp, kd_pts, kd_meta, kd_grid, table, counts, i0, n_tile, stats, order, cost);
+    hipLaunchKernelGGL(k_match_kd_spec<4>, dim3(grid), dim3(256), l4, st, map, chunk, max_scan, slots, kd_depth(max_scan), cand_tgt, cand_tf,
+                       mp, kd_pts, kd_meta, kd_grid, table, counts, i0, n_tile, stats, order, n_wg, cost);
     return;
   }
   if (want >= 2 && match_kd_spec_lds_bytes<2>(max_scan) <= budget) {
     const size_t l2 = match_kd_spec_lds_bytes<2>(max_scan);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_match_kd_spec<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
-    hipLaunchKernelGGL(k_match_kd_spec<2>, dim3(8 * chunk), dim3(128), l2, st, map, chunk, max_scan, slots, kd_depth(max_scan), cand_tgt, cand_tf,
-                       mp, kd_pts, kd_meta, kd_grid, table, counts, i0, n_tile, stats, order, cost);
+    hipLaunchKernelGGL(k_match_kd_spec<2>, dim3(grid), dim3(128), l2, st, map, chunk, max_scan, slots, kd_depth(max_scan), cand_tgt, cand_tf,
+                       mp, kd_pts, kd_meta, kd_grid, table, counts, i0, n_tile, stats, order, n_wg, cost);
     return;
   }
   const size_t lds = match_kd_lds_bytes(max_scan);

@@ -598,6 +598,7 @@ extern "C" int hitl_test_set_switch(const char* name, long long value) {
   else if (k == "kd_grid") d.kd_grid = value != 0;
   else if (k == "kd_spec") d.kd_spec = (int)value;
   else if (k == "kd_order") d.kd_order = value != 0;
+  else if (k == "kd_split") d.kd_split = (int)value;
   else if (k == "stf_lds_targets") d.stf_lds_targets = value != 0;
   else if (k == "pcg_starve") d.pcg_starve = value != 0;
   else if (k == "cu_count") d.cu_count = (int)std::max(0ll, std::min(4096ll, value));

@@ -76,6 +76,7 @@ bool cr_sep_applies(const CrView& chain, const CrSource&, double*, double*) { re
 bool pcg_fused_plan(int, int, int, int, PcgPlan*) { return false; }      // the stub device runs no kernels: the host keeps the launch-per-stage loop
 size_t pcg_fused_sync_words() { return 32; }
 size_t kd_grid_words() { return 8 + 1024; }
+bool match_kd_takes_order(int) { return true; }
 bool launch_pcg_fused(hipStream_t, const PcgPlan&, int, int, const FactorView&, const LinView&, const CrView&, const double*, double, double, double, double, int,
                       double*, const double*, const double*, int, const int*, int, const unsigned char*, double*, unsigned*, uint64_t, double*, unsigned, bool, unsigned long long*) { return false; }
 const char* kernels_build_info() { return "hostcheck stub (no device code)"; }

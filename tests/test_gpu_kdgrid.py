@@ -153,13 +153,15 @@ def test_long_scans_take_fewer_targets_at_a_time(switches, n, m):
 def test_repeated_searches_start_the_long_workgroups_first(switches):
     """From the second search of a map on, the source-major kernel starts the workgroups of the poses that took longest last time
     first (its end is its slowest workgroup's): the mapping of workgroups to poses changes, the result may not -- three searches in a
-    row (moved poses in between), against a solver that never reorders (test hook kd_order = 0)."""
+    row (moved poses in between), against a solver that never reorders (test hook kd_order = 0).  A pose that took much longer than
+    the average is then served by several workgroups, each with every parts-th point (exact: the cap counts per point): with the
+    automatic choice, with EVERY pose in two and in three parts (kd_split = 2, 3), and without splitting (kd_split = 0)."""
     import hitl_slam_amd as H
     d = figure8.make(260, 140, seed=9, laps=3)
     opt = H.default_options()
     res = {}
-    for order in (1, 0):
-        switches(kd_order=order)
+    for order, split in ((1, 1), (0, 1), (1, 3), (1, 2), (1, 0)):
+        switches(kd_order=order, kd_split=split)
         s = H.Solver(opt)
         _fig8_loader(d)(s)
         out = []
@@ -170,7 +172,8 @@ def test_repeated_searches_start_the_long_workgroups_first(switches):
             s.find_correspondences(poses, 0)
             out.append(s.get_correspondences())
         s.close()
-        res[order] = out
-    for a, b in zip(res[1], res[0]):
-        _same(a, b)
-    assert not np.array_equal(res[1][0][3], res[1][2][3])          # (the moved poses did change the sets: the three searches are three problems)
+        res[(order, split)] = out
+    for key in ((1, 1), (1, 3), (1, 2), (1, 0)):
+        for a, b in zip(res[key], res[(0, 1)]):
+            _same(a, b)
+    assert not np.array_equal(res[(1, 1)][0][3], res[(1, 1)][2][3])          # (the moved poses did change the sets: the three searches are three problems)
