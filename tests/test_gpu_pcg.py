@@ -150,3 +150,36 @@ def test_corridor_all_pairs_dense_off_band_rows():
     dxy, dth = _pdiff(pg, po)
     assert dxy <= 1e-4 and dth <= 1e-4
     g.close(); o.close()
+
+
+def test_configs2_at_full_size_both_forms_walk_one_path(switches):
+    """BASELINE configs[2] at bench.py --workload c3's size (1 000 poses x 360 points, 4 laps, 5 + 3 constraint groups, all pairs: the
+    oracle's dense factorisation would take 40 s here; it is held to the oracle at 400 x 120 above): the persistent launch and the
+    launch-per-stage loop take the same LM iterations to the same cost (1e-9) and poses (1e-6), every linear solve of the
+    former is ONE launch, and the map's hub poses (more than 200 off-band partners) are there."""
+    import hitl_slam_amd as H
+    d, rows = _fig8(1000, 360, 4)
+    res, corr = [], None
+    for fused in (1, 0):
+        switches(pcg_fused=fused)
+        opt = H.default_options()
+        opt.timing_level = 2
+        g = _load(H.Solver(opt), d, rows)
+        if corr is None:
+            g.find_correspondences(d["init"], 0)
+            corr = g.get_correspondences()
+        else:
+            g.set_correspondences(*corr)
+        res.append(g.solve(abi.MODE_JOINT, d["init"]))
+        g.close()
+    (pf, sf), (pl, sl) = res
+    partners = np.bincount(np.concatenate([corr[0][np.abs(corr[0] - corr[1]) > sf.band_poses], corr[1][np.abs(corr[0] - corr[1]) > sf.band_poses]]), minlength=1000)
+    assert partners.max() > 200 and sf.num_offband_pairs > 10000
+    assert sf.pcg_timed_calls == sf.iterations and sl.pcg_timed_calls == 0
+    assert (sf.termination, sf.iterations, sf.successful_steps, sf.unsuccessful_steps) == (sl.termination, sl.iterations, sl.successful_steps, sl.unsuccessful_steps)
+    assert abs(sf.final_cost - sl.final_cost) <= 1e-9 * sl.final_cost and sf.final_cost < sf.initial_cost
+    dxy, dth = _pdiff(pf, pl)
+    assert dxy <= 1e-6 and dth <= 1e-6, (dxy, dth)
+    print("configs[2] size: %d LM / %d CG iterations (loop: %d), %.1f us per CG iteration, %d off-band block pairs, hub pose: %d directed partners" % (
+        sf.iterations, sf.linear_iterations - sf.iterations, sl.linear_iterations - sl.iterations, 1e3 * sf.pcg_ms / max(sf.pcg_timed_iterations, 1),
+        sf.num_offband_pairs, int(partners.max())))
