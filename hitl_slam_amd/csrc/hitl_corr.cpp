@@ -251,9 +251,16 @@ int find_correspondences(hitl_solver* s, const float* poses, int64_t window) {
                                                  ") differs from the host's");
         }
     }
+    auto t_al = std::chrono::steady_clock::now();
+    if (timing) { (void)hipStreamSynchronize(st); t_al = std::chrono::steady_clock::now(); }
     TRYC(d_counts.resize((size_t)cnt * slots));
     TRYC(d_counts.zero(st));
     TRYC(d_table.resize((size_t)cnt * slots * s->max_scan));
+    if (timing) {
+      (void)hipStreamSynchronize(st);
+      std::fprintf(stderr, "find_correspondences:     tile: counts + candidate table (%.1f MB; allocated by a solver's first search of this size: ~20 ms of hipMalloc at 720 MB) ready in %.3f ms\n", 1e-6 * 2.0 * (double)cnt * slots * s->max_scan,
+                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_al).count());
+    }
     if (kd_tgt) {
       // the per-point cap cannot bind (slots <= cap): every (source, target) pair is independent, one workgroup per target tree
       if (mp.skip > 1 && hipMemsetAsync(d_table.p, 0xFF, sizeof(uint16_t) * (size_t)cnt * slots * s->max_scan, st) != hipSuccess)
