@@ -183,3 +183,29 @@ def test_configs2_at_full_size_both_forms_walk_one_path(switches):
     print("configs[2] size: %d LM / %d CG iterations (loop: %d), %.1f us per CG iteration, %d off-band block pairs, hub pose: %d directed partners" % (
         sf.iterations, sf.linear_iterations - sf.iterations, sl.linear_iterations - sl.iterations, 1e3 * sf.pcg_ms / max(sf.pcg_timed_iterations, 1),
         sf.num_offband_pairs, int(partners.max())))
+
+
+def test_configs2_at_full_size_against_the_oracles_exact_solve():
+    """BASELINE configs[2] at bench.py --workload c3's size against the oracle (its search walks 15 M trees, its solver factorises a dense
+    3 000 x 3 000 band per LM iteration: about a minute of CPU): identical correspondence sets (17 k directed pairs, 2.09 M matches), the
+    same LM path (iterations, accepted and rejected steps, termination), cost to 1e-8, poses within 1e-4 m / 1e-4 rad."""
+    import hitl_slam_amd as H
+    from oracle import hitl_oracle as O
+    d, rows = _fig8(1000, 360, 4)
+    g, o = _load(H.Solver(), d, rows), _load(O.OracleSolver(), d, rows)
+    g.find_correspondences(d["init"], 0)
+    o.find_correspondences(d["init"], 0, 1)
+    cg, co = g.get_correspondences(), o.get_correspondences()
+    for a, b in zip(cg, co):
+        assert np.array_equal(a, b)
+    assert len(cg[0]) > 15000 and len(cg[3]) > 2000000
+    pg, sg = g.solve(abi.MODE_JOINT, d["init"])
+    po, so = o.solve(abi.MODE_JOINT, d["init"])
+    assert sg.termination == so.termination and sg.iterations == so.iterations
+    assert sg.successful_steps == so.successful_steps and sg.unsuccessful_steps == so.unsuccessful_steps
+    assert abs(sg.final_cost - so.final_cost) <= 1e-8 * so.final_cost
+    dxy, dth = _pdiff(pg, po)
+    assert dxy <= 1e-4 and dth <= 1e-4, (dxy, dth)
+    print("configs[2] size against the oracle: %d pairs, %d matches, %d LM iterations on both sides, cost %.12g (oracle %.12g), |dxy| %.2e |dth| %.2e"
+          % (len(cg[0]), len(cg[3]), sg.iterations, sg.final_cost, so.final_cost, dxy, dth))
+    g.close(); o.close()
