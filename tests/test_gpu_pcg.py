@@ -209,3 +209,49 @@ def test_configs2_at_full_size_against_the_oracles_exact_solve():
     print("configs[2] size against the oracle: %d pairs, %d matches, %d LM iterations on both sides, cost %.12g (oracle %.12g), |dxy| %.2e |dth| %.2e"
           % (len(cg[0]), len(cg[3]), sg.iterations, sg.final_cost, so.final_cost, dxy, dth))
     g.close(); o.close()
+
+
+def test_ragged_map_with_empty_scans_on_the_pcg_path(switches):
+    """Scans of different lengths, two poses without any point (rows of the system that only odometry and the band touch: identity parts
+    of the product items), a few NaN returns: the all-pairs sets equal the oracle's, the persistent launch, the launch-per-stage loop
+    and the oracle's exact solve agree."""
+    import hitl_slam_amd as H
+    from oracle import hitl_oracle as O
+    d, rows = _fig8(220, 100, 2)
+    rng = np.random.default_rng(3)
+    off = np.asarray(d["off"]).copy()
+    cnt = np.diff(off).copy()
+    keep = np.ones(int(off[-1]), bool)
+    for i in range(220):                                   # ragged: drop 0-40 % of every scan's points; two scans entirely
+        drop = rng.random(cnt[i]) < (1.0 if i in (10, 57) else rng.uniform(0.0, 0.4))
+        keep[off[i]:off[i + 1]] = ~drop
+        cnt[i] = int((~drop).sum())
+    d2 = dict(d)
+    d2["off"] = np.concatenate([[0], np.cumsum(cnt)]).astype(off.dtype)
+    for k in ("px", "py", "nx", "ny"):
+        d2[k] = np.asarray(d[k], np.float32)[keep].copy()
+    d2["px"][rng.integers(0, len(d2["px"]), 25)] = np.float32(np.nan)
+    assert cnt[10] == 0 and cnt[57] == 0 and cnt.min() == 0 and cnt.max() > 80
+    res, corr = [], None
+    for fused in (1, 0):
+        switches(pcg_fused=fused)
+        opt = H.default_options()
+        opt.timing_level = 2
+        g = _load(H.Solver(opt), d2, rows)
+        g.find_correspondences(d2["init"], 0)
+        corr = g.get_correspondences()
+        res.append(g.solve(abi.MODE_JOINT, d2["init"]))
+        g.close()
+    o = _load(O.OracleSolver(), d2, rows)
+    o.find_correspondences(d2["init"], 0, 1)
+    for a, b in zip(corr, o.get_correspondences()):
+        assert np.array_equal(a, b)
+    po, so = o.solve(abi.MODE_JOINT, d2["init"])
+    o.close()
+    (pf, sf), (pl, sl) = res
+    assert sf.num_offband_pairs > 0 and sf.pcg_timed_calls == sf.iterations and sl.pcg_timed_calls == 0
+    for sm, p in ((sf, pf), (sl, pl)):
+        assert (sm.termination, sm.iterations, sm.successful_steps) == (so.termination, so.iterations, so.successful_steps)
+        assert abs(sm.final_cost - so.final_cost) <= 1e-8 * so.final_cost
+        dxy, dth = _pdiff(p, po)
+        assert dxy <= 1e-4 and dth <= 1e-4, (dxy, dth)
