@@ -434,7 +434,11 @@ static int enqueue_linear_solve_pcg(hitl_solver* s, const FactorView& fv, int bu
     s->pcg_probe.release();
   }
   if (timed) HIP_TRY(hipEventRecord(s->ev5, st));
-  launch_spmv_step(st, s->n, npad, fv, lv, s->scale.p, s->dt.p, s->rhs.p, xcur, s->qv.p, xcand, s->h_partials, fv.with_stf ? s->pose_cs.p : nullptr);
+  // the step's bookkeeping AND the true residual b - A dt of what the launch returned (one pass over the matrix: the banded flow's
+  // kernel; dt is exactly 0 on constant poses): the recurrence the launch iterates on (r -= alpha s, s = w + beta s) drifts away from
+  // it on ill-conditioned systems, and the host holds the solve to the TRUE residual
+  launch_spmv_residual_step(st, s->n, npad, fv, lv, s->scale.p, mu, mind, maxd, s->dt.p, s->rhs.p, xcur, s->qv.p, xcand, s->h_partials,
+                            fv.with_stf ? s->pose_cs.p : nullptr);
   HIP_TRY(hipGetLastError());
   return HITL_OK;
 }
@@ -1042,7 +1046,15 @@ int lm_solve(hitl_solver* s, int mode, const float* poses_in, const float* poses
         HIP_TRY(hipEventElapsedTime(&ms, s->ev4, s->ev5));
         S.pcg_ms += ms; S.pcg_timed_calls += 1.0; S.pcg_timed_iterations += rec[0];
       }
-      TRY(finish_step_partials(s, nullptr, nullptr, &ss));
+      double rr_true = 0.0, bb_true = 0.0;
+      TRY(finish_step_partials(s, &rr_true, &bb_true, &ss));
+      if (dev_switches().timing)
+        std::fprintf(stderr, "k_pcg_fused: LM iteration %d: %d CG iterations, recurrence |r| / |b| %.3e, true |b - A x| / |b| %.3e (tolerance %.1e)\n", iter, (int)rec[0],
+                     std::sqrt(rec[1] / std::max(rec[3], 1e-300)), std::sqrt(rr_true / std::max(bb_true, 1e-300)), std::max(o.linear_solver_tolerance, 1e-15));
+      {                                                           // the banded flow's guard, on the true residual: a solve that is nowhere near its system is an invalid step, not a step
+        const double guard = std::max(std::max(o.linear_solver_tolerance, 1e-15), 1e-9);
+        if (st_pcg == 0.0 && (!(rr_true == rr_true) || rr_true > guard * guard * bb_true)) ok = false;
+      }
       fused = true;                                               // from here on: the banded flow (the candidate's linearisation is in pinned memory)
     } else if (fused) {
       { RoctxRange r("hitl:queue linear solve + step"); TRY(enqueue_linear_solve_banded(s, fv, cur, radius, xcur, xcand)); }
