@@ -336,6 +336,11 @@ size_t match_kd_lds_bytes(int max_scan);
 size_t match_kd_tgt_lds_bytes(int max_scan, int block, bool full_depth);
 void launch_kd_build(hipStream_t st, const MapView& map, int max_scan, float4* kd_pts, uint32_t* kd_meta);
 // occupancy grid per scan (kd_grid_words() words each): lets the source-major search skip the walks that cannot find anything (exactly: hitl_match.hip)
+// dense form of S J^T J S (3 n x 3 n, column-major, symmetric, A zeroed by the caller) and the extraction of the pose blocks of its inverse's
+// lower triangle: pose covariances of maps with pose pairs outside the band (hitl_vec.hip)
+void launch_dense_fill(hipStream_t st, int n, int Wb, const double* Hband, int n_offband, const int* ob_lo, const int* ob_hi, const double* obblk,
+                       const double* scale, const unsigned char* fixed, double* A);
+void launch_dense_cov_extract(hipStream_t st, int n, const double* Ainv, const double* scale, const unsigned char* fixed, const float2* rot, double* out);
 size_t kd_grid_words();
 void launch_kd_grid(hipStream_t st, const MapView& map, float thr, const float4* kd_pts, uint32_t* grid);
 void launch_match_kd(hipStream_t st, const MapView& map, int max_scan, int slots, const int* cand_tgt, const float* cand_tf, MatchParams mp,

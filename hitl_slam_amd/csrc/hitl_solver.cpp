@@ -634,6 +634,76 @@ void roctx_resolve(bool enable) {
 // =========================================================================================
 // C ABI
 // =========================================================================================
+// ---- pose covariances of a map with pose pairs outside the band: the dense inverse (hitl_vec.hip: k_dense_*) -----------------------
+// rocSOLVER's dense Cholesky (dpotrf + dpotri) is bound at run time: the library carries no link-time dependency on it, and a box
+// without it gets HITL_ERR_UNSUPPORTED for exactly this call, as before round 6.
+namespace {
+struct DenseSolverLib {
+  void* handle = nullptr;            // rocblas_handle
+  int (*create)(void**) = nullptr;
+  int (*set_stream)(void*, hipStream_t) = nullptr;
+  int (*potrf)(void*, int, int, double*, int, int*) = nullptr;
+  int (*potri)(void*, int, int, double*, int, int*) = nullptr;
+  bool ok = false;
+};
+DenseSolverLib& dense_solver_lib() {
+  static DenseSolverLib L = [] {
+    DenseSolverLib l;
+    void* so = nullptr;
+    for (const char* name : {"librocsolver.so", "librocsolver.so.0", "/opt/rocm/lib/librocsolver.so"})
+      if ((so = dlopen(name, RTLD_NOW | RTLD_LOCAL)) != nullptr) break;
+    if (so == nullptr) return l;
+    l.create = reinterpret_cast<int (*)(void**)>(dlsym(so, "rocblas_create_handle"));
+    l.set_stream = reinterpret_cast<int (*)(void*, hipStream_t)>(dlsym(so, "rocblas_set_stream"));
+    l.potrf = reinterpret_cast<int (*)(void*, int, int, double*, int, int*)>(dlsym(so, "rocsolver_dpotrf"));
+    l.potri = reinterpret_cast<int (*)(void*, int, int, double*, int, int*)>(dlsym(so, "rocsolver_dpotri"));
+    if (l.create && l.set_stream && l.potrf && l.potri && l.create(&l.handle) == 0 && l.handle != nullptr) l.ok = true;
+    return l;
+  }();
+  return L;
+}
+}  // namespace
+
+static int pose_covariances_dense(hitl_solver* s, const FactorView& fv, const float* poses_xyt, double* cov9) {
+  if (s->dist_mode()) return fail(HITL_ERR_UNSUPPORTED, "pose_covariances: pose pairs outside the band on a submap rank");
+  const int n = s->n;
+  const int64_t d = 3 * (int64_t)n;
+  if (d > 32768) return fail(HITL_ERR_UNSUPPORTED, "pose_covariances: pose pairs outside the band on a map of more than 10 922 poses (the dense inverse would take " +
+                                                   std::to_string((d * d * 8) >> 30) + " GB)");
+  DenseSolverLib& L = dense_solver_lib();
+  if (!L.ok) return fail(HITL_ERR_UNSUPPORTED, "pose_covariances: pose pairs outside the band need rocSOLVER's dense Cholesky (librocsolver.so could not be bound)");
+  hipStream_t st = s->stream;
+  std::vector<double> hx((size_t)s->npad, 0.0);
+  for (int64_t t = 0; t < d; ++t) hx[(size_t)t] = (double)poses_xyt[t];
+  HIP_TRY(hipMemcpyAsync(s->x.p, hx.data(), sizeof(double) * s->npad, hipMemcpyHostToDevice, st));
+  LinResult lr;
+  TRY(run_linearize(s, fv, s->x.p, 0, &lr));            // J^T J at these poses: band blocks + off-band blocks (no trust-region diagonal)
+  launch_jacobi_scale(st, n, s->npad, fv.band_poses, s->Hband[0].p, s->opt.jacobi_scaling, s->fixed.p, s->scale.p);
+  DevArray<double> A, d_out;
+  DevArray<float2> d_rot;
+  DevArray<int> d_info;
+  std::vector<float2> rot((size_t)n);
+  for (int i = 0; i < n; ++i) { const float a = -poses_xyt[3 * i + 2]; rot[(size_t)i] = make_float2(cosf(a), sinf(a)); }   // Rotation2Df(-angle)
+  TRY(A.resize((size_t)d * (size_t)d)); TRY(d_out.resize((size_t)9 * n)); TRY(d_info.resize(2)); TRY(d_rot.upload(rot, st));
+  TRY(A.zero(st)); TRY(d_info.zero(st));
+  launch_dense_fill(st, n, fv.band_poses, s->Hband[0].p, fv.n_offband, s->ob_lo.p, s->ob_hi.p, s->obblk[0].p, s->scale.p, s->fixed.p, A.p);
+  HIP_TRY(hipGetLastError());
+  constexpr int kFillLower = 122;                        // rocblas_fill_lower
+  if (L.set_stream(L.handle, st) != 0 || L.potrf(L.handle, kFillLower, (int)d, A.p, (int)d, d_info.p) != 0 ||
+      L.potri(L.handle, kFillLower, (int)d, A.p, (int)d, d_info.p + 1) != 0)
+    return fail(HITL_ERR_HIP, "pose_covariances: the dense Cholesky could not be run");
+  launch_dense_cov_extract(st, n, A.p, s->scale.p, s->fixed.p, d_rot.p, d_out.p);
+  int info[2] = {0, 0};
+  if (hipMemcpyAsync(cov9, d_out.p, sizeof(double) * 9 * (size_t)n, hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipMemcpyAsync(info, d_info.p, sizeof(info), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+    return fail(HITL_ERR_HIP, "pose_covariances: kernels failed");
+  if (info[0] != 0 || info[1] != 0) return fail(HITL_ERR_SOLVER_FAILURE, "pose_covariances: J^T J is singular at these poses");
+  for (size_t t = 0; t < (size_t)9 * n; ++t)
+    if (!(cov9[t] == cov9[t])) return fail(HITL_ERR_SOLVER_FAILURE, "pose_covariances: J^T J is singular at these poses");
+  return HITL_OK;
+}
+
+
 extern "C" {
 
 void hitl_options_default(hitl_options* o) {
@@ -1234,6 +1304,7 @@ int hitl_solver_evaluate_jacobian(hitl_solver* s, const float* poses_xyt, double
 
 // ---- pose covariances: what ceres::Covariance + the robot-frame rotation produce at
 // episodic_non_markov_localization/vector_mapping.cpp:2772-2812, from the cyclic-reduction factors ----
+
 int hitl_solver_pose_covariances(hitl_solver* s, int32_t mode, const float* poses_xyt, double* cov9) {
   TRY(check_ready(s, mode));
   if (!poses_xyt || !cov9) return fail(HITL_ERR_INVALID_ARGUMENT, "pose_covariances: null argument");
@@ -1280,7 +1351,7 @@ int hitl_solver_pose_covariances(hitl_solver* s, int32_t mode, const float* pose
   }
   FactorView fv;
   TRY(prepare(s, mode, poses_xyt, poses_xyt, &fv));
-  if (fv.n_offband > 0) return fail(HITL_ERR_UNSUPPORTED, "pose_covariances: pose pairs outside the band (raise max_band_poses)");
+  if (fv.n_offband > 0) return pose_covariances_dense(s, fv, poses_xyt, cov9);
   hipStream_t st = s->stream;
   const int n = s->n, n3 = 3 * n;
   std::vector<double> hx((size_t)s->npad, 0.0);

@@ -295,6 +295,73 @@ void launch_spmv_step(hipStream_t st, int n_poses, int npad, const FactorView& f
 }
 
 // ===========================================================================================
+// Pose covariances of a map with pose pairs OUTSIDE the band (round 6; SURVEY.md 8(f) row 4 on the maps the reference's all-pairs
+// search produces): the marginal 3 x 3 blocks of (J^T J)^-1 do not fall out of the band's cyclic reduction there.  The scaled
+// matrix S J^T J S is written out densely (3 N x 3 N doubles: 72 MB for 1 000 poses), factorised and inverted by the dense Cholesky
+// of rocSOLVER (a plain library operation, bound at run time: hitl_solver.cpp), and the diagonal blocks are unscaled and rotated
+// like the banded path's (k_cov_extract).  Constant poses: identity rows and columns, zero covariance.
+// ===========================================================================================
+__global__ void k_dense_fill_band(int n, int Wb, int64_t d, const double* __restrict__ Hband, const double* __restrict__ scale,
+                                  const unsigned char* __restrict__ fixed, double* __restrict__ A) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // (pose i, offset dd, entry q)
+  if (t >= (int64_t)n * (Wb + 1) * 9) return;
+  const int q = (int)(t % 9), dd = (int)((t / 9) % (Wb + 1)), i = (int)(t / (9 * (Wb + 1)));
+  const int j = i + dd;
+  if (j >= n) return;
+  const int a = q / 3, c = q % 3;
+  const int64_t r = 3 * (int64_t)i + a, col = 3 * (int64_t)j + c;
+  double v = Hband[((size_t)i * (Wb + 1) + dd) * 9 + q] * scale[r] * scale[col];
+  if (fixed[i] || fixed[j]) v = (dd == 0 && a == c) ? 1.0 : 0.0;
+  A[r + col * d] = v;
+  if (dd > 0) A[col + r * d] = v;                                          // the mirrored block (dd == 0: the diagonal block is stored whole)
+}
+__global__ void k_dense_fill_offband(int E, int64_t d, const int* __restrict__ ob_lo, const int* __restrict__ ob_hi, const double* __restrict__ obblk,
+                                     const double* __restrict__ scale, const unsigned char* __restrict__ fixed, double* __restrict__ A) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)E * 9) return;
+  const int q = (int)(t % 9), e = (int)(t / 9);
+  const int i = ob_lo[e], j = ob_hi[e];
+  if (fixed[i] || fixed[j]) return;                                        // (already zero)
+  const int a = q / 3, c = q % 3;
+  const int64_t r = 3 * (int64_t)i + a, col = 3 * (int64_t)j + c;
+  const double v = obblk[(size_t)e * 9 + q] * scale[r] * scale[col];
+  A[r + col * d] = v;
+  A[col + r * d] = v;
+}
+// the inverse's lower triangle (column-major, what potri leaves) -> one rotated 3 x 3 block per pose
+__global__ void k_dense_cov_extract(int n, int64_t d, const double* __restrict__ Ainv, const double* __restrict__ scale,
+                                    const unsigned char* __restrict__ fixed, const float2* __restrict__ rot, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double* o = out + 9 * (size_t)i;
+  if (fixed[i]) { for (int e = 0; e < 9; ++e) o[e] = 0.0; return; }
+  double S[3][3];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) {
+      const int64_t rr = 3 * (int64_t)i + (r >= c ? r : c), cc = 3 * (int64_t)i + (r >= c ? c : r);      // lower triangle: row >= column
+      S[r][c] = Ainv[rr + cc * d] * scale[3 * i + r] * scale[3 * i + c];
+    }
+  const double c = (double)rot[i].x, sn = (double)rot[i].y;     // cos, sin of -angle (fp32 values)
+  const double T[3][3] = {{c, -sn, 0.0}, {sn, c, 0.0}, {0.0, 0.0, 1.0}};
+  double M[3][3];
+  for (int r = 0; r < 3; ++r)
+    for (int q = 0; q < 3; ++q) M[r][q] = T[r][0] * S[0][q] + T[r][1] * S[1][q] + T[r][2] * S[2][q];
+  for (int r = 0; r < 3; ++r)
+    for (int q = 0; q < 3; ++q) o[3 * r + q] = M[r][0] * T[q][0] + M[r][1] * T[q][1] + M[r][2] * T[q][2];
+}
+void launch_dense_fill(hipStream_t st, int n, int Wb, const double* Hband, int n_offband, const int* ob_lo, const int* ob_hi, const double* obblk,
+                       const double* scale, const unsigned char* fixed, double* A) {
+  const int64_t d = 3 * (int64_t)n;
+  const int64_t tb = (int64_t)n * (Wb + 1) * 9;
+  hipLaunchKernelGGL(k_dense_fill_band, dim3((unsigned)((tb + 255) / 256)), dim3(256), 0, st, n, Wb, d, Hband, scale, fixed, A);
+  if (n_offband > 0)
+    hipLaunchKernelGGL(k_dense_fill_offband, dim3((unsigned)(((int64_t)n_offband * 9 + 255) / 256)), dim3(256), 0, st, n_offband, d, ob_lo, ob_hi, obblk, scale, fixed, A);
+}
+void launch_dense_cov_extract(hipStream_t st, int n, const double* Ainv, const double* scale, const unsigned char* fixed, const float2* rot, double* out) {
+  hipLaunchKernelGGL(k_dense_cov_extract, dim3((n + 127) / 128), dim3(128), 0, st, n, 3 * (int64_t)n, Ainv, scale, fixed, rot, out);
+}
+
+// ===========================================================================================
 // small vector kernels
 // ===========================================================================================
 // submap exchange helpers --------------------------------------------------------------------

@@ -334,8 +334,10 @@ int hitl_normalize_angles(int64_t n_poses, float* poses_xyt);
  * episodic_non_markov_localization/vector_mapping.cpp:2772-2812: for every pose the 3x3 diagonal block of (J^T J)^-1 at
  * poses_xyt (constant poses removed, no trust-region diagonal), rotated into the robot frame with
  * transform = blockdiag(Rotation2Df(-angle), 1).  cov9 = n_poses*9 doubles, row-major; zeros for constant poses
- * (the reference never writes pose min_poses).  Computed from the cyclic-reduction factors by selected inversion --
- * no dense inverse, no SVD.  Needs every pose pair inside the band.
+ * (the reference never writes pose min_poses).  Every pose pair inside the band: from the cyclic-reduction factors by selected
+ * inversion -- no dense inverse, no SVD.  Pose pairs outside the band (the all-pairs search on a map that revisits places; one GPU,
+ * at most 10 922 poses): the dense form of the scaled J^T J, inverted by rocSOLVER's Cholesky (bound at run time with dlopen: no
+ * link-time dependency; the first such call loads it, ~0.9 s; HITL_ERR_UNSUPPORTED where librocsolver.so is not to be found).
  * Submap ranks (collective; mode A or C): poses_xyt is the GLOBAL array, cov9 (9 * n_global) receives the blocks of the rank's
  * OWNED poses (zeros elsewhere) -- blocks of the GLOBAL inverse: the rank's own selected inversion minus a low-rank correction
  * through its interface columns, with one all-gather of the interface record. */
