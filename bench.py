@@ -197,6 +197,13 @@ def run_c3(args):
     except (OSError, ValueError, KeyError):
         pass
     d_gt = out.astype(np.float64) - d["gt"]
+    # pose covariances at the solved poses (pose pairs outside the band: the dense inverse through rocSOLVER, bound at first use)
+    t0 = time.time()
+    solver.pose_covariances(H.MODE_JOINT, out)
+    cov_first_ms = (time.time() - t0) * 1e3
+    t0 = time.time()
+    cov = solver.pose_covariances(H.MODE_JOINT, out)
+    cov_ms = (time.time() - t0) * 1e3
     result = {
         "metric": "full batch re-solve throughput (observation rows x Gauss-Newton/LM iterations per second); "
                   "resolve_ms = full batch re-solve wall-clock, gn_iters_per_sec alongside",
@@ -211,6 +218,9 @@ def run_c3(args):
         "termination": int(summ.termination), "initial_cost": summ.initial_cost, "final_cost": summ.final_cost,
         "correspondence_search_ms": match_ms, "correspondence_search_first_call_ms": match_first_ms,
         "max_abs_xy_vs_ground_truth_m": float(np.abs(d_gt[:, :2]).max()),
+        "pose_covariances_ms": cov_ms, "pose_covariances_first_call_ms": cov_first_ms,
+        "pose_covariances_note": "3x3 blocks of (J^T J)^-1 at the solved poses: dense %d x %d inverse (rocSOLVER dpotrf + dpotri, loaded by the first call); "
+                                 "largest positional standard deviation %.4f m" % (3 * n_poses, 3 * n_poses, float(np.sqrt(max(cov[:, 0, 0].max(), cov[:, 1, 1].max())))),
         "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_source, "traffic_stale": traffic_stale,
                      "algorithmic_bytes_per_cg_iteration": alg, "us_per_cg_iteration": us_per_cg, "cg_iterations_per_launch": units,
