@@ -200,7 +200,10 @@ def test_pcg_runs_to_tolerance_behind_a_weak_preconditioner():
     iteration cap (max_linear_solver_iterations = 500, the default here too) the steps are solved to the 1e-12 residual
     tolerance and the LM walks the oracle's exact-Cholesky path: same iterations, same cost.  (A cap of 50 -- the default
     until round 2 -- left the steps inexact: 34 instead of 17 LM iterations on a 10 900-pose map and poses 9 cm away along the
-    weakly observed corridor direction.)  Poses: the cost is flat along that direction, so the bar here is 2e-3 m."""
+    weakly observed corridor direction.)  Poses: the cost is flat along that direction; through round 5 the bar here was 2e-3 m.
+    Round 6: the linear solves run as the persistent launch, whose single-reduction recurrence drifts behind so weak a preconditioner
+    (true residual 5e-11 of |b| where the recurrence says 6e-13); the host holds each solve to its TRUE residual and continues it
+    once -- the poses now land within 1e-6 m (measured: 2e-10) of the oracle's."""
     import hitl_slam_amd as H
     from oracle import hitl_oracle as O
     prob = Problem(6000, 48, ppf=200, groups=6, kind=0)
@@ -216,7 +219,7 @@ def test_pcg_runs_to_tolerance_behind_a_weak_preconditioner():
     assert sg.num_offband_pairs > 10000 and sg.linear_iterations > 60 * sg.iterations
     assert sg.termination == so.termination and sg.iterations == so.iterations
     assert abs(sg.final_cost - so.final_cost) <= 1e-8 * so.final_cost
-    assert np.abs(pg[:, :2] - po[:, :2]).max() <= 2e-3 and np.abs(pg[:, 2] - po[:, 2]).max() <= 1e-4
+    assert np.abs(pg[:, :2] - po[:, :2]).max() <= 1e-6 and np.abs(pg[:, 2] - po[:, 2]).max() <= 1e-6
     g.close(); o.close()
 
 
