@@ -73,9 +73,10 @@ class JointOptGpuT {
   // mode: HITL_MODE_ODOM_HC is what the shipped binary runs (SolveHumanConstraints, :1335);
   // HITL_MODE_JOINT adds the scan-to-scan factors of the commented-out PostHumanOptimization
   // (:1353-1373), matched within +-stf_window poses.  Default 3: within hitl_options.max_band_poses (4) every pair stays
-  // in the block band, the linear solve is the exact cyclic reduction and pose_covariances works.  A wider window (the
-  // legacy kMaxHistory = 80, or 0 = all pairs like FindSTFCorrespondences) is allowed but takes the off-band PCG path
-  // (3 host synchronisations per CG iteration) and a candidate table of n * 2*window * max_scan * 2 bytes.
+  // in the block band and the linear solve is the exact cyclic reduction.  A wider window (the legacy kMaxHistory = 80, or
+  // 0 = all pairs like FindSTFCorrespondences) takes the off-band PCG path (since round 6 one persistent launch per linear
+  // solve and one host wait per LM iteration; pose_covariances through a dense inverse, up to 10 922 poses) and a candidate
+  // table of n * 2*window * max_scan * 2 bytes.
   void SetMode(int mode, int64_t stf_window = 3) { mode_ = mode; stf_window_ = stf_window; }
   // The correspondence search is the reference's own (per-scan KD-trees + pruned FindNearestPointNormal walk) unless this is
   // called with true before the first Run(): then the brute-force definition of the same query (hitl_options.kd_tree_search = 0)
