@@ -16,7 +16,8 @@ struct HC { unsigned type; int constrained_pose_id, anchor_pose_id; float delta_
 typedef hitl::JointOptGpuT<P2, V2, M3, HC> JointOpt;
 
 int main(int argc, char** argv) {
-  if (argc < 5) { std::fprintf(stderr, "usage: shim_driver map.stfs.covars constraints.txt mode out.txt\n"); return 64; }
+  if (argc < 5) { std::fprintf(stderr, "usage: shim_driver map.stfs.covars constraints.txt mode out.txt [stf_window: 3; 0 = all pairs like FindSTFCorrespondences]\n"); return 64; }
+  const long long stf_window = argc > 5 ? std::atoll(argv[5]) : 3;
   hitl_posegraph* g = NULL;
   if (hitl_io_load_stfs_covars(argv[1], 1, &g) != HITL_OK) return 65;
   JointOpt jo;
@@ -40,7 +41,7 @@ int main(int argc, char** argv) {
                      &h.delta_perpendicular, &h.delta_angle, &h.relative_penalty_dir) == 7) group.push_back(h);
   std::fclose(f);
   if (!group.empty()) jo.human_constraints_.push_back(group);
-  jo.SetMode(std::atoi(argv[3]), 3);
+  jo.SetMode(std::atoi(argv[3]), stf_window);
   jo.want_gradients = true;
   jo.want_info_mat = true;
   const int st = jo.RunStatus();

@@ -87,6 +87,36 @@ def test_shim_reproduces_the_oracle(driver, case, mode):
     assert int(fields[19]) == 1                       # an edited scan point (same sizes) was noticed: the map went up again
 
 
+@pytest.mark.gpu
+def test_shim_all_pairs_like_the_reference(driver, tmp_path):
+    """JointOpt with the reference's own matching range -- FindSTFCorrespondences visits every pose pair (JointOptimization.cpp:
+    561-642) -- on a map that revisits places: SetMode(HITL_MODE_JOINT, 0).  The pose pairs leave the band, the linear solves run as
+    the persistent PCG launch behind the shim; poses against the oracle's exact solve."""
+    from hitl_slam_amd.api import hc_rows
+    from oracle import hitl_oracle as O
+    d = figure8.make(240, 90, seed=5, laps=2)
+    path, cpath, out = str(tmp_path / "fig8.stfs.covars"), str(tmp_path / "constraints.txt"), str(tmp_path / "out.txt")
+    hio.save_stfs_covars(path, "AMRL", 1.0, d["init"], d["off"], d["px"], d["py"], d["nx"], d["ny"], d["cov"])
+    rows = figure8.constraints(d["gt"], 3, 2)
+    with open(cpath, "w") as f:
+        for r in rows:
+            f.write("%d %d %d %.9g %.9g %.9g %.9g\n" % r)
+    r = subprocess.run([driver, path, cpath, "2", out, "0"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = np.loadtxt(out, dtype=np.float32).reshape(-1, 3)
+    g = hio.load_stfs_covars(path, fix_normals=True)
+    o = O.OracleSolver()
+    o.set_map(g["obs_offset"], g["px"], g["py"], g["nx"], g["ny"], g["cov9"])
+    o.set_human_constraints(hc_rows(rows))
+    o.find_correspondences(g["poses"], 0, 1)
+    kept = o.get_correspondences()
+    assert np.abs(kept[0] - kept[1]).max() > 50                    # lap-to-lap pairs
+    po, so = o.solve(2, g["poses"])
+    fields = r.stdout.split()
+    assert int(fields[1]) == so.iterations and int(fields[9]) == 2 * so.num_pairs
+    assert np.abs(got - po).max() <= 1e-4 + 1e-6      # results file prints "%f"
+
+
 def test_shim_map_fingerprint_sees_every_bit_and_stays_off_the_critical_path(tmp_path):
     """ADVICE r3: the content fingerprint of JointOptGpu.h runs on EVERY Run() (HitLSLAM::Run re-copies the clouds each time,
     so only the content can say "same map").  It must notice a one-bit edit and a point moved between scans, give the same
